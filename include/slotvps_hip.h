@@ -1,0 +1,129 @@
+/*
+ * slotvps_hip.h - C ABI of the MI355X (gfx950) slot-retriever decode path.
+ *
+ * The reference (SAITPublic/SlotVPS) implements this path in pure PyTorch; it has no FFI of its
+ * own. Every entry point below therefore names the reference *Python* function whose body it
+ * replaces (file:line relative to the reference tree). The host-side mirror of the reference's
+ * module interface lives in slotvps_amd/ and reaches these symbols through ctypes
+ * (slotvps_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Rules common to all entry points
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise
+ *   - the caller owns all buffers, including the workspace; nothing is allocated or freed here
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work,
+ *     they never synchronise (safe under hipGraph capture)
+ *   - return 0 on success, a positive hipError_t value if the runtime refused a launch, or one of
+ *     the negative SVPS_ERR_* codes for argument errors (nothing is enqueued in that case)
+ *   - thread-safe for distinct workspaces / output buffers
+ */
+#ifndef SLOTVPS_HIP_H_
+#define SLOTVPS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVPS_ABI_VERSION 1
+
+#define SVPS_ERR_BAD_ARG (-1)   /* null pointer / inconsistent argument */
+#define SVPS_ERR_BAD_SHAPE (-2) /* shape outside what the kernels are built for */
+#define SVPS_ERR_WORKSPACE (-3) /* workspace smaller than svps_*_workspace_bytes() */
+
+/* flags of svps_slot_attn_fwd */
+#define SVPS_FLAG_SPLIT_P 1 /* carry softmax probabilities as bf16 hi+lo (16-bit mantissa) */
+
+/* flags of svps_mask_decode_fwd */
+#define SVPS_FLAG_OUT_BF16 1 /* write mask logits as bf16 instead of fp32 */
+
+/* kernel ids for the profiling hooks */
+#define SVPS_KERNEL_SLOT_ATTN 0
+#define SVPS_KERNEL_SLOT_ATTN_FINISH 1
+#define SVPS_KERNEL_MASK_DECODE 2
+#define SVPS_KERNEL_POS_EMBED 3
+#define SVPS_KERNEL_KV_PROJECT 4
+#define SVPS_KERNEL_COUNT 8
+
+int svps_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1 slot <-> pixel retriever.
+ * Replaces the tensor program of MaskDynamicConv.forward after the three projections
+ * (mmdet/models/detectors/dynamic_mask_head.py:435-459):
+ *     attn = einsum("b l c, b h w c -> b l h w", q, k)      :435   (unscaled)
+ *     attn = softmax(attn, dim=1)                            :446   (over the L slots)
+ *     out  = einsum("b l h w, b h w c -> b l c", attn, v)    :456   (sum over all pixels)
+ *     out  = ReLU(LayerNorm(out))                            :458-459
+ * for T frames in one launch (the reference loops over frames, dynamic_mask_head.py:302).
+ *
+ *   q    [T, L, D]   bf16, already = norm_q(to_q(slots))               (:431)
+ *   k    [T, HW, D]  bf16, already = norm_k(to_k(feat + pos)), row = pixel h*W + w   (:432)
+ *   v    [T, HW, D]  bf16, already = norm_v(to_v(feat))                 (:433)
+ *   ln_w, ln_b [D]   fp32, inst_interact.norm1 affine, ln_eps its epsilon (1e-5)
+ *   out  [T, L, D]   fp32
+ *   out_pre_ln       optional [T, L, D] fp32: the pixel sum before LayerNorm (NULL to skip)
+ *   D must be 256; 1 <= L <= 256; HW >= 1 (any value, tiles are masked)
+ *   chunks: workgroups per frame, 0 = choose (one resident workgroup per CU)
+ * ------------------------------------------------------------------------------------------- */
+size_t svps_slot_attn_workspace_bytes(int T, int L, int HW, int chunks);
+int svps_slot_attn_plan(int T, int HW, int chunks, int* out_chunks, int* out_tiles_per_chunk);
+int svps_slot_attn_fwd(const void* q, const void* k, const void* v, const float* ln_w,
+                       const float* ln_b, float ln_eps, void* workspace, size_t workspace_bytes,
+                       float* out, float* out_pre_ln, int T, int L, int HW, int D, int flags,
+                       int chunks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2 slot -> mask dot-product decode.
+ * Replaces VPS_Temporal_Slots.generate_final_outputs, main branch
+ * (mmdet/models/detectors/vps_temporal_slots.py:144-160):
+ *     f = feat_bn(f)  (eval BatchNorm2d: per-channel affine)           :146
+ *     f = F.normalize(f, p=2, dim=1)  (eps 1e-12)                       :147
+ *     m = einsum("n c h w, n l c -> n l h w", f, slot_embed)            :149
+ *     m = fg_bn(m)    (eval BatchNorm2d(1) with slots as batch: one scalar affine)  :153
+ *
+ *   feat     [T, HW, D] bf16 finest-level fused feature map, row = pixel
+ *   embed    [T, L, D]  fp32 last-stage slot embeddings
+ *   bn_scale, bn_shift [D] fp32: gamma/sqrt(var+eps), beta - mean*gamma/sqrt(var+eps)
+ *   fg_scale, fg_shift: the scalar affine of fg_bn folded the same way
+ *   out      [T, L, HW] fp32 (or bf16 with SVPS_FLAG_OUT_BF16)
+ *   slot_argmax optional [T, HW] uint8: argmax over slots of the logits (first max wins), NULL to skip
+ * ------------------------------------------------------------------------------------------- */
+int svps_mask_decode_fwd(const void* feat, const float* embed, const float* bn_scale,
+                         const float* bn_shift, float fg_scale, float fg_shift, void* out,
+                         uint8_t* slot_argmax, int T, int L, int HW, int D, int flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sine position embedding, PositionEmbeddingSine.forward with normalize=True, scale 2*pi,
+ * temperature 1e4, all-False mask (mmdet/models/detectors/position_encoding.py:236-256).
+ *   out [H*W, D] fp32, pixel-major (the NHWC view the retriever consumes, dynamic_mask_head.py:430);
+ *   channels [0, D/2) encode y, [D/2, D) encode x, sin on even / cos on odd channels.
+ * ------------------------------------------------------------------------------------------- */
+int svps_pos_embed_sine(float* out, int H, int W, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Profiling hooks: when enabled every kernel launch of this library is bracketed by HIP events on
+ * the launch stream. svps_prof_collect synchronises those events (host-blocking) and returns the
+ * summed device time of one kernel id. Used by bench.py for the roofline line.
+ * ------------------------------------------------------------------------------------------- */
+void svps_prof_enable(int on);
+void svps_prof_reset(void);
+void svps_prof_mark(int kernel_id, int is_end, void* stream);
+int svps_prof_collect(int kernel_id, double* total_ms, int* launches);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hardware-semantics probes (diagnostics, used by tests/test_probes_gpu.py): they pin the
+ * instruction behaviour the kernels rely on - MFMA 32x32x16 bf16 operand/result lane maps, the
+ * ds_read_b64_tr_b16 transposed read, and the swizzled LDS-DMA tile image.
+ *   probe_mfma: a [32,16] bf16, b [16,32] bf16 (row-major) -> c [32,32] fp32 = a @ b
+ *   probe_tile: x [32, 256] bf16 -> rows [32,256] (through read_row_frag) and
+ *               cols [32,256] (through read_col_frag), both must reproduce x
+ * ------------------------------------------------------------------------------------------- */
+int svps_probe_mfma(const void* a, const void* b, float* c, void* stream);
+int svps_probe_tile(const void* x, void* rows, void* cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLOTVPS_HIP_H_ */

@@ -1,0 +1,81 @@
+"""ctypes binding of libslotvps_hip.so (C ABI declared in include/slotvps_hip.h).
+
+The library is the product: there is no Python/NumPy/torch fallback for any entry point. If the
+shared object is missing or a symbol cannot be resolved the import of the calling op raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslotvps_hip.so")
+
+ERR_NAMES = {-1: "SVPS_ERR_BAD_ARG", -2: "SVPS_ERR_BAD_SHAPE", -3: "SVPS_ERR_WORKSPACE"}
+
+FLAG_SPLIT_P = 1
+FLAG_OUT_BF16 = 1
+
+KERNEL_SLOT_ATTN = 0
+KERNEL_SLOT_ATTN_FINISH = 1
+KERNEL_MASK_DECODE = 2
+KERNEL_POS_EMBED = 3
+KERNEL_KV_PROJECT = 4
+
+_c = ctypes
+_vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/slotvps_hip.h
+SIGNATURES = {
+    "svps_abi_version": (_i, []),
+    "svps_slot_attn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "svps_slot_attn_plan": (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i)]),
+    "svps_slot_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "svps_mask_decode_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "svps_pos_embed_sine": (_i, [_vp, _i, _i, _i, _vp]),
+    "svps_prof_enable": (None, [_i]),
+    "svps_prof_reset": (None, []),
+    "svps_prof_mark": (None, [_i, _i, _vp]),
+    "svps_prof_collect": (_i, [_i, _c.POINTER(_c.c_double), _c.POINTER(_i)]),
+    "svps_probe_mfma": (_i, [_vp, _vp, _vp, _vp]),
+    "svps_probe_tile": (_i, [_vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class SlotVPSLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library once and attach prototypes. Raises SlotVPSLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlotVPSLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C slotvps_amd/csrc` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise SlotVPSLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SlotVPSLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.svps_abi_version()
+    if ver != 1:
+        raise SlotVPSLibraryError(f"ABI version {ver} != 1")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code == 0:
+        return
+    if code < 0:
+        raise ValueError(f"{what}: {ERR_NAMES.get(code, code)}")
+    raise RuntimeError(f"{what}: hipError_t {code}")

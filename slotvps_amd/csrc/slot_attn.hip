@@ -1,0 +1,341 @@
+// K1 - slot <-> pixel retriever ("Panoptic Retriever" cross-attention) for gfx950.
+//
+// Replaces the body of MaskDynamicConv.forward in the reference
+// (mmdet/models/detectors/dynamic_mask_head.py:435-459) after the q/k/v projections + LayerNorms:
+//
+//     A[l, p]   = sum_c q[l, c] * k[p, c]                  (unscaled logits,          :435)
+//     P[:, p]   = softmax over the SLOT axis l, per pixel  (F.softmax(dim=1),         :446)
+//     o[l, :]   = sum_p P[l, p] * v[p, :]                  (plain sum over pixels,    :456)
+//     out[l, :] = ReLU(LayerNorm(o[l, :]))                 (norm1 + activation,       :458-459)
+//
+// Because the softmax runs over slots, every pixel column is independent: no online-softmax
+// rescaling across pixel tiles is needed and the only cross-tile state is the [L, 256] fp32 sum.
+//
+// Mapping onto the CU
+//   * one workgroup = NW waves (4 for L <= 128, 8 for L <= 256); wave w owns slots [32w, 32w+32)
+//     for the whole kernel: its 32 x 256 query block lives in 64 VGPRs as MFMA A fragments and its
+//     32 x 256 fp32 output block in 128 accumulator registers.
+//   * the workgroup walks a contiguous range of 32-pixel tiles of ONE frame. k and v tiles
+//     (16 KiB each, bf16 [pixel][channel]) arrive by LDS-DMA into a ring of NST stages, issued
+//     NST-1 tiles ahead behind a counted vmcnt and a raw s_barrier (the DMA is never drained in
+//     the loop). Each HBM byte of k and v is read exactly once.
+//   * S = q k^T: 16 MFMA 32x32x16 per tile and wave, keys read from LDS as row fragments
+//     (ds_read_b128, XOR swizzle). Pixel = accumulator column = lane, so the softmax over this
+//     wave's 32 slots is an in-lane reduction + one lane^32 exchange; the 4 (8) waves then trade
+//     one (max, sum) pair per pixel through LDS: ONE barrier per tile for the softmax.
+//   * P is rounded to bf16 (optionally hi + lo for a 16-bit mantissa, flag SVPS_FLAG_SPLIT_P),
+//     transposed through a wave-private LDS image and multiplied with v fragments obtained with
+//     ds_read_b64_tr_b16 (hardware transpose, pixel-major v needs no transposed copy in HBM).
+//   * every workgroup stores its [L, 256] fp32 partial; `slot_attn_finish` sums the partials in a
+//     fixed order (bitwise reproducible, no float atomics), applies LayerNorm + ReLU.
+#include "common.h"
+
+namespace svps {
+
+constexpr int kPimgStride = 80;  // bytes per slot row of the P image: 32 px * 2 B + 16 B pad
+
+template <int NW, int NST>
+struct AttnLds {
+    static constexpr int ring = 0;                                   // NST * (k tile + v tile)
+    static constexpr int stats = NST * 2 * kTileBytes;               // NW * 32 * float2
+    static constexpr int pimg = stats + NW * kTilePx * 8;            // NW * 2 * 32 * 80 B
+    static constexpr int total = pimg + NW * 2 * 32 * kPimgStride;
+};
+
+template <int NW, int NST, bool SPLIT>
+__global__ __launch_bounds__(NW * 64) void slot_attn_partial(
+    const __bf16* __restrict__ q,   // [T, L, 256]
+    const __bf16* __restrict__ k,   // [T, HW, 256]
+    const __bf16* __restrict__ v,   // [T, HW, 256]
+    float* __restrict__ partial,    // [T, C, L, 256]
+    int L, int HW, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = AttnLds<NW, NST>;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x, C = gridDim.x;
+
+    const int px_begin = c * tiles_per_chunk * kTilePx;
+    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    px_end = px_end < HW ? px_end : HW;
+    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;  // >= 1 by construction
+
+    const char* kb = reinterpret_cast<const char*>(k) + (size_t)t * HW * kRowBytes;
+    const char* vb = reinterpret_cast<const char*>(v) + (size_t)t * HW * kRowBytes;
+
+    // ---- query block of this wave -> registers (A fragments), zero rows past L ------------
+    bf16x8 qf[16];
+    {
+        const int slot = 32 * w + r;
+        const __bf16* qrow = q + ((size_t)t * L + (slot < L ? slot : 0)) * kD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            u32x4 raw = *reinterpret_cast<const u32x4*>(qrow + 16 * ks);
+            if (slot >= L) raw = u32x4{0u, 0u, 0u, 0u};
+            qf[ks] = __builtin_bit_cast(bf16x8, raw);
+        }
+    }
+    // Make sure the query loads have landed before LDS-DMA starts, so that the compiler's wait for
+    // them does not sit behind (and drain) the DMA ring later on.
+    wait_vm<0>();
+
+    // ---- prologue: NST-1 tiles in flight ------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) {
+        if (s < nt) {
+            char* st = smem + Lds::ring + s * 2 * kTileBytes;
+            dma_tile<NW>(kb, px_begin + s * kTilePx, HW - 1, st, w, lane);
+            dma_tile<NW>(vb, px_begin + s * kTilePx, HW - 1, st + kTileBytes, w, lane);
+        }
+    }
+
+    f32x16 o[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+
+    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+    char* pimg_hi = smem + Lds::pimg + w * 2 * 32 * kPimgStride;
+    char* pimg_lo = pimg_hi + 32 * kPimgStride;
+    constexpr int PIECES = 2 * (kTilePx / 2 / NW);  // DMA pieces per wave and tile (k + v)
+
+    for (int it = 0; it < nt; ++it) {
+        // -- tile `it` has landed for this wave; the barrier extends that to every wave and also
+        //    says every wave is done reading tile it-1 (whose stage is refilled just below).
+        if constexpr (NST == 4) {
+            if (it + 2 < nt) wait_vm<2 * PIECES>();
+            else if (it + 1 < nt) wait_vm<PIECES>();
+            else wait_vm<0>();
+        } else if constexpr (NST == 3) {
+            if (it + 1 < nt) wait_vm<PIECES>();
+            else wait_vm<0>();
+        } else {
+            wait_vm<0>();
+        }
+        wg_barrier();
+        if (it + NST - 1 < nt) {
+            char* st = smem + Lds::ring + ((it + NST - 1) % NST) * 2 * kTileBytes;
+            const int px0 = px_begin + (it + NST - 1) * kTilePx;
+            dma_tile<NW>(kb, px0, HW - 1, st, w, lane);
+            dma_tile<NW>(vb, px0, HW - 1, st + kTileBytes, w, lane);
+        }
+        const char* kt = smem + Lds::ring + (it % NST) * 2 * kTileBytes;
+        const char* vt = kt + kTileBytes;
+
+        // -- logits of this wave's 32 slots x 32 pixels ---------------------------------------
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], read_row_frag(kt, ks, r, h), s, 0, 0, 0);
+
+        // -- softmax over slots: local (max, sum) for pixel column r ---------------------------
+        const int slot0 = 32 * w + 4 * h;
+        float mloc = kNegBig;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
+            s[i] = ok ? s[i] : kNegBig;
+            mloc = fmaxf(mloc, s[i]);
+        }
+        mloc = wave_half_xor_max(mloc);
+        float sloc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
+            const float e = __builtin_amdgcn_exp2f((s[i] - mloc) * kLog2e);
+            s[i] = ok ? e : 0.f;
+            sloc += s[i];
+        }
+        sloc = wave_half_xor_sum(sloc);
+        if (h == 0) stats[w * kTilePx + r] = make_float2(mloc, sloc);
+        wg_barrier();
+        float mall = kNegBig;
+        float2 st_w[NW];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            st_w[ww] = stats[ww * kTilePx + r];
+            mall = fmaxf(mall, st_w[ww].x);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww)
+            den += st_w[ww].y * __builtin_amdgcn_exp2f((st_w[ww].x - mall) * kLog2e);
+        float fac = __builtin_amdgcn_exp2f((mloc - mall) * kLog2e) / den;
+        if (px_begin + it * kTilePx + r >= px_end) fac = 0.f;  // pixels past the chunk / frame
+
+        // -- P -> bf16 (hi [+ lo]) -> wave-private [slot][pixel] image --------------------------
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = s[i] * fac;
+            const __bf16 ph = (__bf16)p;
+            const int off = acc_row(i, h) * kPimgStride + r * 2;
+            *reinterpret_cast<__bf16*>(pimg_hi + off) = ph;
+            if constexpr (SPLIT) *reinterpret_cast<__bf16*>(pimg_lo + off) = (__bf16)(p - (float)ph);
+        }
+        wait_lgkm0();
+
+        // -- o += P v ------------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int aoff = r * kPimgStride + 32 * ks + 16 * h;
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(pimg_hi + aoff);
+            bf16x8 al;
+            if constexpr (SPLIT) al = *reinterpret_cast<const bf16x8*>(pimg_lo + aoff);
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const bf16x8 vf = read_col_frag(vt, ks, db, lane);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vf, o[db], 0, 0, 0);
+                if constexpr (SPLIT) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vf, o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial [L, 256] of this workgroup -----------------------------------------------------
+    float* dst = partial + ((size_t)t * C + c) * L * kD;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int slot = 32 * w + acc_row(i, h);
+        if (slot < L) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db) dst[(size_t)slot * kD + 32 * db + r] = o[db][i];
+        }
+    }
+}
+
+// Sum the C partials of every (frame, slot) row in chunk order, then LayerNorm (biased variance,
+// two-pass, eps inside the sqrt - torch.nn.LayerNorm semantics) and ReLU. One 256-thread
+// workgroup per row, thread = channel.
+__global__ __launch_bounds__(256) void slot_attn_finish(const float* __restrict__ partial,
+                                                        const float* __restrict__ ln_w,
+                                                        const float* __restrict__ ln_b, float eps,
+                                                        float* __restrict__ out,      // [T, L, 256]
+                                                        float* __restrict__ out_pre,  // or null
+                                                        int L, int C) {
+    __shared__ float red[8];
+    const int l = blockIdx.x, t = blockIdx.y, d = threadIdx.x;
+    const float* src = partial + ((size_t)t * C * L + l) * kD + d;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc += src[(size_t)c * L * kD];
+    if (out_pre) out_pre[((size_t)t * L + l) * kD + d] = acc;
+
+    auto block_sum = [&](float x) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+        __syncthreads();
+        if ((d & 63) == 0) red[d >> 6] = x;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    const float mean = block_sum(acc) * (1.f / kD);
+    const float dev = acc - mean;
+    const float var = block_sum(dev * dev) * (1.f / kD);
+    float y = dev * rsqrtf(var + eps) * ln_w[d] + ln_b[d];
+    out[((size_t)t * L + l) * kD + d] = y > 0.f ? y : 0.f;
+}
+
+}  // namespace svps
+
+// ------------------------------------------------------------------------------------------------
+// C ABI (declared in include/slotvps_hip.h)
+// ------------------------------------------------------------------------------------------------
+#include "../../include/slotvps_hip.h"
+
+namespace {
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+struct AttnPlan {
+    int chunks;           // workgroups per frame
+    int tiles_per_chunk;  // 32-pixel tiles per workgroup
+};
+
+AttnPlan plan_attn(int T, int HW, int chunks_req) {
+    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+    int chunks = chunks_req;
+    if (chunks <= 0) {
+        // one resident workgroup per CU: the launch is a single wave of workgroups, each streaming
+        // one contiguous pixel range of one frame
+        chunks = num_cus() / (T > 0 ? T : 1);
+        if (chunks < 1) chunks = 1;
+    }
+    if (chunks > tiles) chunks = tiles;
+    int tpc = (tiles + chunks - 1) / chunks;
+    chunks = (tiles + tpc - 1) / tpc;  // drop empty trailing chunks
+    return {chunks, tpc};
+}
+
+template <int NW, int NST, bool SPLIT>
+hipError_t launch_partial(const void* q, const void* k, const void* v, float* partial, int T, int L,
+                          int HW, const AttnPlan& p, hipStream_t stream) {
+    using Lds = svps::AttnLds<NW, NST>;
+    auto kern = svps::slot_attn_partial<NW, NST, SPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Lds::total);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(NW * 64), Lds::total, stream,
+                       static_cast<const __bf16*>(q), static_cast<const __bf16*>(k),
+                       static_cast<const __bf16*>(v), partial, L, HW, p.tiles_per_chunk);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" size_t svps_slot_attn_workspace_bytes(int T, int L, int HW, int chunks) {
+    if (T <= 0 || L <= 0 || HW <= 0) return 0;
+    const AttnPlan p = plan_attn(T, HW, chunks);
+    return (size_t)T * p.chunks * L * svps::kD * sizeof(float);
+}
+
+extern "C" int svps_slot_attn_plan(int T, int HW, int chunks, int* out_chunks, int* out_tiles_per_chunk) {
+    if (T <= 0 || HW <= 0) return SVPS_ERR_BAD_ARG;
+    const AttnPlan p = plan_attn(T, HW, chunks);
+    if (out_chunks) *out_chunks = p.chunks;
+    if (out_tiles_per_chunk) *out_tiles_per_chunk = p.tiles_per_chunk;
+    return 0;
+}
+
+extern "C" int svps_slot_attn_fwd(const void* q, const void* k, const void* v, const float* ln_w,
+                                  const float* ln_b, float ln_eps, void* workspace,
+                                  size_t workspace_bytes, float* out, float* out_pre_ln, int T, int L,
+                                  int HW, int D, int flags, int chunks, void* stream_) {
+    if (!q || !k || !v || !ln_w || !ln_b || !workspace || !out) return SVPS_ERR_BAD_ARG;
+    if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || HW <= 0) return SVPS_ERR_BAD_SHAPE;
+    const AttnPlan p = plan_attn(T, HW, chunks);
+    if (workspace_bytes < (size_t)T * p.chunks * L * svps::kD * sizeof(float)) return SVPS_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* partial = static_cast<float*>(workspace);
+    const bool split = flags & SVPS_FLAG_SPLIT_P;
+    hipError_t e;
+    svps_prof_mark(SVPS_KERNEL_SLOT_ATTN, 0, stream);
+    if (L <= 128)
+        e = split ? launch_partial<4, 4, true>(q, k, v, partial, T, L, HW, p, stream)
+                  : launch_partial<4, 4, false>(q, k, v, partial, T, L, HW, p, stream);
+    else
+        e = split ? launch_partial<8, 3, true>(q, k, v, partial, T, L, HW, p, stream)
+                  : launch_partial<8, 3, false>(q, k, v, partial, T, L, HW, p, stream);
+    svps_prof_mark(SVPS_KERNEL_SLOT_ATTN, 1, stream);
+    if (e != hipSuccess) return (int)e;
+    svps_prof_mark(SVPS_KERNEL_SLOT_ATTN_FINISH, 0, stream);
+    hipLaunchKernelGGL(svps::slot_attn_finish, dim3(L, T), dim3(256), 0, stream, partial, ln_w, ln_b, ln_eps,
+                       out, out_pre_ln, L, p.chunks);
+    svps_prof_mark(SVPS_KERNEL_SLOT_ATTN_FINISH, 1, stream);
+    return (int)hipGetLastError();
+}

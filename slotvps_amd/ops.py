@@ -1,0 +1,123 @@
+"""Tensor-level entry points of the HIP path (thin: argument checks + one C-ABI call each).
+
+PyTorch is used for device memory and the current stream only. Every function requires CUDA
+(ROCm) tensors and the built libslotvps_hip.so; there is deliberately no CPU path here - the CPU
+restatement used for checking lives in oracle/ and is never imported from this package.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+D_MODEL = 256
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need(t, name, dtype, ndim=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: the slot-retriever ops run on the GPU only (got "
+                           f"{'a non-tensor' if not isinstance(t, torch.Tensor) else t.device}); "
+                           "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+
+
+def slot_attn_plan(T, HW, chunks=0):
+    lib = _lib.load()
+    c, tpc = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.svps_slot_attn_plan(T, HW, chunks, ctypes.byref(c), ctypes.byref(tpc)), "svps_slot_attn_plan")
+    return c.value, tpc.value
+
+
+def slot_attn(q, k, v, ln_w, ln_b, eps=1e-5, split_p=True, chunks=0, return_pre_ln=False):
+    """K1: out[t] = ReLU(LN(softmax_over_slots(q[t] k[t]^T) v[t])).
+
+    q [T, L, 256] bf16, k/v [T, HW, 256] bf16 (pixel-major), ln_w/ln_b [256] fp32.
+    Returns out [T, L, 256] fp32 (and the pre-LayerNorm pixel sum if return_pre_ln).
+    Mirrors MaskDynamicConv.forward lines 435-459 of the reference's dynamic_mask_head.py.
+    """
+    lib = _lib.load()
+    _need(q, "q", torch.bfloat16, 3)
+    _need(k, "k", torch.bfloat16, 3)
+    _need(v, "v", torch.bfloat16, 3)
+    _need(ln_w, "ln_w", torch.float32, 1)
+    _need(ln_b, "ln_b", torch.float32, 1)
+    T, L, D = q.shape
+    HW = k.shape[1]
+    if k.shape != (T, HW, D) or v.shape != (T, HW, D) or ln_w.numel() != D or ln_b.numel() != D:
+        raise ValueError(f"shape mismatch q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    ws_bytes = lib.svps_slot_attn_workspace_bytes(T, L, HW, chunks)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=q.device)
+    out = torch.empty((T, L, D), dtype=torch.float32, device=q.device)
+    pre = torch.empty_like(out) if return_pre_ln else None
+    flags = _lib.FLAG_SPLIT_P if split_p else 0
+    rc = lib.svps_slot_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(ws),
+                                ws_bytes, _ptr(out), _ptr(pre), T, L, HW, D, flags, chunks, _stream_ptr())
+    _lib.check(rc, "svps_slot_attn_fwd")
+    return (out, pre) if return_pre_ln else out
+
+
+def mask_decode(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out_bf16=False, want_argmax=False):
+    """K2: mask logits [T, L, HW] from the finest fused feature map [T, HW, 256] bf16 and the
+    last-stage slot embeddings [T, L, 256] fp32 (generate_final_outputs, vps_temporal_slots.py:144-160)."""
+    lib = _lib.load()
+    _need(feat, "feat", torch.bfloat16, 3)
+    _need(embed, "embed", torch.float32, 3)
+    _need(bn_scale, "bn_scale", torch.float32, 1)
+    _need(bn_shift, "bn_shift", torch.float32, 1)
+    T, HW, D = feat.shape
+    L = embed.shape[1]
+    if embed.shape != (T, L, D) or bn_scale.numel() != D or bn_shift.numel() != D:
+        raise ValueError("shape mismatch")
+    out = torch.empty((T, L, HW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=feat.device)
+    amax = torch.empty((T, HW), dtype=torch.uint8, device=feat.device) if want_argmax else None
+    rc = lib.svps_mask_decode_fwd(_ptr(feat), _ptr(embed), _ptr(bn_scale), _ptr(bn_shift), float(fg_scale),
+                                  float(fg_shift), _ptr(out), _ptr(amax), T, L, HW, D,
+                                  _lib.FLAG_OUT_BF16 if out_bf16 else 0, _stream_ptr())
+    _lib.check(rc, "svps_mask_decode_fwd")
+    return (out, amax) if want_argmax else out
+
+
+def pos_embed_sine(H, W, D=D_MODEL, device="cuda"):
+    """Pixel-major [H*W, D] fp32 sine embedding (PositionEmbeddingSine, position_encoding.py:236-256)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("pos_embed_sine runs on the GPU only; there is no CPU fallback")
+    out = torch.empty((H * W, D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.svps_pos_embed_sine(_ptr(out), H, W, D, _stream_ptr()), "svps_pos_embed_sine")
+    return out
+
+
+class KernelTimer:
+    """Device-time accounting of the library's own launches (HIP events on the launch stream)."""
+
+    def __enter__(self):
+        lib = _lib.load()
+        lib.svps_prof_reset()
+        lib.svps_prof_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().svps_prof_enable(0)
+        return False
+
+    @staticmethod
+    def collect(kernel_id):
+        lib = _lib.load()
+        ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        _lib.check(lib.svps_prof_collect(kernel_id, ctypes.byref(ms), ctypes.byref(n)), "svps_prof_collect")
+        return ms.value, n.value
