@@ -68,7 +68,8 @@ int svps_abi_version(void);
  *   chunks: workgroups per frame, 0 = choose (one resident workgroup per CU)
  * ------------------------------------------------------------------------------------------- */
 size_t svps_slot_attn_workspace_bytes(int T, int L, int HW, int chunks);
-int svps_slot_attn_plan(int T, int HW, int chunks, int* out_chunks, int* out_tiles_per_chunk);
+int svps_slot_attn_plan(int T, int L, int HW, int chunks, int* out_chunks, int* out_tiles_per_chunk,
+                        int* out_tile_px);
 int svps_slot_attn_fwd(const void* q, const void* k, const void* v, const float* ln_w,
                        const float* ln_b, float ln_eps, void* workspace, size_t workspace_bytes,
                        float* out, float* out_pre_ln, int T, int L, int HW, int D, int flags,

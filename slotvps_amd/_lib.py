@@ -27,7 +27,7 @@ _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
 SIGNATURES = {
     "svps_abi_version": (_i, []),
     "svps_slot_attn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "svps_slot_attn_plan": (_i, [_i, _i, _i, _c.POINTER(_i), _c.POINTER(_i)]),
+    "svps_slot_attn_plan": (_i, [_i, _i, _i, _i, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i)]),
     "svps_slot_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_mask_decode_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "svps_pos_embed_sine": (_i, [_vp, _i, _i, _i, _vp]),

@@ -207,6 +207,285 @@ __global__ __launch_bounds__(NW * 64) void slot_attn_partial(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised variant for L <= 128: 8 waves = 4 producers + 4 consumers, two waves per SIMD.
+//
+// The 4-wave kernel above serialises  logits -> softmax -> P -> PV  inside every wave, so the
+// matrix pipe idles during the softmax and the VALU idles during the MFMAs. Here the two halves
+// run on DIFFERENT waves of the same SIMD, one 32-pixel tile apart:
+//   producer wave sb (waves 0-3): logits of slot block sb for tile i (16 MFMA), softmax over slots
+//       (in-lane + lane^32 + one (max, sum) exchange with the other three producers), P(i) -> LDS
+//   consumer wave sb (waves 4-7): o[sb, all 256 channels] += P(i-1) v(i-1) (16 MFMA, 32 with
+//       SPLIT) and ALL the LDS-DMA of the workgroup (the producers never touch vector memory)
+// so a SIMD's matrix pipe (mostly the consumer) and its VALU (the producer) are busy together.
+// Two barriers per tile; the consumers cross the softmax barrier between their two 16-pixel
+// k-steps. (A three-stage variant with one barrier per tile measured 5-7 % slower.)
+//
+// LDS: keys in a 5-deep ring, values in a 4-deep ring (16 KiB tiles, 144 KiB), fetched 3 tiles
+// ahead. P(i) is written over k(i) - the keys are dead once all four producers have their logits -
+// as [slot block][pixel][slot] (8-byte packed stores, read back as MFMA A fragments with
+// ds_read_b64_tr_b16). k / v tiles arrive by `buffer_load ... lds` with tile-invariant per-lane
+// offsets plus a scalar tile offset.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPrefetch = 3;             // tiles in flight ahead of the one being consumed
+constexpr int kNK = kPrefetch + 2;       // key / P ring depth
+constexpr int kNV = kPrefetch + 1;       // value ring depth
+
+struct AttnWsLds {
+    static constexpr int kring = 0;
+    static constexpr int vring = kNK * kTileBytes;
+    static constexpr int stats = vring + kNV * kTileBytes;   // [4][32] float2
+    static constexpr int total = stats + 4 * 32 * 8;
+};
+
+// Raw buffer descriptor (4 SGPRs) for `bytes` bytes at `base`; every word is made provably
+// wave-uniform so the asm below can take it in scalar registers.
+__device__ __forceinline__ u32x4 make_srd(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);   // stride = 0
+    d[2] = __builtin_amdgcn_readfirstlane(bytes);
+    d[3] = 0x00020000u;
+    return d;
+}
+
+// One 1-KiB LDS-DMA piece, `buffer_load_dwordx4 ... offen lds`: LDS[lds_addr + lane*16] <-
+// buffer[soff + voff(lane)]. Written in asm on purpose: hipcc treats the builtin form as an LDS
+// store that may alias every later ds_read and drains it with s_waitcnt vmcnt(0) before the first
+// LDS read that follows - which serialises the whole prefetch ring. In asm the load is invisible to
+// the compiler's counters; the kernel orders it by hand (counted vmcnt, then a workgroup barrier,
+// then the reads). M0 (the LDS base of the DMA) is saved and restored inside the statement.
+__device__ __forceinline__ void dma16_srd(u32x4 srd, uint32_t lds_addr, int voff, int soff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+        : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)p);
+}
+
+__device__ __forceinline__ float half_swap_max(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_swap_sum(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ABL != 0 are timing-only ablations for tools/kbench.py (env SVPS_ABLATE); their outputs are wrong.
+//   1: DMA + barriers only   2: producers only (no PV)   4: consumers only (no logits / softmax)   5: no DMA
+template <bool SPLIT, int ABL = 0>
+__global__ __launch_bounds__(512) void slot_attn_partial_ws(
+    const __bf16* __restrict__ q,   // [T, L, 256]
+    const __bf16* __restrict__ k,   // [T, HW, 256]
+    const __bf16* __restrict__ v,   // [T, HW, 256]
+    float* __restrict__ partial,    // [T, C, L, 256]
+    int L, int HW, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = AttnWsLds;
+    constexpr int A = kPrefetch;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sb = w & 3;
+    const bool consumer = w >= 4;
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x, C = gridDim.x;
+
+    const int px_begin = c * tiles_per_chunk * kTilePx;
+    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    px_end = px_end < HW ? px_end : HW;
+    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+
+    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+
+    if (!consumer) {
+        // ================================ producer =============================================
+        bf16x8 qf[16];
+        {
+            const int slot = 32 * sb + r;
+            const __bf16* qrow = q + ((size_t)t * L + (slot < L ? slot : 0)) * kD + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                u32x4 raw = *reinterpret_cast<const u32x4*>(qrow + 16 * ks);
+                if (slot >= L) raw = u32x4{0u, 0u, 0u, 0u};
+                qf[ks] = __builtin_bit_cast(bf16x8, raw);
+            }
+        }
+        const int slot0 = 32 * sb + 4 * h;
+        const int key = (r >> 1) & 3;
+        for (int it = 0; it <= nt; ++it) {
+            wg_barrier();                                        // B_top(it)
+            if (it == nt || ABL == 1 || ABL == 4) { wg_barrier(); continue; }
+            char* kt = smem + Lds::kring + (it % kNK) * kTileBytes;
+            // all 16 key fragments are requested before the first MFMA (hipcc otherwise keeps only
+            // two LDS reads in flight and the dependent MFMA chain runs at LDS latency)
+            bf16x8 kf[16];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) kf[ks] = read_row_frag(kt, ks, r, h);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+            float mloc = kNegBig;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
+                s[i] = ok ? s[i] : kNegBig;
+                mloc = fmaxf(mloc, s[i]);
+            }
+            mloc = half_swap_max(mloc);
+            float sloc = 0.f;
+            const float mneg = -mloc * kLog2e;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[i], kLog2e, mneg));
+                s[i] = ok ? e : 0.f;
+                sloc += s[i];
+            }
+            sloc = half_swap_sum(sloc);
+            if (h == 0) stats[sb * 32 + r] = make_float2(mloc, sloc);
+            wg_barrier();                                        // B_stats(it): also "k(it) is dead"
+            float mall = kNegBig;
+            float2 st_w[4];
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                st_w[ww] = stats[ww * 32 + r];
+                mall = fmaxf(mall, st_w[ww].x);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww)
+                den += st_w[ww].y * __builtin_amdgcn_exp2f((st_w[ww].x - mall) * kLog2e);
+            float fac = __builtin_amdgcn_exp2f((mloc - mall) * kLog2e) / den;
+            if (px_begin + it * kTilePx + r >= px_end) fac = 0.f;   // pixels past the chunk / frame
+            char* prow = kt + sb * 2048 + r * 64 + 8 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = s[4 * g + j] * fac;
+                    ph[j] = (__bf16)p;
+                    if constexpr (SPLIT) pl[j] = (__bf16)(p - (float)ph[j]);
+                }
+                *reinterpret_cast<bf16x4*>(prow + ((g ^ key) * 16)) = ph;
+                if constexpr (SPLIT) *reinterpret_cast<bf16x4*>(prow + 8192 + ((g ^ key) * 16)) = pl;
+            }
+        }
+        return;
+    }
+
+    // =================================== consumer ===============================================
+    const u32x4 krs = make_srd(k + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 vrs = make_srd(v + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    // consumer wave sb stages rows 8 sb .. 8 sb + 7 of every k and v tile (4 pieces of 2 rows each)
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * sb + 2 * i + h;
+        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+    }
+    const uint32_t lds0 = lds_addr_of(smem);
+    auto stage = [&](u32x4 rs, int tile, int buf_off) {
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + buf_off + sb * 4 * 1024);
+        const int px0 = px_begin + tile * kTilePx;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + kTilePx <= HW) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma16_srd(rs, st + i * 1024, voff[i], soff);
+        } else {  // ragged last tile of the frame: clamp source rows (their P is forced to 0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * sb + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                dma16_srd(rs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+            }
+        }
+    };
+    // batch b = { k(b), v(b-1) } must have landed by B_top(b); batches 0 .. A-1 go out here, batch
+    // it + A right after B_top(it)
+    auto issue_batch = [&](int b) {
+        if constexpr (ABL == 5) { if (b > 1) return; }
+        if (b < nt) stage(krs, b, Lds::kring + (b % kNK) * kTileBytes);
+        if (b >= 1 && b - 1 < nt) stage(vrs, b - 1, Lds::vring + ((b - 1) % kNV) * kTileBytes);
+    };
+#pragma unroll
+    for (int b = 0; b < A; ++b) issue_batch(b);
+
+    f32x16 o[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+
+    const int g2 = lane >> 4, ii = lane & 15, qq = ii >> 2, pp = ii & 3;
+    const int pchunk = 2 * (g2 & 1) + (pp >> 1);
+
+    auto pv_step = [&](const char* pt, const char* vt, int ks) {
+        const int px0 = 16 * ks + 8 * (g2 >> 1) + qq;
+        const char* a0 = pt + sb * 2048 + 8 * (pp & 1) + px0 * 64 + ((pchunk ^ ((px0 >> 1) & 3)) * 16);
+        const char* a1 = pt + sb * 2048 + 8 * (pp & 1) + (px0 + 4) * 64 + ((pchunk ^ (((px0 + 4) >> 1) & 3)) * 16);
+        const bf16x8 ah = __builtin_shufflevector(
+            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)a0),
+            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)a1), 0, 1, 2, 3, 4, 5, 6, 7);
+        bf16x8 al;
+        if constexpr (SPLIT)
+            al = __builtin_shufflevector(
+                __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(a0 + 8192)),
+                __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(a1 + 8192)), 0, 1, 2, 3, 4, 5, 6, 7);
+        bf16x8 vf[8];
+#pragma unroll
+        for (int db = 0; db < 8; ++db) vf[db] = read_col_frag(vt, ks, db, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vf[db], o[db], 0, 0, 0);
+            if constexpr (SPLIT) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vf[db], o[db], 0, 0, 0);
+        }
+    };
+
+    for (int it = 0; it <= nt; ++it) {
+        // batch `it` landed for this wave: all but the A-1 younger batches (8 loads each; the tail
+        // batches are smaller, so the last iterations simply drain)
+        if (it + A - 1 < nt) wait_vm<8 * (A - 1)>();
+        else wait_vm<0>();
+        wg_barrier();                                            // B_top(it)
+        if (it + A <= nt) issue_batch(it + A);
+        const bool work = it >= 1 && ABL != 1 && ABL != 2;
+        const char* pt = smem + Lds::kring + ((it + kNK - 1) % kNK) * kTileBytes;   // P(it-1) over k(it-1)
+        const char* vt = smem + Lds::vring + ((it + kNV - 1) % kNV) * kTileBytes;   // v(it-1)
+        if (work) pv_step(pt, vt, 0);
+        wg_barrier();                                            // B_stats(it)
+        if (work) pv_step(pt, vt, 1);
+    }
+
+    float* dst = partial + ((size_t)t * C + c) * L * kD;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int slot = 32 * sb + acc_row(i, h);
+        if (slot < L) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db) dst[(size_t)slot * kD + 32 * db + r] = o[db][i];
+        }
+    }
+}
+
 // Sum the C partials of every (frame, slot) row in chunk order, then LayerNorm (biased variance,
 // two-pass, eps inside the sqrt - torch.nn.LayerNorm semantics) and ReLU. One 256-thread
 // workgroup per row, thread = channel.
@@ -219,8 +498,17 @@ __global__ __launch_bounds__(256) void slot_attn_finish(const float* __restrict_
     __shared__ float red[8];
     const int l = blockIdx.x, t = blockIdx.y, d = threadIdx.x;
     const float* src = partial + ((size_t)t * C * L + l) * kD + d;
-    float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc += src[(size_t)c * L * kD];
+    // fixed summation order (bitwise reproducible): 8 interleaved partial sums keep 8 loads in
+    // flight per thread, then a fixed-order combine
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const size_t cstride = (size_t)L * kD;
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] += src[(size_t)(c + u) * cstride];
+    }
+    for (int u = 0; c < C; ++c, ++u) a8[u] += src[(size_t)c * cstride];
+    float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     if (out_pre) out_pre[((size_t)t * L + l) * kD + d] = acc;
 
     auto block_sum = [&](float x) {
@@ -243,6 +531,8 @@ __global__ __launch_bounds__(256) void slot_attn_finish(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // C ABI (declared in include/slotvps_hip.h)
 // ------------------------------------------------------------------------------------------------
+#include <stdlib.h>
+
 #include "../../include/slotvps_hip.h"
 
 namespace {
@@ -260,11 +550,13 @@ int num_cus() {
 
 struct AttnPlan {
     int chunks;           // workgroups per frame
-    int tiles_per_chunk;  // 32-pixel tiles per workgroup
+    int tiles_per_chunk;  // pixel tiles per workgroup
+    int tile_px;          // pixels per tile (32)
 };
 
-AttnPlan plan_attn(int T, int HW, int chunks_req) {
-    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+AttnPlan plan_attn(int T, int L, int HW, int chunks_req) {
+    const int tile_px = svps::kTilePx;
+    const int tiles = (HW + tile_px - 1) / tile_px;
     int chunks = chunks_req;
     if (chunks <= 0) {
         // one resident workgroup per CU: the launch is a single wave of workgroups, each streaming
@@ -275,7 +567,7 @@ AttnPlan plan_attn(int T, int HW, int chunks_req) {
     if (chunks > tiles) chunks = tiles;
     int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;  // drop empty trailing chunks
-    return {chunks, tpc};
+    return {chunks, tpc, tile_px};
 }
 
 template <int NW, int NST, bool SPLIT>
@@ -296,19 +588,39 @@ hipError_t launch_partial(const void* q, const void* k, const void* v, float* pa
     return hipGetLastError();
 }
 
+template <bool SPLIT, int ABL = 0>
+hipError_t launch_partial_ws(const void* q, const void* k, const void* v, float* partial, int T, int L,
+                             int HW, const AttnPlan& p, hipStream_t stream) {
+    using Lds = svps::AttnWsLds;
+    auto kern = svps::slot_attn_partial_ws<SPLIT, ABL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Lds::total);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream,
+                       static_cast<const __bf16*>(q), static_cast<const __bf16*>(k),
+                       static_cast<const __bf16*>(v), partial, L, HW, p.tiles_per_chunk);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" size_t svps_slot_attn_workspace_bytes(int T, int L, int HW, int chunks) {
     if (T <= 0 || L <= 0 || HW <= 0) return 0;
-    const AttnPlan p = plan_attn(T, HW, chunks);
+    const AttnPlan p = plan_attn(T, L, HW, chunks);
     return (size_t)T * p.chunks * L * svps::kD * sizeof(float);
 }
 
-extern "C" int svps_slot_attn_plan(int T, int HW, int chunks, int* out_chunks, int* out_tiles_per_chunk) {
-    if (T <= 0 || HW <= 0) return SVPS_ERR_BAD_ARG;
-    const AttnPlan p = plan_attn(T, HW, chunks);
+extern "C" int svps_slot_attn_plan(int T, int L, int HW, int chunks, int* out_chunks,
+                                   int* out_tiles_per_chunk, int* out_tile_px) {
+    if (T <= 0 || L <= 0 || HW <= 0) return SVPS_ERR_BAD_ARG;
+    const AttnPlan p = plan_attn(T, L, HW, chunks);
     if (out_chunks) *out_chunks = p.chunks;
     if (out_tiles_per_chunk) *out_tiles_per_chunk = p.tiles_per_chunk;
+    if (out_tile_px) *out_tile_px = p.tile_px;
     return 0;
 }
 
@@ -318,16 +630,24 @@ extern "C" int svps_slot_attn_fwd(const void* q, const void* k, const void* v, c
                                   int HW, int D, int flags, int chunks, void* stream_) {
     if (!q || !k || !v || !ln_w || !ln_b || !workspace || !out) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || HW <= 0) return SVPS_ERR_BAD_SHAPE;
-    const AttnPlan p = plan_attn(T, HW, chunks);
+    const AttnPlan p = plan_attn(T, L, HW, chunks);
     if (workspace_bytes < (size_t)T * p.chunks * L * svps::kD * sizeof(float)) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
     const bool split = flags & SVPS_FLAG_SPLIT_P;
     hipError_t e;
     svps_prof_mark(SVPS_KERNEL_SLOT_ATTN, 0, stream);
-    if (L <= 128)
-        e = split ? launch_partial<4, 4, true>(q, k, v, partial, T, L, HW, p, stream)
-                  : launch_partial<4, 4, false>(q, k, v, partial, T, L, HW, p, stream);
+    static const int ablate = [] { const char* a = getenv("SVPS_ABLATE"); return a ? atoi(a) : 0; }();
+    if (L <= 128 && ablate) {
+        switch (ablate) {
+            case 1: e = launch_partial_ws<true, 1>(q, k, v, partial, T, L, HW, p, stream); break;
+            case 2: e = launch_partial_ws<true, 2>(q, k, v, partial, T, L, HW, p, stream); break;
+            case 4: e = launch_partial_ws<true, 4>(q, k, v, partial, T, L, HW, p, stream); break;
+            default: e = launch_partial_ws<true, 5>(q, k, v, partial, T, L, HW, p, stream); break;
+        }
+    } else if (L <= 128)
+        e = split ? launch_partial_ws<true>(q, k, v, partial, T, L, HW, p, stream)
+                  : launch_partial_ws<false>(q, k, v, partial, T, L, HW, p, stream);
     else
         e = split ? launch_partial<8, 3, true>(q, k, v, partial, T, L, HW, p, stream)
                   : launch_partial<8, 3, false>(q, k, v, partial, T, L, HW, p, stream);

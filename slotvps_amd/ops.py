@@ -34,11 +34,13 @@ def _need(t, name, dtype, ndim=None):
         raise ValueError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
 
 
-def slot_attn_plan(T, HW, chunks=0):
+def slot_attn_plan(T, L, HW, chunks=0):
+    """(workgroups per frame, tiles per workgroup, pixels per tile) the launcher will use."""
     lib = _lib.load()
-    c, tpc = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(lib.svps_slot_attn_plan(T, HW, chunks, ctypes.byref(c), ctypes.byref(tpc)), "svps_slot_attn_plan")
-    return c.value, tpc.value
+    c, tpc, tp = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.svps_slot_attn_plan(T, L, HW, chunks, ctypes.byref(c), ctypes.byref(tpc), ctypes.byref(tp)),
+               "svps_slot_attn_plan")
+    return c.value, tpc.value, tp.value
 
 
 def slot_attn(q, k, v, ln_w, ln_b, eps=1e-5, split_p=True, chunks=0, return_pre_ln=False):
