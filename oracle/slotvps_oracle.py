@@ -46,27 +46,40 @@ def round_bf16(x):
 
 
 class Storage:
-    """Which tensors the path keeps in bf16 in HBM. Each hook returns float32/float64 values."""
+    """Which tensors the path keeps in bf16 in HBM. Each hook returns float32/float64 values.
 
-    def __init__(self, bf16):
+    bf16=False rounds nothing (the reference's fp32 arithmetic). With bf16=True the always-on
+    rounding points are: the fused level map, the operands of the 1x1 fusion conv and of the k/v
+    projections (activations and weight matrices), and the post-LayerNorm q / k / v. ``torch_gemm``
+    additionally models the interim PyTorch producers of the HIP path (a bf16 GEMM rounds its
+    bias and its pre-LayerNorm output to bf16 as well)."""
+
+    def __init__(self, bf16, torch_gemm=False):
         self.bf16 = bool(bf16)
+        self.torch_gemm = bool(torch_gemm)
 
     @classmethod
     def exact(cls):
         return cls(False)
 
     @classmethod
-    def bf16_policy(cls):
-        return cls(True)
+    def bf16_policy(cls, torch_gemm=False):
+        return cls(True, torch_gemm)
 
     def _r(self, x):
         return round_bf16(x).astype(x.dtype) if self.bf16 else x
 
+    def _rt(self, x):
+        return round_bf16(x).astype(x.dtype) if (self.bf16 and self.torch_gemm) else x
+
     feat = _r      # fused level feature map f (input of the projections, the decode, the next level)
+    conv_in = _r   # concat(upsampled previous level, current 128-ch map): operand of the 1x1 conv
     proj_in = _r   # f + pos, the k-projection operand
-    weight = _r    # to_k / to_v weight matrices as MFMA operands
+    weight = _r    # conv / to_k / to_v weight matrices as matrix-core operands
     kv = _r        # post-LayerNorm k and v
     q = _r         # post-LayerNorm q
+    bias = _rt     # conv / projection biases (bf16 only in the interim torch GEMMs)
+    pre_ln = _rt   # projection output before LayerNorm (bf16 only in the interim torch GEMMs)
 
 
 # --------------------------------------------------------------------------------------------
@@ -157,8 +170,10 @@ def retriever_project(slots, feat, pos, params, prefix, st, dt):
     g = lambda n: _p(params, prefix, n, dt)
     q = layer_norm(linear(slots, g("to_q.weight"), g("to_q.bias")), g("norm_q.weight"), g("norm_q.bias"))
     kin = st.proj_in(feat + pos) if pos is not None else feat
-    k = layer_norm(linear(kin, st.weight(g("to_k.weight")), g("to_k.bias")), g("norm_k.weight"), g("norm_k.bias"))
-    v = layer_norm(linear(feat, st.weight(g("to_v.weight")), g("to_v.bias")), g("norm_v.weight"), g("norm_v.bias"))
+    k = layer_norm(st.pre_ln(linear(kin, st.weight(g("to_k.weight")), st.bias(g("to_k.bias")))),
+                   g("norm_k.weight"), g("norm_k.bias"))
+    v = layer_norm(st.pre_ln(linear(feat, st.weight(g("to_v.weight")), st.bias(g("to_v.bias")))),
+                   g("norm_v.weight"), g("norm_v.bias"))
     return st.q(q), st.kv(k), st.kv(v)
 
 
@@ -283,12 +298,15 @@ DEFAULT_CFG = dict(nhead=8, activation="gelu", temporal_activation="relu", num_c
                    per_level_stages=(1, 2, 2, 2), temporal_stages=(3, 4, 5, 6))
 
 
-def head_forward(features, init_slots, pos, params, cfg=None, st=None, dt=np.float32, retriever_fn=None):
+def head_forward(features, init_slots, pos, params, cfg=None, st=None, dt=np.float32, retriever_fn=None,
+                 fused_override=None):
     """MultiScaleDynamicMaskHead.forward :138-228, merge_operation='concat', trans_in_dim=384.
 
     features[t][i]: [128, Hi, Wi] (coarse -> fine), init_slots [L, D] (same embedding for all frames,
     vps_temporal_slots.py:286), pos[i]: [Hi*Wi, D] pixel-major (identical for every frame).
     Returns (logits [T][n_stage][L, C], embeds [T][n_stage][L, D], fused [T][4] each [Hi*Wi, D] pixel-major).
+    fused_override[t][i] ([Hi*Wi, D]) replaces the computed fused map of level i (teacher forcing: lets a
+    test compare everything downstream of the level fusion on identical feature maps).
     """
     cfg = dict(DEFAULT_CFG, **(cfg or {}))
     st = st or Storage.exact()
@@ -310,8 +328,11 @@ def head_forward(features, init_slots, pos, params, cfg=None, st=None, dt=np.flo
                 cat = np.concatenate([x, x, x], axis=0)                      # :183
             else:
                 cat = np.concatenate([upsample2x_bilinear(prev[t]), x], axis=0)   # :178-179
-            y = (wc @ cat.reshape(cat.shape[0], H * W) + bc[:, None])        # 1x1 conv :181/:185
+            cat = st.conv_in(cat)
+            y = (st.weight(wc) @ cat.reshape(cat.shape[0], H * W) + st.bias(bc)[:, None])   # 1x1 conv :181/:185
             y = st.feat(np.ascontiguousarray(y.T))                           # pixel-major [HW, 256]
+            if fused_override is not None:
+                y = np.asarray(fused_override[t][i], dtype=dt)
             cur_pm.append(y)
             prev[t] = np.ascontiguousarray(y.T).reshape(256, H, W)
             fused[t][i] = y

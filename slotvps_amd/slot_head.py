@@ -1,0 +1,367 @@
+"""Host-side mirror of the reference's slot head (mmdet/models/detectors/dynamic_mask_head.py):
+same class names, constructor arguments, parameter names (checkpoint keys) and call signature, but
+the whole clip is processed as one batch and the slot<->pixel retriever runs on the HIP kernel K1.
+
+What runs where
+  * K1 (HIP, libslotvps_hip.so): logits, softmax over slots, attn.v, LayerNorm, ReLU for all T frames
+    of a stage in one launch (MaskDynamicConv.forward lines 435-459).
+  * PyTorch-ROCm (plumbing around the kernel, same math as the reference lines cited inline): the
+    level fusion (bilinear x2, concat, 1x1 conv), the k/v projections + LayerNorm that produce K1's
+    bf16 inputs, and the slot-side operators on [T, L, 256] tensors (self-attention, FFN, temporal
+    head, towers).
+There is no CPU path: modules raise if their tensors are not on a GPU.
+
+Storage policy (what is rounded to bf16 in HBM): the fused level map f, the projection operand f+pos,
+the projection weights, and the post-LayerNorm q / k / v. Slot-side tensors stay fp32.
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .registry import HEADS
+
+BF16 = torch.bfloat16
+
+
+def _get_activation_fn(activation):
+    if activation == "relu":
+        return F.relu
+    if activation == "gelu":
+        return F.gelu
+    if activation == "glu":
+        return F.glu
+    raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
+
+
+def _get_clones(module, n):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+class ConvModule(nn.Module):
+    """1x1 conv + bias held as ``.conv`` - what the reference's ConvModule builds for
+    activation=None and no norm (mmdet/models/utils/conv_module.py:95-97, :135)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, padding=0, activation=None):
+        super().__init__()
+        if kernel_size != 1 or padding != 0 or activation is not None:
+            raise NotImplementedError("only the 1x1 / no-activation form used by the slot head")
+        self.conv = nn.Conv2d(in_channels, out_channels, 1, bias=True)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def _project_ln(x_bf16, lin, norm):
+    """bf16(LayerNorm(x W^T + b)) for pixel rows: the k / v producers of K1 (:432-433)."""
+    y = F.linear(x_bf16, lin.weight.to(BF16), lin.bias.to(BF16))
+    return F.layer_norm(y.float(), (y.shape[-1],), norm.weight, norm.bias, norm.eps).to(BF16)
+
+
+class MaskDynamicConv(nn.Module):
+    """Retriever of the Panoptic Retriever (:403-461). forward keeps the reference signature
+    (pro_features [N, L, C], features [N, C, H, W], pos [N, C, H, W]); ``forward_pm`` is the batched
+    pixel-major entry the head uses."""
+
+    def __init__(self, dh_dim=256, softmax_dim="slots"):
+        super().__init__()
+        if softmax_dim != "slots":
+            raise NotImplementedError("the HIP kernel implements softmax over slots (the configured mode)")
+        self.hidden_dim = dh_dim
+        self.softmax_dim = softmax_dim
+        self.to_q = nn.Linear(dh_dim, dh_dim, bias=True)
+        self.to_k = nn.Linear(dh_dim, dh_dim, bias=True)
+        self.to_v = nn.Linear(dh_dim, dh_dim, bias=True)
+        self.norm_q = nn.LayerNorm(dh_dim)
+        self.norm_k = nn.LayerNorm(dh_dim)
+        self.norm_v = nn.LayerNorm(dh_dim)
+        self.norm1 = nn.LayerNorm(dh_dim)
+        self.activation = nn.ReLU(inplace=True)
+        self.split_p = True     # carry softmax probabilities as bf16 hi+lo inside K1
+
+    def project_kv(self, feat_pm, pos_pm):
+        """feat_pm [T, HW, C] bf16, pos_pm [HW, C] fp32 or None -> k, v [T, HW, C] bf16."""
+        kin = feat_pm if pos_pm is None else (feat_pm.float() + pos_pm).to(BF16)
+        return _project_ln(kin, self.to_k, self.norm_k), _project_ln(feat_pm, self.to_v, self.norm_v)
+
+    def forward_pm(self, slots, feat_pm, pos_pm, kv=None):
+        """slots [T, L, C] fp32, feat_pm [T, HW, C] bf16 -> [T, L, C] fp32."""
+        q = self.norm_q(self.to_q(slots)).to(BF16).contiguous()
+        k, v = kv if kv is not None else self.project_kv(feat_pm, pos_pm)
+        return ops.slot_attn(q, k.contiguous(), v.contiguous(), self.norm1.weight, self.norm1.bias,
+                             eps=self.norm1.eps, split_p=self.split_p)
+
+    def forward(self, pro_features, features, pos, gt_non_void_mask=None):
+        assert gt_non_void_mask is None
+        n, c, h, w = features.shape
+        feat_pm = features.permute(0, 2, 3, 1).reshape(n, h * w, c).to(BF16).contiguous()
+        pos_pm = None
+        if pos is not None:
+            pos_pm = pos[0].permute(1, 2, 0).reshape(h * w, c).float().contiguous()
+        return self.forward_pm(pro_features.float(), feat_pm, pos_pm)
+
+
+class SlotsDynamicConv(nn.Module):
+    """Retriever of the Video Retriever (:530-572): the same math among the T*L slots themselves
+    (<= 2000 rows) - far below one workgroup's worth of work, left to PyTorch."""
+
+    def __init__(self, dh_dim=256, softmax_dim="slots"):
+        super().__init__()
+        if softmax_dim != "slots":
+            raise NotImplementedError
+        self.hidden_dim = dh_dim
+        self.softmax_dim = softmax_dim
+        self.to_q = nn.Linear(dh_dim, dh_dim, bias=True)
+        self.to_k = nn.Linear(dh_dim, dh_dim, bias=True)
+        self.to_v = nn.Linear(dh_dim, dh_dim, bias=True)
+        self.norm_q = nn.LayerNorm(dh_dim)
+        self.norm_k = nn.LayerNorm(dh_dim)
+        self.norm_v = nn.LayerNorm(dh_dim)
+        self.norm1 = nn.LayerNorm(dh_dim)
+        self.activation = nn.ReLU(inplace=True)
+
+    def forward(self, curr_features, features, pos):
+        q = self.norm_q(self.to_q(curr_features))
+        k = self.norm_k(self.to_k(features if pos is None else features + pos))
+        v = self.norm_v(self.to_v(features))
+        attn = torch.softmax(q @ k.transpose(-1, -2), dim=1)        # over the query axis (:562)
+        return self.activation(self.norm1(attn @ v))
+
+
+@HEADS.register_module
+class TemporalSlotsHead(nn.Module):
+    """Video Retriever (:464-527)."""
+
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.1, activation="relu", softmax_dim="slots",
+                 drop_path=0.):
+        super().__init__()
+        if dropout != 0.0 or drop_path != 0.0:
+            raise NotImplementedError("inference path: dropout / drop_path must be 0")
+        self.d_model = d_model
+        self.inst_interact = SlotsDynamicConv(dh_dim=d_model, softmax_dim=softmax_dim)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)   # present in checkpoints, unused by the reference too
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.activation = _get_activation_fn(activation)
+
+    def forward(self, features, mask_query, pos=None, query_pos=None):
+        assert query_pos is None
+        x = mask_query.view(1, -1, self.d_model)
+        f = features.view(1, -1, self.d_model)
+        x = self.norm2(x + self.inst_interact(x, f, pos))
+        x = self.norm3(x + self.linear2(self.activation(self.linear1(x))))
+        return x.squeeze(0)
+
+
+class MaskRCNNHead(nn.Module):
+    """One stage (:231-400)."""
+
+    def __init__(self, d_model, num_classes, dim_feedforward=2048, nhead=8, dropout=0.1, activation="relu",
+                 scale_clamp=math.log(100000.0 / 16), num_cls=1, num_reg=3, use_focal=True, softmax_dim="slots",
+                 drop_path=0., temporal_query_attention_config=None):
+        super().__init__()
+        if dropout != 0.0 or drop_path != 0.0:
+            raise NotImplementedError("inference path: dropout / drop_path must be 0")
+        self.d_model = d_model
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.inst_interact = MaskDynamicConv(dh_dim=d_model, softmax_dim=softmax_dim)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.activation = _get_activation_fn(activation)
+        self.drop_path = None
+        self.temporal_query_head = None
+        if temporal_query_attention_config is not None:
+            self.temporal_query_head = TemporalSlotsHead(**temporal_query_attention_config)
+        cls_module, reg_module = [], []
+        for _ in range(num_cls):
+            cls_module += [nn.Linear(d_model, d_model, False), nn.LayerNorm(d_model), nn.ReLU(inplace=True)]
+        for _ in range(num_reg):
+            reg_module += [nn.Linear(d_model, d_model, False), nn.LayerNorm(d_model), nn.ReLU(inplace=True)]
+        self.cls_module = nn.ModuleList(cls_module)
+        self.reg_module = nn.ModuleList(reg_module)
+        self.use_focal = use_focal
+        self.class_logits = nn.Linear(d_model, num_classes)
+        self.scale_clamp = scale_clamp
+
+    def forward_till_ffn_pm(self, slots, feat_pm, pos_pm):
+        """:342-388 for all frames at once. slots [T, L, C] fp32."""
+        x = slots.transpose(0, 1)                                           # [L, T, C]: sequence-first, frames = batch
+        x = self.norm1(x + self.self_attn(x, x, value=x, key_padding_mask=None, need_weights=False)[0])
+        x = x.transpose(0, 1)
+        x = self.norm2(x + self.inst_interact.forward_pm(x.contiguous(), feat_pm, pos_pm))
+        return self.norm3(x + self.linear2(self.activation(self.linear1(x))))
+
+    def forward_after_ffn_pm(self, obj):
+        """:390-400 -> (class_logits [T, L, nc], slot embedding [T, L, C])."""
+        c = r = obj
+        for layer in self.cls_module:
+            c = layer(c)
+        for layer in self.reg_module:
+            r = layer(r)
+        return self.class_logits(c), r
+
+    def forward_pm(self, slots, feat_pm, pos_pm, stage_enable):
+        T, L, C = slots.shape
+        obj = self.forward_till_ffn_pm(slots, feat_pm, pos_pm)
+        if stage_enable:
+            flat = obj.reshape(T * L, C)                                    # concat along the slot axis (:310)
+            obj = (flat + self.temporal_query_head(features=flat, mask_query=flat)).reshape(T, L, C)   # :313-322
+        else:
+            assert self.temporal_query_head is None
+        return self.forward_after_ffn_pm(obj)
+
+    def forward(self, features, mask_query, pad_mask, pos=None, query_pos=None, gt_non_void_mask=None,
+                stage_enable=True):
+        """Reference signature: lists over frames of [1, C, H, W] / [1, L, C]."""
+        assert pad_mask is None and query_pos is None and gt_non_void_mask is None
+        T = len(features)
+        _, c, h, w = features[0].shape
+        feat_pm = torch.cat(features, 0).permute(0, 2, 3, 1).reshape(T, h * w, c).to(BF16).contiguous()
+        pos_pm = pos[0][0].permute(1, 2, 0).reshape(h * w, c).float().contiguous() if pos is not None else None
+        logits, emb = self.forward_pm(torch.cat(mask_query, 0).float(), feat_pm, pos_pm, stage_enable)
+        return [logits[t:t + 1] for t in range(T)], [emb[t:t + 1] for t in range(T)], None, None
+
+
+@HEADS.register_module
+class MultiScaleDynamicMaskHead(nn.Module):
+    """:36-229. Constructor arguments, attribute names and the forward contract follow the reference."""
+
+    def __init__(self, dh_dim=256, num_classes=9, dim_feedforward=2048, nhead=8, dropout=0.0, activation="relu",
+                 dh_num_heads=8, per_dh_num_heads=2, feat_num_levels=4, merge_operation="add", trans_in_dim=128,
+                 return_intermediate=True, use_focal=True, prior_prob=0.01, num_cls=1, num_reg=3,
+                 softmax_dim="slots", drop_path=0., temporal_query_attention_config=None,
+                 apply_temporal_query_atten_stages=None, other_config=None):
+        super().__init__()
+        if not isinstance(per_dh_num_heads, (list, tuple)):
+            assert per_dh_num_heads * feat_num_levels == dh_num_heads
+            per_dh_num_heads = [per_dh_num_heads] * feat_num_levels
+        else:
+            assert sum(per_dh_num_heads) == dh_num_heads
+        if merge_operation != "concat":
+            raise NotImplementedError("the released configs use merge_operation='concat'")
+        self.per_dh_num_heads = list(per_dh_num_heads)
+        self.dh_dim = dh_dim
+        self.trans_in_dim = trans_in_dim
+        self.apply_temporal_query_atten_stages = apply_temporal_query_atten_stages
+        self.other_config = other_config
+
+        def make_stage(temporal_cfg):
+            return MaskRCNNHead(d_model=dh_dim, num_classes=num_classes, dim_feedforward=dim_feedforward,
+                                nhead=nhead, dropout=dropout, activation=activation, num_cls=num_cls,
+                                num_reg=num_reg, softmax_dim=softmax_dim, drop_path=drop_path,
+                                temporal_query_attention_config=temporal_cfg)
+        stage_idx = 0
+        for i in range(feat_num_levels):
+            # a level gets the temporal sub-head iff its FIRST stage index is a temporal stage (:83-106)
+            temporal = (apply_temporal_query_atten_stages is None
+                        or stage_idx in apply_temporal_query_atten_stages)
+            proto = make_stage(temporal_query_attention_config if temporal else None)
+            setattr(self, f"head_series_{i}", _get_clones(proto, self.per_dh_num_heads[i]))
+            stage_idx += self.per_dh_num_heads[i]
+        self.conv_trans = ConvModule(trans_in_dim, dh_dim, 1, padding=0, activation=None)
+        self.return_intermediate = return_intermediate
+        self.feat_num_levels = feat_num_levels
+        self.merge_operation = merge_operation
+        self.use_focal = use_focal
+        self.num_classes = num_classes
+        if use_focal:
+            self.prior_prob = prior_prob
+            self.bias_value = -math.log((1 - prior_prob) / prior_prob)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():                      # :127-136
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+            if self.use_focal and p.shape[-1] == self.num_classes:
+                nn.init.constant_(p, self.bias_value)
+
+    # ------------------------------------------------------------------------------------------
+    def fuse_level(self, i, cur, prev):
+        """:172-188. cur [T, 128, H, W], prev [T, 256, H/2, W/2] bf16 or None -> fused [T, 256, H, W]
+        bf16 in channels_last memory (so its pixel-major [T, HW, 256] view is free)."""
+        x = cur.to(BF16)
+        if i == 0:
+            cat = torch.cat((x, x, x), dim=1)
+        else:
+            up = F.interpolate(prev, None, 2, mode="bilinear", align_corners=False)
+            cat = torch.cat((up, x), dim=1)
+        conv = self.conv_trans.conv
+        return F.conv2d(cat.contiguous(memory_format=torch.channels_last), conv.weight.to(BF16), conv.bias.to(BF16))
+
+    def forward_clip(self, feats, init_slots, pos_pm):
+        """Batched clip entry.
+        feats: list over the 4 levels (coarse -> fine) of [T, 128, Hi, Wi]; init_slots [L, 256];
+        pos_pm: list of [Hi*Wi, 256] fp32 pixel-major sine embeddings.
+        Returns logits [S, T, L, nc], embeds [S, T, L, 256], fused list of [T, Hi*Wi, 256] bf16."""
+        if not feats[0].is_cuda:
+            raise RuntimeError("MultiScaleDynamicMaskHead runs on the GPU only; there is no CPU fallback")
+        T = feats[0].shape[0]
+        slots = init_slots.float().unsqueeze(0).expand(T, -1, -1).contiguous()
+        all_logits, all_embeds, fused = [], [], []
+        prev = None
+        stage_idx = 0
+        for i in range(self.feat_num_levels):
+            y = self.fuse_level(i, feats[i], prev)
+            _, c, h, w = y.shape
+            f_pm = y.permute(0, 2, 3, 1).reshape(T, h * w, c)
+            if not f_pm.is_contiguous():
+                f_pm = f_pm.contiguous()
+            for stage in getattr(self, f"head_series_{i}"):
+                enable = stage_idx in self.apply_temporal_query_atten_stages
+                logits, slots = stage.forward_pm(slots, f_pm, pos_pm[i], enable)
+                slots = slots.detach()
+                all_logits.append(logits)
+                all_embeds.append(slots)
+                stage_idx += 1
+            prev = y
+            fused.append(f_pm)
+        return torch.stack(all_logits), torch.stack(all_embeds), fused
+
+    def forward(self, features, init_masks, pad_mask, pos=None, query_pos=None, gt_non_void_mask=None):
+        """Reference contract (:138-228): features[t][i] [1, 128, Hi, Wi], init_masks[t] [L, 256] (replaced
+        in place by their batched [1, L, 256] form like the reference does, :152), pos[t][i] [1, 256, Hi, Wi].
+        Returns ([T x [S, 1, L, nc]], [T x [S, 1, L, 256]], [T][4] fused maps [1, 256, Hi, Wi])."""
+        assert pad_mask is None and query_pos is None and gt_non_void_mask is None
+        T, nlev = len(features), len(features[0])
+        assert features[0][0].shape[0] == 1, "batch size 1 per frame (vps_temporal_slots.py:483-484)"
+        feats = [torch.cat([features[t][i] for t in range(T)], 0) for i in range(nlev)]
+        pos_pm = [pos[0][i][0].permute(1, 2, 0).reshape(-1, self.dh_dim).float().contiguous() for i in range(nlev)]
+        init = init_masks[0]
+        for t in range(T):
+            init_masks[t] = init_masks[t][None]
+        logits, embeds, fused = self.forward_clip(feats, init, pos_pm)
+        ret_feats = []
+        for t in range(T):
+            per = []
+            for i in range(nlev):
+                _, _, h, w = feats[i].shape
+                per.append(fused[i][t].view(h, w, -1).permute(2, 0, 1).unsqueeze(0))
+            ret_feats.append(per)
+        if self.return_intermediate:
+            return ([logits[:, t:t + 1] for t in range(T)], [embeds[:, t:t + 1] for t in range(T)], ret_feats)
+        return [logits[-1, t:t + 1][None] for t in range(T)], [embeds[-1, t:t + 1][None] for t in range(T)], None
+
+
+def fold_bn_eval(bn):
+    """Eval-mode BatchNorm -> (scale, shift) fp32 vectors."""
+    scale = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+    return scale.contiguous(), (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
+
+
+def generate_final_outputs(feat_pm, slot_embed, feat_bn, fg_bn, want_argmax=False):
+    """K2 wrapper with the semantics of VPS_Temporal_Slots.generate_final_outputs(aux=False)
+    (vps_temporal_slots.py:144-160): feat_pm [T, HW, 256] bf16 finest fused map, slot_embed
+    [T, L, 256] last-stage embeddings -> mask logits [T, L, HW] fp32 (+ uint8 slot argmax [T, HW])."""
+    scale, shift = fold_bn_eval(feat_bn)
+    fs, fb = fold_bn_eval(fg_bn)
+    return ops.mask_decode(feat_pm, slot_embed.float().contiguous(), scale, shift, float(fs.item()), float(fb.item()),
+                           want_argmax=want_argmax)
