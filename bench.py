@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native Slot-VPS hot path (slot-retriever decode loop + mask decode).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic clip per rank: T=5 frames of
+1024x2048 -> four levels of 128-channel FPN feature maps (32x64 ... 256x512, resident in HBM) ->
+the 7-stage multi-scale slot head (K1 once per stage for all T frames) -> slot->mask decode of all
+T frames (K2). Weights: the R50-FPN Slot-VPS head architecture with seeded synthetic values
+(no checkpoints exist, README.md:25 of the reference). Clips are independent, so ranks share nothing
+(weak scaling); the per-clip results (uint8 slot-argmax maps + class logits) are gathered to rank 0
+over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions):
+  value            frames/s, whole job            = n_gpus * steps * T / max-over-ranks wall time
+  roofline         K1 (slot_attn_partial_*): algorithmic bytes (k and v read once + q + out) of all K1
+                   launches of the timed steps / their summed device time from HIP events recorded on
+                   the launch stream, against the 8 TB/s HBM3E peak
+  cpu_baseline     the CPU oracle (NumPy port of the reference) on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=5, help="T, frames per clip")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--slots", type=int, default=100)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--fast-p", action="store_true", help="bf16 P without the hi/lo split inside K1")
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="0 to skip the CPU oracle leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(a):
+    """Time the CPU oracle (NumPy restatement of the reference, fp32) on a bounded sample of the same
+    workload: single frames (T=1) of the 1024x2048 head + decode, repeated until ~cpu_seconds."""
+    import numpy as np
+    from oracle import slotvps_oracle as orc
+    from slotvps_amd import synth
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    params = synth.make_params(synth.head_shapes(), 0)
+    sizes = synth.level_sizes(a.height, a.width)
+    pos = [orc.pos_embed_sine(h, w) for (h, w) in sizes]
+    rng = np.random.default_rng(1)
+    feats = [[rng.standard_normal((128, h, w)).astype(np.float32) for (h, w) in sizes]]
+    slots = synth.make_slots(1, a.slots)
+    scale, shift = orc.bn_eval_affine(np.ones(256, np.float32), np.zeros(256, np.float32),
+                                      np.zeros(256, np.float32), np.ones(256, np.float32))
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        _, embeds, fused = orc.head_forward(feats, slots, pos, params)
+        m = orc.mask_decode(fused[0][3], embeds[0][-1], scale, shift, np.float32(0.1), np.float32(0.0))
+        orc.slot_argmax(m)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el >= a.cpu_seconds or frames >= 8:
+            break
+    return {"value": round(frames / el, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
+            "sample": f"{frames} single-frame clip(s) (T=1) of the same {a.height}x{a.width} L={a.slots} head + "
+                      f"mask decode, fp32 NumPy oracle, {el:.1f} s wall"}
+
+
+def main():
+    a = parse()
+    from slotvps_amd import _lib, ops, parallel
+    from slotvps_amd.clip import SlotClipRunner
+
+    rank, local_rank, world = parallel.init_distributed()
+    if world != a.gpus and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    _lib.load()
+
+    T = a.frames
+    runner = SlotClipRunner(dev, T, a.height, a.width, L=a.slots, param_seed=0, split_p=not a.fast_p,
+                            use_graph=not a.no_graph)
+    HWf = runner.sizes[-1][0] * runner.sizes[-1][1]
+    # distinct synthetic clips per rank and step (resident in HBM before the timed region)
+    n_pool = 2
+    pool = [runner.random_clip(1234 + rank * 1000 + i) for i in range(n_pool)]
+    results = torch.empty((a.steps, T, HWf), dtype=torch.uint8, device=dev)
+
+    def step(i, record):
+        runner.load_clip(pool[i % n_pool])
+        out = runner.run()
+        if record:
+            results[i].copy_(out["slot_argmax"])
+
+    for i in range(a.warmup):
+        step(i, False)
+    torch.cuda.synchronize(dev)
+
+    # ---------------------------------- timed region -------------------------------------------
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, True)
+    gathered = parallel.gather_to_rank0(results)            # RCCL gather of the per-clip results
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+    if rank == 0:
+        assert len(gathered) == world and gathered[0].shape == results.shape
+
+    # ------------------- roofline leg: same steps, eager, HIP events around every launch --------------
+    roof = None
+    if rank == 0:
+        eager = runner.use_graph
+        runner.use_graph = False
+        for i in range(2):
+            step(i, False)
+        torch.cuda.synchronize(dev)
+        with ops.KernelTimer() as kt:
+            for i in range(a.steps):
+                step(i, False)
+            torch.cuda.synchronize(dev)
+            k1_ms, k1_n = kt.collect(_lib.KERNEL_SLOT_ATTN)
+            fin_ms, fin_n = kt.collect(_lib.KERNEL_SLOT_ATTN_FINISH)
+            k2_ms, k2_n = kt.collect(_lib.KERNEL_MASK_DECODE)
+        runner.use_graph = eager
+        alg = runner.k1_algorithmic_bytes_per_step() * a.steps
+        achieved = alg / (k1_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "slot_attn_partial_ws", "launches": k1_n, "avg_launch_us": round(k1_ms / k1_n * 1e3, 2),
+                "algorithmic_bytes_per_launch_avg": int(alg / k1_n),
+                "other_kernels_us_per_step": {"slot_attn_finish": round(fin_ms / a.steps * 1e3, 1),
+                                              "mask_decode": round(k2_ms / a.steps * 1e3, 1)}}
+
+    if rank == 0:
+        frames = world * a.steps * T
+        line = {
+            "metric": "frames/sec (whole node), 1024x2048 T=5 clip, R50-FPN Slot-VPS inference",
+            "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"slot-retriever decode hot path: R50-FPN Slot-VPS head (7 stages over 4 FPN "
+                                   f"levels) + slot->mask decode, {a.height}x{a.width} T={T} clip, {a.slots} slots, "
+                                   f"synthetic FPN features resident in HBM; backbone/FPN not in the step",
+                       "clip_frames": T, "slots": a.slots, "levels": [list(s) for s in runner.sizes],
+                       "parallelism": f"clip-parallel x{world}", "hipgraph": not a.no_graph,
+                       "k1_split_p": not a.fast_p},
+            "roofline": roof,
+        }
+        if a.cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

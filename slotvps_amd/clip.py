@@ -1,0 +1,110 @@
+"""Clip driver of the hot path: T frames of FPN feature maps -> slot head (K1 per stage) -> mask
+decode (K2), with the launch-bound slot-side operators captured in a hipGraph.
+
+The reference's detector runs [ref_frame, cur_frame] pairs (T = 2, vps_temporal_slots.py:283-291) and
+decodes the current frame only (:297-299); the head itself is generic in T (dynamic_mask_head.py:143-164).
+This driver feeds a whole T-frame clip through the head at once and decodes every frame.
+"""
+import torch
+from torch import nn
+
+from . import ops, synth
+from .slot_head import MultiScaleDynamicMaskHead, fold_bn_eval
+
+
+def build_r50_head(cfg=None):
+    cfg = cfg or synth.R50_HEAD_CFG
+    return MultiScaleDynamicMaskHead(
+        dh_dim=cfg["dh_dim"], num_classes=cfg["num_classes"], dim_feedforward=cfg["dim_feedforward"],
+        nhead=cfg["nhead"], dropout=0.0, activation=cfg["activation"], dh_num_heads=sum(cfg["per_dh_num_heads"]),
+        per_dh_num_heads=list(cfg["per_dh_num_heads"]), feat_num_levels=cfg["feat_num_levels"],
+        merge_operation="concat", trans_in_dim=cfg["trans_in_dim"], num_cls=cfg["num_cls"], num_reg=cfg["num_reg"],
+        temporal_query_attention_config=dict(d_model=cfg["dh_dim"], dim_feedforward=cfg["temporal_dim_feedforward"],
+                                             dropout=0.0, activation=cfg["temporal_activation"],
+                                             softmax_dim="slots", drop_path=0.),
+        apply_temporal_query_atten_stages=list(cfg["apply_temporal_query_atten_stages"]))
+
+
+class SlotClipRunner:
+    """Owns a head replica, the slot initialisation, the decode BatchNorms and (optionally) a captured
+    hipGraph of one clip step. All tensors live on `device`."""
+
+    def __init__(self, device, T, H, W, L=100, param_seed=0, cfg=None, split_p=True, use_graph=True):
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("SlotClipRunner runs on the GPU only; there is no CPU fallback")
+        self.device = torch.device(device)
+        self.T, self.H, self.W, self.L = T, H, W, L
+        self.cfg = cfg or synth.R50_HEAD_CFG
+        self.sizes = synth.level_sizes(H, W)
+        params = synth.make_params(synth.head_shapes(self.cfg), param_seed)
+        self.head = build_r50_head(self.cfg)
+        sd = self.head.state_dict()
+        self.head.load_state_dict({k: torch.from_numpy(v).reshape(sd[k].shape) for k, v in params.items()}, strict=True)
+        self.head.to(self.device).eval()
+        for m in self.head.modules():
+            if hasattr(m, "split_p"):
+                m.split_p = split_p
+        self.init_slots = torch.from_numpy(synth.make_slots(param_seed + 1, L)).to(self.device)
+        # decode BatchNorms at the reference's initial values (vps_capsule.py:129-133): fg_bn weight 0.1
+        self.feat_bn = nn.BatchNorm2d(self.cfg["dh_dim"]).to(self.device).eval()
+        self.fg_bn = nn.BatchNorm2d(1).to(self.device).eval()
+        with torch.no_grad():
+            self.fg_bn.weight.fill_(0.1)
+            self.fg_bn.bias.zero_()
+        self.refold()
+        self.pos_pm = [ops.pos_embed_sine(h, w, self.cfg["dh_dim"], self.device) for (h, w) in self.sizes]
+        self.static_feats = [torch.zeros((T, 128, h, w), device=self.device) for (h, w) in self.sizes]
+        self.use_graph = use_graph
+        self.graph = None
+        self.out = None
+
+    def refold(self):
+        """Fold the eval BatchNorms into the scalars / vectors K2 takes (host floats: no sync per step)."""
+        with torch.no_grad():
+            self.bn_scale, self.bn_shift = fold_bn_eval(self.feat_bn)
+            fs, fb = fold_bn_eval(self.fg_bn)
+            self.fg_scale, self.fg_shift = float(fs.item()), float(fb.item())
+
+    def _step(self):
+        logits, embeds, fused = self.head.forward_clip(self.static_feats, self.init_slots, self.pos_pm)
+        masks, amax = ops.mask_decode(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift,
+                                      self.fg_scale, self.fg_shift, want_argmax=True)
+        return dict(class_logits=logits, slot_embeds=embeds, mask_logits=masks, slot_argmax=amax)
+
+    def load_clip(self, feats):
+        for dst, src in zip(self.static_feats, feats):
+            dst.copy_(src)
+
+    @torch.no_grad()
+    def run(self):
+        """One clip step on the clip currently in the static input buffers."""
+        if not self.use_graph:
+            self.out = self._step()
+            return self.out
+        if self.graph is None:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):                      # warm-up: lazy inits, kernel attributes, allocator
+                    self._step()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._step()
+        self.graph.replay()
+        return self.out
+
+    def random_clip(self, seed):
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        return [torch.randn((self.T, 128, h, w), generator=g, device=self.device) for (h, w) in self.sizes]
+
+    # ---- algorithmic accounting ------------------------------------------------
+    def k1_launch_shapes(self):
+        """[(HW, launches per step)] of K1: one launch per stage covering all T frames."""
+        return [(h * w, n) for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"])]
+
+    def k1_algorithmic_bytes_per_step(self):
+        """k and v read exactly once + q in + out, bf16 / fp32 as stored: 2*HW*D*2 + L*D*(2+4) per frame-stage."""
+        D = self.cfg["dh_dim"]
+        return sum(n * self.T * (2 * hw * D * 2 + self.L * D * (2 + 4)) for hw, n in self.k1_launch_shapes())

@@ -1,122 +1,4 @@
-"""Deterministic synthetic parameters and inputs for the slot head (shared by tools/make_golden.py,
-the tests, bench.py and smoke()). Everything derives from NumPy Generators with fixed seeds, so a
-golden fixture only has to carry the seeds and the reference's outputs.
-
-Parameter names and shapes follow the reference's state_dict for MultiScaleDynamicMaskHead
-(SURVEY.md 8b 'Checkpoint key contract'); values are deliberately non-trivial (LayerNorm affines
-away from (1, 0), non-zero biases) so that every term of every formula is exercised.
-"""
-import numpy as np
-
-D = 256
-R50_HEAD_CFG = dict(dh_dim=256, num_classes=20, dim_feedforward=2048, nhead=8, activation="gelu",
-                    per_dh_num_heads=[1, 2, 2, 2], feat_num_levels=4, trans_in_dim=384, num_cls=2, num_reg=2,
-                    temporal_dim_feedforward=1024, temporal_activation="relu",
-                    apply_temporal_query_atten_stages=[3, 4, 5, 6])
-
-
-def retriever_shapes(prefix):
-    s = {}
-    for n in ("to_q", "to_k", "to_v"):
-        s[f"{prefix}{n}.weight"] = (D, D)
-        s[f"{prefix}{n}.bias"] = (D,)
-    for n in ("norm_q", "norm_k", "norm_v", "norm1"):
-        s[f"{prefix}{n}.weight"] = (D,)
-        s[f"{prefix}{n}.bias"] = (D,)
-    return s
-
-
-def temporal_shapes(prefix, ff):
-    s = retriever_shapes(prefix + "inst_interact.")
-    s[prefix + "linear1.weight"] = (ff, D)
-    s[prefix + "linear1.bias"] = (ff,)
-    s[prefix + "linear2.weight"] = (D, ff)
-    s[prefix + "linear2.bias"] = (D,)
-    for n in ("norm1", "norm2", "norm3"):
-        s[f"{prefix}{n}.weight"] = (D,)
-        s[f"{prefix}{n}.bias"] = (D,)
-    return s
-
-
-def stage_shapes(prefix, cfg, temporal):
-    ff, nc = cfg["dim_feedforward"], cfg["num_classes"]
-    s = {
-        prefix + "self_attn.in_proj_weight": (3 * D, D),
-        prefix + "self_attn.in_proj_bias": (3 * D,),
-        prefix + "self_attn.out_proj.weight": (D, D),
-        prefix + "self_attn.out_proj.bias": (D,),
-        prefix + "linear1.weight": (ff, D),
-        prefix + "linear1.bias": (ff,),
-        prefix + "linear2.weight": (D, ff),
-        prefix + "linear2.bias": (D,),
-        prefix + "class_logits.weight": (nc, D),
-        prefix + "class_logits.bias": (nc,),
-    }
-    s.update(retriever_shapes(prefix + "inst_interact."))
-    for n in ("norm1", "norm2", "norm3"):
-        s[f"{prefix}{n}.weight"] = (D,)
-        s[f"{prefix}{n}.bias"] = (D,)
-    for tower, cnt in (("cls_module", cfg["num_cls"]), ("reg_module", cfg["num_reg"])):
-        for i in range(cnt):
-            s[f"{prefix}{tower}.{3 * i}.weight"] = (D, D)
-            s[f"{prefix}{tower}.{3 * i + 1}.weight"] = (D,)
-            s[f"{prefix}{tower}.{3 * i + 1}.bias"] = (D,)
-    if temporal:
-        s.update(temporal_shapes(prefix + "temporal_query_head.", cfg["temporal_dim_feedforward"]))
-    return s
-
-
-def head_shapes(cfg=None):
-    cfg = cfg or R50_HEAD_CFG
-    s = {"conv_trans.conv.weight": (D, cfg["trans_in_dim"], 1, 1), "conv_trans.conv.bias": (D,)}
-    idx = 0
-    for lvl, n in enumerate(cfg["per_dh_num_heads"]):
-        # the reference attaches the temporal sub-head to every stage of a level whose FIRST stage
-        # index is a temporal stage (dynamic_mask_head.py:83-106)
-        temporal = idx in cfg["apply_temporal_query_atten_stages"]
-        for j in range(n):
-            s.update(stage_shapes(f"head_series_{lvl}.{j}.", cfg, temporal))
-        idx += n
-    return s
-
-
-def make_params(shapes, seed):
-    """name -> float32 array. Matrices xavier-uniform, LayerNorm weights U(0.5, 1.5), biases N(0, 0.1)."""
-    rng = np.random.default_rng(seed)
-    out = {}
-    for name in sorted(shapes):
-        shp = shapes[name]
-        if len(shp) >= 2:
-            fan_out, fan_in = shp[0], int(np.prod(shp[1:]))
-            a = np.sqrt(6.0 / (fan_in + fan_out))
-            out[name] = rng.uniform(-a, a, shp).astype(np.float32)
-        elif name.endswith("weight"):          # LayerNorm scale
-            out[name] = rng.uniform(0.5, 1.5, shp).astype(np.float32)
-        else:
-            out[name] = (0.1 * rng.standard_normal(shp)).astype(np.float32)
-    return out
-
-
-def level_sizes(H, W, nlev=4):
-    """Coarse -> fine feature sizes for an image of H x W padded to /32 (strides 32, 16, 8, 4)."""
-    assert H % 32 == 0 and W % 32 == 0
-    return [(H // s, W // s) for s in (32, 16, 8, 4)][:nlev]
-
-
-def smooth_features(rng, C, h, w):
-    """[C, h, w] float32 with image-like spatial correlation: bilinear-ish blend of coarse noise + detail."""
-    ch, cw = max(h // 4, 1), max(w // 4, 1)
-    coarse = rng.standard_normal((C, ch, cw)).astype(np.float32)
-    up = np.repeat(np.repeat(coarse, -(-h // ch), axis=1), -(-w // cw), axis=2)[:, :h, :w]
-    return (0.8 * up + 0.6 * rng.standard_normal((C, h, w)).astype(np.float32)).astype(np.float32)
-
-
-def make_clip_features(seed, T, H, W, C=128):
-    """features[t][lvl] : [C, Hi, Wi] float32, coarse -> fine (the conv_trans'ed UPSNetFPN maps)."""
-    rng = np.random.default_rng(seed)
-    return [[smooth_features(rng, C, h, w) for (h, w) in level_sizes(H, W)] for _ in range(T)]
-
-
-def make_slots(seed, L):
-    rng = np.random.default_rng(seed)
-    return rng.standard_normal((L, D)).astype(np.float32)
+"""Re-export of the deterministic synthetic-workload helpers (they live in the package so that
+bench.py, smoke() and tools/ share them)."""
+from slotvps_amd.synth import *  # noqa: F401,F403
+from slotvps_amd.synth import R50_HEAD_CFG, D  # noqa: F401
