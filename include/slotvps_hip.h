@@ -102,6 +102,24 @@ int svps_mask_decode_fwd(const void* feat, const float* embed, const float* bn_s
  *   channels [0, D/2) encode y, [D/2, D) encode x, sin on even / cos on odd channels.
  * ------------------------------------------------------------------------------------------- */
 int svps_pos_embed_sine(float* out, int H, int W, int D, void* stream);
+/* The same embedding in its separable form: ytab [H, D/2] (channels [0, D/2) of row y), xtab [W, D/2]
+ * (channels [D/2, D) of column x); pos[h*W + w] = concat(ytab[h], xtab[w]) exactly. */
+int svps_pos_embed_sine_tables(float* ytab, float* xtab, int H, int W, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3 key / value producer of K1: the pixel-side projections of MaskDynamicConv.forward
+ * (mmdet/models/detectors/dynamic_mask_head.py:432-433) for all T frames of a stage:
+ *     k = norm_k(to_k(features + pos))   v = norm_v(to_v(features))
+ *   feat [T, H*W, D] bf16 pixel-major fused level map; pos_y [H, D/2], pos_x [W, D/2] fp32 tables of
+ *   svps_pos_embed_sine_tables (both NULL: no position embedding);
+ *   wk, wv [D, D] bf16 (nn.Linear.weight layout, row = output channel, rounded to bf16 by the caller),
+ *   bk, bv [D] fp32;
+ *   lnk_*, lnv_* the LayerNorm affines and epsilons; k_out, v_out [T, H*W, D] bf16.
+ * ------------------------------------------------------------------------------------------- */
+int svps_kv_project_fwd(const void* feat, const float* pos_y, const float* pos_x, const void* wk,
+                        const float* bk, const float* lnk_w, const float* lnk_b, float lnk_eps,
+                        const void* wv, const float* bv, const float* lnv_w, const float* lnv_b,
+                        float lnv_eps, void* k_out, void* v_out, int T, int H, int W, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Profiling hooks: when enabled every kernel launch of this library is bracketed by HIP events on

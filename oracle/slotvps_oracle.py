@@ -48,38 +48,37 @@ def round_bf16(x):
 class Storage:
     """Which tensors the path keeps in bf16 in HBM. Each hook returns float32/float64 values.
 
-    bf16=False rounds nothing (the reference's fp32 arithmetic). With bf16=True the always-on
-    rounding points are: the fused level map, the operands of the 1x1 fusion conv and of the k/v
-    projections (activations and weight matrices), and the post-LayerNorm q / k / v. ``torch_gemm``
-    additionally models the interim PyTorch producers of the HIP path (a bf16 GEMM rounds its
-    bias and its pre-LayerNorm output to bf16 as well)."""
+    bf16=False rounds nothing (the reference's fp32 arithmetic). With bf16=True the rounding points
+    are: the fused level map, the operands of the 1x1 fusion conv and of the k/v projections
+    (activations and weight matrices), and the post-LayerNorm q / k / v. Biases, accumulation,
+    LayerNorm statistics and everything on the slot side stay fp32. ``torch_conv`` additionally models
+    the interim PyTorch level-fusion conv of the HIP path (a bf16 conv also rounds its bias)."""
 
-    def __init__(self, bf16, torch_gemm=False):
+    def __init__(self, bf16, torch_conv=False):
         self.bf16 = bool(bf16)
-        self.torch_gemm = bool(torch_gemm)
+        self.torch_conv = bool(torch_conv)
 
     @classmethod
     def exact(cls):
         return cls(False)
 
     @classmethod
-    def bf16_policy(cls, torch_gemm=False):
-        return cls(True, torch_gemm)
+    def bf16_policy(cls, torch_conv=False):
+        return cls(True, torch_conv)
 
     def _r(self, x):
         return round_bf16(x).astype(x.dtype) if self.bf16 else x
 
     def _rt(self, x):
-        return round_bf16(x).astype(x.dtype) if (self.bf16 and self.torch_gemm) else x
+        return round_bf16(x).astype(x.dtype) if (self.bf16 and self.torch_conv) else x
 
-    feat = _r      # fused level feature map f (input of the projections, the decode, the next level)
-    conv_in = _r   # concat(upsampled previous level, current 128-ch map): operand of the 1x1 conv
-    proj_in = _r   # f + pos, the k-projection operand
-    weight = _r    # conv / to_k / to_v weight matrices as matrix-core operands
-    kv = _r        # post-LayerNorm k and v
-    q = _r         # post-LayerNorm q
-    bias = _rt     # conv / projection biases (bf16 only in the interim torch GEMMs)
-    pre_ln = _rt   # projection output before LayerNorm (bf16 only in the interim torch GEMMs)
+    feat = _r        # fused level feature map f (input of the projections, the decode, the next level)
+    conv_in = _r     # concat(upsampled previous level, current 128-ch map): operand of the 1x1 conv
+    proj_in = _r     # f + pos, the k-projection operand
+    weight = _r      # conv / to_k / to_v weight matrices as matrix-core operands
+    kv = _r          # post-LayerNorm k and v
+    q = _r           # post-LayerNorm q
+    conv_bias = _rt  # bias of the level-fusion conv (bf16 only in the interim torch conv)
 
 
 # --------------------------------------------------------------------------------------------
@@ -170,10 +169,8 @@ def retriever_project(slots, feat, pos, params, prefix, st, dt):
     g = lambda n: _p(params, prefix, n, dt)
     q = layer_norm(linear(slots, g("to_q.weight"), g("to_q.bias")), g("norm_q.weight"), g("norm_q.bias"))
     kin = st.proj_in(feat + pos) if pos is not None else feat
-    k = layer_norm(st.pre_ln(linear(kin, st.weight(g("to_k.weight")), st.bias(g("to_k.bias")))),
-                   g("norm_k.weight"), g("norm_k.bias"))
-    v = layer_norm(st.pre_ln(linear(feat, st.weight(g("to_v.weight")), st.bias(g("to_v.bias")))),
-                   g("norm_v.weight"), g("norm_v.bias"))
+    k = layer_norm(linear(kin, st.weight(g("to_k.weight")), g("to_k.bias")), g("norm_k.weight"), g("norm_k.bias"))
+    v = layer_norm(linear(feat, st.weight(g("to_v.weight")), g("to_v.bias")), g("norm_v.weight"), g("norm_v.bias"))
     return st.q(q), st.kv(k), st.kv(v)
 
 
@@ -329,7 +326,7 @@ def head_forward(features, init_slots, pos, params, cfg=None, st=None, dt=np.flo
             else:
                 cat = np.concatenate([upsample2x_bilinear(prev[t]), x], axis=0)   # :178-179
             cat = st.conv_in(cat)
-            y = (st.weight(wc) @ cat.reshape(cat.shape[0], H * W) + st.bias(bc)[:, None])   # 1x1 conv :181/:185
+            y = (st.weight(wc) @ cat.reshape(cat.shape[0], H * W) + st.conv_bias(bc)[:, None])   # 1x1 conv :181/:185
             y = st.feat(np.ascontiguousarray(y.T))                           # pixel-major [HW, 256]
             if fused_override is not None:
                 y = np.asarray(fused_override[t][i], dtype=dt)

@@ -31,6 +31,9 @@ SIGNATURES = {
     "svps_slot_attn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_mask_decode_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "svps_pos_embed_sine": (_i, [_vp, _i, _i, _i, _vp]),
+    "svps_pos_embed_sine_tables": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "svps_kv_project_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp,
+                                 _i, _i, _i, _i, _vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

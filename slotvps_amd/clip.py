@@ -52,7 +52,7 @@ class SlotClipRunner:
             self.fg_bn.weight.fill_(0.1)
             self.fg_bn.bias.zero_()
         self.refold()
-        self.pos_pm = [ops.pos_embed_sine(h, w, self.cfg["dh_dim"], self.device) for (h, w) in self.sizes]
+        self.pos_tabs = [ops.pos_embed_sine_tables(h, w, self.cfg["dh_dim"], self.device) for (h, w) in self.sizes]
         self.static_feats = [torch.zeros((T, 128, h, w), device=self.device) for (h, w) in self.sizes]
         self.use_graph = use_graph
         self.graph = None
@@ -66,7 +66,7 @@ class SlotClipRunner:
             self.fg_scale, self.fg_shift = float(fs.item()), float(fb.item())
 
     def _step(self):
-        logits, embeds, fused = self.head.forward_clip(self.static_feats, self.init_slots, self.pos_pm)
+        logits, embeds, fused = self.head.forward_clip(self.static_feats, self.init_slots, self.pos_tabs)
         masks, amax = ops.mask_decode(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift,
                                       self.fg_scale, self.fg_shift, want_argmax=True)
         return dict(class_logits=logits, slot_embeds=embeds, mask_logits=masks, slot_argmax=amax)

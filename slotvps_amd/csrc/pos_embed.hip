@@ -34,7 +34,31 @@ __global__ __launch_bounds__(256) void pos_embed_sine_kernel(float* __restrict__
     }
 }
 
+// The embedding is separable: channels [0, D/2) depend on the row only, [D/2, D) on the column only.
+// tab [n, D/2]: entry (i, c) = sin/cos(((i + 1) / (n + 1e-6) * 2 pi) / 10000^(2 floor(c/2) / (D/2)))
+__global__ __launch_bounds__(256) void pos_embed_table_kernel(float* __restrict__ tab, int n, int half) {
+    const int total = n * half;
+    const float two_pi = 6.283185307179586f;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int cc = idx % half, i = idx / half;
+        const float e = (float)(i + 1) / ((float)n + 1e-6f) * two_pi;
+        const float dim_t = powf(10000.f, 2.f * floorf((float)cc / 2.f) / (float)half);
+        const float a = e / dim_t;
+        tab[idx] = (cc & 1) ? cosf(a) : sinf(a);
+    }
+}
+
 }  // namespace svps
+
+extern "C" int svps_pos_embed_sine_tables(float* ytab, float* xtab, int H, int W, int D, void* stream_) {
+    if (!ytab || !xtab) return SVPS_ERR_BAD_ARG;
+    if (H <= 0 || W <= 0 || D <= 0 || (D & 3)) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int half = D / 2;
+    hipLaunchKernelGGL(svps::pos_embed_table_kernel, dim3((H * half + 255) / 256), dim3(256), 0, stream, ytab, H, half);
+    hipLaunchKernelGGL(svps::pos_embed_table_kernel, dim3((W * half + 255) / 256), dim3(256), 0, stream, xtab, W, half);
+    return (int)hipGetLastError();
+}
 
 extern "C" int svps_pos_embed_sine(float* out, int H, int W, int D, void* stream_) {
     if (!out) return SVPS_ERR_BAD_ARG;

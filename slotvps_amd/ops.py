@@ -104,6 +104,50 @@ def pos_embed_sine(H, W, D=D_MODEL, device="cuda"):
     return out
 
 
+def pos_embed_sine_tables(H, W, D=D_MODEL, device="cuda"):
+    """Separable form of the sine embedding: (ytab [H, D/2], xtab [W, D/2]) fp32."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("pos_embed_sine_tables runs on the GPU only; there is no CPU fallback")
+    ytab = torch.empty((H, D // 2), dtype=torch.float32, device=dev)
+    xtab = torch.empty((W, D // 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.svps_pos_embed_sine_tables(_ptr(ytab), _ptr(xtab), H, W, D, _stream_ptr()),
+                   "svps_pos_embed_sine_tables")
+    return ytab, xtab
+
+
+def kv_project(feat, H, W, pos_tabs, wk, bk, lnk_w, lnk_b, lnk_eps, wv, bv, lnv_w, lnv_b, lnv_eps):
+    """K3: k = bf16(LN_k(W_k bf16(feat + pos) + b_k)), v = bf16(LN_v(W_v feat + b_v)) for all frames.
+    feat [T, H*W, 256] bf16; pos_tabs = (ytab, xtab) or None; wk / wv bf16 [256, 256]; biases and
+    LayerNorm affines fp32.
+    (MaskDynamicConv.forward lines 432-433 of the reference's dynamic_mask_head.py.)"""
+    lib = _lib.load()
+    _need(feat, "feat", torch.bfloat16, 3)
+    T, HW, D = feat.shape
+    if HW != H * W:
+        raise ValueError("feat rows != H*W")
+    for name, x in (("wk", wk), ("wv", wv)):
+        _need(x, name, torch.bfloat16, 2)
+    for name, x in (("bk", bk), ("lnk_w", lnk_w), ("lnk_b", lnk_b), ("bv", bv), ("lnv_w", lnv_w), ("lnv_b", lnv_b)):
+        _need(x, name, torch.float32, 1)
+    ytab = xtab = None
+    if pos_tabs is not None:
+        ytab, xtab = pos_tabs
+        _need(ytab, "pos_y", torch.float32, 2)
+        _need(xtab, "pos_x", torch.float32, 2)
+        if ytab.shape != (H, D // 2) or xtab.shape != (W, D // 2):
+            raise ValueError("pos tables do not match (H, W)")
+    k = torch.empty_like(feat)
+    v = torch.empty_like(feat)
+    rc = lib.svps_kv_project_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(wk), _ptr(bk), _ptr(lnk_w), _ptr(lnk_b),
+                                 float(lnk_eps), _ptr(wv), _ptr(bv), _ptr(lnv_w), _ptr(lnv_b), float(lnv_eps),
+                                 _ptr(k), _ptr(v), T, H, W, D, _stream_ptr())
+    _lib.check(rc, "svps_kv_project_fwd")
+    return k, v
+
+
 class KernelTimer:
     """Device-time accounting of the library's own launches (HIP events on the launch stream)."""
 

@@ -5,10 +5,11 @@ the whole clip is processed as one batch and the slot<->pixel retriever runs on 
 What runs where
   * K1 (HIP, libslotvps_hip.so): logits, softmax over slots, attn.v, LayerNorm, ReLU for all T frames
     of a stage in one launch (MaskDynamicConv.forward lines 435-459).
-  * PyTorch-ROCm (plumbing around the kernel, same math as the reference lines cited inline): the
-    level fusion (bilinear x2, concat, 1x1 conv), the k/v projections + LayerNorm that produce K1's
-    bf16 inputs, and the slot-side operators on [T, L, 256] tensors (self-attention, FFN, temporal
-    head, towers).
+  * K3 (HIP): the pixel-side projections k = norm_k(to_k(f + pos)), v = norm_v(to_v(f)) (:432-433)
+    for all T frames, written as the bf16 tensors K1 streams.
+  * PyTorch-ROCm (plumbing around the kernels, same math as the reference lines cited inline): the
+    level fusion (bilinear x2, concat, 1x1 conv) and the slot-side operators on [T, L, 256] tensors
+    (self-attention, FFN, temporal head, towers).
 There is no CPU path: modules raise if their tensors are not on a GPU.
 
 Storage policy (what is rounded to bf16 in HBM): the fused level map f, the projection operand f+pos,
@@ -55,12 +56,6 @@ class ConvModule(nn.Module):
         return self.conv(x)
 
 
-def _project_ln(x_bf16, lin, norm):
-    """bf16(LayerNorm(x W^T + b)) for pixel rows: the k / v producers of K1 (:432-433)."""
-    y = F.linear(x_bf16, lin.weight.to(BF16), lin.bias.to(BF16))
-    return F.layer_norm(y.float(), (y.shape[-1],), norm.weight, norm.bias, norm.eps).to(BF16)
-
-
 class MaskDynamicConv(nn.Module):
     """Retriever of the Panoptic Retriever (:403-461). forward keeps the reference signature
     (pro_features [N, L, C], features [N, C, H, W], pos [N, C, H, W]); ``forward_pm`` is the batched
@@ -82,26 +77,48 @@ class MaskDynamicConv(nn.Module):
         self.activation = nn.ReLU(inplace=True)
         self.split_p = True     # carry softmax probabilities as bf16 hi+lo inside K1
 
-    def project_kv(self, feat_pm, pos_pm):
-        """feat_pm [T, HW, C] bf16, pos_pm [HW, C] fp32 or None -> k, v [T, HW, C] bf16."""
-        kin = feat_pm if pos_pm is None else (feat_pm.float() + pos_pm).to(BF16)
-        return _project_ln(kin, self.to_k, self.norm_k), _project_ln(feat_pm, self.to_v, self.norm_v)
+    def _bf16_weights(self):
+        """to_k / to_v weight matrices rounded to bf16 once (re-derived if the parameters change)."""
+        key = (self.to_k.weight._version, self.to_v.weight._version, self.to_k.weight.data_ptr())
+        if getattr(self, "_wcache_key", None) != key:
+            self._wcache = (self.to_k.weight.detach().to(BF16).contiguous(),
+                            self.to_v.weight.detach().to(BF16).contiguous())
+            self._wcache_key = key
+        return self._wcache
 
-    def forward_pm(self, slots, feat_pm, pos_pm, kv=None):
-        """slots [T, L, C] fp32, feat_pm [T, HW, C] bf16 -> [T, L, C] fp32."""
+    def project_kv(self, feat_pm, hw, pos_tabs):
+        """K3: feat_pm [T, H*W, C] bf16, hw = (H, W), pos_tabs = (ytab, xtab) or None -> k, v bf16."""
+        wk, wv = self._bf16_weights()
+        return ops.kv_project(feat_pm, hw[0], hw[1], pos_tabs, wk, self.to_k.bias, self.norm_k.weight,
+                              self.norm_k.bias, self.norm_k.eps, wv, self.to_v.bias, self.norm_v.weight,
+                              self.norm_v.bias, self.norm_v.eps)
+
+    def forward_pm(self, slots, feat_pm, hw, pos_tabs):
+        """slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16 -> [T, L, C] fp32 (K3 then K1)."""
         q = self.norm_q(self.to_q(slots)).to(BF16).contiguous()
-        k, v = kv if kv is not None else self.project_kv(feat_pm, pos_pm)
-        return ops.slot_attn(q, k.contiguous(), v.contiguous(), self.norm1.weight, self.norm1.bias,
-                             eps=self.norm1.eps, split_p=self.split_p)
+        k, v = self.project_kv(feat_pm, hw, pos_tabs)
+        return ops.slot_attn(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps, split_p=self.split_p)
 
     def forward(self, pro_features, features, pos, gt_non_void_mask=None):
         assert gt_non_void_mask is None
         n, c, h, w = features.shape
         feat_pm = features.permute(0, 2, 3, 1).reshape(n, h * w, c).to(BF16).contiguous()
-        pos_pm = None
-        if pos is not None:
-            pos_pm = pos[0].permute(1, 2, 0).reshape(h * w, c).float().contiguous()
-        return self.forward_pm(pro_features.float(), feat_pm, pos_pm)
+        return self.forward_pm(pro_features.float(), feat_pm, (h, w), pos_tables_from_map(pos))
+
+
+def pos_tables_from_map(pos):
+    """[N, C, H, W] position map -> the separable (ytab [H, C/2], xtab [W, C/2]) K3 consumes. The sine
+    embedding is separable by construction (position_encoding.py:251-255); anything else is refused."""
+    if pos is None:
+        return None
+    p = pos[0].float()
+    half = p.shape[0] // 2
+    ytab = p[:half, :, 0].t().contiguous()
+    xtab = p[half:, 0, :].t().contiguous()
+    if not (torch.equal(p[:half], ytab.t()[:, :, None].expand_as(p[:half]))
+            and torch.equal(p[half:], xtab.t()[:, None, :].expand_as(p[half:]))):
+        raise NotImplementedError("only separable (sine) position embeddings are supported by the HIP path")
+    return ytab, xtab
 
 
 class SlotsDynamicConv(nn.Module):
@@ -191,12 +208,12 @@ class MaskRCNNHead(nn.Module):
         self.class_logits = nn.Linear(d_model, num_classes)
         self.scale_clamp = scale_clamp
 
-    def forward_till_ffn_pm(self, slots, feat_pm, pos_pm):
+    def forward_till_ffn_pm(self, slots, feat_pm, hw, pos_tabs):
         """:342-388 for all frames at once. slots [T, L, C] fp32."""
         x = slots.transpose(0, 1)                                           # [L, T, C]: sequence-first, frames = batch
         x = self.norm1(x + self.self_attn(x, x, value=x, key_padding_mask=None, need_weights=False)[0])
         x = x.transpose(0, 1)
-        x = self.norm2(x + self.inst_interact.forward_pm(x.contiguous(), feat_pm, pos_pm))
+        x = self.norm2(x + self.inst_interact.forward_pm(x.contiguous(), feat_pm, hw, pos_tabs))
         return self.norm3(x + self.linear2(self.activation(self.linear1(x))))
 
     def forward_after_ffn_pm(self, obj):
@@ -208,9 +225,9 @@ class MaskRCNNHead(nn.Module):
             r = layer(r)
         return self.class_logits(c), r
 
-    def forward_pm(self, slots, feat_pm, pos_pm, stage_enable):
+    def forward_pm(self, slots, feat_pm, hw, pos_tabs, stage_enable):
         T, L, C = slots.shape
-        obj = self.forward_till_ffn_pm(slots, feat_pm, pos_pm)
+        obj = self.forward_till_ffn_pm(slots, feat_pm, hw, pos_tabs)
         if stage_enable:
             flat = obj.reshape(T * L, C)                                    # concat along the slot axis (:310)
             obj = (flat + self.temporal_query_head(features=flat, mask_query=flat)).reshape(T, L, C)   # :313-322
@@ -225,8 +242,8 @@ class MaskRCNNHead(nn.Module):
         T = len(features)
         _, c, h, w = features[0].shape
         feat_pm = torch.cat(features, 0).permute(0, 2, 3, 1).reshape(T, h * w, c).to(BF16).contiguous()
-        pos_pm = pos[0][0].permute(1, 2, 0).reshape(h * w, c).float().contiguous() if pos is not None else None
-        logits, emb = self.forward_pm(torch.cat(mask_query, 0).float(), feat_pm, pos_pm, stage_enable)
+        tabs = pos_tables_from_map(pos[0]) if pos is not None else None
+        logits, emb = self.forward_pm(torch.cat(mask_query, 0).float(), feat_pm, (h, w), tabs, stage_enable)
         return [logits[t:t + 1] for t in range(T)], [emb[t:t + 1] for t in range(T)], None, None
 
 
@@ -297,10 +314,11 @@ class MultiScaleDynamicMaskHead(nn.Module):
         conv = self.conv_trans.conv
         return F.conv2d(cat.contiguous(memory_format=torch.channels_last), conv.weight.to(BF16), conv.bias.to(BF16))
 
-    def forward_clip(self, feats, init_slots, pos_pm):
+    def forward_clip(self, feats, init_slots, pos_tabs):
         """Batched clip entry.
         feats: list over the 4 levels (coarse -> fine) of [T, 128, Hi, Wi]; init_slots [L, 256];
-        pos_pm: list of [Hi*Wi, 256] fp32 pixel-major sine embeddings.
+        pos_tabs: per level the separable sine tables (ytab [Hi, 128], xtab [Wi, 128]) of
+        ops.pos_embed_sine_tables, or None for no position embedding.
         Returns logits [S, T, L, nc], embeds [S, T, L, 256], fused list of [T, Hi*Wi, 256] bf16."""
         if not feats[0].is_cuda:
             raise RuntimeError("MultiScaleDynamicMaskHead runs on the GPU only; there is no CPU fallback")
@@ -317,7 +335,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 f_pm = f_pm.contiguous()
             for stage in getattr(self, f"head_series_{i}"):
                 enable = stage_idx in self.apply_temporal_query_atten_stages
-                logits, slots = stage.forward_pm(slots, f_pm, pos_pm[i], enable)
+                logits, slots = stage.forward_pm(slots, f_pm, (h, w), None if pos_tabs is None else pos_tabs[i], enable)
                 slots = slots.detach()
                 all_logits.append(logits)
                 all_embeds.append(slots)
@@ -334,11 +352,11 @@ class MultiScaleDynamicMaskHead(nn.Module):
         T, nlev = len(features), len(features[0])
         assert features[0][0].shape[0] == 1, "batch size 1 per frame (vps_temporal_slots.py:483-484)"
         feats = [torch.cat([features[t][i] for t in range(T)], 0) for i in range(nlev)]
-        pos_pm = [pos[0][i][0].permute(1, 2, 0).reshape(-1, self.dh_dim).float().contiguous() for i in range(nlev)]
+        pos_tabs = [pos_tables_from_map(pos[0][i]) for i in range(nlev)] if pos is not None else None
         init = init_masks[0]
         for t in range(T):
             init_masks[t] = init_masks[t][None]
-        logits, embeds, fused = self.forward_clip(feats, init, pos_pm)
+        logits, embeds, fused = self.forward_clip(feats, init, pos_tabs)
         ret_feats = []
         for t in range(T):
             per = []

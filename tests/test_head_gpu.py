@@ -48,14 +48,14 @@ def test_head_matches_oracle_and_reference(cuda, tag):
     head = build_head(cuda, params)
     with torch.no_grad():
         tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
-        pos_pm = [ops.pos_embed_sine(h, w, 256, cuda) for (h, w) in sizes]
-        logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(slots).to(cuda), pos_pm)
+        pos_tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in sizes]
+        logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(slots).to(cuda), pos_tabs)
         torch.cuda.synchronize()
     logits, embeds = logits.cpu().numpy(), embeds.cpu().numpy()          # [7, T, L, *]
 
     # ---- yardstick 1: oracle under the same storage policy -------------------------------------
     pos = [orc.pos_embed_sine(h, w) for (h, w) in sizes]
-    st = orc.Storage.bf16_policy(torch_gemm=True)
+    st = orc.Storage.bf16_policy(torch_conv=True)   # the level fusion is still an interim torch conv
     _, _, o_fused = orc.head_forward(feats, slots, pos, params, st=st)
     g_fused = [[fused[i][t].float().cpu().numpy() for i in range(4)] for t in range(T)]
     f_err = max(np.abs(g_fused[t][i] - o_fused[t][i]).max() for t in range(T) for i in range(4))

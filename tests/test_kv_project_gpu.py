@@ -1,0 +1,92 @@
+"""K3 parity: HIP key/value producer vs the CPU oracle's projections under the bf16 storage policy
+(MaskDynamicConv.forward lines 432-433). Outputs are bf16, so the yardstick is the bf16 grid: every
+element must be within one bf16 ulp of the oracle (a flip happens when the fp32 pre-rounding values
+differ by accumulation order across a rounding boundary) and flips must be rare."""
+import numpy as np
+import pytest
+
+import synth
+from util import orc, to_bf16_t, bf16_t_to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_bf16(x):
+    e = np.floor(np.log2(np.maximum(np.abs(x), 1e-30)))
+    return 2.0 ** (e - 7)
+
+
+@pytest.mark.parametrize("T,H,W,with_pos", [
+    (1, 16, 32, True),
+    (2, 33, 65, True),      # ragged: W not a multiple of the tile, HW % 32 != 0
+    (2, 34, 60, True),      # VIPER coarse level
+    (1, 8, 8, False),
+    (3, 64, 128, True),
+])
+def test_kv_project_matches_oracle(cuda, T, H, W, with_pos):
+    import torch
+    from slotvps_amd import ops
+    seed = H * 1000 + W + T
+    params = synth.make_params(synth.retriever_shapes(""), seed)
+    rng = np.random.default_rng(seed)
+    feat = np.stack([synth.smooth_features(rng, 256, H, W).reshape(256, H * W).T for _ in range(T)])
+    tf = to_bf16_t(feat, cuda)
+    g = lambda n: torch.from_numpy(params[n]).to(cuda)
+    tabs = ops.pos_embed_sine_tables(H, W, 256, cuda) if with_pos else None
+    k, v = ops.kv_project(tf, H, W, tabs, g("to_k.weight").to(torch.bfloat16).contiguous(), g("to_k.bias"),
+                          g("norm_k.weight"), g("norm_k.bias"), 1e-5,
+                          g("to_v.weight").to(torch.bfloat16).contiguous(), g("to_v.bias"),
+                          g("norm_v.weight"), g("norm_v.bias"), 1e-5)
+    torch.cuda.synchronize()
+    k, v = bf16_t_to_np(k), bf16_t_to_np(v)
+    fb = bf16_t_to_np(tf)
+    pos = orc.pos_embed_sine(H, W) if with_pos else None
+    if with_pos:   # the separable tables reproduce the full map exactly
+        yt, xt = tabs[0].cpu().numpy(), tabs[1].cpu().numpy()
+        full = np.concatenate([np.repeat(yt[:, None, :], W, 1), np.repeat(xt[None, :, :], H, 0)], -1).reshape(H * W, 256)
+        assert np.abs(full - pos).max() < 5e-6
+        pos = full            # feed the oracle the device's own table values (pins the projection alone)
+    st = orc.Storage.bf16_policy()
+    slots = np.zeros((1, 256), np.float32)
+    worst_k = worst_v = 0.0
+    flips = total = 0
+    for t in range(T):
+        _, ko, vo = orc.retriever_project(slots, fb[t], pos, params, "", st, np.float32)
+        for got, ref in ((k[t], ko), (v[t], vo)):
+            d = np.abs(got - ref)
+            ulp = _ulp_bf16(np.maximum(np.abs(got), np.abs(ref)))      # ulp of the larger binade
+            ij = np.unravel_index(np.argmax(d - ulp), d.shape)
+            # near-zero LayerNorm outputs are differences of O(1) fp32 terms: absolute floor 1e-5
+            assert (d <= ulp * 1.001 + 1e-5).all(), f"more than one bf16 ulp off at {ij}: got {got[ij]!r} ref {ref[ij]!r}"
+            flips += int((d > 0).sum())
+            total += d.size
+        worst_k = max(worst_k, np.abs(k[t] - ko).max())
+        worst_v = max(worst_v, np.abs(v[t] - vo).max())
+    frac = flips / total
+    print(f"\n[kv_project {T}x{H}x{W}] max |dk| {worst_k:.3e} max |dv| {worst_v:.3e} flipped {100 * frac:.3f}% of elements")
+    assert frac < 0.01
+
+
+def test_kv_project_feeds_k1(cuda):
+    """K3 -> K1 chained on device equals the oracle retriever under the same policy (per-call parity)."""
+    import torch
+    from slotvps_amd import ops
+    H, W, L = 32, 64, 100
+    params = synth.make_params(synth.retriever_shapes(""), 77)
+    rng = np.random.default_rng(78)
+    feat = synth.smooth_features(rng, 256, H, W).reshape(256, H * W).T[None]
+    slots = rng.standard_normal((L, 256)).astype(np.float32)
+    tf = to_bf16_t(feat, cuda)
+    g = lambda n: torch.from_numpy(params[n]).to(cuda)
+    tabs = ops.pos_embed_sine_tables(H, W, 256, cuda)
+    k, v = ops.kv_project(tf, H, W, tabs, g("to_k.weight").to(torch.bfloat16).contiguous(), g("to_k.bias"),
+                          g("norm_k.weight"), g("norm_k.bias"), 1e-5,
+                          g("to_v.weight").to(torch.bfloat16).contiguous(), g("to_v.bias"),
+                          g("norm_v.weight"), g("norm_v.bias"), 1e-5)
+    q = orc.layer_norm(orc.linear(slots, params["to_q.weight"], params["to_q.bias"]), params["norm_q.weight"], params["norm_q.bias"])
+    tq = to_bf16_t(q[None], cuda)
+    out = ops.slot_attn(tq, k, v, g("norm1.weight"), g("norm1.bias")).cpu().numpy()[0]
+    ref = orc.retriever(slots, bf16_t_to_np(tf)[0], orc.pos_embed_sine(H, W), params, "", orc.Storage.bf16_policy())
+    err = np.abs(out - ref).max()
+    print(f"\n[K3->K1] max abs err vs same-policy oracle retriever: {err:.3e}")
+    assert err < 5e-3      # a handful of one-ulp k/v flips seen through a sharp softmax
