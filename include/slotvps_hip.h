@@ -44,6 +44,7 @@ extern "C" {
 #define SVPS_KERNEL_MASK_DECODE 2
 #define SVPS_KERNEL_POS_EMBED 3
 #define SVPS_KERNEL_KV_PROJECT 4
+#define SVPS_KERNEL_LEVEL_FUSE 5
 #define SVPS_KERNEL_COUNT 8
 
 int svps_abi_version(void);
@@ -120,6 +121,20 @@ int svps_kv_project_fwd(const void* feat, const float* pos_y, const float* pos_x
                         const float* bk, const float* lnk_w, const float* lnk_b, float lnk_eps,
                         const void* wv, const float* bv, const float* lnv_w, const float* lnv_b,
                         float lnv_eps, void* k_out, void* v_out, int T, int H, int W, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4 level fusion of the multi-scale head (mmdet/models/detectors/dynamic_mask_head.py:171-188), all T
+ * frames of a level per launch:
+ *     level i > 0:  f_i = conv_trans( cat( interpolate(f_{i-1}, x2, bilinear, align_corners=False), x_i ) )
+ *     level 0   :   f_0 = conv_trans( cat( x_0, x_0, x_0 ) )               (prev == NULL)
+ *   cur   the incoming 128-channel map: [T, 128, H, W] fp32 NCHW (cur_is_nchw_f32 != 0, the reference's
+ *         layout) or [T, H*W, 128] bf16 pixel-major
+ *   prev  [T, (H/2)*(W/2), 256] bf16 pixel-major fused map of the previous (coarser) level, or NULL
+ *   wc    [256, 384] bf16 conv_trans weight (row = output channel), bc [256] fp32 bias
+ *   out   [T, H*W, 256] bf16 pixel-major
+ * ------------------------------------------------------------------------------------------- */
+int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, const void* wc,
+                        const float* bc, void* out, int T, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Profiling hooks: when enabled every kernel launch of this library is bracketed by HIP events on

@@ -291,6 +291,21 @@ def upsample2x_bilinear(x):
     return rows[:, :, x0] * (1 - lx)[None, None, :] + rows[:, :, x1] * lx[None, None, :]
 
 
+def fuse_level(x, prev, wc, bc, st=None):
+    """One level of the feature-side glue (:171-188). x [128, H, W] incoming map, prev [256, H/2, W/2]
+    fused map of the coarser level or None (level 0: cat(x, x, x), :183), wc [256, 384], bc [256]
+    -> fused map, pixel-major [H*W, 256]."""
+    st = st or Storage.exact()
+    C, H, W = x.shape
+    if prev is None:
+        cat = np.concatenate([x, x, x], axis=0)                               # :183
+    else:
+        cat = np.concatenate([upsample2x_bilinear(prev), x], axis=0)          # :178-179
+    cat = st.conv_in(cat)
+    y = st.weight(wc) @ cat.reshape(cat.shape[0], H * W) + st.conv_bias(bc)[:, None]   # 1x1 conv :181/:185
+    return st.feat(np.ascontiguousarray(y.T))
+
+
 DEFAULT_CFG = dict(nhead=8, activation="gelu", temporal_activation="relu", num_cls=2, num_reg=2,
                    per_level_stages=(1, 2, 2, 2), temporal_stages=(3, 4, 5, 6))
 
@@ -320,18 +335,11 @@ def head_forward(features, init_slots, pos, params, cfg=None, st=None, dt=np.flo
         cur_pm = []
         for t in range(T):
             x = np.asarray(features[t][i], dtype=dt)
-            C, H, W = x.shape
-            if i == 0:
-                cat = np.concatenate([x, x, x], axis=0)                      # :183
-            else:
-                cat = np.concatenate([upsample2x_bilinear(prev[t]), x], axis=0)   # :178-179
-            cat = st.conv_in(cat)
-            y = (st.weight(wc) @ cat.reshape(cat.shape[0], H * W) + st.conv_bias(bc)[:, None])   # 1x1 conv :181/:185
-            y = st.feat(np.ascontiguousarray(y.T))                           # pixel-major [HW, 256]
+            y = fuse_level(x, prev[t], wc, bc, st)                            # :171-188
             if fused_override is not None:
                 y = np.asarray(fused_override[t][i], dtype=dt)
             cur_pm.append(y)
-            prev[t] = np.ascontiguousarray(y.T).reshape(256, H, W)
+            prev[t] = np.ascontiguousarray(y.T).reshape(256, x.shape[1], x.shape[2])
             fused[t][i] = y
         for j in range(cfg["per_level_stages"][i]):
             prefix = f"head_series_{i}.{j}."

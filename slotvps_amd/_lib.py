@@ -19,6 +19,7 @@ KERNEL_SLOT_ATTN_FINISH = 1
 KERNEL_MASK_DECODE = 2
 KERNEL_POS_EMBED = 3
 KERNEL_KV_PROJECT = 4
+KERNEL_LEVEL_FUSE = 5
 
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
@@ -34,6 +35,7 @@ SIGNATURES = {
     "svps_pos_embed_sine_tables": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "svps_kv_project_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp,
                                  _i, _i, _i, _i, _vp]),
+    "svps_level_fuse_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

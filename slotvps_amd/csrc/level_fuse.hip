@@ -1,0 +1,278 @@
+// K4 - level fusion of the multi-scale slot head for gfx950.
+//
+// Replaces, for all T frames of a pyramid level in one launch, the feature-side glue of
+// MultiScaleDynamicMaskHead.forward (mmdet/models/detectors/dynamic_mask_head.py:171-188):
+//
+//     level i > 0:  f_i = conv1x1_{384->256}( cat( bilinear_x2(f_{i-1}), x_i ) )        :178-181
+//     level 0:      f_0 = conv1x1_{384->256}( cat( x_0, x_0, x_0 ) )                    :182-185
+//
+// with the SAME (shared) 1x1 conv_trans. F.interpolate(scale 2, bilinear, align_corners=False):
+// source coordinate (d + 0.5) / 2 - 0.5 clamped at 0, taps i0 = floor, i1 = min(i0 + 1, n - 1).
+// Output: the bf16 pixel-major [T, H*W, 256] map that K3, the next level and K2 consume.
+//
+// Storage policy: the 384-channel operand (fp32 blend of the four bf16 taps, resp. the incoming
+// 128-channel map) and the weight matrix are rounded to bf16 for the matrix cores; accumulation and
+// bias are fp32; the result is rounded to bf16 once.
+//
+// Mapping: 8 waves, wave w owns output channels [32w, 32w+32) - its 32 x 384 weight block stays in 96
+// VGPRs as MFMA A fragments. Pixels stream in 32-pixel tiles: all threads build the [32 px][384 ch]
+// operand tile in LDS (taps of tile i+1 are fetched into registers while tile i is on the matrix
+// cores), 24 MFMA 32x32x16 per wave and tile, results go through an LDS out-tile so HBM sees whole
+// 512-byte pixel rows. The incoming 128-channel map is read in the reference's own layout
+// ([T, 128, H, W] fp32, NCHW) or as bf16 pixel-major [T, H*W, 128].
+//
+// Roofline: HBM - per output pixel 512 B (fp32 NCHW input) or 256 B (bf16) in, 512 B out; the four
+// upsampling taps come from the 4x smaller previous level (L2 / Infinity Cache resident).
+#include "common.h"
+#include "../../include/slotvps_hip.h"
+
+namespace svps {
+
+constexpr int kFuseIn = 384;                  // concatenated input channels
+constexpr int kFuseRowBytes = kFuseIn * 2;    // 768 B per pixel row of the operand tile
+
+struct FuseLds {
+    static constexpr int atile = 0;                                 // [32][384] bf16, 16-B chunks swizzled
+    static constexpr int otile = kTilePx * kFuseRowBytes;           // [32][256] bf16 out tile
+    static constexpr int total = otile + kTileBytes;
+};
+
+// chunk swizzle of the 48-chunk operand rows: XOR on the low four bits keeps chunks inside their
+// 16-chunk group, conflict-free for ds_read_b128 over 16 rows
+__device__ __forceinline__ int a_off(int row, int chunk) {
+    return row * kFuseRowBytes + (((chunk & ~15) | ((chunk ^ swz(row)) & 15)) * 16);
+}
+
+template <bool NCHW_F32, bool LEVEL0>
+__global__ __launch_bounds__(512) void level_fuse_kernel(
+    const void* __restrict__ cur_,        // [T, 128, H, W] fp32 (NCHW_F32) or [T, H*W, 128] bf16
+    const __bf16* __restrict__ prev,      // [T, (H/2)*(W/2), 256] bf16 pixel-major (unused for LEVEL0)
+    const __bf16* __restrict__ wc,        // [256, 384] bf16 (conv weight, row = output channel)
+    const float* __restrict__ bc,         // [256]
+    __bf16* __restrict__ out,             // [T, H*W, 256]
+    int H, int W, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = FuseLds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r_ = lane & 31, h_ = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x;
+    const int HW = H * W;
+    const int Hp = H >> 1, Wp = W >> 1;
+
+    const int px_begin = c * tiles_per_chunk * kTilePx;
+    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    px_end = px_end < HW ? px_end : HW;
+    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+
+    // ---- weight block of this wave: rows 32w .. 32w+31, 24 k-steps ----------------------------------
+    bf16x8 wf[24];
+    {
+        const __bf16* row = wc + (size_t)(32 * w + r_) * kFuseIn + 8 * h_;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks)
+            wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
+    }
+    float bias[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bias[i] = bc[32 * w + acc_row(i, h_)];
+
+    // ---- operand-tile builders -------------------------------------------------------------------
+    // (a) incoming 128-channel map -> chunks 32..47 (channels 256..383); LEVEL0 also -> 0..15, 16..31
+    //     NCHW fp32: thread = (channel, 8-pixel group): 2 x 16-B loads, 8 two-byte LDS stores
+    //     pixel-major bf16: thread = (pixel, 16-B chunk): one 16-B load, one 16-B LDS store
+    // (b) upsampled previous level -> chunks 0..31: thread = (pixel, 2 chunks), 4 taps each
+    struct Pre {
+        f32x4 c0, c1;           // NCHW path
+        u32x4 cb;               // bf16 path
+        u32x4 tap[2][4];        // [chunk][tap]
+        float wy, wx;           // lambda_y, lambda_x of this thread's pixel
+    };
+    auto prefetch = [&](int tile, Pre& p) {
+        const int px0 = px_begin + tile * kTilePx;
+        if constexpr (NCHW_F32) {
+            const int ch = tid >> 2, pg = tid & 3;                     // channel 0..127, pixel group 0..3
+            int pp = px0 + 8 * pg;
+            const float* src = static_cast<const float*>(cur_) + ((size_t)t * 128 + ch) * HW;
+            if (pp + 8 <= HW) {
+                p.c0 = *reinterpret_cast<const f32x4*>(src + pp);
+                p.c1 = *reinterpret_cast<const f32x4*>(src + pp + 4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    p.c0[j] = src[pp + j < HW ? pp + j : HW - 1];
+                    p.c1[j] = src[pp + 4 + j < HW ? pp + 4 + j : HW - 1];
+                }
+            }
+        } else {
+            const int px = tid >> 4, ck = tid & 15;
+            int pp = px0 + px;
+            pp = pp < HW ? pp : HW - 1;
+            p.cb = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(cur_) + ((size_t)t * HW + pp) * 128 + 8 * ck);
+        }
+        if constexpr (!LEVEL0) {
+            const int px = tid >> 4, ck = tid & 15;                    // chunks ck and ck + 16
+            int pp = px0 + px;
+            pp = pp < HW ? pp : HW - 1;
+            const int y = pp / W, x = pp - y * W;
+            const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1, x1 = x0 + 1 < Wp ? x0 + 1 : Wp - 1;
+            p.wy = sy - (float)y0;
+            p.wx = sx - (float)x0;
+            const __bf16* pb = prev + (size_t)t * Hp * Wp * kD;
+            const __bf16* t00 = pb + ((size_t)y0 * Wp + x0) * kD;
+            const __bf16* t01 = pb + ((size_t)y0 * Wp + x1) * kD;
+            const __bf16* t10 = pb + ((size_t)y1 * Wp + x0) * kD;
+            const __bf16* t11 = pb + ((size_t)y1 * Wp + x1) * kD;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int co = 8 * (ck + 16 * u);
+                p.tap[u][0] = *reinterpret_cast<const u32x4*>(t00 + co);
+                p.tap[u][1] = *reinterpret_cast<const u32x4*>(t01 + co);
+                p.tap[u][2] = *reinterpret_cast<const u32x4*>(t10 + co);
+                p.tap[u][3] = *reinterpret_cast<const u32x4*>(t11 + co);
+            }
+        }
+    };
+    auto commit = [&](const Pre& p) {
+        char* at = smem + Lds::atile;
+        if constexpr (NCHW_F32) {
+            const int ch = tid >> 2, pg = tid & 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = 8 * pg + j;
+                const __bf16 val = (__bf16)(j < 4 ? p.c0[j] : p.c1[j - 4]);
+                const int chunk = 32 + (ch >> 3);
+                *reinterpret_cast<__bf16*>(at + a_off(row, chunk) + (ch & 7) * 2) = val;
+                if constexpr (LEVEL0) {
+                    *reinterpret_cast<__bf16*>(at + a_off(row, chunk - 32) + (ch & 7) * 2) = val;
+                    *reinterpret_cast<__bf16*>(at + a_off(row, chunk - 16) + (ch & 7) * 2) = val;
+                }
+            }
+        } else {
+            const int px = tid >> 4, ck = tid & 15;
+            *reinterpret_cast<u32x4*>(at + a_off(px, 32 + ck)) = p.cb;
+            if constexpr (LEVEL0) {
+                *reinterpret_cast<u32x4*>(at + a_off(px, ck)) = p.cb;
+                *reinterpret_cast<u32x4*>(at + a_off(px, 16 + ck)) = p.cb;
+            }
+        }
+        if constexpr (!LEVEL0) {
+            const int px = tid >> 4, ck = tid & 15;
+            // torch's upsample_bilinear2d: (1-ly) * ((1-lx) a + lx b) + ly * ((1-lx) c + lx d) in fp32
+            const float h1 = p.wy, h0 = 1.f - p.wy, w1 = p.wx, w0 = 1.f - p.wx;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, p.tap[u][0]), b = __builtin_bit_cast(bf16x8, p.tap[u][1]);
+                const bf16x8 cc = __builtin_bit_cast(bf16x8, p.tap[u][2]), d = __builtin_bit_cast(bf16x8, p.tap[u][3]);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = (__bf16)(h0 * (w0 * (float)a[j] + w1 * (float)b[j]) + h1 * (w0 * (float)cc[j] + w1 * (float)d[j]));
+                *reinterpret_cast<bf16x8*>(at + a_off(px, ck + 16 * u)) = o;
+            }
+        }
+    };
+    // out tile -> HBM, all 512 threads: 16 KiB per tile, 2 x 16 B per thread
+    auto store_out = [&](int tile) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int piece = u * 512 + tid;                            // [row][chunk position]
+            const int row = piece >> 5, cpos = piece & 31;
+            const int px = px_begin + tile * kTilePx + row;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(smem + Lds::otile + row * kRowBytes + cpos * 16);
+            if (px < px_end)
+                *reinterpret_cast<u32x4*>(out + ((size_t)t * HW + px) * kD + ((cpos ^ swz(row)) * 8)) = val;
+        }
+    };
+
+    Pre pre;
+    prefetch(0, pre);
+    commit(pre);
+    for (int it = 0; it < nt; ++it) {
+        __syncthreads();                                   // a(it): operand tile it built, out tile it-1 complete
+        if (it >= 1) store_out(it - 1);
+        if (it + 1 < nt) prefetch(it + 1, pre);            // taps of the next tile fly under the MFMAs
+        int r = r_, h = h_;
+        asm volatile("" : "+v"(r), "+v"(h));
+        const char* at = smem + Lds::atile;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bias[i];
+#pragma unroll
+        for (int grp = 0; grp < 3; ++grp) {
+            bf16x8 xf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xf[u] = *reinterpret_cast<const bf16x8*>(at + a_off(r, 2 * (8 * grp + u) + h));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[8 * grp + u], xf[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();                                   // b(it): every wave is done reading operand tile it
+        char* ot = smem + Lds::otile;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[4 * g + j];
+            const int ch0 = 32 * w + 8 * g + 4 * h;
+            *reinterpret_cast<bf16x4*>(ot + r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
+        }
+        if (it + 1 < nt) commit(pre);
+    }
+    __syncthreads();
+    store_out(nt - 1);
+}
+
+}  // namespace svps
+
+namespace {
+int fuse_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+template <bool NCHW, bool L0>
+hipError_t launch_fuse(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
+                       int W, hipStream_t stream) {
+    auto kern = svps::level_fuse_kernel<NCHW, L0>;
+    const int HW = H * W;
+    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+    int chunks = fuse_num_cus() / T;              // one resident 8-wave workgroup per CU
+    if (chunks < 1) chunks = 1;
+    if (chunks > tiles) chunks = tiles;
+    const int tpc = (tiles + chunks - 1) / chunks;
+    chunks = (tiles + tpc - 1) / tpc;
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::FuseLds::total, stream, cur,
+                       static_cast<const __bf16*>(prev), static_cast<const __bf16*>(wc), bc,
+                       static_cast<__bf16*>(out), H, W, tpc);
+    return hipGetLastError();
+}
+}  // namespace
+
+extern "C" int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, const void* wc,
+                                   const float* bc, void* out, int T, int H, int W, void* stream_) {
+    if (!cur || !wc || !bc || !out) return SVPS_ERR_BAD_ARG;
+    if (T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
+    if (prev && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;   // x2 upsampling: even sizes
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 0, stream);
+    hipError_t e;
+    if (prev)
+        e = cur_is_nchw_f32 ? launch_fuse<true, false>(cur, prev, wc, bc, out, T, H, W, stream)
+                            : launch_fuse<false, false>(cur, prev, wc, bc, out, T, H, W, stream);
+    else
+        e = cur_is_nchw_f32 ? launch_fuse<true, true>(cur, prev, wc, bc, out, T, H, W, stream)
+                            : launch_fuse<false, true>(cur, prev, wc, bc, out, T, H, W, stream);
+    svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 1, stream);
+    return (int)e;
+}

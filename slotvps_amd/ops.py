@@ -148,6 +148,40 @@ def kv_project(feat, H, W, pos_tabs, wk, bk, lnk_w, lnk_b, lnk_eps, wv, bv, lnv_
     return k, v
 
 
+def level_fuse(cur, prev, wc, bc, H, W):
+    """K4: fused level map [T, H*W, 256] bf16 = conv1x1(cat(bilinear_x2(prev), cur)) (+ level-0 form when
+    prev is None). cur: [T, 128, H, W] fp32 (NCHW, the reference's layout) or [T, H*W, 128] bf16;
+    prev: [T, (H/2)*(W/2), 256] bf16; wc [256, 384] bf16; bc [256] fp32.
+    (MultiScaleDynamicMaskHead.forward lines 171-188 of the reference's dynamic_mask_head.py.)"""
+    lib = _lib.load()
+    if not isinstance(cur, torch.Tensor) or not cur.is_cuda:
+        raise RuntimeError("level_fuse: GPU tensors only; there is no CPU fallback")
+    if cur.dtype == torch.float32:
+        _need(cur, "cur", torch.float32, 4)
+        T = cur.shape[0]
+        if cur.shape != (T, 128, H, W):
+            raise ValueError(f"cur {tuple(cur.shape)} != [T, 128, {H}, {W}]")
+        nchw = 1
+    else:
+        _need(cur, "cur", torch.bfloat16, 3)
+        T = cur.shape[0]
+        if cur.shape != (T, H * W, 128):
+            raise ValueError(f"cur {tuple(cur.shape)} != [T, {H * W}, 128]")
+        nchw = 0
+    _need(wc, "wc", torch.bfloat16, 2)
+    _need(bc, "bc", torch.float32, 1)
+    if wc.shape != (256, 384):
+        raise ValueError("wc must be [256, 384]")
+    if prev is not None:
+        _need(prev, "prev", torch.bfloat16, 3)
+        if prev.shape != (T, (H // 2) * (W // 2), 256) or H % 2 or W % 2:
+            raise ValueError(f"prev {tuple(prev.shape)} does not match an {H}x{W} level")
+    out = torch.empty((T, H * W, 256), dtype=torch.bfloat16, device=cur.device)
+    _lib.check(lib.svps_level_fuse_fwd(_ptr(cur), nchw, _ptr(prev), _ptr(wc), _ptr(bc), _ptr(out), T, H, W,
+                                       _stream_ptr()), "svps_level_fuse_fwd")
+    return out
+
+
 class KernelTimer:
     """Device-time accounting of the library's own launches (HIP events on the launch stream)."""
 

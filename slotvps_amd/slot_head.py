@@ -7,9 +7,9 @@ What runs where
     of a stage in one launch (MaskDynamicConv.forward lines 435-459).
   * K3 (HIP): the pixel-side projections k = norm_k(to_k(f + pos)), v = norm_v(to_v(f)) (:432-433)
     for all T frames, written as the bf16 tensors K1 streams.
+  * K4 (HIP): the level fusion  f_i = conv1x1(cat(bilinear_x2(f_{i-1}), x_i))  (:171-188).
   * PyTorch-ROCm (plumbing around the kernels, same math as the reference lines cited inline): the
-    level fusion (bilinear x2, concat, 1x1 conv) and the slot-side operators on [T, L, 256] tensors
-    (self-attention, FFN, temporal head, towers).
+    slot-side operators on [T, L, 256] tensors (self-attention, FFN, temporal head, towers).
 There is no CPU path: modules raise if their tensors are not on a GPU.
 
 Storage policy (what is rounded to bf16 in HBM): the fused level map f, the projection operand f+pos,
@@ -144,8 +144,9 @@ class SlotsDynamicConv(nn.Module):
         q = self.norm_q(self.to_q(curr_features))
         k = self.norm_k(self.to_k(features if pos is None else features + pos))
         v = self.norm_v(self.to_v(features))
-        attn = torch.softmax(q @ k.transpose(-1, -2), dim=1)        # over the query axis (:562)
-        return self.activation(self.norm1(attn @ v))
+        # softmax over the QUERY axis (dim=1 of [1, Lq, Lk], :562) = last-dim softmax of the transposed logits
+        attn_t = torch.softmax(k @ q.transpose(-1, -2), dim=-1)     # [1, Lk, Lq]
+        return self.activation(self.norm1(attn_t.transpose(-1, -2) @ v))
 
 
 @HEADS.register_module
@@ -302,21 +303,27 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 nn.init.constant_(p, self.bias_value)
 
     # ------------------------------------------------------------------------------------------
-    def fuse_level(self, i, cur, prev):
-        """:172-188. cur [T, 128, H, W], prev [T, 256, H/2, W/2] bf16 or None -> fused [T, 256, H, W]
-        bf16 in channels_last memory (so its pixel-major [T, HW, 256] view is free)."""
-        x = cur.to(BF16)
-        if i == 0:
-            cat = torch.cat((x, x, x), dim=1)
-        else:
-            up = F.interpolate(prev, None, 2, mode="bilinear", align_corners=False)
-            cat = torch.cat((up, x), dim=1)
+    def _conv_weights(self):
         conv = self.conv_trans.conv
-        return F.conv2d(cat.contiguous(memory_format=torch.channels_last), conv.weight.to(BF16), conv.bias.to(BF16))
+        key = (conv.weight._version, conv.weight.data_ptr())
+        if getattr(self, "_cw_key", None) != key:
+            self._cw = conv.weight.detach().reshape(self.dh_dim, self.trans_in_dim).to(BF16).contiguous()
+            self._cw_key = key
+        return self._cw, conv.bias
 
-    def forward_clip(self, feats, init_slots, pos_tabs):
+    def fuse_level(self, cur, prev_pm, hw):
+        """K4 (:171-188). cur [T, 128, H, W] fp32 (the reference's layout) or [T, H*W, 128] bf16;
+        prev_pm [T, (H/2)*(W/2), 256] bf16 fused map of the coarser level or None (level 0).
+        Returns the fused map [T, H*W, 256] bf16 pixel-major."""
+        wc, bc = self._conv_weights()
+        if cur.dtype not in (torch.float32, BF16):
+            cur = cur.float()
+        return ops.level_fuse(cur.contiguous(), prev_pm, wc, bc, hw[0], hw[1])
+
+    def forward_clip(self, feats, init_slots, pos_tabs, hws=None):
         """Batched clip entry.
-        feats: list over the 4 levels (coarse -> fine) of [T, 128, Hi, Wi]; init_slots [L, 256];
+        feats: list over the 4 levels (coarse -> fine) of [T, 128, Hi, Wi] fp32 (NCHW, the reference's
+        layout) or [T, Hi*Wi, 128] bf16 pixel-major (then hws = [(Hi, Wi)] is required); init_slots [L, 256];
         pos_tabs: per level the separable sine tables (ytab [Hi, 128], xtab [Wi, 128]) of
         ops.pos_embed_sine_tables, or None for no position embedding.
         Returns logits [S, T, L, nc], embeds [S, T, L, 256], fused list of [T, Hi*Wi, 256] bf16."""
@@ -328,11 +335,11 @@ class MultiScaleDynamicMaskHead(nn.Module):
         prev = None
         stage_idx = 0
         for i in range(self.feat_num_levels):
-            y = self.fuse_level(i, feats[i], prev)
-            _, c, h, w = y.shape
-            f_pm = y.permute(0, 2, 3, 1).reshape(T, h * w, c)
-            if not f_pm.is_contiguous():
-                f_pm = f_pm.contiguous()
+            if feats[i].dim() == 4:
+                h, w = feats[i].shape[-2:]
+            else:
+                h, w = hws[i]
+            f_pm = self.fuse_level(feats[i], prev, (h, w))
             for stage in getattr(self, f"head_series_{i}"):
                 enable = stage_idx in self.apply_temporal_query_atten_stages
                 logits, slots = stage.forward_pm(slots, f_pm, (h, w), None if pos_tabs is None else pos_tabs[i], enable)
@@ -340,7 +347,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 all_logits.append(logits)
                 all_embeds.append(slots)
                 stage_idx += 1
-            prev = y
+            prev = f_pm
             fused.append(f_pm)
         return torch.stack(all_logits), torch.stack(all_embeds), fused
 

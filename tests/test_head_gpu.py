@@ -55,14 +55,14 @@ def test_head_matches_oracle_and_reference(cuda, tag):
 
     # ---- yardstick 1: oracle under the same storage policy -------------------------------------
     pos = [orc.pos_embed_sine(h, w) for (h, w) in sizes]
-    st = orc.Storage.bf16_policy(torch_conv=True)   # the level fusion is still an interim torch conv
+    st = orc.Storage.bf16_policy()
     _, _, o_fused = orc.head_forward(feats, slots, pos, params, st=st)
     g_fused = [[fused[i][t].float().cpu().numpy() for i in range(4)] for t in range(T)]
     f_err = max(np.abs(g_fused[t][i] - o_fused[t][i]).max() for t in range(T) for i in range(4))
     f_frac = np.mean([(g_fused[t][3] != o_fused[t][3]).mean() for t in range(T)])
-    # (a) level fusion: bf16 maps of magnitude < 8 -> one bf16 ulp is 2^-5; the interim torch conv
-    #     rounds twice (GEMM result, then + bias), so about a quarter of the elements sit one ulp off.
-    assert f_err <= 3.2e-2, f_err
+    # (a) level fusion (K4), free-running over the four levels: bf16 maps of magnitude < 8 -> one bf16
+    #     ulp is 2^-5; a one-ulp flip at level i is blended into level i+1, so flips accumulate slowly.
+    assert f_err <= 6.3e-2 and f_frac < 0.02, (f_err, f_frac)
     # (b) every stage on IDENTICAL inputs (teacher forcing: the oracle stage is fed the HIP path's own
     #     incoming slots and fused map). This is the per-function parity of a3/a4/a5 + K1. The chain
     #     itself is chaotic with these random weights - logits have sigma ~ 19, so the softmax over

@@ -1,0 +1,65 @@
+"""K4 parity: HIP level fusion (bilinear x2 + concat + shared 1x1 conv, dynamic_mask_head.py:171-188)
+vs the CPU oracle under the bf16 storage policy. bf16 outputs: every element within one bf16 ulp
+(+1e-5 absolute) of the oracle, rounding flips rare."""
+import numpy as np
+import pytest
+
+import synth
+from util import orc, to_bf16_t, bf16_t_to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def _ulp_bf16(x):
+    return 2.0 ** (np.floor(np.log2(np.maximum(np.abs(x), 1e-30))) - 7)
+
+
+@pytest.mark.parametrize("T,H,W,level0,nchw", [
+    (2, 8, 16, True, True),
+    (1, 8, 16, True, False),
+    (2, 16, 32, False, True),
+    (1, 16, 32, False, False),
+    (2, 68, 120, False, True),      # VIPER level 1 from a 34x60 level 0: rows not tile aligned, ragged end
+    (1, 34, 60, True, True),
+    (3, 64, 128, False, True),
+])
+def test_level_fuse_matches_oracle(cuda, T, H, W, level0, nchw):
+    import torch
+    from slotvps_amd import ops
+    seed = 31 * H + W + T
+    rng = np.random.default_rng(seed)
+    params = synth.make_params({"conv_trans.conv.weight": (256, 384, 1, 1), "conv_trans.conv.bias": (256,)}, seed)
+    wc = params["conv_trans.conv.weight"].reshape(256, 384)
+    bc = params["conv_trans.conv.bias"]
+    cur = np.stack([synth.smooth_features(rng, 128, H, W) for _ in range(T)])
+    prev_pm = None
+    if not level0:
+        prev_pm = np.stack([synth.smooth_features(rng, 256, H // 2, W // 2).reshape(256, -1).T * 1.5 for _ in range(T)])
+    st = orc.Storage.bf16_policy()
+    t_prev = to_bf16_t(prev_pm, cuda) if prev_pm is not None else None
+    if nchw:
+        t_cur = torch.from_numpy(cur).to(cuda)
+        cur_seen = cur
+    else:
+        t_cur = to_bf16_t(cur.reshape(T, 128, H * W).transpose(0, 2, 1), cuda)
+        cur_seen = bf16_t_to_np(t_cur).transpose(0, 2, 1).reshape(T, 128, H, W)
+    out = ops.level_fuse(t_cur, t_prev, torch.from_numpy(wc).to(cuda).to(torch.bfloat16).contiguous(),
+                         torch.from_numpy(bc).to(cuda), H, W)
+    torch.cuda.synchronize()
+    out = bf16_t_to_np(out)
+    flips = total = 0
+    worst = 0.0
+    for t in range(T):
+        prev = None
+        if not level0:
+            prev = bf16_t_to_np(t_prev)[t].T.reshape(256, H // 2, W // 2)
+        ref = orc.fuse_level(cur_seen[t].astype(np.float32), prev, wc, bc, st)
+        d = np.abs(out[t] - ref)
+        ulp = _ulp_bf16(np.maximum(np.abs(out[t]), np.abs(ref)))
+        ij = np.unravel_index(np.argmax(d - ulp), d.shape)
+        assert (d <= ulp * 1.001 + 1e-5).all(), f"more than one bf16 ulp off at {ij}: got {out[t][ij]!r} ref {ref[ij]!r}"
+        flips += int((d > 0).sum())
+        total += d.size
+        worst = max(worst, d.max())
+    print(f"\n[level_fuse T{T} {H}x{W} level0={level0} nchw={nchw}] max |d| {worst:.3e}, flipped {100 * flips / total:.3f}%")
+    assert flips / total < 0.01
