@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol the header declares, the ctypes table covers the header, and the product never imports the oracle."""
+import os
+import re
+
+from util import ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "slotvps_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(svps_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from slotvps_amd import _lib
+    lib = _lib.load()                       # raises if the .so is missing or a symbol is absent
+    syms = _header_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/slotvps_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == syms, (sorted(set(syms) ^ set(_lib.SIGNATURES)))
+    assert lib.svps_abi_version() == 1
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    """Entry points validate before touching the device: bad arguments return SVPS_ERR_* codes."""
+    import ctypes
+    from slotvps_amd import _lib
+    lib = _lib.load()
+    assert lib.svps_slot_attn_workspace_bytes(0, 100, 10, 0) == 0
+    assert lib.svps_slot_attn_fwd(None, None, None, None, None, 1e-5, None, 0, None, None, 1, 100, 64, 256, 0, 0, None) == -1
+    assert lib.svps_mask_decode_fwd(None, None, None, None, 1.0, 0.0, None, None, 1, 1, 1, 256, 0, None) == -1
+    assert lib.svps_pos_embed_sine(None, 4, 4, 256, None) == -1
+    c, t, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert lib.svps_slot_attn_plan(5, 100, 131072, 0, ctypes.byref(c), ctypes.byref(t), ctypes.byref(p)) == 0
+    assert c.value * t.value * p.value >= 131072 and (c.value - 1) * t.value * p.value < 131072
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|slotvps_oracle", re.M)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "slotvps_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), f"{f} references the oracle"
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    import pytest
+    import torch
+    from slotvps_amd import ops
+    x = torch.zeros((1, 8, 256), dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.slot_attn(x, x, x, torch.ones(256), torch.zeros(256))
+    with pytest.raises(RuntimeError):
+        ops.pos_embed_sine(4, 4, 256, "cpu")
+    with pytest.raises(RuntimeError):
+        ops.level_fuse(torch.zeros(1, 128, 2, 2), None, torch.zeros(256, 384, dtype=torch.bfloat16), torch.zeros(256), 2, 2)
