@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslotvps_hip.so")
+LIB_PATH = os.environ.get("SLOTVPS_LIB") or os.path.join(_HERE, "libslotvps_hip.so")   # env: A/B builds
 
 ERR_NAMES = {-1: "SVPS_ERR_BAD_ARG", -2: "SVPS_ERR_BAD_SHAPE", -3: "SVPS_ERR_WORKSPACE"}
 

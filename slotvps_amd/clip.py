@@ -29,7 +29,7 @@ class SlotClipRunner:
     """Owns a head replica, the slot initialisation, the decode BatchNorms and (optionally) a captured
     hipGraph of one clip step. All tensors live on `device`."""
 
-    def __init__(self, device, T, H, W, L=100, param_seed=0, cfg=None, split_p=True, use_graph=True):
+    def __init__(self, device, T, H, W, L=100, param_seed=0, cfg=None, split_p=True, use_graph=True, n_slots=1):
         if torch.device(device).type != "cuda":
             raise RuntimeError("SlotClipRunner runs on the GPU only; there is no CPU fallback")
         self.device = torch.device(device)
@@ -53,9 +53,15 @@ class SlotClipRunner:
             self.fg_bn.bias.zero_()
         self.refold()
         self.pos_tabs = [ops.pos_embed_sine_tables(h, w, self.cfg["dh_dim"], self.device) for (h, w) in self.sizes]
-        self.static_feats = [torch.zeros((T, 128, h, w), device=self.device) for (h, w) in self.sizes]
+        # n_slots independent input buffer sets, each with its own captured graph: the producer of the
+        # FPN maps writes clip i straight into slot i % n_slots, so no staging copy sits in the step
+        self.n_slots = n_slots
+        self.slots_feats = [[torch.zeros((T, 128, h, w), device=self.device) for (h, w) in self.sizes]
+                            for _ in range(n_slots)]
+        self.static_feats = self.slots_feats[0]
         self.use_graph = use_graph
-        self.graph = None
+        self.graphs = [None] * n_slots
+        self.outs = [None] * n_slots
         self.out = None
 
     def refold(self):
@@ -65,34 +71,36 @@ class SlotClipRunner:
             fs, fb = fold_bn_eval(self.fg_bn)
             self.fg_scale, self.fg_shift = float(fs.item()), float(fb.item())
 
-    def _step(self):
-        logits, embeds, fused = self.head.forward_clip(self.static_feats, self.init_slots, self.pos_tabs)
+    def _step(self, slot=0):
+        logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs)
         masks, amax = ops.mask_decode(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift,
                                       self.fg_scale, self.fg_shift, want_argmax=True)
         return dict(class_logits=logits, slot_embeds=embeds, mask_logits=masks, slot_argmax=amax)
 
-    def load_clip(self, feats):
-        for dst, src in zip(self.static_feats, feats):
+    def load_clip(self, feats, slot=0):
+        for dst, src in zip(self.slots_feats[slot], feats):
             dst.copy_(src)
 
     @torch.no_grad()
-    def run(self):
-        """One clip step on the clip currently in the static input buffers."""
+    def run(self, slot=0):
+        """One clip step on the clip currently in input slot `slot`."""
         if not self.use_graph:
-            self.out = self._step()
+            self.out = self._step(slot)
             return self.out
-        if self.graph is None:
+        if self.graphs[slot] is None:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 for _ in range(2):                      # warm-up: lazy inits, kernel attributes, allocator
-                    self._step()
+                    self._step(slot)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = self._step()
-        self.graph.replay()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.outs[slot] = self._step(slot)
+            self.graphs[slot] = g
+        self.graphs[slot].replay()
+        self.out = self.outs[slot]
         return self.out
 
     def random_clip(self, seed):
