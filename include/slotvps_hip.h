@@ -137,6 +137,17 @@ int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, 
                         const float* bc, void* out, int T, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K5 fused slot-side row step (rows of D = 256 fp32 values), one launch instead of add + LayerNorm +
+ * ReLU + cast kernels between the small GEMMs of the slot update
+ * (mmdet/models/detectors/dynamic_mask_head.py:356-358, :374-376, :384-385, :394-397, :431, :515-525, :555-570):
+ *     y = LayerNorm(x [+ pre]) * w[g] + b[g];  y = relu(y) if relu;  y += post if post;  g = row / rows_per_group
+ *   x, pre, post [rows, D] fp32 (pre / post may be NULL); w, b [G, D] fp32 with G = ceil(rows / rows_per_group);
+ *   out_f32 [rows, D] and / or out_bf16 [rows, D] (at least one non-NULL).
+ * ------------------------------------------------------------------------------------------- */
+int svps_row_ln(const float* x, const float* pre, const float* post, const float* w, const float* b, float eps,
+                int relu, int rows, int rows_per_group, int D, float* out_f32, void* out_bf16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Profiling hooks: when enabled every kernel launch of this library is bracketed by HIP events on
  * the launch stream. svps_prof_collect synchronises those events (host-blocking) and returns the
  * summed device time of one kernel id. Used by bench.py for the roofline line.

@@ -36,6 +36,7 @@ SIGNATURES = {
     "svps_kv_project_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp,
                                  _i, _i, _i, _i, _vp]),
     "svps_level_fuse_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "svps_row_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

@@ -182,6 +182,35 @@ def level_fuse(cur, prev, wc, bc, H, W):
     return out
 
 
+def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=None, out_bf16=False):
+    """K5: y = LN(x [+ pre]) * w[g] + b[g] (+ReLU) (+post); x [..., 256] fp32; w, b [256] or [G, 256]
+    (group g = row // rows_per_group). Returns fp32, or bf16 when out_bf16."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    shape = x.shape
+    rows = x.numel() // shape[-1]
+    if shape[-1] != D_MODEL:
+        raise ValueError("row_ln works on rows of 256 values")
+    for name, tns in (("pre", pre), ("post", post)):
+        if tns is not None:
+            _need(tns, name, torch.float32)
+            if tns.shape != shape:
+                raise ValueError(f"{name} shape mismatch")
+    _need(w, "w", torch.float32)
+    _need(b, "b", torch.float32)
+    groups = w.numel() // D_MODEL
+    if rows_per_group is None:
+        rows_per_group = rows if groups == 1 else -(-rows // groups)
+    if groups * rows_per_group < rows or b.numel() != w.numel():
+        raise ValueError("affine groups do not cover the rows")
+    out = torch.empty(shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    rc = lib.svps_row_ln(_ptr(x), _ptr(pre), _ptr(post), _ptr(w), _ptr(b), float(eps), int(bool(relu)), rows,
+                         rows_per_group, D_MODEL, _ptr(None if out_bf16 else out), _ptr(out if out_bf16 else None),
+                         _stream_ptr())
+    _lib.check(rc, "svps_row_ln")
+    return out
+
+
 class KernelTimer:
     """Device-time accounting of the library's own launches (HIP events on the launch stream)."""
 

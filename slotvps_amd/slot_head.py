@@ -8,8 +8,9 @@ What runs where
   * K3 (HIP): the pixel-side projections k = norm_k(to_k(f + pos)), v = norm_v(to_v(f)) (:432-433)
     for all T frames, written as the bf16 tensors K1 streams.
   * K4 (HIP): the level fusion  f_i = conv1x1(cat(bilinear_x2(f_{i-1}), x_i))  (:171-188).
-  * PyTorch-ROCm (plumbing around the kernels, same math as the reference lines cited inline): the
-    slot-side operators on [T, L, 256] tensors (self-attention, FFN, temporal head, towers).
+  * K5 (HIP): every  residual + LayerNorm (+ReLU) (+cast)  step of the slot update, one launch each.
+  * PyTorch-ROCm (plumbing around the kernels, same math as the reference lines cited inline): the small
+    GEMMs of the slot side on [T, L, 256] tensors (self-attention, FFN, temporal head, towers).
 There is no CPU path: modules raise if their tensors are not on a GPU.
 
 Storage policy (what is rounded to bf16 in HBM): the fused level map f, the projection operand f+pos,
@@ -40,6 +41,17 @@ def _get_activation_fn(activation):
 
 def _get_clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+def _cached(module, name, params, build):
+    """Derived tensors (stacked / transposed / bf16 copies of parameters), rebuilt when a source changes."""
+    key = tuple((p.data_ptr(), p._version) for p in params)
+    store = module.__dict__.setdefault("_derived", {})
+    hit = store.get(name)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            store[name] = (key, build())
+    return store[name][1]
 
 
 class ConvModule(nn.Module):
@@ -95,7 +107,7 @@ class MaskDynamicConv(nn.Module):
 
     def forward_pm(self, slots, feat_pm, hw, pos_tabs):
         """slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16 -> [T, L, C] fp32 (K3 then K1)."""
-        q = self.norm_q(self.to_q(slots)).to(BF16).contiguous()
+        q = ops.row_ln(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps, out_bf16=True)
         k, v = self.project_kv(feat_pm, hw, pos_tabs)
         return ops.slot_attn(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps, split_p=self.split_p)
 
@@ -141,12 +153,26 @@ class SlotsDynamicConv(nn.Module):
         self.activation = nn.ReLU(inplace=True)
 
     def forward(self, curr_features, features, pos):
-        q = self.norm_q(self.to_q(curr_features))
-        k = self.norm_k(self.to_k(features if pos is None else features + pos))
-        v = self.norm_v(self.to_v(features))
+        if pos is not None or curr_features is not features:
+            q = self.norm_q(self.to_q(curr_features))
+            k = self.norm_k(self.to_k(features if pos is None else features + pos))
+            v = self.norm_v(self.to_v(features))
+        else:
+            # the call site of the head (q, k, v all from the same T*L slots): one batched GEMM for the
+            # three projections and one K5 launch for the three LayerNorms
+            x = curr_features.reshape(-1, self.hidden_dim)
+            lins, norms = (self.to_q, self.to_k, self.to_v), (self.norm_q, self.norm_k, self.norm_v)
+            w3 = _cached(self, "w3", [m.weight for m in lins], lambda: torch.stack([m.weight.t() for m in lins]).contiguous())
+            b3 = _cached(self, "b3", [m.bias for m in lins], lambda: torch.stack([m.bias for m in lins]).unsqueeze(1).contiguous())
+            g3 = _cached(self, "g3", [m.weight for m in norms], lambda: torch.stack([m.weight for m in norms]).contiguous())
+            e3 = _cached(self, "e3", [m.bias for m in norms], lambda: torch.stack([m.bias for m in norms]).contiguous())
+            qkv = torch.baddbmm(b3, x.unsqueeze(0).expand(3, -1, -1), w3)            # [3, M, C]
+            qkv = ops.row_ln(qkv, g3, e3, self.norm_q.eps, rows_per_group=x.shape[0])
+            q, k, v = qkv[0:1], qkv[1:2], qkv[2:3]
         # softmax over the QUERY axis (dim=1 of [1, Lq, Lk], :562) = last-dim softmax of the transposed logits
         attn_t = torch.softmax(k @ q.transpose(-1, -2), dim=-1)     # [1, Lk, Lq]
-        return self.activation(self.norm1(attn_t.transpose(-1, -2) @ v))
+        out = attn_t.transpose(-1, -2) @ v
+        return ops.row_ln(out.contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)
 
 
 @HEADS.register_module
@@ -167,13 +193,18 @@ class TemporalSlotsHead(nn.Module):
         self.norm3 = nn.LayerNorm(d_model)
         self.activation = _get_activation_fn(activation)
 
-    def forward(self, features, mask_query, pos=None, query_pos=None):
+    def forward(self, features, mask_query, pos=None, query_pos=None, add_input=False):
+        """:494-527. add_input=True additionally returns mask_query + result (the caller's residual, :317)
+        fused into the last K5 launch."""
         assert query_pos is None
         x = mask_query.view(1, -1, self.d_model)
-        f = features.view(1, -1, self.d_model)
-        x = self.norm2(x + self.inst_interact(x, f, pos))
-        x = self.norm3(x + self.linear2(self.activation(self.linear1(x))))
-        return x.squeeze(0)
+        f = x if features is mask_query else features.view(1, -1, self.d_model)
+        r = self.inst_interact(x, f, pos)
+        u = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x.contiguous())          # :515-517
+        y = self.linear2(self.activation(self.linear1(u)))                                                    # :520
+        out = ops.row_ln(y, self.norm3.weight, self.norm3.bias, self.norm3.eps, pre=u,
+                         post=x.contiguous() if add_input else None)                                          # :524-525
+        return out.squeeze(0)
 
 
 class MaskRCNNHead(nn.Module):
@@ -210,28 +241,42 @@ class MaskRCNNHead(nn.Module):
         self.scale_clamp = scale_clamp
 
     def forward_till_ffn_pm(self, slots, feat_pm, hw, pos_tabs):
-        """:342-388 for all frames at once. slots [T, L, C] fp32."""
+        """:342-388 for all frames at once. slots [T, L, C] fp32 contiguous."""
         x = slots.transpose(0, 1)                                           # [L, T, C]: sequence-first, frames = batch
-        x = self.norm1(x + self.self_attn(x, x, value=x, key_padding_mask=None, need_weights=False)[0])
-        x = x.transpose(0, 1)
-        x = self.norm2(x + self.inst_interact.forward_pm(x.contiguous(), feat_pm, hw, pos_tabs))
-        return self.norm3(x + self.linear2(self.activation(self.linear1(x))))
+        a = self.self_attn(x, x, value=x, key_padding_mask=None, need_weights=False)[0].transpose(0, 1).contiguous()
+        x1 = ops.row_ln(a, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre=slots)                 # :356-358
+        r = self.inst_interact.forward_pm(x1, feat_pm, hw, pos_tabs)                                        # :368
+        x2 = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x1)                     # :374-376
+        y = self.linear2(self.activation(self.linear1(x2)))                                                  # :379
+        return ops.row_ln(y, self.norm3.weight, self.norm3.bias, self.norm3.eps, pre=x2)                   # :384-385
 
     def forward_after_ffn_pm(self, obj):
-        """:390-400 -> (class_logits [T, L, nc], slot embedding [T, L, C])."""
-        c = r = obj
-        for layer in self.cls_module:
-            c = layer(c)
-        for layer in self.reg_module:
-            r = layer(r)
-        return self.class_logits(c), r
+        """:390-400 -> (class_logits [T, L, nc], slot embedding [T, L, C]). The class and the embedding tower
+        have the same shape, so layer i of both runs as one batched GEMM + one K5 launch."""
+        T, L, C = obj.shape
+        if len(self.cls_module) != len(self.reg_module):
+            c = r = obj
+            for layer in self.cls_module:
+                c = layer(c)
+            for layer in self.reg_module:
+                r = layer(r)
+            return self.class_logits(c), r
+        x = obj.reshape(1, T * L, C).expand(2, -1, -1)
+        for i in range(0, len(self.cls_module), 3):
+            lc, lr = self.cls_module[i], self.reg_module[i]
+            nc, nr = self.cls_module[i + 1], self.reg_module[i + 1]
+            w2 = _cached(self, f"tw{i}", [lc.weight, lr.weight], lambda: torch.stack([lc.weight.t(), lr.weight.t()]).contiguous())
+            g2 = _cached(self, f"tg{i}", [nc.weight, nr.weight], lambda: torch.stack([nc.weight, nr.weight]).contiguous())
+            e2 = _cached(self, f"te{i}", [nc.bias, nr.bias], lambda: torch.stack([nc.bias, nr.bias]).contiguous())
+            x = ops.row_ln(torch.bmm(x, w2), g2, e2, nc.eps, relu=True, rows_per_group=T * L)               # :394-397
+        return self.class_logits(x[0].reshape(T, L, C)), x[1].reshape(T, L, C)
 
     def forward_pm(self, slots, feat_pm, hw, pos_tabs, stage_enable):
         T, L, C = slots.shape
-        obj = self.forward_till_ffn_pm(slots, feat_pm, hw, pos_tabs)
+        obj = self.forward_till_ffn_pm(slots.contiguous(), feat_pm, hw, pos_tabs)
         if stage_enable:
             flat = obj.reshape(T * L, C)                                    # concat along the slot axis (:310)
-            obj = (flat + self.temporal_query_head(features=flat, mask_query=flat)).reshape(T, L, C)   # :313-322
+            obj = self.temporal_query_head(features=flat, mask_query=flat, add_input=True).reshape(T, L, C)   # :313-322
         else:
             assert self.temporal_query_head is None
         return self.forward_after_ffn_pm(obj)
