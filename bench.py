@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--slots", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--fast-p", action="store_true", help="bf16 P without the hi/lo split inside K1")
-    ap.add_argument("--clips-in-flight", type=int, default=1,
+    ap.add_argument("--clips-in-flight", type=int, default=2,
                     help="independent clips per step, each replayed on its own HIP stream (a step then covers that many clips)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 to skip the CPU oracle leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -166,8 +166,15 @@ def main():
         runner.use_graph = eager
         alg = runner.k1_algorithmic_bytes_per_step() * a.steps * cif
         achieved = alg / (k1_ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01", "k1_pmc_traffic.json")
+        if os.path.exists(pmc) and (a.height, a.width, a.frames, a.slots) == (1024, 2048, 5, 100):
+            with open(pmc) as fh:
+                rec = json.load(fh)
+            traffic = int(rec["traffic_bytes_per_launch"])          # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, avg per K1 launch
+            traffic_src = "profiles/r01/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "slot_attn_partial_ws", "launches": k1_n, "avg_launch_us": round(k1_ms / k1_n * 1e3, 2),
                 "algorithmic_bytes_per_launch_avg": int(alg / k1_n),
                 "other_kernels_us_per_clip": {"slot_attn_finish": round(fin_ms / a.steps / cif * 1e3, 1),
