@@ -120,3 +120,36 @@ def make_clip_features(seed, T, H, W, C=128):
 def make_slots(seed, L):
     rng = np.random.default_rng(seed)
     return rng.standard_normal((L, D)).astype(np.float32)
+
+
+def make_post_case(seed, L=100, h=16, w=32, num_classes=20, n_keep=18):
+    """Synthetic head outputs for the panoptic post-process: class_logits [L, nc] with `n_keep` confident
+    slots (stuff classes incl. duplicates, thing classes incl. heavily overlapping same-class pairs and
+    tiny blobs) and smooth blob-shaped mask logits [L, h, w]."""
+    rng = np.random.default_rng(seed)
+    logits = rng.standard_normal((L, num_classes)).astype(np.float32)
+    logits[:, num_classes - 1] += 6.0                                   # default: "no object"
+    chosen = rng.choice(L, size=n_keep, replace=False)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    masks = (0.3 * rng.standard_normal((L, h, w)) - 1.0).astype(np.float32)
+    centers = rng.uniform([0, 0], [h, w], size=(n_keep, 2))
+    for n, s in enumerate(chosen):
+        if n < 6:
+            c = [0, 1, 2, 2, 8, 10][n]                                  # stuff, one duplicated class
+            sig = rng.uniform(0.35, 0.6) * max(h, w)
+        else:
+            c = int(rng.integers(11, num_classes - 1))                  # things
+            sig = rng.uniform(0.05, 0.2) * max(h, w)
+            if n % 4 == 0:                                              # same class + nearly same place as the previous thing
+                c = prev_c
+                centers[n] = centers[n - 1] + rng.normal(0, 0.5, 2)
+            if n % 7 == 6:
+                sig = 0.35                                              # sub-pixel blob: dies in the small-area filter
+        prev_c = c
+        logits[s] = rng.standard_normal(num_classes).astype(np.float32) * 0.3
+        logits[s, c] += rng.uniform(6.0, 9.0)
+        d2 = (yy - centers[n, 0]) ** 2 + (xx - centers[n, 1]) ** 2
+        amp = rng.uniform(1.5, 3.0) if n < 6 else rng.uniform(5.0, 9.0)     # things stand out of the stuff
+        masks[s] = (amp * np.exp(-d2 / (2 * sig * sig)) - rng.uniform(0.3, 1.2)
+                    + 0.15 * rng.standard_normal((h, w))).astype(np.float32)
+    return logits, masks
