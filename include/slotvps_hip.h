@@ -45,6 +45,7 @@ extern "C" {
 #define SVPS_KERNEL_POS_EMBED 3
 #define SVPS_KERNEL_KV_PROJECT 4
 #define SVPS_KERNEL_LEVEL_FUSE 5
+#define SVPS_KERNEL_PANOPTIC_POST 6
 #define SVPS_KERNEL_COUNT 8
 
 int svps_abi_version(void);
@@ -146,6 +147,27 @@ int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, 
  * ------------------------------------------------------------------------------------------- */
 int svps_row_ln(const float* x, const float* pre, const float* post, const float* w, const float* b, float eps,
                 int relu, int rows, int rows_per_group, int D, float* out_f32, void* out_bf16, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6 full-resolution panoptic post-process (PostProcessPanopticInstances.mask_removal / get_ids_area,
+ * mmdet/models/detectors/vps_temporal_slots.py:564-657, :697-698, :724-757; argmax + relabel of simple_test
+ * :411-435). Bilinear upsampling to H x W is fused into both kernels; the order-dependent part of
+ * mask_removal runs on the small integer tables they produce (slotvps_amd/postprocess.py).
+ *
+ * svps_panoptic_candidates: masks [K, h, w] fp32 low-resolution logits of the K kept slots in DESCENDING score
+ *   order, is_thing [K] uint8. Per full-resolution pixel the (at most two) thing slots whose softmax-over-K
+ *   probability reaches pixel_threshold -> cand [H*W, 2] uint8 (255 = none); counts [K] int32 += pixels per
+ *   slot, pairs [K, K] int32 += pixels per candidate pair (row = earlier slot). counts / pairs zeroed by caller.
+ * svps_panoptic_argmax: per pixel, first-max argmax over the n slots sel[j] (indices into the K list) of the
+ *   masks after removal (stuff: upsampled logit; thing: upsampled logit where it is the first kept candidate,
+ *   0 elsewhere; kept [K] uint8), id = lut[j] -> out_ids [H*W] uint8 (nullable), hist [256] int32 += pixels
+ *   per id (nullable, zeroed by caller), out_masks [n, H*W] fp32 the masks themselves (nullable).
+ * ------------------------------------------------------------------------------------------- */
+int svps_panoptic_candidates(const float* masks, const uint8_t* is_thing, int K, int h, int w, int H, int W,
+                             float pixel_threshold, uint8_t* cand, int* counts, int* pairs, void* stream);
+int svps_panoptic_argmax(const float* masks, const uint8_t* sel, const uint8_t* sel_thing, int n,
+                         const uint8_t* kept, const uint8_t* cand, const uint8_t* lut, int h, int w, int H, int W,
+                         uint8_t* out_ids, int* hist, float* out_masks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Profiling hooks: when enabled every kernel launch of this library is bracketed by HIP events on

@@ -1,0 +1,201 @@
+"""GPU panoptic post-process: host-side mirror of the reference's
+PostProcessPanopticInstances (mmdet/models/detectors/vps_temporal_slots.py:528-807) and of the stuff-first
+reorder / argmax / relabel of simple_test (:411-435) on top of the K6 kernels.
+
+The pixel work (upsampling, softmax, candidate detection, argmax, areas) runs in two HIP kernels; the
+order-dependent decisions of mask_removal and the small-area loop run here on K x K integer tables (K <= 100
+kept slots), exactly as the reference's loops would decide them. Full-resolution masks are never
+materialised unless asked for (`materialize_masks`), the reference's K x 8 MB device->host copy disappears.
+"""
+import ctypes
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+_SOFTMAX_MASKING_CONSTANT = -99999.0
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class PostProcessPanopticInstances(nn.Module):
+    """Same constructor arguments and defaults as the reference class (:532-562)."""
+
+    def __init__(self, is_thing_map=None, threshold=0.85, output_dir="", debug=False, fraction_threshold=0.03,
+                 pixel_threshold=0.4, apply_mask_removal=False, apply_mask_removal_only_ins=False,
+                 use_mask_low_constant=False, catgories_color=None, filter_small_option="4", num_classes=20,
+                 num_stuff=11):
+        super().__init__()
+        self.threshold = threshold
+        self.is_thing_map = is_thing_map if is_thing_map is not None else {i: i > 10 for i in range(21)}
+        self.fraction_threshold = fraction_threshold
+        self.pixel_threshold = pixel_threshold
+        self.apply_mask_removal = apply_mask_removal
+        self.apply_mask_removal_only_ins = apply_mask_removal_only_ins
+        if use_mask_low_constant:
+            raise NotImplementedError("use_mask_low_constant=True is not used by the released configs")
+        if not (apply_mask_removal and apply_mask_removal_only_ins):
+            raise NotImplementedError("the GPU path implements the released configuration: mask removal among instances")
+        self.filter_small_option = filter_small_option
+        self.num_classes = num_classes
+        self.num_stuff = num_stuff
+
+    # ---- kernels -------------------------------------------------------------------------------
+    def _candidates(self, m_sorted, thing_u8, size):
+        lib = _lib.load()
+        K, h, w = m_sorted.shape
+        H, W = size
+        dev = m_sorted.device
+        cand = torch.empty((H * W, 2), dtype=torch.uint8, device=dev)
+        counts = torch.zeros(K, dtype=torch.int32, device=dev)
+        pairs = torch.zeros((K, K), dtype=torch.int32, device=dev)
+        _lib.check(lib.svps_panoptic_candidates(_p(m_sorted), _p(thing_u8), K, h, w, H, W, float(self.pixel_threshold),
+                                                _p(cand), _p(counts), _p(pairs), _stream()), "svps_panoptic_candidates")
+        return cand, counts, pairs
+
+    @staticmethod
+    def _argmax(m_sorted, sel, sel_thing, kept_u8, cand, lut, size, want_ids=False, want_hist=True, want_masks=False):
+        lib = _lib.load()
+        K, h, w = m_sorted.shape
+        H, W = size
+        dev = m_sorted.device
+        n = len(sel)
+        t_sel = torch.tensor(sel if n else [0], dtype=torch.uint8, device=dev)
+        t_thing = torch.tensor(sel_thing if n else [0], dtype=torch.uint8, device=dev)
+        t_lut = torch.tensor(lut if n else [0], dtype=torch.uint8, device=dev)
+        ids = torch.empty(H * W, dtype=torch.uint8, device=dev) if want_ids else None
+        hist = torch.zeros(256, dtype=torch.int32, device=dev) if want_hist else None
+        masks = torch.empty((n, H, W), dtype=torch.float32, device=dev) if want_masks else None
+        _lib.check(lib.svps_panoptic_argmax(_p(m_sorted), _p(t_sel), _p(t_thing), n, _p(kept_u8), _p(cand), _p(t_lut),
+                                            h, w, H, W, _p(ids), _p(hist), _p(masks), _stream()), "svps_panoptic_argmax")
+        return ids, hist, masks
+
+    # ---- the reference's forward, on tensors ---------------------------------------------------------
+    @torch.no_grad()
+    def forward_tensors(self, pred_logits, pred_masks, size, materialize_masks=False):
+        """pred_logits [L, nc], pred_masks [L, h, w] (GPU, fp32), size (H, W).
+        Returns a namespace: slot_index [K''] (into the L slots, the reference's filtered Instances order),
+        probs, labels, (masks [K'', H, W] if materialize_masks), plus the state `panoptic_ids` needs."""
+        if not pred_masks.is_cuda:
+            raise RuntimeError("the panoptic post-process runs on the GPU only; there is no CPU fallback")
+        dev = pred_masks.device
+        nc = pred_logits.shape[-1]
+        scores, classes = pred_logits.float().softmax(-1).max(-1)                                   # :684
+        if nc == self.num_classes - 1:
+            keep = scores > self.threshold
+        else:
+            keep = classes.ne(nc - 1) & (scores > self.threshold)                                    # :688-691
+        idx = torch.nonzero(keep).flatten()
+        if idx.numel() == 0:
+            raise ValueError("no slot passes the score threshold (the reference's mask_removal fails here too, :652)")
+        if idx.numel() > 255:
+            raise NotImplementedError("more than 255 kept slots")
+        sc = scores[idx].cpu().numpy()
+        cl = classes[idx].cpu().numpy()
+        order = sc.argsort()[::-1]                                                                   # :580
+        sorted_idx = idx[torch.from_numpy(order.copy()).to(dev)]
+        sc, cl = sc[order], cl[order]
+        K = len(sc)
+        thing = [bool(c > self.num_stuff - 1) for c in cl]                                           # :594
+        m_sorted = pred_masks[sorted_idx].float().contiguous()
+        thing_u8 = torch.tensor(thing, dtype=torch.uint8, device=dev)
+        cand, counts, pairs = self._candidates(m_sorted, thing_u8, size)
+        n_px = size[0] * size[1]
+        counts_h, pairs_h = counts.cpu().numpy(), pairs.cpu().numpy()
+
+        # ---- mask_removal :601-640 on the tables: stuff kept first, then things by descending score --------
+        kept = [not t for t in thing]
+        for i in range(K):
+            if not thing[i]:
+                continue
+            n_i = int(counts_h[i])
+            if n_i == 0 or n_i == n_px:                               # logit.max() == logit.min() / mask_sum == 0
+                continue
+            overlap = sum(int(pairs_h[j, i]) for j in range(i) if thing[j] and kept[j] and cl[j] == cl[i])
+            if overlap / float(n_i) > self.fraction_threshold:
+                continue
+            kept[i] = True
+        kept_u8 = torch.tensor(kept, dtype=torch.uint8, device=dev)
+        cur = [i for i in range(K) if not thing[i]] + [i for i in range(K) if thing[i] and kept[i]]   # keep_inds order
+
+        # ---- get_ids_area(dedup=True) :759, then the small-area loop :760-790 ------------------------------
+        first_of_class = {}
+        lut = []
+        for j, i in enumerate(cur):
+            if not thing[i]:
+                first_of_class.setdefault(int(cl[i]), j)
+                lut.append(first_of_class[int(cl[i])])
+            else:
+                lut.append(j)
+        _, hist, _ = self._argmax(m_sorted, cur, [thing[i] for i in cur], kept_u8, cand, lut, size)
+        area = hist.cpu().numpy()[:len(cur)].tolist()
+        while len(cur) > 0:
+            if self.filter_small_option == "4":
+                small = [a <= 4 for a in area]
+            elif self.filter_small_option == "4_256":
+                small = [a < 256 if thing[i] else a < 4 for a, i in zip(area, cur)]
+            elif self.filter_small_option == "4096_256":
+                small = [a < 4096 if not thing[i] else a < 256 for a, i in zip(area, cur)]
+            else:
+                raise AssertionError("filter_small_option is not valid !!!!!!")
+            if not any(small):
+                break
+            cur = [i for i, s in zip(cur, small) if not s]
+            _, hist, _ = self._argmax(m_sorted, cur, [thing[i] for i in cur], kept_u8, cand, list(range(len(cur))), size)
+            area = hist.cpu().numpy()[:len(cur)].tolist()
+        res = SimpleNamespace(slot_index=sorted_idx[torch.tensor(cur, dtype=torch.long, device=dev)] if cur else sorted_idx[:0],
+                              probs=torch.from_numpy(sc[cur].copy()).to(dev), labels=torch.from_numpy(cl[cur].copy()).to(dev),
+                              area=area, size=size, _m_sorted=m_sorted, _cur=cur, _thing=thing, _kept_u8=kept_u8, _cand=cand)
+        if materialize_masks:
+            _, _, res.masks = self._argmax(m_sorted, cur, [thing[i] for i in cur], kept_u8, cand, list(range(len(cur))),
+                                           size, want_hist=False, want_masks=True)
+        return res
+
+    def forward(self, outputs, processed_sizes, target_sizes=None, id=None):
+        """Reference signature (:659): `outputs` carries pred_logits [L, nc] and pred_masks [L, h, w]."""
+        if target_sizes is None:
+            target_sizes = processed_sizes
+        assert len(processed_sizes) == len(target_sizes) == 1
+        size = tuple(int(s) for s in processed_sizes[0])
+        return self.forward_tensors(outputs.pred_logits, outputs.pred_masks, size, materialize_masks=True)
+
+    # ---- simple_test :411-435 ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def panoptic_ids(self, res, stuff_num=None):
+        """Stuff-first reorder, per-pixel argmax over the surviving masks and the reference's id relabel.
+        Returns (panoptic_output [H, W] uint8, cls_inds (1-based thing classes), instance probabilities)."""
+        stuff_num = self.num_stuff if stuff_num is None else stuff_num
+        cur, thing = res._cur, res._thing
+        labels = res.labels.cpu().numpy()
+        order = [j for j, i in enumerate(cur) if not thing[i]] + [j for j, i in enumerate(cur) if thing[i]]
+        sel = [cur[j] for j in order]
+        sem = [int(labels[j]) for j in order]
+        panoptic_num = len(cur)
+        instance_num = sum(1 for i in cur if thing[i])
+        # pass 1: which positions own pixels (torch.unique of the argmax map, :420)
+        _, hist, _ = self._argmax(res._m_sorted, sel, [thing[i] for i in sel], res._kept_u8, res._cand,
+                                  list(range(len(sel))), res.size)
+        present = [j for j, a in enumerate(hist.cpu().numpy()[:len(sel)].tolist()) if a > 0]
+        lut = [0] * max(len(sel), 1)
+        count = instance_num
+        for pos in range(len(present) - 1, -1, -1):                    # :424-433
+            oid = present[pos]
+            if oid >= panoptic_num - instance_num:
+                lut[oid] = stuff_num + count - 1
+                count -= 1
+            else:
+                lut[oid] = sem[pos]                                    # position in unique(), not the id (:433)
+        ids, _, _ = self._argmax(res._m_sorted, sel, [thing[i] for i in sel], res._kept_u8, res._cand, lut, res.size,
+                                 want_ids=True, want_hist=False)
+        ins = [j for j in range(len(cur)) if thing[cur[j]]]
+        cls_inds = torch.tensor([int(labels[j]) - (stuff_num - 1) for j in ins], dtype=torch.long)
+        return ids.view(res.size[0], res.size[1]), cls_inds, res.probs[torch.tensor(ins, dtype=torch.long, device=res.probs.device)] \
+            if ins else res.probs[:0]
