@@ -64,6 +64,7 @@ __device__ __forceinline__ float upsample(const float* __restrict__ m, const Tap
 
 // masks [K, h, w]: low-resolution logits of the kept slots in DESCENDING SCORE order; is_thing [K].
 // cand [H*W, 2] (255 = none), counts [K], pairs [K, K] (pairs[i*K + j], i < j) - zeroed by the caller.
+// grid = (ceil(W / 256), H): one output row per blockIdx.y.
 __global__ __launch_bounds__(256) void pp_candidates_kernel(const float* __restrict__ masks,
                                                             const uint8_t* __restrict__ is_thing, int K, int h, int w,
                                                             int H, int W, float thr, uint8_t* __restrict__ cand,
@@ -71,29 +72,48 @@ __global__ __launch_bounds__(256) void pp_candidates_kernel(const float* __restr
     __shared__ int lcount[256];
     lcount[threadIdx.x] = 0;
     __syncthreads();
-    const int px = blockIdx.x * 256 + threadIdx.x;
-    if (px < H * W) {
-        const Taps t = make_taps(px / W, px % W, h, w, H, W);
-        const size_t hw = (size_t)h * w;
+    const int Y = blockIdx.y, X = blockIdx.x * 256 + threadIdx.x;
+    int c0 = 255, c1 = 255;
+    if (X < W) {
+        const Taps t = make_taps(Y, X, h, w, H, W);
+        const int hw = h * w;
         float mx = -INFINITY;
-        for (int k = 0; k < K; ++k) mx = fmaxf(mx, upsample(masks + k * hw, t));
-        float sum = 0.f;
-        for (int k = 0; k < K; ++k) sum += expf(upsample(masks + k * hw, t) - mx);
-        int c0 = 255, c1 = 255;
-        for (int k = 0; k < K; ++k) {
-            if (!is_thing[k]) continue;
-            const float p = expf(upsample(masks + k * hw, t) - mx) / sum;
-            if (p >= thr) {
-                if (c0 == 255) c0 = k;
-                else if (c1 == 255) c1 = k;
+        const float* m = masks;
+        for (int k = 0; k < K; ++k, m += hw) mx = fmaxf(mx, upsample(m, t));
+        // softmax over the K slots exactly as the reference evaluates it: e_k = exp(u_k - max), p_k = e_k / sum.
+        // Only the two largest thing terms can reach a threshold > 1/3, so they are tracked in the same pass.
+        float sum = 0.f, e0 = -1.f, e1 = -1.f;
+        int k0 = 255, k1 = 255;
+        m = masks;
+        for (int k = 0; k < K; ++k, m += hw) {
+            const float e = expf(upsample(m, t) - mx);
+            sum += e;
+            if (is_thing[k]) {
+                if (e > e0) { e1 = e0; k1 = k0; e0 = e; k0 = k; }
+                else if (e > e1) { e1 = e; k1 = k; }
             }
         }
-        cand[2 * (size_t)px] = (uint8_t)c0;
-        cand[2 * (size_t)px + 1] = (uint8_t)c1;
+        const bool p0 = k0 != 255 && e0 / sum >= thr, p1 = k1 != 255 && e1 / sum >= thr;
+        const int a = p0 ? k0 : 255, b = p1 ? k1 : 255;
+        c0 = a < b ? a : b;                              // score order = index order
+        c1 = a < b ? b : a;
+        if (c0 == 255) c1 = 255;
+        const size_t px = (size_t)Y * W + X;
+        cand[2 * px] = (uint8_t)c0;
+        cand[2 * px + 1] = (uint8_t)c1;
         if (c0 != 255) atomicAdd(&lcount[c0], 1);
-        if (c1 != 255) {
-            atomicAdd(&lcount[c1], 1);
-            atomicAdd(&pairs[c0 * K + c1], 1);
+        if (c1 != 255) atomicAdd(&lcount[c1], 1);
+    }
+    // pair counts: wave-aggregated - lanes holding the same (c0, c1) pair elect one atomicAdd
+    {
+        int key = (c1 != 255) ? (c0 << 8 | c1) : -1;
+        unsigned long long todo = __ballot(key >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lk = __shfl(key, leader);
+            const unsigned long long same = __ballot(key == lk);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&pairs[(lk >> 8) * K + (lk & 255)], __popcll(same));
+            todo &= ~same;
         }
     }
     __syncthreads();
@@ -110,26 +130,33 @@ __global__ __launch_bounds__(256) void pp_argmax_kernel(const float* __restrict_
                                                         uint8_t* __restrict__ out_ids, int* __restrict__ hist,
                                                         float* __restrict__ out_masks) {
     __shared__ int lhist[256];
+    __shared__ uint8_t s_sel[256], s_thing[256], s_lut[256];
     lhist[threadIdx.x] = 0;
+    if ((int)threadIdx.x < n) {
+        s_sel[threadIdx.x] = sel[threadIdx.x];
+        s_thing[threadIdx.x] = sel_thing[threadIdx.x];
+        s_lut[threadIdx.x] = lut[threadIdx.x];
+    }
     __syncthreads();
-    const int px = blockIdx.x * 256 + threadIdx.x;
-    if (px < H * W) {
-        const Taps t = make_taps(px / W, px % W, h, w, H, W);
-        const size_t hw = (size_t)h * w;
-        const int c0 = cand[2 * (size_t)px], c1 = cand[2 * (size_t)px + 1];
+    const int Y = blockIdx.y, X = blockIdx.x * 256 + threadIdx.x;
+    if (X < W) {
+        const Taps t = make_taps(Y, X, h, w, H, W);
+        const int hw = h * w;
+        const size_t px = (size_t)Y * W + X;
+        const int c0 = cand[2 * px], c1 = cand[2 * px + 1];
         int claimer = 255;
         if (c0 != 255 && kept[c0]) claimer = c0;
         else if (c1 != 255 && kept[c1]) claimer = c1;
         float best = -INFINITY;
         int bj = 0;
         for (int j = 0; j < n; ++j) {
-            const int k = sel[j];
+            const int k = s_sel[j];
             float v = 0.f;
-            if (!sel_thing[j] || k == claimer) v = upsample(masks + k * hw, t);
+            if (!s_thing[j] || k == claimer) v = upsample(masks + k * hw, t);
             if (out_masks) out_masks[(size_t)j * H * W + px] = v;
             if (v > best) { best = v; bj = j; }      // first maximum wins (torch.argmax)
         }
-        const int id = n > 0 ? lut[bj] : 0;
+        const int id = n > 0 ? s_lut[bj] : 0;
         if (out_ids) out_ids[px] = (uint8_t)id;
         if (hist) atomicAdd(&lhist[id], 1);
     }
@@ -144,9 +171,9 @@ extern "C" int svps_panoptic_candidates(const float* masks, const uint8_t* is_th
     if (!masks || !is_thing || !cand || !counts || !pairs) return SVPS_ERR_BAD_ARG;
     if (K <= 0 || K > 255 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int blocks = (H * W + 255) / 256;
+    if (!(pixel_threshold > 1.f / 3.f)) return SVPS_ERR_BAD_ARG;      // at most two slots may reach the threshold
     svps_prof_mark(SVPS_KERNEL_PANOPTIC_POST, 0, stream);
-    hipLaunchKernelGGL(svps::pp_candidates_kernel, dim3(blocks), dim3(256), 0, stream, masks, is_thing, K, h, w, H, W,
+    hipLaunchKernelGGL(svps::pp_candidates_kernel, dim3((W + 255) / 256, H), dim3(256), 0, stream, masks, is_thing, K, h, w, H, W,
                        pixel_threshold, cand, counts, pairs);
     svps_prof_mark(SVPS_KERNEL_PANOPTIC_POST, 1, stream);
     return (int)hipGetLastError();
@@ -158,9 +185,8 @@ extern "C" int svps_panoptic_argmax(const float* masks, const uint8_t* sel, cons
     if (!masks || !cand || !kept || (n > 0 && (!sel || !sel_thing || !lut))) return SVPS_ERR_BAD_ARG;
     if (n < 0 || n > 255 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int blocks = (H * W + 255) / 256;
     svps_prof_mark(SVPS_KERNEL_PANOPTIC_POST, 0, stream);
-    hipLaunchKernelGGL(svps::pp_argmax_kernel, dim3(blocks), dim3(256), 0, stream, masks, sel, sel_thing, n, kept, cand,
+    hipLaunchKernelGGL(svps::pp_argmax_kernel, dim3((W + 255) / 256, H), dim3(256), 0, stream, masks, sel, sel_thing, n, kept, cand,
                        lut, h, w, H, W, out_ids, hist, out_masks);
     svps_prof_mark(SVPS_KERNEL_PANOPTIC_POST, 1, stream);
     return (int)hipGetLastError();
