@@ -46,6 +46,7 @@ extern "C" {
 #define SVPS_KERNEL_KV_PROJECT 4
 #define SVPS_KERNEL_LEVEL_FUSE 5
 #define SVPS_KERNEL_PANOPTIC_POST 6
+#define SVPS_KERNEL_DEFORM_CONV 7
 #define SVPS_KERNEL_COUNT 8
 
 int svps_abi_version(void);
@@ -168,6 +169,17 @@ int svps_panoptic_candidates(const float* masks, const uint8_t* is_thing, int K,
 int svps_panoptic_argmax(const float* masks, const uint8_t* sel, const uint8_t* sel_thing, int n,
                          const uint8_t* kept, const uint8_t* cand, const uint8_t* lut, int h, int w, int H, int W,
                          uint8_t* out_ids, int* hist, float* out_masks, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7 deformable convolution forward, sampling half: deformable im2col of DCNv1
+ * (mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:82-114, :190-241; host wrapper deform_conv_cuda.cpp:152-258).
+ *   x_nhwc [N, H, W, C] fp32 pixel-major input; offset [N, dg*2*kh*kw, Ho, Wo] fp32 in the reference's layout
+ *   (channel 2*(i*kw+j) = dy, +1 = dx); cols [N, Ho*Wo, C*kh*kw] fp32, column index c*kh*kw + i*kw + j, so the
+ *   convolution is cols @ weight.view(O, -1)^T (the reference's addmm, done by the caller).
+ * ------------------------------------------------------------------------------------------- */
+int svps_deform_im2col(const float* x_nhwc, const float* offset, float* cols, int N, int C, int H, int W, int kh,
+                       int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
+                       int deformable_groups, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Profiling hooks: when enabled every kernel launch of this library is bracketed by HIP events on

@@ -375,3 +375,45 @@ def mask_decode(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift):
 def slot_argmax(mask_logits):
     """argmax over the slot axis per pixel (first maximum wins), uint8. mask_logits [L, HW]."""
     return np.argmax(mask_logits, axis=0).astype(np.uint8)
+
+
+# --------------------------------------------------------------------------------------------
+# f2-ii  deformable convolution (DCNv1)   mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:82-114, :190-241
+# --------------------------------------------------------------------------------------------
+def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, deformable_groups=1):
+    """x [C, H, W], offset [dg*2*kh*kw, Ho, Wo] (channel 2*(i*kw+j) = dy, +1 = dx), weight [O, C, kh, kw]
+    -> [O, Ho, Wo]. Published DCNv1 forward as the reference's CUDA kernel evaluates it: sample at
+    (h_in + i*dil + dy, w_in + j*dil + dx), zero outside (-1, H) x (-1, W), bilinear with out-of-image corners = 0,
+    then the ordinary convolution sum (im2col + addmm, deform_conv_cuda.cpp:152-258). Not pinned by a reference
+    run (the reference's op is CUDA-only, deform_conv.py:44-45); pinned by zero-offset == conv2d and
+    integer-offset == shifted conv properties in the tests."""
+    x = np.asarray(x)
+    C, H, W = x.shape
+    O, _, kh, kw = weight.shape
+    Ho = (H + 2 * padding - (dilation * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * padding - (dilation * (kw - 1) + 1)) // stride + 1
+    cpg = C // deformable_groups
+    ys, xs = np.meshgrid(np.arange(Ho), np.arange(Wo), indexing="ij")
+    cols = np.zeros((C, kh * kw, Ho, Wo), dtype=x.dtype)
+    for g in range(deformable_groups):
+        for i in range(kh):
+            for j in range(kw):
+                t = i * kw + j
+                hf = (ys * stride - padding + i * dilation).astype(x.dtype) + offset[g * 2 * kh * kw + 2 * t]
+                wf = (xs * stride - padding + j * dilation).astype(x.dtype) + offset[g * 2 * kh * kw + 2 * t + 1]
+                inside = (hf > -1) & (wf > -1) & (hf < H) & (wf < W)
+                hl, wl = np.floor(hf).astype(np.int64), np.floor(wf).astype(np.int64)
+                hh, wh = hl + 1, wl + 1
+                lh, lw = hf - hl, wf - wl
+                uh, uw = 1 - lh, 1 - lw
+
+                def tap(hi, wi, ok):
+                    ok = ok & inside
+                    v = x[g * cpg:(g + 1) * cpg][:, np.clip(hi, 0, H - 1), np.clip(wi, 0, W - 1)]
+                    return np.where(ok[None], v, 0)
+                v1 = tap(hl, wl, (hl >= 0) & (wl >= 0))
+                v2 = tap(hl, wh, (hl >= 0) & (wh <= W - 1))
+                v3 = tap(hh, wl, (hh <= H - 1) & (wl >= 0))
+                v4 = tap(hh, wh, (hh <= H - 1) & (wh <= W - 1))
+                cols[g * cpg:(g + 1) * cpg, t] = (uh * uw) * v1 + (uh * lw) * v2 + (lh * uw) * v3 + (lh * lw) * v4
+    return np.einsum("ock,ckhw->ohw", weight.reshape(O, C, kh * kw), cols)

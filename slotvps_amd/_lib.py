@@ -21,6 +21,7 @@ KERNEL_POS_EMBED = 3
 KERNEL_KV_PROJECT = 4
 KERNEL_LEVEL_FUSE = 5
 KERNEL_PANOPTIC_POST = 6
+KERNEL_DEFORM_CONV = 7
 
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
@@ -40,6 +41,7 @@ SIGNATURES = {
     "svps_row_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "svps_panoptic_candidates": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "svps_panoptic_argmax": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "svps_deform_im2col": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

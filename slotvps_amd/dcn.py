@@ -1,0 +1,80 @@
+"""Deformable convolution modules on the HIP path: mirrors of the reference's DeformConv
+(mmdet/ops/dcn/deform_conv.py:217-263) and DeformConvWithOffset (mmdet/models/utils/deform_conv_with_offset.py)
+with the same parameter names (`weight`; `conv_offset.{weight,bias}`, `conv.weight`). Forward = K7 deformable
+im2col + one GEMM, the reference's own decomposition (deform_conv_cuda.cpp:152-258)."""
+import ctypes
+import math
+
+import torch
+from torch import nn
+from torch.nn.modules.utils import _pair
+
+from . import _lib
+
+
+def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
+    """x [N, C, H, W] fp32 (any memory format), offset [N, dg*2*kh*kw, Ho, Wo], weight [O, C, kh, kw] -> [N, O, Ho, Wo]."""
+    if not x.is_cuda:
+        raise RuntimeError("deform_conv runs on the GPU only (the reference has no CPU path either, "
+                           "mmdet/ops/dcn/deform_conv.py:44-45); there is no CPU fallback")
+    if groups != 1:
+        raise NotImplementedError("groups != 1 is not used by the Slot-VPS configs")
+    lib = _lib.load()
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    N, C, H, W = x.shape
+    O, _, kh, kw = weight.shape
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    x_nhwc = x.float().permute(0, 2, 3, 1).contiguous()                 # free for channels_last inputs
+    offset = offset.float().contiguous()
+    if offset.shape != (N, deformable_groups * 2 * kh * kw, Ho, Wo):
+        raise ValueError(f"offset shape {tuple(offset.shape)}")
+    cols = torch.empty((N, Ho * Wo, C * kh * kw), dtype=torch.float32, device=x.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.svps_deform_im2col(p(x_nhwc), p(offset), p(cols), N, C, H, W, kh, kw, ph, pw, sh, sw, dh, dw,
+                                deformable_groups, Ho, Wo, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "svps_deform_im2col")
+    out = cols @ weight.reshape(O, -1).t().float()                       # [N, Ho*Wo, O]
+    return out.view(N, Ho, Wo, O).permute(0, 3, 1, 2)                    # NCHW view over channels_last memory
+
+
+class DeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        assert not bias
+        assert in_channels % groups == 0 and out_channels % groups == 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        n = self.in_channels
+        for k in self.kernel_size:
+            n *= k
+        stdv = 1. / math.sqrt(n)
+        self.weight.data.uniform_(-stdv, stdv)
+
+    def forward(self, x, offset):
+        return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
+                           self.deformable_groups)
+
+
+class DeformConvWithOffset(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=True):
+        super().__init__()
+        self.conv_offset = nn.Conv2d(in_channels, kernel_size * kernel_size * 2 * deformable_groups, kernel_size=3,
+                                     stride=1, padding=1)
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+        self.conv = DeformConv(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                               dilation=dilation, groups=groups, deformable_groups=deformable_groups, bias=False)
+
+    def forward(self, x):
+        return self.conv(x, self.conv_offset(x))
