@@ -4,6 +4,12 @@
 # the reference's own file also loads unchanged through slotvps_amd.config.Config.fromfile.
 model = dict(
     type='VPS_Temporal_Slots',
+    pretrained=None,
+    backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1, norm_eval=True,
+                  style='pytorch'),
+    neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5),
+    panoptic=dict(type='UPSNetFPN', in_channels=256, out_channels=128, num_levels=4, num_things_classes=8,
+                  num_classes=19, ignore_label=255, loss_weight=0.5),
     dynamic_mask_head=dict(
         dh_dim=256,
         num_classes=20,            # 11 stuff + 8 things + no-object
@@ -26,11 +32,19 @@ model = dict(
             d_model=256, dim_feedforward=1024, dropout=0.0, activation="relu", softmax_dim="slots", drop_path=0.),
         apply_temporal_query_atten_stages=[3, 4, 5, 6],
     ),
+    postprocess_panoptic=dict(
+        is_thing_map={i: i > 10 for i in range(20)}, threshold=0.85, fraction_threshold=0.03, pixel_threshold=0.4,
+        apply_mask_removal=True, apply_mask_removal_only_ins=True, use_mask_low_constant=False),
+    simple_track_head=dict(num_fcs_query=2, in_channels_query=256, query_matched_weight=1.0),
     other_config=dict(
         proposal_num=100,
         has_no_obj=True,
         pos_config=dict(position_embedding="sine", hidden_dim=256),
+        test_forward_ref_img=True,
+        test_only_save_main_results=True,
     ),
 )
+train_cfg = None
+test_cfg = dict(loss_pano_weight=None, class_mapping={1: 11, 2: 12, 3: 13, 4: 14, 5: 15, 6: 16, 7: 17, 8: 18})
 # clip geometry of the headline benchmark (BASELINE.json configs[1])
 clip = dict(frames=5, height=1024, width=2048)

@@ -180,3 +180,44 @@ def panoptic_relabel(masks, labels, stuff_num=STUFF_NUM_CITYSCAPES):
         else:
             out[region] = sem[i]                                       # position in unique(), not the id (:433)
     return out, cls_inds, sem
+
+
+def track_assign(cur_embed, prev_embed, fc_w, fc_b):
+    """Tracker step of simple_test (vps_temporal_slots.py:345-409) with SimpleTrackHead.forward
+    (simple_track_head.py:58-92) for num_fcs_query = len(fc_w) layers, test_only_save_main_results=True (the
+    memory holds output embeddings only, :32-37). UNPINNED restatement (no reference test / vector exists; the
+    method needs the whole detector). cur_embed [K, D], prev_embed [P, D] ->
+    (det_obj_ids [K] over ALL segments, updated memory [P', D])."""
+    def fcs(x):
+        for i, (w, b) in enumerate(zip(fc_w, fc_b)):
+            x = x @ w.T + b
+            if i < len(fc_w) - 1:
+                x = np.maximum(x, 0)
+        return x
+    prod = fcs(cur_embed.astype(np.float32)) @ fcs(prev_embed.astype(np.float32)).T
+    score = np.concatenate([np.zeros((prod.shape[0], 1), np.float32), prod], axis=1)
+    z = score - score.max(axis=1, keepdims=True)
+    logprob = z - np.log(np.exp(z).sum(axis=1, keepdims=True))
+    likelihood, match_ids = logprob.max(axis=1), logprob.argmax(axis=1)
+    memory = [e for e in prev_embed]
+    det = -np.ones(len(match_ids), dtype=np.int32)
+    best_scores = -100.0 * np.ones(len(prev_embed))
+    best_ids = -np.ones(len(prev_embed), dtype=np.int32)
+    for idx, mid in enumerate(match_ids):
+        if mid == 0:
+            det[idx] = len(memory)
+            memory.append(cur_embed[idx])
+        else:
+            obj = mid - 1
+            if likelihood[idx] > best_scores[obj]:
+                det[idx] = obj
+                if best_ids[obj] >= 0:
+                    det[best_ids[obj]] = -1
+                best_scores[obj] = likelihood[idx]
+                best_ids[obj] = idx
+                memory[obj] = cur_embed[idx]
+    for idx in range(len(det)):
+        if det[idx] < 0:
+            det[idx] = len(memory)
+            memory.append(cur_embed[idx])
+    return det, np.stack(memory)

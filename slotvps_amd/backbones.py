@@ -1,0 +1,169 @@
+"""PyTorch-ROCm backbone / neck / semantic head with the reference's parameter names, so its checkpoints load
+unchanged: ResNet (mmdet/models/backbones/resnet.py), FPN (mmdet/models/necks/fpn.py), UPSNetFPN
+(mmdet/models/panoptic/upsnetFPN.py). These stay framework code by design (north
+star); only the deformable convolution inside UPSNetFPN runs on a HIP kernel (K7)."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .dcn import DeformConvWithOffset
+from .registry import BACKBONES, NECKS, PANOPTIC
+from .slot_head import ConvModule as Conv1x1Module
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style="pytorch"):
+        super().__init__()
+        s1, s2 = (1, stride) if style == "pytorch" else (stride, 1)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+@BACKBONES.register_module
+class ResNet(nn.Module):
+    arch_settings = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth, num_stages=4, strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3),
+                 style="pytorch", frozen_stages=-1, norm_eval=True, **unused):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f"invalid depth {depth} for resnet")
+        self.out_indices = out_indices
+        self.norm_eval, self.frozen_stages = norm_eval, frozen_stages
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        inplanes = 64
+        self.res_layers = []
+        for i, nb in enumerate(self.arch_settings[depth][:num_stages]):
+            planes = 64 * 2 ** i
+            blocks = []
+            for b in range(nb):
+                stride = strides[i] if b == 0 else 1
+                down = None
+                if b == 0 and (stride != 1 or inplanes != planes * 4):
+                    down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                         nn.BatchNorm2d(planes * 4))
+                blocks.append(Bottleneck(inplanes, planes, stride, dilations[i], down, style))
+                inplanes = planes * 4
+            name = f"layer{i + 1}"
+            self.add_module(name, nn.Sequential(*blocks))
+            self.res_layers.append(name)
+
+    def init_weights(self, pretrained=None):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class _ConvModule(nn.Module):
+    """conv (+ bias) held as `.conv`: the reference's ConvModule without norm / activation."""
+
+    def __init__(self, i, o, k, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(i, o, k, padding=padding)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+@NECKS.register_module
+class FPN(nn.Module):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1, add_extra_convs=False, **unused):
+        super().__init__()
+        if add_extra_convs:
+            raise NotImplementedError("add_extra_convs is not used by the Slot-VPS configs")
+        self.in_channels, self.out_channels, self.num_outs = in_channels, out_channels, num_outs
+        self.start_level = start_level
+        self.backbone_end_level = len(in_channels) if end_level == -1 else end_level
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(_ConvModule(in_channels[i], out_channels, 1))
+            self.fpn_convs.append(_ConvModule(out_channels, out_channels, 3, padding=1))
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [lc(inputs[i + self.start_level]) for i, lc in enumerate(self.lateral_convs)]
+        for i in range(len(laterals) - 1, 0, -1):
+            laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], scale_factor=2, mode="nearest")
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(len(laterals))]
+        for _ in range(self.num_outs - len(outs)):
+            outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+        return tuple(outs)
+
+
+@PANOPTIC.register_module
+class UPSNetFPN(nn.Module):
+    """Shared 3 x [DeformConv3x3 + GroupNorm(32) + ReLU] tower on P2..P5; returns the 128-channel per-level maps
+    coarse -> fine for the slot head and the 19-class semantic logits (upsnetFPN.py:36-73)."""
+
+    def __init__(self, in_channels, out_channels, num_levels, num_things_classes, num_classes, ignore_label,
+                 loss_weight, conv_cfg=None, norm_cfg=None, return_feat_levels=4):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_levels = in_channels, out_channels, num_levels
+        self.num_things_classes, self.num_classes = num_things_classes, num_classes
+        self.ignore_label, self.loss_weight = ignore_label, loss_weight
+        self.deform_convs = nn.ModuleList([nn.Sequential(
+            DeformConvWithOffset(in_channels, in_channels, kernel_size=3, padding=1), nn.GroupNorm(32, in_channels),
+            nn.ReLU(inplace=True),
+            DeformConvWithOffset(in_channels, out_channels, kernel_size=3, padding=1), nn.GroupNorm(32, out_channels),
+            nn.ReLU(inplace=True),
+            DeformConvWithOffset(out_channels, out_channels, kernel_size=3, padding=1), nn.GroupNorm(32, out_channels),
+            nn.ReLU(inplace=True))])
+        self.return_feat_levels = return_feat_levels
+        self.conv_pred = _ConvModule(out_channels * 4, num_classes, 1)
+        self.upsample = nn.Upsample(scale_factor=4, mode="bilinear", align_corners=False)
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d) and m is not None:
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        for m in self.modules():                       # the offset convs stay zero (deform_conv_with_offset.py:25-26)
+            if isinstance(m, DeformConvWithOffset):
+                m.conv_offset.weight.data.zero_()
+                m.conv_offset.bias.data.zero_()
+
+    def forward(self, inputs):
+        assert len(inputs) == self.num_levels
+        px = [self.deform_convs[0](inputs[i]) for i in range(self.num_levels)]
+        feat_before = [px[3], px[2], px[1], px[0]] if self.return_feat_levels == 4 else [px[2], px[1], px[0]]
+        ups = [px[0]] + [F.interpolate(px[i], None, 2 ** i, mode="bilinear", align_corners=False) for i in (1, 2, 3)]
+        fcn_score = self.conv_pred(torch.cat(ups, dim=1))
+        return self.upsample(fcn_score), fcn_score, feat_before

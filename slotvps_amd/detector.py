@@ -1,0 +1,324 @@
+"""Detector-level mirror of the reference: `VPS_Capsule` (image model,
+mmdet/models/detectors/vps_capsule.py:26-133), `SimpleTrackHead` (simple_track_head.py:21-92) and
+`VPS_Temporal_Slots` with its test-time flow (vps_temporal_slots.py:40-499), under the reference's class and
+parameter names so `Config.fromfile(<reference config>)` + `build_detector` resolve and a reference
+checkpoint's keys load unchanged.
+
+What runs where:
+  backbone / FPN / GroupNorm / 1x1 convs       PyTorch-ROCm (MIOpen), by design (north star)
+  deformable conv of UPSNetFPN                 K7
+  level fusion, k/v projection, slot attention, slot-side LayerNorms, mask decode   K4 / K3 / K1 / K5 / K2
+  panoptic post-process, argmax, relabel       K6 (+ K x K host tables)
+  tracker                                      two 256x256 Linear layers + one [K, P] product (PyTorch) and
+                                               the reference's greedy sequential matching on the host
+
+Besides the reference's frame-by-frame `simple_test` (current + reference image per call) there is
+`clip_test`: T frames of a clip through the backbone in one batch and through the slot head as one
+T-frame clip (the reference's own temporal attention is defined over the frames handed in, :284-291).
+"""
+import warnings
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops, registry
+from .instances import Instances
+from .position_encoding import build_position_encoding
+from .postprocess import PostProcessPanopticInstances
+from .registry import DETECTORS, HEADS
+from .slot_head import ConvModule, MultiScaleDynamicMaskHead, fold_bn_eval
+
+
+class _AttrDict(dict):
+    __getattr__ = dict.get
+
+
+def _stuff_num(num_classes):
+    """vps_capsule.py:47-57 / vps_temporal_slots.py:62-72."""
+    if num_classes <= 20:
+        return 11            # Cityscapes(-VPS)
+    if num_classes in (46, 47):
+        return 34            # Mapillary Vistas
+    if num_classes in (23, 24):
+        return 13            # VIPER
+    raise AssertionError(f"self.num_classes: {num_classes}")
+
+
+@HEADS.register_module
+class SimpleTrackHead(nn.Module):
+    """Match scores between the current segments' slot embeddings and the tracked ones: shared fc stack on
+    both, dot products, and a leading all-zero "new object" column (simple_track_head.py:58-92)."""
+
+    def __init__(self, num_fcs_query=0, in_channels_query=0, loss_match=None, query_matched_weight=1.0):
+        super().__init__()
+        self.query_matched_weight = query_matched_weight
+        self.num_fcs_query = num_fcs_query
+        if num_fcs_query > 0:
+            self.fcs_query = nn.ModuleList([nn.Linear(in_channels_query, in_channels_query) for _ in range(num_fcs_query)])
+            self.relu = nn.ReLU(inplace=True)
+        self.init_weights()
+
+    def init_weights(self):
+        if self.num_fcs_query > 0:
+            for fc in self.fcs_query:
+                nn.init.normal_(fc.weight, 0, 0.01)
+                nn.init.constant_(fc.bias, 0)
+
+    def _embed(self, x):
+        for idx in range(self.num_fcs_query):
+            x = self.fcs_query[idx](x)
+            if idx < self.num_fcs_query - 1:
+                x = self.relu(x)
+        return x
+
+    def forward(self, x_query=None, ref_x_query=None):
+        x = self._embed(x_query)
+        refs = ref_x_query if isinstance(ref_x_query, list) else [ref_x_query]
+        scores = []
+        for r in refs:
+            prod = x @ self._embed(r).t()
+            scores.append(torch.cat([prod.new_zeros(prod.size(0), 1), prod], dim=1))
+        return scores
+
+
+def greedy_track_assign(match_logprob, n_prev):
+    """The sequential id assignment of simple_test (vps_temporal_slots.py:350-408) on a [K, 1 + P] matrix of
+    log-probabilities (column 0 = "new object").
+    Returns (det_obj_ids [K] int32, updates): `updates` is the ordered list of (prev_index, cur_index) writes the
+    reference applies to its memory of tracked segments - prev_index == current length appends."""
+    likelihood = match_logprob.max(axis=1)
+    match_ids = match_logprob.argmax(axis=1).astype(np.int32)
+    K = match_ids.shape[0]
+    det = np.full(K, -1, dtype=np.int32)
+    best_score = np.full(n_prev, -100.0)
+    best_idx = np.full(n_prev, -1, dtype=np.int32)
+    n = n_prev
+    updates = []
+    for idx in range(K):
+        m = int(match_ids[idx])
+        if m == 0:                                           # new object
+            det[idx] = n
+            updates.append((n, idx))
+            n += 1
+            continue
+        obj = m - 1
+        if likelihood[idx] > best_score[obj]:                # several candidates may pick one tracked object
+            det[idx] = obj
+            if best_idx[obj] >= 0:
+                det[best_idx[obj]] = -1                      # undo the earlier, weaker match
+            best_score[obj] = likelihood[idx]
+            best_idx[obj] = idx
+            updates.append((obj, idx))
+    for idx in range(K):                                     # losers of a contested match become new objects
+        if det[idx] < 0:
+            det[idx] = n
+            updates.append((n, idx))
+            n += 1
+    return det, updates
+
+
+@DETECTORS.register_module
+class VPS_Capsule(nn.Module):
+    """Image model: backbone, neck, semantic tower, slot initialisation, 1x1 transfer conv, slot head, decode BNs."""
+
+    def __init__(self, backbone, train_cfg, test_cfg, neck=None, panoptic=None, dynamic_mask_head=None,
+                 pretrained=None, other_config=None):
+        super().__init__()
+        self.fp16_enabled = False
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.other_config = other_config if other_config is not None else {}
+        self.cfg = train_cfg if train_cfg is not None else test_cfg
+        self.has_no_obj = self.other_config.get("has_no_obj", True)
+        self.num_classes = dynamic_mask_head["num_classes"]
+        self.stuff_num = _stuff_num(self.num_classes)
+        if self.has_no_obj:
+            assert dynamic_mask_head["num_classes"] in [9, 20, 47, 24]
+        self.backbone = registry.build_backbone(backbone)
+        if neck is not None:
+            self.neck = registry.build_neck(neck)
+        if panoptic is not None:
+            panoptic = dict(panoptic)
+            if "feat_num_levels" in dynamic_mask_head:
+                panoptic["return_feat_levels"] = dynamic_mask_head["feat_num_levels"]
+            self.panopticFPN = registry.build_panoptic(panoptic)
+        if dynamic_mask_head is not None:
+            self.init_mask_query = nn.Embedding(self.other_config.get("proposal_num", 100), dynamic_mask_head["dh_dim"])
+            nn.init.xavier_uniform_(self.init_mask_query.weight)
+            out_ch = panoptic["out_channels"]
+            self.conv_trans = ConvModule(out_ch, self.other_config.get("main_trans_out_dim", out_ch), 1, padding=0,
+                                         activation=None)
+            head_cfg = dict(dynamic_mask_head)
+            head_cfg["other_config"] = other_config
+            self.dynamic_mask_head = MultiScaleDynamicMaskHead(**head_cfg)
+            self.query_feat_num_levels = dynamic_mask_head.get("feat_num_levels", 4)
+            self.multi_scale_heads_num = dynamic_mask_head.get("per_dh_num_heads", [1, 2, 2, 2])
+        pos_cfg = self.other_config.get("pos_config", None)
+        self.position_embedding = build_position_encoding(_AttrDict(pos_cfg) if isinstance(pos_cfg, dict) else pos_cfg)
+        self.fg_bn = nn.BatchNorm2d(1)
+        self.feat_bn = nn.BatchNorm2d(dynamic_mask_head["dh_dim"])
+        self.upsample = nn.Upsample(scale_factor=4, mode="bilinear", align_corners=True)
+        self.init_weights(pretrained=pretrained)
+
+    @property
+    def with_neck(self):
+        return hasattr(self, "neck") and self.neck is not None
+
+    @property
+    def with_panoptic(self):
+        return hasattr(self, "panopticFPN") and self.panopticFPN is not None
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):          # 'modelzoo://resnet50' in the reference config: no network here
+            warnings.warn(f"pretrained={pretrained!r} ignored: no model zoo access, load weights with load_state_dict")
+            pretrained = None
+        self.backbone.init_weights(pretrained=pretrained)
+        if self.with_neck:
+            self.neck.init_weights()
+        if self.with_panoptic:
+            self.panopticFPN.init_weights()
+        with torch.no_grad():                    # vps_capsule.py:129-133
+            self.fg_bn.weight.fill_(0.1)
+            self.fg_bn.bias.zero_()
+            self.feat_bn.weight.fill_(1)
+            self.feat_bn.bias.zero_()
+
+
+@DETECTORS.register_module
+class VPS_Temporal_Slots(nn.Module):
+    def __init__(self, backbone, train_cfg, test_cfg, neck=None, panoptic=None, dynamic_mask_head=None, pretrained=None,
+                 postprocess_panoptic=None, simple_track_head=None, other_config=None):
+        super().__init__()
+        self.fp16_enabled = False
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.other_config = other_config if other_config is not None else {}
+        self.cfg = train_cfg if train_cfg is not None else test_cfg
+        self.has_no_obj = self.other_config.get("has_no_obj", True)
+        self.num_classes = dynamic_mask_head["num_classes"]
+        self.stuff_num = _stuff_num(self.num_classes)
+        self.image_model = VPS_Capsule(backbone, train_cfg, test_cfg, neck=neck, panoptic=panoptic,
+                                       dynamic_mask_head=dynamic_mask_head, pretrained=pretrained, other_config=other_config)
+        self.track_head_config = simple_track_head
+        if simple_track_head is not None:
+            self.temporal_track_head = SimpleTrackHead(**simple_track_head)
+        if postprocess_panoptic is not None:
+            pp = dict(postprocess_panoptic)
+            pp.setdefault("num_stuff", self.stuff_num)
+            self.postprocess_panoptic = PostProcessPanopticInstances(**pp)
+        self.prev_embedding = None
+        self._fold = None
+
+    # ---- pieces of simple_test ---------------------------------------------------------------------
+    def extract_semantic_feats(self, x):
+        n = self.image_model.panopticFPN.num_levels
+        fcn_output, fcn_score, fcn_feature = self.image_model.panopticFPN(x[0:n])
+        return fcn_output.float(), fcn_score, fcn_feature
+
+    def semantic_trans_ins(self, fcn_feature):
+        assert len(fcn_feature) == self.image_model.query_feat_num_levels
+        return [self.image_model.conv_trans(f) for f in fcn_feature]
+
+    def _decode_fold(self):
+        if self._fold is None:                   # eval-mode BatchNorms as the scalars / vectors K2 takes
+            scale, shift = fold_bn_eval(self.image_model.feat_bn)
+            fs, fb = fold_bn_eval(self.image_model.fg_bn)
+            self._fold = (scale, shift, float(fs.item()), float(fb.item()))
+        return self._fold
+
+    def load_state_dict(self, *a, **k):
+        self._fold = None
+        return super().load_state_dict(*a, **k)
+
+    @torch.no_grad()
+    def slot_path(self, imgs):
+        """imgs [T, 3, H, W] -> (class logits [T, L, nc] of the last stage, slot embeddings [T, L, 256],
+        mask logits [T, L, H/4, W/4], semantic logits [T, nc_sem, H, W])."""
+        im = self.image_model
+        x = im.backbone(imgs)
+        if im.with_neck:
+            x = im.neck(x)
+        fcn_output, _, fcn_feature = self.extract_semantic_feats(x)
+        feats = [f.float().contiguous() for f in self.semantic_trans_ins(fcn_feature)]         # coarse -> fine
+        D = im.init_mask_query.weight.shape[1]
+        pos_tabs = [ops.pos_embed_sine_tables(f.shape[-2], f.shape[-1], D, f.device) for f in feats]
+        logits, embeds, fused = im.dynamic_mask_head.forward_clip(feats, im.init_mask_query.weight, pos_tabs)
+        scale, shift, fs, fb = self._decode_fold()
+        masks = ops.mask_decode(fused[-1], embeds[-1].contiguous(), scale, shift, fs, fb)
+        h, w = feats[-1].shape[-2:]
+        return logits[-1], embeds[-1], masks.view(masks.shape[0], masks.shape[1], h, w), fcn_output
+
+    def _track(self, embedding, first):
+        """Tracker step over ALL surviving segments of the frame (stuff and things, :345-409)."""
+        K = embedding.shape[0]
+        if first or self.prev_embedding is None:
+            self.prev_embedding = embedding.clone()
+            return np.arange(K, dtype=np.int64)
+        assert K > 0 and self.prev_embedding.shape[0] > 0
+        score = self.temporal_track_head(embedding, self.prev_embedding)[0]
+        logprob = F.log_softmax(score, dim=1).cpu().numpy()
+        det, updates = greedy_track_assign(logprob, self.prev_embedding.shape[0])
+        n_new = max([p for p, _ in updates] + [self.prev_embedding.shape[0] - 1]) + 1
+        mem = torch.cat([self.prev_embedding, embedding.new_zeros(n_new - self.prev_embedding.shape[0], embedding.shape[1])])
+        for p, c in updates:                      # in order: a later, stronger match overwrites an earlier one
+            mem[p] = embedding[c]
+        self.prev_embedding = mem
+        return det.astype(np.int64)
+
+    def _frame_result(self, pred_logits, pred_masks, embedding, fcn_output, ori_shape, first):
+        H, W = int(ori_shape[0]), int(ori_shape[1])
+        res = self.postprocess_panoptic.forward_tensors(pred_logits, pred_masks, (H, W))
+        det = self._track(embedding[res.slot_index], first)
+        labels = res.labels.cpu()
+        ins = labels > self.stuff_num - 1
+        pan, cls_inds, cls_prob = self.postprocess_panoptic.panoptic_ids(res, self.stuff_num)
+        if fcn_output.shape[-2] != H or fcn_output.shape[-1] != W:
+            fcn_output = F.interpolate(fcn_output, size=(H, W), mode="bilinear", align_corners=False)
+        fcn = fcn_output.argmax(dim=1)            # argmax of the softmax (:447)
+        return {"fcn_outputs": fcn[:, :H, :W], "panoptic_cls_inds": cls_inds, "panoptic_cls_prob": cls_prob.cpu(),
+                "panoptic_det_obj_ids": torch.from_numpy(det)[ins], "panoptic_outputs": pan[None, :H, :W].long()}
+
+    # ---- reference entry points ------------------------------------------------------------------------
+    @torch.no_grad()
+    def simple_test(self, img, img_meta, rescale=False, ref_img=None):
+        """One call per frame like the reference (:208-469): `img` [1, 3, H, W], `ref_img` a list holding the
+        reference frame; the slot head sees the clip [ref, cur] and the current frame's outputs are used."""
+        if ref_img is not None and isinstance(ref_img, (list, tuple)):
+            ref_img = ref_img[0]
+        meta = img_meta[0] if isinstance(img_meta, (list, tuple)) else img_meta
+        iid = meta["iid"]
+        div_mod = 100000 if self.num_classes in (23, 24) else 10000
+        self.vid, self.fid = iid // div_mod, iid % div_mod
+        assert self.other_config.get("test_forward_ref_img", False) is True and ref_img is not None
+        if self.num_classes in (19, 20):
+            assert meta["ori_shape"][0] == img.shape[2] and meta["ori_shape"][1] == img.shape[3]
+        logits, embeds, masks, fcn = self.slot_path(torch.cat([ref_img, img], 0))
+        return self._frame_result(logits[1], masks[1], embeds[1], fcn[1:2], meta["ori_shape"], self.fid == 1)
+
+    @torch.no_grad()
+    def clip_test(self, imgs, img_metas):
+        """T frames of one video at once: imgs [T, 3, H, W], img_metas list of T dicts (iid, ori_shape).
+        Returns one result dict per frame; the tracker runs over the frames in order."""
+        logits, embeds, masks, fcn = self.slot_path(imgs)
+        div_mod = 100000 if self.num_classes in (23, 24) else 10000
+        out = []
+        for t, meta in enumerate(img_metas):
+            out.append(self._frame_result(logits[t], masks[t], embeds[t], fcn[t:t + 1], meta["ori_shape"],
+                                          meta["iid"] % div_mod == 1))
+        return out
+
+    def forward_test(self, imgs, img_metas, rescale=False, ref_img=None):
+        for var, name in [(imgs, "imgs"), (img_metas, "img_metas")]:
+            if not isinstance(var, list):
+                raise TypeError(f"{name} must be a list, but got {type(var)}")
+        if len(imgs) != len(img_metas):
+            raise ValueError(f"num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})")
+        assert imgs[0].size(0) == 1
+        if len(imgs) != 1:
+            raise NotImplementedError("test-time augmentation is not part of the released code path")
+        return self.simple_test(imgs[0], img_metas[0], rescale, ref_img)
+
+    def forward(self, img, img_meta, return_loss=True, rescale=None, ref_img=None):
+        if return_loss:
+            raise AssertionError("NOT RELEASED TRAIN CODE YET !!!!!!")          # vps_temporal_slots.py:497
+        return self.forward_test(img, img_meta, rescale, ref_img)

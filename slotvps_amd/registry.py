@@ -64,7 +64,14 @@ LOSSES = Registry("loss")
 DETECTORS = Registry("detector")
 
 
+def _register_all():
+    """The registering modules are imported on first use, not with the package (they pull in torch.nn
+    model code that the kernel-level entry points do not need)."""
+    from . import backbones, detector  # noqa: F401
+
+
 def build(cfg, registry, default_args=None):
+    _register_all()
     if isinstance(cfg, list):
         return nn.Sequential(*[build_from_cfg(c, registry, default_args) for c in cfg])
     return build_from_cfg(cfg, registry, default_args)

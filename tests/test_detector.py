@@ -1,0 +1,209 @@
+"""Detector-level mirror: config resolution, parameter names, the Instances container, the
+tracker's greedy assignment against the oracle restatement, and (GPU) the whole test-time flow of
+VPS_Temporal_Slots against the CPU oracle applied to the same head outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import postprocess_oracle as porc
+from slotvps_amd.config import Config
+from slotvps_amd.detector import SimpleTrackHead, greedy_track_assign
+from slotvps_amd.instances import Instances
+from slotvps_amd.registry import BACKBONES, DETECTORS, HEADS, NECKS, PANOPTIC, build_detector
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "configs", "r50_fpn_slotvps_mi355x.py")
+REF_CFG = "/root/reference/configs/cityscapes/r50_fpn_slotvps.py"
+
+
+def build(cfg_file=CFG):
+    cfg = Config.fromfile(cfg_file)
+    return build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+
+
+def test_registry_resolves_detector_types():
+    det = build()
+    for reg, name in [(BACKBONES, "ResNet"), (NECKS, "FPN"), (PANOPTIC, "UPSNetFPN"), (HEADS, "SimpleTrackHead"),
+                      (DETECTORS, "VPS_Temporal_Slots"), (DETECTORS, "VPS_Capsule")]:
+        assert reg.get(name) is not None
+    sd = det.state_dict()
+    assert len(sd) == 760
+    # key layout of a reference checkpoint (module attribute names of vps_temporal_slots.py / vps_capsule.py /
+    # resnet.py / fpn.py / upsnetFPN.py / simple_track_head.py)
+    for k in ["image_model.backbone.conv1.weight", "image_model.backbone.layer3.5.bn3.running_var",
+              "image_model.backbone.layer2.0.downsample.0.weight", "image_model.neck.lateral_convs.3.conv.bias",
+              "image_model.neck.fpn_convs.0.conv.weight", "image_model.panopticFPN.deform_convs.0.0.conv_offset.weight",
+              "image_model.panopticFPN.deform_convs.0.6.conv.weight", "image_model.panopticFPN.deform_convs.0.7.bias",
+              "image_model.panopticFPN.conv_pred.conv.weight", "image_model.init_mask_query.weight",
+              "image_model.conv_trans.conv.weight", "image_model.dynamic_mask_head.conv_trans.conv.weight",
+              "image_model.dynamic_mask_head.head_series_3.1.temporal_query_head.inst_interact.to_q.weight",
+              "image_model.fg_bn.weight", "image_model.feat_bn.running_mean", "temporal_track_head.fcs_query.1.bias"]:
+        assert k in sd, k
+    assert tuple(sd["image_model.init_mask_query.weight"].shape) == (100, 256)
+    assert tuple(sd["image_model.panopticFPN.conv_pred.conv.weight"].shape) == (19, 512, 1, 1)
+    assert float(sd["image_model.fg_bn.weight"]) == pytest.approx(0.1)             # vps_capsule.py:129
+    assert not sd["image_model.panopticFPN.deform_convs.0.0.conv_offset.weight"].any()   # zero-initialised offsets
+    assert sum(p.numel() for p in det.image_model.backbone.parameters()) == 23508032      # torchvision R50 trunk
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason="reference tree not present (GPU box)")
+def test_reference_config_builds_same_model():
+    with pytest.warns(UserWarning, match="model zoo"):
+        ref = build(REF_CFG)
+    ours = build()
+    a, b = ref.state_dict(), ours.state_dict()
+    assert list(a) == list(b)
+    assert all(a[k].shape == b[k].shape for k in a)
+    assert ref.postprocess_panoptic.threshold == 0.85 and ref.postprocess_panoptic.pixel_threshold == 0.4
+    assert ref.stuff_num == 11 and ref.num_classes == 20
+
+
+def test_train_path_is_not_released():
+    det = build()
+    with pytest.raises(AssertionError, match="NOT RELEASED TRAIN CODE"):
+        det(img=None, img_meta=None, return_loss=True)
+    with pytest.raises(TypeError):
+        det(img=torch.zeros(1, 3, 8, 8), img_meta=[[{}]], return_loss=False)
+
+
+def test_instances_container():
+    a = Instances((1, 1), emb=torch.arange(12.).view(4, 3), ids=torch.tensor([3, 1, 2, 0]))
+    assert len(a) == 4 and a.has("emb") and not a.has("x")
+    b = a[torch.tensor([True, False, True, False])]
+    assert b.ids.tolist() == [3, 2] and b.emb.shape == (2, 3)
+    c = a[1]
+    assert len(c) == 1 and c.ids.tolist() == [1]
+    d = Instances.cat([a[:1], c, a[2:]])
+    assert d.ids.tolist() == [3, 1, 2, 0]
+    with pytest.raises(AssertionError):
+        a.bad = torch.zeros(3)
+    with pytest.raises(AttributeError):
+        a.missing
+    with pytest.raises(IndexError):
+        a[4]
+    assert a.to(torch.device("cpu")).ids.tolist() == [3, 1, 2, 0]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tracker_matches_oracle(seed):
+    rng = np.random.default_rng(seed)
+    K, P, D = int(rng.integers(1, 14)), int(rng.integers(1, 14)), 32
+    head = SimpleTrackHead(num_fcs_query=2, in_channels_query=D)
+    with torch.no_grad():
+        for fc in head.fcs_query:
+            fc.weight.normal_(0, 0.4, generator=torch.Generator().manual_seed(seed))
+            fc.bias.normal_(0, 0.1, generator=torch.Generator().manual_seed(seed + 9))
+    cur = rng.standard_normal((K, D)).astype(np.float32)
+    prev = rng.standard_normal((P, D)).astype(np.float32)
+    if K > 2 and P > 1:
+        cur[1] = prev[0] * 2.0            # force a contested match: two segments both closest to tracked object 0
+        cur[2] = prev[0] * 2.1
+    with torch.no_grad():
+        score = head(torch.from_numpy(cur), torch.from_numpy(prev))[0]
+        logprob = torch.log_softmax(score, 1).numpy()
+    det, updates = greedy_track_assign(logprob, P)
+    mem = [p for p in prev]
+    for p, c in updates:
+        if p == len(mem):
+            mem.append(cur[c])
+        else:
+            mem[p] = cur[c]
+    fw = [fc.weight.detach().numpy() for fc in head.fcs_query]
+    fb = [fc.bias.detach().numpy() for fc in head.fcs_query]
+    want_det, want_mem = porc.track_assign(cur, prev, fw, fb)
+    assert det.tolist() == want_det.tolist()
+    np.testing.assert_array_equal(np.stack(mem), want_mem)
+    assert len(set(det.tolist())) == K                     # ids are unique within a frame
+    assert score.shape == (K, P + 1) and not score[:, 0].any()
+
+
+# ------------------------------------------------ GPU: the whole test-time flow --------------------------------
+def _make_detector(dev):
+    torch.manual_seed(0)
+    det = build().to(dev).eval()
+    with torch.no_grad():
+        det.image_model.fg_bn.weight.fill_(40.0)            # spread the mask logits so that things claim pixels
+        for fc in det.temporal_track_head.fcs_query:
+            fc.weight.normal_(0, 0.2)
+        cls = det.image_model.dynamic_mask_head.head_series_3[-1].class_logits
+        cls.weight.normal_(0, 0.5)                          # confident, varied classes from random weights
+    det._fold = None
+    det.postprocess_panoptic.threshold = 0.3
+    return det
+
+
+@pytest.mark.gpu
+def test_clip_flow_matches_oracle_pipeline():
+    dev = torch.device("cuda:0")
+    det = _make_detector(dev)
+    T, H, W = 3, 128, 256
+    imgs = torch.randn(T, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    metas = [dict(iid=10001 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png") for t in range(T)]
+    logits, embeds, masks, fcn = det.slot_path(imgs)
+    assert logits.shape == (T, 100, 20) and embeds.shape == (T, 100, 256) and masks.shape == (T, 100, H // 4, W // 4)
+    assert fcn.shape == (T, 19, H, W)
+    # random-init slots all predict one class: add a fixed per-slot class preference so that stuff, things,
+    # duplicates of a stuff class and "no object" all occur. The frozen outputs are handed to both sides (the
+    # PyTorch backbone is not run-to-run deterministic - MIOpen picks algorithms at first use).
+    logits = logits + 4.0 * torch.randn(100, 20, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+    det.slot_path = lambda _imgs: (logits, embeds, masks, fcn)
+    results = det.clip_test(imgs, metas)
+    fw = [fc.weight.detach().cpu().numpy() for fc in det.temporal_track_head.fcs_query]
+    fb = [fc.bias.detach().cpu().numpy() for fc in det.temporal_track_head.fcs_query]
+    memory, n_things = None, 0
+    for t in range(T):
+        want = porc.postprocess(logits[t].cpu().numpy(), masks[t].cpu().numpy(), (H, W), threshold=0.3)
+        pan, cls_inds, _ = porc.panoptic_relabel(want["masks"], want["labels"])
+        emb = embeds[t].cpu().numpy()[want["slot_index"]]
+        if memory is None:
+            det_ids, memory = np.arange(len(emb)), emb.copy()
+        else:
+            det_ids, memory = porc.track_assign(emb, memory, fw, fb)
+        ins = want["labels"] > 10
+        got = results[t]
+        np.testing.assert_array_equal(got["panoptic_outputs"][0].cpu().numpy(), pan)
+        assert got["panoptic_cls_inds"].tolist() == cls_inds.tolist()
+        assert got["panoptic_det_obj_ids"].tolist() == det_ids[ins].tolist()
+        np.testing.assert_allclose(got["panoptic_cls_prob"].numpy(), want["probs"][ins], rtol=1e-6)
+        np.testing.assert_array_equal(got["fcn_outputs"][0].cpu().numpy(), fcn[t].argmax(0).cpu().numpy())
+        assert got["panoptic_outputs"].shape == (1, H, W) and got["fcn_outputs"].shape == (1, H, W)
+        n_things += int(ins.sum())
+    assert n_things > 0, "the synthetic case must exercise the instance / tracker branch"
+    np.testing.assert_allclose(det.prev_embedding.cpu().numpy(), memory, rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_simple_test_reference_call_convention():
+    dev = torch.device("cuda:0")
+    det = _make_detector(dev)
+    H, W = 128, 256
+    g = torch.Generator(device=dev).manual_seed(5)
+    frames = [torch.randn(1, 3, H, W, device=dev, generator=g) for _ in range(3)]
+    outs = []
+    for t in (1, 2):                                         # frame t with frame t-1 as its reference image
+        meta = dict(iid=20000 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png")
+        outs.append(det(img=[frames[t]], img_meta=[[meta]], return_loss=False, rescale=True, ref_img=[frames[t - 1]]))
+    for r in outs:
+        assert set(r) == {"fcn_outputs", "panoptic_cls_inds", "panoptic_cls_prob", "panoptic_det_obj_ids", "panoptic_outputs"}
+        ids = torch.unique(r["panoptic_outputs"])
+        assert (ids[ids > 10]).numel() == len(r["panoptic_cls_inds"])          # the reference's MISMATCH check (:453-458)
+        assert len(r["panoptic_det_obj_ids"]) == len(r["panoptic_cls_inds"]) == len(r["panoptic_cls_prob"])
+
+
+@pytest.mark.gpu
+def test_hip_slot_path_is_deterministic():
+    """Everything after the PyTorch trunk (K4, K3, K1, K5, K2) must be bit-reproducible run to run."""
+    dev = torch.device("cuda:0")
+    det = _make_detector(dev)
+    im = det.image_model
+    g = torch.Generator(device=dev).manual_seed(2)
+    sizes = [(4, 8), (8, 16), (16, 32), (32, 64)]
+    feats = [torch.randn(2, 128, h, w, device=dev, generator=g) for h, w in sizes]
+    from slotvps_amd import ops
+    tabs = [ops.pos_embed_sine_tables(h, w, 256, dev) for h, w in sizes]
+    a = im.dynamic_mask_head.forward_clip(feats, im.init_mask_query.weight, tabs)
+    b = im.dynamic_mask_head.forward_clip(feats, im.init_mask_query.weight, tabs)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
