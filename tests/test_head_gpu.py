@@ -154,3 +154,58 @@ def test_head_rejects_cpu():
     feats = [torch.zeros(1, 128, 2 * 2 ** i, 4 * 2 ** i) for i in range(4)]
     with pytest.raises(RuntimeError):
         head.forward_clip(feats, torch.zeros(100, 256), [None] * 4)
+
+
+# BASELINE configs 4 and 5 as parity cases: the Swin-L head (FFN act ReLU, temporal act
+# GELU - swinL_fpn_slotvps.py:41) and the VIPER geometry (24 classes, 200 slots, level sizes that are not
+# multiples of the 32-pixel tile: 1088x1920 gives 34x60 ... 272x480; here the same shape family scaled down).
+VARIANTS = {
+    "swinL_head": dict(cfg=dict(activation="relu", temporal_activation="gelu"), T=2, L=100, sizes=[(2, 4), (4, 8), (8, 16), (16, 32)]),
+    "viper_geometry": dict(cfg=dict(num_classes=24), T=3, L=200, sizes=[(3, 5), (6, 10), (12, 20), (24, 40)]),
+}
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_head_variants_per_stage_parity(cuda, name):
+    import torch
+    from slotvps_amd import ops
+    from slotvps_amd.slot_head import MultiScaleDynamicMaskHead
+    v = VARIANTS[name]
+    cfg = dict(synth.R50_HEAD_CFG, **v["cfg"])
+    T, L, sizes = v["T"], v["L"], v["sizes"]
+    params = synth.make_params(synth.head_shapes(cfg), 21)
+    head = MultiScaleDynamicMaskHead(
+        dh_dim=256, num_classes=cfg["num_classes"], dim_feedforward=cfg["dim_feedforward"], nhead=8, dropout=0.0,
+        activation=cfg["activation"], dh_num_heads=7, per_dh_num_heads=[1, 2, 2, 2], feat_num_levels=4,
+        merge_operation="concat", trans_in_dim=384, num_cls=2, num_reg=2,
+        temporal_query_attention_config=dict(d_model=256, dim_feedforward=1024, dropout=0.0,
+                                             activation=cfg["temporal_activation"], softmax_dim="slots", drop_path=0.),
+        apply_temporal_query_atten_stages=[3, 4, 5, 6])
+    head.load_state_dict({k: torch.from_numpy(p).reshape(head.state_dict()[k].shape) for k, p in params.items()}, strict=True)
+    head.to(cuda).eval()
+    rng = np.random.default_rng(5)
+    feats = [[synth.smooth_features(rng, 128, h, w) for (h, w) in sizes] for _ in range(T)]
+    slots = synth.make_slots(6, L)
+    with torch.no_grad():
+        tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
+        tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in sizes]
+        logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(slots).to(cuda), tabs)
+    logits, embeds = logits.cpu().numpy(), embeds.cpu().numpy()
+    assert logits.shape == (7, T, L, cfg["num_classes"]) and embeds.shape == (7, T, L, 256)
+    pos = [orc.pos_embed_sine(h, w) for (h, w) in sizes]
+    st = orc.Storage.bf16_policy()
+    _, _, o_fused = orc.head_forward(feats, slots, pos, params, st=st)
+    g_fused = [[fused[i][t].float().cpu().numpy() for i in range(4)] for t in range(T)]
+    f_err = max(np.abs(g_fused[t][i] - o_fused[t][i]).max() for t in range(T) for i in range(4))
+    assert f_err <= 6.3e-2, f_err                                  # one bf16 ulp at magnitude < 8 (K4)
+    ocfg = dict(orc.DEFAULT_CFG, activation=cfg["activation"], temporal_activation=cfg["temporal_activation"])
+    errs, sidx = [], 0
+    for lvl, n in enumerate(ocfg["per_level_stages"]):
+        for j in range(n):
+            s_in = [slots.astype(np.float32)] * T if sidx == 0 else [embeds[sidx - 1, t] for t in range(T)]
+            lg, em = orc.stage(s_in, [g_fused[t][lvl] for t in range(T)], [pos[lvl]] * T, params,
+                               f"head_series_{lvl}.{j}.", sidx in ocfg["temporal_stages"], ocfg, st)
+            errs.append(max(max(np.abs(embeds[sidx, t] - em[t]).max(), np.abs(logits[sidx, t] - lg[t]).max()) for t in range(T)))
+            sidx += 1
+    print(f"\n[{name}] fused {f_err:.2e} | per-stage (identical inputs) " + " ".join(f"{e:.1e}" for e in errs))
+    assert max(errs) <= 2e-2, errs                                 # same bound as the R50 case above
