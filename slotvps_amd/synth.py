@@ -153,3 +153,43 @@ def make_post_case(seed, L=100, h=16, w=32, num_classes=20, n_keep=18):
         masks[s] = (amp * np.exp(-d2 / (2 * sig * sig)) - rng.uniform(0.3, 1.2)
                     + 0.15 * rng.standard_normal((h, w))).astype(np.float32)
     return logits, masks
+
+
+def make_harness_case(seed, n_frames=3, H=96, W=160):
+    """Synthetic frames exercising every branch: agreeing / out-voted / disagreeing instances, a frame without
+    instances, duplicate tracked ids, small stuff areas, an unlabeled (255) region."""
+    rng = np.random.default_rng(seed)
+    segs, pans, cls_inds, obj_ids, names = [], [], [], [], []
+    for f in range(n_frames):
+        seg = np.zeros((H, W), np.uint8)
+        pan = np.zeros((H, W), np.uint8)
+        for _ in range(6):                                   # stuff layout shared by both branches
+            c = int(rng.integers(0, 11))
+            y, x = int(rng.integers(0, H - 8)), int(rng.integers(0, W - 8))
+            h, w = int(rng.integers(4, H // 2)), int(rng.integers(4, W // 2))
+            seg[y:y + h, x:x + w] = c
+            pan[y:y + h, x:x + w] = c
+        n_ins = 0 if f == 1 else int(rng.integers(3, 7))
+        cls = rng.integers(1, 9, size=n_ins).astype(np.int64)
+        for k in range(n_ins):
+            y, x = int(rng.integers(0, H - 12)), int(rng.integers(0, W - 12))
+            h, w = int(rng.integers(6, 30)), int(rng.integers(6, 40))
+            pan[y:y + h, x:x + w] = 11 + k
+            mode = k % 3
+            if mode == 0:
+                seg[y:y + h, x:x + w] = 10 + cls[k]           # semantic branch agrees
+            elif mode == 1:
+                seg[y:y + h, x:x + w] = int(rng.integers(0, 11))   # a stuff class out-votes the instance
+            else:
+                seg[y:y + h, x:x + w // 2] = 10 + (cls[k] % 8) + 1  # another thing class on part of it
+        present = [k for k in range(n_ins) if (pan == 11 + k).any()]
+        cls = cls[present]
+        remap = {11 + k: 11 + j for j, k in enumerate(present)}
+        pan2 = pan.copy()
+        for a, b in remap.items():
+            pan2[pan == a] = b
+        if f == 1:
+            pan2[5:15, 5:25] = 13                              # instance ids without any cls_ind -> 255
+        oid = rng.integers(0, 6, size=len(cls)).astype(np.int32)   # duplicates likely
+        segs.append(seg); pans.append(pan2); cls_inds.append(cls); obj_ids.append(oid); names.append(f"frame_{seed}_{f}.png")
+    return segs, pans, cls_inds, obj_ids, names

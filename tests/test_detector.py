@@ -172,6 +172,13 @@ def test_clip_flow_matches_oracle_pipeline():
         n_things += int(ins.sum())
     assert n_things > 0, "the synthetic case must exercise the instance / tracker branch"
     np.testing.assert_allclose(det.prev_embedding.cpu().numpy(), memory, rtol=0, atol=0)
+    # harness loop on top (tools/test_vpq.py:23-59 + get_unified_pan_result): uint8 maps, 3-channel encoding
+    from slotvps_amd import harness
+    r = harness.clip_gpu_test(det, [(imgs, metas)])
+    assert r["all_names"] == [f"f{t}.png" for t in range(T)] and r["all_panos"][0].dtype == np.uint8
+    enc = harness.get_unified_pan_result(r["all_ssegs"], r["all_panos"], r["all_pano_cls_inds"], r["all_pano_obj_ids"],
+                                         stuff_area_limit=64, names=r["all_names"])
+    assert enc["f0.png"].shape == (H, W, 3) and enc["f0.png"].dtype == np.uint8
 
 
 @pytest.mark.gpu
