@@ -29,10 +29,13 @@ class SlotClipRunner:
     """Owns a head replica, the slot initialisation, the decode BatchNorms and (optionally) a captured
     hipGraph of one clip step. All tensors live on `device`."""
 
-    def __init__(self, device, T, H, W, L=100, param_seed=0, cfg=None, split_p=True, use_graph=True, n_slots=1):
+    def __init__(self, device, T, H, W, L=100, param_seed=0, cfg=None, split_p=True, use_graph=True, n_slots=1,
+                 clips_per_launch=1):
         if torch.device(device).type != "cuda":
             raise RuntimeError("SlotClipRunner runs on the GPU only; there is no CPU fallback")
         self.device = torch.device(device)
+        self.clip_frames, self.clips_per_launch = T, clips_per_launch
+        T = T * clips_per_launch                  # clips stacked along the frame axis: one launch covers them all
         self.T, self.H, self.W, self.L = T, H, W, L
         self.cfg = cfg or synth.R50_HEAD_CFG
         self.sizes = synth.level_sizes(H, W)
@@ -72,7 +75,8 @@ class SlotClipRunner:
             self.fg_scale, self.fg_shift = float(fs.item()), float(fb.item())
 
     def _step(self, slot=0):
-        logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs)
+        logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs,
+                                                       clip_frames=self.clip_frames)
         masks, amax = ops.mask_decode(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift,
                                       self.fg_scale, self.fg_shift, want_argmax=True)
         return dict(class_logits=logits, slot_embeds=embeds, mask_logits=masks, slot_argmax=amax)

@@ -152,8 +152,11 @@ class SlotsDynamicConv(nn.Module):
         self.norm1 = nn.LayerNorm(dh_dim)
         self.activation = nn.ReLU(inplace=True)
 
-    def forward(self, curr_features, features, pos):
+    def forward(self, curr_features, features, pos, groups=1):
+        """`groups` > 1: the rows are `groups` independent clips of equal length laid end to end; attention stays
+        inside each clip (a batch of clips per launch - the reference handles one clip per call)."""
         if pos is not None or curr_features is not features:
+            assert groups == 1
             q = self.norm_q(self.to_q(curr_features))
             k = self.norm_k(self.to_k(features if pos is None else features + pos))
             v = self.norm_v(self.to_v(features))
@@ -168,10 +171,10 @@ class SlotsDynamicConv(nn.Module):
             e3 = _cached(self, "e3", [m.bias for m in norms], lambda: torch.stack([m.bias for m in norms]).contiguous())
             qkv = torch.baddbmm(b3, x.unsqueeze(0).expand(3, -1, -1), w3)            # [3, M, C]
             qkv = ops.row_ln(qkv, g3, e3, self.norm_q.eps, rows_per_group=x.shape[0])
-            q, k, v = qkv[0:1], qkv[1:2], qkv[2:3]
+            q, k, v = (qkv[i].view(groups, -1, self.hidden_dim) for i in range(3))
         # softmax over the QUERY axis (dim=1 of [1, Lq, Lk], :562) = last-dim softmax of the transposed logits
         attn_t = torch.softmax(k @ q.transpose(-1, -2), dim=-1)     # [1, Lk, Lq]
-        out = attn_t.transpose(-1, -2) @ v
+        out = (attn_t.transpose(-1, -2) @ v).reshape(1, -1, self.hidden_dim)
         return ops.row_ln(out.contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)
 
 
@@ -193,13 +196,13 @@ class TemporalSlotsHead(nn.Module):
         self.norm3 = nn.LayerNorm(d_model)
         self.activation = _get_activation_fn(activation)
 
-    def forward(self, features, mask_query, pos=None, query_pos=None, add_input=False):
+    def forward(self, features, mask_query, pos=None, query_pos=None, add_input=False, groups=1):
         """:494-527. add_input=True additionally returns mask_query + result (the caller's residual, :317)
-        fused into the last K5 launch."""
+        fused into the last K5 launch. groups: independent clips in the row dimension (see SlotsDynamicConv)."""
         assert query_pos is None
         x = mask_query.view(1, -1, self.d_model)
         f = x if features is mask_query else features.view(1, -1, self.d_model)
-        r = self.inst_interact(x, f, pos)
+        r = self.inst_interact(x, f, pos, groups=groups)
         u = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x.contiguous())          # :515-517
         y = self.linear2(self.activation(self.linear1(u)))                                                    # :520
         out = ops.row_ln(y, self.norm3.weight, self.norm3.bias, self.norm3.eps, pre=u,
@@ -271,12 +274,13 @@ class MaskRCNNHead(nn.Module):
             x = ops.row_ln(torch.bmm(x, w2), g2, e2, nc.eps, relu=True, rows_per_group=T * L)               # :394-397
         return self.class_logits(x[0].reshape(T, L, C)), x[1].reshape(T, L, C)
 
-    def forward_pm(self, slots, feat_pm, hw, pos_tabs, stage_enable):
+    def forward_pm(self, slots, feat_pm, hw, pos_tabs, stage_enable, clips=1):
         T, L, C = slots.shape
         obj = self.forward_till_ffn_pm(slots.contiguous(), feat_pm, hw, pos_tabs)
         if stage_enable:
             flat = obj.reshape(T * L, C)                                    # concat along the slot axis (:310)
-            obj = self.temporal_query_head(features=flat, mask_query=flat, add_input=True).reshape(T, L, C)   # :313-322
+            obj = self.temporal_query_head(features=flat, mask_query=flat, add_input=True,
+                                           groups=clips).reshape(T, L, C)                                     # :313-322
         else:
             assert self.temporal_query_head is None
         return self.forward_after_ffn_pm(obj)
@@ -365,8 +369,10 @@ class MultiScaleDynamicMaskHead(nn.Module):
             cur = cur.float()
         return ops.level_fuse(cur.contiguous(), prev_pm, wc, bc, hw[0], hw[1])
 
-    def forward_clip(self, feats, init_slots, pos_tabs, hws=None):
-        """Batched clip entry.
+    def forward_clip(self, feats, init_slots, pos_tabs, hws=None, clip_frames=None):
+        """Batched clip entry. clip_frames: frames per clip when several clips of equal length are stacked along T
+        (T % clip_frames == 0): every kernel then covers all of them in one launch and the temporal slot attention
+        stays inside each clip. None = one clip of T frames (the reference's call).
         feats: list over the 4 levels (coarse -> fine) of [T, 128, Hi, Wi] fp32 (NCHW, the reference's
         layout) or [T, Hi*Wi, 128] bf16 pixel-major (then hws = [(Hi, Wi)] is required); init_slots [L, 256];
         pos_tabs: per level the separable sine tables (ytab [Hi, 128], xtab [Wi, 128]) of
@@ -375,6 +381,9 @@ class MultiScaleDynamicMaskHead(nn.Module):
         if not feats[0].is_cuda:
             raise RuntimeError("MultiScaleDynamicMaskHead runs on the GPU only; there is no CPU fallback")
         T = feats[0].shape[0]
+        clips = 1 if clip_frames is None else T // clip_frames
+        if clip_frames is not None and clips * clip_frames != T:
+            raise ValueError(f"T={T} is not a multiple of clip_frames={clip_frames}")
         slots = init_slots.float().unsqueeze(0).expand(T, -1, -1).contiguous()
         all_logits, all_embeds, fused = [], [], []
         prev = None
@@ -387,7 +396,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
             f_pm = self.fuse_level(feats[i], prev, (h, w))
             for stage in getattr(self, f"head_series_{i}"):
                 enable = stage_idx in self.apply_temporal_query_atten_stages
-                logits, slots = stage.forward_pm(slots, f_pm, (h, w), None if pos_tabs is None else pos_tabs[i], enable)
+                logits, slots = stage.forward_pm(slots, f_pm, (h, w), None if pos_tabs is None else pos_tabs[i], enable, clips)
                 slots = slots.detach()
                 all_logits.append(logits)
                 all_embeds.append(slots)
