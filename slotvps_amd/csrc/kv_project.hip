@@ -20,12 +20,17 @@
 // (LDS-DMA ring, swizzled rows, pixel = MFMA column = lane). Per tile and wave: 32 MFMA 32x32x16.
 // LayerNorm over the 256 output channels of a pixel = in-lane sums + lane^32 + one (sum, sum of
 // squares) exchange between the four waves of a projection. Results are transposed through an LDS
-// out-tile so that HBM sees whole 512-byte pixel rows. Waves 0-3 issue all LDS-DMA, waves 4-7 all
-// global stores, so each wave's vmcnt queue holds one kind of operation and the DMA ring is waited
-// for with an exact count. Two workgroup barriers per tile.
+// out-tile so that HBM sees whole 512-byte pixel rows. The value waves (4-7) issue all LDS-DMA; every wave stores
+// its own projection's rows; the DMA ring is waited for with exact vmcnt counts. Two workgroup barriers per tile.
+//
+// The position rows of a tile (ytab[y(p)], xtab[x(p)], fp32) also arrive by LDS-DMA, gathered with
+// per-lane source addresses, so that building the key operand bf16(f + pos) is pure LDS + VALU work:
+// a compiler-visible global load in the loop would make hipcc wait on vmcnt, which retires in order
+// and therefore also waits for every global store of the previous tile.
 //
 // Roofline: HBM - reads 512 B and writes 1024 B per pixel (1.5 KB/px); 262 kFLOP/px on the matrix
 // cores (arithmetic intensity 175 flop/B, below the ~300 flop/B ridge of the chip).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -39,7 +44,9 @@ struct ProjLds {
     static constexpr int xk = kProjNF * kTileBytes;              // bf16(f + pos) tile
     static constexpr int outk = xk + kTileBytes;                 // bf16 k rows of the tile
     static constexpr int outv = outk + kTileBytes;
-    static constexpr int stats = outv + kTileBytes;              // [2][4][32] float2
+    static constexpr int posy = outv + kTileBytes;               // [32 px][128] fp32 rows of ytab
+    static constexpr int posx = posy + kTileBytes;               // [32 px][128] fp32 rows of xtab
+    static constexpr int stats = posx + kTileBytes;              // [2][4][32] float2
     static constexpr int affine = stats + 2 * 4 * 32 * 8;        // bk bv gk bk' gv bv' : 6 x 256 fp32
     static constexpr int total = affine + 6 * kD * 4;
 };
@@ -56,16 +63,29 @@ __device__ __forceinline__ u32x4 make_srd_p(const void* base, uint32_t bytes) {
 
 // see slot_attn.hip: asm so that hipcc does not drain the DMA ring before every LDS read
 __device__ __forceinline__ void dma16_srd_p(u32x4 srd, uint32_t lds_addr, int voff, int soff) {
-    uint32_t keep;
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
+        "s_mov_b32 m0, %0\n\t"
         "s_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
         : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
-        : "memory");
+        : "memory", "m0");
+}
+
+// Four 1-KiB pieces with one M0 write: the instruction offset advances BOTH the global address and the LDS
+// address (LDS = M0 + inst_offset + lane * 16), so piece i lands at lds_addr + 1024 i and reads from
+// voff_i + soff + 1024 i - callers pre-subtract 1024 i from voff_i where the source is not contiguous.
+__device__ __forceinline__ void dma16x4_srd_p(u32x4 srd, uint32_t lds_addr, int v0, int v1, int v2, int v3, int soff) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+        "buffer_load_dwordx4 %2, %5, %6 offen offset:1024 lds\n\t"
+        "buffer_load_dwordx4 %3, %5, %6 offen offset:2048 lds\n\t"
+        "buffer_load_dwordx4 %4, %5, %6 offen offset:3072 lds"
+        :
+        : "s"(lds_addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(srd), "s"(soff)
+        : "memory", "m0");
 }
 
 __device__ __forceinline__ float half_swap_add(float x) {
@@ -73,7 +93,18 @@ __device__ __forceinline__ float half_swap_add(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <bool HAS_POS>
+#ifdef SVPS_K3_STAMP
+__device__ unsigned long long k3_stamps[8][8][16];      // [wave][iteration - 8][point]
+#define K3_STAMP(pt)                                                                              \
+    do {                                                                                          \
+        if (blockIdx.x == 7 && blockIdx.y == 0 && it >= 8 && it < 16 && lane == 0)               \
+            k3_stamps[w][it - 8][pt] = __builtin_amdgcn_s_memtime();                              \
+    } while (0)
+#else
+#define K3_STAMP(pt) do {} while (0)
+#endif
+
+template <bool HAS_POS, int ABL = 0>
 __global__ __launch_bounds__(512) void kv_project_kernel(
     const __bf16* __restrict__ feat,    // [T, HW, 256]
     const float* __restrict__ pos_y,    // [H, 128] or null
@@ -137,12 +168,12 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
     }
     auto stage_f = [&](int tile) {
         if (tile >= nt) return;
+        if constexpr (ABL & 4) return;
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (tile % kProjNF) * kTileBytes + ob * 4096);
         const int px0 = px_begin + tile * kTilePx;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
         if (px0 + kTilePx <= HW) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dma16_srd_p(frs, st + i * 1024, voff[i], soff);
+            dma16x4_srd_p(frs, st, voff[0], voff[1] - 1024, voff[2] - 2048, voff[3] - 3072, soff);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -153,61 +184,110 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
         }
     };
 
-    // xk(tile) = bf16(f(tile) + pos), built by waves 4-7 only (thread -> pixel, 32 channels): the DMA
-    // waves 0-3 must not execute compiler-visible vector-memory loads inside the loop - hipcc's waits
-    // for those would drain the asm DMA ring with them (vmcnt retires in order).
+    // position rows of tile `tile` -> LDS, by waves 0-3: wave ob covers pixel rows 8 ob .. 8 ob + 7; one DMA
+    // instruction moves two 512-byte table rows (lanes 0-31: pixel 2i, lanes 32-63: pixel 2i + 1).
+    const u32x4 ysrd = make_srd_p(pos_y, HAS_POS ? (uint32_t)((HW + W - 1) / W) * 512u : 0u);
+    const u32x4 xsrd = make_srd_p(pos_x, HAS_POS ? (uint32_t)W * 512u : 0u);
+    const bool aligned_rows = (W & 31) == 0;
+    auto stage_pos = [&](int tile) {
+        if constexpr (!HAS_POS) return;
+        if (tile >= nt) return;
+        if constexpr (ABL & 4) return;
+        const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::posy + ob * 4096);
+        const uint32_t sx = __builtin_amdgcn_readfirstlane(lds0 + Lds::posx + ob * 4096);
+        if (aligned_rows) {
+            // W % 32 == 0: a tile lies inside one image row. One 512-byte ytab row for the whole tile (build_xk reads
+            // it for every pixel) and 32 consecutive xtab rows = one contiguous 16 KiB block.
+            const int px0 = px_begin + tile * kTilePx;
+            const int y0 = __builtin_amdgcn_readfirstlane(px0 / W), x0 = px0 - y0 * W;
+            if (ob == 0) dma16_srd_p(ysrd, __builtin_amdgcn_readfirstlane(lds0 + Lds::posy), lane * 16, y0 * 512);
+            const int v = ob * 4096 + lane * 16;
+            dma16x4_srd_p(xsrd, sx, v, v, v, v, __builtin_amdgcn_readfirstlane(x0 * 512));
+            return;
+        }
+        const int p = px_begin + tile * kTilePx + 8 * ob + h;
+        const int yy = p / W, xx = p - yy * W;                 // rows past the image read zeros (buffer bounds)
+        int yo = yy * 512 + (lane & 31) * 16, xo = xx * 512 + (lane & 31) * 16;
+        const int xwrap = W * 512 + (lane & 31) * 16;          // xo of column W
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dma16_srd_p(ysrd, sy + i * 1024, yo, 0);
+            dma16_srd_p(xsrd, sx + i * 1024, xo, 0);
+            xo += 1024;                                        // two pixels on; at most two row wraps (W == 1)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const bool wrap = xo >= xwrap;
+                xo = wrap ? xo - W * 512 : xo;
+                yo = wrap ? yo + 512 : yo;
+            }
+        }
+    };
+
+    // xk(tile) = bf16(f(tile) + pos(tile)), by waves 0-3 from LDS only: thread -> 16-byte chunk (8 channels).
     auto build_xk = [&](int tile) {
         if constexpr (!HAS_POS) return;
-        if (w < 4) return;
-        int lt = tid - 256;
+        if (w >= 4) return;
+        int lt = tid;
         asm volatile("" : "+v"(lt));     // opaque: keeps hipcc from hoisting (and then spilling) the addresses
-        const int xpx = lt >> 3, xc = lt & 7;                     // channels 32 xc .. 32 xc + 31
         const char* ft = smem + Lds::fring + (tile % kProjNF) * kTileBytes;
         char* xt = smem + Lds::xk;
-        int p = px_begin + tile * kTilePx + xpx;
-        p = p < HW ? p : HW - 1;
-        const int y = p / W, x = p - y * W;
-        const float* ptab = xc < 4 ? pos_y + (size_t)y * 128 + 32 * xc : pos_x + (size_t)x * 128 + 32 * (xc - 4);
+        bf16x8 fv[4];
+        f32x4 pv[4][2];
+        int offs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                          // twelve LDS reads in flight, then the arithmetic
+            const int id = u * 256 + lt;                       // [px][chunk]
+            const int xpx = id >> 5, cpos = id & 31;
+            offs[u] = xpx * kRowBytes + ((cpos ^ swz(xpx)) * 16);
+            fv[u] = *reinterpret_cast<const bf16x8*>(ft + offs[u]);
+            const char* pt = smem + (cpos < 16 ? Lds::posy + (aligned_rows ? 0 : xpx * 512) : Lds::posx + xpx * 512) + (cpos & 15) * 32;
+            pv[u][0] = *reinterpret_cast<const f32x4*>(pt);
+            pv[u][1] = *reinterpret_cast<const f32x4*>(pt + 16);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int off = xpx * kRowBytes + (((4 * xc + u) ^ swz(xpx)) * 16);
-            const bf16x8 f = *reinterpret_cast<const bf16x8*>(ft + off);
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(ptab + 8 * u);
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(ptab + 8 * u + 4);
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                o[j] = (__bf16)((float)f[j] + p0[j]);
-                o[4 + j] = (__bf16)((float)f[4 + j] + p1[j]);
+                o[j] = (__bf16)((float)fv[u][j] + pv[u][0][j]);
+                o[4 + j] = (__bf16)((float)fv[u][4 + j] + pv[u][1][j]);
             }
-            *reinterpret_cast<bf16x8*>(xt + off) = o;
+            *reinterpret_cast<bf16x8*>(xt + offs[u]) = o;
         }
     };
 
-    // out tile -> HBM by waves 4-7: 32 KiB per tile, 8 x 16 B per thread, whole 512-B rows per piece
+    // out tile of this wave's projection -> HBM: 16 KiB per tile, 4 x 16 B per thread. The global side is linear
+    // (thread -> consecutive 16-byte pieces of the tile's 16 KiB, scalar tile offset, hardware bounds check at the end
+    // of the frame), the LDS side undoes the row swizzle.
+    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((proj ? v_out : k_out) + (size_t)t * HW * kD), 0, (ABL & 1) ? 0 : px_end * kRowBytes, 0x00020000);
     auto store_out = [&](int tile) {
-        int lt = tid - 256;                             // 0..255
+        int lt = tid & 255;
         asm volatile("" : "+v"(lt));
+        const char* src = smem + (proj ? Lds::outv : Lds::outk);
+        // The tile offset goes into the VGPR offset, not into soffset: the hardware range check covers voffset only,
+        // and with an SGPR soffset hipcc omits the wait state gfx950 needs between a >64-bit buffer store and the next
+        // VALU write of its data registers (observed: first data dword of the first store clobbered).
+        const int base = (px_begin + tile * kTilePx) * kRowBytes + lt * 16;
+        u32x4 val[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int piece = u * 256 + lt;             // 0..2047 : [tensor][row][chunk position]
-            const int tens = piece >> 10, row = (piece >> 5) & 31, cpos = piece & 31;
-            const int px = px_begin + tile * kTilePx + row;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(smem + (tens ? Lds::outv : Lds::outk) + row * kRowBytes + cpos * 16);
-            if (px < px_end) {
-                __bf16* dst = (tens ? v_out : k_out) + ((size_t)t * HW + px) * kD + ((cpos ^ swz(row)) * 8);
-                *reinterpret_cast<u32x4*>(dst) = val;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int row = 8 * u + (lt >> 5), gc = lt & 31;           // global chunk gc of pixel row `row`
+            val[u] = *reinterpret_cast<const u32x4*>(src + row * kRowBytes + ((gc ^ swz(row)) * 16));
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            __builtin_amdgcn_raw_buffer_store_b128(val[u], osrd, base + u * 4096, 0, 0);
     };
 
-    if (w < 4) {
+    if (w >= 4) {
+        stage_pos(0);
 #pragma unroll
         for (int b = 0; b < A; ++b) stage_f(b);
-        if (nt > A - 1) wait_vm<4 * (A - 1)>();
+        if (nt > A - 1) wait_vm<4 * (A - 1)>();      // pos(0) and f(0) are the oldest
         else wait_vm<0>();
     }
-    wg_barrier();          // f(0) landed, affine table written
+    wg_barrier();          // f(0), pos(0) landed, affine table written
     build_xk(0);
 
     float2* stats = reinterpret_cast<float2*>(smem + Lds::stats) + proj * 4 * 32;
@@ -216,57 +296,66 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
     const float* bet = aff + (3 + 2 * proj) * kD;
     const float eps = proj ? eps_v : eps_k;
     char* outt = smem + (proj ? Lds::outv : Lds::outk);
+    f32x16 acc[2];
 
-    for (int it = 0; it < nt; ++it) {
-        wg_barrier();                                                  // a(it): xk(it) built, out(it-1) complete
-        if (w < 4) stage_f(it + A);
-        else if (it >= 1) store_out(it - 1);
+    // "heavy" half of a tile: store the previous out tile, 32 MFMA, + bias, LayerNorm partial sums -> LDS
+    auto heavy = [&](int it) {
+        if (it >= 1) store_out(it - 1);
+        K3_STAMP(3);
+        if (it >= nt) return;
         const char* bt = (HAS_POS && proj == 0) ? smem + Lds::xk : smem + Lds::fring + (it % kProjNF) * kTileBytes;
         int r = r_, h = h_;
         asm volatile("" : "+v"(r), "+v"(h));   // opaque per iteration: no loop-invariant address tables in VGPRs
-
-        f32x16 acc[2];
+        // accumulators start from the bias of their channels (acc_row(4g + j, h) = 8g + 4h + j): eight 16-byte LDS
+        // reads straight into the accumulator registers, in flight together with the first operand fragments
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
-#pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {     // 4 feature fragments in flight (register budget: 128 of 256 hold W)
-            bf16x8 xf[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) xf[u] = read_row_frag(bt, 4 * grp + u, r, h);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][4 * grp + u], xf[u], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][4 * grp + u], xf[u], acc[1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // + bias; LayerNorm statistics of this wave's 64 channels for pixel column r
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {            // channels 64 ob + 32 b + 8 g + 4 h + (0..3)
+            for (int g = 0; g < 4; ++g) {
                 const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + 64 * ob + 32 * b + 8 * g + 4 * h);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x = acc[b][4 * g + j] + bb[j];
-                    acc[b][4 * g + j] = x;
-                    s1 += x;
-                    s2 = fmaf(x, x, s2);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep hipcc from pre-loading every table row (VGPR budget)
+                for (int j = 0; j < 4; ++j) acc[b][4 * g + j] = bb[j];
             }
+        if constexpr (!(ABL & 2)) {
+            bf16x8 xf[2][4];                     // operand fragments, double-buffered in groups of four k-steps
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xf[0][u] = read_row_frag(bt, u, r, h);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                if (grp < 3) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) xf[(grp + 1) & 1][u] = read_row_frag(bt, 4 * (grp + 1) + u, r, h);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][4 * grp + u], xf[grp & 1][u], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][4 * grp + u], xf[grp & 1][u], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        K3_STAMP(4);
+        f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};       // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): 2 elements per VALU slot
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 x = {acc[b][i], acc[b][i + 1]};
+                p1 += x;
+                p2 = __builtin_elementwise_fma(x, x, p2);
+            }
+        float s1 = p1[0] + p1[1], s2 = p2[0] + p2[1];
         s1 = half_swap_add(s1);
         s2 = half_swap_add(s2);
         if (h == 0) stats[ob * 32 + r] = make_float2(s1, s2);
-        if (w < 4) {                                                   // f(it+1) landed for the DMA waves
-            if (it + A < nt) wait_vm<4 * (A - 1)>();
-            else wait_vm<0>();
-        }
-        wg_barrier();                                                  // b(it)
+        K3_STAMP(5);
+    };
+
+    // "light" half: LayerNorm of the accumulators with the exchanged statistics -> bf16 out tile
+    auto light = [&](int it) {
+        int r = r_, h = h_;
+        asm volatile("" : "+v"(r), "+v"(h));
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
@@ -277,25 +366,75 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
         const float mean = t1 * (1.f / kD);
         const float var = fmaxf(t2 * (1.f / kD) - mean * mean, 0.f);
         const float rstd = rsqrtf(var + eps);
+        const f32x2 a2 = {rstd, rstd}, b2 = {-mean * rstd, -mean * rstd};     // (x - mean) * rstd = x * a + b
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < ((ABL & 8) ? 0 : 2); ++b) {
+            f32x4 gg[4], be[4];                                        // eight LDS reads in flight per block
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4 o;
                 const int ch0 = 64 * ob + 32 * b + 8 * g + 4 * h;     // acc_row(4g + j, h) = 8g + 4h + j
-                const f32x4 gg = *reinterpret_cast<const f32x4*>(gam + ch0);
-                const f32x4 be = *reinterpret_cast<const f32x4*>(bet + ch0);
+                gg[g] = *reinterpret_cast<const f32x4*>(gam + ch0);
+                be[g] = *reinterpret_cast<const f32x4*>(bet + ch0);
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    o[j] = (__bf16)((acc[b][4 * g + j] - mean) * rstd * gg[j] + be[j]);
+            for (int g = 0; g < 4; ++g) {
+                const int ch0 = 64 * ob + 32 * b + 8 * g + 4 * h;
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x2 x = {acc[b][4 * g + j], acc[b][4 * g + j + 1]};
+                    const f32x2 gj = {gg[g][j], gg[g][j + 1]}, bj = {be[g][j], be[g][j + 1]};
+                    const f32x2 y = __builtin_elementwise_fma(__builtin_elementwise_fma(x, a2, b2), gj, bj);
+                    o[j] = (__bf16)y[0];
+                    o[j + 1] = (__bf16)y[1];
+                }
                 const int chunk = ch0 >> 3;                            // 16-byte chunk of the pixel row
                 *reinterpret_cast<bf16x4*>(outt + r * kRowBytes + ((chunk ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
-                __builtin_amdgcn_sched_barrier(0);
             }
-        if (it + 1 < nt) build_xk(it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Ping-pong: the key waves (0-3) and the value waves (4-7) share every SIMD pairwise and run half a tile
+    // apart, so that the matrix pipe of a SIMD works for one of them while the other does its VALU / LDS / store
+    // part. Two workgroup barriers per tile:
+    //   phase X(it): key waves heavy(it)                       | value waves: all DMA issue, light(it-1)
+    //   phase Y(it): key waves light(it), build xk(it+1)       | value waves heavy(it)
+    for (int it = 0; it <= nt; ++it) {
+        K3_STAMP(0);
+        wg_barrier();                                                  // X(it): xk(it) built, stats_v(it-1) written
+        K3_STAMP(1);
+        if (proj == 0) {
+            heavy(it);
+            K3_STAMP(6);
+            K3_STAMP(7);
+        } else {
+            if (it < nt) {
+                stage_pos(it + 1);                                     // single buffer: pos(it) was consumed in Y(it-1)
+                stage_f(it + A);
+            }
+            K3_STAMP(2);
+            if (it >= 1) light(it - 1);
+            // f(it+1), pos(it+1) landed (this wave's pieces); only f(it+A) [4] is younger than pos(it+1), the stores of
+            // Y(it-1) are older (vmcnt retires in order)
+            if (it + A < nt) wait_vm<4>();
+            else wait_vm<0>();
+            K3_STAMP(7);
+        }
+        wg_barrier();                                                  // Y(it): stats_k(it) written, out_v(it-1) complete
+        K3_STAMP(8);
+        if (proj == 0) {
+            if (it < nt) {
+                light(it);
+                K3_STAMP(9);
+                if (!(ABL & 16) && it + 1 < nt) build_xk(it + 1);
+                K3_STAMP(10);
+            }
+        } else {
+            heavy(it);
+            K3_STAMP(10);
+        }
     }
-    wg_barrier();
-    if (w >= 4) store_out(nt - 1);
 }
 
 }  // namespace svps
@@ -333,6 +472,28 @@ extern "C" int svps_kv_project_fwd(const void* feat, const float* pos_y, const f
     static bool attr_set[2] = {false, false};
     const bool has_pos = pos_y != nullptr;
     auto kern = has_pos ? svps::kv_project_kernel<true> : svps::kv_project_kernel<false>;
+#ifdef SVPS_K3_ABLATE
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("SVPS_K3_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (has_pos) {
+        switch (abl) {
+            case 1: kern = svps::kv_project_kernel<true, 1>; break;
+            case 2: kern = svps::kv_project_kernel<true, 2>; break;
+            case 3: kern = svps::kv_project_kernel<true, 3>; break;
+            case 4: kern = svps::kv_project_kernel<true, 4>; break;
+            case 8: kern = svps::kv_project_kernel<true, 8>; break;
+            case 16: kern = svps::kv_project_kernel<true, 16>; break;
+            case 9: kern = svps::kv_project_kernel<true, 9>; break;
+            case 25: kern = svps::kv_project_kernel<true, 25>; break;
+            case 27: kern = svps::kv_project_kernel<true, 27>; break;
+            case 31: kern = svps::kv_project_kernel<true, 31>; break;
+            case 30: kern = svps::kv_project_kernel<true, 30>; break;
+            default: break;
+        }
+    }
+    static bool abl_attr = false;
+    if (!abl_attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, svps::ProjLds::total); abl_attr = true; }
+#endif
     if (!attr_set[has_pos]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, svps::ProjLds::total);
@@ -347,3 +508,9 @@ extern "C" int svps_kv_project_fwd(const void* feat, const float* pos_y, const f
     svps_prof_mark(SVPS_KERNEL_KV_PROJECT, 1, stream);
     return (int)hipGetLastError();
 }
+
+#ifdef SVPS_K3_STAMP
+extern "C" int svps_k3_debug_read(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(svps::k3_stamps), sizeof(unsigned long long) * 8 * 8 * 16);
+}
+#endif

@@ -21,7 +21,9 @@ def _ulp_bf16(x):
     (2, 33, 65, True),      # ragged: W not a multiple of the tile, HW % 32 != 0
     (2, 34, 60, True),      # VIPER coarse level
     (1, 8, 8, False),
-    (3, 64, 128, True),
+    (3, 64, 128, True),     # several tiles per workgroup, W % 32 == 0: contiguous position rows (fast DMA path)
+    (8, 48, 80, True),      # several tiles per workgroup, tiles straddle image rows (gathered position rows)
+    (8, 48, 80, False),
 ])
 def test_kv_project_matches_oracle(cuda, T, H, W, with_pos):
     import torch

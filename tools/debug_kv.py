@@ -6,7 +6,7 @@ import synth
 from util import orc, to_bf16_t, bf16_t_to_np
 from slotvps_amd import ops
 dev = torch.device("cuda:0")
-for (T, H, W) in [(1, 16, 32), (2, 33, 65)]:
+for (T, H, W) in [(3, 64, 128)]:
     seed = H * 1000 + W + T
     params = synth.make_params(synth.retriever_shapes(""), seed)
     rng = np.random.default_rng(seed)
@@ -30,7 +30,12 @@ for (T, H, W) in [(1, 16, 32), (2, 33, 65)]:
             bad = np.argwhere(rel > 0.006)
             print(f"{T}x{H}x{W} t={t} {nm}: max abs {d.max():.4f} max rel {rel.max():.4f} n(rel>0.6%) {len(bad)} of {d.size}; n diff {(d>0).sum()}")
             if len(bad):
-                print("   bad pixels (px%32):", sorted(set((bad[:, 0] % 32).tolist()))[:32], " channels:", sorted(set(bad[:, 1].tolist()))[:20])
+                print("   bad pixels (px%32):", sorted(set((bad[:, 0] % 32).tolist()))[:32], " channels:", sorted(set(bad[:, 1].tolist()))[:20], " tiles:", sorted(set((bad[:, 0] // 32).tolist()))[:40])
+                big = np.argwhere(d > 0.1)
+                print("   n(abs>0.1)", len(big), "first:", [tuple(x) for x in big[:24].tolist()])
+                if len(big):
+                    import collections
+                    print("   by channel%8:", collections.Counter((big[:, 1] % 8).tolist()), " by px%32:", sorted(collections.Counter((big[:, 0] % 32).tolist()).items())[:32])
                 i, j = bad[0]
                 print("   e.g.", got[i, j], ref[i, j], "pixel", i, "ch", j)
         # also check k computed WITHOUT pos to see if pos was ignored
