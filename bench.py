@@ -5,10 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one synthetic clip per rank: T=5 frames of
-1024x2048 -> four levels of 128-channel FPN feature maps (32x64 ... 256x512, resident in HBM) ->
-the 7-stage multi-scale slot head (K1 once per stage for all T frames) -> slot->mask decode of all
-T frames (K2). Weights: the R50-FPN Slot-VPS head architecture with seeded synthetic values
+One "step" = one pass of the hot path over one batch of synthetic clips per rank: `--clips-per-launch`
+(default 8) independent T=5 clips of 1024x2048 stacked along the frame axis -> four levels of 128-channel
+FPN feature maps (32x64 ... 256x512, resident in HBM) -> the 7-stage multi-scale slot head (K4, K3, K1
+once per level / stage for all frames of the batch; temporal slot attention stays inside each clip) ->
+slot->mask decode of all frames (K2). Weights: the R50-FPN Slot-VPS head architecture with seeded synthetic values
 (no checkpoints exist, README.md:25 of the reference). Clips are independent, so ranks share nothing
 (weak scaling); the per-clip results (uint8 slot-argmax maps + class logits) are gathered to rank 0
 over RCCL inside the timed region.
@@ -45,9 +46,9 @@ def parse():
     ap.add_argument("--slots", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--fast-p", action="store_true", help="bf16 P without the hi/lo split inside K1")
-    ap.add_argument("--clips-in-flight", type=int, default=2,
+    ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="independent clips per step, each replayed on its own HIP stream (a step then covers that many clips)")
-    ap.add_argument("--clips-per-launch", type=int, default=1,
+    ap.add_argument("--clips-per-launch", type=int, default=8,
                     help="independent clips stacked along the frame axis of every kernel launch (temporal attention stays per clip)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 to skip the CPU oracle leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
@@ -171,9 +172,12 @@ def main():
         achieved = alg / (k1_ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01", "k1_pmc_traffic.json")
-        if os.path.exists(pmc) and (a.height, a.width, a.frames, a.slots) == (1024, 2048, 5, 100):
+        wkey = f"{a.height}x{a.width} T={a.frames} L={a.slots} cpl={cpl}"
+        rec = None
+        if os.path.exists(pmc):
             with open(pmc) as fh:
                 rec = json.load(fh)
+        if rec is not None and rec.get("workload_key") == wkey:
             traffic = int(rec["traffic_bytes_per_launch"])          # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, avg per K1 launch
             traffic_src = "profiles/r01/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
