@@ -63,29 +63,35 @@ __device__ __forceinline__ u32x4 make_srd_p(const void* base, uint32_t bytes) {
 
 // see slot_attn.hip: asm so that hipcc does not drain the DMA ring before every LDS read
 __device__ __forceinline__ void dma16_srd_p(u32x4 srd, uint32_t lds_addr, int voff, int soff) {
+    uint32_t keep;      // M0 (LDS base of the DMA) is saved and restored inside the statement
     asm volatile(
-        "s_mov_b32 m0, %0\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %2, %3 offen lds"
-        :
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
         : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
-        : "memory", "m0");
+        : "memory");
 }
 
 // Four 1-KiB pieces with one M0 write: the instruction offset advances BOTH the global address and the LDS
 // address (LDS = M0 + inst_offset + lane * 16), so piece i lands at lds_addr + 1024 i and reads from
 // voff_i + soff + 1024 i - callers pre-subtract 1024 i from voff_i where the source is not contiguous.
 __device__ __forceinline__ void dma16x4_srd_p(u32x4 srd, uint32_t lds_addr, int v0, int v1, int v2, int v3, int soff) {
+    uint32_t keep;
     asm volatile(
-        "s_mov_b32 m0, %0\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
-        "buffer_load_dwordx4 %2, %5, %6 offen offset:1024 lds\n\t"
-        "buffer_load_dwordx4 %3, %5, %6 offen offset:2048 lds\n\t"
-        "buffer_load_dwordx4 %4, %5, %6 offen offset:3072 lds"
-        :
+        "buffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+        "buffer_load_dwordx4 %3, %6, %7 offen offset:1024 lds\n\t"
+        "buffer_load_dwordx4 %4, %6, %7 offen offset:2048 lds\n\t"
+        "buffer_load_dwordx4 %5, %6, %7 offen offset:3072 lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
         : "s"(lds_addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(srd), "s"(soff)
-        : "memory", "m0");
+        : "memory");
 }
 
 __device__ __forceinline__ float half_swap_add(float x) {

@@ -16,6 +16,7 @@
 // HBM-bound: reads T*HW*512 B, writes T*L*HW*4 B. Layout and staging are those of K1 (32-pixel
 // tiles by LDS-DMA into a 4-stage ring, wave w owns slots [32w, 32w+32), pixel = lane), so the
 // logits leave the accumulators as 128-B pixel-contiguous row segments of the [T, L, HW] output.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -189,6 +190,287 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path (L <= 128, HW % 4 == 0, fp32 out): same math and tile machinery, three changes that matter on gfx950
+// (every 1-KiB vector-memory instruction stalls its wave for ~75-200 cycles; hipcc drains the builtin DMA form):
+//   * LDS-DMA in inline asm (invisible to hipcc's counters), one M0 write per tile and wave, counted vmcnt;
+//   * the logits leave through a wave-local LDS transpose: 16 ds_write_b32 per lane, then four 16-byte-per-lane
+//     buffer stores per wave and tile (8 lanes = one 128-byte row segment of a slot) instead of 16 dword stores;
+//     invalid lanes (slot >= L, pixels past the chunk) get an out-of-range offset and are dropped by the hardware
+//     range check, so every wave issues the same number of stores and the vmcnt arithmetic stays exact;
+//   * the cross-wave part of the fused argmax of tile j runs at the top of tile j + 1 (double-buffered candidates):
+//     two workgroup barriers per tile instead of three.
+struct Dec2Lds {
+    static constexpr int kStages = 3;
+    static constexpr int ring = 0;                                   // 3 feature tiles
+    static constexpr int otile = kStages * kTileBytes;               // per wave [32 slots][32 px] fp32, 16-B chunks swizzled
+    static constexpr int affine = otile + 4 * 4096;                  // scale[256], shift[256]
+    static constexpr int norm = affine + 2 * kD * 4;                 // [32]
+    static constexpr int cshift = norm + kTilePx * 4;                // [128]
+    static constexpr int amax = cshift + 128 * 4;                    // [2][4][32] float2
+    static constexpr int total = amax + 2 * 4 * kTilePx * 8;
+};
+
+__device__ __forceinline__ u32x4 make_srd_d(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+    d[2] = __builtin_amdgcn_readfirstlane(bytes);
+    d[3] = 0x00020000u;
+    return d;
+}
+
+__device__ __forceinline__ void dma16_d(u32x4 srd, uint32_t lds_addr, int voff, int soff) {
+    uint32_t keep;      // M0 (LDS base of the DMA) is saved and restored inside the statement
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+        : "memory");
+}
+
+// four pieces, one M0 write: the instruction offset advances the LDS address and the global address together
+__device__ __forceinline__ void dma16x4_d(u32x4 srd, uint32_t lds_addr, int v0, int v1, int v2, int v3, int soff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %6, %7 offen lds\n\t"
+        "buffer_load_dwordx4 %3, %6, %7 offen offset:1024 lds\n\t"
+        "buffer_load_dwordx4 %4, %6, %7 offen offset:2048 lds\n\t"
+        "buffer_load_dwordx4 %5, %6, %7 offen offset:3072 lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(srd), "s"(soff)
+        : "memory");
+}
+
+// counted like the DMA: asm, so that hipcc neither reorders nor skips it (exact vmcnt arithmetic)
+__device__ __forceinline__ void store16_d(u32x4 val, u32x4 srd, int voff) {
+    // s_nop: gfx950 reads the data VGPRs of a >64-bit store late; hipcc's hazard pass does not see inside asm
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(val), "v"(voff), "s"(srd) : "memory");
+}
+__device__ __forceinline__ void store1_d(int val, u32x4 srd, int voff) {
+    asm volatile("buffer_store_byte %0, %1, %2, 0 offen" : : "v"(val), "v"(voff), "s"(srd) : "memory");
+}
+
+__device__ __forceinline__ void wait_vm_dyn(int n) {      // n is wave-uniform
+    switch (n) {
+#define SVPS_WV(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        SVPS_WV(0) SVPS_WV(1) SVPS_WV(2) SVPS_WV(3) SVPS_WV(4) SVPS_WV(5) SVPS_WV(6) SVPS_WV(7) SVPS_WV(8) SVPS_WV(9)
+        SVPS_WV(10) SVPS_WV(11) SVPS_WV(12) SVPS_WV(13) SVPS_WV(14) SVPS_WV(15) SVPS_WV(16) SVPS_WV(17) SVPS_WV(18)
+#undef SVPS_WV
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <bool ARGMAX>
+__global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
+    const __bf16* __restrict__ feat, const float* __restrict__ embed, const float* __restrict__ bn_scale,
+    const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
+    uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = Dec2Lds;
+    constexpr int NST = Lds::kStages;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r_ = lane & 31, h_ = lane >> 5;
+    int r = r_, h = h_;
+    const int t = blockIdx.y, c = blockIdx.x;
+
+    const int px_begin = c * tiles_per_chunk * kTilePx;
+    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    px_end = px_end < HW ? px_end : HW;
+    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+
+    float* aff = reinterpret_cast<float*>(smem + Lds::affine);
+    float* inv_norm = reinterpret_cast<float*>(smem + Lds::norm);
+    float* cs = reinterpret_cast<float*>(smem + Lds::cshift);
+    float2* am = reinterpret_cast<float2*>(smem + Lds::amax);
+
+    for (int i = tid; i < kD; i += 256) {
+        aff[i] = bn_scale[i];
+        aff[kD + i] = bn_shift[i];
+    }
+    __syncthreads();
+
+    bf16x8 eh[16], el[16];
+    {
+        const int slot = 32 * w + r;
+        const float* erow = embed + ((size_t)t * L + (slot < L ? slot : 0)) * kD + 8 * h;
+        float dot = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(erow + 16 * ks);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(erow + 16 * ks + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = 16 * ks + 8 * h + j;
+                float x = j < 4 ? x0[j] : x1[j - 4];
+                if (slot >= L) x = 0.f;
+                dot += x * aff[kD + ch];
+                const float xs = x * aff[ch];
+                const __bf16 hi = (__bf16)xs;
+                eh[ks][j] = hi;
+                el[ks][j] = (__bf16)(xs - (float)hi);
+            }
+        }
+        dot = wave_half_xor_sum(dot);
+        if (h == 0) cs[32 * w + r] = dot;
+    }
+    wait_vm<0>();
+    __syncthreads();
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+    const u32x4 frs = make_srd_d(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 ors = make_srd_d(out + (size_t)t * L * HW, (uint32_t)L * (uint32_t)HW * 4u);
+    const u32x4 ars = make_srd_d(ARGMAX ? slot_argmax + (size_t)t * HW : nullptr, ARGMAX ? (uint32_t)HW : 0u);
+    auto stage = [&](int tile) {          // exactly four DMA instructions per wave, or none
+        if (tile >= nt) return;
+        int voff[4];                      // recomputed per tile (a handful of VALU ops) rather than held in VGPRs
+        {
+            int rr = r_, hh = h_;
+            asm volatile("" : "+v"(rr), "+v"(hh));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * w + 2 * i + hh;
+                voff[i] = row * kRowBytes + ((rr ^ swz(row)) * 16);
+            }
+        }
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * kTileBytes + w * 4096);
+        const int px0 = px_begin + tile * kTilePx;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + kTilePx <= HW) {
+            dma16x4_d(frs, st, voff[0], voff[1] - 1024, voff[2] - 2048, voff[3] - 3072, soff);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * w + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                dma16_d(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+            }
+        }
+    };
+    const int amw = (ARGMAX && w == 0) ? 1 : 0;          // wave 0 also stores the argmax bytes: one more store per tile
+    auto finish_argmax = [&](int tile) {                 // cross-wave part of the argmax of `tile`, wave 0
+        if (h == 0) {
+            float b = -INFINITY;
+            int bs = 0x7fffffff;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const float2 cnd = am[(tile & 1) * 4 * kTilePx + ww * kTilePx + r];
+                const int sl = __float_as_int(cnd.y);
+                if (cnd.x > b || (cnd.x == b && sl < bs)) { b = cnd.x; bs = sl; }
+            }
+            const int px = px_begin + tile * kTilePx + r;
+            store1_d(bs, ars, px < px_end ? px : 0x7ffffff0);
+        } else {
+            store1_d(0, ars, 0x7ffffff0);                // same instruction for every lane; dropped by the range check
+        }
+    };
+
+    stage(0);
+    stage(1);
+
+    char* ot = smem + Lds::otile + w * 4096;
+
+    for (int it = 0; it < nt; ++it) {
+        // tile `it` landed (this wave's pieces). Younger than its DMA, in issue order: argmax(it-3), stores(it-2),
+        // DMA(it+1), argmax(it-2), stores(it-1).
+        wait_vm_dyn(4 * ((it >= 2) + (it >= 1)) + 4 * (it + 1 < nt) + amw * ((it >= 3) + (it >= 2)));
+        wg_barrier();
+        stage(it + 2);
+        int tid_o = tid, lane_o = lane;
+        r = r_; h = h_;
+        asm volatile("" : "+v"(r), "+v"(h), "+v"(tid_o), "+v"(lane_o));   // opaque per tile: no loop-invariant address tables in VGPRs
+        if (ARGMAX && w == 0 && it >= 1) finish_argmax(it - 1);
+        const char* ft = smem + Lds::ring + (it % NST) * kTileBytes;
+
+        {   // ||scale * f + shift||^2 per pixel: 8 threads per pixel, 4 chunks each
+            const int npx = tid_o >> 3, nsub = tid_o & 7;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int chunk = nsub + 8 * i;
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g = (float)x[j] * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
+                    ss += g * g;
+                }
+                __builtin_amdgcn_sched_barrier(0);       // one chunk at a time: the affine rows are not worth 64 VGPRs
+            }
+            ss += __shfl_xor(ss, 1);
+            ss += __shfl_xor(ss, 2);
+            ss += __shfl_xor(ss, 4);
+            if (nsub == 0) inv_norm[npx] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+        }
+
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        {
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {          // four operand fragments in flight (register budget: 128 hold e)
+                bf16x8 ff[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ff[u] = read_row_frag(ft, 4 * grp + u, r, h);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el[4 * grp + u], ff[u], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh[4 * grp + u], ff[u], s, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        wg_barrier();                                    // inv_norm of this tile visible
+
+        const float inr = inv_norm[r];
+        float best = -INFINITY;
+        int best_slot = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int sl = acc_row(i, h);                // slot inside this wave's block of 32
+            f32x4 c4;
+            if ((i & 3) == 0) c4 = *reinterpret_cast<const f32x4*>(cs + 32 * w + sl);   // e . shift of slots sl .. sl + 3
+            const float m = (s[i] + c4[i & 3]) * inr * fg_scale + fg_shift;
+            *reinterpret_cast<float*>(ot + sl * 128 + (((r >> 2) ^ (sl & 7)) * 16) + (r & 3) * 4) = m;
+            if constexpr (ARGMAX) {
+                if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
+            }
+        }
+        if constexpr (ARGMAX) {
+            const float ob = __shfl_xor(best, 32);
+            const int os = __shfl_xor(best_slot, 32);
+            if (ob > best || (ob == best && os < best_slot)) { best = ob; best_slot = os; }
+            if (h == 0) am[(it & 1) * 4 * kTilePx + w * kTilePx + r] = make_float2(best, __int_as_float(best_slot));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local transpose: own writes done, no barrier needed
+        const int px0 = px_begin + it * kTilePx;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int sl = 8 * u + (lane_o >> 3), cc = lane_o & 7;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * 128 + ((cc ^ (sl & 7)) * 16));
+            const int slot = 32 * w + sl, px = px0 + 4 * cc;
+            const bool ok = slot < L && px < px_end;
+            store16_d(val, ors, ok ? (slot * HW + px) * 4 : 0x7ffffff0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (ARGMAX) {
+        wg_barrier();
+        if (w == 0) finish_argmax(nt - 1);
+    }
+}
+
 }  // namespace svps
 
 namespace {
@@ -230,6 +512,29 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
     return hipGetLastError();
 }
 
+template <bool ARGMAX>
+hipError_t launch_decode_v2(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
+                            float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L, int HW,
+                            hipStream_t stream) {
+    auto kern = svps::mask_decode_kernel_v2<ARGMAX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, svps::Dec2Lds::total);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;      // two co-resident workgroups per CU (2 x 68 KiB LDS)
+    int chunks = 2 * dec_num_cus() / T;
+    if (chunks < 1) chunks = 1;
+    if (chunks > tiles) chunks = tiles;
+    const int tpc = (tiles + chunks - 1) / chunks;
+    chunks = (tiles + tpc - 1) / tpc;
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(256), svps::Dec2Lds::total, stream, static_cast<const __bf16*>(feat),
+                       embed, bn_scale, bn_shift, fg_scale, fg_shift, static_cast<float*>(out), slot_argmax, L, HW, tpc);
+    return hipGetLastError();
+}
+
 template <int NW, int NST>
 hipError_t dispatch_decode(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
                            float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L,
@@ -252,7 +557,14 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || HW <= 0) return SVPS_ERR_BAD_SHAPE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 0, stream);
-    hipError_t e = L <= 128 ? dispatch_decode<4, 4>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
+    // fast path: 16-byte row-segment stores need 4-pixel alignment of every slot row; L * HW * 4 must fit a buffer descriptor
+    const bool fast = L <= 128 && (HW & 3) == 0 && !(flags & SVPS_FLAG_OUT_BF16) && (size_t)L * HW * 4 < 0x7ffffff0u &&
+                      getenv("SVPS_K2_LEGACY") == nullptr;
+    hipError_t e = fast ? (slot_argmax ? launch_decode_v2<true>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
+                                                                 slot_argmax, T, L, HW, stream)
+                                       : launch_decode_v2<false>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
+                                                                  slot_argmax, T, L, HW, stream))
+                   : L <= 128 ? dispatch_decode<4, 4>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
                                                     slot_argmax, T, L, HW, flags, stream)
                             : dispatch_decode<8, 4>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
                                                     slot_argmax, T, L, HW, flags, stream);

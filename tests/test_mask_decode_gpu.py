@@ -54,6 +54,9 @@ def _run(cuda, T, L, HW, seed, default_bn):
     (1, 1, 40, False),
     (2, 200, 2040, False),     # VIPER slots (8-wave kernel)
     (1, 128, 8192, True),
+    (20, 100, 6144, False),    # several tiles per workgroup (counted DMA / store ring, deferred argmax), fast path
+    (20, 100, 6148, False),    # the same with a ragged last tile
+    (3, 100, 2050, False),     # HW % 4 != 0: scalar-store kernel
 ])
 def test_mask_decode_matches_oracle(cuda, T, L, HW, default_bn):
     worst = _run(cuda, T, L, HW, seed=L + HW, default_bn=default_bn)
