@@ -6,7 +6,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over one batch of synthetic clips per rank: `--clips-per-launch`
-(default 8) independent T=5 clips of 1024x2048 stacked along the frame axis -> four levels of 128-channel
+(default 16) independent T=5 clips of 1024x2048 stacked along the frame axis -> four levels of 128-channel
 FPN feature maps (32x64 ... 256x512, resident in HBM) -> the 7-stage multi-scale slot head (K4, K3, K1
 once per level / stage for all frames of the batch; temporal slot attention stays inside each clip) ->
 slot->mask decode of all frames (K2). Weights: the R50-FPN Slot-VPS head architecture with seeded synthetic values
@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--fast-p", action="store_true", help="bf16 P without the hi/lo split inside K1")
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="independent clips per step, each replayed on its own HIP stream (a step then covers that many clips)")
-    ap.add_argument("--clips-per-launch", type=int, default=8,
+    ap.add_argument("--clips-per-launch", type=int, default=16,
                     help="independent clips stacked along the frame axis of every kernel launch (temporal attention stays per clip)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 to skip the CPU oracle leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")

@@ -193,8 +193,9 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
     commit(pre);
     for (int it = 0; it < nt; ++it) {
         __syncthreads();                                   // a(it): operand tile it built, out tile it-1 complete
-        if (it >= 1) store_out(it - 1);
+        // loads first: vmcnt retires in order, so the wait for the taps must not sit behind the stores of the previous tile
         if (it + 1 < nt) prefetch(it + 1, pre);            // taps of the next tile fly under the MFMAs
+        if (it >= 1) store_out(it - 1);
         int r = r_, h = h_;
         asm volatile("" : "+v"(r), "+v"(h));
         const char* at = smem + Lds::atile;
