@@ -208,6 +208,9 @@ class VPS_Temporal_Slots(nn.Module):
             self.postprocess_panoptic = PostProcessPanopticInstances(**pp)
         self.prev_embedding = None
         self._fold = None
+        self.reuse_ref_features = True           # keep the previous frame's level maps
+        self._ref_cache = None
+        self.ref_reuse_hits = 0
 
     # ---- pieces of simple_test ---------------------------------------------------------------------
     def extract_semantic_feats(self, x):
@@ -231,22 +234,34 @@ class VPS_Temporal_Slots(nn.Module):
         return super().load_state_dict(*a, **k)
 
     @torch.no_grad()
-    def slot_path(self, imgs):
-        """imgs [T, 3, H, W] -> (class logits [T, L, nc] of the last stage, slot embeddings [T, L, 256],
-        mask logits [T, L, H/4, W/4], semantic logits [T, nc_sem, H, W])."""
+    def trunk(self, imgs):
+        """PyTorch part: imgs [T, 3, H, W] -> (per level [T, 128, Hi, Wi] fp32 maps coarse -> fine, the slot head's
+        input; semantic logits [T, nc_sem, H, W])."""
         im = self.image_model
         x = im.backbone(imgs)
         if im.with_neck:
             x = im.neck(x)
         fcn_output, _, fcn_feature = self.extract_semantic_feats(x)
-        feats = [f.float().contiguous() for f in self.semantic_trans_ins(fcn_feature)]         # coarse -> fine
+        return [f.float().contiguous() for f in self.semantic_trans_ins(fcn_feature)], fcn_output
+
+    @torch.no_grad()
+    def head_path(self, feats):
+        """HIP part: level maps -> (class logits [T, L, nc] of the last stage, slot embeddings [T, L, 256],
+        mask logits [T, L, H/4, W/4])."""
+        im = self.image_model
         D = im.init_mask_query.weight.shape[1]
         pos_tabs = [ops.pos_embed_sine_tables(f.shape[-2], f.shape[-1], D, f.device) for f in feats]
         logits, embeds, fused = im.dynamic_mask_head.forward_clip(feats, im.init_mask_query.weight, pos_tabs)
         scale, shift, fs, fb = self._decode_fold()
         masks = ops.mask_decode(fused[-1], embeds[-1].contiguous(), scale, shift, fs, fb)
         h, w = feats[-1].shape[-2:]
-        return logits[-1], embeds[-1], masks.view(masks.shape[0], masks.shape[1], h, w), fcn_output
+        return logits[-1], embeds[-1], masks.view(masks.shape[0], masks.shape[1], h, w)
+
+    @torch.no_grad()
+    def slot_path(self, imgs):
+        """imgs [T, 3, H, W] -> (class logits, slot embeddings, mask logits, semantic logits [T, nc_sem, H, W])."""
+        feats, fcn_output = self.trunk(imgs)
+        return self.head_path(feats) + (fcn_output,)
 
     def _track(self, embedding, first):
         """Tracker step over ALL surviving segments of the frame (stuff and things, :345-409)."""
@@ -292,8 +307,25 @@ class VPS_Temporal_Slots(nn.Module):
         assert self.other_config.get("test_forward_ref_img", False) is True and ref_img is not None
         if self.num_classes in (19, 20):
             assert meta["ori_shape"][0] == img.shape[2] and meta["ori_shape"][1] == img.shape[3]
-        logits, embeds, masks, fcn = self.slot_path(torch.cat([ref_img, img], 0))
-        return self._frame_result(logits[1], masks[1], embeds[1], fcn[1:2], meta["ori_shape"], self.fid == 1)
+        if not self.reuse_ref_features:
+            logits, embeds, masks, fcn = self.slot_path(torch.cat([ref_img, img], 0))
+            return self._frame_result(logits[1], masks[1], embeds[1], fcn[1:2], meta["ori_shape"], self.fid == 1)
+        # The reference runs backbone + neck + semantic tower on the reference frame again at every step (:245-260),
+        # although it is the frame it processed in the previous call (or the current frame itself for the first frame
+        # of a video, tools/dataset/cityscapes_vps.py:262). Its level maps are kept instead; identity is checked on
+        # the pixels (a copy: loaders may recycle their buffers).
+        cur_feats, fcn = self.trunk(img)
+        if ref_img.shape == img.shape and torch.equal(ref_img, img):
+            ref_feats = cur_feats
+            self.ref_reuse_hits += 1
+        elif self._ref_cache is not None and self._ref_cache[0].shape == ref_img.shape and torch.equal(self._ref_cache[0], ref_img):
+            ref_feats = self._ref_cache[1]
+            self.ref_reuse_hits += 1
+        else:
+            ref_feats, _ = self.trunk(ref_img)
+        self._ref_cache = (img.clone(), cur_feats)
+        logits, embeds, masks = self.head_path([torch.cat([r, c], 0) for r, c in zip(ref_feats, cur_feats)])
+        return self._frame_result(logits[1], masks[1], embeds[1], fcn, meta["ori_shape"], self.fid == 1)
 
     @torch.no_grad()
     def clip_test(self, imgs, img_metas):

@@ -192,11 +192,19 @@ def test_simple_test_reference_call_convention():
     for t in (1, 2):                                         # frame t with frame t-1 as its reference image
         meta = dict(iid=20000 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png")
         outs.append(det(img=[frames[t]], img_meta=[[meta]], return_loss=False, rescale=True, ref_img=[frames[t - 1]]))
+    assert det.ref_reuse_hits == 1           # frame 2's reference frame is frame 1: its level maps were kept
     for r in outs:
         assert set(r) == {"fcn_outputs", "panoptic_cls_inds", "panoptic_cls_prob", "panoptic_det_obj_ids", "panoptic_outputs"}
         ids = torch.unique(r["panoptic_outputs"])
         assert (ids[ids > 10]).numel() == len(r["panoptic_cls_inds"])          # the reference's MISMATCH check (:453-458)
         assert len(r["panoptic_det_obj_ids"]) == len(r["panoptic_cls_inds"]) == len(r["panoptic_cls_prob"])
+    # same frames with the reference's recompute-everything behaviour: same result structure, tracker ids of frame 1
+    det2 = _make_detector(dev)
+    det2.reuse_ref_features = False
+    meta = dict(iid=20001, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename="f1.png")
+    r2 = det2(img=[frames[1]], img_meta=[[meta]], return_loss=False, rescale=True, ref_img=[frames[0]])
+    assert det2.ref_reuse_hits == 0 and set(r2) == set(outs[0])
+    assert r2["panoptic_outputs"].shape == outs[0]["panoptic_outputs"].shape
 
 
 @pytest.mark.gpu
