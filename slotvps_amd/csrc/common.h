@@ -52,6 +52,19 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (0..31; larger values wait for everything)
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+    switch (n) {
+#define SVPS_WV(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        SVPS_WV(0) SVPS_WV(1) SVPS_WV(2) SVPS_WV(3) SVPS_WV(4) SVPS_WV(5) SVPS_WV(6) SVPS_WV(7) SVPS_WV(8) SVPS_WV(9)
+        SVPS_WV(10) SVPS_WV(11) SVPS_WV(12) SVPS_WV(13) SVPS_WV(14) SVPS_WV(15) SVPS_WV(16) SVPS_WV(17) SVPS_WV(18)
+        SVPS_WV(19) SVPS_WV(20) SVPS_WV(21) SVPS_WV(22) SVPS_WV(23) SVPS_WV(24) SVPS_WV(25) SVPS_WV(26) SVPS_WV(27)
+        SVPS_WV(28) SVPS_WV(29) SVPS_WV(30) SVPS_WV(31)
+#undef SVPS_WV
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 // One 1-KiB LDS-DMA piece: 64 lanes x 16 B, destination = lds_base + lane * 16 (hardware adds the
 // lane term; lds_base must be wave-uniform), source = per-lane global pointer.
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_base) {

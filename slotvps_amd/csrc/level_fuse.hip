@@ -23,6 +23,7 @@
 //
 // Roofline: HBM - per output pixel 512 B (fp32 NCHW input) or 256 B (bf16) in, 512 B out; the four
 // upsampling taps come from the 4x smaller previous level (L2 / Infinity Cache resident).
+#include <cstdlib>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -228,6 +229,274 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
     store_out(nt - 1);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path for levels > 0 with W % 32 == 0 (every headline level): a tile is 32 consecutive pixels of ONE output row,
+// so its bilinear taps come from two rows x 18 columns of the previous level. Those 18 KiB are staged once per tile by
+// LDS-DMA (inline asm, 18 instructions per workgroup) and blended from LDS, instead of 8 scattered 16-byte global loads
+// per thread (64 KiB per tile through the texture-address path, 3.5x redundant). The incoming NCHW fp32 map is read
+// by (channel pair, pixel quad) threads - two 16-byte loads, four packed 4-byte LDS writes - and the out tile leaves
+// through buffer stores with linear addressing (hardware range check, no per-store address arithmetic).
+// Order of vector-memory operations per iteration: DMA (asm) and the map loads of tile it+1 first, the stores of tile
+// it-1 last: vmcnt retires in order, so `vmcnt(#stores)` before barrier b covers every load without draining the stores.
+struct Fuse2Lds {
+    static constexpr int atile = 0;                                 // [32][384] bf16 operand tile
+    static constexpr int otile = kTilePx * kFuseRowBytes;           // [32][256] bf16 out tile
+    static constexpr int stage = otile + kTileBytes;                // [2 rows][18 px][512 B] taps of the next tile
+    static constexpr int kStageCols = 18;
+    static constexpr int stage_bytes = 2 * kStageCols * kRowBytes;
+    static constexpr int cur = stage + 2 * stage_bytes;              // incoming map of a tile as it lies in memory: [128][32] fp32 or [32][128] bf16
+    static constexpr int cur_bytes = 128 * kTilePx * 4;
+    static constexpr int total = cur + 2 * cur_bytes;                // taps and map are requested two tiles ahead: double-buffered
+};
+
+template <bool NCHW_F32, int ABL = 0>
+__global__ __launch_bounds__(512) void level_fuse_kernel_v2(
+    const void* __restrict__ cur_, const __bf16* __restrict__ prev, const __bf16* __restrict__ wc,
+    const float* __restrict__ bc, __bf16* __restrict__ out, int H, int W, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = Fuse2Lds;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r_ = lane & 31, h_ = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x;
+    const int HW = H * W;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const int tiles = HW / kTilePx;                                  // W % 32 == 0: no ragged tile
+    const int tile_begin = c * tiles_per_chunk;
+    int tile_end = tile_begin + tiles_per_chunk;
+    tile_end = tile_end < tiles ? tile_end : tiles;
+    const int nt = tile_end - tile_begin;
+    const int px_begin = tile_begin * kTilePx;
+
+    bf16x8 wf[24];
+    {
+        const __bf16* row = wc + (size_t)(32 * w + r_) * kFuseIn + 8 * h_;
+#pragma unroll
+        for (int ks = 0; ks < 24; ++ks)
+            wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
+    }
+    float bias[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bias[i] = bc[32 * w + acc_row(i, h_)];
+
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+    u32x4 psrd;
+    {
+        const uint64_t a = reinterpret_cast<uint64_t>(prev + (size_t)t * Hp * Wp * kD);
+        psrd[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+        psrd[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+        psrd[2] = __builtin_amdgcn_readfirstlane((uint32_t)(Hp * Wp) * kRowBytes);
+        psrd[3] = 0x00020000u;
+    }
+    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(out + (size_t)t * HW * kD), 0, HW * kRowBytes, 0x00020000);
+
+    // tile geometry (wave-uniform): output row y, first column x0; source rows ys0 / ys1 with weight wy of ys1;
+    // staged columns xs_base .. xs_base + 17 (clamped into the row when read from memory)
+    struct Geo { int ys0, ys1, xs_base, x0; float wy; };
+    auto geometry = [&](int tile) {
+        Geo g;
+        const int px0 = px_begin + tile * kTilePx;
+        const int y = px0 / W;
+        g.x0 = px0 - y * W;
+        const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
+        g.ys0 = (int)sy;
+        g.ys1 = g.ys0 + 1 < Hp ? g.ys0 + 1 : Hp - 1;
+        g.wy = sy - (float)g.ys0;
+        g.xs_base = (g.x0 >> 1) - 1;
+        return g;
+    };
+    // DMA instruction q (0..17) of a tile: source row q / 9, staged columns 2 (q % 9) and 2 (q % 9) + 1; wave w issues q = w, w + 8, w + 16
+    auto stage_taps = [&](int tile) {
+        if constexpr (ABL & 8) return;
+        const Geo g = geometry(tile);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int q = w + 8 * k;
+            if (q >= 18) break;
+            const int row = q / 9, cp = q - 9 * row;
+            int col = g.xs_base + 2 * cp + h_;
+            col = col < 0 ? 0 : (col < Wp ? col : Wp - 1);
+            const int ys = row ? g.ys1 : g.ys0;
+            const int voff = (ys * Wp + col) * kRowBytes + (lane & 31) * 16;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::stage + (tile & 1) * Lds::stage_bytes +
+                                                                (row * Lds::kStageCols + 2 * cp) * kRowBytes);
+            uint32_t keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %1\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "s"(dst), "v"(voff), "s"(psrd)
+                : "memory");
+        }
+    };
+
+    // incoming map of a tile -> LDS by DMA, in its memory layout. NCHW fp32: one instruction = 8 channels x 32 pixels
+    // (lane = (channel, pixel quad)), 16 per tile, wave w issues channels 8w.. and 64 + 8w..; pixel-major bf16: the tile is
+    // one contiguous 8 KiB block, one instruction per wave.
+    u32x4 csrd;
+    {
+        const size_t frame = NCHW_F32 ? (size_t)128 * HW * 4 : (size_t)HW * 256;
+        const uint64_t a = reinterpret_cast<uint64_t>(static_cast<const char*>(cur_) + (size_t)t * frame);
+        csrd[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+        csrd[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+        csrd[2] = __builtin_amdgcn_readfirstlane((uint32_t)frame);
+        csrd[3] = 0x00020000u;
+    }
+    constexpr int kCurDma = NCHW_F32 ? 2 : 1;            // map DMA instructions per wave and tile
+    auto stage_cur = [&](int tile) {
+        if constexpr (ABL & 8) return;
+        const int px0 = px_begin + tile * kTilePx;
+        const uint32_t base = lds0 + Lds::cur + (tile & 1) * Lds::cur_bytes;
+#pragma unroll
+        for (int k = 0; k < kCurDma; ++k) {
+            int voff, soff;
+            uint32_t dst;
+            if constexpr (NCHW_F32) {
+                const int ch = 8 * w + 64 * k + (lane >> 3);
+                voff = (ch * HW + 4 * (lane & 7)) * 4;
+                soff = __builtin_amdgcn_readfirstlane(px0 * 4);
+                dst = __builtin_amdgcn_readfirstlane(base + (8 * w + 64 * k) * kTilePx * 4);
+            } else {
+                voff = w * 1024 + lane * 16;
+                soff = __builtin_amdgcn_readfirstlane(px0 * 256);
+                dst = __builtin_amdgcn_readfirstlane(base + w * 1024);
+            }
+            uint32_t keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %1\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "s"(dst), "v"(voff), "s"(csrd), "s"(soff)
+                : "memory");
+        }
+    };
+    auto commit = [&](int tile) {
+        char* at = smem + Lds::atile;
+        const char* cs = smem + Lds::cur + (tile & 1) * Lds::cur_bytes;
+        struct { f32x4 c0, c1; u32x4 cb; } p;
+        if constexpr (NCHW_F32) {
+            const int cp = tid >> 3, pq = tid & 7;                     // channels 2cp, 2cp + 1; pixels 4pq .. 4pq + 3
+            p.c0 = *reinterpret_cast<const f32x4*>(cs + (2 * cp) * kTilePx * 4 + pq * 16);
+            p.c1 = *reinterpret_cast<const f32x4*>(cs + (2 * cp + 1) * kTilePx * 4 + pq * 16);
+            const int chunk = 32 + (cp >> 2), sub = (cp & 3) * 4;      // 16-byte chunk of channels 256 + 2cp, byte inside it
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                bf16x2 v2;
+                v2[0] = (__bf16)p.c0[j];
+                v2[1] = (__bf16)p.c1[j];
+                *reinterpret_cast<bf16x2*>(at + a_off(4 * pq + j, chunk) + sub) = v2;
+            }
+        } else {
+            const int px = tid >> 4, ck = tid & 15;
+            p.cb = *reinterpret_cast<const u32x4*>(cs + px * 256 + ck * 16);
+            *reinterpret_cast<u32x4*>(at + a_off(px, 32 + ck)) = p.cb;
+        }
+        // bilinear x2 from the staged rows: thread = (pixel, chunks ck and ck + 16)
+        const Geo g = geometry(tile);
+        const int px = tid >> 4, ck = tid & 15;
+        const int x = g.x0 + px;
+        const float sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int xs0 = (int)sx;
+        const int xs1 = xs0 + 1 < Wp ? xs0 + 1 : Wp - 1;
+        const float w1 = sx - (float)xs0, w0 = 1.f - w1, h1 = g.wy, h0 = 1.f - g.wy;
+        const char* st = smem + Lds::stage + (tile & 1) * Lds::stage_bytes;
+        const char* t00 = st + (xs0 - g.xs_base) * kRowBytes;
+        const char* t01 = st + (xs1 - g.xs_base) * kRowBytes;
+        const char* t10 = t00 + Lds::kStageCols * kRowBytes;
+        const char* t11 = t01 + Lds::kStageCols * kRowBytes;
+#pragma unroll
+        for (int u = 0; u < ((ABL & 4) ? 0 : 2); ++u) {
+            const int co = 16 * (ck + 16 * u);
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(t00 + co), b = *reinterpret_cast<const bf16x8*>(t01 + co);
+            const bf16x8 cc = *reinterpret_cast<const bf16x8*>(t10 + co), d = *reinterpret_cast<const bf16x8*>(t11 + co);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)   // torch's upsample_bilinear2d: (1-ly) * ((1-lx) a + lx b) + ly * ((1-lx) c + lx d) in fp32
+                o[j] = (__bf16)(h0 * (w0 * (float)a[j] + w1 * (float)b[j]) + h1 * (w0 * (float)cc[j] + w1 * (float)d[j]));
+            *reinterpret_cast<bf16x8*>(at + a_off(px, ck + 16 * u)) = o;
+        }
+    };
+    auto store_out = [&](int tile) {                                  // 16 KiB per tile, 2 x 16 B per thread, linear in HBM
+        const int base = (px_begin + tile * kTilePx) * kRowBytes + tid * 16;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = 16 * u + (tid >> 5), gc = tid & 31;
+            const u32x4 val = *reinterpret_cast<const u32x4*>(smem + Lds::otile + row * kRowBytes + ((gc ^ swz(row)) * 16));
+            if constexpr (!(ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(val, osrd, base + u * 8192, 0, 0);
+        }
+    };
+
+    // Two tiles ahead: taps and map of tile it+2 are requested at the top of iteration it and consumed by commit(it+2)
+    // at the end of iteration it+1, so a full tile of work covers their latency. All requests are asm LDS-DMA (invisible
+    // to hipcc, which would otherwise wait for them early); the only compiler-visible vector-memory operations are the
+    // two buffer stores per thread and tile, which hipcc never waits for.
+    const int n_req = (w < 2 ? 3 : 2) + kCurDma;         // DMA instructions of this wave per tile (18 tap pieces over 8 waves)
+    stage_taps(0);
+    stage_cur(0);
+    if (nt > 1) {
+        stage_taps(1);
+        stage_cur(1);
+        wait_vm_dyn(n_req);                              // tile 0 landed; tile 1 may still fly
+    } else {
+        wait_vm<0>();
+    }
+    __syncthreads();
+    commit(0);
+    for (int it = 0; it < nt; ++it) {
+        __syncthreads();                                   // a(it): operand tile it built, out tile it-1 complete, requests of tile it consumed
+        if (it + 2 < nt) {
+            stage_taps(it + 2);
+            stage_cur(it + 2);
+        }
+        int r = r_, h = h_;
+        asm volatile("" : "+v"(r), "+v"(h));
+        const char* at = smem + Lds::atile;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bias[i];
+#pragma unroll
+        for (int grp = 0; grp < ((ABL & 2) ? 0 : 3); ++grp) {
+            bf16x8 xf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xf[u] = *reinterpret_cast<const bf16x8*>(at + a_off(r, 2 * (8 * grp + u) + h));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[8 * grp + u], xf[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it >= 1) store_out(it - 1);                    // after the MFMAs: the address path has drained the requests above
+        // tile it+1 landed. Younger, in issue order: stores(it-2) [issued in iteration it-1 after the requests of tile
+        // it+1], requests of tile it+2, stores(it-1).
+        if (it + 1 < nt) {
+            constexpr int kSt = (ABL & 1) ? 0 : 2;
+            wait_vm_dyn((it >= 2 ? kSt : 0) + (it + 2 < nt ? n_req : 0) + (it >= 1 ? kSt : 0));
+        }
+        __syncthreads();                                   // b(it): every wave is done reading operand tile it; tile it+1's requests visible
+        char* ot = smem + Lds::otile;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[4 * g + j];
+            const int ch0 = 32 * w + 8 * g + 4 * h;
+            *reinterpret_cast<bf16x4*>(ot + r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
+        }
+        if (it + 1 < nt) commit(it + 1);
+    }
+    __syncthreads();
+    store_out(nt - 1);
+}
+
 }  // namespace svps
 
 namespace {
@@ -258,6 +527,48 @@ hipError_t launch_fuse(const void* cur, const void* prev, const void* wc, const 
                        static_cast<__bf16*>(out), H, W, tpc);
     return hipGetLastError();
 }
+
+template <bool NCHW>
+hipError_t launch_fuse_v2(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
+                          int W, hipStream_t stream) {
+    auto kern = svps::level_fuse_kernel_v2<NCHW>;
+#ifdef SVPS_K4_ABLATE
+    {
+        static int abl = -1;
+        if (abl < 0) { const char* e = getenv("SVPS_K4_ABLATE"); abl = e ? atoi(e) : 0; }
+        switch (abl) {
+            case 1: kern = svps::level_fuse_kernel_v2<NCHW, 1>; break;
+            case 2: kern = svps::level_fuse_kernel_v2<NCHW, 2>; break;
+            case 4: kern = svps::level_fuse_kernel_v2<NCHW, 4>; break;
+            case 8: kern = svps::level_fuse_kernel_v2<NCHW, 8>; break;
+            case 6: kern = svps::level_fuse_kernel_v2<NCHW, 6>; break;
+            case 7: kern = svps::level_fuse_kernel_v2<NCHW, 7>; break;
+            case 15: kern = svps::level_fuse_kernel_v2<NCHW, 15>; break;
+            case 14: kern = svps::level_fuse_kernel_v2<NCHW, 14>; break;
+            case 11: kern = svps::level_fuse_kernel_v2<NCHW, 11>; break;
+            default: break;
+        }
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, svps::Fuse2Lds::total);
+    }
+#endif
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, svps::Fuse2Lds::total);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = H * W / svps::kTilePx;
+    int chunks = fuse_num_cus() / T;
+    if (chunks < 1) chunks = 1;
+    if (chunks > tiles) chunks = tiles;
+    const int tpc = (tiles + chunks - 1) / chunks;
+    chunks = (tiles + tpc - 1) / tpc;
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::Fuse2Lds::total, stream, cur,
+                       static_cast<const __bf16*>(prev), static_cast<const __bf16*>(wc), bc,
+                       static_cast<__bf16*>(out), H, W, tpc);
+    return hipGetLastError();
+}
 }  // namespace
 
 extern "C" int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, const void* wc,
@@ -268,7 +579,12 @@ extern "C" int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const v
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 0, stream);
     hipError_t e;
-    if (prev)
+    // fast path: tiles inside one output row, frame sizes inside a buffer descriptor
+    const bool fast = prev && (W & 31) == 0 && (size_t)H * W * 512 < 0x7fffffffu && getenv("SVPS_K4_LEGACY") == nullptr;
+    if (fast)
+        e = cur_is_nchw_f32 ? launch_fuse_v2<true>(cur, prev, wc, bc, out, T, H, W, stream)
+                            : launch_fuse_v2<false>(cur, prev, wc, bc, out, T, H, W, stream);
+    else if (prev)
         e = cur_is_nchw_f32 ? launch_fuse<true, false>(cur, prev, wc, bc, out, T, H, W, stream)
                             : launch_fuse<false, false>(cur, prev, wc, bc, out, T, H, W, stream);
     else

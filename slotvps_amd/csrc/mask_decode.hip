@@ -261,16 +261,6 @@ __device__ __forceinline__ void store1_d(int val, u32x4 srd, int voff) {
     asm volatile("buffer_store_byte %0, %1, %2, 0 offen" : : "v"(val), "v"(voff), "s"(srd) : "memory");
 }
 
-__device__ __forceinline__ void wait_vm_dyn(int n) {      // n is wave-uniform
-    switch (n) {
-#define SVPS_WV(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        SVPS_WV(0) SVPS_WV(1) SVPS_WV(2) SVPS_WV(3) SVPS_WV(4) SVPS_WV(5) SVPS_WV(6) SVPS_WV(7) SVPS_WV(8) SVPS_WV(9)
-        SVPS_WV(10) SVPS_WV(11) SVPS_WV(12) SVPS_WV(13) SVPS_WV(14) SVPS_WV(15) SVPS_WV(16) SVPS_WV(17) SVPS_WV(18)
-#undef SVPS_WV
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 template <bool ARGMAX>
 __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
     const __bf16* __restrict__ feat, const float* __restrict__ embed, const float* __restrict__ bn_scale,

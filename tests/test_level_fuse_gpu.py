@@ -22,6 +22,8 @@ def _ulp_bf16(x):
     (2, 68, 120, False, True),      # VIPER level 1 from a 34x60 level 0: rows not tile aligned, ragged end
     (1, 34, 60, True, True),
     (3, 64, 128, False, True),
+    (9, 32, 64, False, True),       # several tiles per workgroup on the staged-tap fast path (W % 32 == 0)
+    (9, 32, 64, False, False),
 ])
 def test_level_fuse_matches_oracle(cuda, T, H, W, level0, nchw):
     import torch
