@@ -66,3 +66,80 @@ def test_postprocess_full_size_properties(cuda):
     n_inst = int((labels > 10).sum())
     allowed = set(int(x) for x in labels[labels <= 10]) | set(range(11, 11 + n_inst))
     assert set(np.unique(ids.cpu().numpy()).tolist()) <= allowed
+
+
+def _compare_with_oracle(cuda, logits, masks, size, cfg=CFG):
+    import torch
+    from slotvps_amd.postprocess import PostProcessPanopticInstances
+    pp = PostProcessPanopticInstances(**cfg)
+    res = pp.forward_tensors(torch.from_numpy(logits).to(cuda), torch.from_numpy(masks).to(cuda), size, materialize_masks=True)
+    want = po.postprocess(logits, masks, size, threshold=cfg["threshold"], pixel_threshold=cfg["pixel_threshold"],
+                          fraction_threshold=cfg["fraction_threshold"])
+    np.testing.assert_array_equal(res.slot_index.cpu().numpy(), want["slot_index"])
+    np.testing.assert_array_equal(res.labels.cpu().numpy(), want["labels"])
+    assert res.area == want["area"]
+    got_masks = res.masks.cpu().numpy()
+    assert got_masks.shape == want["masks"].shape and np.abs(got_masks - want["masks"]).max() < 2e-6
+    ids, cls_inds, _ = pp.panoptic_ids(res)
+    want_ids, want_cls, _ = po.panoptic_relabel(want["masks"], want["labels"])
+    np.testing.assert_array_equal(ids.cpu().numpy().astype(np.int64), want_ids)
+    np.testing.assert_array_equal(cls_inds.numpy(), want_cls)
+    return res, want
+
+
+@pytest.mark.parametrize("seed", range(30, 40))
+def test_postprocess_random_cases_match_oracle(cuda, seed):
+    """Varying slot counts, kept-slot counts and (non multiple-of-anything) sizes; the oracle is pinned by the
+    reference's own outputs (tests/test_post_oracle_golden.py)."""
+    rng = np.random.default_rng(seed)
+    L = int(rng.choice([20, 50, 100, 200]))
+    h, w = int(rng.integers(5, 40)), int(rng.integers(5, 70))
+    nk = int(rng.integers(7, min(L, 40)))
+    logits, masks = synth.make_post_case(seed, L, h, w, 20, nk)
+    _compare_with_oracle(cuda, logits, masks, (4 * h, 4 * w))
+
+
+def test_postprocess_edge_cases(cuda):
+    import torch
+    from slotvps_amd.postprocess import PostProcessPanopticInstances
+    L, h, w = 12, 8, 16
+    base = np.full((L, 20), -4.0, np.float32)
+    base[:, 19] = 6.0                                                     # everything "no object" ...
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    blob = lambda cy, cx, s, amp: (amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s)) - 1.0).astype(np.float32)
+    masks = np.full((L, h, w), -3.0, np.float32)
+
+    # (1) no slot passes the score threshold: the reference's mask_removal crashes (np.stack of nothing, :652)
+    pp = PostProcessPanopticInstances(**CFG)
+    with pytest.raises(ValueError):
+        pp.forward_tensors(torch.from_numpy(base).to(cuda), torch.from_numpy(masks).to(cuda), (4 * h, 4 * w))
+
+    # (2) stuff only, two slots of the same stuff class (merged ids), one class owning no pixel at all
+    lg, mk = base.copy(), masks.copy()
+    for s, c in [(0, 3), (1, 3), (2, 7)]:
+        lg[s] = -4.0
+        lg[s, c] = 8.0
+    mk[0], mk[1] = blob(2, 3, 4.0, 6.0), blob(6, 12, 4.0, 6.0)
+    _compare_with_oracle(cuda, lg, mk, (4 * h, 4 * w))
+
+    # (3) things only: identical twins of one class (the weaker one is removed by the overlap rule), an instance of
+    #     another class on top of them (kept: the rule is per class), an instance that never reaches 0.4 anywhere
+    lg, mk = base.copy(), masks.copy()
+    for s, c, sc in [(3, 13, 9.0), (4, 13, 8.0), (5, 15, 8.5), (6, 16, 8.2), (7, 2, 8.0)]:
+        lg[s] = -4.0
+        lg[s, c] = sc
+    mk[3] = mk[4] = blob(4, 8, 2.0, 8.0)
+    mk[5] = blob(4, 8, 1.5, 9.0)
+    mk[6] = np.full((h, w), -2.9, np.float32)                            # flat, below every blob: no candidate pixel
+    mk[7] = np.zeros((h, w), np.float32)                                  # a stuff floor so that the argmax has a background
+    res, want = _compare_with_oracle(cuda, lg, mk, (4 * h, 4 * w))
+    assert 4 not in res.slot_index.tolist() and 6 not in res.slot_index.tolist() and 3 in res.slot_index.tolist()
+
+    # (4) exact ties between two kept slots: the first in the reference's order wins every pixel
+    lg, mk = base.copy(), masks.copy()
+    for s, c, sc in [(8, 1, 9.0), (9, 4, 8.0)]:
+        lg[s] = -4.0
+        lg[s, c] = sc
+    mk[8] = mk[9] = blob(3, 5, 3.0, 4.0)
+    res, want = _compare_with_oracle(cuda, lg, mk, (4 * h, 4 * w))
+    assert res.slot_index.tolist() == [8]                                 # slot 9 owns no pixel -> area 0 -> filtered
