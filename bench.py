@@ -133,6 +133,8 @@ def main():
 
     for i in range(a.warmup):
         step(i, False)
+    if world > 1:
+        parallel.gather_to_rank0(results)        # untimed: RCCL sets up its point-to-point connections at first use
     torch.cuda.synchronize(dev)
 
     # ---------------------------------- timed region -------------------------------------------
@@ -180,10 +182,16 @@ def main():
         if rec is not None and rec.get("workload_key") == wkey:
             traffic = int(rec["traffic_bytes_per_launch"])          # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, avg per K1 launch
             traffic_src = "profiles/r01/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+        oth = runner.other_algorithmic_bytes_per_step()
+        oth_ms = {"kv_project": k3_ms, "level_fuse": k4_ms, "mask_decode": k2_ms}
+        others = {k: {"achieved": round(oth[k] * a.steps * cif / (oth_ms[k] * 1e-3) / 1e9, 1),
+                      "frac": round(oth[k] * a.steps * cif / (oth_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                      "algorithmic_bytes_per_step": int(oth[k])} for k in oth}
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "slot_attn_partial_ws", "launches": k1_n, "avg_launch_us": round(k1_ms / k1_n * 1e3, 2),
                 "algorithmic_bytes_per_launch_avg": int(alg / k1_n),
+                "other_kernels_hbm": others,
                 "other_kernels_us_per_clip": {"slot_attn_finish": round(fin_ms / a.steps / cif / cpl * 1e3, 1),
                                               "mask_decode": round(k2_ms / a.steps / cif / cpl * 1e3, 1),
                                               "kv_project": round(k3_ms / a.steps / cif / cpl * 1e3, 1),

@@ -120,3 +120,13 @@ class SlotClipRunner:
         """k and v read exactly once + q in + out, bf16 / fp32 as stored: 2*HW*D*2 + L*D*(2+4) per frame-stage."""
         D = self.cfg["dh_dim"]
         return sum(n * self.T * (2 * hw * D * 2 + self.L * D * (2 + 4)) for hw, n in self.k1_launch_shapes())
+
+    def other_algorithmic_bytes_per_step(self):
+        """Algorithmic HBM bytes per step of the other pixel-side kernels (all frames of the launch):
+        K3: 512 B in + 1024 B out per pixel and stage; K4: 512 B (fp32 NCHW map) in + 512 B out per pixel, + 128 B of
+        the 4x smaller previous level for levels > 0; K2: 512 B in + L * 4 B + 1 B out per finest-level pixel."""
+        px = [h * w for (h, w) in self.sizes]
+        k3 = sum(n * hw * 1536 for hw, n in self.k1_launch_shapes())
+        k4 = sum(hw * (1024 + (128 if i else 0)) for i, hw in enumerate(px))
+        k2 = px[-1] * (512 + 4 * self.L + 1)
+        return {"kv_project": self.T * k3, "level_fuse": self.T * k4, "mask_decode": self.T * k2}
