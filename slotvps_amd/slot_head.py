@@ -243,10 +243,22 @@ class MaskRCNNHead(nn.Module):
         self.class_logits = nn.Linear(d_model, num_classes)
         self.scale_clamp = scale_clamp
 
+    def _self_attention(self, slots):
+        """nn.MultiheadAttention(self_attn)(x, x, x) for frames-as-batch slots [T, L, C] (:346-355), with the module's own
+        parameters but without its sequence-first layout: the packed projection runs on the contiguous [T*L, C] rows and
+        the attention kernel reads q / k / v as strided views of its output ([T, L, heads, 32] is the layout that kernel
+        uses internally), so no transposed copy is made on the way in or out."""
+        mha = self.self_attn
+        T, L, C = slots.shape
+        nh = mha.num_heads
+        qkv = F.linear(slots, mha.in_proj_weight, mha.in_proj_bias).view(T, L, 3, nh, C // nh)
+        q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [T, heads, L, C / heads] views
+        o = F.scaled_dot_product_attention(q, k, v)                         # softmax(q k^T / sqrt(C / heads)) v
+        return F.linear(o.transpose(1, 2).reshape(T, L, C), mha.out_proj.weight, mha.out_proj.bias)
+
     def forward_till_ffn_pm(self, slots, feat_pm, hw, pos_tabs):
         """:342-388 for all frames at once. slots [T, L, C] fp32 contiguous."""
-        x = slots.transpose(0, 1)                                           # [L, T, C]: sequence-first, frames = batch
-        a = self.self_attn(x, x, value=x, key_padding_mask=None, need_weights=False)[0].transpose(0, 1).contiguous()
+        a = self._self_attention(slots)
         x1 = ops.row_ln(a, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre=slots)                 # :356-358
         r = self.inst_interact.forward_pm(x1, feat_pm, hw, pos_tabs)                                        # :368
         x2 = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x1)                     # :374-376
