@@ -206,7 +206,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"slot-retriever decode hot path: R50-FPN Slot-VPS head (7 stages over 4 FPN "
-                                   f"levels) + slot->mask decode, {a.height}x{a.width} T={T} clip, {a.slots} slots, "
+                                   f"levels) + slot->mask decode, {a.height}x{a.width} T={T} clips, {a.slots} slots, "
+                                   f"{cpl} independent clips stacked per launch x {cif} in flight per step, "
                                    f"synthetic FPN features resident in HBM; backbone/FPN not in the step",
                        "clip_frames": T, "slots": a.slots, "levels": [list(s) for s in runner.sizes],
                        "parallelism": f"clip-parallel x{world}", "hipgraph": not a.no_graph, "clips_in_flight": cif, "clips_per_launch": cpl,
