@@ -222,3 +222,38 @@ def test_hip_slot_path_is_deterministic():
     b = im.dynamic_mask_head.forward_clip(feats, im.init_mask_query.weight, tabs)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+
+
+@pytest.mark.gpu
+def test_baseline_config0_512x1024_first_frame():
+    """BASELINE config 0: the reference's own r50 config, one 512x1024 frame paired with itself (first frame of a
+    video, tools/dataset/cityscapes_vps.py:262), random init. The head sees two identical frames; with random weights no
+    slot reaches the 0.85 score threshold and the reference's mask_removal fails on the empty selection
+    (vps_temporal_slots.py:578, :652) - same failure here. A fixed slot -> class preference makes slots
+    survive; the two identical frames must then give identical head outputs and a well-formed result."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    det = build(REF_CFG if os.path.exists(REF_CFG) else CFG).to(dev).eval()
+    H, W = 512, 1024
+    img = torch.randn(1, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    meta = dict(iid=30001, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename="frankfurt_000000_000001.png")
+    with pytest.raises(ValueError, match="no slot passes the score threshold"):
+        det(img=[img], img_meta=[[meta]], return_loss=False, rescale=True, ref_img=[img])
+    feats, fcn = det.trunk(img)
+    assert [tuple(f.shape[-2:]) for f in feats] == [(16, 32), (32, 64), (64, 128), (128, 256)] and fcn.shape == (1, 19, H, W)
+    logits, embeds, masks = det.head_path([torch.cat([f, f], 0) for f in feats])
+    assert logits.shape == (2, 100, 20) and masks.shape == (2, 100, 128, 256) and torch.isfinite(masks).all()
+    assert torch.equal(logits[0], logits[1]) and torch.equal(masks[0], masks[1])      # identical frames, per-frame kernels
+    with torch.no_grad():                                      # slot l prefers class l % 19, strongly
+        cls = det.image_model.dynamic_mask_head.head_series_3[-1].class_logits
+        table = torch.zeros(100, 20, device=dev)
+        table[torch.arange(100), torch.arange(100) % 19] = 12.0
+        det.image_model.fg_bn.weight.fill_(40.0)
+        det._fold = None
+    base_forward = det.head_path
+    det.head_path = lambda f: (lambda lg, em, mk: (lg + table, em, mk))(*base_forward(f))
+    r = det(img=[img], img_meta=[[meta]], return_loss=False, rescale=True, ref_img=[img])
+    assert r["panoptic_outputs"].shape == (1, H, W) and r["fcn_outputs"].shape == (1, H, W)
+    ids = torch.unique(r["panoptic_outputs"])
+    assert (ids[ids > 10]).numel() == len(r["panoptic_cls_inds"]) == len(r["panoptic_det_obj_ids"])
+    assert det.ref_reuse_hits == 2                            # ref frame == current frame: its level maps were reused
