@@ -67,7 +67,7 @@ DETECTORS = Registry("detector")
 def _register_all():
     """The registering modules are imported on first use, not with the package (they pull in torch.nn
     model code that the kernel-level entry points do not need)."""
-    from . import backbones, detector  # noqa: F401
+    from . import backbones, detector, swin  # noqa: F401
 
 
 def build(cfg, registry, default_args=None):
