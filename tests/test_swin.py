@@ -48,3 +48,19 @@ def test_swin_config_resolves():
     head = det.image_model.dynamic_mask_head
     assert sum(p.numel() for p in det.parameters()) > 200e6
     assert head.head_series_0[0].activation.__name__ in ("relu",)       # swinL config: FFN ReLU, temporal GELU
+
+
+@pytest.mark.gpu
+def test_swin_small_outputs_match_reference_on_gpu():
+    """Same fixture through the ROCm attention kernels (bias + shifted-window mask as one additive attention bias)."""
+    z = np.load(os.path.join(GOLDEN, "swin.npz"))
+    dev = torch.device("cuda:0")
+    m = SwinTransformer(**SMALL).eval()
+    m.load_state_dict(seeded_state(m, 7))
+    m.to(dev)
+    x = torch.randn(2, 3, 70, 91, generator=torch.Generator().manual_seed(8)).to(dev)
+    with torch.no_grad():
+        outs = m(x)
+    for i, o in enumerate(outs):
+        ref = z[f"out{i}"]
+        assert np.abs(o.cpu().numpy() - ref).max() <= 5e-4 * max(1.0, np.abs(ref).max())
