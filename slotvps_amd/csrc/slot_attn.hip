@@ -287,13 +287,16 @@ __device__ __forceinline__ float half_swap_sum(float x) {
 
 // ABL != 0 are timing-only ablations for tools/kbench.py (env SVPS_ABLATE); their outputs are wrong.
 //   1: DMA + barriers only   2: producers only (no PV)   4: consumers only (no logits / softmax)   5: no DMA
-template <bool SPLIT, int ABL = 0>
+// EXT (more than 128 slots): the launch covers the `L` slots starting at row `slot_off` of a query / partial layout with
+// `Lrow` rows per frame, and the per-pixel softmax statistics over ALL slots come from `ext_stats` ([T, HW] of
+// (max logit, 1 / sum of exponentials), written by slot_attn_stats) instead of the exchange between the four producers.
+template <bool SPLIT, int ABL = 0, bool EXT = false>
 __global__ __launch_bounds__(512) void slot_attn_partial_ws(
-    const __bf16* __restrict__ q,   // [T, L, 256]
+    const __bf16* __restrict__ q,   // [T, Lrow, 256]
     const __bf16* __restrict__ k,   // [T, HW, 256]
     const __bf16* __restrict__ v,   // [T, HW, 256]
-    float* __restrict__ partial,    // [T, C, L, 256]
-    int L, int HW, int tiles_per_chunk) {
+    float* __restrict__ partial,    // [T, C, Lrow, 256]
+    int L, int HW, int tiles_per_chunk, int Lrow, int slot_off, const float2* __restrict__ ext_stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Lds = AttnWsLds;
     constexpr int A = kPrefetch;
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(512) void slot_attn_partial_ws(
         bf16x8 qf[16];
         {
             const int slot = 32 * sb + r;
-            const __bf16* qrow = q + ((size_t)t * L + (slot < L ? slot : 0)) * kD + 8 * h;
+            const __bf16* qrow = q + ((size_t)t * Lrow + slot_off + (slot < L ? slot : 0)) * kD + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 u32x4 raw = *reinterpret_cast<const u32x4*>(qrow + 16 * ks);
@@ -327,6 +330,11 @@ __global__ __launch_bounds__(512) void slot_attn_partial_ws(
         }
         const int slot0 = 32 * sb + 4 * h;
         const int key = (r >> 1) & 3;
+        float2 ext_cur = make_float2(0.f, 0.f);
+        if constexpr (EXT) {
+            const int px = px_begin + r;
+            ext_cur = ext_stats[(size_t)t * HW + (px < HW ? px : HW - 1)];
+        }
         for (int it = 0; it <= nt; ++it) {
             wg_barrier();                                        // B_top(it)
             if (it == nt || ABL == 1 || ABL == 4) { wg_barrier(); continue; }
@@ -343,6 +351,34 @@ __global__ __launch_bounds__(512) void slot_attn_partial_ws(
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+            if constexpr (EXT) {
+                // statistics of this tile's pixels are in registers (prefetched one tile ahead): no exchange, one pass
+                const float2 st = ext_cur;
+                {
+                    int px = px_begin + (it + 1) * kTilePx + r;
+                    px = px < HW ? px : HW - 1;
+                    ext_cur = ext_stats[(size_t)t * HW + px];           // next tile; consumed after two barriers
+                }
+                const float mneg = -st.x * kLog2e;
+                float fac = st.y;
+                if (px_begin + it * kTilePx + r >= px_end) fac = 0.f;   // pixels past the chunk / frame
+                wg_barrier();                                        // B_stats(it): "k(it) is dead"
+                char* prow = kt + sb * 2048 + r * 64 + 8 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = slot0 + j + 8 * g < L;
+                        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[4 * g + j], kLog2e, mneg)) * fac : 0.f;
+                        ph[j] = (__bf16)p;
+                        if constexpr (SPLIT) pl[j] = (__bf16)(p - (float)ph[j]);
+                    }
+                    *reinterpret_cast<bf16x4*>(prow + ((g ^ key) * 16)) = ph;
+                    if constexpr (SPLIT) *reinterpret_cast<bf16x4*>(prow + 8192 + ((g ^ key) * 16)) = pl;
+                }
+                continue;
+            }
             float mloc = kNegBig;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -477,7 +513,7 @@ __global__ __launch_bounds__(512) void slot_attn_partial_ws(
         if (work) pv_step(pt, vt, 1);
     }
 
-    float* dst = partial + ((size_t)t * C + c) * L * kD;
+    float* dst = partial + (((size_t)t * C + c) * Lrow + slot_off) * kD;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int slot = 32 * sb + acc_row(i, h);
@@ -485,6 +521,116 @@ __global__ __launch_bounds__(512) void slot_attn_partial_ws(
 #pragma unroll
             for (int db = 0; db < 8; ++db) dst[(size_t)slot * kD + 32 * db + r] = o[db][i];
         }
+    }
+}
+
+// Per-pixel softmax statistics over up to 256 slots (first kernel of the two-kernel path for more than 128 slots):
+// stats[t, p] = (max_l S[l, p], 1 / sum_l exp(S[l, p] - max)), S = q k^T. Eight waves, wave w owns slots [32w, 32w + 32);
+// keys stream through a 4-deep asm LDS-DMA ring (two 1-KiB pieces per wave and tile); reads k once, writes 8 B per pixel.
+struct StatsLds {
+    static constexpr int kStages = 4;
+    static constexpr int ring = 0;
+    static constexpr int stats = kStages * kTileBytes;          // [8][32] float2
+    static constexpr int total = stats + 8 * 32 * 8;
+};
+
+__global__ __launch_bounds__(512) void slot_attn_stats(const __bf16* __restrict__ q,   // [T, L, 256]
+                                                       const __bf16* __restrict__ k,   // [T, HW, 256]
+                                                       float2* __restrict__ out,       // [T, HW]
+                                                       int L, int HW, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = StatsLds;
+    constexpr int NST = Lds::kStages, A = NST - 1;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x;
+    const int px_begin = c * tiles_per_chunk * kTilePx;
+    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    px_end = px_end < HW ? px_end : HW;
+    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+
+    bf16x8 qf[16];
+    {
+        const int slot = 32 * w + r;
+        const __bf16* qrow = q + ((size_t)t * L + (slot < L ? slot : 0)) * kD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            u32x4 raw = *reinterpret_cast<const u32x4*>(qrow + 16 * ks);
+            if (slot >= L) raw = u32x4{0u, 0u, 0u, 0u};
+            qf[ks] = __builtin_bit_cast(bf16x8, raw);
+        }
+    }
+    wait_vm<0>();
+    const u32x4 krs = make_srd(k + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 ors = make_srd(out + (size_t)t * HW, (uint32_t)HW * 8u);
+    const uint32_t lds0 = lds_addr_of(smem);
+    auto stage = [&](int tile) {                                     // rows 4w .. 4w + 3 of the tile: two pieces
+        if (tile >= nt) return;
+        const int px0 = px_begin + tile * kTilePx;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 4 * w + 2 * i + h;
+            const int src = px0 + row < HW ? row : HW - 1 - px0;     // ragged last tile: clamp (those pixels are not stored)
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * kTileBytes + (4 * w + 2 * i) * kRowBytes);
+            dma16_srd(krs, dst, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < A; ++b) stage(b);
+    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+    const int slot0 = 32 * w + 4 * h;
+    for (int it = 0; it < nt; ++it) {
+        // k(it) landed for this wave. Younger, in issue order: store(it-3), DMA(it+1), store(it-2), DMA(it+2), store(it-1)
+        wait_vm_dyn((it < 3 ? it : 3) + 2 * ((it + 1 < nt) + (it + 2 < nt)));
+        wg_barrier();                                                // B_top(it); also: every wave is done with k(it-1)
+        stage(it + A);
+        const char* kt = smem + Lds::ring + (it % NST) * kTileBytes;
+        bf16x8 kf[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) kf[ks] = read_row_frag(kt, ks, r, h);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[ks], kf[ks], s, 0, 0, 0);
+        float mloc = kNegBig;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
+            s[i] = ok ? s[i] : kNegBig;
+            mloc = fmaxf(mloc, s[i]);
+        }
+        mloc = half_swap_max(mloc);
+        float sloc = 0.f;
+        const float mneg = -mloc * kLog2e;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
+            sloc += ok ? __builtin_amdgcn_exp2f(fmaf(s[i], kLog2e, mneg)) : 0.f;
+        }
+        sloc = half_swap_sum(sloc);
+        if (h == 0) stats[w * 32 + r] = make_float2(mloc, sloc);
+        wg_barrier();                                                // B_stats(it)
+        // wave w combines and stores pixels 4w .. 4w + 3 (one store instruction per wave and tile, always issued)
+        float mall = kNegBig;
+        float2 st_w[8];
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) {
+            st_w[ww] = stats[ww * 32 + r];
+            mall = fmaxf(mall, st_w[ww].x);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f((st_w[ww].x - mall) * kLog2e);
+        const int px = px_begin + it * kTilePx + r;
+        const bool mine = h == 0 && (r >> 2) == w && px < px_end;
+        typedef __attribute__((ext_vector_type(2))) float f32x2v;
+        const f32x2v val = {mall, 1.f / den};
+        const int voff = mine ? px * 8 : 0x7ffffff0;                 // out of range -> dropped by the hardware range check
+        asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(val), "v"(voff), "s"(ors) : "memory");
     }
 }
 
@@ -590,11 +736,13 @@ hipError_t launch_partial(const void* q, const void* k, const void* v, float* pa
     return hipGetLastError();
 }
 
-template <bool SPLIT, int ABL = 0>
+template <bool SPLIT, int ABL = 0, bool EXT = false>
 hipError_t launch_partial_ws(const void* q, const void* k, const void* v, float* partial, int T, int L,
-                             int HW, const AttnPlan& p, hipStream_t stream) {
+                             int HW, const AttnPlan& p, hipStream_t stream, int Lrow = 0, int slot_off = 0,
+                             const float2* ext_stats = nullptr) {
     using Lds = svps::AttnWsLds;
-    auto kern = svps::slot_attn_partial_ws<SPLIT, ABL>;
+    auto kern = svps::slot_attn_partial_ws<SPLIT, ABL, EXT>;
+    if (Lrow == 0) Lrow = L;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -604,16 +752,38 @@ hipError_t launch_partial_ws(const void* q, const void* k, const void* v, float*
     }
     hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream,
                        static_cast<const __bf16*>(q), static_cast<const __bf16*>(k),
-                       static_cast<const __bf16*>(v), partial, L, HW, p.tiles_per_chunk);
+                       static_cast<const __bf16*>(v), partial, L, HW, p.tiles_per_chunk, Lrow, slot_off, ext_stats);
     return hipGetLastError();
 }
+
+// more than 128 slots: statistics kernel, then the specialised kernel once per half of the slots
+template <bool SPLIT>
+hipError_t launch_two_pass(const void* q, const void* k, const void* v, float* partial, float2* stats, int T, int L,
+                           int HW, const AttnPlan& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(svps::slot_attn_stats),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, svps::StatsLds::total);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(svps::slot_attn_stats, dim3(p.chunks, T), dim3(512), svps::StatsLds::total, stream,
+                       static_cast<const __bf16*>(q), static_cast<const __bf16*>(k), stats, L, HW, p.tiles_per_chunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = launch_partial_ws<SPLIT, 0, true>(q, k, v, partial, T, 128, HW, p, stream, L, 0, stats);
+    if (e != hipSuccess) return e;
+    return launch_partial_ws<SPLIT, 0, true>(q, k, v, partial, T, L - 128, HW, p, stream, L, 128, stats);
+}
+
+size_t stats_bytes(int T, int L, int HW) { return L > 128 ? (size_t)T * HW * sizeof(float2) : 0; }
 
 }  // namespace
 
 extern "C" size_t svps_slot_attn_workspace_bytes(int T, int L, int HW, int chunks) {
     if (T <= 0 || L <= 0 || HW <= 0) return 0;
     const AttnPlan p = plan_attn(T, L, HW, chunks);
-    return (size_t)T * p.chunks * L * svps::kD * sizeof(float);
+    return (size_t)T * p.chunks * L * svps::kD * sizeof(float) + stats_bytes(T, L, HW);
 }
 
 extern "C" int svps_slot_attn_plan(int T, int L, int HW, int chunks, int* out_chunks,
@@ -633,7 +803,8 @@ extern "C" int svps_slot_attn_fwd(const void* q, const void* k, const void* v, c
     if (!q || !k || !v || !ln_w || !ln_b || !workspace || !out) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || HW <= 0) return SVPS_ERR_BAD_SHAPE;
     const AttnPlan p = plan_attn(T, L, HW, chunks);
-    if (workspace_bytes < (size_t)T * p.chunks * L * svps::kD * sizeof(float)) return SVPS_ERR_WORKSPACE;
+    const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kD * sizeof(float);
+    if (workspace_bytes < partial_bytes + stats_bytes(T, L, HW)) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
     const bool split = flags & SVPS_FLAG_SPLIT_P;
@@ -650,9 +821,14 @@ extern "C" int svps_slot_attn_fwd(const void* q, const void* k, const void* v, c
     } else if (L <= 128)
         e = split ? launch_partial_ws<true>(q, k, v, partial, T, L, HW, p, stream)
                   : launch_partial_ws<false>(q, k, v, partial, T, L, HW, p, stream);
-    else
+    else if (getenv("SVPS_K1_LEGACY"))
         e = split ? launch_partial<8, 3, true>(q, k, v, partial, T, L, HW, p, stream)
                   : launch_partial<8, 3, false>(q, k, v, partial, T, L, HW, p, stream);
+    else {
+        float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);
+        e = split ? launch_two_pass<true>(q, k, v, partial, st, T, L, HW, p, stream)
+                  : launch_two_pass<false>(q, k, v, partial, st, T, L, HW, p, stream);
+    }
     svps_prof_mark(SVPS_KERNEL_SLOT_ATTN, 1, stream);
     if (e != hipSuccess) return (int)e;
     svps_prof_mark(SVPS_KERNEL_SLOT_ATTN_FINISH, 0, stream);
