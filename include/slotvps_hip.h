@@ -69,6 +69,8 @@ int svps_abi_version(void);
  *   out_pre_ln       optional [T, L, D] fp32: the pixel sum before LayerNorm (NULL to skip)
  *   D must be 256; 1 <= L <= 256; HW >= 1 (any value, tiles are masked)
  *   chunks: workgroups per frame, 0 = choose (one resident workgroup per CU)
+ *   workspace: svps_slot_attn_workspace_bytes() bytes = the per-workgroup partial sums [T, chunks, L, D] fp32
+ *              (+ [T, HW] x 8 B of per-pixel softmax statistics when L > 128: two-kernel path)
  * ------------------------------------------------------------------------------------------- */
 size_t svps_slot_attn_workspace_bytes(int T, int L, int HW, int chunks);
 int svps_slot_attn_plan(int T, int L, int HW, int chunks, int* out_chunks, int* out_tiles_per_chunk,
