@@ -470,9 +470,7 @@ extern "C" int svps_kv_project_fwd(const void* feat, const float* pos_y, const f
     const int HW = H * W;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
-    int chunks = proj_num_cus() / T;
-    if (chunks < 1) chunks = 1;
-    if (chunks > tiles) chunks = tiles;
+    int chunks = svps_pick_chunks(T, tiles, proj_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     static bool attr_set[2] = {false, false};

@@ -517,9 +517,7 @@ hipError_t launch_fuse(const void* cur, const void* prev, const void* wc, const 
     auto kern = svps::level_fuse_kernel<NCHW, L0>;
     const int HW = H * W;
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
-    int chunks = fuse_num_cus() / T;              // one resident 8-wave workgroup per CU
-    if (chunks < 1) chunks = 1;
-    if (chunks > tiles) chunks = tiles;
+    int chunks = svps_pick_chunks(T, tiles, fuse_num_cus());   // one resident 8-wave workgroup per CU
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::FuseLds::total, stream, cur,
@@ -559,9 +557,7 @@ hipError_t launch_fuse_v2(const void* cur, const void* prev, const void* wc, con
         attr_set = true;
     }
     const int tiles = H * W / svps::kTilePx;
-    int chunks = fuse_num_cus() / T;
-    if (chunks < 1) chunks = 1;
-    if (chunks > tiles) chunks = tiles;
+    int chunks = svps_pick_chunks(T, tiles, fuse_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::Fuse2Lds::total, stream, cur,

@@ -491,9 +491,7 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
     }
     // two co-resident workgroups per CU (LDS 2 x ~70 KiB): one computes while the other waits
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
-    int chunks = 2 * dec_num_cus() / T;
-    if (chunks < 1) chunks = 1;
-    if (chunks > tiles) chunks = tiles;
+    int chunks = svps_pick_chunks(T, tiles, 2 * dec_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(NW * 64), Lds::total, stream,
@@ -515,9 +513,7 @@ hipError_t launch_decode_v2(const void* feat, const float* embed, const float* b
         attr_set = true;
     }
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;      // two co-resident workgroups per CU (2 x 68 KiB LDS)
-    int chunks = 2 * dec_num_cus() / T;
-    if (chunks < 1) chunks = 1;
-    if (chunks > tiles) chunks = tiles;
+    int chunks = svps_pick_chunks(T, tiles, 2 * dec_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(256), svps::Dec2Lds::total, stream, static_cast<const __bf16*>(feat),

@@ -709,8 +709,7 @@ AttnPlan plan_attn(int T, int L, int HW, int chunks_req) {
     if (chunks <= 0) {
         // one resident workgroup per CU: the launch is a single wave of workgroups, each streaming
         // one contiguous pixel range of one frame
-        chunks = num_cus() / (T > 0 ? T : 1);
-        if (chunks < 1) chunks = 1;
+        chunks = svps_pick_chunks(T, tiles, num_cus());
     }
     if (chunks > tiles) chunks = tiles;
     int tpc = (tiles + chunks - 1) / chunks;
