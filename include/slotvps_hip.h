@@ -67,7 +67,7 @@ int svps_abi_version(void);
  *   ln_w, ln_b [D]   fp32, inst_interact.norm1 affine, ln_eps its epsilon (1e-5)
  *   out  [T, L, D]   fp32
  *   out_pre_ln       optional [T, L, D] fp32: the pixel sum before LayerNorm (NULL to skip)
- *   D must be 256; 1 <= L <= 256; HW >= 1 (any value, tiles are masked)
+ *   D must be 256; 1 <= L <= 256; 1 <= HW <= 4 Mi (any value, tiles are masked; byte offsets inside a frame are 32-bit)
  *   chunks: workgroups per frame, 0 = choose (one resident workgroup per CU)
  *   workspace: svps_slot_attn_workspace_bytes() bytes = the per-workgroup partial sums [T, chunks, L, D] fp32
  *              (+ [T, HW] x 8 B of per-pixel softmax statistics when L > 128: two-kernel path)

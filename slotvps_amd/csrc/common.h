@@ -29,6 +29,7 @@ constexpr int kD = 256;              // channel width of slots / keys / values (
 constexpr int kRowBytes = kD * 2;    // one bf16 pixel row
 constexpr int kTilePx = 32;          // pixels per LDS tile (one MFMA column block)
 constexpr int kTileBytes = kTilePx * kRowBytes;  // 16 KiB
+constexpr size_t kMaxFramePixels = (size_t)1 << 22;   // 4 Mi pixels per frame and level: byte offsets inside a frame fit 31 bits
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kNegBig = -1.0e30f;
 

@@ -467,6 +467,7 @@ extern "C" int svps_kv_project_fwd(const void* feat, const float* pos_y, const f
         return SVPS_ERR_BAD_ARG;
     if ((pos_y == nullptr) != (pos_x == nullptr)) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;   // 32-bit buffer offsets inside a frame
     const int HW = H * W;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;

@@ -571,6 +571,7 @@ extern "C" int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const v
                                    const float* bc, void* out, int T, int H, int W, void* stream_) {
     if (!cur || !wc || !bc || !out) return SVPS_ERR_BAD_ARG;
     if (T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;   // 32-bit buffer offsets inside a frame
     if (prev && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;   // x2 upsampling: even sizes
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 0, stream);

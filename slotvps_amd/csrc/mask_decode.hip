@@ -541,6 +541,7 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
                                     void* stream_) {
     if (!feat || !embed || !bn_scale || !bn_shift || !out) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || HW <= 0) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)HW > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;       // 32-bit buffer offsets inside a frame
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 0, stream);
     // fast path: 16-byte row-segment stores need 4-pixel alignment of every slot row; L * HW * 4 must fit a buffer descriptor

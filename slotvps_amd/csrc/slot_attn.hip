@@ -801,6 +801,7 @@ extern "C" int svps_slot_attn_fwd(const void* q, const void* k, const void* v, c
                                   int HW, int D, int flags, int chunks, void* stream_) {
     if (!q || !k || !v || !ln_w || !ln_b || !workspace || !out) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || HW <= 0) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)HW > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;       // 32-bit buffer offsets inside a frame
     const AttnPlan p = plan_attn(T, L, HW, chunks);
     const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kD * sizeof(float);
     if (workspace_bytes < partial_bytes + stats_bytes(T, L, HW)) return SVPS_ERR_WORKSPACE;
