@@ -32,6 +32,12 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.svps_slot_attn_fwd(None, None, None, None, None, 1e-5, None, 0, None, None, 1, 100, 64, 256, 0, 0, None) == -1
     assert lib.svps_mask_decode_fwd(None, None, None, None, 1.0, 0.0, None, None, 1, 1, 1, 256, 0, None) == -1
     assert lib.svps_pos_embed_sine(None, 4, 4, 256, None) == -1
+    one = ctypes.c_void_p(16)                     # never dereferenced: shape errors are reported first
+    big = (1 << 22) + 1                           # frames above 4 Mi pixels: 32-bit offsets inside a frame
+    assert lib.svps_slot_attn_fwd(one, one, one, one, one, 1e-5, one, 1 << 40, one, None, 1, 100, big, 256, 1, 0, None) == -2
+    assert lib.svps_slot_attn_fwd(one, one, one, one, one, 1e-5, one, 1 << 40, one, None, 1, 257, 64, 256, 1, 0, None) == -2
+    assert lib.svps_slot_attn_fwd(one, one, one, one, one, 1e-5, one, 16, one, None, 1, 100, 4096, 256, 1, 0, None) == -3
+    assert lib.svps_mask_decode_fwd(one, one, one, one, 1.0, 0.0, one, None, 1, 100, big, 256, 0, None) == -2
     c, t, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.svps_slot_attn_plan(5, 100, 131072, 0, ctypes.byref(c), ctypes.byref(t), ctypes.byref(p)) == 0
     assert c.value * t.value * p.value >= 131072 and (c.value - 1) * t.value * p.value < 131072
