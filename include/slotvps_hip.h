@@ -182,6 +182,12 @@ int svps_panoptic_argmax(const float* masks, const uint8_t* sel, const uint8_t* 
 int svps_deform_im2col(const float* x_nhwc, const float* offset, float* cols, int N, int C, int H, int W, int kh,
                        int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
                        int deformable_groups, int Ho, int Wo, void* stream);
+/* bf16 operand form (matrix-core GEMM with fp32 accumulation): x_nhwc [N, H, W, C] bf16; cols [N, Ho*Wo, kh*kw, C] bf16,
+ * TAP-major - the matching GEMM operand is weight.permute(0, 2, 3, 1).reshape(O, kh*kw*C). Sampling and validity rules
+ * as above, blend in fp32. (C / deformable_groups) % 8 == 0. */
+int svps_deform_im2col_bf16(const void* x_nhwc, const float* offset, void* cols, int N, int C, int H, int W, int kh,
+                            int kw, int pad_h, int pad_w, int stride_h, int stride_w, int dil_h, int dil_w,
+                            int deformable_groups, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Profiling hooks: when enabled every kernel launch of this library is bracketed by HIP events on

@@ -42,6 +42,7 @@ SIGNATURES = {
     "svps_panoptic_candidates": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "svps_panoptic_argmax": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "svps_deform_im2col": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
+    "svps_deform_im2col_bf16": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

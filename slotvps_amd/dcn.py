@@ -12,8 +12,12 @@ from torch.nn.modules.utils import _pair
 from . import _lib
 
 
-def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
-    """x [N, C, H, W] fp32 (any memory format), offset [N, dg*2*kh*kw, Ho, Wo], weight [O, C, kh, kw] -> [N, O, Ho, Wo]."""
+def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, bf16_operands=False,
+                weight_taps=None):
+    """x [N, C, H, W] fp32 (any memory format), offset [N, dg*2*kh*kw, Ho, Wo], weight [O, C, kh, kw] -> [N, O, Ho, Wo].
+    bf16_operands: sampled columns and weights as bf16 matrix-core operands with fp32 accumulation (the storage policy of
+    the feature path; ~6x faster than the fp32 columns + fp32 GEMM); weight_taps = cached
+    weight.permute(0, 2, 3, 1).reshape(O, -1) in bf16."""
     if not x.is_cuda:
         raise RuntimeError("deform_conv runs on the GPU only (the reference has no CPU path either, "
                            "mmdet/ops/dcn/deform_conv.py:44-45); there is no CPU fallback")
@@ -27,12 +31,23 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, de
     O, _, kh, kw = weight.shape
     Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
     Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
-    x_nhwc = x.float().permute(0, 2, 3, 1).contiguous()                 # free for channels_last inputs
     offset = offset.float().contiguous()
     if offset.shape != (N, deformable_groups * 2 * kh * kw, Ho, Wo):
         raise ValueError(f"offset shape {tuple(offset.shape)}")
-    cols = torch.empty((N, Ho * Wo, C * kh * kw), dtype=torch.float32, device=x.device)
     p = lambda t: ctypes.c_void_p(t.data_ptr())
+    if bf16_operands and (C // deformable_groups) % 8 == 0:
+        x_nhwc = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+        x_nhwc.copy_(x.permute(0, 2, 3, 1))                              # cast + transpose in one pass
+        cols = torch.empty((N * Ho * Wo, kh * kw * C), dtype=torch.bfloat16, device=x.device)
+        rc = lib.svps_deform_im2col_bf16(p(x_nhwc), p(offset), p(cols), N, C, H, W, kh, kw, ph, pw, sh, sw, dh, dw,
+                                         deformable_groups, Ho, Wo, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "svps_deform_im2col_bf16")
+        if weight_taps is None:
+            weight_taps = weight.permute(0, 2, 3, 1).reshape(O, -1).to(torch.bfloat16).contiguous()
+        out = torch.mm(cols, weight_taps.t(), out_dtype=torch.float32)   # [N*Ho*Wo, O], fp32 accumulate and output
+        return out.view(N, Ho, Wo, O).permute(0, 3, 1, 2)
+    x_nhwc = x.float().permute(0, 2, 3, 1).contiguous()                 # free for channels_last inputs
+    cols = torch.empty((N, Ho * Wo, C * kh * kw), dtype=torch.float32, device=x.device)
     rc = lib.svps_deform_im2col(p(x_nhwc), p(offset), p(cols), N, C, H, W, kh, kw, ph, pw, sh, sw, dh, dw,
                                 deformable_groups, Ho, Wo, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "svps_deform_im2col")
@@ -51,6 +66,8 @@ class DeformConv(nn.Module):
         self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
         self.groups, self.deformable_groups = groups, deformable_groups
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        self.bf16_operands = True            # matrix-core operands in bf16, fp32 accumulation (False: fp32 throughout)
+        self._wt = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -60,9 +77,16 @@ class DeformConv(nn.Module):
         stdv = 1. / math.sqrt(n)
         self.weight.data.uniform_(-stdv, stdv)
 
+    def _weight_taps(self):
+        key = (self.weight._version, self.weight.data_ptr())
+        if self._wt is None or self._wt[0] != key:
+            O = self.weight.shape[0]
+            self._wt = (key, self.weight.detach().permute(0, 2, 3, 1).reshape(O, -1).to(torch.bfloat16).contiguous())
+        return self._wt[1]
+
     def forward(self, x, offset):
         return deform_conv(x, offset, self.weight, self.stride, self.padding, self.dilation, self.groups,
-                           self.deformable_groups)
+                           self.deformable_groups, self.bf16_operands, self._weight_taps() if self.bf16_operands else None)
 
 
 class DeformConvWithOffset(nn.Module):

@@ -58,6 +58,28 @@ def test_hip_deform_conv_matches_oracle(cuda, N, C, O, H, W, dg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,C,O,H,W,dg", [(2, 256, 128, 16, 32, 1), (1, 32, 16, 12, 10, 2), (1, 128, 128, 33, 20, 1)])
+def test_hip_deform_conv_bf16_operands_match_oracle(cuda, N, C, O, H, W, dg):
+    """bf16 operand path: the oracle (float64) on the same bf16-rounded input and weight; what is left is the bf16
+    rounding of the blended samples: 9*C terms of size ~ |x| |w| 2^-9 ~ 0.8 * (9C)^-1/2 * 2e-3 with random signs, i.e. a
+    standard deviation of ~1.6e-3 on outputs of order 1 (max over 1e5 outputs ~ 5 sigma), plus fp32 accumulation."""
+    import torch
+    from slotvps_amd.dcn import deform_conv
+    rng = np.random.default_rng(C + H + 1)
+    x = orc.round_bf16(rng.standard_normal((N, C, H, W)).astype(np.float32))
+    w = orc.round_bf16((rng.standard_normal((O, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32))
+    off = (2.5 * rng.standard_normal((N, dg * 18, H, W))).astype(np.float32)
+    out = deform_conv(torch.from_numpy(x).to(cuda), torch.from_numpy(off).to(cuda), torch.from_numpy(w).to(cuda),
+                      1, 1, 1, 1, dg, bf16_operands=True)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for n in range(N):
+        ref = orc.deform_conv(x[n].astype(np.float64), off[n].astype(np.float64), w.astype(np.float64), 1, 1, 1, dg)
+        err = np.abs(out[n] - ref)
+        assert err.max() < 1.2e-2 and err.mean() < 2e-3, (err.max(), err.mean())
+
+
+@pytest.mark.gpu
 def test_hip_deform_conv_with_offset_module_zero_init_is_conv(cuda):
     """The offset conv is zero-initialised (deform_conv_with_offset.py:25-26): a fresh module == conv2d."""
     import torch
@@ -65,6 +87,11 @@ def test_hip_deform_conv_with_offset_module_zero_init_is_conv(cuda):
     m = DeformConvWithOffset(32, 16, kernel_size=3, padding=1).to(cuda)
     x = torch.randn(2, 32, 10, 14, device=cuda)
     with torch.no_grad():
+        m.conv.bf16_operands = False
         got = m(x)
         want = torch.nn.functional.conv2d(x, m.conv.weight, padding=1)
-    assert (got - want).abs().max().item() < 1e-5
+        assert (got - want).abs().max().item() < 1e-5
+        m.conv.bf16_operands = True           # default: bf16 operands == conv2d of the bf16-rounded input and weight
+        got = m(x)
+        want = torch.nn.functional.conv2d(x.bfloat16().float(), m.conv.weight.bfloat16().float(), padding=1)
+        assert (got - want).abs().max().item() < 1e-4
