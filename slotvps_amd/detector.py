@@ -209,6 +209,7 @@ class VPS_Temporal_Slots(nn.Module):
         self.prev_embedding = None
         self._fold = None
         self.reuse_ref_features = True           # keep the previous frame's level maps
+        self.trunk_bf16 = False                  # bf16 autocast for the PyTorch trunk (backbone, FPN, semantic tower)
         self._ref_cache = None
         self.ref_reuse_hits = 0
 
@@ -238,11 +239,15 @@ class VPS_Temporal_Slots(nn.Module):
         """PyTorch part: imgs [T, 3, H, W] -> (per level [T, 128, Hi, Wi] fp32 maps coarse -> fine, the slot head's
         input; semantic logits [T, nc_sem, H, W])."""
         im = self.image_model
-        x = im.backbone(imgs)
-        if im.with_neck:
-            x = im.neck(x)
-        fcn_output, _, fcn_feature = self.extract_semantic_feats(x)
-        return [f.float().contiguous() for f in self.semantic_trans_ins(fcn_feature)], fcn_output
+        # trunk_bf16: PyTorch autocast (bf16 convolutions / GEMMs, fp32 normalisation layers) around the PyTorch part;
+        # off by default: the reference's trunk is fp32
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.trunk_bf16):
+            x = im.backbone(imgs)
+            if im.with_neck:
+                x = im.neck(x)
+            fcn_output, _, fcn_feature = self.extract_semantic_feats(x)
+            feats = self.semantic_trans_ins(fcn_feature)
+        return [f.float().contiguous() for f in feats], fcn_output.float()
 
     @torch.no_grad()
     def head_path(self, feats):

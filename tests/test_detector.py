@@ -257,3 +257,18 @@ def test_baseline_config0_512x1024_first_frame():
     ids = torch.unique(r["panoptic_outputs"])
     assert (ids[ids > 10]).numel() == len(r["panoptic_cls_inds"]) == len(r["panoptic_det_obj_ids"])
     assert det.ref_reuse_hits == 2                            # ref frame == current frame: its level maps were reused
+
+
+@pytest.mark.gpu
+def test_trunk_bf16_autocast_option():
+    """Optional bf16 autocast of the PyTorch trunk: same shapes / dtypes, level maps close to the fp32 trunk."""
+    dev = torch.device("cuda:0")
+    det = _make_detector(dev)
+    imgs = torch.randn(2, 3, 128, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    f32, s32 = det.trunk(imgs)
+    det.trunk_bf16 = True
+    f16, s16 = det.trunk(imgs)
+    assert s16.dtype == torch.float32 and all(f.dtype == torch.float32 and f.is_contiguous() for f in f16)
+    for a, b in zip(f32, f16):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 0.05 * a.abs().max().item() + 1e-3

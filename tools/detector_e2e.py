@@ -36,6 +36,12 @@ with torch.no_grad():
     t_neck, xn = timed(lambda: im.neck(x))
     t_ups, _ = timed(lambda: det.extract_semantic_feats(xn))
 print(f"backbone {t_bb:.1f} ms, FPN {t_neck:.1f} ms, UPSNetFPN {t_ups:.1f} ms per T=5 clip")
+det.trunk_bf16 = True
+with torch.no_grad():
+    t_trunk16, _ = timed(lambda: det.trunk(imgs))
+    t_all16, _ = timed(lambda: det.clip_test(imgs, metas))
+print(f"with trunk_bf16 (autocast): trunk {t_trunk16:.1f} ms, clip_test {t_all16:.1f} ms per clip -> {T / t_all16 * 1e3:.1f} frames/s")
+det.trunk_bf16 = False
 from torch.profiler import profile, ProfilerActivity
 with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof:
     det.extract_semantic_feats(xn); torch.cuda.synchronize()
