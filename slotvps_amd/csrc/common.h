@@ -128,13 +128,15 @@ __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
 // All workgroups of a launch do the same amount of work, so the launch runs in whole "rounds" of `slots` workgroups:
 // take the smallest count >= slots / T whose last round is (nearly) full - e.g. 80 frames on 256 CUs: 3 per frame would
 // leave 16 CUs idle for the whole launch, 16 per frame fills five rounds exactly.
-static inline int svps_pick_chunks(int T, int tiles, int slots, int max_mult = 8) {
+static inline int svps_pick_chunks(int T, int tiles, int slots, int min_tiles = 16, int max_mult = 8) {
     int base = slots / (T > 0 ? T : 1);
     if (base < 1) base = 1;
     if (base >= tiles) return tiles;
     int best = base;
     double best_eff = 0.0;
-    const int hi = base * max_mult < tiles ? base * max_mult : tiles;   // more workgroups = more per-workgroup prologue / partial traffic
+    int hi = base * max_mult < tiles ? base * max_mult : tiles;   // more workgroups = more per-workgroup prologue / partial traffic:
+    if (hi > tiles / min_tiles) hi = tiles / min_tiles;           // keep at least `min_tiles` tiles per workgroup
+    if (hi < base) hi = base;
     for (int c = base; c <= hi; ++c) {
         const long wg = (long)T * c;
         const long rounds = (wg + slots - 1) / slots;

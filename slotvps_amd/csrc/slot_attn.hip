@@ -709,7 +709,7 @@ AttnPlan plan_attn(int T, int L, int HW, int chunks_req) {
     if (chunks <= 0) {
         // one resident workgroup per CU: the launch is a single wave of workgroups, each streaming
         // one contiguous pixel range of one frame
-        chunks = svps_pick_chunks(T, tiles, num_cus());
+        chunks = svps_pick_chunks(T, tiles, num_cus(), 64);   // every workgroup costs a [L, 256] fp32 partial and a query load
     }
     if (chunks > tiles) chunks = tiles;
     int tpc = (tiles + chunks - 1) / chunks;
