@@ -42,9 +42,13 @@ constexpr int kProjNF = kProjAhead + 1;  // feature ring depth
 struct ProjLds {
     static constexpr int fring = 0;                              // kProjNF x 16 KiB
     static constexpr int xk = kProjNF * kTileBytes;              // bf16(f + pos) tile
+    // out tiles: rows padded to 528 B instead of swizzled - every LDS address of the LayerNorm epilogue is then
+    // "lane base + compile-time constant" (no per-write address arithmetic), at a two-way bank conflict on the 8-byte writes
+    static constexpr int kOutRow = kRowBytes + 16;
+    static constexpr int kOutTile = kTilePx * kOutRow;           // 16.5 KiB
     static constexpr int outk = xk + kTileBytes;                 // bf16 k rows of the tile
-    static constexpr int outv = outk + kTileBytes;
-    static constexpr int posy = outv + kTileBytes;               // [32 px][128] fp32 rows of ytab
+    static constexpr int outv = outk + kOutTile;
+    static constexpr int posy = outv + kOutTile;                 // [32 px][128] fp32 rows of ytab
     static constexpr int posx = posy + kTileBytes;               // [32 px][128] fp32 rows of xtab
     static constexpr int stats = posx + kTileBytes;              // [2][4][32] float2
     static constexpr int affine = stats + 2 * 4 * 32 * 8;        // bk bv gk bk' gv bv' : 6 x 256 fp32
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = 8 * u + (lt >> 5), gc = lt & 31;           // global chunk gc of pixel row `row`
-            val[u] = *reinterpret_cast<const u32x4*>(src + row * kRowBytes + ((gc ^ swz(row)) * 16));
+            val[u] = *reinterpret_cast<const u32x4*>(src + row * Lds::kOutRow + gc * 16);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
                     o[j + 1] = (__bf16)y[1];
                 }
                 const int chunk = ch0 >> 3;                            // 16-byte chunk of the pixel row
-                *reinterpret_cast<bf16x4*>(outt + r * kRowBytes + ((chunk ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
+                *reinterpret_cast<bf16x4*>(outt + r * Lds::kOutRow + chunk * 16 + (ch0 & 7) * 2) = o;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
