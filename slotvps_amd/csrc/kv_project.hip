@@ -31,6 +31,7 @@
 // Roofline: HBM - reads 512 B and writes 1024 B per pixel (1.5 KB/px); 262 kFLOP/px on the matrix
 // cores (arithmetic intensity 175 flop/B, below the ~300 flop/B ridge of the chip).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -46,7 +47,7 @@ struct ProjLds {
     // "lane base + compile-time constant" (no per-write address arithmetic), at a two-way bank conflict on the 8-byte writes
     static constexpr int kOutRow = kRowBytes + 16;
     static constexpr int kOutTile = kTilePx * kOutRow;           // 16.5 KiB
-    static constexpr int outk = xk + kTileBytes;                 // bf16 k rows of the tile
+    static constexpr int outk = xk + kOutTile;                   // bf16 k rows of the tile (xk is padded the same way)
     static constexpr int outv = outk + kOutTile;
     static constexpr int posy = outv + kOutTile;                 // [32 px][128] fp32 rows of ytab
     static constexpr int posx = posy + kTileBytes;               // [32 px][128] fp32 rows of xtab
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
         for (int u = 0; u < 4; ++u) {                          // twelve LDS reads in flight, then the arithmetic
             const int id = u * 256 + lt;                       // [px][chunk]
             const int xpx = id >> 5, cpos = id & 31;
-            offs[u] = xpx * kRowBytes + ((cpos ^ swz(xpx)) * 16);
-            fv[u] = *reinterpret_cast<const bf16x8*>(ft + offs[u]);
+            offs[u] = xpx * Lds::kOutRow + cpos * 16;                           // xk rows are padded, not swizzled
+            fv[u] = *reinterpret_cast<const bf16x8*>(ft + xpx * kRowBytes + ((cpos ^ swz(xpx)) * 16));
             const char* pt = smem + (cpos < 16 ? Lds::posy + (aligned_rows ? 0 : xpx * 512) : Lds::posx + xpx * 512) + (cpos & 15) * 32;
             pv[u][0] = *reinterpret_cast<const f32x4*>(pt);
             pv[u][1] = *reinterpret_cast<const f32x4*>(pt + 16);
@@ -309,7 +310,8 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
     f32x16 acc[2];
 
     // "heavy" half of a tile: store the previous out tile, 32 MFMA, + bias, LayerNorm partial sums -> LDS
-    auto heavy = [&](int it) {
+    auto heavy = [&](int it, auto padded_tag) {
+        constexpr bool PADDED = decltype(padded_tag)::value;      // B operand rows padded to 528 B (xk) or swizzled (feature ring)
         if (it >= 1) store_out(it - 1);
         K3_STAMP(3);
         if (it >= nt) return;
@@ -326,15 +328,19 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[b][4 * g + j] = bb[j];
             }
+        auto frag = [&](int ks) {
+            if constexpr (PADDED) return *reinterpret_cast<const bf16x8*>(bt + r * Lds::kOutRow + (2 * ks + h) * 16);
+            else return read_row_frag(bt, ks, r, h);
+        };
         if constexpr (!(ABL & 2)) {
             bf16x8 xf[2][4];                     // operand fragments, double-buffered in groups of four k-steps
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xf[0][u] = read_row_frag(bt, u, r, h);
+            for (int u = 0; u < 4; ++u) xf[0][u] = frag(u);
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
                 if (grp < 3) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) xf[(grp + 1) & 1][u] = read_row_frag(bt, 4 * (grp + 1) + u, r, h);
+                    for (int u = 0; u < 4; ++u) xf[(grp + 1) & 1][u] = frag(4 * (grp + 1) + u);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -415,7 +421,7 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
         wg_barrier();                                                  // X(it): xk(it) built, stats_v(it-1) written
         K3_STAMP(1);
         if (proj == 0) {
-            heavy(it);
+            heavy(it, std::bool_constant<HAS_POS>{});
             K3_STAMP(6);
             K3_STAMP(7);
         } else {
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
                 K3_STAMP(10);
             }
         } else {
-            heavy(it);
+            heavy(it, std::false_type{});
             K3_STAMP(10);
         }
     }
