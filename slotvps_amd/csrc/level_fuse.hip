@@ -240,9 +240,13 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
 // Order of vector-memory operations per iteration: DMA (asm) and the map loads of tile it+1 first, the stores of tile
 // it-1 last: vmcnt retires in order, so `vmcnt(#stores)` before barrier b covers every load without draining the stores.
 struct Fuse2Lds {
+    // operand and out tiles with PADDED rows (784 B / 528 B) instead of the chunk swizzle: every LDS address is then
+    // "lane base + compile-time constant"; the 16-byte fragment reads of 16 consecutive rows still hit 16 distinct bank groups
+    static constexpr int kARow = kFuseRowBytes + 16;
+    static constexpr int kORow = kRowBytes + 16;
     static constexpr int atile = 0;                                 // [32][384] bf16 operand tile
-    static constexpr int otile = kTilePx * kFuseRowBytes;           // [32][256] bf16 out tile
-    static constexpr int stage = otile + kTileBytes;                // [2 rows][18 px][512 B] taps of the next tile
+    static constexpr int otile = kTilePx * kARow;                   // [32][256] bf16 out tile
+    static constexpr int stage = otile + kTilePx * kORow;           // [2 rows][18 px][512 B] taps of the next tile
     static constexpr int kStageCols = 18;
     static constexpr int stage_bytes = 2 * kStageCols * kRowBytes;
     static constexpr int cur = stage + 2 * stage_bytes;              // incoming map of a tile as it lies in memory: [128][32] fp32 or [32][128] bf16
@@ -394,12 +398,12 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
                 bf16x2 v2;
                 v2[0] = (__bf16)p.c0[j];
                 v2[1] = (__bf16)p.c1[j];
-                *reinterpret_cast<bf16x2*>(at + a_off(4 * pq + j, chunk) + sub) = v2;
+                *reinterpret_cast<bf16x2*>(at + (4 * pq + j) * Lds::kARow + chunk * 16 + sub) = v2;
             }
         } else {
             const int px = tid >> 4, ck = tid & 15;
             p.cb = *reinterpret_cast<const u32x4*>(cs + px * 256 + ck * 16);
-            *reinterpret_cast<u32x4*>(at + a_off(px, 32 + ck)) = p.cb;
+            *reinterpret_cast<u32x4*>(at + px * Lds::kARow + (32 + ck) * 16) = p.cb;
         }
         // bilinear x2 from the staged rows: thread = (pixel, chunks ck and ck + 16)
         const Geo g = geometry(tile);
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
 #pragma unroll
             for (int j = 0; j < 8; ++j)   // torch's upsample_bilinear2d: (1-ly) * ((1-lx) a + lx b) + ly * ((1-lx) c + lx d) in fp32
                 o[j] = (__bf16)(h0 * (w0 * (float)a[j] + w1 * (float)b[j]) + h1 * (w0 * (float)cc[j] + w1 * (float)d[j]));
-            *reinterpret_cast<bf16x8*>(at + a_off(px, ck + 16 * u)) = o;
+            *reinterpret_cast<bf16x8*>(at + px * Lds::kARow + (ck + 16 * u) * 16) = o;
         }
     };
     auto store_out = [&](int tile) {                                  // 16 KiB per tile, 2 x 16 B per thread, linear in HBM
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int row = 16 * u + (tid >> 5), gc = tid & 31;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(smem + Lds::otile + row * kRowBytes + ((gc ^ swz(row)) * 16));
+            const u32x4 val = *reinterpret_cast<const u32x4*>(smem + Lds::otile + row * Lds::kORow + gc * 16);
             if constexpr (!(ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(val, osrd, base + u * 8192, 0, 0);
         }
     };
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
         for (int grp = 0; grp < ((ABL & 2) ? 0 : 3); ++grp) {
             bf16x8 xf[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xf[u] = *reinterpret_cast<const bf16x8*>(at + a_off(r, 2 * (8 * grp + u) + h));
+            for (int u = 0; u < 8; ++u) xf[u] = *reinterpret_cast<const bf16x8*>(at + r * Lds::kARow + (2 * (8 * grp + u) + h) * 16);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[8 * grp + u], xf[u], acc, 0, 0, 0);
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[4 * g + j];
             const int ch0 = 32 * w + 8 * g + 4 * h;
-            *reinterpret_cast<bf16x4*>(ot + r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
+            *reinterpret_cast<bf16x4*>(ot + r * Lds::kORow + (ch0 >> 3) * 16 + (ch0 & 7) * 2) = o;
         }
         if (it + 1 < nt) commit(it + 1);
     }
