@@ -204,8 +204,10 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
 struct Dec2Lds {
     static constexpr int kStages = 3;
     static constexpr int ring = 0;                                   // 3 feature tiles
-    static constexpr int otile = kStages * kTileBytes;               // per wave [32 slots][32 px] fp32, 16-B chunks swizzled
-    static constexpr int affine = otile + 4 * 4096;                  // scale[256], shift[256]
+    static constexpr int kORow = 144;                                // per wave [32 slots][32 px] fp32, rows padded to 144 B:
+    static constexpr int kOWave = 32 * kORow;                        // every epilogue address is lane base + constant
+    static constexpr int otile = kStages * kTileBytes;
+    static constexpr int affine = otile + 4 * kOWave;                // scale[256], shift[256]
     static constexpr int norm = affine + 2 * kD * 4;                 // [32]
     static constexpr int cshift = norm + kTilePx * 4;                // [128]
     static constexpr int amax = cshift + 128 * 4;                    // [2][4][32] float2
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
     stage(0);
     stage(1);
 
-    char* ot = smem + Lds::otile + w * 4096;
+    char* ot = smem + Lds::otile + w * Lds::kOWave;
 
     for (int it = 0; it < nt; ++it) {
         // tile `it` landed (this wave's pieces). Younger than its DMA, in issue order: argmax(it-3), stores(it-2),
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
             f32x4 c4;
             if ((i & 3) == 0) c4 = *reinterpret_cast<const f32x4*>(cs + 32 * w + sl);   // e . shift of slots sl .. sl + 3
             const float m = (s[i] + c4[i & 3]) * inr * fg_scale + fg_shift;
-            *reinterpret_cast<float*>(ot + sl * 128 + (((r >> 2) ^ (sl & 7)) * 16) + (r & 3) * 4) = m;
+            *reinterpret_cast<float*>(ot + sl * Lds::kORow + r * 4) = m;
             if constexpr (ARGMAX) {
                 if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
             }
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int sl = 8 * u + (lane_o >> 3), cc = lane_o & 7;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * 128 + ((cc ^ (sl & 7)) * 16));
+            const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * Lds::kORow + cc * 16);
             const int slot = 32 * w + sl, px = px0 + 4 * cc;
             const bool ok = slot < L && px < px_end;
             store16_d(val, ors, ok ? (slot * HW + px) * 4 : 0x7ffffff0);
