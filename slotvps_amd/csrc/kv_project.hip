@@ -328,9 +328,17 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[b][4 * g + j] = bb[j];
             }
+        // swizzled rows: the XOR with swz(r) < 16 only touches the low four bits of the chunk index 2ks + h, so k-steps
+        // ks and ks + 8 differ by a constant 256 B: eight computed offsets serve all sixteen fragments
+        int o8[8];
+        if constexpr (!PADDED) {
+            const int s4 = swz(r);
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) o8[k8] = r * kRowBytes + (((2 * k8 + h) ^ s4) << 4);
+        }
         auto frag = [&](int ks) {
             if constexpr (PADDED) return *reinterpret_cast<const bf16x8*>(bt + r * Lds::kOutRow + (2 * ks + h) * 16);
-            else return read_row_frag(bt, ks, r, h);
+            else return *reinterpret_cast<const bf16x8*>(bt + o8[ks & 7] + (ks >> 3) * 256);
         };
         if constexpr (!(ABL & 2)) {
             bf16x8 xf[2][4];                     // operand fragments, double-buffered in groups of four k-steps
