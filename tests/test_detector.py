@@ -271,4 +271,5 @@ def test_trunk_bf16_autocast_option():
     assert s16.dtype == torch.float32 and all(f.dtype == torch.float32 and f.is_contiguous() for f in f16)
     for a, b in zip(f32, f16):
         assert a.shape == b.shape
-        assert (a - b).abs().max().item() <= 0.05 * a.abs().max().item() + 1e-3
+        d, scale = (a - b).abs(), a.abs().max().item()          # ~50 bf16 convolution layers in a row, random weights
+        assert d.max().item() <= 0.12 * scale + 1e-3 and d.mean().item() <= 0.02 * scale
