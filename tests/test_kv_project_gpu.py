@@ -92,3 +92,34 @@ def test_kv_project_feeds_k1(cuda):
     err = np.abs(out - ref).max()
     print(f"\n[K3->K1] max abs err vs same-policy oracle retriever: {err:.3e}")
     assert err < 5e-3      # a handful of one-ulp k/v flips seen through a sharp softmax
+
+
+def test_kv_project_full_size_properties(cuda):
+    """BASELINE size (T=5 frames of the 256x512 level = 80 tiles per workgroup): with unit LayerNorm affines every key /
+    value row has mean 0 and variance 1 over its 256 channels (up to bf16 rounding), the result does not depend on how
+    the frames are batched, and a torch fp32 evaluation of sampled rows agrees to bf16 accuracy."""
+    import torch
+    from slotvps_amd import ops
+    T, H, W = 5, 256, 512
+    g = torch.Generator(device=cuda).manual_seed(3)
+    feat = torch.randn((T, H * W, 256), generator=g, device=cuda).to(torch.bfloat16)
+    wk = (torch.randn((256, 256), generator=g, device=cuda) / 16).to(torch.bfloat16)
+    wv = (torch.randn((256, 256), generator=g, device=cuda) / 16).to(torch.bfloat16)
+    bk, bv = torch.randn(256, generator=g, device=cuda) * 0.1, torch.randn(256, generator=g, device=cuda) * 0.1
+    one, zero = torch.ones(256, device=cuda), torch.zeros(256, device=cuda)
+    tabs = ops.pos_embed_sine_tables(H, W, 256, cuda)
+    k, v = ops.kv_project(feat, H, W, tabs, wk, bk, one, zero, 1e-5, wv, bv, one, zero, 1e-5)
+    for x in (k, v):
+        xf = x.float()
+        assert xf.mean(-1).abs().max().item() < 2e-2 and (xf.var(-1, unbiased=False) - 1).abs().max().item() < 3e-2
+    k1, v1 = ops.kv_project(feat[3:4].contiguous(), H, W, tabs, wk, bk, one, zero, 1e-5, wv, bv, one, zero, 1e-5)
+    assert torch.equal(k1[0], k[3]) and torch.equal(v1[0], v[3])
+    rows = torch.tensor([0, 511, 512, 77777, H * W - 1], device=cuda)
+    yt, xt = tabs
+    pos = torch.cat([yt[rows // W], xt[rows % W]], -1)
+    xk = (feat[2, rows].float() + pos).to(torch.bfloat16).float()
+    ln = torch.nn.functional.layer_norm
+    ref_k = ln(xk @ wk.float().t() + bk, (256,))
+    ref_v = ln(feat[2, rows].float() @ wv.float().t() + bv, (256,))
+    assert (k[2, rows].float() - ref_k).abs().max().item() < 3.2e-2      # one bf16 ulp at |x| < 4
+    assert (v[2, rows].float() - ref_v).abs().max().item() < 3.2e-2

@@ -65,3 +65,33 @@ def test_level_fuse_matches_oracle(cuda, T, H, W, level0, nchw):
         worst = max(worst, d.max())
     print(f"\n[level_fuse T{T} {H}x{W} level0={level0} nchw={nchw}] max |d| {worst:.3e}, flipped {100 * flips / total:.3f}%")
     assert flips / total < 0.01
+
+
+def test_level_fuse_full_size_properties(cuda):
+    """BASELINE size (T=5, 256x512 from a 128x256 level): zero inputs give the bias everywhere; a constant previous level
+    and a constant incoming map give one constant output vector (the bilinear weights sum to 1, borders included); frames
+    are independent of their batch."""
+    import torch
+    from slotvps_amd import ops
+    T, H, W = 5, 256, 512
+    g = torch.Generator(device=cuda).manual_seed(9)
+    wc = (torch.randn((256, 384), generator=g, device=cuda) / 20).to(torch.bfloat16)
+    bc = torch.randn(256, generator=g, device=cuda)
+    cur0 = torch.zeros((T, 128, H, W), device=cuda)
+    prev0 = torch.zeros((T, H * W // 4, 256), device=cuda, dtype=torch.bfloat16)
+    out = ops.level_fuse(cur0, prev0, wc, bc, H, W)
+    assert torch.equal(out, bc.to(torch.bfloat16).expand(T, H * W, 256))
+    cvec = torch.randn(128, generator=g, device=cuda).to(torch.bfloat16).float()
+    pvec = torch.randn(256, generator=g, device=cuda).to(torch.bfloat16)
+    cur = cvec.view(1, 128, 1, 1).expand(T, 128, H, W).contiguous()
+    prev = pvec.expand(T, H * W // 4, 256).contiguous()
+    out = ops.level_fuse(cur, prev, wc, bc, H, W)
+    want = (torch.cat([pvec.float(), cvec]) @ wc.float().t() + bc).to(torch.bfloat16)
+    d = (out.float() - want.float()).abs().max().item()
+    assert d <= 2 * 2.0 ** -5, d                                       # fp32 accumulation order across one bf16 rounding, |x| < 8
+    assert torch.equal(out[0], out[4])
+    cur_r = torch.randn((T, 128, H, W), generator=g, device=cuda)
+    prev_r = torch.randn((T, H * W // 4, 256), generator=g, device=cuda).to(torch.bfloat16)
+    full = ops.level_fuse(cur_r, prev_r, wc, bc, H, W)
+    one = ops.level_fuse(cur_r[2:3].contiguous(), prev_r[2:3].contiguous(), wc, bc, H, W)
+    assert torch.equal(one[0], full[2])
