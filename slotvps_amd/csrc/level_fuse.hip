@@ -423,10 +423,21 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
             const int co = 16 * (ck + 16 * u);
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(t00 + co), b = *reinterpret_cast<const bf16x8*>(t01 + co);
             const bf16x8 cc = *reinterpret_cast<const bf16x8*>(t10 + co), d = *reinterpret_cast<const bf16x8*>(t11 + co);
+            // torch's upsample_bilinear2d expression, (1-ly) * ((1-lx) a + lx b) + ly * ((1-lx) c + lx d) in fp32, evaluated on
+            // channel pairs with packed fp32 math (v_pk_mul / v_pk_fma: two channels per VALU slot)
+            const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+            const u32x4 uc = __builtin_bit_cast(u32x4, cc), ud = __builtin_bit_cast(u32x4, d);
+            const f32x2 w0v = {w0, w0}, w1v = {w1, w1}, h0v = {h0, h0}, h1v = {h1, h1};
             bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)   // torch's upsample_bilinear2d: (1-ly) * ((1-lx) a + lx b) + ly * ((1-lx) c + lx d) in fp32
-                o[j] = (__bf16)(h0 * (w0 * (float)a[j] + w1 * (float)b[j]) + h1 * (w0 * (float)cc[j] + w1 * (float)d[j]));
+            for (int q = 0; q < 4; ++q) {            // dword q holds channels 2q (low half) and 2q + 1 (high half)
+                auto pair = [](uint32_t x) { return f32x2{__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u)}; };
+                const f32x2 top = __builtin_elementwise_fma(w1v, pair(ub[q]), w0v * pair(ua[q]));
+                const f32x2 bot = __builtin_elementwise_fma(w1v, pair(ud[q]), w0v * pair(uc[q]));
+                const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
+                o[2 * q] = (__bf16)y[0];
+                o[2 * q + 1] = (__bf16)y[1];
+            }
             *reinterpret_cast<bf16x8*>(at + px * Lds::kARow + (ck + 16 * u) * 16) = o;
         }
     };
