@@ -182,6 +182,19 @@ def main():
         if rec is not None and rec.get("workload_key") == wkey:
             traffic = int(rec["traffic_bytes_per_launch"])          # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, avg per K1 launch
             traffic_src = "profiles/r01/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+        # measured on-box ceiling next to the vendor peak: a plain device-to-device copy of 1 GiB (bytes read + written)
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        copy_gbs = 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
         oth = runner.other_algorithmic_bytes_per_step()
         oth_ms = {"kv_project": k3_ms, "level_fuse": k4_ms, "mask_decode": k2_ms}
         others = {k: {"achieved": round(oth[k] * a.steps * cif / (oth_ms[k] * 1e-3) / 1e9, 1),
@@ -191,6 +204,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "slot_attn_partial_ws", "launches": k1_n, "avg_launch_us": round(k1_ms / k1_n * 1e3, 2),
                 "algorithmic_bytes_per_launch_avg": int(alg / k1_n),
+                "copy_kernel_ceiling": {"gbps": round(copy_gbs, 1), "frac_of_it": round(achieved / copy_gbs, 4),
+                                        "what": "torch device-to-device copy of 1 GiB, bytes read + written"},
                 "other_kernels_hbm": others,
                 "other_kernels_us_per_clip": {"slot_attn_finish": round(fin_ms / a.steps / cif / cpl * 1e3, 1),
                                               "mask_decode": round(k2_ms / a.steps / cif / cpl * 1e3, 1),
