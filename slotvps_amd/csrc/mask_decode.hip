@@ -491,7 +491,8 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    // two co-resident workgroups per CU (LDS 2 x ~70 KiB): one computes while the other waits
+    // sized for two workgroups per CU by LDS (2 x ~70 KiB); this first kernel needs 297 registers per lane, so in practice
+    // one is resident - the fast path below is the one built for two
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
     int chunks = svps_pick_chunks(T, tiles, 2 * dec_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
