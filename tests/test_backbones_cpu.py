@@ -8,9 +8,9 @@ import torch
 
 from util import GOLDEN, ROOT
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from make_golden_backbone import FPN as FPN_CFG, R50, seeded_state   # noqa: E402
+from make_golden_backbone import FPN as FPN_CFG, R50, UPS, seeded_state   # noqa: E402
 
-from slotvps_amd.backbones import FPN, ResNet
+from slotvps_amd.backbones import FPN, ResNet, UPSNetFPN
 
 
 def test_resnet50_and_fpn_match_reference():
@@ -33,3 +33,11 @@ def test_resnet50_and_fpn_match_reference():
     for i, o in enumerate(p):
         ref = z[f"p{i}"]
         assert o.shape == ref.shape and np.abs(o.numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_semantic_tower_checkpoint_contract():
+    """UPSNetFPN's parameter names / shapes equal the reference module's (tests/golden/semantic_tower.npz)."""
+    z = np.load(os.path.join(GOLDEN, "semantic_tower.npz"))
+    sd = UPSNetFPN(**UPS).state_dict()
+    assert list(sd) == z["keys"].tolist()
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == z["shapes"].tolist()

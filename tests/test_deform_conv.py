@@ -95,3 +95,40 @@ def test_hip_deform_conv_with_offset_module_zero_init_is_conv(cuda):
         got = m(x)
         want = torch.nn.functional.conv2d(x.bfloat16().float(), m.conv.weight.bfloat16().float(), padding=1)
         assert (got - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_semantic_tower_matches_reference_structure(cuda):
+    """UPSNetFPN (three deformable convolutions + GroupNorm + ReLU per level, x2/x4/x8 upsampling, prediction conv) against
+    tests/golden/semantic_tower.npz: the REFERENCE's module run with the oracle's deformable convolution in place of its
+    CUDA-only op (tools/make_golden_backbone.py), offsets non-zero. fp32 operands: 1e-3; bf16 operands: storage tolerance."""
+    import os
+    import torch
+    from util import GOLDEN, ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_golden_backbone import UPS, seeded_state
+    from slotvps_amd.backbones import UPSNetFPN
+    from slotvps_amd.dcn import DeformConv
+
+    z = np.load(os.path.join(GOLDEN, "semantic_tower.npz"))
+    tower = UPSNetFPN(**UPS).eval()
+    st = seeded_state(tower, 6)
+    for k in st:
+        if "conv_offset" in k:
+            st[k] = st[k] * 0.3
+    tower.load_state_dict(st)
+    tower = tower.cuda()
+    g = torch.Generator().manual_seed(7)
+    lv = [torch.randn(1, 32, 16 >> i, 24 >> i, generator=g).cuda() for i in range(4)]
+    for bf16, tol_max, tol_mean in ((False, 1e-3, 1e-4), (True, 0.15, 0.02)):
+        for m in tower.modules():
+            if isinstance(m, DeformConv):
+                m.bf16_operands = bf16
+        with torch.no_grad():
+            up, score, feats = tower(lv)
+        torch.cuda.synchronize()
+        pairs = [(up, z["up"]), (score, z["score"])] + [(f, z[f"feat{i}"]) for i, f in enumerate(feats)]
+        for got, ref in pairs:
+            d = np.abs(got.float().cpu().numpy() - ref)
+            scale = max(1.0, np.abs(ref).max())
+            assert got.shape == ref.shape and d.max() <= tol_max * scale and d.mean() <= tol_mean * scale, (bf16, d.max(), d.mean())
