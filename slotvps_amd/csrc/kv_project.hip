@@ -20,7 +20,7 @@
 // (LDS-DMA ring, swizzled rows, pixel = MFMA column = lane). Per tile and wave: 32 MFMA 32x32x16.
 // LayerNorm over the 256 output channels of a pixel = in-lane sums + lane^32 + one (sum, sum of
 // squares) exchange between the four waves of a projection. Results are transposed through an LDS
-// out-tile so that HBM sees whole 512-byte pixel rows. The value waves (4-7) issue all LDS-DMA; every wave stores
+// out-tile so that HBM sees whole 512-byte pixel rows. The key waves issue the feature LDS-DMA, the value waves the position rows; every wave stores
 // its own projection's rows; the DMA ring is waited for with exact vmcnt counts. Two workgroup barriers per tile.
 //
 // The position rows of a tile (ytab[y(p)], xtab[x(p)], fp32) also arrive by LDS-DMA, gathered with
@@ -37,7 +37,9 @@
 
 namespace svps {
 
-constexpr int kProjAhead = 3;            // feature tiles in flight
+constexpr int kProjAhead = 2;            // feature tiles in flight (the vector L1 returns in order and an HBM miss takes
+                                         // about 0.7 tile times: two tiles ahead are enough, and the LDS of the fourth
+                                         // ring slot buys the second position buffer)
 constexpr int kProjNF = kProjAhead + 1;  // feature ring depth
 
 struct ProjLds {
@@ -49,9 +51,15 @@ struct ProjLds {
     static constexpr int kOutTile = kTilePx * kOutRow;           // 16.5 KiB
     static constexpr int outk = xk + kOutTile;                   // bf16 k rows of the tile (xk is padded the same way)
     static constexpr int outv = outk + kOutTile;
-    static constexpr int posy = outv + kOutTile;                 // [32 px][128] fp32 rows of ytab
-    static constexpr int posx = posy + kTileBytes;               // [32 px][128] fp32 rows of xtab
-    static constexpr int stats = posx + kTileBytes;              // [2][4][32] float2
+    // position rows. W % 32 == 0 (a tile lies inside one image row): two buffers of 32 xtab rows (16 KiB each) and of one
+    // ytab row (512 B each), requested TWO tiles ahead - the vector L1 returns loads in order, so these L2 hits come
+    // back behind the feature tiles (HBM misses) requested before them and a request for the next tile would land late.
+    // Other widths: one buffer of per-pixel ytab rows (16 KiB) and one of xtab rows, requested one tile ahead.
+    static constexpr int posx = outv + kOutTile;                 // [2][32 px][128] fp32 | ytab rows, then xtab rows
+    static constexpr int posy = posx + 2 * kTileBytes;           // [2][256] fp32 (aligned tiles only; one 64-lane DMA = 1 KiB, the row is its first half)
+    static constexpr int posx_of(bool aligned, int tile) { return posx + (aligned ? (tile & 1) * kTileBytes : kTileBytes); }
+    static constexpr int posy_of(bool aligned, int tile) { return aligned ? posy + (tile & 1) * 1024 : posx; }
+    static constexpr int stats = posy + 2048;              // [2][4][32] float2
     static constexpr int affine = stats + 2 * 4 * 32 * 8;        // bk bv gk bk' gv bv' : 6 x 256 fp32
     static constexpr int total = affine + 6 * kD * 4;
 };
@@ -204,14 +212,14 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
         if constexpr (!HAS_POS) return;
         if (tile >= nt) return;
         if constexpr (ABL & 4) return;
-        const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::posy + ob * 4096);
-        const uint32_t sx = __builtin_amdgcn_readfirstlane(lds0 + Lds::posx + ob * 4096);
+        const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::posy_of(aligned_rows, tile) + ob * 4096);
+        const uint32_t sx = __builtin_amdgcn_readfirstlane(lds0 + Lds::posx_of(aligned_rows, tile) + ob * 4096);
         if (aligned_rows) {
             // W % 32 == 0: a tile lies inside one image row. One 512-byte ytab row for the whole tile (build_xk reads
             // it for every pixel) and 32 consecutive xtab rows = one contiguous 16 KiB block.
             const int px0 = px_begin + tile * kTilePx;
             const int y0 = __builtin_amdgcn_readfirstlane(px0 / W), x0 = px0 - y0 * W;
-            if (ob == 0) dma16_srd_p(ysrd, __builtin_amdgcn_readfirstlane(lds0 + Lds::posy), lane * 16, y0 * 512);
+            if (ob == 0) dma16_srd_p(ysrd, __builtin_amdgcn_readfirstlane(lds0 + Lds::posy_of(true, tile)), lane * 16, y0 * 512);
             const int v = ob * 4096 + lane * 16;
             dma16x4_srd_p(xsrd, sx, v, v, v, v, __builtin_amdgcn_readfirstlane(x0 * 512));
             return;
@@ -240,18 +248,23 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
         if (w >= 4) return;
         int lt = tid;
         asm volatile("" : "+v"(lt));     // opaque: keeps hipcc from hoisting (and then spilling) the addresses
-        const char* ft = smem + Lds::fring + (tile % kProjNF) * kTileBytes;
-        char* xt = smem + Lds::xk;
+        // chunk u of this thread = 16-byte chunk cpos of pixel row 8u + q. Everything is "one lane base + u * constant":
+        // swz(8u + q) = swz(q) ^ (2 if u is odd), i.e. the swizzled source chunk of odd u is the even one with address
+        // bit 5 flipped; the position row advances by 8 rows per u (not at all for the single ytab row of an aligned tile).
+        const int q = lt >> 5, cpos = lt & 31;
+        const int fe = Lds::fring + (tile % kProjNF) * kTileBytes + q * kRowBytes + ((cpos ^ swz(q)) << 4);
+        const int fo = fe ^ 32;
+        const bool ypart = cpos < 16;
+        const int pb = (ypart ? Lds::posy_of(aligned_rows, tile) + (aligned_rows ? 0 : q * 512)
+                              : Lds::posx_of(aligned_rows, tile) + q * 512) + (cpos & 15) * 32;
+        const int ps = (ypart && aligned_rows) ? 0 : 8 * 512;
+        const int xo = Lds::xk + q * Lds::kOutRow + cpos * 16;                  // xk rows are padded, not swizzled
         bf16x8 fv[4];
         f32x4 pv[4][2];
-        int offs[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                          // twelve LDS reads in flight, then the arithmetic
-            const int id = u * 256 + lt;                       // [px][chunk]
-            const int xpx = id >> 5, cpos = id & 31;
-            offs[u] = xpx * Lds::kOutRow + cpos * 16;                           // xk rows are padded, not swizzled
-            fv[u] = *reinterpret_cast<const bf16x8*>(ft + xpx * kRowBytes + ((cpos ^ swz(xpx)) * 16));
-            const char* pt = smem + (cpos < 16 ? Lds::posy + (aligned_rows ? 0 : xpx * 512) : Lds::posx + xpx * 512) + (cpos & 15) * 32;
+            fv[u] = *reinterpret_cast<const bf16x8*>(smem + ((u & 1) ? fo : fe) + u * 8 * kRowBytes);
+            const char* pt = smem + pb + u * ps;
             pv[u][0] = *reinterpret_cast<const f32x4*>(pt);
             pv[u][1] = *reinterpret_cast<const f32x4*>(pt + 16);
         }
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
                 o[j] = (__bf16)((float)fv[u][j] + pv[u][0][j]);
                 o[4 + j] = (__bf16)((float)fv[u][4 + j] + pv[u][1][j]);
             }
-            *reinterpret_cast<bf16x8*>(xt + offs[u]) = o;
+            *reinterpret_cast<bf16x8*>(smem + xo + u * 8 * Lds::kOutRow) = o;
         }
     };
 
@@ -291,12 +304,18 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
             __builtin_amdgcn_raw_buffer_store_b128(val[u], osrd, base + u * 4096, 0, 0);
     };
 
+    // DMA issue is split between the roles: the value waves gather the position rows, the key waves (which have slack
+    // at the end of their matrix half) stream the feature tiles.
+    const int pa = aligned_rows ? 2 : 1;                                 // position rows: tiles ahead
+    const int npos = aligned_rows ? (ob == 0 ? 5 : 4) : 8;              // DMA instructions of one stage_pos() of this wave
     if (w >= 4) {
         stage_pos(0);
+        if (pa == 2) stage_pos(1);
+        wait_vm<0>();
+    } else {
 #pragma unroll
         for (int b = 0; b < A; ++b) stage_f(b);
-        if (nt > A - 1) wait_vm<4 * (A - 1)>();      // pos(0) and f(0) are the oldest
-        else wait_vm<0>();
+        wait_vm_dyn(4 * (1 < nt));                   // f(0) is the oldest
     }
     wg_barrier();          // f(0), pos(0) landed, affine table written
     build_xk(0);
@@ -306,15 +325,21 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
     const float* gam = aff + (2 + 2 * proj) * kD;
     const float* bet = aff + (3 + 2 * proj) * kD;
     const float eps = proj ? eps_v : eps_k;
-    char* outt = smem + (proj ? Lds::outv : Lds::outk);
     f32x16 acc[2];
+    // bias of this lane's 32 accumulator rows, resident (acc_row(4g + j, h) = 8g + 4h + j): the accumulators start from it
+    f32x16 breg[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + 64 * ob + 32 * b + 8 * g + 4 * h_);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) breg[b][4 * g + j] = bb[j];
+        }
 
     // "heavy" half of a tile: store the previous out tile, 32 MFMA, + bias, LayerNorm partial sums -> LDS
     auto heavy = [&](int it, auto padded_tag) {
         constexpr bool PADDED = decltype(padded_tag)::value;      // B operand rows padded to 528 B (xk) or swizzled (feature ring)
-        if (it >= 1) store_out(it - 1);
-        K3_STAMP(3);
-        if (it >= nt) return;
         const char* bt = (HAS_POS && proj == 0) ? smem + Lds::xk : smem + Lds::fring + (it % kProjNF) * kTileBytes;
         int r = r_, h = h_;
         asm volatile("" : "+v"(r), "+v"(h));   // opaque per iteration: no loop-invariant address tables in VGPRs
@@ -323,11 +348,7 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + 64 * ob + 32 * b + 8 * g + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[b][4 * g + j] = bb[j];
-            }
+            for (int i = 0; i < 16; ++i) acc[b][i] = (ABL & 64) ? 0.f : breg[b][i];
         // swizzled rows: the XOR with swz(r) < 16 only touches the low four bits of the chunk index 2ks + h, so k-steps
         // ks and ks + 8 differ by a constant 256 B: eight computed offsets serve all sixteen fragments
         int o8[8];
@@ -380,6 +401,9 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
     auto light = [&](int it) {
         int r = r_, h = h_;
         asm volatile("" : "+v"(r), "+v"(h));
+        // out-tile write address = lane base + compile-time constant: channel 64 ob + 32 b + 8 g + 4 h of pixel row r
+        int wo = (proj ? Lds::outv : Lds::outk) + r * Lds::kOutRow + 8 * h + 128 * ob;
+        asm volatile("" : "+v"(wo));
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
@@ -397,12 +421,16 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch0 = 64 * ob + 32 * b + 8 * g + 4 * h;     // acc_row(4g + j, h) = 8g + 4h + j
+                if constexpr (ABL & 32) {                              // ablation: affine-free LayerNorm
+                    gg[g] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    be[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    continue;
+                }
                 gg[g] = *reinterpret_cast<const f32x4*>(gam + ch0);
                 be[g] = *reinterpret_cast<const f32x4*>(bet + ch0);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int ch0 = 64 * ob + 32 * b + 8 * g + 4 * h;
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
@@ -412,8 +440,7 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
                     o[j] = (__bf16)y[0];
                     o[j + 1] = (__bf16)y[1];
                 }
-                const int chunk = ch0 >> 3;                            // 16-byte chunk of the pixel row
-                *reinterpret_cast<bf16x4*>(outt + r * Lds::kOutRow + chunk * 16 + (ch0 & 7) * 2) = o;
+                *reinterpret_cast<bf16x4*>(smem + wo + 64 * b + 16 * g) = o;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -424,40 +451,59 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
     // part. Two workgroup barriers per tile:
     //   phase X(it): key waves heavy(it)                       | value waves: all DMA issue, light(it-1)
     //   phase Y(it): key waves light(it), build xk(it+1)       | value waves heavy(it)
-    for (int it = 0; it <= nt; ++it) {
-        K3_STAMP(0);
-        wg_barrier();                                                  // X(it): xk(it) built, stats_v(it-1) written
-        K3_STAMP(1);
-        if (proj == 0) {
+    // The two roles run separate loops (same number of barriers): with one loop body for both, hipcc kept two copies of
+    // the accumulators and moved 32 registers back and forth per tile. The last half-phases (stores of the last tile,
+    // LayerNorm of the last value tile) are peeled so that every iteration redefines the accumulators unconditionally.
+    if (nt <= 0) return;
+    if (proj == 0) {
+        for (int it = 0; it < nt; ++it) {
+            K3_STAMP(0);
+            wg_barrier();                                              // X(it): xk(it) built, stats_v(it-1) written
+            K3_STAMP(1);
+            if (it >= 1) store_out(it - 1);
+            K3_STAMP(3);
             heavy(it, std::bool_constant<HAS_POS>{});
             K3_STAMP(6);
+            stage_f(it + A);
+            // f(it+1) (this wave's pieces, issued in X(it+1-A)) has to be in LDS before build_xk(it+1): vmcnt retires in
+            // order, younger are the stores of X(it) and f(it+2)
+            static_assert(A == 2, "wait count below assumes two tiles in flight");
+            wait_vm_dyn(4 * ((it >= 1) + (it + 2 < nt)));
             K3_STAMP(7);
-        } else {
-            if (it < nt) {
-                stage_pos(it + 1);                                     // single buffer: pos(it) was consumed in Y(it-1)
-                stage_f(it + A);
-            }
+            wg_barrier();                                              // Y(it): stats_k(it) written
+            K3_STAMP(8);
+            light(it);
+            K3_STAMP(9);
+            if (!(ABL & 16) && it + 1 < nt) build_xk(it + 1);
+            K3_STAMP(10);
+        }
+        wg_barrier();                                                  // X(nt)
+        store_out(nt - 1);
+        wg_barrier();                                                  // Y(nt)
+    } else {
+        for (int it = 0; it < nt; ++it) {
+            K3_STAMP(0);
+            wg_barrier();                                              // X(it)
+            K3_STAMP(1);
+            stage_pos(it + pa);                                        // its buffer held pos(it), consumed in Y(it-1)
             K3_STAMP(2);
             if (it >= 1) light(it - 1);
-            // f(it+1), pos(it+1) landed (this wave's pieces); only f(it+A) [4] is younger than pos(it+1), the stores of
-            // Y(it-1) are older (vmcnt retires in order)
-            if (it + A < nt) wait_vm<4>();
+            K3_STAMP(11);
+            // pos(it+1) landed. Two tiles ahead: it was requested in X(it-1); younger are the stores of Y(it-1) and pos(it+2)
+            if (pa == 2) wait_vm_dyn(4 * (it >= 2) + ((it + 2 < nt) ? npos : 0));
             else wait_vm<0>();
             K3_STAMP(7);
-        }
-        wg_barrier();                                                  // Y(it): stats_k(it) written, out_v(it-1) complete
-        K3_STAMP(8);
-        if (proj == 0) {
-            if (it < nt) {
-                light(it);
-                K3_STAMP(9);
-                if (!(ABL & 16) && it + 1 < nt) build_xk(it + 1);
-                K3_STAMP(10);
-            }
-        } else {
+            wg_barrier();                                              // Y(it): out_v(it-1) complete
+            K3_STAMP(8);
+            if (it >= 1) store_out(it - 1);
+            K3_STAMP(3);
             heavy(it, std::false_type{});
             K3_STAMP(10);
         }
+        wg_barrier();                                                  // X(nt)
+        light(nt - 1);
+        wg_barrier();                                                  // Y(nt)
+        store_out(nt - 1);
     }
 }
 
@@ -511,6 +557,9 @@ extern "C" int svps_kv_project_fwd(const void* feat, const float* pos_y, const f
             case 27: kern = svps::kv_project_kernel<true, 27>; break;
             case 31: kern = svps::kv_project_kernel<true, 31>; break;
             case 30: kern = svps::kv_project_kernel<true, 30>; break;
+            case 32: kern = svps::kv_project_kernel<true, 32>; break;
+            case 64: kern = svps::kv_project_kernel<true, 64>; break;
+            case 96: kern = svps::kv_project_kernel<true, 96>; break;
             default: break;
         }
     }

@@ -22,12 +22,12 @@ buf = np.zeros((8, 8, 16), dtype=np.uint64)
 rc = lib.svps_k3_debug_read(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 names = {0: "pre-B1", 1: "B1 done", 2: "dma issued", 3: "stores issued", 4: "mfma done", 5: "stats done", 6: "heavy ret",
-         7: "pre-B2", 8: "B2 done", 9: "light done", 10: "end"}
+         7: "pre-B2", 8: "B2 done", 9: "light done", 10: "end", 11: "light(v) done"}
 base = buf[:, 0, 0].min()
 for w in (0, 4):
     print(f"--- wave {w} ({'key' if w < 4 else 'value'}) ; s_memtime ticks (100 MHz: 1 tick = 10 ns) relative")
     for it in range(1, 5):
         row = buf[w, it].astype(np.int64) - int(base)
-        print(f"it {it+8}: " + "  ".join(f"{names[i]}={row[i]}" for i in range(11) if buf[w, it, i]))
+        print(f"it {it+8}: " + "  ".join(f"{names[i]}={row[i]}" for i in range(12) if buf[w, it, i]))
 per_tile = (buf[0, 7, 0].astype(np.int64) - buf[0, 1, 0].astype(np.int64)) / 6
 print("ticks per tile", per_tile)
