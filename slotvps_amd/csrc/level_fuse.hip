@@ -297,6 +297,39 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
     const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(out + (size_t)t * HW * kD), 0, HW * kRowBytes, 0x00020000);
 
+    // horizontal blend weights as MFMA B fragments (tile-invariant: a tile starts at an even column, the staged columns
+    // start one source pixel to its left and are clamped into the row when they are read from memory): pixel n takes
+    // staged columns c0 = (n + 1) >> 1 and c0 + 1 with weights (1 - lx, lx), lx = 0.25 for odd n, 0.75 for even n.
+    // Lane (n, h) holds taps 16 ks + 8 h + j, j = 0..7.
+    bf16x8 bwx[2];
+    {
+        const int c0 = (r_ + 1) >> 1;
+        const float lx = (r_ & 1) ? 0.25f : 0.75f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = 16 * ks + 8 * h_ + j;
+                bwx[ks][j] = (__bf16)(kk == c0 ? 1.f - lx : (kk == c0 + 1 ? lx : 0.f));
+            }
+    }
+    // A fragments = staged taps transposed, channels 32w .. 32w+31: byte offsets of the two transposed reads of k-step ks
+    // inside one staged source row (see read_col_frag in common.h); taps past column 17 carry weight 0 and are clamped
+    // onto column 17 so that they read finite data.
+    int tap_off[2][2];
+    {
+        const int gq = lane >> 4, i = lane & 15, q = i >> 2, p4 = i & 3;
+        const int chunk = 4 * w + 2 * (gq & 1) + (p4 >> 1), sub = 8 * (p4 & 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                int row = 16 * ks + 8 * (gq >> 1) + q + 4 * half;
+                row = row < Fuse2Lds::kStageCols ? row : Fuse2Lds::kStageCols - 1;
+                tap_off[ks][half] = row * kRowBytes + ((chunk ^ swz(row)) * 16) + sub;
+            }
+    }
+
     // tile geometry (wave-uniform): output row y, first column x0; source rows ys0 / ys1 with weight wy of ys1;
     // staged columns xs_base .. xs_base + 17 (clamped into the row when read from memory)
     struct Geo { int ys0, ys1, xs_base, x0; float wy; };
@@ -324,7 +357,9 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
             int col = g.xs_base + 2 * cp + h_;
             col = col < 0 ? 0 : (col < Wp ? col : Wp - 1);
             const int ys = row ? g.ys1 : g.ys0;
-            const int voff = (ys * Wp + col) * kRowBytes + (lane & 31) * 16;
+            // 16-byte chunks XOR-swizzled by the staged column index (on the source side, as in K1): the transposed
+            // fragment reads of the blend then touch distinct banks
+            const int voff = (ys * Wp + col) * kRowBytes + (((lane & 31) ^ swz(2 * cp + h_)) * 16);
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::stage + (tile & 1) * Lds::stage_bytes +
                                                                 (row * Lds::kStageCols + 2 * cp) * kRowBytes);
             uint32_t keep;
@@ -405,40 +440,46 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
             p.cb = *reinterpret_cast<const u32x4*>(cs + px * 256 + ck * 16);
             *reinterpret_cast<u32x4*>(at + px * Lds::kARow + (32 + ck) * 16) = p.cb;
         }
-        // bilinear x2 from the staged rows: thread = (pixel, chunks ck and ck + 16)
-        const Geo g = geometry(tile);
-        const int px = tid >> 4, ck = tid & 15;
-        const int x = g.x0 + px;
-        const float sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
-        const int xs0 = (int)sx;
-        const int xs1 = xs0 + 1 < Wp ? xs0 + 1 : Wp - 1;
-        const float w1 = sx - (float)xs0, w0 = 1.f - w1, h1 = g.wy, h0 = 1.f - g.wy;
-        const char* st = smem + Lds::stage + (tile & 1) * Lds::stage_bytes;
-        const char* t00 = st + (xs0 - g.xs_base) * kRowBytes;
-        const char* t01 = st + (xs1 - g.xs_base) * kRowBytes;
-        const char* t10 = t00 + Lds::kStageCols * kRowBytes;
-        const char* t11 = t01 + Lds::kStageCols * kRowBytes;
+        // bilinear x2 on the matrix cores: up[c][px] = h0 * (Wx . row0)[c][px] + h1 * (Wx . row1)[c][px], where Wx[tap][px]
+        // holds the two horizontal weights of pixel px (bwx, the same for every tile). Wave w blends channels 32w .. 32w+31
+        // of all 32 pixels: A = staged taps transposed (hardware-transposed LDS reads), 2 k-steps of 16 taps per source row.
+        // The products (bf16 tap x {0, .25, .75, 1}) are exact and at most two are non-zero per sum, so each row sum is
+        // round(w0 a + w1 b) - torch's upsample_bilinear2d expression  (1-ly) ((1-lx) a + lx b) + ly ((1-lx) c + lx d).
+        if constexpr (!(ABL & 4)) {
+            const Geo g = geometry(tile);
+            const float h1 = g.wy, h0 = 1.f - g.wy;
+            const int so = Lds::stage + (tile & 1) * Lds::stage_bytes;
+            f32x16 up[2];
 #pragma unroll
-        for (int u = 0; u < ((ABL & 4) ? 0 : 2); ++u) {
-            const int co = 16 * (ck + 16 * u);
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(t00 + co), b = *reinterpret_cast<const bf16x8*>(t01 + co);
-            const bf16x8 cc = *reinterpret_cast<const bf16x8*>(t10 + co), d = *reinterpret_cast<const bf16x8*>(t11 + co);
-            // torch's upsample_bilinear2d expression, (1-ly) * ((1-lx) a + lx b) + ly * ((1-lx) c + lx d) in fp32, evaluated on
-            // channel pairs with packed fp32 math (v_pk_mul / v_pk_fma: two channels per VALU slot)
-            const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
-            const u32x4 uc = __builtin_bit_cast(u32x4, cc), ud = __builtin_bit_cast(u32x4, d);
-            const f32x2 w0v = {w0, w0}, w1v = {w1, w1}, h0v = {h0, h0}, h1v = {h1, h1};
-            bf16x8 o;
+            for (int row = 0; row < 2; ++row) {
+                bf16x8 af[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {            // dword q holds channels 2q (low half) and 2q + 1 (high half)
-                auto pair = [](uint32_t x) { return f32x2{__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u)}; };
-                const f32x2 top = __builtin_elementwise_fma(w1v, pair(ub[q]), w0v * pair(ua[q]));
-                const f32x2 bot = __builtin_elementwise_fma(w1v, pair(ud[q]), w0v * pair(uc[q]));
-                const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
-                o[2 * q] = (__bf16)y[0];
-                o[2 * q + 1] = (__bf16)y[1];
+                for (int ks = 0; ks < 2; ++ks) {
+                    const char* base = smem + so + row * Lds::kStageCols * kRowBytes;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(base + tap_off[ks][0]));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(base + tap_off[ks][1]));
+                    af[ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                f32x16 z;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) z[i] = 0.f;
+                z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bwx[0], z, 0, 0, 0);
+                up[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bwx[1], z, 0, 0, 0);
             }
-            *reinterpret_cast<bf16x8*>(at + px * Lds::kARow + (ck + 16 * u) * 16) = o;
+            const f32x2 h0v = {h0, h0}, h1v = {h1, h1};
+            const int wo = Lds::atile + r_ * Lds::kARow + (32 * w + 4 * h_) * 2;      // pixel row r_, channels 32w + 8g + 4h ..
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f32x2 top = {up[0][4 * gq + j], up[0][4 * gq + j + 1]}, bot = {up[1][4 * gq + j], up[1][4 * gq + j + 1]};
+                    const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
+                    o[j] = (__bf16)y[0];
+                    o[j + 1] = (__bf16)y[1];
+                }
+                *reinterpret_cast<bf16x4*>(smem + wo + 16 * gq) = o;
+            }
         }
     };
     auto store_out = [&](int tile) {                                  // 16 KiB per tile, 2 x 16 B per thread, linear in HBM
