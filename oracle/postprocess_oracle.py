@@ -14,8 +14,10 @@ modules, Tensor.cuda() made a no-op) and records its outputs in tests/golden/pos
 One dependency is RESTATED, not imported: panopticapi.utils.id2rgb / rgb2id (un-vendored, unpinned git
 install, README.md:13 of the reference) - the published base-256 pack / unpack; together with the
 same-size PIL NEAREST resize at :745-751 it is the identity for ids < 2^24, which is how it is
-modelled here. The relabel of simple_test lives in a method that needs the whole detector; it is
-restated from :411-435 and unpinned (no reference test or vector exists for it).
+modelled here. The relabel (:411-435) and the tracker assignment (:328-409) of simple_test are PINNED too:
+tools/make_golden_simple_test.py runs the reference's own simple_test on a four-frame synthetic video (detector
+object without its constructor, canned tensors upstream of the head outputs) and tests/test_simple_test_golden.py
+checks the pipeline postprocess -> panoptic_relabel -> track_assign against every frame's result dict, bit for bit.
 """
 import numpy as np
 
@@ -185,8 +187,8 @@ def panoptic_relabel(masks, labels, stuff_num=STUFF_NUM_CITYSCAPES):
 def track_assign(cur_embed, prev_embed, fc_w, fc_b):
     """Tracker step of simple_test (vps_temporal_slots.py:345-409) with SimpleTrackHead.forward
     (simple_track_head.py:58-92) for num_fcs_query = len(fc_w) layers, test_only_save_main_results=True (the
-    memory holds output embeddings only, :32-37). UNPINNED restatement (no reference test / vector exists; the
-    method needs the whole detector). cur_embed [K, D], prev_embed [P, D] ->
+    memory holds output embeddings only, :32-37). Pinned by tests/golden/simple_test.npz (the reference's own
+    simple_test, see the module header). cur_embed [K, D], prev_embed [P, D] ->
     (det_obj_ids [K] over ALL segments, updated memory [P', D])."""
     def fcs(x):
         for i, (w, b) in enumerate(zip(fc_w, fc_b)):

@@ -193,3 +193,27 @@ def make_harness_case(seed, n_frames=3, H=96, W=160):
         oid = rng.integers(0, 6, size=len(cls)).astype(np.int32)   # duplicates likely
         segs.append(seg); pans.append(pan2); cls_inds.append(cls); obj_ids.append(oid); names.append(f"frame_{seed}_{f}.png")
     return segs, pans, cls_inds, obj_ids, names
+
+
+def make_simple_test_case(seed, n_frames=4, L=100, h=16, w=32, num_classes=20, embed_dim=256):
+    """Head outputs of an `n_frames` video for the test-time flow after the head (post-process, relabel, tracker):
+    per frame class logits [L, nc] and mask logits [L, h, w] (make_post_case: the surviving slots change from frame to
+    frame), slot embeddings [L, D] that drift slowly (slot l of frame f resembles slot l of frame f-1, so the tracker
+    re-identifies most instances, meets new ones and has contested matches), semantic logits [19, 4h, 4w]; and the
+    tracker's two fully connected layers."""
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((L, embed_dim)).astype(np.float32)
+    frames = []
+    for f in range(n_frames):
+        logits, masks = make_post_case(seed * 10 + f // 2, L, h, w, num_classes, 16 + 2 * (f % 2))
+        if f % 2 == 1:                                       # odd frames: same scene as the frame before, perturbed
+            logits = (logits + 0.3 * rng.standard_normal(logits.shape)).astype(np.float32)
+            masks = (masks + 0.2 * rng.standard_normal(masks.shape)).astype(np.float32)
+        embed = (base + 0.15 * (f + 1) * rng.standard_normal(base.shape)).astype(np.float32)
+        if f >= 1:                                           # two slots collapse onto one older identity: contested match
+            embed[(7 * f) % L] = frames[-1]["embed"][(7 * f + 1) % L] * 1.05
+        fcn = rng.standard_normal((num_classes - 1, 4 * h, 4 * w)).astype(np.float32)
+        frames.append(dict(logits=logits, masks=masks, embed=embed, fcn=fcn))
+    fc_w = [(0.2 * rng.standard_normal((embed_dim, embed_dim))).astype(np.float32) for _ in range(2)]
+    fc_b = [(0.1 * rng.standard_normal(embed_dim)).astype(np.float32) for _ in range(2)]
+    return frames, fc_w, fc_b
