@@ -217,3 +217,14 @@ def make_simple_test_case(seed, n_frames=4, L=100, h=16, w=32, num_classes=20, e
     fc_w = [(0.2 * rng.standard_normal((embed_dim, embed_dim))).astype(np.float32) for _ in range(2)]
     fc_b = [(0.1 * rng.standard_normal(embed_dim)).astype(np.float32) for _ in range(2)]
     return frames, fc_w, fc_b
+
+
+def make_decode_case(seed, L=100, h=12, w=20, D=256):
+    """Inputs of generate_final_outputs: finest fused map [D, h, w], slot embeddings [L, D], eval-mode BatchNorm
+    parameters (weight, bias, running_mean, running_var) of feat_bn [D] and fg_bn [1]."""
+    rng = np.random.default_rng(seed)
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    return dict(feat=f32(rng.standard_normal((D, h, w))), embed=f32(rng.standard_normal((L, D))),
+                feat_bn=(f32(rng.uniform(0.5, 1.5, D)), f32(0.1 * rng.standard_normal(D)), f32(0.2 * rng.standard_normal(D)),
+                         f32(rng.uniform(0.5, 2.0, D))),
+                fg_bn=(f32([0.1]), f32([0.03]), f32([0.2]), f32([1.7])))

@@ -68,3 +68,16 @@ def test_detector_flow_equals_reference_simple_test():
         assert got["panoptic_det_obj_ids"].tolist() == z[f"f{f}_panoptic_det_obj_ids"].tolist()
         np.testing.assert_allclose(got["panoptic_cls_prob"].cpu().numpy(), z[f"f{f}_panoptic_cls_prob"], rtol=1e-6)
     np.testing.assert_array_equal(det.prev_embedding.cpu().numpy(), z["memory"])
+
+
+def test_oracle_mask_decode_equals_reference_generate_final_outputs():
+    """a8 against the reference's own method (vps_temporal_slots.py:144-160), not a re-execution of its torch ops."""
+    from util import orc
+    z = np.load(os.path.join(GOLDEN, "simple_test.npz"))
+    case = synth.make_decode_case(int(z["decode_seed"][0]))
+    D, h, w = case["feat"].shape
+    scale, shift = orc.bn_eval_affine(*case["feat_bn"])
+    fgs, fgb = orc.bn_eval_affine(*case["fg_bn"])
+    m = orc.mask_decode(case["feat"].reshape(D, h * w).T, case["embed"], scale, shift, float(fgs[0]), float(fgb[0]))
+    ref = z["decode_mask"].reshape(len(case["embed"]), h * w)
+    assert m.shape == ref.shape and np.abs(m - ref).max() < 2e-6

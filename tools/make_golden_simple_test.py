@@ -132,6 +132,20 @@ def main():
         print(f, "cls_inds", out[f"f{f}_panoptic_cls_inds"].tolist(), "obj_ids", out[f"f{f}_panoptic_det_obj_ids"].tolist(),
               "ids", np.unique(out[f"f{f}_panoptic_outputs"]).tolist())
     out["memory"] = det.prev_instances.output_embedding.numpy().astype(np.float32)
+
+    # ---- a8 by the reference's own generate_final_outputs (:144-160) ------------------------------------------------
+    # (tools/make_golden.py could only execute the torch ops of those lines: that module loader has no vps_temporal_slots)
+    case = synth.make_decode_case(SEED + 1)
+    feat_bn, fg_bn = torch.nn.BatchNorm2d(256).eval(), torch.nn.BatchNorm2d(1).eval()
+    for bn, (w_, b_, mu, var) in ((feat_bn, case["feat_bn"]), (fg_bn, case["fg_bn"])):
+        bn.weight.copy_(torch.from_numpy(w_)); bn.bias.copy_(torch.from_numpy(b_))
+        bn.running_mean.copy_(torch.from_numpy(mu)); bn.running_var.copy_(torch.from_numpy(var))
+    fake = types.SimpleNamespace(image_model=types.SimpleNamespace(feat_bn=feat_bn, fg_bn=fg_bn), other_config={})
+    _, mask, _ = vts.VPS_Temporal_Slots.generate_final_outputs(
+        fake, [torch.from_numpy(case["feat"])[None].clone()], [torch.from_numpy(case["embed"])[None]], generate_aux_output=False)
+    out["decode_mask"] = mask[0].numpy().astype(np.float32)
+    out["decode_seed"] = np.array([SEED + 1], dtype=np.int64)
+    print("decode", out["decode_mask"].shape, float(np.abs(out["decode_mask"]).max()))
     out["meta"] = np.array([SEED, N_FRAMES, L, LH, LW], dtype=np.int64)
     np.savez_compressed(os.path.join(GOLDEN, "simple_test.npz"), **out)
     print("simple_test.npz", os.path.getsize(os.path.join(GOLDEN, "simple_test.npz")) // 1024, "KiB; memory", out["memory"].shape)
