@@ -25,7 +25,7 @@ names = {0: "pre-B1", 1: "B1 done", 2: "dma issued", 3: "stores issued", 4: "mfm
          7: "pre-B2", 8: "B2 done", 9: "light done", 10: "end", 11: "light(v) done"}
 base = buf[:, 0, 0].min()
 for w in (0, 4):
-    print(f"--- wave {w} ({'key' if w < 4 else 'value'}) ; s_memtime ticks (100 MHz: 1 tick = 10 ns) relative")
+    print(f"--- wave {w} ({'key' if w < 4 else 'value'}) ; s_memtime ticks (shader clock cycles: about 2 GHz, checked against the kernel time) relative")
     for it in range(1, 5):
         row = buf[w, it].astype(np.int64) - int(base)
         print(f"it {it+8}: " + "  ".join(f"{names[i]}={row[i]}" for i in range(12) if buf[w, it, i]))
