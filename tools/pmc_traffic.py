@@ -48,11 +48,14 @@ def main():
     wb = write[k]["sum_kb"] * 1024 / n
     rec = {"kernel": "slot_attn_partial_ws",
            "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                      "--warmup 1 --cpu-baseline 0 --no-graph (default workload: 8 clips of T=5 per launch)",
+                      "--warmup 1 --cpu-baseline 0 --no-graph (default workload: 16 clips of T=5 stacked per launch)",
            "launches": n, "fetch_bytes_per_launch_corrected_x2": fb, "write_bytes_per_launch": wb,
            "traffic_bytes_per_launch": fb + wb,
            "note": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streams -> doubled "
                    "(MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
+           "per_kernel_traffic_bytes_per_launch": {
+               kk: (fetch[kk]["sum_kb"] * 2048 + write.get(kk, {"sum_kb": 0.0})["sum_kb"] * 1024) / fetch[kk]["launches"]
+               for kk in fetch},
            "all_kernels": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}
     if len(sys.argv) > 4:
         rec["workload_key"] = sys.argv[4]
