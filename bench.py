@@ -20,6 +20,8 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions
                    launches of the timed steps / their summed device time from HIP events recorded on
                    the launch stream, against the 8 TB/s HBM3E peak
   cpu_baseline     the CPU oracle (NumPy port of the reference) on the host cores, bounded sample
+  whole_detector   informational (N=1 only, outside the timed region, never part of `value`): one clip through the whole
+                   detector - PyTorch-ROCm ResNet-50 + FPN + semantic tower, this path, GPU post-process, tracker
 """
 import argparse
 import json
@@ -52,6 +54,8 @@ def parse():
                     help="independent clips stacked along the frame axis of every kernel launch (temporal attention stays per clip)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 to skip the CPU oracle leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--whole-detector", type=int, default=1,
+                    help="0 to skip the informational whole-detector leg (PyTorch trunk + this path + post-process + tracker)")
     return ap.parse_args()
 
 
@@ -86,6 +90,50 @@ def cpu_baseline(a):
     return {"value": round(frames / el, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"{frames} single-frame clip(s) (T=1) of the same {a.height}x{a.width} L={a.slots} head + "
                       f"mask decode, fp32 NumPy oracle, {el:.1f} s wall"}
+
+
+def whole_detector_leg(a, dev):
+    """Informational, rank 0 at N=1, outside the timed region and never part of `value`: one synthetic T-frame clip through
+    the WHOLE detector of configs/r50_fpn_slotvps_mi355x.py - ResNet-50 + FPN + semantic tower in PyTorch-ROCm (fp32, as
+    the reference runs them; random weights), the slot head and decode of this library (eager, one clip, no stacking), the
+    GPU post-process and the tracker (detector.VPS_Temporal_Slots.clip_test). Says what the hot path is a part of."""
+    from slotvps_amd.config import Config
+    from slotvps_amd.registry import build_detector
+    cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "r50_fpn_slotvps_mi355x.py"))
+    torch.manual_seed(0)
+    det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
+    T, H, W = a.frames, a.height, a.width
+    imgs = torch.randn(T, 3, H, W, device=dev)
+    # random-init slots all predict "no object": a fixed slot -> class table lets segments survive the post-process (SURVEY 8d)
+    table = torch.zeros(a.slots, 20, device=dev)
+    table[torch.arange(a.slots), torch.arange(a.slots) % 19] = 12.0
+    with torch.no_grad():
+        det.image_model.fg_bn.weight.fill_(40.0)
+    base = det.head_path
+    det.head_path = lambda f: (lambda lg, em, mk: (lg + table, em, mk))(*base(f))
+    metas = [dict(iid=10001 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png") for t in range(T)]
+
+    def timed(fn, n=2):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3, out
+
+    with torch.no_grad():
+        t_trunk, (feats, _fcn) = timed(lambda: det.trunk(imgs))
+        t_head, _ = timed(lambda: det.head_path(feats))
+        t_all, res = timed(lambda: det.clip_test(imgs, metas))
+        det.trunk_bf16 = True
+        t_all16, _ = timed(lambda: det.clip_test(imgs, metas))
+    return {"value": round(T / t_all * 1e3, 2), "unit": "frames/s", "ms_per_clip": round(t_all, 2),
+            "trunk_ms": round(t_trunk, 2), "slot_head_and_decode_ms": round(t_head, 2),
+            "post_process_and_tracker_ms": round(t_all - t_trunk - t_head, 2),
+            "value_with_bf16_autocast_trunk": round(T / t_all16 * 1e3, 2),
+            "segments_per_frame": [int(len(r["panoptic_cls_inds"])) for r in res],
+            "what": f"one {H}x{W} T={T} clip, whole detector, PyTorch fp32 trunk + this library, eager, n_gpus=1; informational"}
 
 
 def main():
@@ -231,6 +279,11 @@ def main():
         }
         if a.cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a)
+        if a.whole_detector and world == 1:
+            try:
+                line["whole_detector"] = whole_detector_leg(a, dev)
+            except Exception as e:                       # informational leg: never costs the bench line
+                line["whole_detector"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
         print(json.dumps(line), flush=True)
     if world > 1:
         parallel.barrier()
