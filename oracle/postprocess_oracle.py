@@ -8,14 +8,14 @@ NumPy restatement of
     fraction_threshold 0.03, apply_mask_removal + only_ins, filter_small_option '4')
   * the stuff-first reorder, per-pixel argmax and id relabel of simple_test (:411-435)
 
-Parity status: PINNED for the class above - tools/make_golden_post.py imports the reference's
+Parity status: PINNED for the class above - tests/golden/make_golden_post.py imports the reference's
 vps_temporal_slots.py in the build container (non-arithmetic stand-ins for mmcv / registry / sibling
 modules, Tensor.cuda() made a no-op) and records its outputs in tests/golden/postprocess.npz.
 One dependency is RESTATED, not imported: panopticapi.utils.id2rgb / rgb2id (un-vendored, unpinned git
 install, README.md:13 of the reference) - the published base-256 pack / unpack; together with the
 same-size PIL NEAREST resize at :745-751 it is the identity for ids < 2^24, which is how it is
 modelled here. The relabel (:411-435) and the tracker assignment (:328-409) of simple_test are PINNED too:
-tools/make_golden_simple_test.py runs the reference's own simple_test on a four-frame synthetic video (detector
+tests/golden/make_golden_flow.py runs the reference's own simple_test on a four-frame synthetic video (detector
 object without its constructor, canned tensors upstream of the head outputs) and tests/test_simple_test_golden.py
 checks the pipeline postprocess -> panoptic_relabel -> track_assign against every frame's result dict, bit for bit.
 """

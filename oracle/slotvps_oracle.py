@@ -6,12 +6,12 @@ the checker for the HIP path: only tests/, __graft_entry__.smoke() and bench.py'
 may import it. Nothing under slotvps_amd/ imports it and the product has no CPU fallback.
 
 Parity status: PINNED.  tests/test_oracle_golden.py checks every function below against golden
-vectors that tools/make_golden.py captured by importing the reference's own modules
+vectors that tests/golden/make_golden.py captured by importing the reference's own modules
 (mmdet/models/detectors/dynamic_mask_head.py, position_encoding.py) in the build container and
 running them on seeded inputs (fixtures under tests/golden/). The reference has no tests or
 known-answer vectors of its own, so these captured outputs are the pin.
 generate_final_outputs (vps_temporal_slots.py:144-160) is pinned by executing the torch ops of
-those lines on the same seeded inputs inside tools/make_golden.py (the enclosing module needs
+those lines on the same seeded inputs inside tests/golden/make_golden.py (the enclosing module needs
 mmcv, which the container lacks).
 
 Parameters are passed as flat dicts keyed by the reference's state_dict names, e.g.

@@ -1,4 +1,4 @@
-"""Deterministic synthetic parameters and inputs for the slot head (shared by tools/make_golden.py,
+"""Deterministic synthetic parameters and inputs for the slot head (shared by tests/golden/make_golden.py,
 the tests, bench.py and smoke()). Everything derives from NumPy Generators with fixed seeds, so a
 golden fixture only has to carry the seeds and the reference's outputs.
 

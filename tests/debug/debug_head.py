@@ -1,7 +1,7 @@
 """Teacher-forced localisation of head differences (GPU vs oracle), stage 0 of level 0/3."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth
 from util import orc

@@ -18,7 +18,7 @@ generate_final_outputs (vps_temporal_slots.py:144-160) cannot be imported (its m
 its fixture is produced by executing the torch ops of those six lines here (eval BatchNorm2d,
 F.normalize, einsum, BatchNorm2d(1) with slots as batch).
 
-Usage: python tools/make_golden.py [--ref /root/reference]
+Usage: python tests/golden/make_golden.py [--ref /root/reference]
 """
 import argparse
 import importlib.util
@@ -30,7 +30,8 @@ import numpy as np
 import torch
 from torch import nn
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth  # noqa: E402
 

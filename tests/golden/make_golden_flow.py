@@ -8,7 +8,7 @@ head return the canned tensors of slotvps_amd.synth.make_simple_test_case; gener
 logits (that function is pinned by tests/golden/head_small.npz on its own). Everything downstream is the reference's
 code as it stands: PostProcessPanopticInstances, the Instances container, SimpleTrackHead (mmdet/models/detectors/
 simple_track_head.py, seeded weights), the greedy assignment (:328-409), the relabel (:411-435), the result dict.
-Other stand-ins as in tools/make_golden_post.py (registry decorators, auto_fp16, DataContainer, Tensor.cuda() -> no-op,
+Other stand-ins as in tests/golden/make_golden_post.py (registry decorators, auto_fp16, DataContainer, Tensor.cuda() -> no-op,
 torch.cuda.current_device() -> "cpu",
 panopticapi's id2rgb / rgb2id restated - un-vendored dependency, unused on this path).
 Stored: the result dict of every frame and the tracker memory after the last frame (inputs are regenerated from the seed).
@@ -21,9 +21,8 @@ import types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
 from slotvps_amd import synth  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -134,7 +133,7 @@ def main():
     out["memory"] = det.prev_instances.output_embedding.numpy().astype(np.float32)
 
     # ---- a8 by the reference's own generate_final_outputs (:144-160) ------------------------------------------------
-    # (tools/make_golden.py could only execute the torch ops of those lines: that module loader has no vps_temporal_slots)
+    # (tests/golden/make_golden.py could only execute the torch ops of those lines: that module loader has no vps_temporal_slots)
     case = synth.make_decode_case(SEED + 1)
     feat_bn, fg_bn = torch.nn.BatchNorm2d(256).eval(), torch.nn.BatchNorm2d(1).eval()
     for bn, (w_, b_, mu, var) in ((feat_bn, case["feat_bn"]), (fg_bn, case["fg_bn"])):

@@ -14,7 +14,7 @@ import types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REF = "/root/reference"
 SMALL = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[2, 4, 8, 16], window_size=7, mlp_ratio=4., qkv_bias=True,

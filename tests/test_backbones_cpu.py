@@ -1,5 +1,5 @@
 """PyTorch backbone / neck mirrors against the reference's own ResNet-50 and FPN (tests/golden/backbone.npz, made by
-tools/make_golden_backbone.py): state-dict key / shape lists (the checkpoint contract) and outputs on a seeded input."""
+tests/golden/make_golden_backbone.py): state-dict key / shape lists (the checkpoint contract) and outputs on a seeded input."""
 import os
 import sys
 
@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from util import GOLDEN, ROOT
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from make_golden_backbone import FPN as FPN_CFG, R50, UPS, seeded_state   # noqa: E402
 
 from slotvps_amd.backbones import FPN, ResNet, UPSNetFPN

@@ -101,11 +101,11 @@ def test_hip_deform_conv_with_offset_module_zero_init_is_conv(cuda):
 def test_semantic_tower_matches_reference_structure(cuda):
     """UPSNetFPN (three deformable convolutions + GroupNorm + ReLU per level, x2/x4/x8 upsampling, prediction conv) against
     tests/golden/semantic_tower.npz: the REFERENCE's module run with the oracle's deformable convolution in place of its
-    CUDA-only op (tools/make_golden_backbone.py), offsets non-zero. fp32 operands: 1e-3; bf16 operands: storage tolerance."""
+    CUDA-only op (tests/golden/make_golden_backbone.py), offsets non-zero. fp32 operands: 1e-3; bf16 operands: storage tolerance."""
     import os
     import torch
     from util import GOLDEN, ROOT
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_golden_backbone import UPS, seeded_state
     from slotvps_amd.backbones import UPSNetFPN
     from slotvps_amd.dcn import DeformConv

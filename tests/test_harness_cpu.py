@@ -1,5 +1,5 @@
 """Harness glue: get_unified_pan_result against outputs of the reference's own method
-(tests/golden/harness.npz, made by tools/make_golden_harness.py) and the single_gpu_test result layout."""
+(tests/golden/harness.npz, made by tests/golden/make_golden_harness.py) and the single_gpu_test result layout."""
 import os
 
 import numpy as np

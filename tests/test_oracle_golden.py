@@ -1,5 +1,5 @@
 """Pins the CPU oracle against golden vectors captured from the reference's own modules
-(tools/make_golden.py). CPU only; float32 arithmetic like the reference, tolerances cover
+(tests/golden/make_golden.py). CPU only; float32 arithmetic like the reference, tolerances cover
 BLAS summation-order noise only."""
 import os
 
@@ -14,7 +14,7 @@ F32 = np.float32
 
 def _load(name):
     path = os.path.join(GOLDEN, name)
-    assert os.path.exists(path), f"missing fixture {path} (run tools/make_golden.py in the build container)"
+    assert os.path.exists(path), f"missing fixture {path} (run tests/golden/make_golden.py in the build container)"
     return np.load(path)
 
 

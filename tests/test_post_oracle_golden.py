@@ -1,5 +1,5 @@
 """Pins the post-process oracle (a9) against outputs of the reference's own PostProcessPanopticInstances
-(tools/make_golden_post.py). Integer results (kept slots, labels) bit-exact, float masks to 2e-6."""
+(tests/golden/make_golden_post.py). Integer results (kept slots, labels) bit-exact, float masks to 2e-6."""
 import os
 
 import numpy as np

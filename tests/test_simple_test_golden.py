@@ -1,6 +1,6 @@
 """Test-time flow after the head - post-process, relabel (vps_temporal_slots.py:411-435), tracker assignment (:328-409),
 result dict - against the reference's OWN simple_test run on a four-frame synthetic video (tests/golden/simple_test.npz,
-made by tools/make_golden_simple_test.py). CPU: pins the oracle restatements (postprocess_oracle.panoptic_relabel /
+made by tests/golden/make_golden_flow.py). CPU: pins the oracle restatements (postprocess_oracle.panoptic_relabel /
 track_assign were unpinned before). GPU: the product (K6 + host tables + tracker) on the same head outputs."""
 import os
 

@@ -1,5 +1,5 @@
 """Swin backbone (PyTorch, config 4 of BASELINE): parameter names / shapes of the Swin-L configuration and the outputs
-of a small seeded configuration against the reference's own module (tests/golden/swin.npz, tools/make_golden_swin.py)."""
+of a small seeded configuration against the reference's own module (tests/golden/swin.npz, tests/golden/make_golden_swin.py)."""
 import os
 import sys
 
@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from util import GOLDEN, ROOT
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from make_golden_swin import LARGE, SMALL, seeded_state   # noqa: E402  (seed / config shared with the generator)
 
 from slotvps_amd.config import Config
