@@ -89,7 +89,8 @@ def cpu_baseline(a):
             break
     return {"value": round(frames / el, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
             "sample": f"{frames} single-frame clip(s) (T=1) of the same {a.height}x{a.width} L={a.slots} head + "
-                      f"mask decode, fp32 NumPy oracle, {el:.1f} s wall"}
+                      f"mask decode, fp32 NumPy oracle ({threads} BLAS threads for the matrix products; softmax, "
+                      f"LayerNorm and resampling are single-threaded NumPy), {el:.1f} s wall"}
 
 
 def whole_detector_leg(a, dev):
