@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X-native Slot-VPS hot path (slot-retriever decode loop + mask decode).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts N ranks itself, one per GPU, and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W          (the driver's form: this process is one rank)
 
 One "step" = one pass of the hot path over one batch of synthetic clips per rank: `--clips-per-launch`
 (default 16) independent T=5 clips of 1024x2048 stacked along the frame axis -> four levels of 128-channel
@@ -11,15 +11,17 @@ FPN feature maps (32x64 ... 256x512, resident in HBM) -> the 7-stage multi-scale
 once per level / stage for all frames of the batch; temporal slot attention stays inside each clip) ->
 slot->mask decode of all frames (K2). Weights: the R50-FPN Slot-VPS head architecture with seeded synthetic values
 (no checkpoints exist, README.md:25 of the reference). Clips are independent, so ranks share nothing
-(weak scaling); the per-clip results (uint8 slot-argmax maps + class logits) are gathered to rank 0
-over RCCL inside the timed region.
+(weak scaling); after every step the results of its clips (uint8 slot-argmax maps + class logits of every frame) are
+gathered to rank 0 over RCCL on a side stream, overlapped with the next step, inside the timed region.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions):
   value            frames/s, whole job            = n_gpus * steps * T / max-over-ranks wall time
   roofline         K1 (slot_attn_partial_*): algorithmic bytes (k and v read once + q + out) of all K1
                    launches of the timed steps / their summed device time from HIP events recorded on
                    the launch stream, against the 8 TB/s HBM3E peak
-  cpu_baseline     the CPU oracle (NumPy port of the reference) on the host cores, bounded sample
+  cpu_baseline     the PyTorch-CPU restatement of the same head + decode (oracle/torch_cpu_head.py, pinned through the
+                   NumPy oracle against the reference's own modules) on the host cores: T = 5 clips, fp32, all cores
+                   (median) and 8 threads, bounded sample
   whole_detector   informational (N=1 only, outside the timed region, never part of `value`): one clip through the whole
                    detector - PyTorch-ROCm ResNet-50 + FPN + semantic tower, this path, GPU post-process, tracker
 """
@@ -53,44 +55,66 @@ def parse():
     ap.add_argument("--clips-per-launch", type=int, default=16,
                     help="independent clips stacked along the frame axis of every kernel launch (temporal attention stays per clip)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 to skip the CPU oracle leg")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher / rendezvous / gather rehearsal without kernels (gloo on CPU; used by tests/test_parallel_cpu.py)")
     ap.add_argument("--whole-detector", type=int, default=1,
                     help="0 to skip the informational whole-detector leg (PyTorch trunk + this path + post-process + tracker)")
     return ap.parse_args()
 
 
 def cpu_baseline(a):
-    """Time the CPU oracle (NumPy restatement of the reference, fp32) on a bounded sample of the same
-    workload: single frames (T=1) of the 1024x2048 head + decode, repeated until ~cpu_seconds."""
+    """the PyTorch-CPU restatement of the slot head + mask decode (oracle/torch_cpu_head.py; the
+    reference's own files do not travel) on the host cores of this box: one T-frame clip per iteration, fp32,
+    torch.set_num_threads(all cores) - 1 warm-up, then timed iterations until ~cpu_seconds (at least 3, at most 10), median -
+    and one timed iteration at 8 threads for comparability with the survey container."""
+    import statistics
     import numpy as np
     from oracle import slotvps_oracle as orc
+    from oracle.torch_cpu_head import TorchCpuHead
     from slotvps_amd import synth
+    cores = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
     params = synth.make_params(synth.head_shapes(), 0)
+    head = TorchCpuHead(params)
     sizes = synth.level_sizes(a.height, a.width)
-    pos = [orc.pos_embed_sine(h, w) for (h, w) in sizes]
-    rng = np.random.default_rng(1)
-    feats = [[rng.standard_normal((128, h, w)).astype(np.float32) for (h, w) in sizes]]
-    slots = synth.make_slots(1, a.slots)
-    scale, shift = orc.bn_eval_affine(np.ones(256, np.float32), np.zeros(256, np.float32),
-                                      np.zeros(256, np.float32), np.ones(256, np.float32))
-    frames, t0 = 0, time.perf_counter()
-    while True:
-        _, embeds, fused = orc.head_forward(feats, slots, pos, params)
-        m = orc.mask_decode(fused[0][3], embeds[0][-1], scale, shift, np.float32(0.1), np.float32(0.0))
-        orc.slot_argmax(m)
-        frames += 1
-        el = time.perf_counter() - t0
-        if el >= a.cpu_seconds or frames >= 8:
-            break
-    return {"value": round(frames / el, 4), "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": f"{frames} single-frame clip(s) (T=1) of the same {a.height}x{a.width} L={a.slots} head + "
-                      f"mask decode, fp32 NumPy oracle ({threads} BLAS threads for the matrix products; softmax, "
-                      f"LayerNorm and resampling are single-threaded NumPy), {el:.1f} s wall"}
+    pos = [torch.from_numpy(orc.pos_embed_sine(h, w)) for (h, w) in sizes]
+    g = torch.Generator().manual_seed(1)
+    T = a.frames
+    feats = [[torch.randn((128, h, w), generator=g) for (h, w) in sizes] for _ in range(T)]
+    slots = torch.from_numpy(synth.make_slots(1, a.slots))
+    scale, shift = torch.ones(256), torch.zeros(256)
+
+    def clip():
+        _, embeds, fused = head.forward(feats, slots, pos)
+        for t in range(T):
+            TorchCpuHead.mask_decode(fused[t][3], embeds[t][-1], scale, shift, 0.1, 0.0).argmax(0)
+
+    def timed(n_threads, budget, lo, hi):
+        torch.set_num_threads(n_threads)
+        clip()                                                    # warm-up
+        ts, t_all = [], time.perf_counter()
+        while len(ts) < hi and (len(ts) < lo or time.perf_counter() - t_all < budget):
+            t0 = time.perf_counter()
+            clip()
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    keep = torch.get_num_threads()
+    ts = timed(cores, a.cpu_seconds * 0.6, 3, 10)
+    ts8 = timed(min(8, cores), 0.0, 1, 1)
+    torch.set_num_threads(keep)
+    med = statistics.median(ts)
+    return {"value": round(T / med, 4), "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "value_8_threads": round(T / ts8[0], 4), "median_s_per_clip": round(med, 3), "min_s_per_clip": round(min(ts), 3),
+            "iterations": len(ts),
+            "sample": f"{len(ts)} timed {a.height}x{a.width} T={T} L={a.slots} clips (7-stage head + mask decode of every frame) "
+                      f"after 1 warm-up, PyTorch CPU fp32 restatement of the reference's head (oracle/torch_cpu_head.py, "
+                      f"frames looped in Python like the reference), torch.set_num_threads({cores}); median reported; "
+                      f"plus 1 clip at {min(8, cores)} threads"}
 
 
 def whole_detector_leg(a, dev):
@@ -137,16 +161,79 @@ def whole_detector_leg(a, dev):
             "what": f"one {H}x{W} T={T} clip, whole detector, PyTorch fp32 trunk + this library, eager, n_gpus=1; informational"}
 
 
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: this process becomes the launcher. It has
+    not touched the GPU (no torch.cuda / HIP call above this point) and never will: it starts one rank per GPU as child
+    processes through torch.distributed.run, relays their output (rank 0 prints the JSON line) and exits with their code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, a.gpus))))
+    print(f"[bench] launcher: starting {a.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env)
+    if proc.returncode != 0:
+        print(f"[bench] launcher: a rank failed (exit code {proc.returncode})", file=sys.stderr, flush=True)
+    return proc.returncode
+
+
+def dry_run_cpu(a):
+    """Rehearsal of everything around the kernels on CPU ranks (gloo): rendezvous, clip sharding, the overlapped per-step
+    gather, max-over-ranks timing, rank 0's JSON line. No HIP call; `value` is meaningless and marked as such."""
+    from slotvps_amd import parallel
+    rank, local_rank, world = parallel.init_distributed(backend="gloo")
+    dev = torch.device("cpu")
+    T, cpl = a.frames, max(1, a.clips_per_launch)
+    tmpl = {"slot_argmax": torch.zeros((cpl * T, 64), dtype=torch.uint8), "class_logits": torch.zeros((cpl * T, a.slots, 20))}
+    gat = parallel.ClipResultGatherer(tmpl, depth=2)
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = {"slot_argmax": torch.full_like(tmpl["slot_argmax"], (rank * 16 + i) % 251),
+               "class_logits": torch.full_like(tmpl["class_logits"], float(rank))}
+        d = gat.submit(out)
+    gat.drain()
+    parallel.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    ok = True
+    if rank == 0 and a.steps > 0:
+        got = gat.last(d)
+        ok = all(int(got["slot_argmax"][r][0, 0]) == (r * 16 + a.steps - 1) % 251 and float(got["class_logits"][r][0, 0, 0]) == r
+                 for r in range(world))
+        print(json.dumps({"metric": "dry run (no kernels)", "value": 0.0, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "dry_run": True, "gather_ok": bool(ok), "world_size": world,
+                          "backend": "gloo", "ms_per_step": round(elapsed / max(1, a.steps) * 1e3, 3)}), flush=True)
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        return launch_ranks(a, sys.argv[1:])                   # before anything touches the GPU
+    if env_world is not None and int(env_world) != a.gpus:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={env_world}: refusing to report a line for a job of another size",
+              file=sys.stderr, flush=True)
+        return 2
+    if a.dry_run_cpu:
+        return dry_run_cpu(a)
     from slotvps_amd import _lib, ops, parallel
     from slotvps_amd.clip import SlotClipRunner
 
-    rank, local_rank, world = parallel.init_distributed()
-    if world != a.gpus and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    rank, local_rank, world = parallel.init_distributed()
+    if rank == 0 and world > 1:
+        print(f"[bench] {world} ranks, backend {torch.distributed.get_backend()} (RCCL), one GPU each", file=sys.stderr, flush=True)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     _lib.load()
@@ -158,17 +245,24 @@ def main():
     runner = SlotClipRunner(dev, T, a.height, a.width, L=a.slots, param_seed=0, split_p=not a.fast_p,
                             use_graph=not a.no_graph, n_slots=n_pool, clips_per_launch=cpl)
     HWf = runner.sizes[-1][0] * runner.sizes[-1][1]
+    ncls = runner.cfg["num_classes"]
     # synthetic clips, resident in HBM (in the runner's input slots) before the timed region
     for i in range(n_pool):
         runner.load_clip(runner.random_clip(1234 + rank * 1000 + i), slot=i)
-    results = torch.empty((a.steps, cif, cpl * T, HWf), dtype=torch.uint8, device=dev)
+    # per-step results of this rank's clips -> rank 0, overlapped with the next step (one gatherer per stream)
+    tmpl = {"slot_argmax": torch.zeros((cpl * T, HWf), dtype=torch.uint8, device=dev),
+            "class_logits": torch.zeros((cpl * T, a.slots, ncls), dtype=torch.float32, device=dev)}
+    gatherers = [parallel.ClipResultGatherer(tmpl, depth=2) for _ in range(cif)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(cif)] if cif > 1 else None
+
+    def result_of(out):
+        return {"slot_argmax": out["slot_argmax"], "class_logits": out["class_logits"][-1]}
 
     def step(i, record):
         if cif == 1:
             out = runner.run(slot=i % n_pool)
             if record:
-                results[i, 0].copy_(out["slot_argmax"])
+                gatherers[0].submit(result_of(out))
             return
         main_s = torch.cuda.current_stream(dev)
         for j, st in enumerate(streams):                 # independent clips: one hipGraph replay per stream
@@ -176,14 +270,16 @@ def main():
             with torch.cuda.stream(st):
                 out = runner.run(slot=(cif * i + j) % n_pool)
                 if record:
-                    results[i, j].copy_(out["slot_argmax"])
+                    gatherers[j].submit(result_of(out))
         for st in streams:
             main_s.wait_stream(st)
 
     for i in range(a.warmup):
         step(i, False)
-    if world > 1:
-        parallel.gather_to_rank0(results)        # untimed: RCCL sets up its point-to-point connections at first use
+    if world > 1:                                        # untimed: RCCL sets up its point-to-point connections at first use
+        step(0, True)
+        for g in gatherers:
+            g.drain()
     torch.cuda.synchronize(dev)
 
     # ---------------------------------- timed region -------------------------------------------
@@ -192,14 +288,16 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, True)
-    gathered = parallel.gather_to_rank0(results)            # RCCL gather of the per-clip results
+    for g in gatherers:                                  # the last gathers in flight
+        g.drain()
     torch.cuda.synchronize(dev)
     parallel.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(elapsed, dev)
-    if rank == 0:
-        assert len(gathered) == world and gathered[0].shape == results.shape
+    if rank == 0 and a.steps > 0:
+        got = gatherers[0].last((gatherers[0].n - 1) % gatherers[0].depth)
+        assert len(got["slot_argmax"]) == world and got["slot_argmax"][0].shape == tmpl["slot_argmax"].shape
 
     # ------------------- roofline leg: same steps, eager, HIP events around every launch --------------
     roof = None
@@ -274,7 +372,9 @@ def main():
                                    f"{cpl} independent clips stacked per launch x {cif} in flight per step, "
                                    f"synthetic FPN features resident in HBM; backbone/FPN not in the step",
                        "clip_frames": T, "slots": a.slots, "levels": [list(s) for s in runner.sizes],
-                       "parallelism": f"clip-parallel x{world}", "hipgraph": not a.no_graph, "clips_in_flight": cif, "clips_per_launch": cpl,
+                       "parallelism": f"clip-parallel x{world}", "world_size": world,
+                       "gather": f"per step, {gatherers[0].bytes_per_submit} B per rank to rank 0, async on a side stream (RCCL)" if world > 1 else "none (one rank)",
+                       "hipgraph": not a.no_graph, "clips_in_flight": cif, "clips_per_launch": cpl,
                        "k1_split_p": not a.fast_p},
             "roofline": roof,
         }
@@ -289,7 +389,8 @@ def main():
     if world > 1:
         parallel.barrier()
         torch.distributed.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -124,6 +124,33 @@ __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
 
 }  // namespace svps
 
+// Host side, launch state that is per DEVICE, not per process (a process may drive several GPUs): the CU count and the
+// "dynamic LDS above 64 KiB allowed" attribute of a kernel, both looked up for the device current at the call.
+static inline int svps_cur_device() {
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess ? (d & 63) : 0;
+}
+static inline int svps_num_cus() {
+    static int n[64];
+    const int d = svps_cur_device();
+    if (n[d] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 256;
+        n[d] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n[d];
+}
+struct SvpsLdsAttr {          // one static instance per launch site (= per kernel instantiation)
+    bool done[64] = {};
+    hipError_t ensure(const void* kernel, int lds_bytes) {
+        const int d = svps_cur_device();
+        if (done[d]) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e == hipSuccess) done[d] = true;
+        return e;
+    }
+};
+
 // Host side: workgroups per frame for a launch of T frames on `slots` resident workgroups (CUs x workgroups per CU).
 // All workgroups of a launch do the same amount of work, so the launch runs in whole "rounds" of `slots` workgroups:
 // take the smallest count >= slots / T whose last round is (nearly) full - e.g. 80 frames on 256 CUs: 3 per frame would

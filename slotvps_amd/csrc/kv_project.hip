@@ -510,16 +510,7 @@ __global__ __launch_bounds__(512) void kv_project_kernel(
 }  // namespace svps
 
 namespace {
-int proj_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
+int proj_num_cus() { return svps_num_cus(); }
 }  // namespace
 
 extern "C" int svps_kv_project_fwd(const void* feat, const float* pos_y, const float* pos_x, const void* wk,
@@ -538,7 +529,7 @@ extern "C" int svps_kv_project_fwd(const void* feat, const float* pos_y, const f
     int chunks = svps_pick_chunks(T, tiles, proj_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
-    static bool attr_set[2] = {false, false};
+    static SvpsLdsAttr attr[2];
     const bool has_pos = pos_y != nullptr;
     auto kern = has_pos ? svps::kv_project_kernel<true> : svps::kv_project_kernel<false>;
 #ifdef SVPS_K3_ABLATE
@@ -566,12 +557,8 @@ extern "C" int svps_kv_project_fwd(const void* feat, const float* pos_y, const f
     static bool abl_attr = false;
     if (!abl_attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, svps::ProjLds::total); abl_attr = true; }
 #endif
-    if (!attr_set[has_pos]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, svps::ProjLds::total);
-        if (e != hipSuccess) return (int)e;
-        attr_set[has_pos] = true;
-    }
+    if (hipError_t ae = attr[has_pos].ensure(reinterpret_cast<const void*>(kern), svps::ProjLds::total); ae != hipSuccess)
+        return (int)ae;
     svps_prof_mark(SVPS_KERNEL_KV_PROJECT, 0, stream);
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::ProjLds::total, stream,
                        static_cast<const __bf16*>(feat), pos_y, pos_x, static_cast<const __bf16*>(wk),

@@ -556,16 +556,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
 }  // namespace svps
 
 namespace {
-int fuse_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
+int fuse_num_cus() { return svps_num_cus(); }
 
 template <bool NCHW, bool L0>
 hipError_t launch_fuse(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
@@ -605,13 +596,8 @@ hipError_t launch_fuse_v2(const void* cur, const void* prev, const void* wc, con
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, svps::Fuse2Lds::total);
     }
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, svps::Fuse2Lds::total);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::Fuse2Lds::total); ae != hipSuccess) return ae;
     const int tiles = H * W / svps::kTilePx;
     int chunks = svps_pick_chunks(T, tiles, fuse_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;

@@ -467,16 +467,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
 
 namespace {
 
-int dec_num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
+int dec_num_cus() { return svps_num_cus(); }
 
 template <int NW, int NST, bool ARGMAX, typename OutT>
 hipError_t launch_decode(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
@@ -484,13 +475,8 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
                          int HW, hipStream_t stream) {
     using Lds = svps::DecLds<NW, NST>;
     auto kern = svps::mask_decode_kernel<NW, NST, ARGMAX, OutT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Lds::total);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
     // sized for two workgroups per CU by LDS (2 x ~70 KiB); this first kernel needs 297 registers per lane, so in practice
     // one is resident - the fast path below is the one built for two
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
@@ -508,13 +494,8 @@ hipError_t launch_decode_v2(const void* feat, const float* embed, const float* b
                             float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L, int HW,
                             hipStream_t stream) {
     auto kern = svps::mask_decode_kernel_v2<ARGMAX>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, svps::Dec2Lds::total);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::Dec2Lds::total); ae != hipSuccess) return ae;
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;      // two co-resident workgroups per CU (2 x 68 KiB LDS)
     int chunks = svps_pick_chunks(T, tiles, 2 * dec_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;

@@ -685,16 +685,7 @@ __global__ __launch_bounds__(256) void slot_attn_finish(const float* __restrict_
 
 namespace {
 
-int num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return n;
-}
+int num_cus() { return svps_num_cus(); }
 
 struct AttnPlan {
     int chunks;           // workgroups per frame
@@ -722,13 +713,8 @@ hipError_t launch_partial(const void* q, const void* k, const void* v, float* pa
                           int HW, const AttnPlan& p, hipStream_t stream) {
     using Lds = svps::AttnLds<NW, NST>;
     auto kern = svps::slot_attn_partial<NW, NST, SPLIT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Lds::total);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
     hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(NW * 64), Lds::total, stream,
                        static_cast<const __bf16*>(q), static_cast<const __bf16*>(k),
                        static_cast<const __bf16*>(v), partial, L, HW, p.tiles_per_chunk);
@@ -742,13 +728,8 @@ hipError_t launch_partial_ws(const void* q, const void* k, const void* v, float*
     using Lds = svps::AttnWsLds;
     auto kern = svps::slot_attn_partial_ws<SPLIT, ABL, EXT>;
     if (Lrow == 0) Lrow = L;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Lds::total);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
     hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream,
                        static_cast<const __bf16*>(q), static_cast<const __bf16*>(k),
                        static_cast<const __bf16*>(v), partial, L, HW, p.tiles_per_chunk, Lrow, slot_off, ext_stats);
@@ -759,13 +740,8 @@ hipError_t launch_partial_ws(const void* q, const void* k, const void* v, float*
 template <bool SPLIT>
 hipError_t launch_two_pass(const void* q, const void* k, const void* v, float* partial, float2* stats, int T, int L,
                            int HW, const AttnPlan& p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(svps::slot_attn_stats),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, svps::StatsLds::total);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(svps::slot_attn_stats), svps::StatsLds::total); ae != hipSuccess) return ae;
     hipLaunchKernelGGL(svps::slot_attn_stats, dim3(p.chunks, T), dim3(512), svps::StatsLds::total, stream,
                        static_cast<const __bf16*>(q), static_cast<const __bf16*>(k), stats, L, HW, p.tiles_per_chunk);
     hipError_t e = hipGetLastError();

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 from torch.nn.modules.utils import _pair
 
-from . import _lib
+from . import _lib, ops
 
 
 def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, bf16_operands=False,
@@ -39,8 +39,9 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, de
         x_nhwc = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
         x_nhwc.copy_(x.permute(0, 2, 3, 1))                              # cast + transpose in one pass
         cols = torch.empty((N * Ho * Wo, kh * kw * C), dtype=torch.bfloat16, device=x.device)
-        rc = lib.svps_deform_im2col_bf16(p(x_nhwc), p(offset), p(cols), N, C, H, W, kh, kw, ph, pw, sh, sw, dh, dw,
-                                         deformable_groups, Ho, Wo, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        with ops._on(x_nhwc, offset, cols) as ctx:
+            rc = lib.svps_deform_im2col_bf16(p(x_nhwc), p(offset), p(cols), N, C, H, W, kh, kw, ph, pw, sh, sw, dh, dw,
+                                             deformable_groups, Ho, Wo, ctx.stream)
         _lib.check(rc, "svps_deform_im2col_bf16")
         if weight_taps is None:
             weight_taps = weight.permute(0, 2, 3, 1).reshape(O, -1).to(torch.bfloat16).contiguous()
@@ -48,8 +49,9 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, de
         return out.view(N, Ho, Wo, O).permute(0, 3, 1, 2)
     x_nhwc = x.float().permute(0, 2, 3, 1).contiguous()                 # free for channels_last inputs
     cols = torch.empty((N, Ho * Wo, C * kh * kw), dtype=torch.float32, device=x.device)
-    rc = lib.svps_deform_im2col(p(x_nhwc), p(offset), p(cols), N, C, H, W, kh, kw, ph, pw, sh, sw, dh, dw,
-                                deformable_groups, Ho, Wo, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    with ops._on(x_nhwc, offset, cols) as ctx:
+        rc = lib.svps_deform_im2col(p(x_nhwc), p(offset), p(cols), N, C, H, W, kh, kw, ph, pw, sh, sw, dh, dw,
+                                    deformable_groups, Ho, Wo, ctx.stream)
     _lib.check(rc, "svps_deform_im2col")
     out = cols @ weight.reshape(O, -1).t().float()                       # [N, Ho*Wo, O]
     return out.view(N, Ho, Wo, O).permute(0, 3, 1, 2)                    # NCHW view over channels_last memory
@@ -66,7 +68,9 @@ class DeformConv(nn.Module):
         self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
         self.groups, self.deformable_groups = groups, deformable_groups
         self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
-        self.bf16_operands = True            # matrix-core operands in bf16, fp32 accumulation (False: fp32 throughout)
+        # False (default): fp32 columns and fp32 GEMM, like the reference's op. True: bf16 columns / weights on the matrix
+        # cores with fp32 accumulation - switched together with the detector's `trunk_bf16` (detector.py), never silently
+        self.bf16_operands = False
         self._wt = None
         self.reset_parameters()
 

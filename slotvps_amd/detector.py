@@ -207,9 +207,10 @@ class VPS_Temporal_Slots(nn.Module):
             pp.setdefault("num_stuff", self.stuff_num)
             self.postprocess_panoptic = PostProcessPanopticInstances(**pp)
         self.prev_embedding = None
+        self.test_track_instances = None         # segment table of the last frame (the reference's attribute, :303-346)
         self._fold = None
         self.reuse_ref_features = True           # keep the previous frame's level maps
-        self.trunk_bf16 = False                  # bf16 autocast for the PyTorch trunk (backbone, FPN, semantic tower)
+        self._trunk_bf16 = False
         self._ref_cache = None
         self.ref_reuse_hits = 0
 
@@ -223,16 +224,30 @@ class VPS_Temporal_Slots(nn.Module):
         assert len(fcn_feature) == self.image_model.query_feat_num_levels
         return [self.image_model.conv_trans(f) for f in fcn_feature]
 
-    def _decode_fold(self):
-        if self._fold is None:                   # eval-mode BatchNorms as the scalars / vectors K2 takes
-            scale, shift = fold_bn_eval(self.image_model.feat_bn)
-            fs, fb = fold_bn_eval(self.image_model.fg_bn)
-            self._fold = (scale, shift, float(fs.item()), float(fb.item()))
-        return self._fold
+    @property
+    def trunk_bf16(self):
+        """bf16 for the PyTorch trunk: autocast around backbone / FPN / semantic tower AND bf16 matrix-core operands in the
+        deformable convolutions (K7). Off by default: the reference's trunk is fp32 (fp16_enabled = False, :55)."""
+        return self._trunk_bf16
 
-    def load_state_dict(self, *a, **k):
-        self._fold = None
-        return super().load_state_dict(*a, **k)
+    @trunk_bf16.setter
+    def trunk_bf16(self, on):
+        self._trunk_bf16 = bool(on)
+        for m in self.modules():
+            if hasattr(m, "bf16_operands"):
+                m.bf16_operands = bool(on)
+
+    def _decode_fold(self):
+        """Eval-mode BatchNorms as the scalars / vectors K2 takes. Keyed on the identity and version of every tensor that
+        enters the fold, so in-place edits, submodule / mmcv-style checkpoint loads and .to(device) all invalidate it."""
+        bns = (self.image_model.feat_bn, self.image_model.fg_bn)
+        key = tuple((t.data_ptr(), t._version, str(t.device))
+                    for bn in bns for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        if self._fold is None or self._fold[0] != key:
+            scale, shift = fold_bn_eval(bns[0])
+            fs, fb = fold_bn_eval(bns[1])
+            self._fold = (key, (scale, shift, float(fs.item()), float(fb.item())))
+        return self._fold[1]
 
     @torch.no_grad()
     def trunk(self, imgs):
@@ -290,6 +305,9 @@ class VPS_Temporal_Slots(nn.Module):
         res = self.postprocess_panoptic.forward_tensors(pred_logits, pred_masks, (H, W))
         det = self._track(embedding[res.slot_index], first)
         labels = res.labels.cpu()
+        self.test_track_instances = Instances((H, W), slot_index=res.slot_index, labels=res.labels,
+                                              output_embedding=embedding[res.slot_index],
+                                              obj_ids=torch.from_numpy(det))
         ins = labels > self.stuff_num - 1
         pan, cls_inds, cls_prob = self.postprocess_panoptic.panoptic_ids(res, self.stuff_num)
         if fcn_output.shape[-2] != H or fcn_output.shape[-1] != W:

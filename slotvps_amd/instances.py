@@ -1,83 +1,112 @@
-"""Minimal field container with the semantics the tracker and post-process rely on (the reference uses a
-Detectron2-style `Instances`, mmdet/models/structures/instances.py:11-228): named per-instance fields of
-equal length, boolean / integer / slice indexing over all fields, `cat`, `to(device)`, `has`."""
-import itertools
+"""Per-frame segment table: equal-length columns (slot embeddings, ids, scores, class labels ...) selected
+together - what the tracker and the post-process of this package pass around.
 
+Role of the reference's `Instances` (mmdet/models/structures/instances.py:11-228, used at
+vps_temporal_slots.py:303-346 for `pred_logits` / `pred_masks` / `output_embedding` / `obj_ids`), written for
+what this package needs from it: column access by attribute, row selection with a mask / index tensor /
+slice / int applied to every column, concatenation of tables, device moves. Columns are torch tensors or
+Python lists; a table with no columns has no length.
+"""
 import torch
+
+_RESERVED = ("_size", "_cols")
+
+
+def _take(col, sel):
+    """Rows `sel` of one column. Lists follow tensor semantics for masks, index tensors and slices."""
+    if not isinstance(col, list):
+        return col[sel]
+    if isinstance(sel, slice):
+        return col[sel]
+    idx = torch.as_tensor(sel)
+    if idx.dtype == torch.bool:
+        idx = idx.nonzero().flatten()
+    return [col[int(i)] for i in idx.reshape(-1)]
 
 
 class Instances:
-    def __init__(self, image_size, **kwargs):
-        object.__setattr__(self, "_image_size", image_size)
-        object.__setattr__(self, "_fields", {})
-        for k, v in kwargs.items():
-            self.set(k, v)
+    def __init__(self, image_size, **columns):
+        self.__dict__["_size"] = tuple(image_size)
+        self.__dict__["_cols"] = {}
+        for name, col in columns.items():
+            self.set(name, col)
 
+    # ---- columns ------------------------------------------------------------------------------------
     @property
     def image_size(self):
-        return self._image_size
+        return self._size
 
-    def __setattr__(self, name, val):
-        if name.startswith("_"):
-            object.__setattr__(self, name, val)
-        else:
-            self.set(name, val)
-
-    def __getattr__(self, name):
-        if name == "_fields" or name not in self._fields:
-            raise AttributeError(f"Cannot find field '{name}' in the given Instances!")
-        return self._fields[name]
-
-    def set(self, name, value):
-        n = len(value)
-        if len(self._fields):
-            assert len(self) == n, f"Adding a field of length {n} to a Instances of length {len(self)}"
-        self._fields[name] = value
+    def set(self, name, col):
+        rows = len(col)
+        if self._cols and rows != len(self):
+            raise AssertionError(f"column '{name}' has {rows} rows, the table has {len(self)}")
+        self._cols[name] = col
 
     def has(self, name):
-        return name in self._fields
+        return name in self._cols
 
     def remove(self, name):
-        del self._fields[name]
+        self._cols.pop(name)
 
     def get_fields(self):
-        return self._fields
+        return self._cols
 
-    def to(self, *args, **kwargs):
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            ret.set(k, v.to(*args, **kwargs) if hasattr(v, "to") else v)
-        return ret
+    def __setattr__(self, name, col):
+        if name in _RESERVED:
+            self.__dict__[name] = col
+        else:
+            self.set(name, col)
 
-    def __getitem__(self, item):
-        if isinstance(item, int):
-            if item >= len(self) or item < -len(self):
-                raise IndexError("Instances index out of range!")
-            item = slice(item, None, len(self))
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            ret.set(k, v[item])
-        return ret
+    def __getattr__(self, name):          # only reached when normal lookup fails, i.e. for column names
+        cols = self.__dict__.get("_cols", {})
+        if name in cols:
+            return cols[name]
+        raise AttributeError(f"no column '{name}' in this segment table (columns: {sorted(cols)})")
 
     def __len__(self):
-        for v in self._fields.values():
-            return len(v)
-        raise NotImplementedError("Empty Instances does not support __len__!")
+        if not self._cols:
+            raise NotImplementedError("a segment table without columns has no length")
+        return len(next(iter(self._cols.values())))
+
+    def __repr__(self):
+        n = len(self) if self._cols else 0
+        return f"Instances(rows={n}, image_size={self._size}, columns={sorted(self._cols)})"
+
+    # ---- row selection / movement -----------------------------------------------------------------
+    def _like(self, columns):
+        out = Instances(self._size)
+        for name, col in columns:
+            out.set(name, col)
+        return out
+
+    def __getitem__(self, sel):
+        if isinstance(sel, int):                       # a single row stays a table of one row
+            n = len(self)
+            if not -n <= sel < n:
+                raise IndexError(f"row {sel} of a segment table with {n} rows")
+            sel = sel % n
+            sel = slice(sel, sel + 1)
+        return self._like((name, _take(col, sel)) for name, col in self._cols.items())
+
+    def to(self, *args, **kwargs):
+        return self._like((name, col.to(*args, **kwargs) if isinstance(col, torch.Tensor) else col)
+                          for name, col in self._cols.items())
 
     @staticmethod
-    def cat(instance_lists):
-        assert len(instance_lists) > 0
-        if len(instance_lists) == 1:
-            return instance_lists[0]
-        ret = Instances(instance_lists[0].image_size)
-        for k in instance_lists[0]._fields.keys():
-            values = [i._fields[k] for i in instance_lists]
-            v0 = values[0]
-            if isinstance(v0, torch.Tensor):
-                values = torch.cat(values, dim=0)
-            elif isinstance(v0, list):
-                values = list(itertools.chain(*values))
+    def cat(tables):
+        tables = list(tables)
+        if not tables:
+            raise AssertionError("nothing to concatenate")
+        first = tables[0]
+        if len(tables) == 1:
+            return first
+        out = Instances(first.image_size)
+        for name, col in first.get_fields().items():
+            parts = [t.get_fields()[name] for t in tables]
+            if isinstance(col, torch.Tensor):
+                out.set(name, torch.cat(parts, dim=0))
+            elif isinstance(col, list):
+                out.set(name, [x for part in parts for x in part])
             else:
-                raise ValueError(f"Unsupported type {type(v0)} for concatenation")
-            ret.set(k, values)
-        return ret
+                raise ValueError(f"column '{name}': cannot concatenate {type(col).__name__}")
+        return out

@@ -13,8 +13,35 @@ from . import _lib
 D_MODEL = 256
 
 
-def _stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+class _on:
+    """Launch context of one C-ABI call: all tensor arguments must live on ONE GPU; that GPU is made current for the
+    call (kernel attributes, CU count and the launch itself are per device) and `.stream` is the current stream OF
+    THAT DEVICE - not of whichever device happens to be current in the caller."""
+
+    def __init__(self, *tensors):
+        devs = {t.device for t in tensors if isinstance(t, torch.Tensor)}
+        if len(devs) != 1:
+            raise ValueError(f"tensor arguments on different devices: {sorted(map(str, devs))}")
+        self.device = devs.pop()
+        if self.device.type != "cuda":
+            raise RuntimeError(f"GPU tensors only (got {self.device}); there is no CPU fallback")
+        self._guard = None
+
+    def __enter__(self):
+        if self.device.index != torch.cuda.current_device():
+            self._guard = torch.cuda.device(self.device)
+            self._guard.__enter__()
+        self.stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        if self._guard is not None:
+            self._guard.__exit__(*exc)
+        return False
+
+
+def _stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _ptr(t):
@@ -65,8 +92,9 @@ def slot_attn(q, k, v, ln_w, ln_b, eps=1e-5, split_p=True, chunks=0, return_pre_
     out = torch.empty((T, L, D), dtype=torch.float32, device=q.device)
     pre = torch.empty_like(out) if return_pre_ln else None
     flags = _lib.FLAG_SPLIT_P if split_p else 0
-    rc = lib.svps_slot_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(ws),
-                                ws_bytes, _ptr(out), _ptr(pre), T, L, HW, D, flags, chunks, _stream_ptr())
+    with _on(q, k, v, ln_w, ln_b) as ctx:
+        rc = lib.svps_slot_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(ws),
+                                    ws_bytes, _ptr(out), _ptr(pre), T, L, HW, D, flags, chunks, ctx.stream)
     _lib.check(rc, "svps_slot_attn_fwd")
     return (out, pre) if return_pre_ln else out
 
@@ -85,9 +113,10 @@ def mask_decode(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out_bf16=Fa
         raise ValueError("shape mismatch")
     out = torch.empty((T, L, HW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=feat.device)
     amax = torch.empty((T, HW), dtype=torch.uint8, device=feat.device) if want_argmax else None
-    rc = lib.svps_mask_decode_fwd(_ptr(feat), _ptr(embed), _ptr(bn_scale), _ptr(bn_shift), float(fg_scale),
-                                  float(fg_shift), _ptr(out), _ptr(amax), T, L, HW, D,
-                                  _lib.FLAG_OUT_BF16 if out_bf16 else 0, _stream_ptr())
+    with _on(feat, embed, bn_scale, bn_shift) as ctx:
+        rc = lib.svps_mask_decode_fwd(_ptr(feat), _ptr(embed), _ptr(bn_scale), _ptr(bn_shift), float(fg_scale),
+                                      float(fg_shift), _ptr(out), _ptr(amax), T, L, HW, D,
+                                      _lib.FLAG_OUT_BF16 if out_bf16 else 0, ctx.stream)
     _lib.check(rc, "svps_mask_decode_fwd")
     return (out, amax) if want_argmax else out
 
@@ -99,8 +128,8 @@ def pos_embed_sine(H, W, D=D_MODEL, device="cuda"):
     if dev.type != "cuda":
         raise RuntimeError("pos_embed_sine runs on the GPU only; there is no CPU fallback")
     out = torch.empty((H * W, D), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.svps_pos_embed_sine(_ptr(out), H, W, D, _stream_ptr()), "svps_pos_embed_sine")
+    with _on(out) as ctx:
+        _lib.check(lib.svps_pos_embed_sine(_ptr(out), H, W, D, ctx.stream), "svps_pos_embed_sine")
     return out
 
 
@@ -112,8 +141,8 @@ def pos_embed_sine_tables(H, W, D=D_MODEL, device="cuda"):
         raise RuntimeError("pos_embed_sine_tables runs on the GPU only; there is no CPU fallback")
     ytab = torch.empty((H, D // 2), dtype=torch.float32, device=dev)
     xtab = torch.empty((W, D // 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.svps_pos_embed_sine_tables(_ptr(ytab), _ptr(xtab), H, W, D, _stream_ptr()),
+    with _on(ytab, xtab) as ctx:
+        _lib.check(lib.svps_pos_embed_sine_tables(_ptr(ytab), _ptr(xtab), H, W, D, ctx.stream),
                    "svps_pos_embed_sine_tables")
     return ytab, xtab
 
@@ -141,9 +170,10 @@ def kv_project(feat, H, W, pos_tabs, wk, bk, lnk_w, lnk_b, lnk_eps, wv, bv, lnv_
             raise ValueError("pos tables do not match (H, W)")
     k = torch.empty_like(feat)
     v = torch.empty_like(feat)
-    rc = lib.svps_kv_project_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(wk), _ptr(bk), _ptr(lnk_w), _ptr(lnk_b),
-                                 float(lnk_eps), _ptr(wv), _ptr(bv), _ptr(lnv_w), _ptr(lnv_b), float(lnv_eps),
-                                 _ptr(k), _ptr(v), T, H, W, D, _stream_ptr())
+    with _on(feat, ytab, xtab, wk, bk, lnk_w, lnk_b, wv, bv, lnv_w, lnv_b) as ctx:
+        rc = lib.svps_kv_project_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(wk), _ptr(bk), _ptr(lnk_w), _ptr(lnk_b),
+                                     float(lnk_eps), _ptr(wv), _ptr(bv), _ptr(lnv_w), _ptr(lnv_b), float(lnv_eps),
+                                     _ptr(k), _ptr(v), T, H, W, D, ctx.stream)
     _lib.check(rc, "svps_kv_project_fwd")
     return k, v
 
@@ -177,8 +207,9 @@ def level_fuse(cur, prev, wc, bc, H, W):
         if prev.shape != (T, (H // 2) * (W // 2), 256) or H % 2 or W % 2:
             raise ValueError(f"prev {tuple(prev.shape)} does not match an {H}x{W} level")
     out = torch.empty((T, H * W, 256), dtype=torch.bfloat16, device=cur.device)
-    _lib.check(lib.svps_level_fuse_fwd(_ptr(cur), nchw, _ptr(prev), _ptr(wc), _ptr(bc), _ptr(out), T, H, W,
-                                       _stream_ptr()), "svps_level_fuse_fwd")
+    with _on(cur, prev, wc, bc) as ctx:
+        _lib.check(lib.svps_level_fuse_fwd(_ptr(cur), nchw, _ptr(prev), _ptr(wc), _ptr(bc), _ptr(out), T, H, W,
+                                           ctx.stream), "svps_level_fuse_fwd")
     return out
 
 
@@ -204,9 +235,10 @@ def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=No
     if groups * rows_per_group < rows or b.numel() != w.numel():
         raise ValueError("affine groups do not cover the rows")
     out = torch.empty(shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    rc = lib.svps_row_ln(_ptr(x), _ptr(pre), _ptr(post), _ptr(w), _ptr(b), float(eps), int(bool(relu)), rows,
-                         rows_per_group, D_MODEL, _ptr(None if out_bf16 else out), _ptr(out if out_bf16 else None),
-                         _stream_ptr())
+    with _on(x, pre, post, w, b) as ctx:
+        rc = lib.svps_row_ln(_ptr(x), _ptr(pre), _ptr(post), _ptr(w), _ptr(b), float(eps), int(bool(relu)), rows,
+                             rows_per_group, D_MODEL, _ptr(None if out_bf16 else out), _ptr(out if out_bf16 else None),
+                             ctx.stream)
     _lib.check(rc, "svps_row_ln")
     return out
 

@@ -28,8 +28,9 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
+        if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
+            torch.cuda.set_device(local_rank)            # also for gloo ranks that compute on a GPU
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
@@ -75,3 +76,97 @@ def merge_clip_results(gathered, n_clips, world):
             if c < n_clips:
                 merged[c] = block[j]
     return merged
+
+
+# ---------------------------------------------------------------------------------------------------
+# Per-clip result gather, overlapped with the next clip
+# ---------------------------------------------------------------------------------------------------
+def clip_result_template(T, H, W, device, max_segments=100):
+    """Tensors a rank ships per clip: the harness' per-frame outputs as it stores them (tools/test_vpq.py:44-46 casts
+    `panoptic_outputs` / `fcn_outputs` to uint8) plus up to `max_segments` (class, probability, object id) triples per
+    frame and their count."""
+    return {"panoptic_outputs": torch.zeros((T, H, W), dtype=torch.uint8, device=device),
+            "fcn_outputs": torch.zeros((T, H, W), dtype=torch.uint8, device=device),
+            "segments": torch.zeros((T, max_segments, 3), dtype=torch.float32, device=device),
+            "num_segments": torch.zeros((T,), dtype=torch.int32, device=device)}
+
+
+def pack_clip_result(frame_dicts, template):
+    """Result dicts of `VPS_Temporal_Slots.clip_test` (one per frame) -> the fixed-shape tensors of `clip_result_template`."""
+    out = {k: torch.zeros_like(v) for k, v in template.items()}
+    for t, r in enumerate(frame_dicts):
+        out["panoptic_outputs"][t].copy_(r["panoptic_outputs"][0].to(torch.uint8))
+        out["fcn_outputs"][t].copy_(r["fcn_outputs"][0].to(torch.uint8))
+        n = min(len(r["panoptic_cls_inds"]), out["segments"].shape[1])
+        out["num_segments"][t] = n
+        if n:
+            seg = torch.stack([torch.as_tensor(r["panoptic_cls_inds"][:n]).float(), torch.as_tensor(r["panoptic_cls_prob"][:n]).float(),
+                               torch.as_tensor(r["panoptic_det_obj_ids"][:n]).float()], dim=1)
+            out["segments"][t, :n].copy_(seg)
+    return out
+
+
+class ClipResultGatherer:
+    """Gathers a fixed set of result tensors to rank 0 once per clip (or per step), WITHOUT stopping the compute stream:
+    `submit` copies the results into one of `depth` staging sets on the caller's stream, then issues the gathers
+    asynchronously behind an event on a side stream (RCCL runs them on its own stream; rank 0 receives from every peer
+    over that peer's direct xGMI link); the caller goes on with the next clip and a staging set is only waited for when
+    it comes round again. `drain` waits for everything in flight. No collective touches the data path of the kernels.
+
+    Single process (world 1): the staging copy is the whole operation."""
+
+    def __init__(self, template, depth=2):
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.names = sorted(template)
+        self.depth = max(1, depth)
+        self.device = next(iter(template.values())).device
+        self.stage = [{k: torch.empty_like(template[k]) for k in self.names} for _ in range(self.depth)]
+        self.recv = None
+        if self.world > 1 and self.rank == 0:
+            self.recv = [{k: [torch.empty_like(template[k]) for _ in range(self.world)] for k in self.names}
+                         for _ in range(self.depth)]
+        self.pending = [[] for _ in range(self.depth)]
+        self.n = 0
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.bytes_per_submit = sum(t.numel() * t.element_size() for t in template.values())
+
+    def _wait(self, d):
+        for w in self.pending[d]:
+            w.wait()
+        self.pending[d] = []
+
+    def submit(self, tensors):
+        """tensors: name -> tensor shaped like the template. Returns the staging index used."""
+        d = self.n % self.depth
+        self.n += 1
+        self._wait(d)                                     # this staging set was handed to a gather `depth` submits ago
+        st = self.stage[d]
+        for k in self.names:
+            st[k].copy_(tensors[k], non_blocking=True)
+        if self.world == 1:
+            return d
+        if self.cuda:
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
+            ctx = torch.cuda.stream(self.side)
+        else:
+            import contextlib
+            ctx = contextlib.nullcontext()
+        with ctx:
+            for k in self.names:
+                gl = self.recv[d][k] if self.rank == 0 else None
+                self.pending[d].append(dist.gather(st[k], gather_list=gl, dst=0, async_op=True))
+        return d
+
+    def drain(self):
+        for d in range(self.depth):
+            self._wait(d)
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+
+    def last(self, d):
+        """Rank 0, after the staging set `d` has been waited for: name -> list over ranks of the gathered tensors."""
+        if self.world == 1:
+            return {k: [self.stage[d][k]] for k in self.names}
+        return self.recv[d] if self.rank == 0 else None

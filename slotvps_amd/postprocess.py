@@ -22,8 +22,7 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+from .ops import _on
 
 
 class PostProcessPanopticInstances(nn.Module):
@@ -57,8 +56,9 @@ class PostProcessPanopticInstances(nn.Module):
         cand = torch.empty((H * W, 2), dtype=torch.uint8, device=dev)
         counts = torch.zeros(K, dtype=torch.int32, device=dev)
         pairs = torch.zeros((K, K), dtype=torch.int32, device=dev)
-        _lib.check(lib.svps_panoptic_candidates(_p(m_sorted), _p(thing_u8), K, h, w, H, W, float(self.pixel_threshold),
-                                                _p(cand), _p(counts), _p(pairs), _stream()), "svps_panoptic_candidates")
+        with _on(m_sorted, thing_u8, cand, counts, pairs) as ctx:
+            _lib.check(lib.svps_panoptic_candidates(_p(m_sorted), _p(thing_u8), K, h, w, H, W, float(self.pixel_threshold),
+                                                    _p(cand), _p(counts), _p(pairs), ctx.stream), "svps_panoptic_candidates")
         return cand, counts, pairs
 
     @staticmethod
@@ -74,8 +74,9 @@ class PostProcessPanopticInstances(nn.Module):
         ids = torch.empty(H * W, dtype=torch.uint8, device=dev) if want_ids else None
         hist = torch.zeros(256, dtype=torch.int32, device=dev) if want_hist else None
         masks = torch.empty((n, H, W), dtype=torch.float32, device=dev) if want_masks else None
-        _lib.check(lib.svps_panoptic_argmax(_p(m_sorted), _p(t_sel), _p(t_thing), n, _p(kept_u8), _p(cand), _p(t_lut),
-                                            h, w, H, W, _p(ids), _p(hist), _p(masks), _stream()), "svps_panoptic_argmax")
+        with _on(m_sorted, t_sel, t_thing, kept_u8, cand, t_lut, ids, hist, masks) as ctx:
+            _lib.check(lib.svps_panoptic_argmax(_p(m_sorted), _p(t_sel), _p(t_thing), n, _p(kept_u8), _p(cand), _p(t_lut),
+                                                h, w, H, W, _p(ids), _p(hist), _p(masks), ctx.stream), "svps_panoptic_argmax")
         return ids, hist, masks
 
     # ---- the reference's forward, on tensors ---------------------------------------------------------

@@ -63,3 +63,74 @@ def test_single_process_helpers():
     assert parallel.max_over_ranks(3.5, torch.device("cpu")) == 3.5
     merged = parallel.merge_clip_results([torch.tensor([[0], [2]]), torch.tensor([[1], [9]])], 3, 2)
     assert [int(m) for m in merged] == [0, 1, 2]
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from slotvps_amd import parallel
+    parallel.init_distributed(backend="gloo")
+    T, H, W = 3, 16, 32
+    tmpl = parallel.clip_result_template(T, H, W, torch.device("cpu"), max_segments=100)
+    gat = parallel.ClipResultGatherer(tmpl, depth=2)
+    last = None
+    for clip in range(5):                               # five clips per rank, two staging sets: sets are reused
+        frames = []
+        for t in range(T):
+            k = (rank + clip + t) % 4
+            frames.append({"panoptic_outputs": torch.full((1, H, W), 10 * rank + clip, dtype=torch.int64),
+                           "fcn_outputs": torch.full((1, H, W), t, dtype=torch.int64),
+                           "panoptic_cls_inds": torch.arange(1, k + 1), "panoptic_cls_prob": torch.full((k,), 0.9),
+                           "panoptic_det_obj_ids": torch.arange(k) + 100 * rank})
+        last = gat.submit(parallel.pack_clip_result(frames, tmpl))
+    gat.drain()
+    if rank == 0:
+        got = gat.last(last)
+        q.put({"pan": [int(got["panoptic_outputs"][r][0, 0, 0]) for r in range(world)],
+               "fcn": [int(got["fcn_outputs"][r][2, 0, 0]) for r in range(world)],
+               "nseg": [got["num_segments"][r].tolist() for r in range(world)],
+               "ids": [got["segments"][r][2, :, 2].tolist()[:3] for r in range(world)],
+               "bytes": gat.bytes_per_submit})
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_per_clip_gather_overlapped_two_ranks():
+    """SURVEY 8e payload (uint8 panoptic + semantic maps [T, H, W] and <= 100 (class, prob, id) triples per frame),
+    gathered once per clip through the double-buffered asynchronous gatherer."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert out["pan"] == [4, 14] and out["fcn"] == [2, 2]                  # the LAST clip (index 4) of each rank
+    assert out["nseg"] == [[(0 + 4 + t) % 4 for t in range(3)], [(1 + 4 + t) % 4 for t in range(3)]]
+    assert out["ids"][1][:3] == [100.0, 101.0, 102.0]                       # rank 1, frame 2: k = (1 + 4 + 2) % 4 = 3 segments
+    assert out["bytes"] == 3 * 16 * 32 * 2 + 3 * 100 * 3 * 4 + 3 * 4
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` (no torch.distributed environment) must start two ranks, report n_gpus = 2 from rank 0 and
+    exit 0; a WORLD_SIZE that contradicts --gpus must be refused. Rehearsed with --dry-run-cpu (gloo, no kernels)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["gather_ok"] is True and line["steps"] == 4
+    env["WORLD_SIZE"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "refusing" in r.stderr
