@@ -63,6 +63,37 @@ def parse():
     return ap.parse_args()
 
 
+def note(msg):
+    """Progress on stderr (a silent leg of several minutes looks hung to the GPU runner)."""
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota where one is set (a box that
+    shows 128 logical CPUs but grants 16 would be timed 8x oversubscribed otherwise)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota = txt[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                    period = float(fh2.read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(a):
     """the PyTorch-CPU restatement of the slot head + mask decode (oracle/torch_cpu_head.py; the
     reference's own files do not travel) on the host cores of this box: one T-frame clip per iteration, fp32,
@@ -73,11 +104,7 @@ def cpu_baseline(a):
     from oracle import slotvps_oracle as orc
     from oracle.torch_cpu_head import TorchCpuHead
     from slotvps_amd import synth
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
+    cores = host_cores()
     params = synth.make_params(synth.head_shapes(), 0)
     head = TorchCpuHead(params)
     sizes = synth.level_sizes(a.height, a.width)
@@ -93,19 +120,23 @@ def cpu_baseline(a):
         for t in range(T):
             TorchCpuHead.mask_decode(fused[t][3], embeds[t][-1], scale, shift, 0.1, 0.0).argmax(0)
 
-    def timed(n_threads, budget, lo, hi):
+    def timed(n_threads, budget, lo, hi, warm):
         torch.set_num_threads(n_threads)
-        clip()                                                    # warm-up
         ts, t_all = [], time.perf_counter()
+        if warm:
+            clip()
+            note(f"cpu_baseline: warm-up clip at {n_threads} threads took {time.perf_counter() - t_all:.1f} s")
+        t_all = time.perf_counter()
         while len(ts) < hi and (len(ts) < lo or time.perf_counter() - t_all < budget):
             t0 = time.perf_counter()
             clip()
             ts.append(time.perf_counter() - t0)
+            note(f"cpu_baseline: clip {len(ts)} at {n_threads} threads: {ts[-1]:.2f} s")
         return ts
 
     keep = torch.get_num_threads()
-    ts = timed(cores, a.cpu_seconds * 0.6, 3, 10)
-    ts8 = timed(min(8, cores), 0.0, 1, 1)
+    ts = timed(cores, a.cpu_seconds, 2, 10, True)
+    ts8 = timed(min(8, cores), 0.0, 1, 1, False)
     torch.set_num_threads(keep)
     med = statistics.median(ts)
     return {"value": round(T / med, 4), "unit": "frames/s", "cores": int(cores), "kind": "port",
@@ -299,6 +330,8 @@ def main():
         got = gatherers[0].last((gatherers[0].n - 1) % gatherers[0].depth)
         assert len(got["slot_argmax"]) == world and got["slot_argmax"][0].shape == tmpl["slot_argmax"].shape
 
+    if rank == 0:
+        note(f"timed region done: {elapsed / max(1, a.steps) * 1e3:.2f} ms per step; roofline leg ...")
     # ------------------- roofline leg: same steps, eager, HIP events around every launch --------------
     roof = None
     if rank == 0:
@@ -379,8 +412,10 @@ def main():
             "roofline": roof,
         }
         if a.cpu_baseline and world == 1:
+            note("cpu_baseline leg (PyTorch CPU restatement, bounded sample) ...")
             line["cpu_baseline"] = cpu_baseline(a)
         if a.whole_detector and world == 1:
+            note("whole_detector leg (informational) ...")
             try:
                 line["whole_detector"] = whole_detector_leg(a, dev)
             except Exception as e:                       # informational leg: never costs the bench line

@@ -47,7 +47,10 @@ extern "C" {
 #define SVPS_KERNEL_LEVEL_FUSE 5
 #define SVPS_KERNEL_PANOPTIC_POST 6
 #define SVPS_KERNEL_DEFORM_CONV 7
-#define SVPS_KERNEL_COUNT 8
+#define SVPS_KERNEL_RETR_STATS 8
+#define SVPS_KERNEL_RETR_ATTN 9
+#define SVPS_KERNEL_RETR_FINISH 10
+#define SVPS_KERNEL_COUNT 11
 
 int svps_abi_version(void);
 
@@ -209,6 +212,66 @@ int svps_prof_collect(int kernel_id, double* total_ms, int* launches);
  * ------------------------------------------------------------------------------------------- */
 int svps_probe_mfma(const void* a, const void* b, float* c, void* stream);
 int svps_probe_tile(const void* x, void* rows, void* cols, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Statistics-fused retriever (K3' + K1'): MaskDynamicConv.forward (dynamic_mask_head.py:423-461) without k / v tensors.
+ * Both pixel-side LayerNorms are "one scalar per pixel times an affine map":
+ *     norm_k(to_k(x_p)) = gamma_k * rstd_k(p) * (W~_k x_p + b~_k) + beta_k,   W~ = (I - 11^T / 256) W,  b~ = b - mean(b)
+ * so the pixel side only has to produce rstd_k(p), rstd_v(p) (svps_retr_stats_fwd), the key projection is folded into the
+ * queries and the value projection is applied after the pixel sum (svps_retr_attn_fwd + a [L, 264] x [264, 256] product on the
+ * slot side). The fused map is read once per kernel; nothing of size [HW, 256] is written.
+ *
+ * svps_retr_stats_fwd   (:432-433, the LayerNorm statistics only)
+ *   feat  [T, HW, 256] bf16 fused map; pos_y [H, 128] / pos_x [W, 128] fp32 separable sine tables or NULL
+ *   rk, rv [256, 256] bf16: the UPPER-TRIANGULAR factor R of  [W~ | b~] = Q [R | r]  for to_k / to_v (host, float64 QR);
+ *   rbk, rbv [256] fp32: the column r.   |R x + r|^2 = |W~ x + b~|^2 = 256 * var.
+ *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] bf16 = {1, hi(1/rstd_v), lo(1/rstd_v), 0 ...}
+ *
+ * svps_retr_attn_fwd    (:435-456)
+ *   qh, ql [T, 128, 256] bf16: hi / lo halves of Q'' = (q * gamma_k) W~_k, rows >= L zero   (q = norm_q(to_q(slots)), :431)
+ *   cy [T, H, 128], cx [T, W, 128] fp32: Q''[:, :128] . pos_y[y] + (q * gamma_k) . b~_k  and  Q''[:, 128:] . pos_x[x]
+ *   c3 [T, 128] fp32: q . beta_k
+ *   out_ext [T, L, 264] fp32: { A_l = sum_p P rstd_v f_p (256), s1_l = sum_p P rstd_v, s0_l = sum_p P, 0 x 6 };
+ *       pre-LayerNorm output (:456) = out_ext @ [ (gamma_v * W~_v)^T ; gamma_v * b~_v ; beta_v ; 0 ]
+ *   1 <= L <= 128; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 264] fp32
+ * ------------------------------------------------------------------------------------------- */
+int svps_retr_stats_fwd(const void* feat, const float* pos_y, const float* pos_x, const void* rk, const float* rbk,
+                        float lnk_eps, const void* rv, const float* rbv, float lnv_eps, float* rstd_k, float* rstd_v,
+                        void* aux, int T, int H, int W, int D, void* stream);
+size_t svps_retr_attn_workspace_bytes(int T, int L, int HW, int chunks);
+int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
+                       const void* feat, const float* rstd_k, const float* rstd_v, const void* aux, void* workspace,
+                       size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Exact mode: fp32 storage and fp32 arithmetic for the whole pixel side (slotvps_amd/csrc/exact_f32.hip).
+ * The reference runs this path in fp32 (fp16_enabled = False, mmdet/models/detectors/vps_temporal_slots.py:55);
+ * these entry points take and return `float` where their bf16 counterparts above take bf16, round nothing
+ * below fp32, and exist so that the head can be compared free-running with the reference's fp32 outputs.
+ * Same layouts (pixel-major [T, HW, 256]), same argument meaning, same error codes.
+ *
+ *   svps_level_fuse_f32_fwd    = svps_level_fuse_fwd    (dynamic_mask_head.py:171-188)
+ *        cur [T, 128, H, W] fp32 NCHW; prev [T, (H/2)(W/2), 256] fp32 or NULL (level 0);
+ *        wT [384, 256] fp32 = conv_trans.conv.weight[256, 384, 1, 1] TRANSPOSED; bc [256]; out [T, HW, 256] fp32
+ *   svps_kv_project_f32_fwd    = svps_kv_project_fwd    (dynamic_mask_head.py:428-433)
+ *        feat [T, HW, 256] fp32; wkT / wvT [256 in, 256 out] fp32 = to_k / to_v weight TRANSPOSED; k_out / v_out fp32
+ *   svps_slot_attn_f32_fwd     = svps_slot_attn_fwd     (dynamic_mask_head.py:435-459); q, k, v fp32
+ *        workspace: svps_slot_attn_f32_workspace_bytes(T, L, HW)
+ *   svps_mask_decode_f32_fwd   = svps_mask_decode_fwd   (vps_temporal_slots.py:144-160); feat fp32, out [T, L, HW] fp32
+ * ------------------------------------------------------------------------------------------- */
+int svps_level_fuse_f32_fwd(const float* cur, const float* prev, const float* wT, const float* bc, float* out, int T,
+                            int H, int W, void* stream);
+int svps_kv_project_f32_fwd(const float* feat, const float* pos_y, const float* pos_x, const float* wkT,
+                            const float* bk, const float* lnk_w, const float* lnk_b, float lnk_eps, const float* wvT,
+                            const float* bv, const float* lnv_w, const float* lnv_b, float lnv_eps, float* k_out,
+                            float* v_out, int T, int H, int W, int D, void* stream);
+size_t svps_slot_attn_f32_workspace_bytes(int T, int L, int HW);
+int svps_slot_attn_f32_fwd(const float* q, const float* k, const float* v, const float* ln_w, const float* ln_b,
+                           float ln_eps, void* workspace, size_t workspace_bytes, float* out, float* out_pre_ln, int T,
+                           int L, int HW, int D, void* stream);
+int svps_mask_decode_f32_fwd(const float* feat, const float* embed, const float* bn_scale, const float* bn_shift,
+                             float fg_scale, float fg_shift, float* out, int T, int L, int HW, int D, void* stream);
 
 #ifdef __cplusplus
 }

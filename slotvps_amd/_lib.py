@@ -22,6 +22,9 @@ KERNEL_KV_PROJECT = 4
 KERNEL_LEVEL_FUSE = 5
 KERNEL_PANOPTIC_POST = 6
 KERNEL_DEFORM_CONV = 7
+KERNEL_RETR_STATS = 8
+KERNEL_RETR_ATTN = 9
+KERNEL_RETR_FINISH = 10
 
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
@@ -43,6 +46,15 @@ SIGNATURES = {
     "svps_panoptic_argmax": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "svps_deform_im2col": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "svps_deform_im2col_bf16": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
+    "svps_retr_stats_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "svps_retr_attn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "svps_retr_attn_fwd": (_i, [_vp] * 10 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "svps_level_fuse_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "svps_kv_project_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp,
+                                     _i, _i, _i, _i, _vp]),
+    "svps_slot_attn_f32_workspace_bytes": (_sz, [_i, _i, _i]),
+    "svps_slot_attn_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "svps_mask_decode_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _i, _vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

@@ -1,0 +1,447 @@
+// K1' - statistics-fused slot <-> pixel retriever for gfx950: reads the fused feature map ONCE per stage, no k / v tensors.
+//
+// MaskDynamicConv.forward (mmdet/models/detectors/dynamic_mask_head.py:423-461), with both pixel-side LayerNorms written
+// as "one scalar per pixel times an affine map" (see retr_stats.hip for rstd_k, rstd_v and the centred weights W~, b~):
+//
+//   logits (:435)   S[l, p] = q_l . k_p = rstd_k(p) * ( Q''_l . f_p + Q''_l . pos_p + a'_l ) + c3_l
+//                       Q''_l = W~_k^T (q_l * gamma_k)   a'_l = (q_l * gamma_k) . b~_k   c3_l = q_l . beta_k
+//                   pos is separable (position_encoding.py:251-255): Q''_l . pos_p = Cy[y(p), l] + Cx[x(p), l], two small
+//                   fp32 tables per frame and stage (a' folded into Cy) - the position term never passes through bf16
+//   softmax (:446)  over the SLOT axis, per pixel (no cross-tile state)
+//   attn.v  (:456)  o_l = sum_p P[l, p] v_p = gamma_v * ( W~_v A_l + b~_v s1_l ) + beta_v s0_l
+//                       A_l = sum_p P rstd_v f_p    s1_l = sum_p P rstd_v    s0_l = sum_p P
+//                   this kernel accumulates A (and s1, s0 through a ninth "aux" channel block, retr_stats.hip); the
+//                   256 x 256 product with W~_v, norm1 and ReLU (:458-459) follow on [L, 256] tensors (slot side).
+//
+// Q'' is carried as bf16 hi + lo (16-bit mantissa), P * rstd_v as bf16 hi + lo, f is the stored bf16 map itself: the only
+// roundings are those two splits, fp32 accumulation and v_exp_f32. Against a float64 evaluation of the reference formulas
+// on the same bf16 map the slot update agrees to ~2e-4 (bf16 k / v: 1.2e-1).
+//
+// Structure = the wave-specialised K1 (slot_attn.hip): 8 waves, producers 0-3 / consumers 4-7, one producer and one
+// consumer per SIMD, two barriers per tile, LDS-DMA ring three tiles ahead.
+//   producer sb: logits of slot block sb: 16 + 16 MFMA (Q'' hi, lo) on the row fragments of f(i); + position terms
+//       (per-lane loads from the two tables, L2-resident); * rstd_k + c3; softmax statistics exchange; P * rstd_v -> LDS
+//   consumer sb: A[sb, 0:256] += P(i-1) f(i-1) and the aux block: 36 MFMA per tile (hi + lo); all LDS-DMA
+// LDS: feature ring 5 x 16 KiB, aux ring 5 x 2 KiB, P ring 2 x 16 KiB (P can no longer overwrite a dead key tile: the
+// feature tile is still needed as the value operand).
+#include <stdlib.h>
+
+#include "common.h"
+#include "../../include/slotvps_hip.h"
+
+namespace svps {
+
+constexpr int kRPrefetch = 3;
+constexpr int kRNF = kRPrefetch + 2;       // feature / aux ring depth
+constexpr int kAuxRow = 64;                // bytes per pixel of the aux tensor (32 bf16)
+constexpr int kAuxTile = kTilePx * kAuxRow;
+constexpr int kPartRow = 264;              // floats per slot row of a partial: 256 channels of A + 8 aux columns
+
+struct RetrLds {
+    static constexpr int fring = 0;
+    static constexpr int aring = kRNF * kTileBytes;
+    static constexpr int pring = aring + kRNF * kAuxTile;       // [2][hi 8 KiB | lo 8 KiB], slot block sb at sb * 2 KiB
+    static constexpr int stats = pring + 2 * kTileBytes;        // [4][32] float2
+    static constexpr int c3 = stats + 4 * 32 * 8;               // [128] float
+    static constexpr int total = c3 + 128 * 4;
+};
+
+__device__ __forceinline__ u32x4 ra_make_srd(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+    d[2] = __builtin_amdgcn_readfirstlane(bytes);
+    d[3] = 0x00020000u;
+    return d;
+}
+
+// asm LDS-DMA with the non-temporal hint (the map is read once per launch); see slot_attn.hip for why this is asm
+__device__ __forceinline__ void ra_dma16(u32x4 srd, uint32_t lds_addr, int voff, int soff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+        : "memory");
+}
+
+__device__ __forceinline__ float ra_half_swap_max(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float ra_half_swap_sum(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// aux tile: 32 pixel rows of 64 B, linear. B fragment of its 32 columns for k-step ks (pixels 16 ks .. + 16)
+__device__ __forceinline__ bf16x8 read_col_frag_aux(const char* at, int ks, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int row0 = 16 * ks + 8 * (g >> 1) + q;
+    const int off = (2 * (g & 1) + (p >> 1)) * 16 + 8 * (p & 1);
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(at + row0 * kAuxRow + off));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(at + (row0 + 4) * kAuxRow + off));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ABL: timing-only ablations (env SVPS_RETR_ABLATE), outputs wrong. 1: DMA + barriers only  2: producers only  4: consumers only
+template <int ABL = 0>
+__global__ __launch_bounds__(512) void retr_attn_kernel(
+    const __bf16* __restrict__ qh,      // [T, 128, 256]  hi(Q''), rows >= L zero
+    const __bf16* __restrict__ ql,      // [T, 128, 256]  lo(Q'')
+    const float* __restrict__ cy,       // [T, H, 128]    Q''[:, 0:128] . ytab[y] + a'
+    const float* __restrict__ cx,       // [T, W, 128]    Q''[:, 128:256] . xtab[x]
+    const float* __restrict__ c3g,      // [T, 128]
+    const __bf16* __restrict__ feat,    // [T, HW, 256]
+    const float* __restrict__ rstd_k,   // [T, HW]
+    const float* __restrict__ rstd_v,   // [T, HW]
+    const __bf16* __restrict__ aux,     // [T, HW, 32]
+    float* __restrict__ partial,        // [T, C, L, 264]
+    int L, int HW, int H, int W, float inv_w, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = RetrLds;
+    constexpr int A = kRPrefetch;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sb = w & 3;
+    const bool consumer = w >= 4;
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x, C = gridDim.x;
+
+    const int px_begin = c * tiles_per_chunk * kTilePx;
+    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    px_end = px_end < HW ? px_end : HW;
+    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+
+    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+    float* c3l = reinterpret_cast<float*>(smem + Lds::c3);
+    if (threadIdx.x < 128) c3l[threadIdx.x] = c3g[(size_t)t * 128 + threadIdx.x];
+
+    if (!consumer) {
+        // ================================ producer =============================================
+        bf16x8 qfh[16], qfl[16];
+        {
+            const size_t row = ((size_t)t * 128 + 32 * sb + r) * kD + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                qfh[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
+                qfl[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
+            }
+        }
+        const int slot0 = 32 * sb + 4 * h;
+        const int key = (r >> 1) & 3;
+        // tables through buffer descriptors (scalar registers) + 32-bit lane offsets: no 64-bit pointers in vector registers
+        auto uniform_rsrc = [](const void* p, int bytes) {          // every word provably wave-uniform: no waterfall loops
+            const uint64_t a = reinterpret_cast<uint64_t>(p);
+            const uint64_t u = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)a);
+            return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * 128, H * 512);
+        const __amdgpu_buffer_rsrc_t cxr = uniform_rsrc(cx + (size_t)t * W * 128, W * 512);
+        const __amdgpu_buffer_rsrc_t rkr = uniform_rsrc(rstd_k + (size_t)t * HW, HW * 4);
+        const __amdgpu_buffer_rsrc_t rvr = uniform_rsrc(rstd_v + (size_t)t * HW, HW * 4);
+        // Position terms and statistics of this lane's pixel of tile `tile` (L2-resident tables): requested one tile ahead,
+        // right after the MFMA chain (its fragment registers are free then), summed at the end of the iteration into the
+        // INITIAL value of the next tile's accumulator.
+        f32x4 cyv[4], cxv[4];
+        float rk_n, tau_n;
+        auto request = [&](int tile) {
+            int px = px_begin + tile * kTilePx + r;
+            px = px < HW ? px : HW - 1;
+            int yy = (int)((float)px * inv_w);
+            int xx = px - yy * W;
+            if (xx < 0) { xx += W; --yy; }
+            if (xx >= W) { xx -= W; ++yy; }
+            const int yo = (yy * 128 + slot0) * 4, xo = (xx * 128 + slot0) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                cyv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
+                cxv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cxr, xo + 32 * g, 0, 0));
+            }
+            rk_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rkr, px * 4, 0, 0));
+            tau_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvr, px * 4, 0, 0));
+        };
+        f32x16 cinit;
+        float rk, tau;
+        auto settle = [&]() {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cinit[4 * g + j] = cyv[g][j] + cxv[g][j];
+            rk = rk_n;
+            tau = tau_n;
+        };
+        request(0);
+        settle();
+        for (int it = 0; it <= nt; ++it) {
+            wg_barrier();                                        // B_top(it)
+            if (it == nt || ABL == 1 || ABL == 4) { wg_barrier(); continue; }
+            const char* kt = smem + Lds::fring + (it % kRNF) * kTileBytes;
+            int rr = r, hh = h;
+            asm volatile("" : "+v"(rr), "+v"(hh));              // opaque per iteration: no hoisted fragment address tables
+            const bool live = px_begin + it * kTilePx + r < px_end;
+            f32x16 s = cinit;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {              // fragments in two batches of eight (register budget)
+                bf16x8 kf[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kf[u] = read_row_frag(kt, 8 * half + u, rr, hh);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[8 * half + u], kf[u], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[8 * half + u], kf[u], s, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float rk_c = rk, tau_c = tau;
+            if (it + 1 < nt) request(it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // S = rstd_k * (Q''.f + Cy + Cx) + c3 ; rows past L -> -inf
+            float mloc = kNegBig;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 c3v = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = slot0 + j + 8 * g < L;
+                    const float v = fmaf(rk_c, s[4 * g + j], c3v[j]);
+                    s[4 * g + j] = ok ? v : kNegBig;
+                    mloc = fmaxf(mloc, s[4 * g + j]);
+                }
+            }
+            mloc = ra_half_swap_max(mloc);
+            float sloc = 0.f;
+            const float mneg = -mloc * kLog2e;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[i], kLog2e, mneg));
+                s[i] = ok ? e : 0.f;
+                sloc += s[i];
+            }
+            sloc = ra_half_swap_sum(sloc);
+            if (h == 0) stats[sb * 32 + r] = make_float2(mloc, sloc);
+            wg_barrier();                                        // B_stats(it)
+            float mall = kNegBig;
+            float2 st_w[4];
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                st_w[ww] = stats[ww * 32 + r];
+                mall = fmaxf(mall, st_w[ww].x);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww)
+                den += st_w[ww].y * __builtin_amdgcn_exp2f((st_w[ww].x - mall) * kLog2e);
+            float fac = __builtin_amdgcn_exp2f((mloc - mall) * kLog2e) / den * tau_c;    // P * rstd_v
+            if (!live) fac = 0.f;                                                       // pixels past the chunk / frame
+            char* prow = smem + Lds::pring + (it & 1) * kTileBytes + sb * 2048 + r * 64 + 8 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = s[4 * g + j] * fac;
+                    ph[j] = (__bf16)p;
+                    pl[j] = (__bf16)(p - (float)ph[j]);
+                }
+                *reinterpret_cast<bf16x4*>(prow + ((g ^ key) * 16)) = ph;
+                *reinterpret_cast<bf16x4*>(prow + 8192 + ((g ^ key) * 16)) = pl;
+            }
+            if (it + 1 < nt) settle();
+        }
+        return;
+    }
+
+    // =================================== consumer ===============================================
+    const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 ars = ra_make_srd(aux + (size_t)t * HW * 32, (uint32_t)HW * kAuxRow);
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * sb + 2 * i + h;
+        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+    }
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+    const int nb = 4 + (sb < 2 ? 1 : 0);                        // DMA instructions of one batch of this wave
+    auto issue_batch = [&](int b) {
+        if (b >= nt) return;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % kRNF) * kTileBytes + sb * 4 * 1024);
+        const int px0 = px_begin + b * kTilePx;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + kTilePx <= HW) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra_dma16(frs, st + i * 1024, voff[i], soff);
+        } else {                                                 // ragged last tile of the frame: clamp the source rows (their P is 0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * sb + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+            }
+        }
+        if (sb < 2) {                                            // aux tile: two 1-KiB pieces; rows past the frame read zeros (range check on voff)
+            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % kRNF) * kAuxTile + sb * 1024);
+            ra_dma16(ars, sa, px0 * kAuxRow + sb * 1024 + lane * 16, 0);
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < A; ++b) issue_batch(b);
+
+    f32x16 o[8], oa;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        oa[i] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[db][i] = 0.f;
+    }
+    auto pv_step = [&](const char* pt, const char* vt, const char* at, int ks) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                            // opaque per call: no hoisted address tables
+        const int g2 = ln >> 4, ii = ln & 15, qq = ii >> 2, pp = ii & 3;
+        const int pchunk = 2 * (g2 & 1) + (pp >> 1);
+        const int px0 = 16 * ks + 8 * (g2 >> 1) + qq;
+        const char* a0 = pt + sb * 2048 + 8 * (pp & 1) + px0 * 64 + ((pchunk ^ ((px0 >> 1) & 3)) * 16);
+        const char* a1 = pt + sb * 2048 + 8 * (pp & 1) + (px0 + 4) * 64 + ((pchunk ^ (((px0 + 4) >> 1) & 3)) * 16);
+        const bf16x8 ah = __builtin_shufflevector(
+            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)a0),
+            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)a1), 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 al = __builtin_shufflevector(
+            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(a0 + 8192)),
+            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(a1 + 8192)), 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 af = read_col_frag_aux(at, ks, ln);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bf16x8 vf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vf[u] = read_col_frag(vt, ks, 4 * half + u, ln);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vf[u], o[4 * half + u], 0, 0, 0);
+                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vf[u], o[4 * half + u], 0, 0, 0);
+            }
+            if (half == 0) {
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, af, oa, 0, 0, 0);
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, af, oa, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    for (int it = 0; it <= nt; ++it) {
+        // batch `it` (feature + aux tile it) landed for this wave: all but the A-1 younger batches
+        if (it + A - 1 < nt) wait_vm_dyn(nb * (A - 1));
+        else wait_vm<0>();
+        wg_barrier();                                            // B_top(it)
+        issue_batch(it + A);
+        const bool work = it >= 1 && ABL != 1 && ABL != 2;
+        const char* pt = smem + Lds::pring + ((it + 1) & 1) * kTileBytes;                 // P(it-1)
+        const char* vt = smem + Lds::fring + ((it + kRNF - 1) % kRNF) * kTileBytes;       // f(it-1)
+        const char* at = smem + Lds::aring + ((it + kRNF - 1) % kRNF) * kAuxTile;
+        if (work) pv_step(pt, vt, at, 0);
+        wg_barrier();                                            // B_stats(it)
+        if (work) pv_step(pt, vt, at, 1);
+    }
+
+    float* dst = partial + ((size_t)t * C + c) * L * kPartRow;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int slot = 32 * sb + acc_row(i, h);
+        if (slot < L) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db) dst[(size_t)slot * kPartRow + 32 * db + r] = o[db][i];
+            if (r < 8) dst[(size_t)slot * kPartRow + 256 + r] = oa[i];
+        }
+    }
+}
+
+// Sum of the C partials of every (frame, slot) row in chunk order (bitwise reproducible, no float atomics):
+// out row = { A[0:256], s1, s0, 0 x 6 }, the operand of the slot-side product with [ (gamma_v W~_v)^T ; gamma_v b~_v ; beta_v ].
+__global__ __launch_bounds__(256) void retr_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int L, int C) {
+    const int l = blockIdx.x, t = blockIdx.y, d = threadIdx.x;
+    const size_t cstride = (size_t)L * kPartRow;
+    const float* src = partial + ((size_t)t * C * L + l) * kPartRow;
+    auto colsum = [&](int col) {
+        const float* s = src + col;
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += s[(size_t)(c + u) * cstride];
+        }
+        for (int u = 0; c < C; ++c, ++u) a8[u] += s[(size_t)c * cstride];
+        return ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    };
+    float* o = out + ((size_t)t * L + l) * kPartRow;
+    o[d] = colsum(d);
+    if (d < 8) {
+        float v = 0.f;
+        if (d == 0) v = colsum(256);                         // s1 = sum_p P rstd_v
+        else if (d == 1) v = colsum(257) + colsum(258);      // s0 = sum_p P  (sigma_v carried as hi + lo)
+        o[256 + d] = v;
+    }
+}
+
+}  // namespace svps
+
+namespace {
+struct RetrPlan {
+    int chunks, tiles_per_chunk;
+};
+RetrPlan plan_retr(int T, int HW, int chunks_req) {
+    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+    int chunks = chunks_req;
+    if (chunks <= 0) chunks = svps_pick_chunks(T, tiles, svps_num_cus(), 64);
+    if (chunks > tiles) chunks = tiles;
+    const int tpc = (tiles + chunks - 1) / chunks;
+    chunks = (tiles + tpc - 1) / tpc;
+    return {chunks, tpc};
+}
+}  // namespace
+
+extern "C" size_t svps_retr_attn_workspace_bytes(int T, int L, int HW, int chunks) {
+    if (T <= 0 || L <= 0 || HW <= 0) return 0;
+    const RetrPlan p = plan_retr(T, HW, chunks);
+    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
+}
+
+extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
+                                  const void* feat, const float* rstd_k, const float* rstd_v, const void* aux,
+                                  void* workspace, size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D,
+                                  int chunks, void* stream_) {
+    if (!qh || !ql || !cy || !cx || !c3 || !feat || !rstd_k || !rstd_v || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
+    if (D != svps::kD || T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
+    const int HW = H * W;
+    const RetrPlan p = plan_retr(T, HW, chunks);
+    if (workspace_bytes < (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float)) return SVPS_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* partial = static_cast<float*>(workspace);
+    static const int ablate = [] { const char* a = getenv("SVPS_RETR_ABLATE"); return a ? atoi(a) : 0; }();
+    auto kern = svps::retr_attn_kernel<0>;
+    if (ablate == 1) kern = svps::retr_attn_kernel<1>;
+    else if (ablate == 2) kern = svps::retr_attn_kernel<2>;
+    else if (ablate == 4) kern = svps::retr_attn_kernel<4>;
+    static SvpsLdsAttr attr[4];
+    if (hipError_t ae = attr[ablate == 1 ? 1 : ablate == 2 ? 2 : ablate == 4 ? 3 : 0].ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess)
+        return (int)ae;
+    svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
+    hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, static_cast<const __bf16*>(qh),
+                       static_cast<const __bf16*>(ql), cy, cx, c3, static_cast<const __bf16*>(feat), rstd_k, rstd_v,
+                       static_cast<const __bf16*>(aux), partial, L, HW, H, W, 1.0f / (float)W, p.tiles_per_chunk);
+    svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 0, stream);
+    hipLaunchKernelGGL(svps::retr_finish_kernel, dim3(L, T), dim3(256), 0, stream, partial, out_ext, L, p.chunks);
+    svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 1, stream);
+    return (int)hipGetLastError();
+}

@@ -273,7 +273,8 @@ class VPS_Temporal_Slots(nn.Module):
         pos_tabs = [ops.pos_embed_sine_tables(f.shape[-2], f.shape[-1], D, f.device) for f in feats]
         logits, embeds, fused = im.dynamic_mask_head.forward_clip(feats, im.init_mask_query.weight, pos_tabs)
         scale, shift, fs, fb = self._decode_fold()
-        masks = ops.mask_decode(fused[-1], embeds[-1].contiguous(), scale, shift, fs, fb)
+        decode = ops.mask_decode_f32 if fused[-1].dtype == torch.float32 else ops.mask_decode     # exact mode: fp32 map
+        masks = decode(fused[-1], embeds[-1].contiguous(), scale, shift, fs, fb)
         h, w = feats[-1].shape[-2:]
         return logits[-1], embeds[-1], masks.view(masks.shape[0], masks.shape[1], h, w)
 

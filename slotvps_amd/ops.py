@@ -243,6 +243,161 @@ def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=No
     return out
 
 
+# ---- statistics-fused retriever (csrc/retr_stats.hip, csrc/retr_attn.hip) -------------------------------------------
+def retr_stats(feat, H, W, pos_tabs, rk, rbk, eps_k, rv, rbv, eps_v):
+    """K3': per-pixel reciprocal standard deviations of the key / value LayerNorms (+ the aux rows K1' consumes).
+    feat [T, H*W, 256] bf16; rk / rv [256, 256] bf16 upper-triangular QR factors of the centred projections; rbk / rbv [256]
+    fp32. Returns rstd_k [T, HW], rstd_v [T, HW] fp32, aux [T, HW, 32] bf16."""
+    lib = _lib.load()
+    _need(feat, "feat", torch.bfloat16, 3)
+    T, HW, D = feat.shape
+    if HW != H * W:
+        raise ValueError("feat rows != H*W")
+    for name, x in (("rk", rk), ("rv", rv)):
+        _need(x, name, torch.bfloat16, 2)
+        if x.shape != (D, D):
+            raise ValueError(f"{name} must be [256, 256]")
+    _need(rbk, "rbk", torch.float32, 1)
+    _need(rbv, "rbv", torch.float32, 1)
+    ytab = xtab = None
+    if pos_tabs is not None:
+        ytab, xtab = pos_tabs
+        _need(ytab, "pos_y", torch.float32, 2)
+        _need(xtab, "pos_x", torch.float32, 2)
+        if ytab.shape != (H, D // 2) or xtab.shape != (W, D // 2):
+            raise ValueError("pos tables do not match (H, W)")
+    rstd_k = torch.empty((T, HW), dtype=torch.float32, device=feat.device)
+    rstd_v = torch.empty((T, HW), dtype=torch.float32, device=feat.device)
+    aux = torch.empty((T, HW, 32), dtype=torch.bfloat16, device=feat.device)
+    with _on(feat, ytab, xtab, rk, rbk, rv, rbv) as ctx:
+        rc = lib.svps_retr_stats_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(rk), _ptr(rbk), float(eps_k), _ptr(rv), _ptr(rbv),
+                                     float(eps_v), _ptr(rstd_k), _ptr(rstd_v), _ptr(aux), T, H, W, D, ctx.stream)
+    _lib.check(rc, "svps_retr_stats_fwd")
+    return rstd_k, rstd_v, aux
+
+
+def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
+    """K1': out_ext [T, L, 264] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
+    rstd_k (Q''.f + cy + cx) + c3. qh / ql [T, 128, 256] bf16, cy [T, H, 128], cx [T, W, 128], c3 [T, 128] fp32."""
+    lib = _lib.load()
+    _need(qh, "qh", torch.bfloat16, 3)
+    _need(ql, "ql", torch.bfloat16, 3)
+    _need(feat, "feat", torch.bfloat16, 3)
+    _need(aux, "aux", torch.bfloat16, 3)
+    for name, x in (("cy", cy), ("cx", cx)):
+        _need(x, name, torch.float32, 3)
+    for name, x in (("c3", c3), ("rstd_k", rstd_k), ("rstd_v", rstd_v)):
+        _need(x, name, torch.float32, 2)
+    T, HW, D = feat.shape
+    if (HW != H * W or qh.shape != (T, 128, D) or ql.shape != (T, 128, D) or cy.shape != (T, H, 128) or cx.shape != (T, W, 128)
+            or c3.shape != (T, 128) or rstd_k.shape != (T, HW) or rstd_v.shape != (T, HW) or aux.shape != (T, HW, 32)):
+        raise ValueError("shape mismatch")
+    if not 1 <= L <= 128:
+        raise ValueError("the fused retriever covers 1 <= L <= 128 slots")
+    ws_bytes = lib.svps_retr_attn_workspace_bytes(T, L, HW, chunks)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)
+    out = torch.empty((T, L, 264), dtype=torch.float32, device=feat.device)
+    with _on(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux) as ctx:
+        rc = lib.svps_retr_attn_fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(rstd_k), _ptr(rstd_v),
+                                    _ptr(aux), _ptr(ws), ws_bytes, _ptr(out), T, L, H, W, D, chunks, ctx.stream)
+    _lib.check(rc, "svps_retr_attn_fwd")
+    return out
+
+
+# ---- exact mode: fp32 storage, fp32 arithmetic (csrc/exact_f32.hip) ---------------------------------------------
+F32 = torch.float32
+
+
+def level_fuse_f32(cur, prev, wT, bc, H, W):
+    """Exact-mode K4: cur [T, 128, H, W] fp32, prev [T, (H/2)(W/2), 256] fp32 or None, wT [384, 256] fp32 (the 1x1 conv
+    weight transposed), bc [256] -> fused map [T, H*W, 256] fp32 (dynamic_mask_head.py:171-188)."""
+    lib = _lib.load()
+    _need(cur, "cur", F32, 4)
+    _need(wT, "wT", F32, 2)
+    _need(bc, "bc", F32, 1)
+    T = cur.shape[0]
+    if cur.shape != (T, 128, H, W) or wT.shape != (384, 256):
+        raise ValueError(f"cur {tuple(cur.shape)} / wT {tuple(wT.shape)}")
+    if prev is not None:
+        _need(prev, "prev", F32, 3)
+        if prev.shape != (T, (H // 2) * (W // 2), 256) or H % 2 or W % 2:
+            raise ValueError(f"prev {tuple(prev.shape)} does not match an {H}x{W} level")
+    out = torch.empty((T, H * W, 256), dtype=F32, device=cur.device)
+    with _on(cur, prev, wT, bc) as ctx:
+        _lib.check(lib.svps_level_fuse_f32_fwd(_ptr(cur), _ptr(prev), _ptr(wT), _ptr(bc), _ptr(out), T, H, W, ctx.stream),
+                   "svps_level_fuse_f32_fwd")
+    return out
+
+
+def kv_project_f32(feat, H, W, pos_tabs, wkT, bk, lnk_w, lnk_b, lnk_eps, wvT, bv, lnv_w, lnv_b, lnv_eps):
+    """Exact-mode K3: feat [T, H*W, 256] fp32, wkT / wvT [256, 256] fp32 TRANSPOSED Linear weights -> k, v fp32."""
+    lib = _lib.load()
+    _need(feat, "feat", F32, 3)
+    T, HW, D = feat.shape
+    if HW != H * W:
+        raise ValueError("feat rows != H*W")
+    for name, x in (("wkT", wkT), ("wvT", wvT)):
+        _need(x, name, F32, 2)
+    for name, x in (("bk", bk), ("lnk_w", lnk_w), ("lnk_b", lnk_b), ("bv", bv), ("lnv_w", lnv_w), ("lnv_b", lnv_b)):
+        _need(x, name, F32, 1)
+    ytab = xtab = None
+    if pos_tabs is not None:
+        ytab, xtab = pos_tabs
+        _need(ytab, "pos_y", F32, 2)
+        _need(xtab, "pos_x", F32, 2)
+        if ytab.shape != (H, D // 2) or xtab.shape != (W, D // 2):
+            raise ValueError("pos tables do not match (H, W)")
+    k = torch.empty_like(feat)
+    v = torch.empty_like(feat)
+    with _on(feat, ytab, xtab, wkT, bk, lnk_w, lnk_b, wvT, bv, lnv_w, lnv_b) as ctx:
+        rc = lib.svps_kv_project_f32_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(wkT), _ptr(bk), _ptr(lnk_w), _ptr(lnk_b),
+                                         float(lnk_eps), _ptr(wvT), _ptr(bv), _ptr(lnv_w), _ptr(lnv_b), float(lnv_eps),
+                                         _ptr(k), _ptr(v), T, H, W, D, ctx.stream)
+    _lib.check(rc, "svps_kv_project_f32_fwd")
+    return k, v
+
+
+def slot_attn_f32(q, k, v, ln_w, ln_b, eps=1e-5, return_pre_ln=False):
+    """Exact-mode K1: q [T, L, 256], k / v [T, HW, 256], all fp32 -> ReLU(LN(softmax_over_slots(q k^T) v)) fp32."""
+    lib = _lib.load()
+    for name, x in (("q", q), ("k", k), ("v", v)):
+        _need(x, name, F32, 3)
+    _need(ln_w, "ln_w", F32, 1)
+    _need(ln_b, "ln_b", F32, 1)
+    T, L, D = q.shape
+    HW = k.shape[1]
+    if k.shape != (T, HW, D) or v.shape != (T, HW, D):
+        raise ValueError("shape mismatch")
+    ws_bytes = lib.svps_slot_attn_f32_workspace_bytes(T, L, HW)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=F32, device=q.device)
+    out = torch.empty((T, L, D), dtype=F32, device=q.device)
+    pre = torch.empty_like(out) if return_pre_ln else None
+    with _on(q, k, v, ln_w, ln_b) as ctx:
+        rc = lib.svps_slot_attn_f32_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(ws), ws_bytes,
+                                        _ptr(out), _ptr(pre), T, L, HW, D, ctx.stream)
+    _lib.check(rc, "svps_slot_attn_f32_fwd")
+    return (out, pre) if return_pre_ln else out
+
+
+def mask_decode_f32(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift):
+    """Exact-mode K2: feat [T, HW, 256] fp32, embed [T, L, 256] fp32 -> mask logits [T, L, HW] fp32."""
+    lib = _lib.load()
+    _need(feat, "feat", F32, 3)
+    _need(embed, "embed", F32, 3)
+    _need(bn_scale, "bn_scale", F32, 1)
+    _need(bn_shift, "bn_shift", F32, 1)
+    T, HW, D = feat.shape
+    L = embed.shape[1]
+    if embed.shape != (T, L, D):
+        raise ValueError("shape mismatch")
+    out = torch.empty((T, L, HW), dtype=F32, device=feat.device)
+    with _on(feat, embed, bn_scale, bn_shift) as ctx:
+        rc = lib.svps_mask_decode_f32_fwd(_ptr(feat), _ptr(embed), _ptr(bn_scale), _ptr(bn_shift), float(fg_scale),
+                                          float(fg_shift), _ptr(out), T, L, HW, D, ctx.stream)
+    _lib.check(rc, "svps_mask_decode_f32_fwd")
+    return out
+
+
 class KernelTimer:
     """Device-time accounting of the library's own launches (HIP events on the launch stream)."""
 

@@ -15,6 +15,11 @@ There is no CPU path: modules raise if their tensors are not on a GPU.
 
 Storage policy (what is rounded to bf16 in HBM): the fused level map f, the projection operand f+pos,
 the projection weights, and the post-LayerNorm q / k / v. Slot-side tensors stay fp32.
+
+Exact mode (`head.set_precision("fp32")`): the reference runs this path in fp32 (vps_temporal_slots.py:55); in this
+mode nothing is stored below fp32 and the pixel side runs on the fp32 kernels of csrc/exact_f32.hip (level fusion,
+projections + LayerNorm, retriever, decode), the slot-side self-attention on explicit fp32 matrix products. One to two
+orders of magnitude slower; it exists so that the head can be compared free-running with the reference's own outputs.
 """
 import copy
 import math
@@ -88,6 +93,10 @@ class MaskDynamicConv(nn.Module):
         self.norm1 = nn.LayerNorm(dh_dim)
         self.activation = nn.ReLU(inplace=True)
         self.split_p = True     # carry softmax probabilities as bf16 hi+lo inside K1
+        self.precision = "bf16"  # "fp32": exact mode (csrc/exact_f32.hip)
+        # bf16 mode, two forms of the same function: "fused" (default where it applies, L <= 128): statistics-fused retriever
+        # K3' + K1' - no k / v tensors, the map is read once per kernel; "kv": K3 writes bf16 k / v, K1 streams them
+        self.retriever = "fused"
 
     def _bf16_weights(self):
         """to_k / to_v weight matrices rounded to bf16 once (re-derived if the parameters change)."""
@@ -98,6 +107,67 @@ class MaskDynamicConv(nn.Module):
             self._wcache_key = key
         return self._wcache
 
+    def _fused_consts(self):
+        """Weight-only constants of the fused form, derived once per weight version in float64 on the host:
+        centred projections W~ = (I - 11^T/256) W, b~ = b - mean(b); the upper-triangular QR factor of [W~ | b~] for the
+        statistics kernel; the slot-side matrices of the key fold and of the value epilogue."""
+        srcs = [self.to_k.weight, self.to_k.bias, self.to_v.weight, self.to_v.bias, self.norm_k.weight, self.norm_k.bias,
+                self.norm_v.weight, self.norm_v.bias]
+
+        def build():
+            dev = self.to_k.weight.device
+            out = {}
+            for name, lin in (("k", self.to_k), ("v", self.to_v)):
+                w = lin.weight.detach().double().cpu()
+                b = lin.bias.detach().double().cpu()
+                wc = w - w.mean(dim=0, keepdim=True)                    # subtract the mean over OUTPUT channels (rows)
+                bc = b - b.mean()
+                r = torch.linalg.qr(torch.cat([wc, bc[:, None]], dim=1), mode="r").R          # [256, 257] upper trapezoidal
+                out["r" + name] = torch.triu(r[:, :256]).to(dev).to(BF16).contiguous()
+                out["rb" + name] = r[:, 256].float().to(dev).contiguous()
+                out["wc" + name], out["bc" + name] = wc, bc
+            out["wck"] = out["wck"].float().to(dev).contiguous()                               # Q'' = (q * gamma_k) @ W~_k
+            out["bck"] = out["bck"].float().to(dev).contiguous()
+            gv = self.norm_v.weight.detach().double().cpu()
+            wext = torch.zeros((264, 256), dtype=torch.float64)
+            wext[:256] = (gv[:, None] * out.pop("wcv")).t()                                   # (gamma_v * W~_v)^T
+            wext[256] = gv * out.pop("bcv")
+            wext[257] = self.norm_v.bias.detach().double().cpu()
+            out["wext"] = wext.float().to(dev).contiguous()
+            return out
+        return _cached(self, "fused", srcs, build)
+
+    def forward_fused(self, slots, feat_pm, hw, pos_tabs, stats=None):
+        """K3' + K1' (csrc/retr_stats.hip, csrc/retr_attn.hip): slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16.
+        `stats` = (rstd_k, rstd_v, aux) if already computed for this (map, stage)."""
+        c = self._fused_consts()
+        T, L, C = slots.shape
+        H, W = hw
+        if stats is None:
+            stats = ops.retr_stats(feat_pm, H, W, pos_tabs, c["rk"], c["rbk"], self.norm_k.eps, c["rv"], c["rbv"], self.norm_v.eps)
+        q = ops.row_ln(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps)      # :431, fp32
+        g = q * self.norm_k.weight
+        q2 = g @ c["wck"]                                                  # Q'' [T, L, 256]
+        a1 = g @ c["bck"]                                                  # [T, L]
+        dev = slots.device
+        qh = torch.zeros((T, 128, C), dtype=BF16, device=dev)
+        ql = torch.zeros((T, 128, C), dtype=BF16, device=dev)
+        hi = q2.to(BF16)
+        qh[:, :L] = hi
+        ql[:, :L] = (q2 - hi.float()).to(BF16)
+        cy = torch.zeros((T, H, 128), dtype=torch.float32, device=dev)
+        cx = torch.zeros((T, W, 128), dtype=torch.float32, device=dev)
+        if pos_tabs is not None:
+            ytab, xtab = pos_tabs
+            cy[:, :, :L] = torch.matmul(ytab, q2[:, :, :C // 2].transpose(1, 2))
+            cx[:, :, :L] = torch.matmul(xtab, q2[:, :, C // 2:].transpose(1, 2))
+        cy[:, :, :L] += a1[:, None, :]
+        c3 = torch.zeros((T, 128), dtype=torch.float32, device=dev)
+        c3[:, :L] = q @ self.norm_k.bias
+        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats[0], stats[1], stats[2], L, H, W)
+        pre = (ext.view(T * L, 264) @ c["wext"]).view(T, L, C)                                       # :456 (value projection after the sum)
+        return ops.row_ln(pre, self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)        # :458-459
+
     def project_kv(self, feat_pm, hw, pos_tabs):
         """K3: feat_pm [T, H*W, C] bf16, hw = (H, W), pos_tabs = (ytab, xtab) or None -> k, v bf16."""
         wk, wv = self._bf16_weights()
@@ -106,7 +176,17 @@ class MaskDynamicConv(nn.Module):
                               self.norm_v.bias, self.norm_v.eps)
 
     def forward_pm(self, slots, feat_pm, hw, pos_tabs):
-        """slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16 -> [T, L, C] fp32 (K3 then K1)."""
+        """slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16 (fp32 in exact mode) -> [T, L, C] fp32 (K3 then K1)."""
+        if self.precision == "fp32":
+            q = ops.row_ln(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps)
+            wkT = _cached(self, "wkT", [self.to_k.weight], lambda: self.to_k.weight.t().contiguous())
+            wvT = _cached(self, "wvT", [self.to_v.weight], lambda: self.to_v.weight.t().contiguous())
+            k, v = ops.kv_project_f32(feat_pm, hw[0], hw[1], pos_tabs, wkT, self.to_k.bias, self.norm_k.weight,
+                                      self.norm_k.bias, self.norm_k.eps, wvT, self.to_v.bias, self.norm_v.weight,
+                                      self.norm_v.bias, self.norm_v.eps)
+            return ops.slot_attn_f32(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
+        if self.retriever == "fused" and slots.shape[1] <= 128:
+            return self.forward_fused(slots, feat_pm, hw, pos_tabs)
         q = ops.row_ln(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps, out_bf16=True)
         k, v = self.project_kv(feat_pm, hw, pos_tabs)
         return ops.slot_attn(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps, split_p=self.split_p)
@@ -114,7 +194,8 @@ class MaskDynamicConv(nn.Module):
     def forward(self, pro_features, features, pos, gt_non_void_mask=None):
         assert gt_non_void_mask is None
         n, c, h, w = features.shape
-        feat_pm = features.permute(0, 2, 3, 1).reshape(n, h * w, c).to(BF16).contiguous()
+        store = torch.float32 if self.precision == "fp32" else BF16
+        feat_pm = features.permute(0, 2, 3, 1).reshape(n, h * w, c).to(store).contiguous()
         return self.forward_pm(pro_features.float(), feat_pm, (h, w), pos_tables_from_map(pos))
 
 
@@ -242,6 +323,7 @@ class MaskRCNNHead(nn.Module):
         self.use_focal = use_focal
         self.class_logits = nn.Linear(d_model, num_classes)
         self.scale_clamp = scale_clamp
+        self.precision = "bf16"
 
     def _self_attention(self, slots):
         """nn.MultiheadAttention(self_attn)(x, x, x) for frames-as-batch slots [T, L, C] (:346-355), with the module's own
@@ -253,7 +335,11 @@ class MaskRCNNHead(nn.Module):
         nh = mha.num_heads
         qkv = F.linear(slots, mha.in_proj_weight, mha.in_proj_bias).view(T, L, 3, nh, C // nh)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [T, heads, L, C / heads] views
-        o = F.scaled_dot_product_attention(q, k, v)                         # softmax(q k^T / sqrt(C / heads)) v
+        if self.precision == "fp32":                                        # explicit fp32 products, torch's own order (:352)
+            attn = torch.softmax((q * (1.0 / math.sqrt(C // nh))) @ k.transpose(-1, -2), dim=-1)
+            o = attn @ v
+        else:
+            o = F.scaled_dot_product_attention(q, k, v)                     # softmax(q k^T / sqrt(C / heads)) v
         return F.linear(o.transpose(1, 2).reshape(T, L, C), mha.out_proj.weight, mha.out_proj.bias)
 
     def forward_till_ffn_pm(self, slots, feat_pm, hw, pos_tabs):
@@ -303,7 +389,8 @@ class MaskRCNNHead(nn.Module):
         assert pad_mask is None and query_pos is None and gt_non_void_mask is None
         T = len(features)
         _, c, h, w = features[0].shape
-        feat_pm = torch.cat(features, 0).permute(0, 2, 3, 1).reshape(T, h * w, c).to(BF16).contiguous()
+        store = torch.float32 if self.precision == "fp32" else BF16
+        feat_pm = torch.cat(features, 0).permute(0, 2, 3, 1).reshape(T, h * w, c).to(store).contiguous()
         tabs = pos_tables_from_map(pos[0]) if pos is not None else None
         logits, emb = self.forward_pm(torch.cat(mask_query, 0).float(), feat_pm, (h, w), tabs, stage_enable)
         return [logits[t:t + 1] for t in range(T)], [emb[t:t + 1] for t in range(T)], None, None
@@ -354,7 +441,27 @@ class MultiScaleDynamicMaskHead(nn.Module):
         if use_focal:
             self.prior_prob = prior_prob
             self.bias_value = -math.log((1 - prior_prob) / prior_prob)
+        self.precision = "bf16"
         self._reset_parameters()
+
+    def set_precision(self, mode):
+        """"bf16" (default): bf16 storage of the pixel-side tensors, matrix-core kernels. "fp32": exact mode - fp32 storage and
+        arithmetic everywhere (csrc/exact_f32.hip), the reference's own dtype (vps_temporal_slots.py:55)."""
+        if mode not in ("bf16", "fp32"):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', not {mode!r}")
+        for m in self.modules():
+            if hasattr(m, "precision"):
+                m.precision = mode
+        return self
+
+    def set_retriever(self, form):
+        """bf16 mode only: "fused" (K3' + K1', default) or "kv" (K3 + K1 through bf16 k / v tensors)."""
+        if form not in ("fused", "kv"):
+            raise ValueError(f"retriever must be 'fused' or 'kv', not {form!r}")
+        for m in self.modules():
+            if hasattr(m, "retriever"):
+                m.retriever = form
+        return self
 
     def _reset_parameters(self):
         for p in self.parameters():                      # :127-136
@@ -376,6 +483,10 @@ class MultiScaleDynamicMaskHead(nn.Module):
         """K4 (:171-188). cur [T, 128, H, W] fp32 (the reference's layout) or [T, H*W, 128] bf16;
         prev_pm [T, (H/2)*(W/2), 256] bf16 fused map of the coarser level or None (level 0).
         Returns the fused map [T, H*W, 256] bf16 pixel-major."""
+        if self.precision == "fp32":
+            conv = self.conv_trans.conv
+            wT = _cached(self, "cwT", [conv.weight], lambda: conv.weight.reshape(self.dh_dim, self.trans_in_dim).t().contiguous())
+            return ops.level_fuse_f32(cur.float().contiguous(), prev_pm, wT, conv.bias, hw[0], hw[1])
         wc, bc = self._conv_weights()
         if cur.dtype not in (torch.float32, BF16):
             cur = cur.float()
@@ -454,5 +565,8 @@ def generate_final_outputs(feat_pm, slot_embed, feat_bn, fg_bn, want_argmax=Fals
     [T, L, 256] last-stage embeddings -> mask logits [T, L, HW] fp32 (+ uint8 slot argmax [T, HW])."""
     scale, shift = fold_bn_eval(feat_bn)
     fs, fb = fold_bn_eval(fg_bn)
+    if feat_pm.dtype == torch.float32:                       # exact mode
+        masks = ops.mask_decode_f32(feat_pm, slot_embed.float().contiguous(), scale, shift, float(fs.item()), float(fb.item()))
+        return (masks, masks.argmax(dim=1).to(torch.uint8)) if want_argmax else masks
     return ops.mask_decode(feat_pm, slot_embed.float().contiguous(), scale, shift, float(fs.item()), float(fb.item()),
                            want_argmax=want_argmax)

@@ -1,0 +1,92 @@
+"""Statistics-fused retriever (K3' retr_stats + K1' retr_attn + slot-side epilogue) against the float64 oracle.
+
+Yardstick: `oracle.retriever` (the restatement of MaskDynamicConv.forward, pinned against the reference module) in
+float64 with NO storage rounding, evaluated on the same bf16-stored feature map. The only differences left are the
+kernel's own roundings: Q'' and P * rstd_v as bf16 hi + lo, the statistics operand f + pos and the QR factor as bf16,
+fp32 accumulation. Tolerances are written at the assertions."""
+import numpy as np
+import pytest
+
+from util import orc, to_bf16_t
+
+pytestmark = pytest.mark.gpu
+
+
+def make_module(cuda, seed):
+    import torch
+    from slotvps_amd.slot_head import MaskDynamicConv
+    rng = np.random.default_rng(seed)
+    m = MaskDynamicConv(256).to(cuda).eval()
+    P = {}
+    with torch.no_grad():
+        for n in ("to_q", "to_k", "to_v"):
+            lin = getattr(m, n)
+            lim = float(np.sqrt(6.0 / 512))                                      # xavier-uniform
+            P[f"{n}.weight"] = rng.uniform(-lim, lim, (256, 256)).astype(np.float32)
+            P[f"{n}.bias"] = (0.1 * rng.standard_normal(256)).astype(np.float32)
+            lin.weight.copy_(torch.from_numpy(P[f"{n}.weight"]))
+            lin.bias.copy_(torch.from_numpy(P[f"{n}.bias"]))
+        for n in ("norm_q", "norm_k", "norm_v", "norm1"):
+            ln = getattr(m, n)
+            P[f"{n}.weight"] = rng.uniform(0.5, 1.5, 256).astype(np.float32)
+            P[f"{n}.bias"] = (0.1 * rng.standard_normal(256)).astype(np.float32)
+            ln.weight.copy_(torch.from_numpy(P[f"{n}.weight"]))
+            ln.bias.copy_(torch.from_numpy(P[f"{n}.bias"]))
+    return m, P
+
+
+@pytest.mark.parametrize("T,H,W,pos", [(2, 8, 32, True), (1, 5, 20, True), (1, 3, 64, False), (2, 34, 60, True), (1, 7, 9, True)])
+def test_retr_stats(cuda, T, H, W, pos):
+    import torch
+    from slotvps_amd import ops
+    m, P = make_module(cuda, H * W)
+    rng = np.random.default_rng(W)
+    HW = H * W
+    feat = orc.round_bf16(rng.standard_normal((T, HW, 256)).astype(np.float32))
+    c = m._fused_consts()
+    tabs = ops.pos_embed_sine_tables(H, W, 256, cuda) if pos else None
+    rk, rv, aux = ops.retr_stats(to_bf16_t(feat, cuda), H, W, tabs, c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
+    torch.cuda.synchronize()
+    rk, rv, aux = rk.cpu().numpy(), rv.cpu().numpy(), aux.float().cpu().numpy()
+    pm = orc.pos_embed_sine(H, W).astype(np.float64) if pos else 0.0
+    d = lambda n: P[n].astype(np.float64)
+    for t in range(T):
+        f64 = feat[t].astype(np.float64)
+        uk = orc.linear(f64 + pm, d("to_k.weight"), d("to_k.bias"))
+        uv = orc.linear(f64, d("to_v.weight"), d("to_v.bias"))
+        for got, u in ((rk[t], uk), (rv[t], uv)):
+            ref = 1.0 / np.sqrt(u.var(axis=1) + 1e-5)
+            rel = np.abs(got - ref) / ref
+            # bf16 rounding of the operand (f + pos) and of the triangular factor: ~2^-9 relative per element, averaged over
+            # 256 random terms -> a few 1e-5 on the variance; bound 5e-4
+            assert rel.max() <= 5e-4, rel.max()
+        sig = 1.0 / rv[t].astype(np.float64)
+        assert np.all(aux[t][:, 0] == 1.0) and np.all(aux[t][:, 3:] == 0.0)
+        assert np.abs(aux[t][:, 1].astype(np.float64) + aux[t][:, 2] - sig).max() <= 3e-5 * sig.max()   # hi + lo: 16-bit mantissa
+
+
+@pytest.mark.parametrize("T,H,W,L,pos", [(2, 8, 32, 100, True), (1, 16, 64, 128, True), (1, 5, 20, 37, True),
+                                         (2, 34, 60, 100, True), (1, 3, 64, 1, False), (1, 40, 32, 100, True)])
+def test_fused_retriever_matches_float64_oracle(cuda, T, H, W, L, pos):
+    import torch
+    from slotvps_amd import ops
+    m, P = make_module(cuda, 7 + L)
+    rng = np.random.default_rng(L + W)
+    HW = H * W
+    feat = orc.round_bf16(rng.standard_normal((T, HW, 256)).astype(np.float32))
+    slots = rng.standard_normal((T, L, 256)).astype(np.float32)
+    tabs = ops.pos_embed_sine_tables(H, W, 256, cuda) if pos else None
+    with torch.no_grad():
+        got = m.forward_fused(torch.from_numpy(slots).to(cuda), to_bf16_t(feat, cuda), (H, W), tabs)
+        torch.cuda.synchronize()
+        again = m.forward_fused(torch.from_numpy(slots).to(cuda), to_bf16_t(feat, cuda), (H, W), tabs)
+    assert torch.equal(got, again)                                          # fixed-order partial sums: bitwise reproducible
+    got = got.cpu().numpy()
+    pm = orc.pos_embed_sine(H, W) if pos else None
+    worst = 0.0
+    for t in range(T):
+        ref = orc.retriever(slots[t], feat[t], pm, P, "", st=orc.Storage.exact(), dt=np.float64)
+        worst = max(worst, float(np.abs(got[t] - ref).max()))
+    print(f"\nfused retriever T={T} {H}x{W} L={L}: max abs err vs float64 oracle {worst:.2e}")
+    # post-LayerNorm outputs are O(1); measured 1e-4 ... 4e-4 (bf16 k / v tensors: 1e-1)
+    assert worst <= 1.5e-3
