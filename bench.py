@@ -16,9 +16,11 @@ gathered to rank 0 over RCCL on a side stream, overlapped with the next step, in
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions):
   value            frames/s, whole job            = n_gpus * steps * T / max-over-ranks wall time
-  roofline         K1 (slot_attn_partial_*): algorithmic bytes (k and v read once + q + out) of all K1
-                   launches of the timed steps / their summed device time from HIP events recorded on
-                   the launch stream, against the 8 TB/s HBM3E peak
+  roofline         the DOMINANT kernel of the step by device time (HIP events recorded on the launch stream around every
+                   launch of the library, in a second, eager pass over the same steps): its algorithmic bytes against the
+                   8 TB/s HBM3E peak and its algorithmic matrix flops against the 2.5 PFLOP/s dense bf16 peak; `bound` is the
+                   larger of the two fractions. `per_kernel` carries the same for every kernel, `retriever_pair` for
+                   K3' + K1' together (accounting: SlotClipRunner.algorithmic_per_step)
   cpu_baseline     the PyTorch-CPU restatement of the same head + decode (oracle/torch_cpu_head.py, pinned through the
                    NumPy oracle against the reference's own modules) on the host cores: T = 5 clips, fp32, all cores
                    (median) and 8 threads, bounded sample
@@ -37,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak (same table; the 5 PF headline includes 2:1 sparsity)
 
 
 def parse():
@@ -50,6 +53,8 @@ def parse():
     ap.add_argument("--slots", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--fast-p", action="store_true", help="bf16 P without the hi/lo split inside K1")
+    ap.add_argument("--retriever", choices=["fused", "kv"], default="fused",
+                    help="fused: statistics-fused retriever K3' + K1' (default); kv: K3 + K1 through bf16 k / v tensors")
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="independent clips per step, each replayed on its own HIP stream (a step then covers that many clips)")
     ap.add_argument("--clips-per-launch", type=int, default=16,
@@ -275,6 +280,7 @@ def main():
     n_pool = 2 * cif    # distinct synthetic clips per rank, each resident in its own input slot
     runner = SlotClipRunner(dev, T, a.height, a.width, L=a.slots, param_seed=0, split_p=not a.fast_p,
                             use_graph=not a.no_graph, n_slots=n_pool, clips_per_launch=cpl)
+    runner.head.set_retriever(a.retriever)
     HWf = runner.sizes[-1][0] * runner.sizes[-1][1]
     ncls = runner.cfg["num_classes"]
     # synthetic clips, resident in HBM (in the runner's input slots) before the timed region
@@ -332,7 +338,7 @@ def main():
 
     if rank == 0:
         note(f"timed region done: {elapsed / max(1, a.steps) * 1e3:.2f} ms per step; roofline leg ...")
-    # ------------------- roofline leg: same steps, eager, HIP events around every launch --------------
+    # ------------------- roofline leg: same steps, eager, HIP events around every launch of the library --------------
     roof = None
     if rank == 0:
         eager = runner.use_graph
@@ -340,28 +346,45 @@ def main():
         for i in range(2):
             step(i, False)
         torch.cuda.synchronize(dev)
+        kids = {"slot_attn": _lib.KERNEL_SLOT_ATTN, "slot_attn_finish": _lib.KERNEL_SLOT_ATTN_FINISH,
+                "mask_decode": _lib.KERNEL_MASK_DECODE, "kv_project": _lib.KERNEL_KV_PROJECT, "level_fuse": _lib.KERNEL_LEVEL_FUSE,
+                "retr_stats": _lib.KERNEL_RETR_STATS, "retr_attn": _lib.KERNEL_RETR_ATTN, "retr_finish": _lib.KERNEL_RETR_FINISH}
         with ops.KernelTimer() as kt:
             for i in range(a.steps):
                 step(i, False)
             torch.cuda.synchronize(dev)
-            k1_ms, k1_n = kt.collect(_lib.KERNEL_SLOT_ATTN)
-            fin_ms, fin_n = kt.collect(_lib.KERNEL_SLOT_ATTN_FINISH)
-            k2_ms, k2_n = kt.collect(_lib.KERNEL_MASK_DECODE)
-            k3_ms, k3_n = kt.collect(_lib.KERNEL_KV_PROJECT)
-            k4_ms, k4_n = kt.collect(_lib.KERNEL_LEVEL_FUSE)
+            timed = {name: kt.collect(kid) for name, kid in kids.items()}
         runner.use_graph = eager
-        alg = runner.k1_algorithmic_bytes_per_step() * a.steps * cif
-        achieved = alg / (k1_ms * 1e-3) / 1e9
+        alg = runner.algorithmic_per_step()
+        nsteps = a.steps * cif
+        per = {}
+        for name, (ms, n) in timed.items():
+            if n == 0:
+                continue
+            e = {"launches": n, "avg_launch_us": round(ms / n * 1e3, 2), "us_per_clip": round(ms / nsteps / cpl * 1e3, 1)}
+            if name in alg:
+                sec = ms * 1e-3
+                e["algorithmic_bytes_per_launch"] = int(alg[name]["bytes"] * nsteps / n)
+                e["algorithmic_flops_per_launch"] = int(alg[name]["flops"] * nsteps / n)
+                e["hbm_gbs"] = round(alg[name]["bytes"] * nsteps / sec / 1e9, 1)
+                e["hbm_frac"] = round(e["hbm_gbs"] / HBM_PEAK_GBS, 4)
+                e["mfma_tflops"] = round(alg[name]["flops"] * nsteps / sec / 1e12, 1)
+                e["mfma_frac"] = round(e["mfma_tflops"] / MFMA_PEAK_TFLOPS, 4)
+                e["bound"] = "hbm" if e["hbm_frac"] >= e["mfma_frac"] else "mfma"
+            per[name] = e
+        dom = max((k for k in per if k in alg), key=lambda k: timed[k][0])
+        d = per[dom]
+        hbm = d["bound"] == "hbm"
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01", "k1_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
         wkey = f"{a.height}x{a.width} T={a.frames} L={a.slots} cpl={cpl}"
-        rec = None
         if os.path.exists(pmc):
             with open(pmc) as fh:
                 rec = json.load(fh)
-        if rec is not None and rec.get("workload_key") == wkey:
-            traffic = int(rec["traffic_bytes_per_launch"])          # FETCH_SIZE x2 (gfx950) + WRITE_SIZE, avg per K1 launch
-            traffic_src = "profiles/r01/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+            if rec.get("workload_key") == wkey and dom in rec.get("kernels", {}):
+                traffic = int(rec["kernels"][dom]["traffic_bytes_per_launch"])
+                traffic_src = ("from the stored profile profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                               f"separate passes, calibrated on a known-bytes copy in the same pass; bench {rec.get('bench_sha', '?')}), not measured in this run")
         # measured on-box ceiling next to the vendor peak: a plain device-to-device copy of 1 GiB (bytes read + written)
         src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         dst = torch.empty_like(src)
@@ -375,23 +398,24 @@ def main():
         torch.cuda.synchronize(dev)
         copy_gbs = 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
-        oth = runner.other_algorithmic_bytes_per_step()
-        oth_ms = {"kv_project": k3_ms, "level_fuse": k4_ms, "mask_decode": k2_ms}
-        others = {k: {"achieved": round(oth[k] * a.steps * cif / (oth_ms[k] * 1e-3) / 1e9, 1),
-                      "frac": round(oth[k] * a.steps * cif / (oth_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                      "algorithmic_bytes_per_step": int(oth[k])} for k in oth}
-        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "slot_attn_partial_ws", "launches": k1_n, "avg_launch_us": round(k1_ms / k1_n * 1e3, 2),
-                "algorithmic_bytes_per_launch_avg": int(alg / k1_n),
-                "copy_kernel_ceiling": {"gbps": round(copy_gbs, 1), "frac_of_it": round(achieved / copy_gbs, 4),
-                                        "what": "torch device-to-device copy of 1 GiB, bytes read + written"},
-                "other_kernels_hbm": others,
-                "other_kernels_us_per_clip": {"slot_attn_finish": round(fin_ms / a.steps / cif / cpl * 1e3, 1),
-                                              "mask_decode": round(k2_ms / a.steps / cif / cpl * 1e3, 1),
-                                              "kv_project": round(k3_ms / a.steps / cif / cpl * 1e3, 1),
-                                              "level_fuse": round(k4_ms / a.steps / cif / cpl * 1e3, 1),
-                                              "slot_attn_partial": round(k1_ms / a.steps / cif / cpl * 1e3, 1)}}
+        roof = {"bound": d["bound"], "achieved": d["hbm_gbs"] if hbm else d["mfma_tflops"],
+                "peak": HBM_PEAK_GBS if hbm else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm else "TFLOP/s",
+                "frac": d["hbm_frac"] if hbm else d["mfma_frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": dom, "what": "dominant kernel of the step by device time; both fractions of every kernel in per_kernel",
+                "launches": d["launches"], "avg_launch_us": d["avg_launch_us"],
+                "algorithmic_bytes_per_launch_avg": d["algorithmic_bytes_per_launch"],
+                "algorithmic_flops_per_launch_avg": d["algorithmic_flops_per_launch"],
+                "retriever_form": runner.retriever_form,
+                "copy_kernel_ceiling": {"gbps": round(copy_gbs, 1), "what": "torch device-to-device copy of 1 GiB, bytes read + written"},
+                "per_kernel": per}
+        pair = [k for k in ("retr_stats", "retr_attn") if k in per] or [k for k in ("kv_project", "slot_attn") if k in per]
+        if len(pair) == 2:                              # the retriever as a pair (the yardstick of VERDICT r01 item 1b)
+            ms = sum(timed[k][0] for k in pair)
+            by = sum(alg[k]["bytes"] for k in pair) * nsteps
+            fl = sum(alg[k]["flops"] for k in pair) * nsteps
+            roof["retriever_pair"] = {"kernels": pair, "ms_per_step": round(ms / nsteps, 3),
+                                      "hbm_frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "mfma_frac": round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
 
     if rank == 0:
         frames = world * a.steps * T * cif * cpl
@@ -408,7 +432,7 @@ def main():
                        "parallelism": f"clip-parallel x{world}", "world_size": world,
                        "gather": f"per step, {gatherers[0].bytes_per_submit} B per rank to rank 0, async on a side stream (RCCL)" if world > 1 else "none (one rank)",
                        "hipgraph": not a.no_graph, "clips_in_flight": cif, "clips_per_launch": cpl,
-                       "k1_split_p": not a.fast_p},
+                       "k1_split_p": not a.fast_p, "retriever": runner.retriever_form},
             "roofline": roof,
         }
         if a.cpu_baseline and world == 1:

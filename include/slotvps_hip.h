@@ -223,7 +223,8 @@ int svps_probe_tile(const void* x, void* rows, void* cols, void* stream);
  *
  * svps_retr_stats_fwd   (:432-433, the LayerNorm statistics only)
  *   feat  [T, HW, 256] bf16 fused map; pos_y [H, 128] / pos_x [W, 128] fp32 separable sine tables or NULL
- *   rk, rv [256, 256] bf16: the UPPER-TRIANGULAR factor R of  [W~ | b~] = Q [R | r]  for to_k / to_v (host, float64 QR);
+ *   rk [256, 256] FP16, rv [256, 256] bf16: the UPPER-TRIANGULAR factor R of  [W~ | b~] = Q [R | r]  for to_k / to_v
+ *       (host, float64 QR; the key side runs fp16 x fp16 on fp16(feat + pos): rstd_k needs the three extra mantissa bits);
  *   rbk, rbv [256] fp32: the column r.   |R x + r|^2 = |W~ x + b~|^2 = 256 * var.
  *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] bf16 = {1, hi(1/rstd_v), lo(1/rstd_v), 0 ...}
  *

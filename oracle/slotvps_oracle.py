@@ -54,9 +54,10 @@ class Storage:
     LayerNorm statistics and everything on the slot side stay fp32. ``torch_conv`` additionally models
     the interim PyTorch level-fusion conv of the HIP path (a bf16 conv also rounds its bias)."""
 
-    def __init__(self, bf16, torch_conv=False):
+    def __init__(self, bf16, torch_conv=False, kv_bf16=True):
         self.bf16 = bool(bf16)
         self.torch_conv = bool(torch_conv)
+        self.kv_bf16 = bool(kv_bf16)
 
     @classmethod
     def exact(cls):
@@ -64,7 +65,14 @@ class Storage:
 
     @classmethod
     def bf16_policy(cls, torch_conv=False):
+        """The first form of the fast path (K3 + K1): bf16 fused map AND bf16 projection operands / weights / q / k / v."""
         return cls(True, torch_conv)
+
+    @classmethod
+    def fused_policy(cls):
+        """The statistics-fused retriever (K3' + K1'): only the fused level map (and the 1x1 fusion conv's operands) are
+        bf16; nothing on the projection / q / k / v side is rounded as a tensor."""
+        return cls(True, False, kv_bf16=False)
 
     def _r(self, x):
         return round_bf16(x).astype(x.dtype) if self.bf16 else x
@@ -72,12 +80,16 @@ class Storage:
     def _rt(self, x):
         return round_bf16(x).astype(x.dtype) if (self.bf16 and self.torch_conv) else x
 
+    def _rk(self, x):
+        return round_bf16(x).astype(x.dtype) if (self.bf16 and self.kv_bf16) else x
+
     feat = _r        # fused level feature map f (input of the projections, the decode, the next level)
     conv_in = _r     # concat(upsampled previous level, current 128-ch map): operand of the 1x1 conv
-    proj_in = _r     # f + pos, the k-projection operand
-    weight = _r      # conv / to_k / to_v weight matrices as matrix-core operands
-    kv = _r          # post-LayerNorm k and v
-    q = _r           # post-LayerNorm q
+    proj_in = _rk    # f + pos, the k-projection operand
+    weight = _r      # level-fusion conv weight matrix as a matrix-core operand
+    proj_weight = _rk  # to_k / to_v weight matrices as matrix-core operands
+    kv = _rk         # post-LayerNorm k and v
+    q = _rk          # post-LayerNorm q
     conv_bias = _rt  # bias of the level-fusion conv (bf16 only in the interim torch conv)
 
 
@@ -169,8 +181,8 @@ def retriever_project(slots, feat, pos, params, prefix, st, dt):
     g = lambda n: _p(params, prefix, n, dt)
     q = layer_norm(linear(slots, g("to_q.weight"), g("to_q.bias")), g("norm_q.weight"), g("norm_q.bias"))
     kin = st.proj_in(feat + pos) if pos is not None else feat
-    k = layer_norm(linear(kin, st.weight(g("to_k.weight")), g("to_k.bias")), g("norm_k.weight"), g("norm_k.bias"))
-    v = layer_norm(linear(feat, st.weight(g("to_v.weight")), g("to_v.bias")), g("norm_v.weight"), g("norm_v.bias"))
+    k = layer_norm(linear(kin, st.proj_weight(g("to_k.weight")), g("to_k.bias")), g("norm_k.weight"), g("norm_k.bias"))
+    v = layer_norm(linear(feat, st.proj_weight(g("to_v.weight")), g("to_v.bias")), g("norm_v.weight"), g("norm_v.bias"))
     return st.q(q), st.kv(k), st.kv(v)
 
 

@@ -113,20 +113,45 @@ class SlotClipRunner:
 
     # ---- algorithmic accounting (SURVEY.md 8d) ------------------------------------------------
     def k1_launch_shapes(self):
-        """[(HW, launches per step)] of K1: one launch per stage covering all T frames."""
+        """[(HW, launches per step)] of the retriever: one launch per stage covering all T frames."""
         return [(h * w, n) for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"])]
 
+    @property
+    def retriever_form(self):
+        for m in self.head.modules():
+            if hasattr(m, "retriever"):
+                return m.retriever if self.L <= 128 else "kv"
+        return "kv"
+
     def k1_algorithmic_bytes_per_step(self):
-        """k and v read exactly once + q in + out, bf16 / fp32 as stored: 2*HW*D*2 + L*D*(2+4) per frame-stage."""
+        """kv form (K1): k and v read exactly once + q in + out: 2*HW*D*2 + L*D*(2+4) per frame-stage."""
         D = self.cfg["dh_dim"]
         return sum(n * self.T * (2 * hw * D * 2 + self.L * D * (2 + 4)) for hw, n in self.k1_launch_shapes())
 
-    def other_algorithmic_bytes_per_step(self):
-        """Algorithmic HBM bytes per step of the other pixel-side kernels (all frames of the launch):
-        K3: 512 B in + 1024 B out per pixel and stage; K4: 512 B (fp32 NCHW map) in + 512 B out per pixel, + 128 B of
-        the 4x smaller previous level for levels > 0; K2: 512 B in + L * 4 B + 1 B out per finest-level pixel."""
+    def algorithmic_per_step(self):
+        """Per library kernel: algorithmic HBM bytes and matrix flops of one step (all frames of the launch), the figures the
+        roofline fractions are computed from. Per pixel and stage (D = 256, L slots):
+          retr_stats (K3')  bytes: 512 (map) + 8 (two statistics) + 64 (aux row) out
+                            flops: the two triangular products |R x|^2, 36 of 64 blocks each: 2 * (36/64) * 2 * D^2
+          retr_attn  (K1')  bytes: 512 (map) + 8 + 64 in, + per frame-stage L*D*(2+2) (Q'' hi / lo) + tables (H+W)*128*4 + L*264*4 out
+                            flops: 4 * L * D (logits + attn.v; the hi / lo splits are not algorithmic)
+          kv_project (K3)   bytes: 512 in + 1024 out; flops 4 * D^2
+          slot_attn  (K1)   bytes: 1024 in (+ q, out per frame-stage); flops 4 * L * D
+          level_fuse (K4)   bytes: 512 (fp32 NCHW map) in + 512 out (+ 128 of the 4x smaller previous level); flops 2 * 384 * D
+          mask_decode (K2)  bytes: 512 in + 4 L + 1 out (finest level only); flops 2 * L * D"""
+        D, L, T = self.cfg["dh_dim"], self.L, self.T
         px = [h * w for (h, w) in self.sizes]
-        k3 = sum(n * hw * 1536 for hw, n in self.k1_launch_shapes())
-        k4 = sum(hw * (1024 + (128 if i else 0)) for i, hw in enumerate(px))
-        k2 = px[-1] * (512 + 4 * self.L + 1)
-        return {"kv_project": self.T * k3, "level_fuse": self.T * k4, "mask_decode": self.T * k2}
+        ps = sum(n * hw for hw, n in self.k1_launch_shapes())              # pixel-stages per frame
+        stages = sum(n for _, n in self.k1_launch_shapes())
+        out = {
+            "level_fuse": {"bytes": T * sum(hw * (1024 + (128 if i else 0)) for i, hw in enumerate(px)), "flops": T * sum(px) * 2 * 384 * D},
+            "mask_decode": {"bytes": T * px[-1] * (512 + 4 * L + 1), "flops": T * px[-1] * 2 * L * D},
+        }
+        if self.retriever_form == "fused":
+            tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
+            out["retr_stats"] = {"bytes": T * ps * (512 + 8 + 64), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
+            out["retr_attn"] = {"bytes": T * (ps * (512 + 8 + 64) + stages * (L * D * 4 + L * 264 * 4) + tabs), "flops": T * ps * 4 * L * D}
+        else:
+            out["kv_project"] = {"bytes": T * ps * 1536, "flops": T * ps * 4 * D * D}
+            out["slot_attn"] = {"bytes": self.k1_algorithmic_bytes_per_step(), "flops": T * ps * 4 * L * D}
+        return out

@@ -139,7 +139,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         // tables through buffer descriptors (scalar registers) + 32-bit lane offsets: no 64-bit pointers in vector registers
         auto uniform_rsrc = [](const void* p, int bytes) {          // every word provably wave-uniform: no waterfall loops
             const uint64_t a = reinterpret_cast<uint64_t>(p);
-            const uint64_t u = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)a);
+            // readfirstlane returns a SIGNED int: widen through uint32_t or the low word sign-extends into the high one
+            const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
             return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
         };
         const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * 128, H * 512);

@@ -22,8 +22,13 @@
 // Mapping: 8 waves, two per SIMD. Waves 0-3 = key projection (operand bf16(f + pos), built in LDS by themselves for the
 // NEXT tile, double-buffered), waves 4-7 = value projection (operand = the feature tile as it arrives) and all LDS-DMA
 // (feature tiles three ahead in a 4-deep ring, position rows two ahead in a double buffer). One workgroup barrier per tile.
-// Storage policy: f is bf16 (by definition of the fast path), the operand f + pos is rounded to bf16 (as in K3), R is bf16;
-// accumulation and everything after it fp32. A rounding of R or x perturbs rstd by ~4e-5 relative (random, 256 terms).
+// Precision. rstd_k multiplies logits of magnitude up to ~80 in front of a sharp softmax: it has to be good to ~1e-4, and
+// with bf16 operands it is not (measured 3e-4 mean / 1e-3 max relative, mostly the rounding of f + pos). The KEY side
+// therefore runs on v_mfma_f32_32x32x16_f16: R_k is handed over as fp16 and the operand is built as fp16(f + pos) - three
+// more mantissa bits on both operands at the same matrix rate (f is stored as bf16, so fp16(f) loses nothing unless
+// |f + pos| >= 65504, which overflows to inf and shows up as NaN downstream - fused maps are O(10)). rstd_v only scales the
+// contribution of its own pixel to a sum over thousands of pixels; the VALUE side stays bf16 x bf16 on the tile as it arrives
+// (1e-4 mean / 4e-4 max). Accumulation and everything after it is fp32.
 #include <cstdlib>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
@@ -84,6 +89,8 @@ __device__ __forceinline__ void st_dma16x4(u32x4 srd, uint32_t lds_addr, int v0,
         : "memory");
 }
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
 __device__ __forceinline__ float st_half_swap_add(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -94,8 +101,8 @@ __device__ __forceinline__ void retr_stats_role(
     const __bf16* __restrict__ feat,    // [T, HW, 256]
     const float* __restrict__ pos_y,    // [H, 128] or null
     const float* __restrict__ pos_x,    // [W, 128] or null
-    const __bf16* __restrict__ rk,      // [256, 256] bf16 upper triangular (row = output row of R_k)
-    const __bf16* __restrict__ rv,
+    const __bf16* __restrict__ rk,      // [256, 256] FP16 bits, upper triangular (row = output row of R_k)
+    const __bf16* __restrict__ rv,      // [256, 256] bf16, upper triangular
     const float* __restrict__ rbk,      // [256] r_k (the QR-transformed centred bias)
     const float* __restrict__ rbv,
     float eps_k, float eps_v,
@@ -205,12 +212,11 @@ __device__ __forceinline__ void retr_stats_role(
             }
         }
     };
-    const int pa = aligned_rows ? 2 : 1;                                 // position rows: tiles ahead
+    const int pa = (aligned_rows || !HAS_POS) ? 2 : 1;                   // position rows: tiles ahead
     const int npos = HAS_POS ? (aligned_rows ? (j == 0 ? 5 : 4) : 8) : 0;
 
     // xk(tile) = bf16(f(tile) + pos(tile)) by the key waves, LDS only: thread -> 16-byte chunk cpos of pixel rows q + 8u
     auto build_xk = [&](int tile) {
-        if constexpr (!HAS_POS) return;
         int lt = tid;
         asm volatile("" : "+v"(lt));
         const int q = lt >> 5, cpos = lt & 31;
@@ -226,19 +232,24 @@ __device__ __forceinline__ void retr_stats_role(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             fv[u] = *reinterpret_cast<const bf16x8*>(smem + ((u & 1) ? fo : fe) + u * 8 * kRowBytes);
-            const char* pt = smem + pb + u * ps;
-            pv[u][0] = *reinterpret_cast<const f32x4*>(pt);
-            pv[u][1] = *reinterpret_cast<const f32x4*>(pt + 16);
+            if constexpr (HAS_POS) {
+                const char* pt = smem + pb + u * ps;
+                pv[u][0] = *reinterpret_cast<const f32x4*>(pt);
+                pv[u][1] = *reinterpret_cast<const f32x4*>(pt + 16);
+            } else {
+                pv[u][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pv[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            bf16x8 o;
+            f16x8 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                o[i] = (__bf16)((float)fv[u][i] + pv[u][0][i]);
-                o[4 + i] = (__bf16)((float)fv[u][4 + i] + pv[u][1][i]);
+                o[i] = (_Float16)((float)fv[u][i] + pv[u][0][i]);
+                o[4 + i] = (_Float16)((float)fv[u][4 + i] + pv[u][1][i]);
             }
-            *reinterpret_cast<bf16x8*>(smem + xo + u * 8 * Lds::kXkRow) = o;
+            *reinterpret_cast<f16x8*>(smem + xo + u * 8 * Lds::kXkRow) = o;
         }
     };
 
@@ -250,7 +261,7 @@ __device__ __forceinline__ void retr_stats_role(
 
     // sum of squares of (R x + r) over this wave's 64 rows, per pixel
     auto heavy = [&](int it) {
-        const bool padded = HAS_POS && proj == 0;
+        constexpr bool padded = proj == 0;                     // key operand: the fp16 tile built by build_xk (padded rows)
         const char* bt = padded ? smem + Lds::xk + (it & 1) * Lds::kXkTile : smem + Lds::fring + (it % kStNF) * kTileBytes;
         int rr = r, hh = h;
         asm volatile("" : "+v"(rr), "+v"(hh));
@@ -272,7 +283,11 @@ __device__ __forceinline__ void retr_stats_role(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ks = 4 * grp + u;
-                if constexpr (true) {
+                if constexpr (proj == 0) {                      // key side: fp16 x fp16
+                    const f16x8 xh = __builtin_bit_cast(f16x8, xf[u]);
+                    if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0]), xh, a0, 0, 0, 0);
+                    if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0]), xh, a1, 0, 0, 0);
+                } else {
                     if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0], xf[u], a0, 0, 0, 0);
                     if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0], xf[u], a1, 0, 0, 0);
                 }

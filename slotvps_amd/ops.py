@@ -246,17 +246,17 @@ def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=No
 # ---- statistics-fused retriever (csrc/retr_stats.hip, csrc/retr_attn.hip) -------------------------------------------
 def retr_stats(feat, H, W, pos_tabs, rk, rbk, eps_k, rv, rbv, eps_v):
     """K3': per-pixel reciprocal standard deviations of the key / value LayerNorms (+ the aux rows K1' consumes).
-    feat [T, H*W, 256] bf16; rk / rv [256, 256] bf16 upper-triangular QR factors of the centred projections; rbk / rbv [256]
-    fp32. Returns rstd_k [T, HW], rstd_v [T, HW] fp32, aux [T, HW, 32] bf16."""
+    feat [T, H*W, 256] bf16; rk [256, 256] fp16 / rv [256, 256] bf16: upper-triangular QR factors of the centred
+    projections; rbk / rbv [256] fp32. Returns rstd_k [T, HW], rstd_v [T, HW] fp32, aux [T, HW, 32] bf16."""
     lib = _lib.load()
     _need(feat, "feat", torch.bfloat16, 3)
     T, HW, D = feat.shape
     if HW != H * W:
         raise ValueError("feat rows != H*W")
-    for name, x in (("rk", rk), ("rv", rv)):
-        _need(x, name, torch.bfloat16, 2)
-        if x.shape != (D, D):
-            raise ValueError(f"{name} must be [256, 256]")
+    _need(rk, "rk", torch.float16, 2)           # key factor fp16, value factor bf16 (see the kernel header)
+    _need(rv, "rv", torch.bfloat16, 2)
+    if rk.shape != (D, D) or rv.shape != (D, D):
+        raise ValueError("rk / rv must be [256, 256]")
     _need(rbk, "rbk", torch.float32, 1)
     _need(rbv, "rbv", torch.float32, 1)
     ytab = xtab = None

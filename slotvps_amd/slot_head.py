@@ -123,7 +123,8 @@ class MaskDynamicConv(nn.Module):
                 wc = w - w.mean(dim=0, keepdim=True)                    # subtract the mean over OUTPUT channels (rows)
                 bc = b - b.mean()
                 r = torch.linalg.qr(torch.cat([wc, bc[:, None]], dim=1), mode="r").R          # [256, 257] upper trapezoidal
-                out["r" + name] = torch.triu(r[:, :256]).to(dev).to(BF16).contiguous()
+                # key factor as fp16, value factor as bf16 (csrc/retr_stats.hip, "Precision")
+                out["r" + name] = torch.triu(r[:, :256]).to(dev).to(torch.float16 if name == "k" else BF16).contiguous()
                 out["rb" + name] = r[:, 256].float().to(dev).contiguous()
                 out["wc" + name], out["bc" + name] = wc, bc
             out["wck"] = out["wck"].float().to(dev).contiguous()                               # Q'' = (q * gamma_k) @ W~_k

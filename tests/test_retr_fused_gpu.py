@@ -54,12 +54,13 @@ def test_retr_stats(cuda, T, H, W, pos):
         f64 = feat[t].astype(np.float64)
         uk = orc.linear(f64 + pm, d("to_k.weight"), d("to_k.bias"))
         uv = orc.linear(f64, d("to_v.weight"), d("to_v.bias"))
-        for got, u in ((rk[t], uk), (rv[t], uv)):
+        for got, u, bound in ((rk[t], uk, 1.5e-4), (rv[t], uv, 1e-3)):
             ref = 1.0 / np.sqrt(u.var(axis=1) + 1e-5)
             rel = np.abs(got - ref) / ref
-            # bf16 rounding of the operand (f + pos) and of the triangular factor: ~2^-9 relative per element, averaged over
-            # 256 random terms -> a few 1e-5 on the variance; bound 5e-4
-            assert rel.max() <= 5e-4, rel.max()
+            # key side fp16 x fp16 (2^-12 relative per element, averaged over ~100 random terms): measured ~2e-5 mean;
+            # value side bf16 x bf16: measured 1e-4 mean / 4.7e-4 max (harmless there, see the kernel header)
+            print(f"rstd rel err max {rel.max():.2e} mean {rel.mean():.2e} (bound {bound:.1e})")
+            assert rel.max() <= bound, rel.max()
         sig = 1.0 / rv[t].astype(np.float64)
         assert np.all(aux[t][:, 0] == 1.0) and np.all(aux[t][:, 3:] == 0.0)
         assert np.abs(aux[t][:, 1].astype(np.float64) + aux[t][:, 2] - sig).max() <= 3e-5 * sig.max()   # hi + lo: 16-bit mantissa
