@@ -189,18 +189,24 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             asm volatile("" : "+v"(rr), "+v"(hh));              // opaque per iteration: no hoisted fragment address tables
             const bool live = px_begin + it * kTilePx + r < px_end;
             f32x16 s = cinit;
+            {   // row fragments in groups of four, double-buffered: the reads of group g+1 fly under the 8 MFMAs of group g
+                bf16x8 kf[2][4];
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {              // fragments in two batches of eight (register budget)
-                bf16x8 kf[8];
+                for (int u = 0; u < 4; ++u) kf[0][u] = read_row_frag(kt, u, rr, hh);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) kf[u] = read_row_frag(kt, 8 * half + u, rr, hh);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int grp = 0; grp < 4; ++grp) {
+                    if (grp < 3) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[8 * half + u], kf[u], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[8 * half + u], kf[u], s, 0, 0, 0);
+                        for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = read_row_frag(kt, 4 * (grp + 1) + u, rr, hh);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             const float rk_c = rk, tau_c = tau;
             if (it + 1 < nt) request(it + 1);
@@ -319,16 +325,20 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(a0 + 8192)),
             __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(a1 + 8192)), 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8 af = read_col_frag_aux(at, ks, ln);
+        bf16x8 vf[2][4];                                        // value fragments double-buffered in two halves of four blocks
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vf[0][u] = read_col_frag(vt, ks, u, ln);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            bf16x8 vf[4];
+            if (half == 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) vf[u] = read_col_frag(vt, ks, 4 * half + u, ln);
+                for (int u = 0; u < 4; ++u) vf[1][u] = read_col_frag(vt, ks, 4 + u, ln);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vf[u], o[4 * half + u], 0, 0, 0);
-                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vf[u], o[4 * half + u], 0, 0, 0);
+                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vf[half][u], o[4 * half + u], 0, 0, 0);
+                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vf[half][u], o[4 * half + u], 0, 0, 0);
             }
             if (half == 0) {
                 oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, af, oa, 0, 0, 0);

@@ -96,7 +96,9 @@ __device__ __forceinline__ float st_half_swap_add(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <bool HAS_POS, int PROJ, int J>
+// ABL: timing-only ablations (env SVPS_STATS_ABLATE), outputs wrong. 1: no MFMA  2: no build of the key operand
+// 4: no position DMA  8: no feature DMA after the prologue  16: no finish (statistics combine + stores)
+template <bool HAS_POS, int PROJ, int J, int ABL = 0>
 __device__ __forceinline__ void retr_stats_role(
     const __bf16* __restrict__ feat,    // [T, HW, 256]
     const float* __restrict__ pos_y,    // [H, 128] or null
@@ -163,6 +165,7 @@ __device__ __forceinline__ void retr_stats_role(
     }
     auto stage_f = [&](int tile) {
         if (tile >= nt) return;
+        if constexpr (ABL & 8) { if (tile >= kStNF) return; }
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (tile % kStNF) * kTileBytes + j * 4096);
         const int px0 = px_begin + tile * kTilePx;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
@@ -184,6 +187,7 @@ __device__ __forceinline__ void retr_stats_role(
     // waits below rely on it)
     auto stage_pos = [&](int tile) {
         if constexpr (!HAS_POS) return;
+        if constexpr (ABL & 4) return;
         if (tile >= nt) return;
         const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::posy_of(aligned_rows, tile) + j * 4096);
         const uint32_t sx = __builtin_amdgcn_readfirstlane(lds0 + Lds::posx_of(aligned_rows, tile) + j * 4096);
@@ -217,6 +221,7 @@ __device__ __forceinline__ void retr_stats_role(
 
     // xk(tile) = bf16(f(tile) + pos(tile)) by the key waves, LDS only: thread -> 16-byte chunk cpos of pixel rows q + 8u
     auto build_xk = [&](int tile) {
+        if constexpr (ABL & 2) return;
         int lt = tid;
         asm volatile("" : "+v"(lt));
         const int q = lt >> 5, cpos = lt & 31;
@@ -272,24 +277,30 @@ __device__ __forceinline__ void retr_stats_role(
         for (int k8 = 0; k8 < 8; ++k8)
             o8[k8] = padded ? rr * Lds::kXkRow + ((2 * k8 + hh) << 4) : rr * kRowBytes + (((2 * k8 + hh) ^ s4) << 4);
         auto frag = [&](int ks) { return *reinterpret_cast<const bf16x8*>(bt + o8[ks & 7] + (ks >> 3) * 256); };
-        // k-steps 2j .. 15 for row block j; row block 7-j joins from k-step 2(7-j). Fragments in groups of four.
+        // k-steps 2j .. 15 for row block j; row block 7-j joins from k-step 2(7-j). Fragments in groups of four, double-
+        // buffered: the reads of group g+1 are in flight under the MFMAs of group g (no exposed LDS latency after the first)
+        constexpr int G0 = (2 * j) / 4;                          // first group that holds a k-step >= 2j
+        bf16x8 xf[2][4];
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            if (4 * grp + 3 < 2 * j) continue;                  // this group lies entirely left of the diagonal block
-            bf16x8 xf[4];
+        for (int u = 0; u < 4; ++u) xf[G0 & 1][u] = frag(4 * G0 + u);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xf[u] = frag(4 * grp + u);
+        for (int grp = G0; grp < 4; ++grp) {
+            if (grp < 3) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xf[(grp + 1) & 1][u] = frag(4 * (grp + 1) + u);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ks = 4 * grp + u;
+                if constexpr (ABL & 1) continue;
                 if constexpr (proj == 0) {                      // key side: fp16 x fp16
-                    const f16x8 xh = __builtin_bit_cast(f16x8, xf[u]);
+                    const f16x8 xh = __builtin_bit_cast(f16x8, xf[grp & 1][u]);
                     if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0]), xh, a0, 0, 0, 0);
                     if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0]), xh, a1, 0, 0, 0);
                 } else {
-                    if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0], xf[u], a0, 0, 0, 0);
-                    if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0], xf[u], a1, 0, 0, 0);
+                    if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0], xf[grp & 1][u], a0, 0, 0, 0);
+                    if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0], xf[grp & 1][u], a1, 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -306,6 +317,7 @@ __device__ __forceinline__ void retr_stats_role(
     // statistics of tile `it` -> HBM, by wave 0 of each projection (after the barrier that follows heavy(it))
     auto finish = [&](int it) {
         if (j != 0) return;
+        if constexpr (ABL & 16) return;
         const float* sp = stats + ((it & 1) * 2 + proj) * 4 * 32 + r;
         const float tot = (sp[0] + sp[32]) + (sp[64] + sp[96]);
         const float sigma = sqrtf(tot * (1.f / kD) + eps);
@@ -347,7 +359,8 @@ __device__ __forceinline__ void retr_stats_role(
     for (int it = 0; it < nt; ++it) {
         if (proj) {
             // landed by now: everything except the feature tile requested last (f(it+2), issued in iteration it-1)
-            wait_vm_dyn(it + 2 < nt ? 4 : 0);
+            if constexpr (ABL & 8) wait_vm<0>();
+            else wait_vm_dyn(it + 2 < nt ? 4 : 0);
         }
         wg_barrier();
         if (it >= 1) finish(it - 1);
@@ -374,14 +387,14 @@ __device__ __forceinline__ void retr_stats_role(
     (void)npos;
 }
 
-template <bool HAS_POS>
+template <bool HAS_POS, int ABL = 0>
 __global__ __launch_bounds__(512) void retr_stats_kernel(
     const __bf16* __restrict__ feat, const float* __restrict__ pos_y, const float* __restrict__ pos_x,
     const __bf16* __restrict__ rk, const __bf16* __restrict__ rv, const float* __restrict__ rbk, const float* __restrict__ rbv,
     float eps_k, float eps_v, float* __restrict__ rstd_k, float* __restrict__ rstd_v, __bf16* __restrict__ aux,
     int HW, int W, int tiles_per_chunk) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#define SVPS_ROLE(P, JJ) retr_stats_role<HAS_POS, P, JJ>(feat, pos_y, pos_x, rk, rv, rbk, rbv, eps_k, eps_v, rstd_k, rstd_v, aux, HW, W, tiles_per_chunk)
+#define SVPS_ROLE(P, JJ) retr_stats_role<HAS_POS, P, JJ, ABL>(feat, pos_y, pos_x, rk, rv, rbk, rbv, eps_k, eps_v, rstd_k, rstd_v, aux, HW, W, tiles_per_chunk)
     switch (w) {                 // every role runs the same sequence of workgroup barriers
         case 0: SVPS_ROLE(0, 0); break;
         case 1: SVPS_ROLE(0, 1); break;
@@ -412,8 +425,25 @@ extern "C" int svps_retr_stats_fwd(const void* feat, const float* pos_y, const f
     chunks = (tiles + tpc - 1) / tpc;
     const bool has_pos = pos_y != nullptr;
     auto kern = has_pos ? svps::retr_stats_kernel<true> : svps::retr_stats_kernel<false>;
-    static SvpsLdsAttr attr[2];
-    if (hipError_t ae = attr[has_pos].ensure(reinterpret_cast<const void*>(kern), svps::StatsPLds::total); ae != hipSuccess)
+    int slot = has_pos;
+#ifdef SVPS_STATS_ABLATE
+    static const int abl = [] { const char* e = getenv("SVPS_STATS_ABLATE"); return e ? atoi(e) : 0; }();
+    if (has_pos && abl) {
+        switch (abl) {
+            case 1: kern = svps::retr_stats_kernel<true, 1>; slot = 2; break;
+            case 2: kern = svps::retr_stats_kernel<true, 2>; slot = 3; break;
+            case 4: kern = svps::retr_stats_kernel<true, 4>; slot = 4; break;
+            case 6: kern = svps::retr_stats_kernel<true, 6>; slot = 5; break;
+            case 8: kern = svps::retr_stats_kernel<true, 8>; slot = 6; break;
+            case 16: kern = svps::retr_stats_kernel<true, 16>; slot = 7; break;
+            case 7: kern = svps::retr_stats_kernel<true, 7>; slot = 8; break;
+            case 14: kern = svps::retr_stats_kernel<true, 14>; slot = 9; break;
+            default: break;
+        }
+    }
+#endif
+    static SvpsLdsAttr attr[10];
+    if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::StatsPLds::total); ae != hipSuccess)
         return (int)ae;
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::StatsPLds::total, stream, static_cast<const __bf16*>(feat),
