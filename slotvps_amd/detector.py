@@ -35,6 +35,66 @@ class _AttrDict(dict):
     __getattr__ = dict.get
 
 
+class SlotMasks:
+    """Mask logits of a clip, decoded on demand (K2). The reference materialises `pred_masks` for all L slots
+    ([L, h, w] fp32 per frame, vps_temporal_slots.py:297-308) and its post-process then keeps the few slots whose class
+    score passes the threshold (:685-691, computed from the [L, nc] class logits alone). Here the decode of a frame runs
+    AFTER that selection, on the kept slots only, in the order the post-process wants them: K2 then writes 4 K HW bytes
+    per frame instead of 4 L HW, and nobody gathers rows out of a [L, HW] tensor. `dense()` is the reference's all-slot
+    form (same kernel, bit-identical rows)."""
+
+    def __init__(self, fused, embeds, fold, hw):
+        self.fused, self.embeds, self.fold, self.hw = fused, embeds, fold, hw     # [T, HW, 256], [T, L, 256]
+        self._dense = None
+
+    @property
+    def shape(self):
+        return (self.embeds.shape[0], self.embeds.shape[1]) + tuple(self.hw)
+
+    @property
+    def is_cuda(self):
+        return self.fused.is_cuda
+
+    @property
+    def device(self):
+        return self.fused.device
+
+    def _decode(self, t0, t1, embed):
+        scale, shift, fs, fb = self.fold
+        decode = ops.mask_decode_f32 if self.fused.dtype == torch.float32 else ops.mask_decode   # exact mode: fp32 map
+        m = decode(self.fused[t0:t1], embed.contiguous(), scale, shift, fs, fb)
+        return m.view(m.shape[0], m.shape[1], *self.hw)
+
+    def dense(self):
+        if self._dense is None:
+            self._dense = self._decode(0, self.embeds.shape[0], self.embeds)
+        return self._dense
+
+    def __getitem__(self, t):
+        return FrameSlotMasks(self, int(t))
+
+
+class FrameSlotMasks:
+    """One frame of `SlotMasks`: `select(idx)` decodes the listed slots ([K, h, w], in that order)."""
+
+    def __init__(self, clip, t):
+        self.clip, self.t = clip, t
+
+    shape = property(lambda self: self.clip.shape[1:])
+    is_cuda = property(lambda self: self.clip.is_cuda)
+    device = property(lambda self: self.clip.device)
+
+    def select(self, idx):
+        c = self.clip
+        return c._decode(self.t, self.t + 1, c.embeds[self.t][idx][None])[0]
+
+    def dense(self):
+        return self.clip.dense()[self.t]
+
+    def cpu(self):
+        return self.dense().cpu()
+
+
 def _stuff_num(num_classes):
     """vps_capsule.py:47-57 / vps_temporal_slots.py:62-72."""
     if num_classes <= 20:
@@ -210,6 +270,9 @@ class VPS_Temporal_Slots(nn.Module):
         self.test_track_instances = None         # segment table of the last frame (the reference's attribute, :303-346)
         self._fold = None
         self.reuse_ref_features = True           # keep the previous frame's level maps
+        self.decode_selected = True              # K2 decodes only the slots the post-process keeps (SlotMasks)
+        self.use_graph = False                   # replay the slot head as one hipGraph per input geometry (_head_clip)
+        self._head_cache = {}
         self._trunk_bf16 = False
         self._ref_cache = None
         self.ref_reuse_hits = 0
@@ -264,19 +327,48 @@ class VPS_Temporal_Slots(nn.Module):
             feats = self.semantic_trans_ins(fcn_feature)
         return [f.float().contiguous() for f in feats], fcn_output.float()
 
-    @torch.no_grad()
-    def head_path(self, feats):
-        """HIP part: level maps -> (class logits [T, L, nc] of the last stage, slot embeddings [T, L, 256],
-        mask logits [T, L, H/4, W/4])."""
+    def _head_clip(self, feats):
+        """The slot head on one clip's level maps; with `use_graph` the whole head (about 200 launches) is captured once per
+        input geometry into a hipGraph and replayed on static buffers (the returned tensors are then valid until the next call)."""
         im = self.image_model
-        D = im.init_mask_query.weight.shape[1]
-        pos_tabs = [ops.pos_embed_sine_tables(f.shape[-2], f.shape[-1], D, f.device) for f in feats]
-        logits, embeds, fused = im.dynamic_mask_head.forward_clip(feats, im.init_mask_query.weight, pos_tabs)
-        scale, shift, fs, fb = self._decode_fold()
-        decode = ops.mask_decode_f32 if fused[-1].dtype == torch.float32 else ops.mask_decode     # exact mode: fp32 map
-        masks = decode(fused[-1], embeds[-1].contiguous(), scale, shift, fs, fb)
-        h, w = feats[-1].shape[-2:]
-        return logits[-1], embeds[-1], masks.view(masks.shape[0], masks.shape[1], h, w)
+        key = tuple(tuple(f.shape) for f in feats) + (str(feats[0].device),)
+        ent = self._head_cache.get(key)
+        if ent is None:
+            D = im.init_mask_query.weight.shape[1]
+            ent = {"pos": [ops.pos_embed_sine_tables(f.shape[-2], f.shape[-1], D, f.device) for f in feats], "graph": None}
+            self._head_cache = {key: ent}                    # one geometry at a time
+        run = lambda fs: im.dynamic_mask_head.forward_clip(fs, im.init_mask_query.weight, ent["pos"])
+        if not self.use_graph:
+            return run(feats)
+        if ent["graph"] is None:
+            dev = feats[0].device
+            ent["static"] = [f.clone() for f in feats]
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):                           # lazy initialisations, weight-derived constants, allocator
+                    run(ent["static"])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ent["out"] = run(ent["static"])
+            ent["graph"] = g
+        for dst, src in zip(ent["static"], feats):
+            dst.copy_(src)
+        ent["graph"].replay()
+        return ent["out"]
+
+    @torch.no_grad()
+    def head_path(self, feats, dense=None):
+        """HIP part: level maps -> (class logits [T, L, nc] of the last stage, slot embeddings [T, L, 256], mask logits).
+        Mask logits: `SlotMasks` (decoded per frame for the slots the post-process keeps) or, with dense=True /
+        self.decode_selected = False, the reference's [T, L, H/4, W/4] tensor of all slots."""
+        logits, embeds, fused = self._head_clip(feats)
+        masks = SlotMasks(fused[-1], embeds[-1].contiguous(), self._decode_fold(), tuple(feats[-1].shape[-2:]))
+        if dense is None:
+            dense = not self.decode_selected
+        return logits[-1], embeds[-1], masks.dense() if dense else masks
 
     @torch.no_grad()
     def slot_path(self, imgs):

@@ -82,7 +82,8 @@ class PostProcessPanopticInstances(nn.Module):
     # ---- the reference's forward, on tensors ---------------------------------------------------------
     @torch.no_grad()
     def forward_tensors(self, pred_logits, pred_masks, size, materialize_masks=False):
-        """pred_logits [L, nc], pred_masks [L, h, w] (GPU, fp32), size (H, W).
+        """pred_logits [L, nc], pred_masks [L, h, w] (GPU, fp32) or a lazy frame of mask logits with
+        `.select(slot_indices) -> [K, h, w]` (detector.FrameSlotMasks: only the kept slots are ever decoded), size (H, W).
         Returns a namespace: slot_index [K''] (into the L slots, the reference's filtered Instances order),
         probs, labels, (masks [K'', H, W] if materialize_masks), plus the state `panoptic_ids` needs."""
         if not pred_masks.is_cuda:
@@ -106,7 +107,10 @@ class PostProcessPanopticInstances(nn.Module):
         sc, cl = sc[order], cl[order]
         K = len(sc)
         thing = [bool(c > self.num_stuff - 1) for c in cl]                                           # :594
-        m_sorted = pred_masks[sorted_idx].float().contiguous()
+        if hasattr(pred_masks, "select"):                            # decode the kept slots only, already in score order
+            m_sorted = pred_masks.select(sorted_idx).float().contiguous()
+        else:
+            m_sorted = pred_masks[sorted_idx].float().contiguous()
         thing_u8 = torch.tensor(thing, dtype=torch.uint8, device=dev)
         cand, counts, pairs = self._candidates(m_sorted, thing_u8, size)
         n_px = size[0] * size[1]

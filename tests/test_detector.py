@@ -144,6 +144,9 @@ def test_clip_flow_matches_oracle_pipeline():
     logits, embeds, masks, fcn = det.slot_path(imgs)
     assert logits.shape == (T, 100, 20) and embeds.shape == (T, 100, 256) and masks.shape == (T, 100, H // 4, W // 4)
     assert fcn.shape == (T, 19, H, W)
+    # the decode runs on demand for the slots the post-process keeps; the kept rows equal those of the all-slot decode bit for bit
+    pick = torch.tensor([7, 3, 99, 0, 41], device=dev)
+    assert torch.equal(masks[1].select(pick), masks.dense()[1][pick])
     # random-init slots all predict one class: add a fixed per-slot class preference so that stuff, things,
     # duplicates of a stuff class and "no object" all occur. The frozen outputs are handed to both sides (the
     # PyTorch backbone is not run-to-run deterministic - MIOpen picks algorithms at first use).
@@ -241,7 +244,7 @@ def test_baseline_config0_512x1024_first_frame():
         det(img=[img], img_meta=[[meta]], return_loss=False, rescale=True, ref_img=[img])
     feats, fcn = det.trunk(img)
     assert [tuple(f.shape[-2:]) for f in feats] == [(16, 32), (32, 64), (64, 128), (128, 256)] and fcn.shape == (1, 19, H, W)
-    logits, embeds, masks = det.head_path([torch.cat([f, f], 0) for f in feats])
+    logits, embeds, masks = det.head_path([torch.cat([f, f], 0) for f in feats], dense=True)   # the reference's all-slot form
     assert logits.shape == (2, 100, 20) and masks.shape == (2, 100, 128, 256) and torch.isfinite(masks).all()
     assert torch.equal(logits[0], logits[1]) and torch.equal(masks[0], masks[1])      # identical frames, per-frame kernels
     with torch.no_grad():                                      # slot l prefers class l % 19, strongly
