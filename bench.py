@@ -217,135 +217,6 @@ def single_clip_latency(a, dev):
     return round((time.perf_counter() - t0) / 20 * 1e3, 3)
 
 
-def note(msg):
-    """Progress on stderr (a silent leg of several minutes looks hung to the GPU runner)."""
-    print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
-
-def host_cores():
-    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota where one is set (a box that
-    shows 128 logical CPUs but grants 16 would be timed 8x oversubscribed otherwise)."""
-    n = os.cpu_count() or 1
-    try:
-        n = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            with open(path) as fh:
-                txt = fh.read().split()
-            if path.endswith("cpu.max"):
-                quota, period = txt[0], float(txt[1])
-            else:
-                quota = txt[0]
-                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
-                    period = float(fh2.read())
-            if quota not in ("max", "-1"):
-                n = max(1, min(n, int(float(quota) / period + 0.5)))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n
-
-
-def cpu_baseline(a):
-    """the PyTorch-CPU restatement of the slot head + mask decode (oracle/torch_cpu_head.py; the
-    reference's own files do not travel) on the host cores of this box: one T-frame clip per iteration, fp32,
-    torch.set_num_threads(all cores) - 1 warm-up, then timed iterations until ~cpu_seconds (at least 3, at most 10), median -
-    and one timed iteration at 8 threads for comparability with the survey container."""
-    import statistics
-    import numpy as np
-    from oracle import slotvps_oracle as orc
-    from oracle.torch_cpu_head import TorchCpuHead
-    from slotvps_amd import synth
-    cores = host_cores()
-    params = synth.make_params(synth.head_shapes(), 0)
-    head = TorchCpuHead(params)
-    sizes = synth.level_sizes(a.height, a.width)
-    pos = [torch.from_numpy(orc.pos_embed_sine(h, w)) for (h, w) in sizes]
-    g = torch.Generator().manual_seed(1)
-    T = a.frames
-    feats = [[torch.randn((128, h, w), generator=g) for (h, w) in sizes] for _ in range(T)]
-    slots = torch.from_numpy(synth.make_slots(1, a.slots))
-    scale, shift = torch.ones(256), torch.zeros(256)
-
-    def clip():
-        _, embeds, fused = head.forward(feats, slots, pos)
-        for t in range(T):
-            TorchCpuHead.mask_decode(fused[t][3], embeds[t][-1], scale, shift, 0.1, 0.0).argmax(0)
-
-    def timed(n_threads, budget, lo, hi, warm):
-        torch.set_num_threads(n_threads)
-        ts, t_all = [], time.perf_counter()
-        if warm:
-            clip()
-            note(f"cpu_baseline: warm-up clip at {n_threads} threads took {time.perf_counter() - t_all:.1f} s")
-        t_all = time.perf_counter()
-        while len(ts) < hi and (len(ts) < lo or time.perf_counter() - t_all < budget):
-            t0 = time.perf_counter()
-            clip()
-            ts.append(time.perf_counter() - t0)
-            note(f"cpu_baseline: clip {len(ts)} at {n_threads} threads: {ts[-1]:.2f} s")
-        return ts
-
-    keep = torch.get_num_threads()
-    ts = timed(cores, a.cpu_seconds, 2, 10, True)
-    ts8 = timed(min(8, cores), 0.0, 1, 1, False)
-    torch.set_num_threads(keep)
-    med = statistics.median(ts)
-    return {"value": round(T / med, 4), "unit": "frames/s", "cores": int(cores), "kind": "port",
-            "value_8_threads": round(T / ts8[0], 4), "median_s_per_clip": round(med, 3), "min_s_per_clip": round(min(ts), 3),
-            "iterations": len(ts),
-            "sample": f"{len(ts)} timed {a.height}x{a.width} T={T} L={a.slots} clips (7-stage head + mask decode of every frame) "
-                      f"after 1 warm-up, PyTorch CPU fp32 restatement of the reference's head (oracle/torch_cpu_head.py, "
-                      f"frames looped in Python like the reference), torch.set_num_threads({cores}); median reported; "
-                      f"plus 1 clip at {min(8, cores)} threads"}
-
-
-def whole_detector_leg(a, dev):
-    """Informational, rank 0 at N=1, outside the timed region and never part of `value`: one synthetic T-frame clip through
-    the WHOLE detector of configs/r50_fpn_slotvps_mi355x.py - ResNet-50 + FPN + semantic tower in PyTorch-ROCm (fp32, as
-    the reference runs them; random weights), the slot head and decode of this library (eager, one clip, no stacking), the
-    GPU post-process and the tracker (detector.VPS_Temporal_Slots.clip_test). Says what the hot path is a part of."""
-    from slotvps_amd.config import Config
-    from slotvps_amd.registry import build_detector
-    cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "r50_fpn_slotvps_mi355x.py"))
-    torch.manual_seed(0)
-    det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
-    T, H, W = a.frames, a.height, a.width
-    imgs = torch.randn(T, 3, H, W, device=dev)
-    # random-init slots all predict "no object": a fixed slot -> class table lets segments survive the post-process (SURVEY 8d)
-    table = torch.zeros(a.slots, 20, device=dev)
-    table[torch.arange(a.slots), torch.arange(a.slots) % 19] = 12.0
-    with torch.no_grad():
-        det.image_model.fg_bn.weight.fill_(40.0)
-    base = det.head_path
-    det.head_path = lambda f: (lambda lg, em, mk: (lg + table, em, mk))(*base(f))
-    metas = [dict(iid=10001 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png") for t in range(T)]
-
-    def timed(fn, n=2):
-        fn()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(n):
-            out = fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n * 1e3, out
-
-    with torch.no_grad():
-        t_trunk, (feats, _fcn) = timed(lambda: det.trunk(imgs))
-        t_head, _ = timed(lambda: det.head_path(feats))
-        t_all, res = timed(lambda: det.clip_test(imgs, metas))
-        det.trunk_bf16 = True
-        t_all16, _ = timed(lambda: det.clip_test(imgs, metas))
-    return {"value": round(T / t_all * 1e3, 2), "unit": "frames/s", "ms_per_clip": round(t_all, 2),
-            "trunk_ms": round(t_trunk, 2), "slot_head_and_decode_ms": round(t_head, 2),
-            "post_process_and_tracker_ms": round(t_all - t_trunk - t_head, 2),
-            "value_with_bf16_autocast_trunk": round(T / t_all16 * 1e3, 2),
-            "segments_per_frame": [int(len(r["panoptic_cls_inds"])) for r in res],
-            "what": f"one {H}x{W} T={T} clip, whole detector, PyTorch fp32 trunk + this library, eager, n_gpus=1; informational"}
-
-
 def launch_ranks(a, argv):
     """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: this process becomes the launcher. It has
     not touched the GPU (no torch.cuda / HIP call above this point) and never will: it starts one rank per GPU as child

@@ -229,12 +229,15 @@ int svps_probe_tile(const void* x, void* rows, void* cols, void* stream);
  *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] bf16 = {1, hi(1/rstd_v), lo(1/rstd_v), 0 ...}
  *
  * svps_retr_attn_fwd    (:435-456)
- *   qh, ql [T, 128, 256] bf16: hi / lo halves of Q'' = (q * gamma_k) W~_k, rows >= L zero   (q = norm_q(to_q(slots)), :431)
- *   cy [T, H, 128], cx [T, W, 128] fp32: Q''[:, :128] . pos_y[y] + (q * gamma_k) . b~_k  and  Q''[:, 128:] . pos_x[x]
- *   c3 [T, 128] fp32: q . beta_k
+ *   The slot axis of the inputs is padded to LP = 128 rows (L <= 128) or 256 rows (L <= 256), rows >= L zero:
+ *   qh, ql [T, LP, 256] bf16: hi / lo halves of Q'' = (q * gamma_k) W~_k   (q = norm_q(to_q(slots)), :431)
+ *   cy [T, H, LP], cx [T, W, LP] fp32: Q''[:, :128] . pos_y[y] + (q * gamma_k) . b~_k  and  Q''[:, 128:] . pos_x[x]
+ *   c3 [T, LP] fp32: q . beta_k
  *   out_ext [T, L, 264] fp32: { A_l = sum_p P rstd_v f_p (256), s1_l = sum_p P rstd_v, s0_l = sum_p P, 0 x 6 };
  *       pre-LayerNorm output (:456) = out_ext @ [ (gamma_v * W~_v)^T ; gamma_v * b~_v ; beta_v ; 0 ]
- *   1 <= L <= 128; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 264] fp32
+ *   1 <= L <= 256; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 264] fp32
+ *   (+ [T, HW] x 8 B when L > 128: per-pixel softmax statistics over all slots, written by a first kernel; the retriever then
+ *   runs once per half of the slots)
  * ------------------------------------------------------------------------------------------- */
 int svps_retr_stats_fwd(const void* feat, const float* pos_y, const float* pos_x, const void* rk, const float* rbk,
                         float lnk_eps, const void* rv, const float* rbv, float lnv_eps, float* rstd_k, float* rstd_v,

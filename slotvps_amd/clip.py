@@ -120,7 +120,7 @@ class SlotClipRunner:
     def retriever_form(self):
         for m in self.head.modules():
             if hasattr(m, "retriever"):
-                return m.retriever if self.L <= 128 else "kv"
+                return m.retriever
         return "kv"
 
     def k1_algorithmic_bytes_per_step(self):

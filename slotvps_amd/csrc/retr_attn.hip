@@ -90,19 +90,23 @@ __device__ __forceinline__ bf16x8 read_col_frag_aux(const char* at, int ks, int 
 }
 
 // ABL: timing-only ablations (env SVPS_RETR_ABLATE), outputs wrong. 1: DMA + barriers only  2: producers only  4: consumers only
-template <int ABL = 0>
+// EXT (more than 128 slots, LP = 256): the launch covers the `L` slots starting at row `slot_off`; the per-pixel softmax
+// statistics over ALL slots come from `ext_stats` ([T, HW] of (max logit, 1 / sum of exponentials), written by
+// retr_logit_stats_kernel) instead of the exchange between the four producers: one softmax pass, no second payload.
+template <int ABL = 0, bool EXT = false>
 __global__ __launch_bounds__(512) void retr_attn_kernel(
-    const __bf16* __restrict__ qh,      // [T, 128, 256]  hi(Q''), rows >= L zero
-    const __bf16* __restrict__ ql,      // [T, 128, 256]  lo(Q'')
-    const float* __restrict__ cy,       // [T, H, 128]    Q''[:, 0:128] . ytab[y] + a'
-    const float* __restrict__ cx,       // [T, W, 128]    Q''[:, 128:256] . xtab[x]
-    const float* __restrict__ c3g,      // [T, 128]
+    const __bf16* __restrict__ qh,      // [T, LP, 256]  hi(Q''), rows >= the real slot count zero
+    const __bf16* __restrict__ ql,      // [T, LP, 256]  lo(Q'')
+    const float* __restrict__ cy,       // [T, H, LP]    Q''[:, 0:128] . ytab[y] + a'
+    const float* __restrict__ cx,       // [T, W, LP]    Q''[:, 128:256] . xtab[x]
+    const float* __restrict__ c3g,      // [T, LP]
     const __bf16* __restrict__ feat,    // [T, HW, 256]
     const float* __restrict__ rstd_k,   // [T, HW]
     const float* __restrict__ rstd_v,   // [T, HW]
     const __bf16* __restrict__ aux,     // [T, HW, 32]
-    float* __restrict__ partial,        // [T, C, L, 264]
-    int L, int HW, int H, int W, float inv_w, int tiles_per_chunk) {
+    float* __restrict__ partial,        // [T, C, Lrow, 264]
+    int L, int HW, int H, int W, float inv_w, int tiles_per_chunk, int LP, int Lrow, int slot_off,
+    const float2* __restrict__ ext_stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Lds = RetrLds;
     constexpr int A = kRPrefetch;
@@ -121,13 +125,13 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
 
     float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
     float* c3l = reinterpret_cast<float*>(smem + Lds::c3);
-    if (threadIdx.x < 128) c3l[threadIdx.x] = c3g[(size_t)t * 128 + threadIdx.x];
+    if (threadIdx.x < 128) c3l[threadIdx.x] = c3g[(size_t)t * LP + slot_off + threadIdx.x];
 
     if (!consumer) {
         // ================================ producer =============================================
         bf16x8 qfh[16], qfl[16];
         {
-            const size_t row = ((size_t)t * 128 + 32 * sb + r) * kD + 8 * h;
+            const size_t row = ((size_t)t * LP + slot_off + 32 * sb + r) * kD + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 qfh[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
@@ -144,8 +148,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
             return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
         };
-        const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * 128, H * 512);
-        const __amdgpu_buffer_rsrc_t cxr = uniform_rsrc(cx + (size_t)t * W * 128, W * 512);
+        const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * LP + slot_off, H * LP * 4 - slot_off * 4);
+        const __amdgpu_buffer_rsrc_t cxr = uniform_rsrc(cx + (size_t)t * W * LP + slot_off, W * LP * 4 - slot_off * 4);
+        const __amdgpu_buffer_rsrc_t exr = uniform_rsrc(EXT ? (const void*)(ext_stats + (size_t)t * HW) : (const void*)rstd_k, EXT ? HW * 8 : 0);
         const __amdgpu_buffer_rsrc_t rkr = uniform_rsrc(rstd_k + (size_t)t * HW, HW * 4);
         const __amdgpu_buffer_rsrc_t rvr = uniform_rsrc(rstd_v + (size_t)t * HW, HW * 4);
         // Position terms and statistics of this lane's pixel of tile `tile` (L2-resident tables): requested one tile ahead,
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         // INITIAL value of the next tile's accumulator.
         f32x4 cyv[4], cxv[4];
         float rk_n, tau_n;
+        f32x2 ext_n = {0.f, 0.f};
         auto request = [&](int tile) {
             int px = px_begin + tile * kTilePx + r;
             px = px < HW ? px : HW - 1;
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             int xx = px - yy * W;
             if (xx < 0) { xx += W; --yy; }
             if (xx >= W) { xx -= W; ++yy; }
-            const int yo = (yy * 128 + slot0) * 4, xo = (xx * 128 + slot0) * 4;
+            const int yo = (yy * LP + slot0) * 4, xo = (xx * LP + slot0) * 4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 cyv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
@@ -168,10 +174,13 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             }
             rk_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rkr, px * 4, 0, 0));
             tau_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvr, px * 4, 0, 0));
+            if constexpr (EXT) ext_n = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(exr, px * 8, 0, 0));
         };
         f32x16 cinit;
         float rk, tau;
+        f32x2 ext = {0.f, 0.f};
         auto settle = [&]() {
+            ext = ext_n;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -209,8 +218,34 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 }
             }
             const float rk_c = rk, tau_c = tau;
+            const f32x2 ext_c = ext;
             if (it + 1 < nt) request(it + 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (EXT) {
+                // statistics over all slots are known: P = exp(S - max) / sum, one pass, no exchange
+                const float mneg = -ext_c[0] * kLog2e;
+                float fac = ext_c[1] * tau_c;
+                if (!live) fac = 0.f;
+                wg_barrier();                                    // B_stats(it)
+                char* prow = smem + Lds::pring + (it & 1) * kTileBytes + sb * 2048 + r * 64 + 8 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 c3v = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
+                    bf16x4 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = slot0 + j + 8 * g < L;
+                        const float v = fmaf(rk_c, s[4 * g + j], c3v[j]);
+                        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(v, kLog2e, mneg)) * fac : 0.f;
+                        ph[j] = (__bf16)p;
+                        pl[j] = (__bf16)(p - (float)ph[j]);
+                    }
+                    *reinterpret_cast<bf16x4*>(prow + ((g ^ key) * 16)) = ph;
+                    *reinterpret_cast<bf16x4*>(prow + 8192 + ((g ^ key) * 16)) = pl;
+                }
+                if (it + 1 < nt) settle();
+                continue;
+            }
             // S = rstd_k * (Q''.f + Cy + Cx) + c3 ; rows past L -> -inf
             float mloc = kNegBig;
 #pragma unroll
@@ -363,7 +398,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         if (work) pv_step(pt, vt, at, 1);
     }
 
-    float* dst = partial + ((size_t)t * C + c) * L * kPartRow;
+    float* dst = partial + (((size_t)t * C + c) * Lrow + slot_off) * kPartRow;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int slot = 32 * sb + acc_row(i, h);
@@ -372,6 +407,171 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             for (int db = 0; db < 8; ++db) dst[(size_t)slot * kPartRow + 32 * db + r] = o[db][i];
             if (r < 8) dst[(size_t)slot * kPartRow + 256 + r] = oa[i];
         }
+    }
+}
+
+// Per-pixel softmax statistics over up to 256 slots (first kernel of the path for more than 128 slots):
+// stats[t, p] = (max_l S[l, p], 1 / sum_l exp(S[l, p] - max)) with S exactly as in retr_attn_kernel. Eight waves = eight slot
+// blocks, each with its Q'' hi / lo block resident; the feature tiles stream through a 4-deep asm LDS-DMA ring (two 1-KiB
+// pieces per wave and tile); reads the map once, writes 8 B per pixel.
+struct LStatsLds {
+    static constexpr int kStages = 4;
+    static constexpr int ring = 0;
+    static constexpr int stats = kStages * kTileBytes;          // [8][32] float2
+    static constexpr int c3 = stats + 8 * 32 * 8;               // [256] float
+    static constexpr int total = c3 + 256 * 4;
+};
+
+__global__ __launch_bounds__(512) void retr_logit_stats_kernel(
+    const __bf16* __restrict__ qh, const __bf16* __restrict__ ql,      // [T, 256, 256]
+    const float* __restrict__ cy, const float* __restrict__ cx,        // [T, H, 256], [T, W, 256]
+    const float* __restrict__ c3g,                                     // [T, 256]
+    const __bf16* __restrict__ feat, const float* __restrict__ rstd_k,
+    float2* __restrict__ out,                                          // [T, HW]
+    int L, int HW, int H, int W, float inv_w, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = LStatsLds;
+    constexpr int NST = Lds::kStages, A = NST - 1, LP = 256;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x;
+    const int px_begin = c * tiles_per_chunk * kTilePx;
+    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    px_end = px_end < HW ? px_end : HW;
+    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+
+    float* c3l = reinterpret_cast<float*>(smem + Lds::c3);
+    if (threadIdx.x < 256) c3l[threadIdx.x] = c3g[(size_t)t * LP + threadIdx.x];
+    bf16x8 qfh[16], qfl[16];
+    {
+        const size_t row = ((size_t)t * LP + 32 * w + r) * kD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            qfh[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
+            qfl[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
+        }
+    }
+    wait_vm<0>();
+    const int slot0 = 32 * w + 4 * h;
+    auto uniform_rsrc = [](const void* p, int bytes) {
+        const uint64_t a = reinterpret_cast<uint64_t>(p);
+        const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * LP, H * LP * 4);
+    const __amdgpu_buffer_rsrc_t cxr = uniform_rsrc(cx + (size_t)t * W * LP, W * LP * 4);
+    const __amdgpu_buffer_rsrc_t rkr = uniform_rsrc(rstd_k + (size_t)t * HW, HW * 4);
+    const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 ors = ra_make_srd(out + (size_t)t * HW, (uint32_t)HW * 8u);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+    auto stage = [&](int tile) {                                     // rows 4w .. 4w + 3 of the tile: two pieces
+        if (tile >= nt) return;
+        const int px0 = px_begin + tile * kTilePx;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 4 * w + 2 * i + h;
+            const int src = px0 + row < HW ? row : HW - 1 - px0;     // ragged last tile: clamp (those pixels are not stored)
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * kTileBytes + (4 * w + 2 * i) * kRowBytes);
+            ra_dma16(frs, dst, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+        }
+    };
+    // Position terms + rstd_k of this lane's pixel: compiler-visible loads, requested at the END of the previous iteration
+    // and consumed at the top of this one. hipcc waits for them with vmcnt(0), which also drains this wave's feature DMA
+    // (all of it older): the effective prefetch distance of this kernel is one tile, not three.
+    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+#pragma unroll
+    for (int b = 0; b < A; ++b) stage(b);
+    f32x4 cyv[4], cxv[4];
+    float rk_n;
+    auto request = [&](int tile) {
+        int px = px_begin + tile * kTilePx + r;
+        px = px < HW ? px : HW - 1;
+        int yy = (int)((float)px * inv_w);
+        int xx = px - yy * W;
+        if (xx < 0) { xx += W; --yy; }
+        if (xx >= W) { xx -= W; ++yy; }
+        const int yo = (yy * LP + slot0) * 4, xo = (xx * LP + slot0) * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            cyv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
+            cxv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cxr, xo + 32 * g, 0, 0));
+        }
+        rk_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rkr, px * 4, 0, 0));
+    };
+    request(0);
+    for (int it = 0; it < nt; ++it) {
+        f32x16 s;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[g][j] + cxv[g][j];      // vmcnt(0): also f(it) (and everything older) landed
+        const float rk = rk_n;
+        wg_barrier();                                                // B_top(it); also: every wave is done with f(it-1)
+        stage(it + A);
+        const char* kt = smem + Lds::ring + (it % NST) * kTileBytes;
+        int rr = r, hh = h;
+        asm volatile("" : "+v"(rr), "+v"(hh));
+        {
+            bf16x8 kf[2][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kf[0][u] = read_row_frag(kt, u, rr, hh);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp) {
+                if (grp < 3) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = read_row_frag(kt, 4 * (grp + 1) + u, rr, hh);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float mloc = kNegBig;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 c3v = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = slot0 + j + 8 * g < L;
+                const float v = fmaf(rk, s[4 * g + j], c3v[j]);
+                s[4 * g + j] = ok ? v : kNegBig;
+                mloc = fmaxf(mloc, s[4 * g + j]);
+            }
+        }
+        mloc = ra_half_swap_max(mloc);
+        float sloc = 0.f;
+        const float mneg = -mloc * kLog2e;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
+            sloc += ok ? __builtin_amdgcn_exp2f(fmaf(s[i], kLog2e, mneg)) : 0.f;
+        }
+        sloc = ra_half_swap_sum(sloc);
+        if (h == 0) stats[w * 32 + r] = make_float2(mloc, sloc);
+        wg_barrier();                                                // B_stats(it)
+        float mall = kNegBig;
+        float2 st_w[8];
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) {
+            st_w[ww] = stats[ww * 32 + r];
+            mall = fmaxf(mall, st_w[ww].x);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f((st_w[ww].x - mall) * kLog2e);
+        const int pxs = px_begin + it * kTilePx + r;
+        const bool mine = h == 0 && (r >> 2) == w && pxs < px_end;   // wave w stores pixels 4w .. 4w + 3
+        const f32x2 val = {mall, 1.f / den};
+        const int voff = mine ? pxs * 8 : 0x7ffffff0;                // out of range -> dropped by the hardware range check
+        asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(val), "v"(voff), "s"(ors) : "memory");
+        if (it + 1 < nt) request(it + 1);
     }
 }
 
@@ -419,10 +619,14 @@ RetrPlan plan_retr(int T, int HW, int chunks_req) {
 }
 }  // namespace
 
+namespace {
+size_t retr_stats_bytes(int T, int L, int HW) { return L > 128 ? (size_t)T * HW * sizeof(float2) : 0; }
+}  // namespace
+
 extern "C" size_t svps_retr_attn_workspace_bytes(int T, int L, int HW, int chunks) {
     if (T <= 0 || L <= 0 || HW <= 0) return 0;
     const RetrPlan p = plan_retr(T, HW, chunks);
-    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
+    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float) + retr_stats_bytes(T, L, HW);
 }
 
 extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
@@ -430,27 +634,54 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
                                   void* workspace, size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D,
                                   int chunks, void* stream_) {
     if (!qh || !ql || !cy || !cx || !c3 || !feat || !rstd_k || !rstd_v || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
-    if (D != svps::kD || T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
+    if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     const int HW = H * W;
     const RetrPlan p = plan_retr(T, HW, chunks);
-    if (workspace_bytes < (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float)) return SVPS_ERR_WORKSPACE;
+    const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
+    if (workspace_bytes < partial_bytes + retr_stats_bytes(T, L, HW)) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
-    static const int ablate = [] { const char* a = getenv("SVPS_RETR_ABLATE"); return a ? atoi(a) : 0; }();
-    auto kern = svps::retr_attn_kernel<0>;
-    if (ablate == 1) kern = svps::retr_attn_kernel<1>;
-    else if (ablate == 2) kern = svps::retr_attn_kernel<2>;
-    else if (ablate == 4) kern = svps::retr_attn_kernel<4>;
-    static SvpsLdsAttr attr[4];
-    if (hipError_t ae = attr[ablate == 1 ? 1 : ablate == 2 ? 2 : ablate == 4 ? 3 : 0].ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess)
-        return (int)ae;
+    const __bf16* qh_ = static_cast<const __bf16*>(qh);
+    const __bf16* ql_ = static_cast<const __bf16*>(ql);
+    const __bf16* f_ = static_cast<const __bf16*>(feat);
+    const __bf16* a_ = static_cast<const __bf16*>(aux);
+    const float inv_w = 1.0f / (float)W;
+    hipError_t e;
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
-    hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, static_cast<const __bf16*>(qh),
-                       static_cast<const __bf16*>(ql), cy, cx, c3, static_cast<const __bf16*>(feat), rstd_k, rstd_v,
-                       static_cast<const __bf16*>(aux), partial, L, HW, H, W, 1.0f / (float)W, p.tiles_per_chunk);
+    if (L <= 128) {
+        static const int ablate = [] { const char* a = getenv("SVPS_RETR_ABLATE"); return a ? atoi(a) : 0; }();
+        auto kern = svps::retr_attn_kernel<0, false>;
+        int slot = 0;
+        if (ablate == 1) { kern = svps::retr_attn_kernel<1, false>; slot = 1; }
+        else if (ablate == 2) { kern = svps::retr_attn_kernel<2, false>; slot = 2; }
+        else if (ablate == 4) { kern = svps::retr_attn_kernel<4, false>; slot = 3; }
+        static SvpsLdsAttr attr[4];
+        if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, rstd_k, rstd_v,
+                           a_, partial, L, HW, H, W, inv_w, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr);
+        e = hipGetLastError();
+    } else {
+        // more than 128 slots (padded layouts of 256 rows): softmax statistics over all slots first, then the retriever
+        // once per half of the slots with those statistics
+        float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);
+        static SvpsLdsAttr attr_s, attr_e;
+        if (hipError_t ae = attr_s.ensure(reinterpret_cast<const void*>(svps::retr_logit_stats_kernel), svps::LStatsLds::total); ae != hipSuccess) return (int)ae;
+        auto kern = svps::retr_attn_kernel<0, true>;
+        if (hipError_t ae = attr_e.ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(svps::retr_logit_stats_kernel, dim3(p.chunks, T), dim3(512), svps::LStatsLds::total, stream, qh_, ql_, cy, cx,
+                           c3, f_, rstd_k, st, L, HW, H, W, inv_w, p.tiles_per_chunk);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, rstd_k, rstd_v,
+                           a_, partial, 128, HW, H, W, inv_w, p.tiles_per_chunk, 256, L, 0, (const float2*)st);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, rstd_k, rstd_v,
+                           a_, partial, L - 128, HW, H, W, inv_w, p.tiles_per_chunk, 256, L, 128, (const float2*)st);
+        e = hipGetLastError();
+    }
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
-    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 0, stream);
     hipLaunchKernelGGL(svps::retr_finish_kernel, dim3(L, T), dim3(256), 0, stream, partial, out_ext, L, p.chunks);

@@ -75,7 +75,7 @@ class SlotMasks:
 
 
 class FrameSlotMasks:
-    """One frame of `SlotMasks`: `select(idx)` decodes the listed slots ([K, h, w], in that order)."""
+    """One frame of `SlotMasks`: `decode_slots(idx)` decodes the listed slots ([K, h, w], in that order)."""
 
     def __init__(self, clip, t):
         self.clip, self.t = clip, t
@@ -84,7 +84,7 @@ class FrameSlotMasks:
     is_cuda = property(lambda self: self.clip.is_cuda)
     device = property(lambda self: self.clip.device)
 
-    def select(self, idx):
+    def decode_slots(self, idx):
         c = self.clip
         return c._decode(self.t, self.t + 1, c.embeds[self.t][idx][None])[0]
 

@@ -276,9 +276,15 @@ def retr_stats(feat, H, W, pos_tabs, rk, rbk, eps_k, rv, rbv, eps_v):
     return rstd_k, rstd_v, aux
 
 
+def retr_slot_pad(L):
+    """Rows of the slot axis in the layouts K1' takes: 128 for L <= 128, 256 for L <= 256."""
+    return 128 if L <= 128 else 256
+
+
 def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
     """K1': out_ext [T, L, 264] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
-    rstd_k (Q''.f + cy + cx) + c3. qh / ql [T, 128, 256] bf16, cy [T, H, 128], cx [T, W, 128], c3 [T, 128] fp32."""
+    rstd_k (Q''.f + cy + cx) + c3. qh / ql [T, LP, 256] bf16, cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
+    padded to LP = 128 (L <= 128) or 256 (L <= 256; statistics kernel + two retriever launches)."""
     lib = _lib.load()
     _need(qh, "qh", torch.bfloat16, 3)
     _need(ql, "ql", torch.bfloat16, 3)
@@ -289,11 +295,12 @@ def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
     for name, x in (("c3", c3), ("rstd_k", rstd_k), ("rstd_v", rstd_v)):
         _need(x, name, torch.float32, 2)
     T, HW, D = feat.shape
-    if (HW != H * W or qh.shape != (T, 128, D) or ql.shape != (T, 128, D) or cy.shape != (T, H, 128) or cx.shape != (T, W, 128)
-            or c3.shape != (T, 128) or rstd_k.shape != (T, HW) or rstd_v.shape != (T, HW) or aux.shape != (T, HW, 32)):
+    if not 1 <= L <= 256:
+        raise ValueError("the fused retriever covers 1 <= L <= 256 slots")
+    LP = retr_slot_pad(L)
+    if (HW != H * W or qh.shape != (T, LP, D) or ql.shape != (T, LP, D) or cy.shape != (T, H, LP) or cx.shape != (T, W, LP)
+            or c3.shape != (T, LP) or rstd_k.shape != (T, HW) or rstd_v.shape != (T, HW) or aux.shape != (T, HW, 32)):
         raise ValueError("shape mismatch")
-    if not 1 <= L <= 128:
-        raise ValueError("the fused retriever covers 1 <= L <= 128 slots")
     ws_bytes = lib.svps_retr_attn_workspace_bytes(T, L, HW, chunks)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)
     out = torch.empty((T, L, 264), dtype=torch.float32, device=feat.device)

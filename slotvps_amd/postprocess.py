@@ -83,7 +83,7 @@ class PostProcessPanopticInstances(nn.Module):
     @torch.no_grad()
     def forward_tensors(self, pred_logits, pred_masks, size, materialize_masks=False):
         """pred_logits [L, nc], pred_masks [L, h, w] (GPU, fp32) or a lazy frame of mask logits with
-        `.select(slot_indices) -> [K, h, w]` (detector.FrameSlotMasks: only the kept slots are ever decoded), size (H, W).
+        `.decode_slots(slot_indices) -> [K, h, w]` (detector.FrameSlotMasks: only the kept slots are ever decoded), size (H, W).
         Returns a namespace: slot_index [K''] (into the L slots, the reference's filtered Instances order),
         probs, labels, (masks [K'', H, W] if materialize_masks), plus the state `panoptic_ids` needs."""
         if not pred_masks.is_cuda:
@@ -107,8 +107,8 @@ class PostProcessPanopticInstances(nn.Module):
         sc, cl = sc[order], cl[order]
         K = len(sc)
         thing = [bool(c > self.num_stuff - 1) for c in cl]                                           # :594
-        if hasattr(pred_masks, "select"):                            # decode the kept slots only, already in score order
-            m_sorted = pred_masks.select(sorted_idx).float().contiguous()
+        if hasattr(pred_masks, "decode_slots"):                            # decode the kept slots only, already in score order
+            m_sorted = pred_masks.decode_slots(sorted_idx).float().contiguous()
         else:
             m_sorted = pred_masks[sorted_idx].float().contiguous()
         thing_u8 = torch.tensor(thing, dtype=torch.uint8, device=dev)

@@ -151,19 +151,20 @@ class MaskDynamicConv(nn.Module):
         q2 = g @ c["wck"]                                                  # Q'' [T, L, 256]
         a1 = g @ c["bck"]                                                  # [T, L]
         dev = slots.device
-        qh = torch.zeros((T, 128, C), dtype=BF16, device=dev)
-        ql = torch.zeros((T, 128, C), dtype=BF16, device=dev)
+        LP = ops.retr_slot_pad(L)
+        qh = torch.zeros((T, LP, C), dtype=BF16, device=dev)
+        ql = torch.zeros((T, LP, C), dtype=BF16, device=dev)
         hi = q2.to(BF16)
         qh[:, :L] = hi
         ql[:, :L] = (q2 - hi.float()).to(BF16)
-        cy = torch.zeros((T, H, 128), dtype=torch.float32, device=dev)
-        cx = torch.zeros((T, W, 128), dtype=torch.float32, device=dev)
+        cy = torch.zeros((T, H, LP), dtype=torch.float32, device=dev)
+        cx = torch.zeros((T, W, LP), dtype=torch.float32, device=dev)
         if pos_tabs is not None:
             ytab, xtab = pos_tabs
             cy[:, :, :L] = torch.matmul(ytab, q2[:, :, :C // 2].transpose(1, 2))
             cx[:, :, :L] = torch.matmul(xtab, q2[:, :, C // 2:].transpose(1, 2))
         cy[:, :, :L] += a1[:, None, :]
-        c3 = torch.zeros((T, 128), dtype=torch.float32, device=dev)
+        c3 = torch.zeros((T, LP), dtype=torch.float32, device=dev)
         c3[:, :L] = q @ self.norm_k.bias
         ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats[0], stats[1], stats[2], L, H, W)
         pre = (ext.view(T * L, 264) @ c["wext"]).view(T, L, C)                                       # :456 (value projection after the sum)
@@ -186,7 +187,7 @@ class MaskDynamicConv(nn.Module):
                                       self.norm_k.bias, self.norm_k.eps, wvT, self.to_v.bias, self.norm_v.weight,
                                       self.norm_v.bias, self.norm_v.eps)
             return ops.slot_attn_f32(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
-        if self.retriever == "fused" and slots.shape[1] <= 128:
+        if self.retriever == "fused":
             return self.forward_fused(slots, feat_pm, hw, pos_tabs)
         q = ops.row_ln(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps, out_bf16=True)
         k, v = self.project_kv(feat_pm, hw, pos_tabs)

@@ -146,7 +146,7 @@ def test_clip_flow_matches_oracle_pipeline():
     assert fcn.shape == (T, 19, H, W)
     # the decode runs on demand for the slots the post-process keeps; the kept rows equal those of the all-slot decode bit for bit
     pick = torch.tensor([7, 3, 99, 0, 41], device=dev)
-    assert torch.equal(masks[1].select(pick), masks.dense()[1][pick])
+    assert torch.equal(masks[1].decode_slots(pick), masks.dense()[1][pick])
     # random-init slots all predict one class: add a fixed per-slot class preference so that stuff, things,
     # duplicates of a stuff class and "no object" all occur. The frozen outputs are handed to both sides (the
     # PyTorch backbone is not run-to-run deterministic - MIOpen picks algorithms at first use).

@@ -231,7 +231,7 @@ def test_head_variants_per_stage_parity(cuda, name):
     logits, embeds = logits.cpu().numpy(), embeds.cpu().numpy()
     assert logits.shape == (7, T, L, cfg["num_classes"]) and embeds.shape == (7, T, L, 256)
     pos = [orc.pos_embed_sine(h, w) for (h, w) in sizes]
-    form = "fused" if L <= 128 else "kv"                           # the fused retriever covers L <= 128; 200 slots run K3 + K1
+    form = "fused"                                                 # 200 slots: statistics kernel + two retriever launches
     st = orc.Storage.fused_policy() if form == "fused" else orc.Storage.bf16_policy()
     _, _, o_fused = orc.head_forward(feats, slots, pos, params, st=st)
     g_fused = [[fused[i][t].float().cpu().numpy() for i in range(4)] for t in range(T)]

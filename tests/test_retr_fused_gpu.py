@@ -67,7 +67,8 @@ def test_retr_stats(cuda, T, H, W, pos):
 
 
 @pytest.mark.parametrize("T,H,W,L,pos", [(2, 8, 32, 100, True), (1, 16, 64, 128, True), (1, 5, 20, 37, True),
-                                         (2, 34, 60, 100, True), (1, 3, 64, 1, False), (1, 40, 32, 100, True)])
+                                         (2, 34, 60, 100, True), (1, 3, 64, 1, False), (1, 40, 32, 100, True),
+                                         (2, 34, 60, 200, True), (1, 16, 32, 256, True), (1, 9, 20, 129, False)])
 def test_fused_retriever_matches_float64_oracle(cuda, T, H, W, L, pos):
     import torch
     from slotvps_amd import ops
