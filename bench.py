@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--slots", type=int, default=100)
+    ap.add_argument("--num-classes", type=int, default=20, help="head classes incl. no-object (20 Cityscapes-VPS, 24 VIPER)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--fast-p", action="store_true", help="bf16 P without the hi/lo split inside K1")
     ap.add_argument("--retriever", choices=["fused", "kv"], default="fused",
@@ -203,8 +204,9 @@ def single_clip_latency(a, dev):
     """Latency of the hot path on ONE clip (no stacking): the same graph-replayed step as the timed region with
     clips_per_launch = 1. The headline `value` stacks 16 clips per launch for throughput; this is what one clip waits."""
     from slotvps_amd.clip import SlotClipRunner
-    r1 = SlotClipRunner(dev, a.frames, a.height, a.width, L=a.slots, param_seed=0, split_p=not a.fast_p, use_graph=True,
-                        n_slots=1, clips_per_launch=1)
+    from slotvps_amd import synth
+    r1 = SlotClipRunner(dev, a.frames, a.height, a.width, L=a.slots, param_seed=0, cfg=dict(synth.R50_HEAD_CFG, num_classes=a.num_classes),
+                        split_p=not a.fast_p, use_graph=True, n_slots=1, clips_per_launch=1)
     r1.head.set_retriever(a.retriever)
     r1.load_clip(r1.random_clip(99))
     for _ in range(3):
@@ -298,7 +300,9 @@ def main():
     cif = max(1, a.clips_in_flight)
     cpl = max(1, a.clips_per_launch)
     n_pool = 2 * cif    # distinct synthetic clips per rank, each resident in its own input slot
-    runner = SlotClipRunner(dev, T, a.height, a.width, L=a.slots, param_seed=0, split_p=not a.fast_p,
+    from slotvps_amd import synth
+    head_cfg = dict(synth.R50_HEAD_CFG, num_classes=a.num_classes)
+    runner = SlotClipRunner(dev, T, a.height, a.width, L=a.slots, param_seed=0, cfg=head_cfg, split_p=not a.fast_p,
                             use_graph=not a.no_graph, n_slots=n_pool, clips_per_launch=cpl)
     runner.head.set_retriever(a.retriever)
     HWf = runner.sizes[-1][0] * runner.sizes[-1][1]
@@ -440,7 +444,7 @@ def main():
     if rank == 0:
         frames = world * a.steps * T * cif * cpl
         line = {
-            "metric": "frames/sec (whole node), 1024x2048 T=5 clip, R50-FPN Slot-VPS inference",
+            "metric": f"frames/sec (whole node), {a.height}x{a.width} T={T} clip, R50-FPN Slot-VPS inference",
             "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

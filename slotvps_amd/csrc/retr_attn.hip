@@ -503,11 +503,15 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
     };
     request(0);
     for (int it = 0; it < nt; ++it) {
+        // Explicit drain BEFORE the barrier: this wave's pieces of f(it) (and the table loads) have landed. hipcc's own wait
+        // for the table loads is free to sink below the barrier (the sums are register arithmetic), which would let other
+        // waves read this wave's rows of the tile before they arrive.
+        wait_vm<0>();
         f32x16 s;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[g][j] + cxv[g][j];      // vmcnt(0): also f(it) (and everything older) landed
+            for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[g][j] + cxv[g][j];
         const float rk = rk_n;
         wg_barrier();                                                // B_top(it); also: every wave is done with f(it-1)
         stage(it + A);

@@ -276,3 +276,55 @@ def test_trunk_bf16_autocast_option():
         assert a.shape == b.shape
         d, scale = (a - b).abs(), a.abs().max().item()          # ~50 bf16 convolution layers in a row, random weights
         assert d.max().item() <= 0.12 * scale + 1e-3 and d.mean().item() <= 0.02 * scale
+
+
+# ---- the two other BASELINE configurations resolve from the repository's own config files (no reference tree needed) ----
+def test_swinL_and_viper_configs_build_on_any_box():
+    from slotvps_amd.config import Config
+    from slotvps_amd.registry import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "viper_r50_slotvps_mi355x.py"))
+    det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    im = det.image_model
+    assert det.stuff_num == 13 and det.num_classes == 24                    # vps_temporal_slots.py:68-70
+    assert im.init_mask_query.weight.shape == (200, 256)                    # proposal_num = 200
+    assert im.dynamic_mask_head.head_series_3[1].class_logits.weight.shape == (24, 256)
+    assert cfg.clip == dict(frames=10, height=1088, width=1920)
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "swinL_fpn_slotvps_mi355x.py"))
+    det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    bb = det.image_model.backbone
+    assert type(bb).__name__ == "SwinTransformer" and sum(p.numel() for p in bb.parameters()) > 190e6      # Swin-L
+    stage = det.image_model.dynamic_mask_head.head_series_0[0]
+    assert stage.activation is torch.nn.functional.relu and stage.temporal_query_head is None
+    assert det.image_model.dynamic_mask_head.head_series_2[0].temporal_query_head.activation is torch.nn.functional.gelu
+    swin_ref = "/root/reference/configs/cityscapes/swinL_fpn_slotvps.py"
+    if os.path.exists(swin_ref):                                            # same model as the reference's own file
+        ref = build_detector(Config.fromfile(swin_ref).model, train_cfg=None, test_cfg=cfg.test_cfg)
+        assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == {k: tuple(v.shape) for k, v in det.state_dict().items()}
+
+
+@pytest.mark.gpu
+def test_viper_config_clip_runs_through_the_whole_detector():
+    """VIPER geometry at reduced size (level sizes 17x30 ... no multiple of the tile), 200 slots, 24 classes, T = 3:
+    trunk + fused retriever for more than 128 slots + selected-slot decode + post-process + tracker."""
+    from slotvps_amd.config import Config
+    from slotvps_amd.registry import build_detector
+    dev = torch.device("cuda:0")
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "viper_r50_slotvps_mi355x.py"))
+    torch.manual_seed(1)
+    det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
+    T, H, W = 3, 544, 960
+    imgs = torch.randn(T, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    table = torch.zeros(200, 24, device=dev)
+    table[torch.arange(200), torch.arange(200) % 23] = 12.0
+    with torch.no_grad():
+        det.image_model.fg_bn.weight.fill_(40.0)
+    base = det.head_path
+    det.head_path = lambda f: (lambda lg, em, mk: (lg + table, em, mk))(*base(f))
+    metas = [dict(iid=100001 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png") for t in range(T)]   # vid * 100000 + fid (:220-222)
+    res = det.clip_test(imgs, metas)
+    assert len(res) == T
+    for r in res:
+        assert r["panoptic_outputs"].shape == (1, H, W) and r["fcn_outputs"].shape == (1, H, W)
+        assert int(r["fcn_outputs"].max()) <= 22
+        ids = torch.unique(r["panoptic_outputs"])
+        assert (ids[ids > 12]).numel() == len(r["panoptic_cls_inds"]) == len(r["panoptic_det_obj_ids"])

@@ -92,3 +92,49 @@ def test_fused_retriever_matches_float64_oracle(cuda, T, H, W, L, pos):
     print(f"\nfused retriever T={T} {H}x{W} L={L}: max abs err vs float64 oracle {worst:.2e}")
     # post-LayerNorm outputs are O(1); measured 1e-4 ... 4e-4 (bf16 k / v tensors: 1e-1)
     assert worst <= 1.5e-3
+
+
+@pytest.mark.parametrize("name,T,H,W,L", [("R50 finest level, BASELINE config 1", 5, 256, 512, 100),
+                                          ("VIPER finest level, BASELINE config 4", 10, 272, 480, 200),
+                                          ("VIPER level 2 (width no multiple of the tile)", 10, 136, 240, 200)])
+def test_full_size_sum_over_slots_properties(cuda, name, T, H, W, L):
+    """Size-independent properties at the BASELINE sizes (the oracle does not finish there in seconds). The softmax runs
+    over slots, so every pixel's column sums to one:
+        sum_l A_l = sum_p rstd_v(p) f_p      sum_l s1_l = sum_p rstd_v(p)      sum_l s0_l = HW
+    and the launch is bitwise reproducible."""
+    import torch
+    from slotvps_amd import ops
+    m, _ = make_module(cuda, 3)
+    g = torch.Generator(device=cuda).manual_seed(5)
+    HW = H * W
+    feat = torch.randn((T, HW, 256), generator=g, device=cuda).to(torch.bfloat16)
+    slots = torch.randn((T, L, 256), generator=g, device=cuda)
+    tabs = ops.pos_embed_sine_tables(H, W, 256, cuda)
+    c = m._fused_consts()
+    with torch.no_grad():
+        st = ops.retr_stats(feat, H, W, tabs, c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
+        q = ops.row_ln(m.to_q(slots), m.norm_q.weight, m.norm_q.bias, m.norm_q.eps)
+        # the inputs of K1' exactly as MaskDynamicConv.forward_fused prepares them
+        got = {}
+        orig = ops.retr_attn
+        def spy(*a, **k):
+            got["ext"] = orig(*a, **k)
+            return got["ext"]
+        ops.retr_attn = spy
+        try:
+            out1 = m.forward_fused(slots, feat, (H, W), tabs, stats=st)
+            ext1 = got["ext"].clone()
+            out2 = m.forward_fused(slots, feat, (H, W), tabs, stats=st)
+        finally:
+            ops.retr_attn = orig
+        torch.cuda.synchronize()
+        assert torch.equal(out1, out2) and torch.isfinite(out1).all()
+        tau = st[1].double()                                                    # [T, HW]
+        want_a = torch.einsum("tp,tpc->tc", tau, feat.double())                 # sum_p rstd_v f_p
+        a_sum = ext1[:, :, :256].double().sum(1)
+        scale = want_a.abs().max().item()
+        assert (a_sum - want_a).abs().max().item() <= 2e-4 * max(scale, 1.0), ((a_sum - want_a).abs().max().item(), scale)
+        s1 = ext1[:, :, 256].double().sum(1)
+        s0 = ext1[:, :, 257].double().sum(1)
+        assert ((s1 - tau.sum(1)).abs() / tau.sum(1)).max().item() <= 2e-5
+        assert ((s0 - HW).abs() / HW).max().item() <= 2e-5
