@@ -155,6 +155,23 @@ int svps_row_ln(const float* x, const float* pre, const float* post, const float
                 int relu, int rows, int rows_per_group, int D, float* out_f32, void* out_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Slot-side helpers (slotvps_amd/csrc/row_ops.hip), rows of D = 256 fp32 values.
+ *
+ * svps_retr_query_prep: the query side of the fused retriever from x = to_q(slots) [T, L, D] (dynamic_mask_head.py:431):
+ *     q = LN(x; lnq)   gp[t, l] = q * lnk_w   c3[t, l] = q . lnk_b   a1[t, l] = gp[t, l] . bck      (rows l >= L: zeros)
+ *     gp [T, LP, D] is the operand of Q'' = gp W~_k;  c3, a1 [T, LP];  LP = 128 or 256 >= L;  bck [D] = centred to_k bias
+ * svps_retr_split: q2 [n] fp32 -> hi = bf16(q2), lo = bf16(q2 - hi) (n a multiple of 4)
+ * svps_slot_self_attn: softmax(q k^T / sqrt(head_dim)) v per (frame, head) on the packed projection
+ *     qkv [T, L, 3, nheads, head_dim] fp32 -> out [T, L, nheads * head_dim]; head_dim = 32, L <= 256
+ *     (the attention of nn.MultiheadAttention between in_proj and out_proj, dynamic_mask_head.py:346-355)
+ * ------------------------------------------------------------------------------------------- */
+int svps_retr_query_prep(const float* x, const float* lnq_w, const float* lnq_b, float lnq_eps, const float* lnk_w,
+                         const float* lnk_b, const float* bck, float* gp, float* c3, float* a1, int T, int L, int LP, int D,
+                         void* stream);
+int svps_retr_split(const float* q2, void* hi, void* lo, size_t n, void* stream);
+int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K6 full-resolution panoptic post-process (PostProcessPanopticInstances.mask_removal / get_ids_area,
  * mmdet/models/detectors/vps_temporal_slots.py:564-657, :697-698, :724-757; argmax + relabel of simple_test
  * :411-435). Bilinear upsampling to H x W is fused into both kernels; the order-dependent part of

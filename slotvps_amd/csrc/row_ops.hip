@@ -63,7 +63,130 @@ __global__ __launch_bounds__(256) void row_ln_kernel(const float* __restrict__ x
     }
 }
 
+// ---- query side of the statistics-fused retriever (retr_attn.hip) -------------------------------------------------
+// One wavefront per (frame, padded slot row). From x = to_q(slots) (the GEMM stays a library call):
+//     q = norm_q(x)                         MaskDynamicConv.forward :431
+//     g = q * gamma_k   -> gp [T, LP, 256]  operand of the key fold  Q'' = g W~_k   (rows >= L written as zeros)
+//     c3 = q . beta_k   -> [T, LP]          a1 = g . b~_k -> [T, LP]
+__global__ __launch_bounds__(256) void retr_query_prep_kernel(const float* __restrict__ x,      // [T, L, 256]
+                                                              const float* __restrict__ qw, const float* __restrict__ qb, float eps,
+                                                              const float* __restrict__ gk, const float* __restrict__ bek,
+                                                              const float* __restrict__ bck,
+                                                              float* __restrict__ gp, float* __restrict__ c3, float* __restrict__ a1,
+                                                              int T, int L, int LP) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T * LP) return;
+    const int t = row / LP, l = row - t * LP;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float c3v = 0.f, a1v = 0.f;
+    if (l < L) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)t * L + l) * 256 + 4 * lane);
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        const float rstd = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f) + eps);
+        const float4 w4 = *reinterpret_cast<const float4*>(qw + 4 * lane), b4 = *reinterpret_cast<const float4*>(qb + 4 * lane);
+        const float4 q = make_float4(dx * rstd * w4.x + b4.x, dy * rstd * w4.y + b4.y, dz * rstd * w4.z + b4.z, dw * rstd * w4.w + b4.w);
+        const float4 k4 = *reinterpret_cast<const float4*>(gk + 4 * lane), e4 = *reinterpret_cast<const float4*>(bek + 4 * lane);
+        const float4 c4 = *reinterpret_cast<const float4*>(bck + 4 * lane);
+        g = make_float4(q.x * k4.x, q.y * k4.y, q.z * k4.z, q.w * k4.w);
+        c3v = wave_sum(q.x * e4.x + q.y * e4.y + q.z * e4.z + q.w * e4.w);
+        a1v = wave_sum(g.x * c4.x + g.y * c4.y + g.z * c4.z + g.w * c4.w);
+    }
+    *reinterpret_cast<float4*>(gp + (size_t)row * 256 + 4 * lane) = g;
+    if (lane == 0) { c3[row] = c3v; a1[row] = a1v; }
+}
+
+// Q'' [rows, 256] fp32 -> bf16 hi and lo = bf16(Q'' - hi), the two A operands of K1'
+__global__ __launch_bounds__(256) void retr_split_kernel(const float* __restrict__ q2, __bf16* __restrict__ hi, __bf16* __restrict__ lo, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    const float4 v = reinterpret_cast<const float4*>(q2)[i];
+    bf16x4_t h, l;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]); l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+    reinterpret_cast<bf16x4_t*>(hi)[i] = h;
+    reinterpret_cast<bf16x4_t*>(lo)[i] = l;
+}
+
+// ---- slot self-attention (nn.MultiheadAttention of a stage, dynamic_mask_head.py:346-355) -------------------------------
+// softmax(q k^T / sqrt(hd)) v for one (frame, head) per workgroup on the packed projection qkv [T, L, 3, nh, hd] (hd = 32):
+// L <= 256 slots, k and v of the head in LDS (transposed k: conflict-free dot products), one thread per query row, fp32
+// throughout, two-pass softmax (max, then exp / sum) like torch. Replaces the framework's generic attention kernel for
+// these tiny shapes (100 x 100 x 32 per head).
+__global__ __launch_bounds__(256) void slot_self_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int nh, float scale) {
+    constexpr int HD = 32;
+    __shared__ float kT[HD][256 + 1];
+    __shared__ float vs[256][HD + 1];
+    const int t = blockIdx.y, hh = blockIdx.x, tid = threadIdx.x;
+    const size_t rs = (size_t)3 * nh * HD;                            // floats per (frame, slot) row of qkv
+    const float* base = qkv + (size_t)t * L * rs + hh * HD;
+    for (int i = tid; i < L * HD; i += 256) {
+        const int l = i / HD, d = i - l * HD;
+        kT[d][l] = base[(size_t)l * rs + (size_t)nh * HD + d];
+        vs[l][d] = base[(size_t)l * rs + (size_t)2 * nh * HD + d];
+    }
+    __syncthreads();
+    if (tid >= L) return;
+    float q[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) q[d] = base[(size_t)tid * rs + d] * scale;           // q * (1 / sqrt(hd)), torch's order
+    float m = -INFINITY;
+    for (int j = 0; j < L; ++j) {
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) sc = fmaf(q[d], kT[d][j], sc);
+        m = fmaxf(m, sc);
+    }
+    float o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    float den = 0.f;
+    for (int j = 0; j < L; ++j) {
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) sc = fmaf(q[d], kT[d][j], sc);
+        const float e = expf(sc - m);
+        den += e;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = fmaf(e, vs[j][d], o[d]);
+    }
+    const float inv = 1.f / den;
+    float* dst = out + ((size_t)t * L + tid) * nh * HD + hh * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dst[d] = o[d] * inv;
+}
+
 }  // namespace svps
+
+extern "C" int svps_retr_query_prep(const float* x, const float* lnq_w, const float* lnq_b, float lnq_eps, const float* lnk_w,
+                                    const float* lnk_b, const float* bck, float* gp, float* c3, float* a1, int T, int L, int LP,
+                                    int D, void* stream_) {
+    if (!x || !lnq_w || !lnq_b || !lnk_w || !lnk_b || !bck || !gp || !c3 || !a1) return SVPS_ERR_BAD_ARG;
+    if (D != 256 || T <= 0 || L <= 0 || L > LP || (LP != 128 && LP != 256)) return SVPS_ERR_BAD_SHAPE;
+    const int rows = T * LP;
+    hipLaunchKernelGGL(svps::retr_query_prep_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), x, lnq_w,
+                       lnq_b, lnq_eps, lnk_w, lnk_b, bck, gp, c3, a1, T, L, LP);
+    return (int)hipGetLastError();
+}
+
+extern "C" int svps_retr_split(const float* q2, void* hi, void* lo, size_t n, void* stream_) {
+    if (!q2 || !hi || !lo) return SVPS_ERR_BAD_ARG;
+    if (n == 0 || (n & 3)) return SVPS_ERR_BAD_SHAPE;
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(svps::retr_split_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), q2,
+                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), n4);
+    return (int)hipGetLastError();
+}
+
+extern "C" int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream_) {
+    if (!qkv || !out) return SVPS_ERR_BAD_ARG;
+    if (T <= 0 || L <= 0 || L > 256 || nheads <= 0 || head_dim != 32) return SVPS_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(svps::slot_self_attn_kernel, dim3(nheads, T), dim3(256), 0, static_cast<hipStream_t>(stream_), qkv, out, L, nheads,
+                       1.0f / sqrtf((float)head_dim));
+    return (int)hipGetLastError();
+}
 
 extern "C" int svps_row_ln(const float* x, const float* pre, const float* post, const float* w, const float* b,
                            float eps, int relu, int rows, int rows_per_group, int D, float* out_f32, void* out_bf16,

@@ -311,6 +311,49 @@ def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
     return out
 
 
+def retr_query_prep(x, lnq_w, lnq_b, lnq_eps, lnk_w, lnk_b, bck, LP):
+    """x = to_q(slots) [T, L, 256] fp32 -> (gp [T, LP, 256] = norm_q(x) * lnk_w zero-padded, c3 [T, LP], a1 [T, LP])."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32, 3)
+    for name, v in (("lnq_w", lnq_w), ("lnq_b", lnq_b), ("lnk_w", lnk_w), ("lnk_b", lnk_b), ("bck", bck)):
+        _need(v, name, torch.float32, 1)
+    T, L, D = x.shape
+    gp = torch.empty((T, LP, D), dtype=torch.float32, device=x.device)
+    c3 = torch.empty((T, LP), dtype=torch.float32, device=x.device)
+    a1 = torch.empty((T, LP), dtype=torch.float32, device=x.device)
+    with _on(x, lnq_w, lnq_b, lnk_w, lnk_b, bck) as ctx:
+        rc = lib.svps_retr_query_prep(_ptr(x), _ptr(lnq_w), _ptr(lnq_b), float(lnq_eps), _ptr(lnk_w), _ptr(lnk_b), _ptr(bck),
+                                      _ptr(gp), _ptr(c3), _ptr(a1), T, L, LP, D, ctx.stream)
+    _lib.check(rc, "svps_retr_query_prep")
+    return gp, c3, a1
+
+
+def retr_split(q2):
+    """fp32 tensor -> (hi, lo) bf16 with hi + lo = q2 to a 16-bit mantissa."""
+    lib = _lib.load()
+    _need(q2, "q2", torch.float32)
+    hi = torch.empty(q2.shape, dtype=torch.bfloat16, device=q2.device)
+    lo = torch.empty_like(hi)
+    with _on(q2) as ctx:
+        _lib.check(lib.svps_retr_split(_ptr(q2), _ptr(hi), _ptr(lo), q2.numel(), ctx.stream), "svps_retr_split")
+    return hi, lo
+
+
+def slot_self_attn(qkv, nheads):
+    """qkv [T, L, 3 * C] fp32 (packed in_proj output: q | k | v, each nheads x 32) -> [T, L, C] = softmax(q k^T / sqrt(32)) v
+    per frame and head (nn.MultiheadAttention between its two projections, dynamic_mask_head.py:346-355)."""
+    lib = _lib.load()
+    _need(qkv, "qkv", torch.float32, 3)
+    T, L, C3 = qkv.shape
+    C = C3 // 3
+    if C3 != 3 * C or C != nheads * 32:
+        raise ValueError("slot_self_attn: head_dim must be 32")
+    out = torch.empty((T, L, C), dtype=torch.float32, device=qkv.device)
+    with _on(qkv) as ctx:
+        _lib.check(lib.svps_slot_self_attn(_ptr(qkv), _ptr(out), T, L, nheads, 32, ctx.stream), "svps_slot_self_attn")
+    return out
+
+
 # ---- exact mode: fp32 storage, fp32 arithmetic (csrc/exact_f32.hip) ---------------------------------------------
 F32 = torch.float32
 

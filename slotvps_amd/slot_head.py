@@ -146,26 +146,19 @@ class MaskDynamicConv(nn.Module):
         H, W = hw
         if stats is None:
             stats = ops.retr_stats(feat_pm, H, W, pos_tabs, c["rk"], c["rbk"], self.norm_k.eps, c["rv"], c["rbv"], self.norm_v.eps)
-        q = ops.row_ln(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps)      # :431, fp32
-        g = q * self.norm_k.weight
-        q2 = g @ c["wck"]                                                  # Q'' [T, L, 256]
-        a1 = g @ c["bck"]                                                  # [T, L]
-        dev = slots.device
         LP = ops.retr_slot_pad(L)
-        qh = torch.zeros((T, LP, C), dtype=BF16, device=dev)
-        ql = torch.zeros((T, LP, C), dtype=BF16, device=dev)
-        hi = q2.to(BF16)
-        qh[:, :L] = hi
-        ql[:, :L] = (q2 - hi.float()).to(BF16)
-        cy = torch.zeros((T, H, LP), dtype=torch.float32, device=dev)
-        cx = torch.zeros((T, W, LP), dtype=torch.float32, device=dev)
-        if pos_tabs is not None:
+        # :431 q = norm_q(to_q(slots)); g = q * gamma_k (zero rows up to LP), c3 = q . beta_k, a1 = g . b~_k: one launch
+        gp, c3, a1 = ops.retr_query_prep(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps,
+                                         self.norm_k.weight, self.norm_k.bias, c["bck"], LP)
+        q2 = gp @ c["wck"]                                                 # Q'' [T, LP, 256]: the key projection folded into the queries
+        qh, ql = ops.retr_split(q2)
+        if pos_tabs is not None:                                           # separable position terms + a' (two small tables per frame)
             ytab, xtab = pos_tabs
-            cy[:, :, :L] = torch.matmul(ytab, q2[:, :, :C // 2].transpose(1, 2))
-            cx[:, :, :L] = torch.matmul(xtab, q2[:, :, C // 2:].transpose(1, 2))
-        cy[:, :, :L] += a1[:, None, :]
-        c3 = torch.zeros((T, LP), dtype=torch.float32, device=dev)
-        c3[:, :L] = q @ self.norm_k.bias
+            cy = torch.baddbmm(a1[:, None, :], ytab.expand(T, -1, -1), q2[:, :, :C // 2].transpose(1, 2))
+            cx = torch.matmul(xtab, q2[:, :, C // 2:].transpose(1, 2))
+        else:
+            cy = a1[:, None, :].expand(T, H, LP).contiguous()
+            cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
         ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats[0], stats[1], stats[2], L, H, W)
         pre = (ext.view(T * L, 264) @ c["wext"]).view(T, L, C)                                       # :456 (value projection after the sum)
         return ops.row_ln(pre, self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)        # :458-459
@@ -340,6 +333,10 @@ class MaskRCNNHead(nn.Module):
         if self.precision == "fp32":                                        # explicit fp32 products, torch's own order (:352)
             attn = torch.softmax((q * (1.0 / math.sqrt(C // nh))) @ k.transpose(-1, -2), dim=-1)
             o = attn @ v
+        elif C // nh == 32 and L <= 256:
+            # the library's own kernel for these tiny (L x L x 32 per head) problems, on the packed projection as it stands
+            o = ops.slot_self_attn(qkv.view(T, L, 3 * C), nh)
+            return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
         else:
             o = F.scaled_dot_product_attention(q, k, v)                     # softmax(q k^T / sqrt(C / heads)) v
         return F.linear(o.transpose(1, 2).reshape(T, L, C), mha.out_proj.weight, mha.out_proj.bias)

@@ -40,3 +40,47 @@ def test_row_ln_matches_oracle(cuda, rows, groups, relu, pre, post, bf16):
         ref = ref + q
     tol = 2e-2 if bf16 else 2e-5          # bf16 output: one ulp at |y| < 4; fp32: accumulation order only
     assert np.abs(got - ref).max() < tol
+
+
+@pytest.mark.parametrize("T,L", [(3, 100), (2, 37), (1, 200), (1, 256)])
+def test_slot_self_attention_kernel_matches_oracle_mha(cuda, T, L):
+    """svps_slot_self_attn + the two projections == the oracle's nn.MultiheadAttention restatement (float64)."""
+    import torch
+    from slotvps_amd import ops
+    from util import orc
+    rng = np.random.default_rng(L)
+    P = {"in_proj_weight": (rng.standard_normal((768, 256)) / 16).astype(np.float32),
+         "in_proj_bias": (0.1 * rng.standard_normal(768)).astype(np.float32),
+         "out_proj.weight": (rng.standard_normal((256, 256)) / 16).astype(np.float32),
+         "out_proj.bias": (0.1 * rng.standard_normal(256)).astype(np.float32)}
+    x = rng.standard_normal((T, L, 256)).astype(np.float32)
+    tx = torch.from_numpy(x).to(cuda)
+    g = lambda n: torch.from_numpy(P[n]).to(cuda)
+    qkv = torch.nn.functional.linear(tx, g("in_proj_weight"), g("in_proj_bias"))
+    o = ops.slot_self_attn(qkv.contiguous(), 8)
+    got = torch.nn.functional.linear(o, g("out_proj.weight"), g("out_proj.bias")).cpu().numpy()
+    for t in range(T):
+        ref = orc.multihead_self_attention(x[t].astype(np.float64), P, "", 8, np.float64)
+        assert np.abs(got[t] - ref).max() <= 2e-5
+
+
+def test_retr_query_prep_and_split(cuda):
+    import torch
+    from slotvps_amd import ops
+    from util import orc
+    rng = np.random.default_rng(1)
+    T, L, LP = 2, 100, 128
+    x = rng.standard_normal((T, L, 256)).astype(np.float32)
+    v = {n: rng.uniform(0.5, 1.5, 256).astype(np.float32) if n.endswith("w") else (0.1 * rng.standard_normal(256)).astype(np.float32)
+         for n in ("qw", "qb", "kw", "kb", "bck")}
+    g = lambda n: torch.from_numpy(v[n]).to(cuda)
+    gp, c3, a1 = ops.retr_query_prep(torch.from_numpy(x).to(cuda), g("qw"), g("qb"), 1e-5, g("kw"), g("kb"), g("bck"), LP)
+    q = orc.layer_norm(x.astype(np.float64), v["qw"].astype(np.float64), v["qb"].astype(np.float64))
+    gr = q * v["kw"]
+    assert gp.shape == (T, LP, 256) and torch.all(gp[:, L:] == 0) and torch.all(c3[:, L:] == 0) and torch.all(a1[:, L:] == 0)
+    assert np.abs(gp[:, :L].cpu().numpy() - gr).max() <= 1e-5
+    assert np.abs(c3[:, :L].cpu().numpy() - q @ v["kb"].astype(np.float64)).max() <= 2e-5
+    assert np.abs(a1[:, :L].cpu().numpy() - gr @ v["bck"].astype(np.float64)).max() <= 2e-5
+    hi, lo = ops.retr_split(gp)
+    assert torch.equal(hi, gp.to(torch.bfloat16)) and torch.equal(lo, (gp - hi.float()).to(torch.bfloat16))
+    assert (hi.float() + lo.float() - gp).abs().max().item() <= 2.0 ** -16 * gp.abs().max().item()
