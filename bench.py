@@ -62,6 +62,7 @@ def parse():
                     help="independent clips stacked along the frame axis of every kernel launch (temporal attention stays per clip)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 to skip the CPU oracle leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--latency-leg", type=int, default=1, help="0 to skip the single-clip latency leg (profiling runs)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / rendezvous / gather rehearsal without kernels (gloo on CPU; used by tests/test_parallel_cpu.py)")
     ap.add_argument("--whole-detector", type=int, default=1,
@@ -462,7 +463,7 @@ def main():
         if a.cpu_baseline and world == 1:
             note("cpu_baseline leg (PyTorch CPU restatement, bounded sample) ...")
             line["cpu_baseline"] = cpu_baseline(a)
-        if world == 1:
+        if world == 1 and a.latency_leg:
             del runner, gatherers
             torch.cuda.empty_cache()
             note("single-clip latency leg ...")

@@ -1,23 +1,34 @@
-"""Summarise the HBM-traffic PMC passes of bench.py into profiles/<round>/k1_pmc_traffic.json.
+"""Summarise the HBM-traffic PMC passes of bench.py into profiles/<round>/pmc_traffic.json, per kernel, CALIBRATED in the
+same pass on a kernel whose bytes are known.
 
-Collect (GPU box; counters in their own runs, kernel-trace only - MI355X_MICROARCH.md, HBM section):
+Collect on the GPU box (counters in their own runs, kernel-trace only - MI355X_MICROARCH.md, HBM / rocprofv3 sections; the
+program itself after `--`, no launcher in between):
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -o f --output-format csv -- \
-        python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --no-graph
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o w --output-format csv -- \
-        python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --no-graph
-    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01/k1_pmc_traffic.json
-FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1 KB = 1024 B per the counter definition (value * 1024 B);
-gfx950 correction: FETCH_SIZE tallies the 128-B requests of wide coalesced streams at 64 B -> doubled."""
+        python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --whole-detector 0 --latency-leg 0 --no-graph
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o w --output-format csv -- (same command)
+    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02/pmc_traffic.json "<workload key>"
+
+Units and corrections. The counters come in KiB (value * 1024 B). The microarchitecture guide states that on gfx950
+FETCH_SIZE tallies the 128-byte requests of wide coalesced streams at 64 B (so it reads half the bytes) and that WRITE_SIZE is
+exact. Instead of trusting that factor blindly it is MEASURED here: bench.py's copy-ceiling leg runs a 1 GiB device-to-device
+torch copy (13 launches of one elementwise kernel reading 2^30 and writing 2^30 bytes each) inside the same profiled
+process; `calibration.fetch_factor` = known bytes / reported bytes of those launches (expected: 2.0), likewise for writes
+(expected: 1.0). Both the raw and the calibrated numbers are stored."""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 
+KERNELS = ("retr_attn_kernel", "retr_stats_kernel", "retr_logit_stats", "retr_finish", "slot_attn_partial", "slot_attn_finish",
+           "kv_project", "level_fuse", "mask_decode", "row_ln")
+COPY_BYTES = 1 << 30
+
 
 def per_kernel(directory, counter):
-    out = {}
+    out, copies = {}, []
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit(f"no counter_collection.csv under {directory}")
@@ -26,44 +37,50 @@ def per_kernel(directory, counter):
             for row in csv.DictReader(fh):
                 if row.get("Counter_Name") != counter:
                     continue
-                name = row["Kernel_Name"]
-                key = next((k for k in ("slot_attn_partial", "slot_attn_finish", "kv_project", "level_fuse", "mask_decode",
-                                        "row_ln") if k in name), None)
-                if key is None:
-                    continue
-                rec = out.setdefault(key, {"launches": 0, "sum_kb": 0.0})
-                rec["launches"] += 1
-                rec["sum_kb"] += float(row["Counter_Value"])
-    return out
+                name, val = row["Kernel_Name"], float(row["Counter_Value"])
+                key = next((k for k in KERNELS if k in name), None)
+                if key is not None:
+                    rec = out.setdefault(key, {"launches": 0, "sum_kb": 0.0})
+                    rec["launches"] += 1
+                    rec["sum_kb"] += val
+                elif "elementwise" in name and abs(val * 1024 / COPY_BYTES - (0.5 if counter == "FETCH_SIZE" else 1.0)) < 0.2:
+                    copies.append(val * 1024)            # the 1 GiB copy launches (a 2x window around the expected reading)
+    return out, copies
 
 
 def main():
     fetch_dir, write_dir, dst = sys.argv[1:4]
-    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
-    write = per_kernel(write_dir, "WRITE_SIZE")
-    k = "slot_attn_partial"
-    n = fetch[k]["launches"]
-    assert n == write[k]["launches"], (n, write[k]["launches"])
-    fb = fetch[k]["sum_kb"] * 1024 * 2 / n
-    wb = write[k]["sum_kb"] * 1024 / n
-    rec = {"kernel": "slot_attn_partial_ws",
-           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                      "--warmup 1 --cpu-baseline 0 --no-graph (default workload: 16 clips of T=5 stacked per launch)",
-           "launches": n, "fetch_bytes_per_launch_corrected_x2": fb, "write_bytes_per_launch": wb,
-           "traffic_bytes_per_launch": fb + wb,
-           "note": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streams -> doubled "
-                   "(MI355X_MICROARCH.md HBM section); WRITE_SIZE exact",
-           "per_kernel_traffic_bytes_per_launch": {
-               kk: (fetch[kk]["sum_kb"] * 2048 + write.get(kk, {"sum_kb": 0.0})["sum_kb"] * 1024) / fetch[kk]["launches"]
-               for kk in fetch},
-           "all_kernels": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}}
+    fetch, fcop = per_kernel(fetch_dir, "FETCH_SIZE")
+    write, wcop = per_kernel(write_dir, "WRITE_SIZE")
+    if not fcop or not wcop:
+        raise SystemExit("calibration launches (1 GiB torch copy) not found in the counter CSVs")
+    ff = COPY_BYTES / (sum(fcop) / len(fcop))
+    wf = COPY_BYTES / (sum(wcop) / len(wcop))
+    kernels = {}
+    for k in fetch:
+        n = fetch[k]["launches"]
+        raw_f = fetch[k]["sum_kb"] * 1024 / n
+        raw_w = write.get(k, {"sum_kb": 0.0, "launches": n})["sum_kb"] * 1024 / max(1, write.get(k, {"launches": n})["launches"])
+        kernels[k] = {"launches": n, "fetch_bytes_per_launch_raw": raw_f, "write_bytes_per_launch_raw": raw_w,
+                      "fetch_bytes_per_launch": raw_f * ff, "write_bytes_per_launch": raw_w * wf,
+                      "traffic_bytes_per_launch": raw_f * ff + raw_w * wf}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "bench.py"), "rb") as fh:
+        sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+    rec = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
+                      "--cpu-baseline 0 --whole-detector 0 --latency-leg 0 --no-graph",
+           "bench_sha": sha,
+           "calibration": {"what": "1 GiB device-to-device torch copy launched by the same process (bench.py copy-ceiling leg)",
+                           "copy_launches_seen": [len(fcop), len(wcop)], "fetch_factor": ff, "write_factor": wf,
+                           "expected": "fetch 2.0 (gfx950 tallies 128-B requests at 64 B), write 1.0"},
+           "kernels": kernels}
     if len(sys.argv) > 4:
         rec["workload_key"] = sys.argv[4]
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     with open(dst, "w") as fh:
         json.dump(rec, fh, indent=1)
-    print(json.dumps({kk: rec[kk] for kk in ("launches", "fetch_bytes_per_launch_corrected_x2", "write_bytes_per_launch",
-                                             "traffic_bytes_per_launch")}))
+    print(json.dumps({"fetch_factor": ff, "write_factor": wf,
+                      **{k: round(v["traffic_bytes_per_launch"] / 1e9, 3) for k, v in kernels.items()}}))
 
 
 if __name__ == "__main__":
