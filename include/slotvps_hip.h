@@ -229,6 +229,9 @@ int svps_prof_collect(int kernel_id, double* total_ms, int* launches);
  * ------------------------------------------------------------------------------------------- */
 int svps_probe_mfma(const void* a, const void* b, float* c, void* stream);
 int svps_probe_tile(const void* x, void* rows, void* cols, void* stream);
+/* svps_probe_copy: dst[0:bytes] = src[0:bytes] with 16 B per lane streaming loads / stores (bytes a multiple of 16): the
+ * known-bytes kernel the HBM counters are calibrated on and the hand-written copy ceiling of bench.py */
+int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Statistics-fused retriever (K3' + K1'): MaskDynamicConv.forward (dynamic_mask_head.py:423-461) without k / v tensors.

@@ -64,6 +64,7 @@ SIGNATURES = {
     "svps_prof_collect": (_i, [_i, _c.POINTER(_c.c_double), _c.POINTER(_i)]),
     "svps_probe_mfma": (_i, [_vp, _vp, _vp, _vp]),
     "svps_probe_tile": (_i, [_vp, _vp, _vp, _vp]),
+    "svps_probe_copy": (_i, [_vp, _vp, _sz, _vp]),
 }
 
 _lib = None

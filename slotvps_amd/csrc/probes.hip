@@ -45,7 +45,24 @@ __global__ __launch_bounds__(64) void probe_tile_kernel(const __bf16* x, __bf16*
         }
 }
 
+// Known-bytes streaming kernel: 16 B per lane in, 16 B per lane out, every byte once - the access shape of the library's own
+// streams. bench.py times it (a hand-written copy ceiling next to the vendor peak) and tools/pmc_traffic.py calibrates the
+// FETCH_SIZE / WRITE_SIZE counters on it inside the profiled process.
+__global__ __launch_bounds__(256) void probe_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 }  // namespace svps
+
+extern "C" int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream) {
+    if (!src || !dst) return SVPS_ERR_BAD_ARG;
+    if (bytes == 0 || (bytes & 15)) return SVPS_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(svps::probe_copy_kernel, dim3(svps_num_cus() * 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const svps::u32x4*>(src), static_cast<svps::u32x4*>(dst), bytes / 16);
+    return (int)hipGetLastError();
+}
 
 extern "C" int svps_probe_mfma(const void* a, const void* b, float* c, void* stream) {
     if (!a || !b || !c) return SVPS_ERR_BAD_ARG;

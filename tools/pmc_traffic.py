@@ -11,9 +11,9 @@ program itself after `--`, no launcher in between):
 
 Units and corrections. The counters come in KiB (value * 1024 B). The microarchitecture guide states that on gfx950
 FETCH_SIZE tallies the 128-byte requests of wide coalesced streams at 64 B (so it reads half the bytes) and that WRITE_SIZE is
-exact. Instead of trusting that factor blindly it is MEASURED here: bench.py's copy-ceiling leg runs a 1 GiB device-to-device
-torch copy (13 launches of one elementwise kernel reading 2^30 and writing 2^30 bytes each) inside the same profiled
-process; `calibration.fetch_factor` = known bytes / reported bytes of those launches (expected: 2.0), likewise for writes
+exact. Instead of trusting that factor blindly it is MEASURED here: bench.py's copy-ceiling leg launches the library's own
+known-bytes streaming kernel (svps_probe_copy: 16 B per lane loads and stores, the access shape of the library's streams,
+13 launches reading 2^30 and writing 2^30 bytes each) inside the same profiled process; `calibration.fetch_factor` = known bytes / reported bytes of those launches (expected: 2.0), likewise for writes
 (expected: 1.0). Both the raw and the calibrated numbers are stored."""
 import csv
 import glob
@@ -43,8 +43,8 @@ def per_kernel(directory, counter):
                     rec = out.setdefault(key, {"launches": 0, "sum_kb": 0.0})
                     rec["launches"] += 1
                     rec["sum_kb"] += val
-                elif "elementwise" in name and abs(val * 1024 / COPY_BYTES - (0.5 if counter == "FETCH_SIZE" else 1.0)) < 0.2:
-                    copies.append(val * 1024)            # the 1 GiB copy launches (a 2x window around the expected reading)
+                elif "probe_copy_kernel" in name:
+                    copies.append(val * 1024)            # the library's known-bytes streaming kernel: 1 GiB in, 1 GiB out per launch
     return out, copies
 
 
@@ -67,10 +67,10 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "bench.py"), "rb") as fh:
         sha = hashlib.sha256(fh.read()).hexdigest()[:16]
-    rec = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
+    rec = {"calibration_kernel": "svps::probe_copy_kernel (csrc/probes.hip)", "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
                       "--cpu-baseline 0 --whole-detector 0 --latency-leg 0 --no-graph",
            "bench_sha": sha,
-           "calibration": {"what": "1 GiB device-to-device torch copy launched by the same process (bench.py copy-ceiling leg)",
+           "calibration": {"what": "1 GiB copies by svps::probe_copy_kernel launched by the same process (bench.py copy-ceiling leg)",
                            "copy_launches_seen": [len(fcop), len(wcop)], "fetch_factor": ff, "write_factor": wf,
                            "expected": "fetch 2.0 (gfx950 tallies 128-B requests at 64 B), write 1.0"},
            "kernels": kernels}
