@@ -116,7 +116,19 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const int sb = w & 3;
     const bool consumer = w >= 4;
     const int r = lane & 31, h = lane >> 5;
-    const int t = blockIdx.y, c = blockIdx.x, C = gridDim.x;
+    const int C = gridDim.x;
+    int t = blockIdx.y, c = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        // XCD-aware frame placement (speed only, any mapping is correct): workgroups are handed to the 8 XCDs round-robin
+        // by linear id, and the producers re-read their frame's position tables (cy / cx, ~0.4 MB per frame) every image
+        // row. With the natural (chunk, frame) order a frame's workgroups land on all 8 XCDs and every 4 MB L2 sees the
+        // tables of all frames in flight (measured: 1.35x the algorithmic bytes leave L2); here all chunks of a frame go
+        // to ONE XCD, so an L2 holds the tables of the two or three frames its 32 CUs work on.
+        const int b = blockIdx.y * C + blockIdx.x;
+        const int n = b >> 3;
+        t = (b & 7) + 8 * (n / C);
+        c = n % C;
+    }
 
     const int px_begin = c * tiles_per_chunk * kTilePx;
     int px_end = px_begin + tiles_per_chunk * kTilePx;
