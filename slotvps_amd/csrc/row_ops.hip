@@ -112,50 +112,60 @@ __global__ __launch_bounds__(256) void retr_split_kernel(const float* __restrict
 
 // ---- slot self-attention (nn.MultiheadAttention of a stage, dynamic_mask_head.py:346-355) -------------------------------
 // softmax(q k^T / sqrt(hd)) v for one (frame, head) per workgroup on the packed projection qkv [T, L, 3, nh, hd] (hd = 32):
-// L <= 256 slots, k and v of the head in LDS (transposed k: conflict-free dot products), one thread per query row, fp32
-// throughout, two-pass softmax (max, then exp / sum) like torch. Replaces the framework's generic attention kernel for
+// L <= 256 slots, k and v of the head row-major in LDS (all threads walk the keys together: 16-byte broadcast reads), one
+// thread per query row, fp32 throughout, two-pass softmax (max, then exp / sum) like torch. Replaces the framework's generic attention kernel for
 // these tiny shapes (100 x 100 x 32 per head).
 __global__ __launch_bounds__(256) void slot_self_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int nh, float scale) {
     constexpr int HD = 32;
-    __shared__ float kT[HD][256 + 1];
-    __shared__ float vs[256][HD + 1];
+    extern __shared__ __attribute__((aligned(16))) char sa_smem[];    // 2 x L x 128 B: sized by the launch, so that the ~26 KiB of
+    float4 (*ks)[HD / 4] = reinterpret_cast<float4 (*)[HD / 4]>(sa_smem);               // L = 100 leave room for 5 workgroups per CU
+    float4 (*vs)[HD / 4] = ks + L;                                    // row-major: every thread reads the SAME key row -> LDS broadcast
     const int t = blockIdx.y, hh = blockIdx.x, tid = threadIdx.x;
     const size_t rs = (size_t)3 * nh * HD;                            // floats per (frame, slot) row of qkv
     const float* base = qkv + (size_t)t * L * rs + hh * HD;
-    for (int i = tid; i < L * HD; i += 256) {
-        const int l = i / HD, d = i - l * HD;
-        kT[d][l] = base[(size_t)l * rs + (size_t)nh * HD + d];
-        vs[l][d] = base[(size_t)l * rs + (size_t)2 * nh * HD + d];
+    for (int i = tid; i < L * (HD / 4); i += blockDim.x) {
+        const int l = i / (HD / 4), d4 = i - l * (HD / 4);
+        ks[l][d4] = *reinterpret_cast<const float4*>(base + (size_t)l * rs + (size_t)nh * HD + 4 * d4);
+        vs[l][d4] = *reinterpret_cast<const float4*>(base + (size_t)l * rs + (size_t)2 * nh * HD + 4 * d4);
     }
     __syncthreads();
     if (tid >= L) return;
-    float q[HD];
+    float4 q[HD / 4];
 #pragma unroll
-    for (int d = 0; d < HD; ++d) q[d] = base[(size_t)tid * rs + d] * scale;           // q * (1 / sqrt(hd)), torch's order
-    float m = -INFINITY;
-    for (int j = 0; j < L; ++j) {
-        float sc = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) sc = fmaf(q[d], kT[d][j], sc);
-        m = fmaxf(m, sc);
+    for (int d4 = 0; d4 < HD / 4; ++d4) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)tid * rs + 4 * d4);
+        q[d4] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);      // q * (1 / sqrt(hd)), torch's order
     }
-    float o[HD];
+    auto score = [&](int j) {
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+        for (int d4 = 0; d4 < HD / 4; d4 += 2) {
+            const float4 a = ks[j][d4], b = ks[j][d4 + 1];
+            s0 = fmaf(q[d4].x, a.x, s0); s0 = fmaf(q[d4].y, a.y, s0); s0 = fmaf(q[d4].z, a.z, s0); s0 = fmaf(q[d4].w, a.w, s0);
+            s1 = fmaf(q[d4 + 1].x, b.x, s1); s1 = fmaf(q[d4 + 1].y, b.y, s1); s1 = fmaf(q[d4 + 1].z, b.z, s1); s1 = fmaf(q[d4 + 1].w, b.w, s1);
+        }
+        return s0 + s1;
+    };
+    float m = -INFINITY;
+    for (int j = 0; j < L; ++j) m = fmaxf(m, score(j));
+    float4 o[HD / 4];
+#pragma unroll
+    for (int d4 = 0; d4 < HD / 4; ++d4) o[d4] = make_float4(0.f, 0.f, 0.f, 0.f);
     float den = 0.f;
     for (int j = 0; j < L; ++j) {
-        float sc = 0.f;
-#pragma unroll
-        for (int d = 0; d < HD; ++d) sc = fmaf(q[d], kT[d][j], sc);
-        const float e = expf(sc - m);
+        const float e = expf(score(j) - m);
         den += e;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) o[d] = fmaf(e, vs[j][d], o[d]);
+        for (int d4 = 0; d4 < HD / 4; ++d4) {
+            const float4 v = vs[j][d4];
+            o[d4].x = fmaf(e, v.x, o[d4].x); o[d4].y = fmaf(e, v.y, o[d4].y); o[d4].z = fmaf(e, v.z, o[d4].z); o[d4].w = fmaf(e, v.w, o[d4].w);
+        }
     }
     const float inv = 1.f / den;
     float* dst = out + ((size_t)t * L + tid) * nh * HD + hh * HD;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) dst[d] = o[d] * inv;
+    for (int d4 = 0; d4 < HD / 4; ++d4)
+        *reinterpret_cast<float4*>(dst + 4 * d4) = make_float4(o[d4].x * inv, o[d4].y * inv, o[d4].z * inv, o[d4].w * inv);
 }
 
 }  // namespace svps
@@ -183,8 +193,8 @@ extern "C" int svps_retr_split(const float* q2, void* hi, void* lo, size_t n, vo
 extern "C" int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream_) {
     if (!qkv || !out) return SVPS_ERR_BAD_ARG;
     if (T <= 0 || L <= 0 || L > 256 || nheads <= 0 || head_dim != 32) return SVPS_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(svps::slot_self_attn_kernel, dim3(nheads, T), dim3(256), 0, static_cast<hipStream_t>(stream_), qkv, out, L, nheads,
-                       1.0f / sqrtf((float)head_dim));
+    hipLaunchKernelGGL(svps::slot_self_attn_kernel, dim3(nheads, T), dim3(L <= 128 ? 128 : 256), (size_t)2 * L * head_dim * sizeof(float),
+                       static_cast<hipStream_t>(stream_), qkv, out, L, nheads, 1.0f / sqrtf((float)head_dim));
     return (int)hipGetLastError();
 }
 
