@@ -12,7 +12,7 @@ running them on seeded inputs (fixtures under tests/golden/). The reference has 
 known-answer vectors of its own, so these captured outputs are the pin.
 generate_final_outputs (vps_temporal_slots.py:144-160) is pinned by executing the torch ops of
 those lines on the same seeded inputs inside tests/golden/make_golden.py (the enclosing module needs
-mmcv, which the container lacks).
+mmcv, which the container lacks). Exception: deform_conv (f2-ii) is parity-UNPINNED, see its docstring.
 
 Parameters are passed as flat dicts keyed by the reference's state_dict names, e.g.
 ``head_series_2.1.inst_interact.to_k.weight``, so captured checkpoints plug in unchanged.
@@ -396,9 +396,11 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, deformable_g
     """x [C, H, W], offset [dg*2*kh*kw, Ho, Wo] (channel 2*(i*kw+j) = dy, +1 = dx), weight [O, C, kh, kw]
     -> [O, Ho, Wo]. Published DCNv1 forward as the reference's CUDA kernel evaluates it: sample at
     (h_in + i*dil + dy, w_in + j*dil + dx), zero outside (-1, H) x (-1, W), bilinear with out-of-image corners = 0,
-    then the ordinary convolution sum (im2col + addmm, deform_conv_cuda.cpp:152-258). Not pinned by a reference
-    run (the reference's op is CUDA-only, deform_conv.py:44-45); pinned by zero-offset == conv2d and
-    integer-offset == shifted conv properties in the tests."""
+    then the ordinary convolution sum (im2col + addmm, deform_conv_cuda.cpp:152-258).
+    PARITY UNPINNED for this function: the reference's op is CUDA-only (deform_conv.py:44-45) and cannot run in the build
+    container, and the reference holds no vectors for it; what the tests check are properties of the published DCNv1
+    formula (zero offsets == conv2d, integer offsets == shifted conv, fractional offsets == the hand-computed bilinear
+    blend). The semantic-tower fixture that uses it is therefore not an independent pin either."""
     x = np.asarray(x)
     C, H, W = x.shape
     O, _, kh, kw = weight.shape
