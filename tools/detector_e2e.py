@@ -1,48 +1,69 @@
-"""Informational: whole-detector timing on one synthetic 1024x2048 T=5 clip (PyTorch trunk + HIP head + GPU post-process)."""
-import os, sys, time
+"""Informational: whole-detector timing of one synthetic clip at a config's own geometry (PyTorch trunk + HIP head + GPU
+post-process + tracker), one JSON line. Random weights, a fixed slot -> class table so that segments survive the post-process.
+    python tools/detector_e2e.py [--config configs/swinL_fpn_slotvps_mi355x.py] [--frames N] [--profile-tower 1]"""
+import argparse, json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from slotvps_amd.config import Config
 from slotvps_amd.registry import build_detector
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default=os.path.join(ROOT, "configs", "r50_fpn_slotvps_mi355x.py"))
+ap.add_argument("--frames", type=int, default=0)
+ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--graph", type=int, default=1)
+ap.add_argument("--profile-tower", type=int, default=0)
+a = ap.parse_args()
 dev = torch.device("cuda:0")
-cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "r50_fpn_slotvps_mi355x.py"))
+cfg = Config.fromfile(a.config)
 torch.manual_seed(0)
 det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
-T, H, W = 5, 1024, 2048
+det.use_graph = bool(a.graph)
+T = a.frames or cfg.clip["frames"]
+H, W = cfg.clip["height"], cfg.clip["width"]
+L = det.image_model.init_mask_query.weight.shape[0]
+nc = det.num_classes
+div = 100000 if nc in (23, 24) else 10000
 imgs = torch.randn(T, 3, H, W, device=dev)
-table = torch.zeros(100, 20, device=dev); table[torch.arange(100), torch.arange(100) % 19] = 12.0
+table = torch.zeros(L, nc, device=dev)
+table[torch.arange(L), torch.arange(L) % (nc - 1)] = 12.0
 with torch.no_grad():
     det.image_model.fg_bn.weight.fill_(40.0)
 base = det.head_path
 det.head_path = lambda f: (lambda lg, em, mk: (lg + table, em, mk))(*base(f))
-metas = [dict(iid=10001 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png") for t in range(T)]
-def timed(fn, n=3):
+metas = [dict(iid=div + 1 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png") for t in range(T)]
+
+
+def timed(fn, n=a.iters):
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(n): out = fn()
+    for _ in range(n):
+        out = fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3, out
+
+
 with torch.no_grad():
     t_trunk, (feats, fcn) = timed(lambda: det.trunk(imgs))
-    t_head, (lg, em, mk) = timed(lambda: det.head_path(feats))
+    t_head, _ = timed(lambda: det.head_path(feats))
     t_all, res = timed(lambda: det.clip_test(imgs, metas))
-print(f"trunk (R50 + FPN + UPSNetFPN/K7 + conv_trans, PyTorch): {t_trunk:.1f} ms per clip ({t_trunk / T:.1f} ms/frame)")
-print(f"slot head + decode (HIP, eager, one clip): {t_head:.1f} ms per clip")
-print(f"clip_test total incl. post-process + tracker: {t_all:.1f} ms per clip -> {T / t_all * 1e3:.1f} frames/s; post-process+tracker ~ {t_all - t_trunk - t_head:.1f} ms")
-print("segments per frame:", [len(r["panoptic_cls_inds"]) for r in res])
-with torch.no_grad():
     im = det.image_model
     t_bb, x = timed(lambda: im.backbone(imgs))
     t_neck, xn = timed(lambda: im.neck(x))
     t_ups, _ = timed(lambda: det.extract_semantic_feats(xn))
-print(f"backbone {t_bb:.1f} ms, FPN {t_neck:.1f} ms, UPSNetFPN {t_ups:.1f} ms per T=5 clip")
-det.trunk_bf16 = True
-with torch.no_grad():
-    t_trunk16, _ = timed(lambda: det.trunk(imgs))
+    det.trunk_bf16 = True
     t_all16, _ = timed(lambda: det.clip_test(imgs, metas))
-print(f"with trunk_bf16 (autocast): trunk {t_trunk16:.1f} ms, clip_test {t_all16:.1f} ms per clip -> {T / t_all16 * 1e3:.1f} frames/s")
-det.trunk_bf16 = False
-from torch.profiler import profile, ProfilerActivity
-with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof:
-    det.extract_semantic_feats(xn); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=12, max_name_column_width=70))
+    det.trunk_bf16 = False
+print(json.dumps({"config": os.path.basename(a.config), "backbone": type(im.backbone).__name__, "clip": [T, H, W], "slots": L,
+                  "frames_per_s": round(T / t_all * 1e3, 2), "ms_per_clip": round(t_all, 1), "trunk_ms": round(t_trunk, 1),
+                  "backbone_ms": round(t_bb, 1), "fpn_ms": round(t_neck, 1), "semantic_tower_ms": round(t_ups, 1),
+                  "slot_head_ms": round(t_head, 1), "post_process_and_tracker_ms": round(t_all - t_trunk - t_head, 1),
+                  "frames_per_s_bf16_trunk": round(T / t_all16 * 1e3, 2),
+                  "segments_per_frame": [len(r["panoptic_cls_inds"]) for r in res],
+                  "peak_mem_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}), flush=True)
+if a.profile_tower:
+    from torch.profiler import profile, ProfilerActivity
+    with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof:
+        det.extract_semantic_feats(xn); torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=12, max_name_column_width=70))
