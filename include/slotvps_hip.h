@@ -155,6 +155,19 @@ int svps_row_ln(const float* x, const float* pre, const float* post, const float
                 int relu, int rows, int rows_per_group, int D, float* out_f32, void* out_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K7' deformable convolution forward without a column buffer (slotvps_amd/csrc/deform_conv_fused.hip): replaces
+ * deform_conv_forward_cuda (mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-258 = deformable_im2col,
+ * deform_conv_cuda_kernel.cu:190-241, + addmm_) in one kernel: the 3 x 3 bilinear taps of 128 output pixels are gathered
+ * chunk by chunk into LDS as matrix-core operands; operands as bf16 hi + lo, three products, fp32 accumulation (fp32-class).
+ *   x_nhwc [N, H, W, C] fp32; offset [N, 18, Ho, Wo] fp32 (channel 2t = dy, 2t+1 = dx of tap t = 3i + j);
+ *   wpack: the weight [O, C, 3, 3] as [O/32][9C/16][2 (hi, lo)][64 lanes][8] bf16 in MFMA A-fragment order with k = t*C + c:
+ *          element (ob, ks, part, 32h + r, j) = part(W[32 ob + r, c, i, j']) at k = 16 ks + 8 h + j  (slotvps_amd/dcn.py packs it)
+ *   out [N, Ho*Wo, O] fp32 pixel-major.   3 x 3 kernels, one deformable group, C % 64 == 0, O = 128 or 256.
+ * ------------------------------------------------------------------------------------------- */
+int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, int N, int C, int H,
+                               int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho, int Wo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Slot-side helpers (slotvps_amd/csrc/row_ops.hip), rows of D = 256 fp32 values.
  *
  * svps_retr_query_prep: the query side of the fused retriever from x = to_q(slots) [T, L, D] (dynamic_mask_head.py:431):

@@ -1,0 +1,215 @@
+// K7' - deformable convolution forward (DCNv1) WITHOUT a column buffer, for gfx950.
+//
+// Replaces deform_conv_forward_cuda of the reference (mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-258): the reference samples
+// the 3 x 3 bilinear taps into a [C * 9, N * Ho * Wo] column buffer (deformable_im2col_gpu_kernel,
+// deform_conv_cuda_kernel.cu:190-241, bilinear rule :82-114) and multiplies it with the flattened weight (addmm_).
+// Here the sampled taps never leave the CU: a workgroup owns 128 output pixels, gathers one (tap, 64-channel) chunk of
+// their samples at a time into LDS as a matrix-core B tile and accumulates  out[o, px] += W[o, tap, c] * sample[px, tap, c]
+// on v_mfma_f32_32x32x16_bf16.
+//
+// Precision: the reference's op is fp32. Both operands are carried as bf16 hi + lo (16-bit mantissa) and the three
+// significant products (hi.hi, lo.hi, hi.lo) are accumulated in fp32: "split-bf16", relative error ~1e-5 of the largest
+// term - the class of the fp32 op's own summation-order noise - at a third of the bf16 matrix rate instead of the fp32
+// matrix rate, which on gfx950 is the vector rate (1/16).
+//
+// Layouts: input pixel-major NHWC fp32 (a pixel's 64-channel chunk is 256 contiguous bytes: coalesced corner reads);
+// offsets in the reference's layout [N, 2*kh*kw, Ho, Wo] (channel 2t = dy, 2t+1 = dx of tap t); weights pre-packed by the
+// host into MFMA A-fragment order (hi and lo), k = tap * C + c; output pixel-major [N, Ho*Wo, O] fp32.
+// Sampling rule (:82-114, :222-236): a sample outside (-1, H) x (-1, W) is zero; corners outside the image contribute zero.
+//
+// Mapping: 8 waves. O = 256: wave w owns output channels [32w, 32w+32) for all four 32-pixel blocks of the tile;
+// O = 128: wave w owns channel block w & 3 for pixel blocks 2(w>>2), 2(w>>2)+1. Per chunk and wave 48 (24) MFMA; the gather
+// of chunk i+1 (16 x 16-byte loads per thread) is in flight under the MFMAs of chunk i, its blend + hi/lo split + LDS
+// write follow; one workgroup barrier per chunk; weights stream from L2 in fragment order (1 KiB per wave instruction).
+#include "common.h"
+#include "../../include/slotvps_hip.h"
+
+namespace svps {
+
+constexpr int kDcPx = 128;                 // output pixels per workgroup
+constexpr int kDcCh = 64;                  // channels per chunk (4 k-steps)
+constexpr int kDcRow = kDcCh * 2 + 16;     // bytes per pixel row of a sample tile (padded: conflict-free 16-byte fragment reads)
+
+struct DcLds {
+    static constexpr int coords = 0;                                   // [9][128] x {int idx[4]; float w[4]}
+    static constexpr int bufs = 9 * kDcPx * 32;                        // [2][hi | lo][128 px][kDcRow]
+    static constexpr int buf_bytes = 2 * kDcPx * kDcRow;
+    static constexpr int total = bufs + 2 * buf_bytes;
+};
+
+template <int OB>                          // output channel blocks: 8 (O = 256) or 4 (O = 128)
+__global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __restrict__ x,        // [N, H, W, C]
+                                                                const float* __restrict__ offset,   // [N, 18, Ho, Wo]
+                                                                const __bf16* __restrict__ wpack,   // [OB, KS, 2, 64, 8]
+                                                                float* __restrict__ out,            // [N, Ho*Wo, 32 OB]
+                                                                int C, int H, int W, int Ho, int Wo, int pad, int stride, int dil) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = DcLds;
+    constexpr int NB = 32 / OB;            // pixel blocks per wave: 4 or ... (OB = 8 -> 4, OB = 4 -> 2)
+    constexpr int NPB = (OB == 8) ? 4 : 2;
+    static_assert(OB == 8 || OB == 4, "O = 256 or 128");
+    (void)NB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y;
+    const int HWo = Ho * Wo;
+    const int p0 = blockIdx.x * kDcPx;
+    const int ob = (OB == 8) ? w : (w & 3);
+    const int pb0 = (OB == 8) ? 0 : 2 * (w >> 2);
+    const int KS = 9 * C / 16;
+    const int cchunks = C / kDcCh, nch = 9 * cchunks;
+    const float* xn = x + (size_t)n * H * W * C;
+
+    // ---- sampling coordinates of the tile: 9 taps x 128 pixels -> 4 clamped corner indices + 4 weights (0 where invalid) ----
+    for (int e = tid; e < 9 * kDcPx; e += 512) {
+        const int t = e / kDcPx, px = e - t * kDcPx;
+        int p = p0 + px;
+        p = p < HWo ? p : HWo - 1;
+        const int ho = p / Wo, wo = p - ho * Wo;
+        const float* off = offset + ((size_t)n * 18 + 2 * t) * HWo + p;
+        const int i = t / 3, j = t - 3 * i;
+        const float hf = (float)(ho * stride - pad + i * dil) + off[0];
+        const float wf = (float)(wo * stride - pad + j * dil) + off[HWo];
+        int idx[4] = {0, 0, 0, 0};
+        float wt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (hf > -1.f && wf > -1.f && hf < (float)H && wf < (float)W) {
+            const int hl = (int)floorf(hf), wl = (int)floorf(wf);
+            const int hh = hl + 1, wh = wl + 1;
+            const float lh = hf - (float)hl, lw = wf - (float)wl;
+            const float uh = 1.f - lh, uw = 1.f - lw;
+            const int hlc = hl < 0 ? 0 : hl, wlc = wl < 0 ? 0 : wl;
+            const int hhc = hh > H - 1 ? H - 1 : hh, whc = wh > W - 1 ? W - 1 : wh;
+            idx[0] = hlc * W + wlc; idx[1] = hlc * W + whc; idx[2] = hhc * W + wlc; idx[3] = hhc * W + whc;
+            wt[0] = (hl >= 0 && wl >= 0) ? uh * uw : 0.f;
+            wt[1] = (hl >= 0 && wh <= W - 1) ? uh * lw : 0.f;
+            wt[2] = (hh <= H - 1 && wl >= 0) ? lh * uw : 0.f;
+            wt[3] = (hh <= H - 1 && wh <= W - 1) ? lh * lw : 0.f;
+        }
+        int* ci = reinterpret_cast<int*>(smem + Lds::coords + e * 32);
+        ci[0] = idx[0]; ci[1] = idx[1]; ci[2] = idx[2]; ci[3] = idx[3];
+        float* cw = reinterpret_cast<float*>(ci + 4);
+        cw[0] = wt[0]; cw[1] = wt[1]; cw[2] = wt[2]; cw[3] = wt[3];
+    }
+    __syncthreads();
+
+    // ---- gather / blend: thread -> items q = tid + 512 i (i < 4): pixel q >> 4, channel group (q & 15) * 4 of the chunk ----
+    f32x4 gv[4][4];                       // [item][corner]
+    f32x4 gw[4];                          // corner weights of the item's (tap, pixel)
+    auto gather = [&](int ch) {
+        const int t = ch / cchunks, c0 = (ch - t * cchunks) * kDcCh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 512 * i, px = q >> 4, cg = (q & 15) * 4;
+            const int* ci = reinterpret_cast<const int*>(smem + Lds::coords + (t * kDcPx + px) * 32);
+            const u32x4 id = *reinterpret_cast<const u32x4*>(ci);
+            gw[i] = *reinterpret_cast<const f32x4*>(ci + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                gv[i][k] = *reinterpret_cast<const f32x4*>(xn + (size_t)id[k] * C + c0 + cg);
+        }
+    };
+    auto blend_store = [&](int buf) {
+        char* bh = smem + Lds::bufs + buf * Lds::buf_bytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 512 * i, px = q >> 4, cg = (q & 15) * 4;
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // the reference's expression: w1 v1 + w2 v2 + w3 v3 + w4 v4 (:112)
+                const float v = gw[i][0] * gv[i][0][e] + gw[i][1] * gv[i][1][e] + gw[i][2] * gv[i][2][e] + gw[i][3] * gv[i][3][e];
+                vh[e] = (__bf16)v;
+                vl[e] = (__bf16)(v - (float)vh[e]);
+            }
+            *reinterpret_cast<bf16x4*>(bh + px * kDcRow + cg * 2) = vh;
+            *reinterpret_cast<bf16x4*>(bh + kDcPx * kDcRow + px * kDcRow + cg * 2) = vl;
+        }
+    };
+
+    f32x16 acc[NPB];
+#pragma unroll
+    for (int b = 0; b < NPB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+
+    gather(0);
+    blend_store(0);
+    __syncthreads();
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpack) + ((size_t)ob * KS * 2) * 64 + lane;   // fragment (ks, part): + (ks * 2 + part) * 64
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) gather(ch + 1);                                  // in flight under the MFMAs below
+        const char* bh = smem + Lds::bufs + (ch & 1) * Lds::buf_bytes;
+        const char* bl = bh + kDcPx * kDcRow;
+        // weights of the chunk's four k-steps (hi, lo): k-step index of chunk ch = ch * 4 + u  (k = tap * C + c)
+        bf16x8 ah[4], al[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ah[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ch * 4 + u) * 2) * 64]);
+            al[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ch * 4 + u) * 2 + 1) * 64]);
+        }
+#pragma unroll
+        for (int b = 0; b < NPB; ++b) {
+            const int prow = (32 * (pb0 + b) + r) * kDcRow + 16 * h;
+            bf16x8 sh[4], sl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sh[u] = *reinterpret_cast<const bf16x8*>(bh + prow + 32 * u);
+                sl[u] = *reinterpret_cast<const bf16x8*>(bl + prow + 32 * u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], sh[u], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], sh[u], acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], sl[u], acc[b], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nch) blend_store((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- out[n, p, o]: lane (pixel r of block b, h) holds output channels 32 ob + 8 g + 4 h + i ----
+    float* on = out + (size_t)n * HWo * (32 * OB);
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+        const int p = p0 + 32 * (pb0 + b) + r;
+        if (p < HWo) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[b][4 * g], acc[b][4 * g + 1], acc[b][4 * g + 2], acc[b][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(on + (size_t)p * (32 * OB) + 32 * ob + 8 * g + 4 * h) = v;
+            }
+        }
+    }
+}
+
+}  // namespace svps
+
+extern "C" int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, int N, int C,
+                                          int H, int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho, int Wo,
+                                          void* stream_) {
+    if (!x_nhwc || !offset || !wpack || !out) return SVPS_ERR_BAD_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || kh != 3 || kw != 3 || C <= 0 || (C % svps::kDcCh) || (O != 128 && O != 256) || stride <= 0 ||
+        dil <= 0 || pad < 0)
+        return SVPS_ERR_BAD_SHAPE;
+    if (Ho != (H + 2 * pad - (dil * 2 + 1)) / stride + 1 || Wo != (W + 2 * pad - (dil * 2 + 1)) / stride + 1) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)H * W * C >= ((size_t)1 << 31)) return SVPS_ERR_BAD_SHAPE;          // 32-bit pixel indices inside a frame
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tiles = (Ho * Wo + svps::kDcPx - 1) / svps::kDcPx;
+    svps_prof_mark(SVPS_KERNEL_DEFORM_CONV, 0, stream);
+    if (O == 256) {
+        auto kern = svps::deform_conv_fused_kernel<8>;
+        static SvpsLdsAttr attr;
+        if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DcLds::total); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(kern, dim3(tiles, N), dim3(512), svps::DcLds::total, stream, x_nhwc, offset, static_cast<const __bf16*>(wpack),
+                           out, C, H, W, Ho, Wo, pad, stride, dil);
+    } else {
+        auto kern = svps::deform_conv_fused_kernel<4>;
+        static SvpsLdsAttr attr;
+        if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DcLds::total); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(kern, dim3(tiles, N), dim3(512), svps::DcLds::total, stream, x_nhwc, offset, static_cast<const __bf16*>(wpack),
+                           out, C, H, W, Ho, Wo, pad, stride, dil);
+    }
+    svps_prof_mark(SVPS_KERNEL_DEFORM_CONV, 1, stream);
+    return (int)hipGetLastError();
+}

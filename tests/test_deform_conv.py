@@ -58,6 +58,42 @@ def test_hip_deform_conv_matches_oracle(cuda, N, C, O, H, W, dg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,C,O,H,W,scale", [(2, 256, 256, 16, 32, 2.5), (1, 256, 128, 33, 20, 2.5), (2, 128, 128, 9, 7, 6.0),
+                                             (1, 64, 128, 40, 40, 0.0)])
+def test_fused_deform_conv_without_column_buffer_matches_oracle(cuda, N, C, O, H, W, scale):
+    """K7' (csrc/deform_conv_fused.hip): one kernel, no column buffer, split-bf16 products with fp32 accumulation, against
+    the float64 oracle on the same fp32 input: fp32-class tolerance (the im2col + fp32 GEMM path holds 2e-5). Offsets reach
+    far outside the image (scale 6), ragged tiles (pixel counts no multiple of 128), and zero offsets == conv2d."""
+    import torch
+    from slotvps_amd.dcn import DeformConv
+    rng = np.random.default_rng(C + O + H)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    m = DeformConv(C, O, 3, padding=1).to(cuda)
+    w = (rng.standard_normal((O, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32)
+    with torch.no_grad():
+        m.weight.copy_(torch.from_numpy(w))
+    off = (scale * rng.standard_normal((N, 18, H, W))).astype(np.float32)
+    with torch.no_grad():
+        assert m.fused and not m.bf16_operands
+        out = m(torch.from_numpy(x).to(cuda), torch.from_numpy(off).to(cuda))
+        m.fused = False
+        out_im2col = m(torch.from_numpy(x).to(cuda), torch.from_numpy(off).to(cuda))
+    torch.cuda.synchronize()
+    assert out.shape == (N, O, H, W)
+    out, out_im2col = out.cpu().numpy(), out_im2col.cpu().numpy()
+    worst = 0.0
+    for n in range(N):
+        ref = orc.deform_conv(x[n].astype(np.float64), off[n].astype(np.float64), w.astype(np.float64), 1, 1, 1, 1)
+        worst = max(worst, float(np.abs(out[n] - ref).max()))
+    print(f"\nK7' C={C} O={O} {H}x{W}: max abs err vs float64 oracle {worst:.2e} (outputs of order 1); "
+          f"vs the im2col + fp32 GEMM path {np.abs(out - out_im2col).max():.2e}")
+    assert worst < 3e-5
+    if scale == 0.0:
+        want = torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1).numpy()
+        assert np.abs(out - want).max() < 3e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,C,O,H,W,dg", [(2, 256, 128, 16, 32, 1), (1, 32, 16, 12, 10, 2), (1, 128, 128, 33, 20, 1)])
 def test_hip_deform_conv_bf16_operands_match_oracle(cuda, N, C, O, H, W, dg):
     """bf16 operand path: the oracle (float64) on the same bf16-rounded input and weight; what is left is the bf16
