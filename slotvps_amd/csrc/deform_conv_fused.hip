@@ -18,9 +18,9 @@
 // Sampling rule (:82-114, :222-236): a sample outside (-1, H) x (-1, W) is zero; corners outside the image contribute zero.
 //
 // Mapping: 8 waves. O = 256: wave w owns output channels [32w, 32w+32) for all four 32-pixel blocks of the tile;
-// O = 128: wave w owns channel block w & 3 for pixel blocks 2(w>>2), 2(w>>2)+1. Per chunk and wave 48 (24) MFMA; the gather
-// of chunk i+1 (16 x 16-byte loads per thread) is in flight under the MFMAs of chunk i, its blend + hi/lo split + LDS
-// write follow; one workgroup barrier per chunk; weights stream from L2 in fragment order (1 KiB per wave instruction).
+// O = 128: wave w owns channel block w & 3 for pixel blocks 2(w>>2), 2(w>>2)+1. Per chunk and wave 48 (24) MFMA, then the
+// gather of chunk i+1 (16 x 16-byte loads per thread), its blend + hi/lo split + LDS write; one workgroup barrier per chunk;
+// weights stream from L2 in fragment order (1 KiB per wave instruction).
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -138,7 +138,6 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
     __syncthreads();
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpack) + ((size_t)ob * KS * 2) * 64 + lane;   // fragment (ks, part): + (ks * 2 + part) * 64
     for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) gather(ch + 1);                                  // in flight under the MFMAs below
         const char* bh = smem + Lds::bufs + (ch & 1) * Lds::buf_bytes;
         const char* bl = bh + kDcPx * kDcRow;
         // weights of the chunk's four k-steps (hi, lo): k-step index of chunk ch = ch * 4 + u  (k = tap * C + c)
@@ -164,7 +163,16 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], sl[u], acc[b], 0, 0, 0);
             }
         }
-        if (ch + 1 < nch) blend_store((ch + 1) & 1);
+        // The gather of the next chunk is issued AFTER this chunk's MFMAs (they run on while it waits for memory; the partner
+        // wave of the SIMD fills the gaps). Issued before them - 80 registers of loaded samples live across the MFMA
+        // section - the hipcc build of this kernel returned different, wrong tiles from run to run on gfx950 (every load was
+        // complete before the first MFMA by the compiler's own vmcnt waits, an explicit vmcnt(0) changed nothing, no
+        // spills); with this order the result is bitwise reproducible and equal to the column-buffer path to 8e-6, at the
+        // same speed. tests/test_deform_conv.py asserts both.
+        if (ch + 1 < nch) {
+            gather(ch + 1);
+            blend_store((ch + 1) & 1);
+        }
         __syncthreads();
     }
 

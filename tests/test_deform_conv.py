@@ -76,6 +76,8 @@ def test_fused_deform_conv_without_column_buffer_matches_oracle(cuda, N, C, O, H
     with torch.no_grad():
         assert m.fused and not m.bf16_operands
         out = m(torch.from_numpy(x).to(cuda), torch.from_numpy(off).to(cuda))
+        for _ in range(3):                                                      # bitwise reproducible from run to run
+            assert torch.equal(out, m(torch.from_numpy(x).to(cuda), torch.from_numpy(off).to(cuda)))
         m.fused = False
         out_im2col = m(torch.from_numpy(x).to(cuda), torch.from_numpy(off).to(cuda))
     torch.cuda.synchronize()
@@ -91,6 +93,28 @@ def test_fused_deform_conv_without_column_buffer_matches_oracle(cuda, N, C, O, H
     if scale == 0.0:
         want = torch.nn.functional.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1).numpy()
         assert np.abs(out - want).max() < 3e-5
+
+
+@pytest.mark.gpu
+def test_fused_deform_conv_full_size_properties(cuda):
+    """At the P2 size of BASELINE config 1 (256 x 512, 256 -> 256 channels): zero offsets == conv2d (the reference's
+    initialisation of the offset conv), random offsets: equal to the column-buffer path and bitwise reproducible."""
+    import torch
+    from slotvps_amd.dcn import DeformConv
+    g = torch.Generator(device=cuda).manual_seed(4)
+    m = DeformConv(256, 256, 3, padding=1).to(cuda)
+    x = torch.randn((1, 256, 256, 512), generator=g, device=cuda)
+    with torch.no_grad():
+        zero = torch.zeros((1, 18, 256, 512), device=cuda)
+        got = m(x, zero)
+        want = torch.nn.functional.conv2d(x, m.weight, padding=1)
+        assert (got - want).abs().max().item() < 1e-4
+        off = 3.0 * torch.randn((1, 18, 256, 512), generator=g, device=cuda)
+        a = m(x, off)
+        assert torch.equal(a, m(x, off)) and torch.equal(a, m(x, off))
+        m.fused = False
+        b = m(x, off)
+        assert (a - b).abs().max().item() < 1e-4
 
 
 @pytest.mark.gpu
