@@ -272,7 +272,18 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
     int tile_end = tile_begin + tiles_per_chunk;
     tile_end = tile_end < tiles ? tile_end : tiles;
     const int nt = tile_end - tile_begin;
-    const int px_begin = tile_begin * kTilePx;
+    // Tile order = COLUMN STRIPS: the g-th tile of the frame is strip g / H (32 output columns), row g % H, so a workgroup
+    // walks DOWN a strip. Consecutive tiles then share their tap rows (output rows 2m+1 and 2m+2 read the same two source
+    // rows, 2m+3 one of them): with row-major order the second use came a whole image row of streaming later
+    // (32 workgroups x 0.5 MB against a 4 MB L2) and was fetched again - 1.33x the algorithmic bytes left L2; now it comes
+    // one tile later. The out tile is still one contiguous 16 KiB block, the incoming map is read as before.
+    const int tiles_per_row = W / kTilePx;
+    (void)tiles_per_row;
+    auto tile_px0 = [&](int tile) {
+        const int g = tile_begin + tile;
+        const int strip = g / H;
+        return (g - strip * H) * W + strip * kTilePx;
+    };
 
     bf16x8 wf[24];
     {
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
     struct Geo { int ys0, ys1, xs_base, x0; float wy; };
     auto geometry = [&](int tile) {
         Geo g;
-        const int px0 = px_begin + tile * kTilePx;
+        const int px0 = tile_px0(tile);
         const int y = px0 / W;
         g.x0 = px0 - y * W;
         const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
     constexpr int kCurDma = NCHW_F32 ? 2 : 1;            // map DMA instructions per wave and tile
     auto stage_cur = [&](int tile) {
         if constexpr (ABL & 8) return;
-        const int px0 = px_begin + tile * kTilePx;
+        const int px0 = tile_px0(tile);
         const uint32_t base = lds0 + Lds::cur + (tile & 1) * Lds::cur_bytes;
 #pragma unroll
         for (int k = 0; k < kCurDma; ++k) {
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
         }
     };
     auto store_out = [&](int tile) {                                  // 16 KiB per tile, 2 x 16 B per thread, linear in HBM
-        const int base = (px_begin + tile * kTilePx) * kRowBytes + tid * 16;
+        const int base = tile_px0(tile) * kRowBytes + tid * 16;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int row = 16 * u + (tid >> 5), gc = tid & 31;
