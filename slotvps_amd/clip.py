@@ -96,13 +96,24 @@ class SlotClipRunner:
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 for _ in range(2):                      # warm-up: lazy inits, kernel attributes, allocator
-                    self._step(slot)
+                    eager = self._step(slot)
+                eager = {k: v.clone() for k, v in eager.items()}
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.outs[slot] = self._step(slot)
             self.graphs[slot] = g
+            # A launch the runtime refuses during capture does not fail there, it is simply missing from the graph:
+            # validate the FIRST replay against the eager step on the same inputs (every kernel is deterministic).
+            g.replay()
+            torch.cuda.synchronize(self.device)
+            for k, ref in eager.items():
+                got = self.outs[slot][k]
+                if not torch.equal(got, ref):
+                    bad = float((got.float() - ref.float()).abs().max())
+                    raise RuntimeError(f"hipGraph replay of the clip step differs from the eager step in '{k}' (max abs {bad}): "
+                                       "a launch was refused or reordered during capture")
         self.graphs[slot].replay()
         self.out = self.outs[slot]
         return self.out
