@@ -171,7 +171,8 @@ int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const v
  * Slot-side helpers (slotvps_amd/csrc/row_ops.hip), rows of D = 256 fp32 values.
  *
  * svps_retr_query_prep: the query side of the fused retriever from x = to_q(slots) [T, L, D] (dynamic_mask_head.py:431):
- *     q = LN(x; lnq)   gp[t, l] = q * lnk_w   c3[t, l] = q . lnk_b   a1[t, l] = gp[t, l] . bck      (rows l >= L: zeros)
+ *     q = LN(x; lnq)   gp[t, l] = q * lnk_w   c3[t, l] = log2(e) q . lnk_b   a1[t, l] = gp[t, l] . bck
+ *     rows l >= L: gp = 0, a1 = 0, c3 = -1e30 (the padding convention of svps_retr_attn_fwd)
  *     gp [T, LP, D] is the operand of Q'' = gp W~_k;  c3, a1 [T, LP];  LP = 128 or 256 >= L;  bck [D] = centred to_k bias
  * svps_retr_split: q2 [n] fp32 -> hi = bf16(q2), lo = bf16(q2 - hi) (n a multiple of 4)
  * svps_slot_self_attn: softmax(q k^T / sqrt(head_dim)) v per (frame, head) on the packed projection
@@ -265,7 +266,8 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *   The slot axis of the inputs is padded to LP = 128 rows (L <= 128) or 256 rows (L <= 256), rows >= L zero:
  *   qh, ql [T, LP, 256] bf16: hi / lo halves of Q'' = (q * gamma_k) W~_k   (q = norm_q(to_q(slots)), :431)
  *   cy [T, H, LP], cx [T, W, LP] fp32: Q''[:, :128] . pos_y[y] + (q * gamma_k) . b~_k  and  Q''[:, 128:] . pos_x[x]
- *   c3 [T, LP] fp32: q . beta_k
+ *   c3 [T, LP] fp32: log2(e) * q . beta_k, and <= -1e30 in the padded rows l >= L (that, with their zero Q'' / cy / cx,
+ *       is what removes them from the softmax: the kernel applies no mask)
  *   out_ext [T, L, 264] fp32: { A_l = sum_p P rstd_v f_p (256), s1_l = sum_p P rstd_v, s0_l = sum_p P, 0 x 6 };
  *       pre-LayerNorm output (:456) = out_ext @ [ (gamma_v * W~_v)^T ; gamma_v * b~_v ; beta_v ; 0 ]
  *   1 <= L <= 256; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 264] fp32

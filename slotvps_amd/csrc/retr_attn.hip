@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const __bf16* __restrict__ ql,      // [T, LP, 256]  lo(Q'')
     const float* __restrict__ cy,       // [T, H, LP]    Q''[:, 0:128] . ytab[y] + a'
     const float* __restrict__ cx,       // [T, W, LP]    Q''[:, 128:256] . xtab[x]
-    const float* __restrict__ c3g,      // [T, LP]
+    const float* __restrict__ c3g,      // [T, LP]  log2(e) * q . beta_k; -1e30 in the padded rows
     const __bf16* __restrict__ feat,    // [T, HW, 256]
     const float* __restrict__ rstd_k,   // [T, HW]
     const float* __restrict__ rstd_v,   // [T, HW]
@@ -229,13 +229,13 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            const float rk_c = rk, tau_c = tau;
+            const float rk_c = rk * kLog2e, tau_c = tau;     // logits are formed directly in the log2 domain (c3 arrives pre-scaled)
             const f32x2 ext_c = ext;
             if (it + 1 < nt) request(it + 1);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (EXT) {
                 // statistics over all slots are known: P = exp(S - max) / sum, one pass, no exchange
-                const float mneg = -ext_c[0] * kLog2e;
+                const float mneg = -ext_c[0];                    // statistics are in the log2 domain as well
                 float fac = ext_c[1] * tau_c;
                 if (!live) fac = 0.f;
                 wg_barrier();                                    // B_stats(it)
@@ -246,9 +246,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                     bf16x4 ph, pl;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const bool ok = slot0 + j + 8 * g < L;
-                        const float v = fmaf(rk_c, s[4 * g + j], c3v[j]);
-                        const float p = ok ? __builtin_amdgcn_exp2f(fmaf(v, kLog2e, mneg)) * fac : 0.f;
+                        const float p = __builtin_amdgcn_exp2f(fmaf(rk_c, s[4 * g + j], c3v[j]) + mneg) * fac;
                         ph[j] = (__bf16)p;
                         pl[j] = (__bf16)(p - (float)ph[j]);
                     }
@@ -258,27 +256,23 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 if (it + 1 < nt) settle();
                 continue;
             }
-            // S = rstd_k * (Q''.f + Cy + Cx) + c3 ; rows past L -> -inf
+            // log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no masking: their
+            // Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep), so they come out as -1e30 and exp2 to exactly 0.
             float mloc = kNegBig;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 c3v = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool ok = slot0 + j + 8 * g < L;
-                    const float v = fmaf(rk_c, s[4 * g + j], c3v[j]);
-                    s[4 * g + j] = ok ? v : kNegBig;
+                    s[4 * g + j] = fmaf(rk_c, s[4 * g + j], c3v[j]);
                     mloc = fmaxf(mloc, s[4 * g + j]);
                 }
             }
             mloc = ra_half_swap_max(mloc);
             float sloc = 0.f;
-            const float mneg = -mloc * kLog2e;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[i], kLog2e, mneg));
-                s[i] = ok ? e : 0.f;
+                s[i] = __builtin_amdgcn_exp2f(s[i] - mloc);
                 sloc += s[i];
             }
             sloc = ra_half_swap_sum(sloc);
@@ -294,8 +288,8 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             float den = 0.f;
 #pragma unroll
             for (int ww = 0; ww < 4; ++ww)
-                den += st_w[ww].y * __builtin_amdgcn_exp2f((st_w[ww].x - mall) * kLog2e);
-            float fac = __builtin_amdgcn_exp2f((mloc - mall) * kLog2e) / den * tau_c;    // P * rstd_v
+                den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
+            float fac = __builtin_amdgcn_exp2f(mloc - mall) / den * tau_c;               // P * rstd_v
             if (!live) fac = 0.f;                                                       // pixels past the chunk / frame
             char* prow = smem + Lds::pring + (it & 1) * kTileBytes + sb * 2048 + r * 64 + 8 * h;
 #pragma unroll
@@ -524,7 +518,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[g][j] + cxv[g][j];
-        const float rk = rk_n;
+        const float rk = rk_n * kLog2e;                              // log2 domain, like retr_attn_kernel
         wg_barrier();                                                // B_top(it); also: every wave is done with f(it-1)
         stage(it + A);
         const char* kt = smem + Lds::ring + (it % NST) * kTileBytes;
@@ -555,20 +549,14 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
             const f32x4 c3v = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool ok = slot0 + j + 8 * g < L;
-                const float v = fmaf(rk, s[4 * g + j], c3v[j]);
-                s[4 * g + j] = ok ? v : kNegBig;
+                s[4 * g + j] = fmaf(rk, s[4 * g + j], c3v[j]);       // padded rows: c3' = -1e30
                 mloc = fmaxf(mloc, s[4 * g + j]);
             }
         }
         mloc = ra_half_swap_max(mloc);
         float sloc = 0.f;
-        const float mneg = -mloc * kLog2e;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const bool ok = slot0 + (i & 3) + 8 * (i >> 2) < L;
-            sloc += ok ? __builtin_amdgcn_exp2f(fmaf(s[i], kLog2e, mneg)) : 0.f;
-        }
+        for (int i = 0; i < 16; ++i) sloc += __builtin_amdgcn_exp2f(s[i] - mloc);
         sloc = ra_half_swap_sum(sloc);
         if (h == 0) stats[w * 32 + r] = make_float2(mloc, sloc);
         wg_barrier();                                                // B_stats(it)
@@ -581,7 +569,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
         }
         float den = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 8; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f((st_w[ww].x - mall) * kLog2e);
+        for (int ww = 0; ww < 8; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
         const int pxs = px_begin + it * kTilePx + r;
         const bool mine = h == 0 && (r >> 2) == w && pxs < px_end;   // wave w stores pixels 4w .. 4w + 3
         const f32x2 val = {mall, 1.f / den};

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void row_ln_kernel(const float* __restrict__ x
 // One wavefront per (frame, padded slot row). From x = to_q(slots) (the GEMM stays a library call):
 //     q = norm_q(x)                         MaskDynamicConv.forward :431
 //     g = q * gamma_k   -> gp [T, LP, 256]  operand of the key fold  Q'' = g W~_k   (rows >= L written as zeros)
-//     c3 = q . beta_k   -> [T, LP]          a1 = g . b~_k -> [T, LP]
+//     c3 = log2(e) q . beta_k (rows >= L: -1e30) -> [T, LP]          a1 = g . b~_k -> [T, LP]
 __global__ __launch_bounds__(256) void retr_query_prep_kernel(const float* __restrict__ x,      // [T, L, 256]
                                                               const float* __restrict__ qw, const float* __restrict__ qb, float eps,
                                                               const float* __restrict__ gk, const float* __restrict__ bek,
@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void retr_query_prep_kernel(const float* __res
         a1v = wave_sum(g.x * c4.x + g.y * c4.y + g.z * c4.z + g.w * c4.w);
     }
     *reinterpret_cast<float4*>(gp + (size_t)row * 256 + 4 * lane) = g;
-    if (lane == 0) { c3[row] = c3v; a1[row] = a1v; }
+    // c3 leaves in the form K1' consumes: log2(e) * q . beta_k (its softmax runs on exp2), and -1e30 in the padded rows, which
+    // is what removes them from every pixel's softmax without a mask in the kernel
+    if (lane == 0) { c3[row] = l < L ? c3v * 1.4426950408889634f : -1.0e30f; a1[row] = a1v; }
 }
 
 // Q'' [rows, 256] fp32 -> bf16 hi and lo = bf16(Q'' - hi), the two A operands of K1'

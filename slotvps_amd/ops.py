@@ -312,7 +312,8 @@ def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
 
 
 def retr_query_prep(x, lnq_w, lnq_b, lnq_eps, lnk_w, lnk_b, bck, LP):
-    """x = to_q(slots) [T, L, 256] fp32 -> (gp [T, LP, 256] = norm_q(x) * lnk_w zero-padded, c3 [T, LP], a1 [T, LP])."""
+    """x = to_q(slots) [T, L, 256] fp32 -> (gp [T, LP, 256] = norm_q(x) * lnk_w zero-padded, c3 [T, LP] = log2(e) q . lnk_b
+    with -1e30 in the padded rows, a1 [T, LP] = gp . bck)."""
     lib = _lib.load()
     _need(x, "x", torch.float32, 3)
     for name, v in (("lnq_w", lnq_w), ("lnq_b", lnq_b), ("lnk_w", lnk_w), ("lnk_b", lnk_b), ("bck", bck)):

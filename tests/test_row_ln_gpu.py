@@ -77,9 +77,9 @@ def test_retr_query_prep_and_split(cuda):
     gp, c3, a1 = ops.retr_query_prep(torch.from_numpy(x).to(cuda), g("qw"), g("qb"), 1e-5, g("kw"), g("kb"), g("bck"), LP)
     q = orc.layer_norm(x.astype(np.float64), v["qw"].astype(np.float64), v["qb"].astype(np.float64))
     gr = q * v["kw"]
-    assert gp.shape == (T, LP, 256) and torch.all(gp[:, L:] == 0) and torch.all(c3[:, L:] == 0) and torch.all(a1[:, L:] == 0)
+    assert gp.shape == (T, LP, 256) and torch.all(gp[:, L:] == 0) and torch.all(c3[:, L:] <= -1e30) and torch.all(a1[:, L:] == 0)
     assert np.abs(gp[:, :L].cpu().numpy() - gr).max() <= 1e-5
-    assert np.abs(c3[:, :L].cpu().numpy() - q @ v["kb"].astype(np.float64)).max() <= 2e-5
+    assert np.abs(c3[:, :L].cpu().numpy() - np.log2(np.e) * (q @ v["kb"].astype(np.float64))).max() <= 4e-5
     assert np.abs(a1[:, :L].cpu().numpy() - gr @ v["bck"].astype(np.float64)).max() <= 2e-5
     hi, lo = ops.retr_split(gp)
     assert torch.equal(hi, gp.to(torch.bfloat16)) and torch.equal(lo, (gp - hi.float()).to(torch.bfloat16))
