@@ -61,7 +61,7 @@ def test_slot_self_attention_kernel_matches_oracle_mha(cuda, T, L):
     got = torch.nn.functional.linear(o, g("out_proj.weight"), g("out_proj.bias")).cpu().numpy()
     for t in range(T):
         ref = orc.multihead_self_attention(x[t].astype(np.float64), P, "", 8, np.float64)
-        assert np.abs(got[t] - ref).max() <= 2e-5
+        assert np.abs(got[t] - ref).max() <= 5e-5          # split-bf16 products with fp32 accumulation: fp32-class
 
 
 def test_retr_query_prep_and_split(cuda):

@@ -22,8 +22,11 @@ import json
 import os
 import sys
 
-KERNELS = ("retr_attn_kernel", "retr_stats_kernel", "retr_logit_stats", "retr_finish", "slot_attn_partial", "slot_attn_finish",
-           "kv_project", "level_fuse", "mask_decode", "row_ln")
+# kernel-name fragment in the trace -> the name bench.py uses in `roofline.per_kernel`
+KERNELS = {"retr_attn_kernel": "retr_attn", "retr_stats_kernel": "retr_stats", "retr_logit_stats": "retr_logit_stats",
+           "retr_finish": "retr_finish", "slot_attn_partial": "slot_attn", "slot_attn_finish": "slot_attn_finish",
+           "kv_project": "kv_project", "level_fuse": "level_fuse", "mask_decode": "mask_decode", "row_ln": "row_ln",
+           "slot_self_attn": "slot_self_attn"}
 COPY_BYTES = 1 << 30
 
 
@@ -38,7 +41,7 @@ def per_kernel(directory, counter):
                 if row.get("Counter_Name") != counter:
                     continue
                 name, val = row["Kernel_Name"], float(row["Counter_Value"])
-                key = next((k for k in KERNELS if k in name), None)
+                key = next((v for k, v in KERNELS.items() if k in name), None)
                 if key is not None:
                     rec = out.setdefault(key, {"launches": 0, "sum_kb": 0.0})
                     rec["launches"] += 1
