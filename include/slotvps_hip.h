@@ -186,6 +186,16 @@ int svps_retr_split(const float* q2, void* hi, void* lo, size_t n, void* stream)
 int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K8 dense layers of the slot update (slotvps_amd/csrc/slot_gemm.hip): y = act(x W^T + bias), the nn.Linear layers of
+ * MaskRCNNHead / TemporalSlotsHead / MaskDynamicConv.to_q (dynamic_mask_head.py:342-400, :494-572, :431) on [M, K] rows.
+ * Matrix cores with both operands as bf16 hi + lo, three products, fp32 accumulation (fp32-class; the reference is fp32).
+ *   x [M, K] fp32; wpack: W [N, K] as [N/32][K/16][2 (hi, lo)][64 lanes][8] bf16 in MFMA B-fragment order
+ *   (element (cb, ks, part, 32h + r, j) = part(W[32 cb + r, 16 ks + 8 h + j]); slotvps_amd/ops.py pack_b_fragments);
+ *   bias [N] fp32 or NULL; act 0 none / 1 ReLU / 2 GELU (erf form); y [M, N] fp32.  K % 16 == 0, N % 256 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int svps_slot_gemm(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K6 full-resolution panoptic post-process (PostProcessPanopticInstances.mask_removal / get_ids_area,
  * mmdet/models/detectors/vps_temporal_slots.py:564-657, :697-698, :724-757; argmax + relabel of simple_test
  * :411-435). Bilinear upsampling to H x W is fused into both kernels; the order-dependent part of
@@ -252,7 +262,7 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  * Both pixel-side LayerNorms are "one scalar per pixel times an affine map":
  *     norm_k(to_k(x_p)) = gamma_k * rstd_k(p) * (W~_k x_p + b~_k) + beta_k,   W~ = (I - 11^T / 256) W,  b~ = b - mean(b)
  * so the pixel side only has to produce rstd_k(p), rstd_v(p) (svps_retr_stats_fwd), the key projection is folded into the
- * queries and the value projection is applied after the pixel sum (svps_retr_attn_fwd + a [L, 264] x [264, 256] product on the
+ * queries and the value projection is applied after the pixel sum (svps_retr_attn_fwd + a [L, 272] x [272, 256] product on the
  * slot side). The fused map is read once per kernel; nothing of size [HW, 256] is written.
  *
  * svps_retr_stats_fwd   (:432-433, the LayerNorm statistics only)
@@ -268,7 +278,7 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *   cy [T, H, LP], cx [T, W, LP] fp32: Q''[:, :128] . pos_y[y] + (q * gamma_k) . b~_k  and  Q''[:, 128:] . pos_x[x]
  *   c3 [T, LP] fp32: log2(e) * q . beta_k, and <= -1e30 in the padded rows l >= L (that, with their zero Q'' / cy / cx,
  *       is what removes them from the softmax: the kernel applies no mask)
- *   out_ext [T, L, 264] fp32: { A_l = sum_p P rstd_v f_p (256), s1_l = sum_p P rstd_v, s0_l = sum_p P, 0 x 6 };
+ *   out_ext [T, L, 272] fp32: { A_l = sum_p P rstd_v f_p (256), s1_l = sum_p P rstd_v, s0_l = sum_p P, 0 x 14 };
  *       pre-LayerNorm output (:456) = out_ext @ [ (gamma_v * W~_v)^T ; gamma_v * b~_v ; beta_v ; 0 ]
  *   1 <= L <= 256; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 264] fp32
  *   (+ [T, HW] x 8 B when L > 128: per-pixel softmax statistics over all slots, written by a first kernel; the retriever then

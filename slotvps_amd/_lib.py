@@ -59,6 +59,7 @@ SIGNATURES = {
     "svps_slot_attn_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_mask_decode_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _i, _vp]),
     "svps_deform_conv_fused_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "svps_slot_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

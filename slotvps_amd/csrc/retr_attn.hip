@@ -40,6 +40,7 @@ constexpr int kRNF = kRPrefetch + 2;       // feature / aux ring depth
 constexpr int kAuxRow = 64;                // bytes per pixel of the aux tensor (32 bf16)
 constexpr int kAuxTile = kTilePx * kAuxRow;
 constexpr int kPartRow = 264;              // floats per slot row of a partial: 256 channels of A + 8 aux columns
+constexpr int kExtRow = 272;               // floats per slot row of the finished result: 17 k-steps of 16 for the slot-side product
 
 struct RetrLds {
     static constexpr int fring = 0;
@@ -584,7 +585,8 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
 }
 
 // Sum of the C partials of every (frame, slot) row in chunk order (bitwise reproducible, no float atomics):
-// out row = { A[0:256], s1, s0, 0 x 6 }, the operand of the slot-side product with [ (gamma_v W~_v)^T ; gamma_v b~_v ; beta_v ].
+// out row (272 floats) = { A[0:256], s1, s0, 0 x 14 }, the operand of the slot-side product with
+// [ (gamma_v W~_v)^T ; gamma_v b~_v ; beta_v ; 0 ].
 __global__ __launch_bounds__(256) void retr_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int L, int C) {
     const int l = blockIdx.x, t = blockIdx.y, d = threadIdx.x;
     const size_t cstride = (size_t)L * kPartRow;
@@ -600,9 +602,9 @@ __global__ __launch_bounds__(256) void retr_finish_kernel(const float* __restric
         for (int u = 0; c < C; ++c, ++u) a8[u] += s[(size_t)c * cstride];
         return ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     };
-    float* o = out + ((size_t)t * L + l) * kPartRow;
+    float* o = out + ((size_t)t * L + l) * kExtRow;
     o[d] = colsum(d);
-    if (d < 8) {
+    if (d < kExtRow - 256) {
         float v = 0.f;
         if (d == 0) v = colsum(256);                         // s1 = sum_p P rstd_v
         else if (d == 1) v = colsum(257) + colsum(258);      // s0 = sum_p P  (sigma_v carried as hi + lo)

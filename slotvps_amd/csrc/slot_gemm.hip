@@ -1,0 +1,143 @@
+// K8 - the dense layers of the slot update on the matrix cores with fp32-class precision, for gfx950.
+//
+// The slot side of a stage (mmdet/models/detectors/dynamic_mask_head.py:342-400, :494-572) is a chain of nn.Linear layers on
+// [T * L, 256] rows: self-attention projections, to_q, the FFN (256 -> 2048 -> 256), the temporal head, the class / embedding
+// towers. The reference runs them in fp32; the fp32 matrix instructions of gfx950 run at the vector rate (1/16 of bf16), and
+// with 8 000 rows per launch the GEMM library reaches ~50 TFLOP/s on them. Here
+//     y[m, n] = act( sum_k x[m, k] W[n, k] + b[n] )
+// runs on v_mfma_f32_32x32x16_bf16 with BOTH operands carried as bf16 hi + lo (16-bit mantissa) and the three significant
+// products accumulated in fp32 ("split-bf16": relative error ~1e-5 of the largest term, the class of fp32 summation-order
+// noise), the weight pre-packed by the host into MFMA B-fragment order (hi and lo), the activation rows split on the fly.
+//
+// Mapping: workgroup = 64 rows x 256 output columns, 8 waves = 2 row blocks x 4 column groups of 64 (two 32 x 32
+// accumulators per wave). K is walked in chunks of 64: the workgroup stages x[64 rows, 64 k] as bf16 hi / lo in LDS
+// (double-buffered, one barrier per chunk), every wave reads its A fragments from there and streams its B fragments from
+// L2 in fragment order (1 KiB per wave instruction, each byte of the weight once per workgroup).
+// Epilogue: + bias[n], ReLU or GELU (exact erf form, F.gelu's default), fp32 store (32 consecutive columns per half-wave).
+#include "common.h"
+#include "../../include/slotvps_hip.h"
+
+namespace svps {
+
+constexpr int kGmRows = 64;                 // rows per workgroup
+constexpr int kGmCols = 256;                // output columns per workgroup
+constexpr int kGmK = 64;                    // k per chunk
+constexpr int kGmRow = kGmK * 2 + 16;       // bytes per row of the staged A tile (padded: conflict-free 16-byte fragment reads)
+
+struct GemmLds {
+    static constexpr int buf_bytes = 2 * kGmRows * kGmRow;      // hi | lo
+    static constexpr int total = 2 * buf_bytes;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int ACT>                          // 0 none, 1 ReLU, 2 GELU (erf)
+__global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict__ x,        // [M, K]
+                                                        const __bf16* __restrict__ wpack,   // [N/32][K/16][2][64][8]
+                                                        const float* __restrict__ bias,     // [N] or null
+                                                        float* __restrict__ y,              // [M, N]
+                                                        int M, int K, int N) {
+    __shared__ __attribute__((aligned(16))) char smem[GemmLds::total];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int rb = w & 1, cg = w >> 1;                          // row block, column group (64 columns)
+    const int m0 = blockIdx.x * kGmRows, n0 = blockIdx.y * kGmCols;
+    const int KS = K / 16, nch = (K + kGmK - 1) / kGmK;
+
+    // A tile staging: thread -> two (row, 4-k group) items per chunk
+    f32x4 av[2];
+    auto gather = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 512 * i, row = q >> 4, kg = (q & 15) * 4;
+            const int m = m0 + row, k = ch * kGmK + kg;
+            av[i] = (m < M && k < K) ? *reinterpret_cast<const f32x4*>(x + (size_t)m * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto split_store = [&](int buf) {
+        char* bh = smem + buf * GemmLds::buf_bytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 512 * i, row = q >> 4, kg = (q & 15) * 4;
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vh[e] = (__bf16)av[i][e];
+                vl[e] = (__bf16)(av[i][e] - (float)vh[e]);
+            }
+            *reinterpret_cast<bf16x4*>(bh + row * kGmRow + kg * 2) = vh;
+            *reinterpret_cast<bf16x4*>(bh + kGmRows * kGmRow + row * kGmRow + kg * 2) = vl;
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+
+    gather(0);
+    split_store(0);
+    __syncthreads();
+    // B fragments of column block cb, k-step ks, part p: u32x4 index ((cb * KS + ks) * 2 + p) * 64 + lane
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpack) + lane;
+    const int cb0 = (n0 >> 5) + 2 * cg;
+    for (int ch = 0; ch < nch; ++ch) {
+        const char* ah = smem + (ch & 1) * GemmLds::buf_bytes + (32 * rb + r) * kGmRow + 16 * h;
+        const char* al = ah + kGmRows * kGmRow;
+        const int nks = (KS - ch * 4) < 4 ? (KS - ch * 4) : 4;   // k-steps of this chunk (the last chunk may be short)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u < nks) {
+                const int ks = ch * 4 + u;
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + 32 * u);
+                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + 32 * u);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const size_t f = ((size_t)(cb0 + b) * KS + ks) * 2 * 64;
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wsrc[f]);
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, wsrc[f + 64]);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[b], 0, 0, 0);
+                }
+            }
+        }
+        if (ch + 1 < nch) {                                     // after the MFMAs (see deform_conv_fused.hip for the order)
+            gather(ch + 1);
+            split_store((ch + 1) & 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: register i of a block = row (i & 3) + 8 (i >> 2) + 4 h, column = lane r
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + 64 * cg + 32 * b + r;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int m = m0 + 32 * rb + (i & 3) + 8 * (i >> 2) + 4 * h;
+            float v = acc[b][i] + bv;
+            if constexpr (ACT == 1) v = v > 0.f ? v : 0.f;
+            if constexpr (ACT == 2) v = gelu_erf(v);
+            if (m < M) y[(size_t)m * N + n] = v;
+        }
+    }
+}
+
+}  // namespace svps
+
+extern "C" int svps_slot_gemm(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, int act,
+                              void* stream_) {
+    if (!x || !wpack || !y) return SVPS_ERR_BAD_ARG;
+    if (M <= 0 || K <= 0 || (K & 15) || N <= 0 || (N % svps::kGmCols) || act < 0 || act > 2) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const dim3 grid((M + svps::kGmRows - 1) / svps::kGmRows, N / svps::kGmCols);
+    const __bf16* wp = static_cast<const __bf16*>(wpack);
+    if (act == 0) hipLaunchKernelGGL(svps::slot_gemm_kernel<0>, grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N);
+    else if (act == 1) hipLaunchKernelGGL(svps::slot_gemm_kernel<1>, grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N);
+    else hipLaunchKernelGGL(svps::slot_gemm_kernel<2>, grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N);
+    return (int)hipGetLastError();
+}

@@ -282,7 +282,7 @@ def retr_slot_pad(L):
 
 
 def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
-    """K1': out_ext [T, L, 264] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
+    """K1': out_ext [T, L, 272] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
     rstd_k (Q''.f + cy + cx) + c3. qh / ql [T, LP, 256] bf16, cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
     padded to LP = 128 (L <= 128) or 256 (L <= 256; statistics kernel + two retriever launches)."""
     lib = _lib.load()
@@ -303,7 +303,7 @@ def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
         raise ValueError("shape mismatch")
     ws_bytes = lib.svps_retr_attn_workspace_bytes(T, L, HW, chunks)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)
-    out = torch.empty((T, L, 264), dtype=torch.float32, device=feat.device)
+    out = torch.empty((T, L, 272), dtype=torch.float32, device=feat.device)
     with _on(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux) as ctx:
         rc = lib.svps_retr_attn_fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(rstd_k), _ptr(rstd_v),
                                     _ptr(aux), _ptr(ws), ws_bytes, _ptr(out), T, L, H, W, D, chunks, ctx.stream)
@@ -352,6 +352,46 @@ def slot_self_attn(qkv, nheads):
     out = torch.empty((T, L, C), dtype=torch.float32, device=qkv.device)
     with _on(qkv) as ctx:
         _lib.check(lib.svps_slot_self_attn(_ptr(qkv), _ptr(out), T, L, nheads, 32, ctx.stream), "svps_slot_self_attn")
+    return out
+
+
+def pack_b_fragments(weight):
+    """nn.Linear weight [N, K] fp32 -> bf16 [N/32, K/16, 2, 64, 8]: hi / lo halves in MFMA B-fragment order (the layout
+    svps_slot_gemm streams: one 1-KiB wave instruction per fragment). N % 32 == 0, K % 16 == 0."""
+    N, K = weight.shape
+    if N % 32 or K % 16:
+        raise ValueError("pack_b_fragments: N % 32 == 0 and K % 16 == 0 required")
+    w = weight.detach().float().contiguous()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+
+    def frag(m):                                   # (cb, r, ks, h, j) -> (cb, ks, h, r, j): lane = 32 h + r
+        return m.view(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(N // 32, K // 16, 64, 8)
+    return torch.stack([frag(hi), frag(lo)], dim=2).contiguous()
+
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def slot_gemm(x, wpack, bias=None, act=ACT_NONE, out=None):
+    """K8: y = act(x @ W^T + bias) for x [..., K] fp32 and wpack = pack_b_fragments(W [N, K]); N % 256 == 0, K % 16 == 0.
+    Split-bf16 matrix-core products with fp32 accumulation (fp32-class; see csrc/slot_gemm.hip)."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    _need(wpack, "wpack", torch.bfloat16, 5)
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = wpack.shape[0] * 32
+    if wpack.shape[1] * 16 != K or N % 256:
+        raise ValueError(f"slot_gemm: x[..., {K}] does not match the packed weight {tuple(wpack.shape)} or N % 256 != 0")
+    if bias is not None:
+        _need(bias, "bias", torch.float32, 1)
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+    elif out.shape != x.shape[:-1] + (N,) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("slot_gemm: out must be a contiguous fp32 tensor of shape x.shape[:-1] + (N,)")
+    with _on(x, wpack, bias, out) as ctx:
+        _lib.check(lib.svps_slot_gemm(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), M, K, N, int(act), ctx.stream), "svps_slot_gemm")
     return out
 
 

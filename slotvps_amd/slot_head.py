@@ -59,6 +59,28 @@ def _cached(module, name, params, build):
     return store[name][1]
 
 
+def fast_linear(owner, name, x, weight, bias=None, act=None, out=None):
+    """y = act(x @ weight^T + bias) for the dense layers of the slot update. bf16 mode: K8 (csrc/slot_gemm.hip: matrix cores,
+    split-bf16 products, fp32 accumulation - fp32-class) with the weight packed once per version into fragment order;
+    exact mode (owner.precision == "fp32") or shapes K8 does not cover: the GEMM library in fp32.
+    act: None, "relu" or "gelu"."""
+    N, K = weight.shape
+    if getattr(owner, "precision", "bf16") == "fp32" or N % 256 or K % 16 or not x.is_cuda or not owner.use_slot_gemm:
+        y = F.linear(x, weight, bias)
+        y = F.relu(y) if act == "relu" else (F.gelu(y) if act == "gelu" else y)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    wp = _cached(owner, "wp_" + name, [weight], lambda: ops.pack_b_fragments(weight))
+    code = {None: ops.ACT_NONE, "relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act]
+    return ops.slot_gemm(x.contiguous(), wp, bias, code, out)
+
+
+def _act_name(fn):
+    return "relu" if fn is F.relu else ("gelu" if fn is F.gelu else None)
+
+
 class ConvModule(nn.Module):
     """1x1 conv + bias held as ``.conv`` - what the reference's ConvModule builds for
     activation=None and no norm (mmdet/models/utils/conv_module.py:95-97, :135)."""
@@ -97,6 +119,7 @@ class MaskDynamicConv(nn.Module):
         # bf16 mode, two forms of the same function: "fused" (default where it applies, L <= 128): statistics-fused retriever
         # K3' + K1' - no k / v tensors, the map is read once per kernel; "kv": K3 writes bf16 k / v, K1 streams them
         self.retriever = "fused"
+        self.use_slot_gemm = True   # K8 for the dense layers (bf16 mode)
 
     def _bf16_weights(self):
         """to_k / to_v weight matrices rounded to bf16 once (re-derived if the parameters change)."""
@@ -130,11 +153,13 @@ class MaskDynamicConv(nn.Module):
             out["wck"] = out["wck"].float().to(dev).contiguous()                               # Q'' = (q * gamma_k) @ W~_k
             out["bck"] = out["bck"].float().to(dev).contiguous()
             gv = self.norm_v.weight.detach().double().cpu()
-            wext = torch.zeros((264, 256), dtype=torch.float64)
+            wext = torch.zeros((272, 256), dtype=torch.float64)
             wext[:256] = (gv[:, None] * out.pop("wcv")).t()                                   # (gamma_v * W~_v)^T
             wext[256] = gv * out.pop("bcv")
             wext[257] = self.norm_v.bias.detach().double().cpu()
             out["wext"] = wext.float().to(dev).contiguous()
+            out["wext_lin"] = out["wext"].t().contiguous()                                      # [256, 272]: the nn.Linear form of the same product
+            out["wck_lin"] = out["wck"].t().contiguous()                                        # [256 (i), 256 (c)]
             return out
         return _cached(self, "fused", srcs, build)
 
@@ -148,9 +173,9 @@ class MaskDynamicConv(nn.Module):
             stats = ops.retr_stats(feat_pm, H, W, pos_tabs, c["rk"], c["rbk"], self.norm_k.eps, c["rv"], c["rbv"], self.norm_v.eps)
         LP = ops.retr_slot_pad(L)
         # :431 q = norm_q(to_q(slots)); g = q * gamma_k (zero rows up to LP), c3 = q . beta_k, a1 = g . b~_k: one launch
-        gp, c3, a1 = ops.retr_query_prep(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps,
-                                         self.norm_k.weight, self.norm_k.bias, c["bck"], LP)
-        q2 = gp @ c["wck"]                                                 # Q'' [T, LP, 256]: the key projection folded into the queries
+        gp, c3, a1 = ops.retr_query_prep(fast_linear(self, "to_q", slots, self.to_q.weight, self.to_q.bias), self.norm_q.weight,
+                                         self.norm_q.bias, self.norm_q.eps, self.norm_k.weight, self.norm_k.bias, c["bck"], LP)
+        q2 = fast_linear(self, "wck", gp, c["wck_lin"])                    # Q'' [T, LP, 256] = gp @ W~_k: the key projection folded into the queries
         qh, ql = ops.retr_split(q2)
         if pos_tabs is not None:                                           # separable position terms + a' (two small tables per frame)
             ytab, xtab = pos_tabs
@@ -160,7 +185,7 @@ class MaskDynamicConv(nn.Module):
             cy = a1[:, None, :].expand(T, H, LP).contiguous()
             cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
         ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats[0], stats[1], stats[2], L, H, W)
-        pre = (ext.view(T * L, 264) @ c["wext"]).view(T, L, C)                                       # :456 (value projection after the sum)
+        pre = fast_linear(self, "wext", ext, c["wext_lin"])                                          # :456 (value projection after the sum)
         return ops.row_ln(pre, self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)        # :458-459
 
     def project_kv(self, feat_pm, hw, pos_tabs):
@@ -227,6 +252,8 @@ class SlotsDynamicConv(nn.Module):
         self.norm_v = nn.LayerNorm(dh_dim)
         self.norm1 = nn.LayerNorm(dh_dim)
         self.activation = nn.ReLU(inplace=True)
+        self.precision = "bf16"
+        self.use_slot_gemm = True
 
     def forward(self, curr_features, features, pos, groups=1):
         """`groups` > 1: the rows are `groups` independent clips of equal length laid end to end; attention stays
@@ -245,7 +272,12 @@ class SlotsDynamicConv(nn.Module):
             b3 = _cached(self, "b3", [m.bias for m in lins], lambda: torch.stack([m.bias for m in lins]).unsqueeze(1).contiguous())
             g3 = _cached(self, "g3", [m.weight for m in norms], lambda: torch.stack([m.weight for m in norms]).contiguous())
             e3 = _cached(self, "e3", [m.bias for m in norms], lambda: torch.stack([m.bias for m in norms]).contiguous())
-            qkv = torch.baddbmm(b3, x.unsqueeze(0).expand(3, -1, -1), w3)            # [3, M, C]
+            if self.precision != "fp32" and self.use_slot_gemm and x.is_cuda:
+                qkv = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+                for i, m in enumerate(lins):                                        # three K8 launches into one [3, M, C] buffer
+                    fast_linear(self, f"qkv{i}", x, m.weight, m.bias, out=qkv[i])
+            else:
+                qkv = torch.baddbmm(b3, x.unsqueeze(0).expand(3, -1, -1), w3)        # [3, M, C]
             qkv = ops.row_ln(qkv, g3, e3, self.norm_q.eps, rows_per_group=x.shape[0])
             q, k, v = (qkv[i].view(groups, -1, self.hidden_dim) for i in range(3))
         # softmax over the QUERY axis (dim=1 of [1, Lq, Lk], :562) = last-dim softmax of the transposed logits
@@ -271,6 +303,8 @@ class TemporalSlotsHead(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.norm3 = nn.LayerNorm(d_model)
         self.activation = _get_activation_fn(activation)
+        self.precision = "bf16"
+        self.use_slot_gemm = True
 
     def forward(self, features, mask_query, pos=None, query_pos=None, add_input=False, groups=1):
         """:494-527. add_input=True additionally returns mask_query + result (the caller's residual, :317)
@@ -280,7 +314,8 @@ class TemporalSlotsHead(nn.Module):
         f = x if features is mask_query else features.view(1, -1, self.d_model)
         r = self.inst_interact(x, f, pos, groups=groups)
         u = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x.contiguous())          # :515-517
-        y = self.linear2(self.activation(self.linear1(u)))                                                    # :520
+        hid = fast_linear(self, "linear1", u, self.linear1.weight, self.linear1.bias, act=_act_name(self.activation))
+        y = fast_linear(self, "linear2", hid, self.linear2.weight, self.linear2.bias)                         # :520
         out = ops.row_ln(y, self.norm3.weight, self.norm3.bias, self.norm3.eps, pre=u,
                          post=x.contiguous() if add_input else None)                                          # :524-525
         return out.squeeze(0)
@@ -319,6 +354,7 @@ class MaskRCNNHead(nn.Module):
         self.class_logits = nn.Linear(d_model, num_classes)
         self.scale_clamp = scale_clamp
         self.precision = "bf16"
+        self.use_slot_gemm = True
 
     def _self_attention(self, slots):
         """nn.MultiheadAttention(self_attn)(x, x, x) for frames-as-batch slots [T, L, C] (:346-355), with the module's own
@@ -328,7 +364,7 @@ class MaskRCNNHead(nn.Module):
         mha = self.self_attn
         T, L, C = slots.shape
         nh = mha.num_heads
-        qkv = F.linear(slots, mha.in_proj_weight, mha.in_proj_bias).view(T, L, 3, nh, C // nh)
+        qkv = fast_linear(self, "in_proj", slots, mha.in_proj_weight, mha.in_proj_bias).view(T, L, 3, nh, C // nh)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [T, heads, L, C / heads] views
         if self.precision == "fp32":                                        # explicit fp32 products, torch's own order (:352)
             attn = torch.softmax((q * (1.0 / math.sqrt(C // nh))) @ k.transpose(-1, -2), dim=-1)
@@ -336,7 +372,7 @@ class MaskRCNNHead(nn.Module):
         elif C // nh == 32 and L <= 256:
             # the library's own kernel for these tiny (L x L x 32 per head) problems, on the packed projection as it stands
             o = ops.slot_self_attn(qkv.view(T, L, 3 * C), nh)
-            return F.linear(o, mha.out_proj.weight, mha.out_proj.bias)
+            return fast_linear(self, "out_proj", o, mha.out_proj.weight, mha.out_proj.bias)
         else:
             o = F.scaled_dot_product_attention(q, k, v)                     # softmax(q k^T / sqrt(C / heads)) v
         return F.linear(o.transpose(1, 2).reshape(T, L, C), mha.out_proj.weight, mha.out_proj.bias)
@@ -347,7 +383,8 @@ class MaskRCNNHead(nn.Module):
         x1 = ops.row_ln(a, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre=slots)                 # :356-358
         r = self.inst_interact.forward_pm(x1, feat_pm, hw, pos_tabs)                                        # :368
         x2 = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x1)                     # :374-376
-        y = self.linear2(self.activation(self.linear1(x2)))                                                  # :379
+        hid = fast_linear(self, "linear1", x2, self.linear1.weight, self.linear1.bias, act=_act_name(self.activation))
+        y = fast_linear(self, "linear2", hid, self.linear2.weight, self.linear2.bias)                        # :379
         return ops.row_ln(y, self.norm3.weight, self.norm3.bias, self.norm3.eps, pre=x2)                   # :384-385
 
     def forward_after_ffn_pm(self, obj):
@@ -368,7 +405,13 @@ class MaskRCNNHead(nn.Module):
             w2 = _cached(self, f"tw{i}", [lc.weight, lr.weight], lambda: torch.stack([lc.weight.t(), lr.weight.t()]).contiguous())
             g2 = _cached(self, f"tg{i}", [nc.weight, nr.weight], lambda: torch.stack([nc.weight, nr.weight]).contiguous())
             e2 = _cached(self, f"te{i}", [nc.bias, nr.bias], lambda: torch.stack([nc.bias, nr.bias]).contiguous())
-            x = ops.row_ln(torch.bmm(x, w2), g2, e2, nc.eps, relu=True, rows_per_group=T * L)               # :394-397
+            if self.precision != "fp32" and self.use_slot_gemm:
+                y2 = torch.empty((2, T * L, C), dtype=torch.float32, device=obj.device)
+                fast_linear(self, f"cls{i}", x[0], lc.weight, out=y2[0])
+                fast_linear(self, f"reg{i}", x[1], lr.weight, out=y2[1])
+            else:
+                y2 = torch.bmm(x, w2)
+            x = ops.row_ln(y2, g2, e2, nc.eps, relu=True, rows_per_group=T * L)                             # :394-397
         return self.class_logits(x[0].reshape(T, L, C)), x[1].reshape(T, L, C)
 
     def forward_pm(self, slots, feat_pm, hw, pos_tabs, stage_enable, clips=1):
@@ -451,6 +494,13 @@ class MultiScaleDynamicMaskHead(nn.Module):
         for m in self.modules():
             if hasattr(m, "precision"):
                 m.precision = mode
+        return self
+
+    def set_slot_gemm(self, on):
+        """bf16 mode: K8 (split-bf16 matrix-core GEMM, default) or the GEMM library in fp32 for the dense slot-side layers."""
+        for m in self.modules():
+            if hasattr(m, "use_slot_gemm"):
+                m.use_slot_gemm = bool(on)
         return self
 
     def set_retriever(self, form):

@@ -84,3 +84,29 @@ def test_retr_query_prep_and_split(cuda):
     hi, lo = ops.retr_split(gp)
     assert torch.equal(hi, gp.to(torch.bfloat16)) and torch.equal(lo, (gp - hi.float()).to(torch.bfloat16))
     assert (hi.float() + lo.float() - gp).abs().max().item() <= 2.0 ** -16 * gp.abs().max().item()
+
+
+@pytest.mark.parametrize("M,K,N,act,bias", [(8000, 256, 768, None, True), (500, 2048, 256, None, True), (1000, 256, 2048, "gelu", True),
+                                            (37, 272, 256, None, False), (200, 256, 1024, "relu", True), (65, 256, 256, None, False)])
+def test_slot_gemm_matches_float64_linear(cuda, M, K, N, act, bias):
+    """K8 (csrc/slot_gemm.hip): y = act(x W^T + b) with split-bf16 matrix-core products against float64: fp32-class."""
+    import torch
+    from slotvps_amd import ops
+    from util import orc
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(N)).astype(np.float32) if bias else None
+    wp = ops.pack_b_fragments(torch.from_numpy(w).to(cuda))
+    code = {None: ops.ACT_NONE, "relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act]
+    got = ops.slot_gemm(torch.from_numpy(x).to(cuda), wp, None if b is None else torch.from_numpy(b).to(cuda), code)
+    again = ops.slot_gemm(torch.from_numpy(x).to(cuda), wp, None if b is None else torch.from_numpy(b).to(cuda), code)
+    assert torch.equal(got, again)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + (0 if b is None else b.astype(np.float64))
+    if act == "relu":
+        ref = np.maximum(ref, 0)
+    elif act == "gelu":
+        ref = orc.gelu(ref)
+    err = np.abs(got.cpu().numpy() - ref).max()
+    print(f"\nK8 M={M} K={K} N={N} act={act}: max abs err vs float64 {err:.2e} (outputs of order 1)")
+    assert err <= 3e-5
