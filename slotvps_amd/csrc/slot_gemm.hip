@@ -19,7 +19,7 @@
 
 namespace svps {
 
-constexpr int kGmRows = 64;                 // rows per workgroup
+constexpr int kGmRows = 64;                 // rows per workgroup (template RBW = 2; RBW = 1: 32 rows, for launches with few workgroups)
 constexpr int kGmCols = 256;                // output columns per workgroup
 constexpr int kGmK = 64;                    // k per chunk
 constexpr int kGmRow = kGmK * 2 + 16;       // bytes per row of the staged A tile (padded: conflict-free 16-byte fragment reads)
@@ -31,7 +31,7 @@ struct GemmLds {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int ACT>                          // 0 none, 1 ReLU, 2 GELU (erf)
+template <int ACT, int RBW>                 // ACT: 0 none, 1 ReLU, 2 GELU (erf); RBW: row blocks per workgroup (2 or 1)
 __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict__ x,        // [M, K]
                                                         const __bf16* __restrict__ wpack,   // [N/32][K/16][2][64][8]
                                                         const float* __restrict__ bias,     // [N] or null
@@ -41,15 +41,16 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int rb = w & 1, cg = w >> 1;                          // row block, column group (64 columns)
-    const int m0 = blockIdx.x * kGmRows, n0 = blockIdx.y * kGmCols;
+    constexpr int ROWS = 32 * RBW, NB = RBW;                    // rows per workgroup; column blocks per wave (8 waves cover 8 x RBW blocks)
+    const int rb = w % RBW, cg = w / RBW;                       // row block, column group (32 NB columns)
+    const int m0 = blockIdx.x * ROWS, n0 = blockIdx.y * kGmCols;
     const int KS = K / 16, nch = (K + kGmK - 1) / kGmK;
 
     // A tile staging: thread -> two (row, 4-k group) items per chunk
-    f32x4 av[2];
+    f32x4 av[RBW];
     auto gather = [&](int ch) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RBW; ++i) {
             const int q = tid + 512 * i, row = q >> 4, kg = (q & 15) * 4;
             const int m = m0 + row, k = ch * kGmK + kg;
             av[i] = (m < M && k < K) ? *reinterpret_cast<const f32x4*>(x + (size_t)m * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
     auto split_store = [&](int buf) {
         char* bh = smem + buf * GemmLds::buf_bytes;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RBW; ++i) {
             const int q = tid + 512 * i, row = q >> 4, kg = (q & 15) * 4;
             bf16x4 vh, vl;
 #pragma unroll
@@ -71,50 +72,74 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[NB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
 
-    gather(0);
-    split_store(0);
-    __syncthreads();
     // B fragments of column block cb, k-step ks, part p: u32x4 index ((cb * KS + ks) * 2 + p) * 64 + lane
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpack) + lane;
-    const int cb0 = (n0 >> 5) + 2 * cg;
-    for (int ch = 0; ch < nch; ++ch) {
+    const int cb0 = (n0 >> 5) + NB * cg;
+    // weights of one chunk: 4 k-steps x 2 column blocks x (hi, lo) = 16 fragments = 64 registers; the NEXT chunk's set is
+    // requested before this chunk's MFMAs (register double buffer, loop unrolled by two), so that the L2 latency of the
+    // weight stream (one workgroup per CU for the 256-column layers: nobody else to hide it) runs under the matrix work
+    auto load_w = [&](int ch, u32x4 (&wb)[8 * NB]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ks = ch * 4 + u;
+            const int kc = ks < KS ? ks : KS - 1;               // short last chunk: a valid address, the fragment is not used
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const size_t f = ((size_t)(cb0 + b) * KS + kc) * 2 * 64;
+                wb[2 * NB * u + 2 * b] = wsrc[f];
+                wb[2 * NB * u + 2 * b + 1] = wsrc[f + 64];
+            }
+        }
+    };
+    auto mma = [&](int ch, const u32x4 (&wb)[8 * NB]) {
         const char* ah = smem + (ch & 1) * GemmLds::buf_bytes + (32 * rb + r) * kGmRow + 16 * h;
         const char* al = ah + kGmRows * kGmRow;
         const int nks = (KS - ch * 4) < 4 ? (KS - ch * 4) : 4;   // k-steps of this chunk (the last chunk may be short)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (u < nks) {
-                const int ks = ch * 4 + u;
                 const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + 32 * u);
                 const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + 32 * u);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const size_t f = ((size_t)(cb0 + b) * KS + ks) * 2 * 64;
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wsrc[f]);
-                    const bf16x8 wl = __builtin_bit_cast(bf16x8, wsrc[f + 64]);
+                for (int b = 0; b < NB; ++b) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[2 * NB * u + 2 * b]);
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, wb[2 * NB * u + 2 * b + 1]);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[b], 0, 0, 0);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[b], 0, 0, 0);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[b], 0, 0, 0);
                 }
             }
         }
-        if (ch + 1 < nch) {                                     // after the MFMAs (see deform_conv_fused.hip for the order)
-            gather(ch + 1);
-            split_store((ch + 1) & 1);
-        }
+    };
+    u32x4 w0[8 * NB], w1[8 * NB];
+    gather(0);
+    load_w(0, w0);
+    split_store(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ch += 2) {
+        // even chunk: weights in w0
+        if (ch + 1 < nch) { gather(ch + 1); load_w(ch + 1, w1); }
+        mma(ch, w0);
+        if (ch + 1 < nch) split_store((ch + 1) & 1);
+        __syncthreads();
+        if (ch + 1 >= nch) break;
+        // odd chunk: weights in w1
+        if (ch + 2 < nch) { gather(ch + 2); load_w(ch + 2, w0); }
+        mma(ch + 1, w1);
+        if (ch + 2 < nch) split_store(ch & 1);
         __syncthreads();
     }
 
     // ---- epilogue: register i of a block = row (i & 3) + 8 (i >> 2) + 4 h, column = lane r
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + 64 * cg + 32 * b + r;
+    for (int b = 0; b < NB; ++b) {
+        const int n = n0 + 32 * NB * cg + 32 * b + r;
         const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -134,10 +159,18 @@ extern "C" int svps_slot_gemm(const float* x, const void* wpack, const float* bi
     if (!x || !wpack || !y) return SVPS_ERR_BAD_ARG;
     if (M <= 0 || K <= 0 || (K & 15) || N <= 0 || (N % svps::kGmCols) || act < 0 || act > 2) return SVPS_ERR_BAD_SHAPE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const dim3 grid((M + svps::kGmRows - 1) / svps::kGmRows, N / svps::kGmCols);
     const __bf16* wp = static_cast<const __bf16*>(wpack);
-    if (act == 0) hipLaunchKernelGGL(svps::slot_gemm_kernel<0>, grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N);
-    else if (act == 1) hipLaunchKernelGGL(svps::slot_gemm_kernel<1>, grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N);
-    else hipLaunchKernelGGL(svps::slot_gemm_kernel<2>, grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N);
+    // 64-row tiles unless that leaves most of the chip idle (the 256-column layers on 8 000 rows: 125 workgroups): 32-row tiles then
+    const int wg64 = ((M + 63) / 64) * (N / svps::kGmCols);
+    const bool small = wg64 < (3 * svps_num_cus()) / 4;
+    const int rows = small ? 32 : 64;
+    const dim3 grid((M + rows - 1) / rows, N / svps::kGmCols);
+#define SVPS_GEMM(A, R) hipLaunchKernelGGL((svps::slot_gemm_kernel<A, R>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N)
+    if (small) {
+        if (act == 0) SVPS_GEMM(0, 1); else if (act == 1) SVPS_GEMM(1, 1); else SVPS_GEMM(2, 1);
+    } else {
+        if (act == 0) SVPS_GEMM(0, 2); else if (act == 1) SVPS_GEMM(1, 2); else SVPS_GEMM(2, 2);
+    }
+#undef SVPS_GEMM
     return (int)hipGetLastError();
 }

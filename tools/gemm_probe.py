@@ -1,47 +1,50 @@
-"""fp32 vs split-bf16 vs `allow_tf32` on the slot-side GEMM shapes (16 stacked clips: 8000 rows): time (HIP events) and error.
-
-MI355X has no TF32 matrix instruction; with allow_tf32 hipBLASLt runs an fp32 GEMM as split-bf16 products."""
+"""K8 (split-bf16 slot GEMM) against the GEMM library in fp32 on the slot-side shapes: device time (HIP events) and error."""
+import os, sys
 import torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slotvps_amd import ops
 dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
 
 
-def timeit(fn, n=50):
-    for _ in range(10):
-        fn()
+def t(fn, n=20):
+    """Device time per call: n calls captured into one hipGraph (no host launch overhead between them), replayed 5 times."""
+    for _ in range(3):
+        o = fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(n):
+                o = fn()
+    torch.cuda.current_stream().wait_stream(side)
+    gr.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        fn()
+    for _ in range(5):
+        gr.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
+    return e0.elapsed_time(e1) / (5 * n) * 1e3, o
 
 
-def split(x):
-    hi = x.to(torch.bfloat16)
-    return hi, (x - hi.float()).to(torch.bfloat16)
-
-
-for (M, K, N) in [(8000, 256, 2048), (8000, 2048, 256), (8000, 256, 256), (8000, 256, 768), (8000, 256, 1024), (8000, 1024, 256)]:
-    g = torch.Generator(device=dev).manual_seed(0)
-    x = torch.randn(M, K, device=dev, generator=g)
-    w = torch.randn(N, K, device=dev, generator=g) * 0.05
-    b = torch.randn(N, device=dev, generator=g)
-    ref = x.double() @ w.double().t() + b.double()
-    sc = ref.abs().max().item()
-    torch.backends.cuda.matmul.allow_tf32 = False
-    y32 = torch.addmm(b, x, w.t())
-    t32 = timeit(lambda: torch.addmm(b, x, w.t()))
-    torch.backends.cuda.matmul.allow_tf32 = True
-    ytf = torch.addmm(b, x, w.t())
-    ttf = timeit(lambda: torch.addmm(b, x, w.t()))
-    torch.backends.cuda.matmul.allow_tf32 = False
-    xh, xl = split(x)
-    wh, wl = split(w)
-    xs, ws = torch.cat([xh, xl, xh], 1).contiguous(), torch.cat([wh, wh, wl], 1).contiguous()
-    y3 = torch.mm(xs, ws.t(), out_dtype=torch.float32) + b
-    t3 = timeit(lambda: torch.mm(xs, ws.t(), out_dtype=torch.float32))
-    err = lambda y: (y.double() - ref).abs().max().item() / sc
-    print(f"M{M} K{K} N{N}: fp32 {t32:6.1f} us err {err(y32):.1e} | allow_tf32 {ttf:6.1f} us err {err(ytf):.1e} | "
-          f"split-bf16 [hi,lo,hi]x[hi,hi,lo] {t3:6.1f} us err {err(y3):.1e} (+ operand split)")
+tot_a = tot_b = 0.0
+for (M, K, N, act, cnt) in [(8000, 256, 768, None, 7), (8000, 256, 256, None, 7 * 7), (10240, 256, 256, None, 7), (8000, 272, 256, None, 7),
+                            (8000, 256, 2048, "gelu", 7), (8000, 2048, 256, None, 7), (8000, 256, 1024, "relu", 4), (8000, 1024, 256, None, 4)]:
+    x = torch.randn((M, K), generator=g, device=dev)
+    w = torch.randn((N, K), generator=g, device=dev) / K ** 0.5
+    b = torch.randn((N,), generator=g, device=dev)
+    wp = ops.pack_b_fragments(w)
+    code = {None: 0, "relu": 1, "gelu": 2}[act]
+    ta, ya = t(lambda: ops.slot_gemm(x, wp, b, code))
+    f = (lambda y: y) if act is None else (F.relu if act == "relu" else F.gelu)
+    tb, yb = t(lambda: f(F.linear(x, w, b)))
+    ref = f(F.linear(x.double(), w.double(), b.double()))
+    tot_a += ta * cnt
+    tot_b += tb * cnt
+    print(f"M={M} K={K} N={N} act={act}: K8 {ta:6.1f} us  library fp32 {tb:6.1f} us   err K8 {(ya - ref).abs().max().item():.1e} lib {(yb - ref).abs().max().item():.1e}")
+print(f"per step (7 stages, counts as in the head): K8 {tot_a / 1e3:.2f} ms, library {tot_b / 1e3:.2f} ms")
