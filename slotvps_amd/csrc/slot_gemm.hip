@@ -31,7 +31,10 @@ struct GemmLds {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int ACT, int RBW>                 // ACT: 0 none, 1 ReLU, 2 GELU (erf); RBW: row blocks per workgroup (2 or 1)
+// ACT: 0 none, 1 ReLU, 2 GELU (erf); RBW: row blocks per workgroup (2 or 1); PREF: weights of the next chunk requested before
+// this chunk's MFMAs (register double buffer, 192 registers: one workgroup per CU - for launches that do not fill the chip
+// several times over; wide layers run several 110-register workgroups per CU instead, which hide the latency by themselves)
+template <int ACT, int RBW, bool PREF>
 __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict__ x,        // [M, K]
                                                         const __bf16* __restrict__ wpack,   // [N/32][K/16][2][64][8]
                                                         const float* __restrict__ bias,     // [N] or null
@@ -117,21 +120,32 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
             }
         }
     };
-    u32x4 w0[8 * NB], w1[8 * NB];
+    u32x4 w0[8 * NB], w1[PREF ? 8 * NB : 1];
     gather(0);
-    load_w(0, w0);
+    if constexpr (PREF) load_w(0, w0);
     split_store(0);
     __syncthreads();
+    if constexpr (!PREF) {
+        for (int ch = 0; ch < nch; ++ch) {
+            load_w(ch, w0);
+            mma(ch, w0);
+            if (ch + 1 < nch) {                                 // after the MFMAs
+                gather(ch + 1);
+                split_store((ch + 1) & 1);
+            }
+            __syncthreads();
+        }
+    } else
     for (int ch = 0; ch < nch; ch += 2) {
         // even chunk: weights in w0
-        if (ch + 1 < nch) { gather(ch + 1); load_w(ch + 1, w1); }
+        if (ch + 1 < nch) { gather(ch + 1); if constexpr (PREF) load_w(ch + 1, w1); }
         mma(ch, w0);
         if (ch + 1 < nch) split_store((ch + 1) & 1);
         __syncthreads();
         if (ch + 1 >= nch) break;
         // odd chunk: weights in w1
         if (ch + 2 < nch) { gather(ch + 2); load_w(ch + 2, w0); }
-        mma(ch + 1, w1);
+        if constexpr (PREF) mma(ch + 1, w1);
         if (ch + 2 < nch) split_store(ch & 1);
         __syncthreads();
     }
@@ -165,11 +179,14 @@ extern "C" int svps_slot_gemm(const float* x, const void* wpack, const float* bi
     const bool small = wg64 < (3 * svps_num_cus()) / 4;
     const int rows = small ? 32 : 64;
     const dim3 grid((M + rows - 1) / rows, N / svps::kGmCols);
-#define SVPS_GEMM(A, R) hipLaunchKernelGGL((svps::slot_gemm_kernel<A, R>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N)
+#define SVPS_GEMM(A, R, P) hipLaunchKernelGGL((svps::slot_gemm_kernel<A, R, P>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N)
+    const bool wide = wg64 > svps_num_cus();                   // more workgroups than CUs: light variant, several co-resident workgroups per CU
     if (small) {
-        if (act == 0) SVPS_GEMM(0, 1); else if (act == 1) SVPS_GEMM(1, 1); else SVPS_GEMM(2, 1);
+        if (act == 0) SVPS_GEMM(0, 1, true); else if (act == 1) SVPS_GEMM(1, 1, true); else SVPS_GEMM(2, 1, true);
+    } else if (wide) {
+        if (act == 0) SVPS_GEMM(0, 2, false); else if (act == 1) SVPS_GEMM(1, 2, false); else SVPS_GEMM(2, 2, false);
     } else {
-        if (act == 0) SVPS_GEMM(0, 2); else if (act == 1) SVPS_GEMM(1, 2); else SVPS_GEMM(2, 2);
+        if (act == 0) SVPS_GEMM(0, 2, true); else if (act == 1) SVPS_GEMM(1, 2, true); else SVPS_GEMM(2, 2, true);
     }
 #undef SVPS_GEMM
     return (int)hipGetLastError();
