@@ -396,6 +396,8 @@ def main():
                 e["mfma_tflops"] = round(alg[name]["flops"] * nsteps / sec / 1e12, 1)
                 e["mfma_frac"] = round(e["mfma_tflops"] / MFMA_PEAK_TFLOPS, 4)
                 e["bound"] = "hbm" if e["hbm_frac"] >= e["mfma_frac"] else "mfma"
+                if "executed_flops" in alg[name]:           # informational: matrix work actually issued (operand splits included)
+                    e["mfma_frac_executed"] = round(alg[name]["executed_flops"] * nsteps / sec / 1e12 / MFMA_PEAK_TFLOPS, 4)
             per[name] = e
         dom = max((k for k in per if k in alg), key=lambda k: timed[k][0])
         d = per[dom]
