@@ -94,6 +94,22 @@ __device__ __forceinline__ bf16x8 read_col_frag_aux(const char* at, int ks, int 
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+#ifdef SVPS_RETR_STAMP
+// diagnostic build only (tools/retr_stamps.py): s_memtime stamps of one workgroup's producer 0 and consumer 0, iterations
+// 8 .. 15, plus (s_memtime, s_memrealtime) around the loop of every workgroup's wave 0 for the in-kernel clock
+__device__ unsigned long long retr_stamps[2][8][8];      // [producer / consumer][iteration - 8][point]
+__device__ unsigned long long retr_clock[4096][4];       // [workgroup][memtime0, realtime0, memtime1, realtime1]
+#define RETR_STAMP(role, pt)                                                                          \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && sb == 0 && it >= 8 && it < 16 && lane == 0)         \
+            retr_stamps[role][it - 8][pt] = __builtin_amdgcn_s_memtime();                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define RETR_STAMP(role, pt) do {} while (0)
+#endif
+
 // ABL: timing-only ablations (env SVPS_RETR_ABLATE), outputs wrong. 1: DMA + barriers only  2: producers only  4: consumers only
 // EXT (more than 128 slots, LP = 256): the launch covers the `L` slots starting at row `slot_off`; the per-pixel softmax
 // statistics over ALL slots come from `ext_stats` ([T, HW] of (max logit, 1 / sum of exponentials), written by
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     float* __restrict__ partial,        // [T, C, Lrow, 264]
     int L, int HW, int H, int W, float inv_w, int tiles_per_chunk, int LP, int Lrow, int slot_off,
     const float2* __restrict__ ext_stats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];   // tile bases are multiples of 512 B (the fragment address XORs rely on it)
     using Lds = RetrLds;
     constexpr int A = kRPrefetch;
 
@@ -144,6 +160,13 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     float* c3l = reinterpret_cast<float*>(smem + Lds::c3);
     if (threadIdx.x < 128) c3l[threadIdx.x] = c3g[(size_t)t * LP + slot_off + threadIdx.x];
 
+#ifdef SVPS_RETR_STAMP
+    const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && wg_lin < 4096) {
+        retr_clock[wg_lin][0] = __builtin_amdgcn_s_memtime();
+        retr_clock[wg_lin][1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (!consumer) {
         // ================================ producer =============================================
         bf16x8 qfh[16], qfl[16];
@@ -157,6 +180,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         }
         const int slot0 = 32 * sb + 4 * h;
         const int key = (r >> 1) & 3;
+        const uint32_t lane_row = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem) + Lds::fring + r * kRowBytes + ((h ^ swz(r)) << 4);
         // tables through buffer descriptors (scalar registers) + 32-bit lane offsets: no 64-bit pointers in vector registers
         auto uniform_rsrc = [](const void* p, int bytes) {          // every word provably wave-uniform: no waterfall loops
             const uint64_t a = reinterpret_cast<uint64_t>(p);
@@ -208,32 +232,40 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         request(0);
         settle();
         for (int it = 0; it <= nt; ++it) {
+            RETR_STAMP(0, 0);
             wg_barrier();                                        // B_top(it)
+            RETR_STAMP(0, 1);
             if (it == nt || ABL == 1 || ABL == 4) { wg_barrier(); continue; }
-            const char* kt = smem + Lds::fring + (it % kRNF) * kTileBytes;
-            int rr = r, hh = h;
-            asm volatile("" : "+v"(rr), "+v"(hh));              // opaque per iteration: no hoisted fragment address tables
+            // LDS byte address of this lane's 16-B chunk of k-step ks = 8 a + b in the tile: (tile + lane_row) ^ (b << 5), + 256 a:
+            // eight XORs per tile, the rest are instruction offsets (the swizzle touches chunk bits 0-3 only)
+            const uint32_t tb = lane_row + (uint32_t)(it % kRNF) * kTileBytes;
+            auto frag = [&](int ks) {
+                return *reinterpret_cast<SVPS_LDS const bf16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
+            };
             const bool live = px_begin + it * kTilePx + r < px_end;
             f32x16 s = cinit;
-            {   // row fragments in groups of four, double-buffered: the reads of group g+1 fly under the 8 MFMAs of group g
+            {   // row fragments in groups of four (k-steps 2g, 2g + 8, 2g + 1, 2g + 9), double-buffered: the reads of group
+                // g + 1 fly under the 8 MFMAs of group g
+                constexpr int kOrd[4] = {0, 8, 1, 9};
                 bf16x8 kf[2][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) kf[0][u] = read_row_frag(kt, u, rr, hh);
+                for (int u = 0; u < 4; ++u) kf[0][u] = frag(kOrd[u]);
 #pragma unroll
                 for (int grp = 0; grp < 4; ++grp) {
                     if (grp < 3) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = read_row_frag(kt, 4 * (grp + 1) + u, rr, hh);
+                        for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = frag(2 * (grp + 1) + kOrd[u]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            RETR_STAMP(0, 2);
             const float rk_c = rk * kLog2e, tau_c = tau;     // logits are formed directly in the log2 domain (c3 arrives pre-scaled)
             const f32x2 ext_c = ext;
             if (it + 1 < nt) request(it + 1);
@@ -274,6 +306,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 }
             }
             mloc = ra_half_swap_max(mloc);
+            RETR_STAMP(0, 6);
             float sloc = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -282,7 +315,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             }
             sloc = ra_half_swap_sum(sloc);
             if (h == 0) stats[sb * 32 + r] = make_float2(mloc, sloc);
+            RETR_STAMP(0, 3);
             wg_barrier();                                        // B_stats(it)
+            RETR_STAMP(0, 4);
             float mall = kNegBig;
             float2 st_w[4];
 #pragma unroll
@@ -309,8 +344,16 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 *reinterpret_cast<bf16x4*>(prow + ((g ^ key) * 16)) = ph;
                 *reinterpret_cast<bf16x4*>(prow + 8192 + ((g ^ key) * 16)) = pl;
             }
+            RETR_STAMP(0, 7);
             if (it + 1 < nt) settle();
+            RETR_STAMP(0, 5);
         }
+#ifdef SVPS_RETR_STAMP
+        if (threadIdx.x == 0 && wg_lin < 4096) {
+            retr_clock[wg_lin][2] = __builtin_amdgcn_s_memtime();
+            retr_clock[wg_lin][3] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         return;
     }
 
@@ -356,29 +399,39 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
 #pragma unroll
         for (int db = 0; db < 8; ++db) o[db][i] = 0.f;
     }
-    auto pv_step = [&](const char* pt, const char* vt, const char* at, int ks) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));                            // opaque per call: no hoisted address tables
-        const int g2 = ln >> 4, ii = ln & 15, qq = ii >> 2, pp = ii & 3;
-        const int pchunk = 2 * (g2 & 1) + (pp >> 1);
-        const int px0 = 16 * ks + 8 * (g2 >> 1) + qq;
-        const char* a0 = pt + sb * 2048 + 8 * (pp & 1) + px0 * 64 + ((pchunk ^ ((px0 >> 1) & 3)) * 16);
-        const char* a1 = pt + sb * 2048 + 8 * (pp & 1) + (px0 + 4) * 64 + ((pchunk ^ (((px0 + 4) >> 1) & 3)) * 16);
-        const bf16x8 ah = __builtin_shufflevector(
-            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)a0),
-            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)a1), 0, 1, 2, 3, 4, 5, 6, 7);
-        const bf16x8 al = __builtin_shufflevector(
-            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(a0 + 8192)),
-            __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(a1 + 8192)), 0, 1, 2, 3, 4, 5, 6, 7);
-        const bf16x8 af = read_col_frag_aux(at, ks, ln);
+    // Fragment addresses (LDS byte addresses): everything that depends on the k-step, the channel block or hi / lo is an
+    // instruction offset or one XOR; per tile the ring slot is added to five per-lane terms.
+    //   value  V[pixels 16 ks + 8 h' .. + 8][channel 32 db + n]: rows rowl (+4), chunk (4 db + cl) ^ swz(row)
+    //          = vt + 8192 ks + 256 (db >> 2) + (lane_v{0,1} ^ ((db & 3) << 6))
+    //   P      rows rowl (+4) of 64 B, chunk cl ^ ((row >> 1) & 3): pt + 1024 ks (+ 8192 for lo) + lane_p{0,1}
+    //   aux    rows rowl (+4) of 64 B, linear: at + 1024 ks (+ 256) + lane_a
+    const int g2 = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int cl = 2 * (g2 & 1) + (pp >> 1), sub = 8 * (pp & 1), rowl = 8 * (g2 >> 1) + qq;
+    const uint32_t lane_v0 = rowl * kRowBytes + (((cl ^ (2 * (g2 >> 1))) + 4 * qq) << 4) + sub;
+    const uint32_t lane_v1 = (rowl + 4) * kRowBytes + (((cl ^ (2 * (g2 >> 1) + 1)) + 4 * qq) << 4) + sub;
+    const uint32_t lane_p0 = sb * 2048 + sub + rowl * 64 + ((cl ^ (qq >> 1)) << 4);
+    const uint32_t lane_p1 = sb * 2048 + sub + (rowl + 4) * 64 + ((cl ^ (qq >> 1) ^ 2) << 4);
+    const uint32_t lane_a = rowl * kAuxRow + cl * 16 + sub;
+    auto tr = [](uint32_t a) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<SVPS_LDS bf16x4*>((uintptr_t)a)); };
+    auto cat = [](bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); };
+    auto pv_step = [&](uint32_t pt, uint32_t vt, uint32_t at, int ks) {
+        const uint32_t p0 = pt + lane_p0 + 1024 * ks, p1 = pt + lane_p1 + 1024 * ks;
+        const uint32_t v0 = vt + lane_v0, v1 = vt + lane_v1, aa = at + lane_a + 1024 * ks;
+        auto vfrag = [&](int db) {
+            const uint32_t o = 8192 * ks + 256 * (db >> 2);
+            return cat(tr((v0 ^ ((db & 3) << 6)) + o), tr((v1 ^ ((db & 3) << 6)) + o));
+        };
+        const bf16x8 ah = cat(tr(p0), tr(p1));
+        const bf16x8 al = cat(tr(p0 + 8192), tr(p1 + 8192));
+        const bf16x8 af = cat(tr(aa), tr(aa + 256));
         bf16x8 vf[2][4];                                        // value fragments double-buffered in two halves of four blocks
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vf[0][u] = read_col_frag(vt, ks, u, ln);
+        for (int u = 0; u < 4; ++u) vf[0][u] = vfrag(u);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half == 0) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) vf[1][u] = read_col_frag(vt, ks, 4 + u, ln);
+                for (int u = 0; u < 4; ++u) vf[1][u] = vfrag(4 + u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -396,17 +449,23 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
 
     for (int it = 0; it <= nt; ++it) {
         // batch `it` (feature + aux tile it) landed for this wave: all but the A-1 younger batches
+        RETR_STAMP(1, 0);
         if (it + A - 1 < nt) wait_vm_dyn(nb * (A - 1));
         else wait_vm<0>();
+        RETR_STAMP(1, 1);
         wg_barrier();                                            // B_top(it)
+        RETR_STAMP(1, 2);
         issue_batch(it + A);
         const bool work = it >= 1 && ABL != 1 && ABL != 2;
-        const char* pt = smem + Lds::pring + ((it + 1) & 1) * kTileBytes;                 // P(it-1)
-        const char* vt = smem + Lds::fring + ((it + kRNF - 1) % kRNF) * kTileBytes;       // f(it-1)
-        const char* at = smem + Lds::aring + ((it + kRNF - 1) % kRNF) * kAuxTile;
+        const uint32_t pt = lds0 + Lds::pring + ((it + 1) & 1) * kTileBytes;                 // P(it-1)
+        const uint32_t vt = lds0 + Lds::fring + ((it + kRNF - 1) % kRNF) * kTileBytes;       // f(it-1)
+        const uint32_t at = lds0 + Lds::aring + ((it + kRNF - 1) % kRNF) * kAuxTile;
         if (work) pv_step(pt, vt, at, 0);
+        RETR_STAMP(1, 3);
         wg_barrier();                                            // B_stats(it)
+        RETR_STAMP(1, 4);
         if (work) pv_step(pt, vt, at, 1);
+        RETR_STAMP(1, 5);
     }
 
     float* dst = partial + (((size_t)t * C + c) * Lrow + slot_off) * kPartRow;
@@ -698,3 +757,11 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
     svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 1, stream);
     return (int)hipGetLastError();
 }
+
+#ifdef SVPS_RETR_STAMP
+extern "C" int svps_retr_debug_read(unsigned long long* stamps, unsigned long long* clock) {
+    hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::retr_stamps), sizeof(unsigned long long) * 2 * 8 * 8);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyFromSymbol(clock, HIP_SYMBOL(svps::retr_clock), sizeof(unsigned long long) * 4096 * 4);
+}
+#endif

@@ -47,6 +47,7 @@ def test_retr_stats(cuda, T, H, W, pos):
     tabs = ops.pos_embed_sine_tables(H, W, 256, cuda) if pos else None
     rk, rv, aux = ops.retr_stats(to_bf16_t(feat, cuda), H, W, tabs, c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
     torch.cuda.synchronize()
+    aux_raw = aux.cpu().view(torch.int16).numpy().view(np.uint16)               # [T, HW, 32] bf16 bit patterns
     rk, rv, aux = rk.cpu().numpy(), rv.cpu().numpy(), aux.float().cpu().numpy()
     pm = orc.pos_embed_sine(H, W).astype(np.float64) if pos else 0.0
     d = lambda n: P[n].astype(np.float64)
@@ -62,7 +63,10 @@ def test_retr_stats(cuda, T, H, W, pos):
             print(f"rstd rel err max {rel.max():.2e} mean {rel.mean():.2e} (bound {bound:.1e})")
             assert rel.max() <= bound, rel.max()
         sig = 1.0 / rv[t].astype(np.float64)
-        assert np.all(aux[t][:, 0] == 1.0) and np.all(aux[t][:, 3:] == 0.0)
+        assert np.all(aux[t][:, 0] == 1.0) and np.all(aux[t][:, 3:8] == 0.0) and np.all(aux_raw[t][:, 12:] == 0)
+        # columns 8 .. 11 of the row: rstd_k, rstd_v as raw fp32 (what K1's producers read from the staged tile)
+        packed = np.ascontiguousarray(aux_raw[t][:, 8:12]).view(np.float32)
+        assert np.array_equal(packed[:, 0], rk[t]) and np.array_equal(packed[:, 1], rv[t])
         assert np.abs(aux[t][:, 1].astype(np.float64) + aux[t][:, 2] - sig).max() <= 3e-5 * sig.max()   # hi + lo: 16-bit mantissa
 
 
