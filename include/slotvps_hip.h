@@ -270,7 +270,8 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *   rk [256, 256] FP16, rv [256, 256] bf16: the UPPER-TRIANGULAR factor R of  [W~ | b~] = Q [R | r]  for to_k / to_v
  *       (host, float64 QR; the key side runs fp16 x fp16 on fp16(feat + pos): rstd_k needs the three extra mantissa bits);
  *   rbk, rbv [256] fp32: the column r.   |R x + r|^2 = |W~ x + b~|^2 = 256 * var.
- *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] bf16 = {1, hi(1/rstd_v), lo(1/rstd_v), 0 ...}
+ *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] bf16 = {1, hi(1/rstd_v), lo(1/rstd_v), 0 x 5,
+ *       rstd_k, rstd_v once more as raw fp32 (columns 8 .. 11), 0 x 20}: the 64-byte row svps_retr_attn_fwd stages with every pixel
  *
  * svps_retr_attn_fwd    (:435-456)
  *   The slot axis of the inputs is padded to LP = 128 rows (L <= 128) or 256 rows (L <= 256), rows >= L zero:
@@ -280,6 +281,8 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *       is what removes them from the softmax: the kernel applies no mask)
  *   out_ext [T, L, 272] fp32: { A_l = sum_p P rstd_v f_p (256), s1_l = sum_p P rstd_v, s0_l = sum_p P, 0 x 14 };
  *       pre-LayerNorm output (:456) = out_ext @ [ (gamma_v * W~_v)^T ; gamma_v * b~_v ; beta_v ; 0 ]
+ *   rstd_k / rstd_v: the arrays of svps_retr_stats_fwd (the kernel for L <= 128 takes both values from the aux rows; rstd_k is read
+ *       by the statistics kernel of the L > 128 path)
  *   1 <= L <= 256; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 264] fp32
  *   (+ [T, HW] x 8 B when L > 128: per-pixel softmax statistics over all slots, written by a first kernel; the retriever then
  *   runs once per half of the slots)
@@ -287,7 +290,7 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
 int svps_retr_stats_fwd(const void* feat, const float* pos_y, const float* pos_x, const void* rk, const float* rbk,
                         float lnk_eps, const void* rv, const float* rbv, float lnv_eps, float* rstd_k, float* rstd_v,
                         void* aux, int T, int H, int W, int D, void* stream);
-size_t svps_retr_attn_workspace_bytes(int T, int L, int HW, int chunks);
+size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int chunks);
 int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
                        const void* feat, const float* rstd_k, const float* rstd_v, const void* aux, void* workspace,
                        size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,

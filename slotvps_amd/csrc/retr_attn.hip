@@ -30,26 +30,31 @@
 // nothing.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
 namespace svps {
 
 constexpr int kRPrefetch = 3;
-constexpr int kRNF = kRPrefetch + 2;       // feature / aux ring depth
+constexpr int kRNF = kRPrefetch + 3;       // feature / aux / Cy ring depth: tiles it-2 .. it+3 are live in iteration it
 constexpr int kAuxRow = 64;                // bytes per pixel of the aux tensor (32 bf16)
 constexpr int kAuxTile = kTilePx * kAuxRow;
+constexpr int kCyTile = 1024;              // one LDS-DMA piece: the Cy row of the tile's image row (LP = 128: and the next row)
 constexpr int kPartRow = 264;              // floats per slot row of a partial: 256 channels of A + 8 aux columns
 constexpr int kExtRow = 272;               // floats per slot row of the finished result: 17 k-steps of 16 for the slot-side product
 
 struct RetrLds {
-    static constexpr int fring = 0;
+    static constexpr int fring = 0;                             // tile bases are multiples of 512 B (fragment address XORs)
     static constexpr int aring = kRNF * kTileBytes;
-    static constexpr int pring = aring + kRNF * kAuxTile;       // [2][hi 8 KiB | lo 8 KiB], slot block sb at sb * 2 KiB
-    static constexpr int stats = pring + 2 * kTileBytes;        // [4][32] float2
-    static constexpr int c3 = stats + 4 * 32 * 8;               // [128] float
+    static constexpr int yring = aring + kRNF * kAuxTile;
+    static constexpr int pring = yring + kRNF * kCyTile;        // [2][hi 8 KiB | lo 8 KiB], slot block sb at sb * 2 KiB
+    static constexpr int stats = pring + 2 * kTileBytes;        // [2][4][32] float2
+    static constexpr int c3 = stats + 2 * 4 * 32 * 8;           // [128] float
     static constexpr int total = c3 + 128 * 4;
 };
+static_assert(RetrLds::pring % 512 == 0 && RetrLds::total <= 160 * 1024, "LDS layout");
 
 __device__ __forceinline__ u32x4 ra_make_srd(const void* base, uint32_t bytes) {
     const uint64_t a = reinterpret_cast<uint64_t>(base);
@@ -74,6 +79,19 @@ __device__ __forceinline__ void ra_dma16(u32x4 srd, uint32_t lds_addr, int voff,
         : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
         : "memory");
 }
+// the same without the hint: the Cy rows are re-read by every workgroup of the frame (L2-resident)
+__device__ __forceinline__ void ra_dma16_cached(u32x4 srd, uint32_t lds_addr, int voff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(srd)
+        : "memory");
+}
 
 __device__ __forceinline__ float ra_half_swap_max(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -82,16 +100,6 @@ __device__ __forceinline__ float ra_half_swap_max(float x) {
 __device__ __forceinline__ float ra_half_swap_sum(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// aux tile: 32 pixel rows of 64 B, linear. B fragment of its 32 columns for k-step ks (pixels 16 ks .. + 16)
-__device__ __forceinline__ bf16x8 read_col_frag_aux(const char* at, int ks, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const int row0 = 16 * ks + 8 * (g >> 1) + q;
-    const int off = (2 * (g & 1) + (p >> 1)) * 16 + 8 * (p & 1);
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(at + row0 * kAuxRow + off));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(at + (row0 + 4) * kAuxRow + off));
-    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 #ifdef SVPS_RETR_STAMP
@@ -113,7 +121,19 @@ __device__ unsigned long long retr_clock[4096][4];       // [workgroup][memtime0
 // ABL: timing-only ablations (env SVPS_RETR_ABLATE), outputs wrong. 1: DMA + barriers only  2: producers only  4: consumers only
 // EXT (more than 128 slots, LP = 256): the launch covers the `L` slots starting at row `slot_off`; the per-pixel softmax
 // statistics over ALL slots come from `ext_stats` ([T, HW] of (max logit, 1 / sum of exponentials), written by
-// retr_logit_stats_kernel) instead of the exchange between the four producers: one softmax pass, no second payload.
+// retr_logit_stats_kernel) instead of the exchange between the four producers.
+//
+// Tile order. A tile is 32 consecutive pixels of one image row; a workgroup walks DOWN a 32-pixel-wide column strip
+// (tile id = strip * H + row, a chunk = a run of tile ids), so the Cx terms of its lanes' pixel columns stay in 16 registers for
+// a whole strip and the only per-tile position data is the 512-byte Cy row, which arrives by LDS-DMA with the feature
+// tile. rstd_k / rstd_v come out of the aux tile (retr_stats.hip stores them there as raw fp32). The producers therefore
+// issue NO global loads per tile (they cost 60 - 100 cycles of issue each: ten of them were a third of the tile time).
+//
+// Schedule (one workgroup barrier B(it) per tile; P(i), stats(i) = results of tile i):
+//   producer, iteration it:  MFMA chain of tile it  ||  softmax finish of tile it-1 (reads stats(it-1), writes P(it-1))
+//                            then the softmax head of tile it: logits, block maximum, exponentials, block sum -> stats(it)
+//   consumer, iteration it:  LDS-DMA of batch it+3;  A += P(it-2) f(it-2) (36 MFMA)
+// The exponentials of a tile stay in 16 registers across the barrier; the statistics buffer and the P ring are double-buffered.
 template <int ABL = 0, bool EXT = false>
 __global__ __launch_bounds__(512) void retr_attn_kernel(
     const __bf16* __restrict__ qh,      // [T, LP, 256]  hi(Q''), rows >= the real slot count zero
@@ -122,13 +142,11 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const float* __restrict__ cx,       // [T, W, LP]    Q''[:, 128:256] . xtab[x]
     const float* __restrict__ c3g,      // [T, LP]  log2(e) * q . beta_k; -1e30 in the padded rows
     const __bf16* __restrict__ feat,    // [T, HW, 256]
-    const float* __restrict__ rstd_k,   // [T, HW]
-    const float* __restrict__ rstd_v,   // [T, HW]
-    const __bf16* __restrict__ aux,     // [T, HW, 32]
+    const __bf16* __restrict__ aux,     // [T, HW, 32]   retr_stats.hip: {1, hi sigma_v, lo sigma_v, 0 x 5, rstd_k, rstd_v (fp32), 0 ...}
     float* __restrict__ partial,        // [T, C, Lrow, 264]
-    int L, int HW, int H, int W, float inv_w, int tiles_per_chunk, int LP, int Lrow, int slot_off,
+    int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off,
     const float2* __restrict__ ext_stats) {
-    extern __shared__ __attribute__((aligned(1024))) char smem[];   // tile bases are multiples of 512 B (the fragment address XORs rely on it)
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = RetrLds;
     constexpr int A = kRPrefetch;
 
@@ -141,25 +159,22 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     int t = blockIdx.y, c = blockIdx.x;
     if ((gridDim.y & 7) == 0) {
         // XCD-aware frame placement (speed only, any mapping is correct): workgroups are handed to the 8 XCDs round-robin
-        // by linear id, and the producers re-read their frame's position tables (cy / cx, ~0.4 MB per frame) every image
-        // row. With the natural (chunk, frame) order a frame's workgroups land on all 8 XCDs and every 4 MB L2 sees the
-        // tables of all frames in flight (measured: 1.35x the algorithmic bytes leave L2); here all chunks of a frame go
-        // to ONE XCD, so an L2 holds the tables of the two or three frames its 32 CUs work on.
+        // by linear id; here all chunks of a frame go to ONE XCD, so an L2 holds the position tables and the slot operands
+        // of the two or three frames its 32 CUs work on instead of those of every frame in flight.
         const int b = blockIdx.y * C + blockIdx.x;
         const int n = b >> 3;
         t = (b & 7) + 8 * (n / C);
         c = n % C;
     }
+    const int tiles = ((W + kTilePx - 1) / kTilePx) * H;
+    const int tid0 = c * tiles_per_chunk;
+    int nt = tiles - tid0;
+    nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;           // >= 1 by construction of the grid
+    const int strip0 = tid0 / H, row0 = tid0 - strip0 * H;      // first tile of the chunk
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
 
-    const int px_begin = c * tiles_per_chunk * kTilePx;
-    int px_end = px_begin + tiles_per_chunk * kTilePx;
-    px_end = px_end < HW ? px_end : HW;
-    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
-
-    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
     float* c3l = reinterpret_cast<float*>(smem + Lds::c3);
     if (threadIdx.x < 128) c3l[threadIdx.x] = c3g[(size_t)t * LP + slot_off + threadIdx.x];
-
 #ifdef SVPS_RETR_STAMP
     const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
     if (threadIdx.x == 0 && wg_lin < 4096) {
@@ -167,6 +182,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         retr_clock[wg_lin][1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+
     if (!consumer) {
         // ================================ producer =============================================
         bf16x8 qfh[16], qfl[16];
@@ -178,9 +194,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 qfl[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
             }
         }
-        const int slot0 = 32 * sb + 4 * h;
+        const int slot0 = 32 * sb + 4 * h;                          // accumulator register 4 g + j <-> slot row slot0 + 8 g + j
         const int key = (r >> 1) & 3;
-        const uint32_t lane_row = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem) + Lds::fring + r * kRowBytes + ((h ^ swz(r)) << 4);
+        const uint32_t lane_row = lds0 + Lds::fring + r * kRowBytes + ((h ^ swz(r)) << 4);
         // tables through buffer descriptors (scalar registers) + 32-bit lane offsets: no 64-bit pointers in vector registers
         auto uniform_rsrc = [](const void* p, int bytes) {          // every word provably wave-uniform: no waterfall loops
             const uint64_t a = reinterpret_cast<uint64_t>(p);
@@ -191,163 +207,210 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         };
         const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * LP + slot_off, H * LP * 4 - slot_off * 4);
         const __amdgpu_buffer_rsrc_t cxr = uniform_rsrc(cx + (size_t)t * W * LP + slot_off, W * LP * 4 - slot_off * 4);
-        const __amdgpu_buffer_rsrc_t exr = uniform_rsrc(EXT ? (const void*)(ext_stats + (size_t)t * HW) : (const void*)rstd_k, EXT ? HW * 8 : 0);
-        const __amdgpu_buffer_rsrc_t rkr = uniform_rsrc(rstd_k + (size_t)t * HW, HW * 4);
-        const __amdgpu_buffer_rsrc_t rvr = uniform_rsrc(rstd_v + (size_t)t * HW, HW * 4);
-        // Position terms and statistics of this lane's pixel of tile `tile` (L2-resident tables): requested one tile ahead,
-        // right after the MFMA chain (its fragment registers are free then), summed at the end of the iteration into the
-        // INITIAL value of the next tile's accumulator.
-        f32x4 cyv[4], cxv[4];
-        float rk_n, tau_n;
-        f32x2 ext_n = {0.f, 0.f};
-        auto request = [&](int tile) {
-            int px = px_begin + tile * kTilePx + r;
-            px = px < HW ? px : HW - 1;
-            int yy = (int)((float)px * inv_w);
-            int xx = px - yy * W;
-            if (xx < 0) { xx += W; --yy; }
-            if (xx >= W) { xx -= W; ++yy; }
-            const int yo = (yy * LP + slot0) * 4, xo = (xx * LP + slot0) * 4;
+        const __amdgpu_buffer_rsrc_t exr = uniform_rsrc(EXT ? (const void*)(ext_stats + (size_t)t * HW) : (const void*)cy, EXT ? HW * 8 : 0);
+
+        // Cx of this lane's pixel column: constant down a strip (clamped past the right edge: those pixels are masked)
+        f32x4 cxv[4];
+        auto load_cx = [&](int strip) {
+            int xx = kTilePx * strip + r;
+            xx = xx < W ? xx : W - 1;
+            const int xo = (xx * LP + slot0) * 4;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                cyv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
-                cxv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cxr, xo + 32 * g, 0, 0));
-            }
-            rk_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rkr, px * 4, 0, 0));
-            tau_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rvr, px * 4, 0, 0));
-            if constexpr (EXT) ext_n = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(exr, px * 8, 0, 0));
+            for (int g = 0; g < 4; ++g) cxv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cxr, xo + 32 * g, 0, 0));
         };
-        f32x16 cinit;
-        float rk, tau;
-        f32x2 ext = {0.f, 0.f};
-        auto settle = [&]() {
-            ext = ext_n;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) cinit[4 * g + j] = cyv[g][j] + cxv[g][j];
-            rk = rk_n;
-            tau = tau_n;
-        };
-        request(0);
-        settle();
-        for (int it = 0; it <= nt; ++it) {
-            RETR_STAMP(0, 0);
-            wg_barrier();                                        // B_top(it)
-            RETR_STAMP(0, 1);
-            if (it == nt || ABL == 1 || ABL == 4) { wg_barrier(); continue; }
-            // LDS byte address of this lane's 16-B chunk of k-step ks = 8 a + b in the tile: (tile + lane_row) ^ (b << 5), + 256 a:
-            // eight XORs per tile, the rest are instruction offsets (the swizzle touches chunk bits 0-3 only)
-            const uint32_t tb = lane_row + (uint32_t)(it % kRNF) * kTileBytes;
-            auto frag = [&](int ks) {
-                return *reinterpret_cast<SVPS_LDS const bf16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
-            };
-            const bool live = px_begin + it * kTilePx + r < px_end;
-            f32x16 s = cinit;
-            {   // row fragments in groups of four (k-steps 2g, 2g + 8, 2g + 1, 2g + 9), double-buffered: the reads of group
-                // g + 1 fly under the 8 MFMAs of group g
-                constexpr int kOrd[4] = {0, 8, 1, 9};
-                bf16x8 kf[2][4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) kf[0][u] = frag(kOrd[u]);
-#pragma unroll
-                for (int grp = 0; grp < 4; ++grp) {
-                    if (grp < 3) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = frag(2 * (grp + 1) + kOrd[u]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            RETR_STAMP(0, 2);
-            const float rk_c = rk * kLog2e, tau_c = tau;     // logits are formed directly in the log2 domain (c3 arrives pre-scaled)
-            const f32x2 ext_c = ext;
-            if (it + 1 < nt) request(it + 1);
-            __builtin_amdgcn_sched_barrier(0);
+        int ts = strip0, ty = row0;                                 // strip / image row of tile `it`
+        f32x16 cinit;                                               // Cy + Cx of tile `it`: the initial value of its accumulator
+        f32x2 ext_n = {0.f, 0.f};                                   // EXT: statistics of this lane's pixel, requested one tile ahead
+        auto request_ext = [&](int strip, int row) {
             if constexpr (EXT) {
-                // statistics over all slots are known: P = exp(S - max) / sum, one pass, no exchange
-                const float mneg = -ext_c[0];                    // statistics are in the log2 domain as well
-                float fac = ext_c[1] * tau_c;
-                if (!live) fac = 0.f;
-                wg_barrier();                                    // B_stats(it)
-                char* prow = smem + Lds::pring + (it & 1) * kTileBytes + sb * 2048 + r * 64 + 8 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 c3v = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
-                    bf16x4 ph, pl;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(rk_c, s[4 * g + j], c3v[j]) + mneg) * fac;
-                        ph[j] = (__bf16)p;
-                        pl[j] = (__bf16)(p - (float)ph[j]);
-                    }
-                    *reinterpret_cast<bf16x4*>(prow + ((g ^ key) * 16)) = ph;
-                    *reinterpret_cast<bf16x4*>(prow + 8192 + ((g ^ key) * 16)) = pl;
-                }
-                if (it + 1 < nt) settle();
-                continue;
+                int px = row * W + kTilePx * strip + r;
+                px = px < HW ? px : HW - 1;
+                ext_n = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(exr, px * 8, 0, 0));
             }
-            // log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no masking: their
-            // Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep), so they come out as -1e30 and exp2 to exactly 0.
-            float mloc = kNegBig;
+        };
+        load_cx(ts);
+        {   // tile 0: its Cy row straight from global memory (the rows of the later tiles arrive by LDS-DMA, one batch early)
+            const int yo = (ty * LP + slot0) * 4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 c3v = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
+                const f32x4 cyv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[4 * g + j] = fmaf(rk_c, s[4 * g + j], c3v[j]);
-                    mloc = fmaxf(mloc, s[4 * g + j]);
-                }
+                for (int j = 0; j < 4; ++j) cinit[4 * g + j] = cyv[j] + cxv[g][j];
             }
-            mloc = ra_half_swap_max(mloc);
-            RETR_STAMP(0, 6);
-            float sloc = 0.f;
+        }
+        request_ext(ts, ty);
+
+        f32x16 e;                                                   // exponentials of the previous tile (relative to its block maximum)
+        float mloc_p = 0.f, tau_p = 0.f;
+        bool live_p = false;
+        f32x2 ext_p = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s[i] = __builtin_amdgcn_exp2f(s[i] - mloc);
-                sloc += s[i];
-            }
-            sloc = ra_half_swap_sum(sloc);
-            if (h == 0) stats[sb * 32 + r] = make_float2(mloc, sloc);
-            RETR_STAMP(0, 3);
-            wg_barrier();                                        // B_stats(it)
-            RETR_STAMP(0, 4);
-            float mall = kNegBig;
+        for (int i = 0; i < 16; ++i) e[i] = 0.f;
+        float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+
+        // first fragment group and (rstd_k, rstd_v) of a tile: requested at the END of the previous iteration (the consumers
+        // let a barrier pass only when the batch after the current one has landed), so their latency runs under the barrier
+        bf16x8 kf0[4];
+        f32x2 rt = {0.f, 0.f};
+        constexpr int kOrd[4] = {0, 8, 1, 9};                       // group g: k-steps 2g, 2g + 8, 2g + 1, 2g + 9
+        // LDS byte address of this lane's 16-B chunk of k-step ks = 8 a + b in a tile: (tile + lane_row) ^ (b << 5), + 256 a
+        auto frag = [&](uint32_t tb, int ks) {
+            return *reinterpret_cast<SVPS_LDS const bf16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
+        };
+        auto prefetch = [&](int tile) {
+            const uint32_t slot = (uint32_t)(tile % kRNF);
+            const uint32_t tb = lane_row + slot * kTileBytes;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kf0[u] = frag(tb, kOrd[u]);
+            // (rstd_k, rstd_v) of this lane's pixel: bytes 16 .. 23 of its aux row
+            rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + slot * kAuxTile + r * kAuxRow + 16));
+        };
+
+        // One iteration. CHAIN: tile `it` exists (MFMA chain + softmax head); P2: tile it-1 exists (softmax finish).
+        auto body = [&](int it, auto chain_tag, auto p2_tag) {
+            constexpr bool CHAIN = decltype(chain_tag)::value, P2 = decltype(p2_tag)::value;
+            const uint32_t tb = lane_row + (uint32_t)(it % kRNF) * kTileBytes;
+            // ---- softmax finish of tile it-1, part 1: the four blocks' statistics (requested now, used under the second MFMA group)
+            float fac = 0.f;
             float2 st_w[4];
+            if constexpr (P2 && !EXT) {
+                const float2* st = stats + ((it - 1) & 1) * 128 + r;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                st_w[ww] = stats[ww * 32 + r];
-                mall = fmaxf(mall, st_w[ww].x);
+                for (int ww = 0; ww < 4; ++ww) st_w[ww] = st[ww * 32];
             }
-            float den = 0.f;
+            auto p2_factor = [&]() {                                // normalisation factor of this lane's pixel: P * rstd_v = e * fac
+                if constexpr (EXT) {
+                    fac = ext_p[1] * tau_p;
+                } else {
+                    float mall = kNegBig;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww)
-                den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
-            float fac = __builtin_amdgcn_exp2f(mloc - mall) / den * tau_c;               // P * rstd_v
-            if (!live) fac = 0.f;                                                       // pixels past the chunk / frame
-            char* prow = smem + Lds::pring + (it & 1) * kTileBytes + sb * 2048 + r * 64 + 8 * h;
+                    for (int ww = 0; ww < 4; ++ww) mall = fmaxf(mall, st_w[ww].x);
+                    float den = 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+                    for (int ww = 0; ww < 4; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
+                    fac = __builtin_amdgcn_exp2f(mloc_p - mall) * __builtin_amdgcn_rcpf(den) * tau_p;
+                }
+                if (!live_p) fac = 0.f;                             // pixels past the right edge of the map
+            };
+            char* prow = smem + Lds::pring + ((it - 1) & 1) * kTileBytes + sb * 2048 + r * 64 + 8 * h;
+            auto p2_store = [&](int g) {                            // four slots of P(it-1) = e * fac as bf16 hi + lo
                 bf16x4 ph, pl;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float p = s[4 * g + j] * fac;
+                    const float p = e[4 * g + j] * fac;
                     ph[j] = (__bf16)p;
                     pl[j] = (__bf16)(p - (float)ph[j]);
                 }
                 *reinterpret_cast<bf16x4*>(prow + ((g ^ key) * 16)) = ph;
                 *reinterpret_cast<bf16x4*>(prow + 8192 + ((g ^ key) * 16)) = pl;
+            };
+            f32x16 s = cinit;
+            f32x4 c3v[4];
+            const float rk_c = rt[0] * kLog2e, tau_c = rt[1];
+            if constexpr (CHAIN) {
+                // row fragments in groups of four, double-buffered: the reads of group g + 1 (after the last group: the c3 terms)
+                // and a part of the softmax finish of tile it-1 run in the shadow of the 8 MFMAs of group g
+                bf16x8 kf[2][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kf[0][u] = kf0[u];
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    if (grp < 3) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = frag(tb, 2 * (grp + 1) + kOrd[u]);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) c3v[g] = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                    }
+                    if constexpr (P2) {
+                        if (grp == 0) p2_factor();
+                        if (grp == 1) { p2_store(0); p2_store(1); }
+                        if (grp == 2) { p2_store(2); p2_store(3); }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {                   // one MFMA, then its share of the other work
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (u < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if constexpr (P2) {
+                p2_factor();
+#pragma unroll
+                for (int g = 0; g < 4; ++g) p2_store(g);
             }
-            RETR_STAMP(0, 7);
-            if (it + 1 < nt) settle();
+            RETR_STAMP(0, 2);
+            if constexpr (!CHAIN) return;
+            // ---- softmax head of tile it
+            // log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no masking: their
+            // Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep), so they come out as -1e30 and exp2 to exactly 0.
+            live_p = kTilePx * ts + r < W;
+            ++ty;
+            if (ty == H) { ty = 0; ++ts; if (it + 1 < nt) load_cx(ts); }
+            const bool more = it + 1 < nt;
+            float mloc = kNegBig;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[4 * g + j] = fmaf(rk_c, s[4 * g + j], c3v[g][j]);
+                    if constexpr (!EXT) mloc = fmaxf(mloc, s[4 * g + j]);
+                }
+            }
+            // Cy row of tile it+1 (staged with batch `it`): requested now, added to Cx after the exponentials
+            f32x4 cyv[4];
+            const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + ((it + 1) % kRNF) * kCyTile) + slot_off + slot0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cyv[g] = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
+            const f32x2 ext_c = ext_n;
+            if constexpr (EXT) mloc = ext_c[0];                     // statistics over all slots are known (log2 domain as well)
+            else mloc = ra_half_swap_max(mloc);
+            if (more) request_ext(ts, ty);
+            RETR_STAMP(0, 6);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] -= mloc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+            if constexpr (!EXT) {
+                float sl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sl[i] = (s[i] + s[4 + i]) + (s[8 + i] + s[12 + i]);
+                const float sloc = ra_half_swap_sum((sl[0] + sl[1]) + (sl[2] + sl[3]));
+                if (h == 0) stats[(it & 1) * 128 + sb * 32 + r] = make_float2(mloc, sloc);
+            }
+            e = s;
+            mloc_p = mloc;
+            tau_p = tau_c;
+            ext_p = ext_c;
+            RETR_STAMP(0, 3);
+            // ---- next tile: position terms, first fragment group
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cinit[4 * g + j] = cyv[g][j] + cxv[g][j];
+            if (more) prefetch(it + 1);
             RETR_STAMP(0, 5);
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        constexpr bool kRun = ABL != 1 && ABL != 4;
+        wg_barrier();                                               // B(0)
+        if constexpr (kRun) { prefetch(0); body(0, T_{}, F_{}); }
+        for (int it = 1; it < nt; ++it) {
+            RETR_STAMP(0, 0);
+            wg_barrier();                                           // B(it)
+            RETR_STAMP(0, 1);
+            if constexpr (kRun) body(it, T_{}, T_{});
         }
+        wg_barrier();                                               // B(nt)
+        if constexpr (kRun) body(nt, F_{}, T_{});
+        wg_barrier();                                               // B(nt + 1)
 #ifdef SVPS_RETR_STAMP
         if (threadIdx.x == 0 && wg_lin < 4096) {
             retr_clock[wg_lin][2] = __builtin_amdgcn_s_memtime();
@@ -360,23 +423,24 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     // =================================== consumer ===============================================
     const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
     const u32x4 ars = ra_make_srd(aux + (size_t)t * HW * 32, (uint32_t)HW * kAuxRow);
+    const u32x4 yrs = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
     int voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 8 * sb + 2 * i + h;
         voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
     }
-    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
-    const int nb = 4 + (sb < 2 ? 1 : 0);                        // DMA instructions of one batch of this wave
+    const int nb = 4 + (sb < 3 ? 1 : 0);                        // DMA instructions of one batch of this wave
+    int ds = strip0, dy = row0;                                 // strip / image row of the next batch
     auto issue_batch = [&](int b) {
         if (b >= nt) return;
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % kRNF) * kTileBytes + sb * 4 * 1024);
-        const int px0 = px_begin + b * kTilePx;
+        const int px0 = dy * W + kTilePx * ds;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
         if (px0 + kTilePx <= HW) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra_dma16(frs, st + i * 1024, voff[i], soff);
-        } else {                                                 // ragged last tile of the frame: clamp the source rows (their P is 0)
+        } else {                                                 // last row of a ragged strip: clamp the source rows (their P is 0)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = 8 * sb + 2 * i + h;
@@ -384,9 +448,14 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
             }
         }
+        ++dy;
+        if (dy == H) { dy = 0; ++ds; }
         if (sb < 2) {                                            // aux tile: two 1-KiB pieces; rows past the frame read zeros (range check on voff)
             const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % kRNF) * kAuxTile + sb * 1024);
             ra_dma16(ars, sa, px0 * kAuxRow + sb * 1024 + lane * 16, 0);
+        } else if (sb == 2) {                                    // Cy row of tile b + 1 (1 KiB from the start of its image row)
+            const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b + 1) % kRNF) * kCyTile);
+            ra_dma16_cached(yrs, sy, dy * LP * 4 + lane * 16);
         }
     };
 #pragma unroll
@@ -414,57 +483,65 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const uint32_t lane_a = rowl * kAuxRow + cl * 16 + sub;
     auto tr = [](uint32_t a) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<SVPS_LDS bf16x4*>((uintptr_t)a)); };
     auto cat = [](bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); };
-    auto pv_step = [&](uint32_t pt, uint32_t vt, uint32_t at, int ks) {
-        const uint32_t p0 = pt + lane_p0 + 1024 * ks, p1 = pt + lane_p1 + 1024 * ks;
-        const uint32_t v0 = vt + lane_v0, v1 = vt + lane_v1, aa = at + lane_a + 1024 * ks;
-        auto vfrag = [&](int db) {
-            const uint32_t o = 8192 * ks + 256 * (db >> 2);
-            return cat(tr((v0 ^ ((db & 3) << 6)) + o), tr((v1 ^ ((db & 3) << 6)) + o));
-        };
-        const bf16x8 ah = cat(tr(p0), tr(p1));
-        const bf16x8 al = cat(tr(p0 + 8192), tr(p1 + 8192));
-        const bf16x8 af = cat(tr(aa), tr(aa + 256));
-        bf16x8 vf[2][4];                                        // value fragments double-buffered in two halves of four blocks
+    // A += P f for one tile: 4 steps (k-step, half of the channel blocks) of 8 MFMA (+ 2 for the aux block), the fragments of
+    // step q + 1 requested before the MFMAs of step q; those of step 0 before the LDS-DMA of the iteration is issued
+    bf16x8 ah[2], al[2], af[2], vf[2][4];
+    uint32_t p0 = 0, p1 = 0, v0 = 0, v1 = 0, aa = 0;
+    auto vfrag = [&](int ks, int db) {
+        const uint32_t o_ = 8192 * ks + 256 * (db >> 2);
+        return cat(tr((v0 ^ ((db & 3) << 6)) + o_), tr((v1 ^ ((db & 3) << 6)) + o_));
+    };
+    auto pv_begin = [&](int j) {
+        const uint32_t pt = lds0 + Lds::pring + (j & 1) * kTileBytes, vt = lds0 + Lds::fring + (j % kRNF) * kTileBytes;
+        const uint32_t at = lds0 + Lds::aring + (j % kRNF) * kAuxTile;
+        p0 = pt + lane_p0, p1 = pt + lane_p1, v0 = vt + lane_v0, v1 = vt + lane_v1, aa = at + lane_a;
+        ah[0] = cat(tr(p0), tr(p1));
+        al[0] = cat(tr(p0 + 8192), tr(p1 + 8192));
+        af[0] = cat(tr(aa), tr(aa + 256));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vf[0][u] = vfrag(u);
+        for (int u = 0; u < 4; ++u) vf[0][u] = vfrag(0, u);
+    };
+    auto pv_rest = [&]() {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half == 0) {
+        for (int q = 0; q < 4; ++q) {
+            const int ks = q >> 1, half = q & 1;
+            if (q < 3) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) vf[1][u] = vfrag(4 + u);
+                for (int u = 0; u < 4; ++u) vf[(q + 1) & 1][u] = vfrag((q + 1) >> 1, 4 * ((q + 1) & 1) + u);
+            }
+            if (q == 1) {
+                ah[1] = cat(tr(p0 + 1024), tr(p1 + 1024));
+                al[1] = cat(tr(p0 + 1024 + 8192), tr(p1 + 1024 + 8192));
+                af[1] = cat(tr(aa + 1024), tr(aa + 1024 + 256));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vf[half][u], o[4 * half + u], 0, 0, 0);
-                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vf[half][u], o[4 * half + u], 0, 0, 0);
+                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
+                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
             }
             if (half == 0) {
-                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, af, oa, 0, 0, 0);
-                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, af, oa, 0, 0, 0);
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], af[ks], oa, 0, 0, 0);
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], af[ks], oa, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    for (int it = 0; it <= nt; ++it) {
-        // batch `it` (feature + aux tile it) landed for this wave: all but the A-1 younger batches
+    for (int it = 0; it <= nt + 1; ++it) {
+        // batches <= it+1 (feature + aux tiles, the Cy row of the tile after) landed for this wave: all but the youngest batch
+        // (the producers request the first fragments of tile it+1 at the end of iteration it)
         RETR_STAMP(1, 0);
-        if (it + A - 1 < nt) wait_vm_dyn(nb * (A - 1));
+        if (it + A - 1 < nt) wait_vm_dyn(nb * (A - 2));
         else wait_vm<0>();
         RETR_STAMP(1, 1);
-        wg_barrier();                                            // B_top(it)
+        wg_barrier();                                            // B(it)
         RETR_STAMP(1, 2);
+        const bool work = it >= 2 && ABL != 1 && ABL != 2;
+        if (work) pv_begin(it - 2);
         issue_batch(it + A);
-        const bool work = it >= 1 && ABL != 1 && ABL != 2;
-        const uint32_t pt = lds0 + Lds::pring + ((it + 1) & 1) * kTileBytes;                 // P(it-1)
-        const uint32_t vt = lds0 + Lds::fring + ((it + kRNF - 1) % kRNF) * kTileBytes;       // f(it-1)
-        const uint32_t at = lds0 + Lds::aring + ((it + kRNF - 1) % kRNF) * kAuxTile;
-        if (work) pv_step(pt, vt, at, 0);
         RETR_STAMP(1, 3);
-        wg_barrier();                                            // B_stats(it)
-        RETR_STAMP(1, 4);
-        if (work) pv_step(pt, vt, at, 1);
+        if (work) pv_rest();
         RETR_STAMP(1, 5);
     }
 
@@ -677,8 +754,9 @@ namespace {
 struct RetrPlan {
     int chunks, tiles_per_chunk;
 };
-RetrPlan plan_retr(int T, int HW, int chunks_req) {
-    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+// retriever: tiles of 32 pixels inside an image row, walked strip by strip (retr_attn_kernel)
+RetrPlan plan_retr(int T, int H, int W, int chunks_req) {
+    const int tiles = ((W + svps::kTilePx - 1) / svps::kTilePx) * H;
     int chunks = chunks_req;
     if (chunks <= 0) chunks = svps_pick_chunks(T, tiles, svps_num_cus(), 64);
     if (chunks > tiles) chunks = tiles;
@@ -686,16 +764,22 @@ RetrPlan plan_retr(int T, int HW, int chunks_req) {
     chunks = (tiles + tpc - 1) / tpc;
     return {chunks, tpc};
 }
-}  // namespace
-
-namespace {
+// logit statistics (more than 128 slots): linear tiles of 32 pixels
+RetrPlan plan_linear(int T, int HW) {
+    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+    int chunks = svps_pick_chunks(T, tiles, svps_num_cus(), 64);
+    if (chunks > tiles) chunks = tiles;
+    const int tpc = (tiles + chunks - 1) / chunks;
+    chunks = (tiles + tpc - 1) / tpc;
+    return {chunks, tpc};
+}
 size_t retr_stats_bytes(int T, int L, int HW) { return L > 128 ? (size_t)T * HW * sizeof(float2) : 0; }
 }  // namespace
 
-extern "C" size_t svps_retr_attn_workspace_bytes(int T, int L, int HW, int chunks) {
-    if (T <= 0 || L <= 0 || HW <= 0) return 0;
-    const RetrPlan p = plan_retr(T, HW, chunks);
-    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float) + retr_stats_bytes(T, L, HW);
+extern "C" size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int chunks) {
+    if (T <= 0 || L <= 0 || H <= 0 || W <= 0) return 0;
+    const RetrPlan p = plan_retr(T, H, W, chunks);
+    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float) + retr_stats_bytes(T, L, H * W);
 }
 
 extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
@@ -706,7 +790,7 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     const int HW = H * W;
-    const RetrPlan p = plan_retr(T, HW, chunks);
+    const RetrPlan p = plan_retr(T, H, W, chunks);
     const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
     if (workspace_bytes < partial_bytes + retr_stats_bytes(T, L, HW)) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -715,7 +799,6 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
     const __bf16* ql_ = static_cast<const __bf16*>(ql);
     const __bf16* f_ = static_cast<const __bf16*>(feat);
     const __bf16* a_ = static_cast<const __bf16*>(aux);
-    const float inv_w = 1.0f / (float)W;
     hipError_t e;
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
     if (L <= 128) {
@@ -727,27 +810,29 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         else if (ablate == 4) { kern = svps::retr_attn_kernel<4, false>; slot = 3; }
         static SvpsLdsAttr attr[4];
         if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
-        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, rstd_k, rstd_v,
-                           a_, partial, L, HW, H, W, inv_w, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr);
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
+                           L, HW, H, W, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr);
         e = hipGetLastError();
     } else {
         // more than 128 slots (padded layouts of 256 rows): softmax statistics over all slots first, then the retriever
         // once per half of the slots with those statistics
         float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);
+        const RetrPlan pl = plan_linear(T, HW);
+        const float inv_w = 1.0f / (float)W;
         static SvpsLdsAttr attr_s, attr_e;
         if (hipError_t ae = attr_s.ensure(reinterpret_cast<const void*>(svps::retr_logit_stats_kernel), svps::LStatsLds::total); ae != hipSuccess) return (int)ae;
         auto kern = svps::retr_attn_kernel<0, true>;
         if (hipError_t ae = attr_e.ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
-        hipLaunchKernelGGL(svps::retr_logit_stats_kernel, dim3(p.chunks, T), dim3(512), svps::LStatsLds::total, stream, qh_, ql_, cy, cx,
-                           c3, f_, rstd_k, st, L, HW, H, W, inv_w, p.tiles_per_chunk);
+        hipLaunchKernelGGL(svps::retr_logit_stats_kernel, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream, qh_, ql_, cy, cx,
+                           c3, f_, rstd_k, st, L, HW, H, W, inv_w, pl.tiles_per_chunk);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, rstd_k, rstd_v,
-                           a_, partial, 128, HW, H, W, inv_w, p.tiles_per_chunk, 256, L, 0, (const float2*)st);
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
+                           128, HW, H, W, p.tiles_per_chunk, 256, L, 0, (const float2*)st);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, rstd_k, rstd_v,
-                           a_, partial, L - 128, HW, H, W, inv_w, p.tiles_per_chunk, 256, L, 128, (const float2*)st);
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
+                           L - 128, HW, H, W, p.tiles_per_chunk, 256, L, 128, (const float2*)st);
         e = hipGetLastError();
     }
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);

@@ -301,7 +301,7 @@ def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
     if (HW != H * W or qh.shape != (T, LP, D) or ql.shape != (T, LP, D) or cy.shape != (T, H, LP) or cx.shape != (T, W, LP)
             or c3.shape != (T, LP) or rstd_k.shape != (T, HW) or rstd_v.shape != (T, HW) or aux.shape != (T, HW, 32)):
         raise ValueError("shape mismatch")
-    ws_bytes = lib.svps_retr_attn_workspace_bytes(T, L, HW, chunks)
+    ws_bytes = lib.svps_retr_attn_workspace_bytes(T, L, H, W, chunks)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)
     out = torch.empty((T, L, 272), dtype=torch.float32, device=feat.device)
     with _on(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux) as ctx:

@@ -42,10 +42,10 @@ rt = (clock[ok, 3] - clock[ok, 1]).astype(np.float64)          # 100 MHz ticks
 ghz = cyc / rt * 0.1
 print(f"workgroups {ok.sum()}: in-kernel clock median {np.median(ghz):.3f} GHz (min {ghz.min():.3f}, max {ghz.max():.3f}); "
       f"loop cycles median {np.median(cyc):.0f}, loop time median {np.median(rt) * 10:.0f} ns")
-names = [{0: "pre B_top", 1: "B_top done", 2: "MFMAs issued", 6: "logits + max", 3: "exp + sum + stats write", 4: "B_stats done",
-          7: "P written", 5: "settle (end)"},
-         {0: "pre wait_vm", 1: "DMA landed", 2: "B_top done", 3: "pv 0 done", 4: "B_stats done", 5: "pv 1 done (end)"}]
-order = [[0, 1, 2, 6, 3, 4, 7, 5], [0, 1, 2, 3, 4, 5]]
+names = [{0: "pre B", 1: "B done", 2: "MFMA chain + finish of tile it-1", 6: "logits + max", 3: "exp + sum + stats write",
+          5: "next tile's position terms (end)"},
+         {0: "pre wait_vm", 1: "DMA landed", 2: "B done", 3: "DMA issued", 5: "36 MFMA (end)"}]
+order = [[0, 1, 2, 6, 3, 5], [0, 1, 2, 3, 5]]
 for role in (0, 1):
     print("--- producer 0" if role == 0 else "--- consumer 0")
     for it in range(1, 5):
