@@ -174,7 +174,7 @@ int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const v
  *     q = LN(x; lnq)   gp[t, l] = q * lnk_w   c3[t, l] = log2(e) q . lnk_b   a1[t, l] = gp[t, l] . bck
  *     rows l >= L: gp = 0, a1 = 0, c3 = -1e30 (the padding convention of svps_retr_attn_fwd)
  *     gp [T, LP, D] is the operand of Q'' = gp W~_k;  c3, a1 [T, LP];  LP = 128 or 256 >= L;  bck [D] = centred to_k bias
- * svps_retr_split: q2 [n] fp32 -> hi = bf16(q2), lo = bf16(q2 - hi) (n a multiple of 4)
+ * svps_retr_split: q2 [n] fp32 -> hi = fp16(q2), lo = fp16(q2 - hi) (n a multiple of 4): the FP16 operand pair of svps_retr_attn_fwd
  * svps_slot_self_attn: softmax(q k^T / sqrt(head_dim)) v per (frame, head) on the packed projection
  *     qkv [T, L, 3, nheads, head_dim] fp32 -> out [T, L, nheads * head_dim]; head_dim = 32, L <= 256
  *     (the attention of nn.MultiheadAttention between in_proj and out_proj, dynamic_mask_head.py:346-355)
@@ -270,12 +270,12 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *   rk [256, 256] FP16, rv [256, 256] bf16: the UPPER-TRIANGULAR factor R of  [W~ | b~] = Q [R | r]  for to_k / to_v
  *       (host, float64 QR; the key side runs fp16 x fp16 on fp16(feat + pos): rstd_k needs the three extra mantissa bits);
  *   rbk, rbv [256] fp32: the column r.   |R x + r|^2 = |W~ x + b~|^2 = 256 * var.
- *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] bf16 = {1, hi(1/rstd_v), lo(1/rstd_v), 0 x 5,
+ *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] FP16 = {1, hi(1/rstd_v), lo(1/rstd_v), 0 x 5,
  *       rstd_k, rstd_v once more as raw fp32 (columns 8 .. 11), 0 x 20}: the 64-byte row svps_retr_attn_fwd stages with every pixel
  *
  * svps_retr_attn_fwd    (:435-456)
  *   The slot axis of the inputs is padded to LP = 128 rows (L <= 128) or 256 rows (L <= 256), rows >= L zero:
- *   qh, ql [T, LP, 256] bf16: hi / lo halves of Q'' = (q * gamma_k) W~_k   (q = norm_q(to_q(slots)), :431)
+ *   qh, ql [T, LP, 256] FP16: hi / lo halves of Q'' = (q * gamma_k) W~_k   (q = norm_q(to_q(slots)), :431; svps_retr_split)
  *   cy [T, H, LP], cx [T, W, LP] fp32: Q''[:, :128] . pos_y[y] + (q * gamma_k) . b~_k  and  Q''[:, 128:] . pos_x[x]
  *   c3 [T, LP] fp32: log2(e) * q . beta_k, and <= -1e30 in the padded rows l >= L (that, with their zero Q'' / cy / cx,
  *       is what removes them from the softmax: the kernel applies no mask)

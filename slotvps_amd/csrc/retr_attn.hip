@@ -37,10 +37,16 @@
 
 namespace svps {
 
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
+typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
 constexpr int kRPrefetch = 3;
 constexpr int kRNF = kRPrefetch + 3;       // feature / aux / Cy ring depth: tiles it-2 .. it+3 are live in iteration it
 constexpr int kAuxRow = 64;                // bytes per pixel of the aux tensor (32 bf16)
 constexpr int kAuxTile = kTilePx * kAuxRow;
+constexpr int kPTile = 8192;               // P tile: 128 slots x 32 pixels fp16
 constexpr int kCyTile = 1024;              // one LDS-DMA piece: the Cy row of the tile's image row (LP = 128: and the next row)
 constexpr int kPartRow = 264;              // floats per slot row of a partial: 256 channels of A + 8 aux columns
 constexpr int kExtRow = 272;               // floats per slot row of the finished result: 17 k-steps of 16 for the slot-side product
@@ -49,8 +55,8 @@ struct RetrLds {
     static constexpr int fring = 0;                             // tile bases are multiples of 512 B (fragment address XORs)
     static constexpr int aring = kRNF * kTileBytes;
     static constexpr int yring = aring + kRNF * kAuxTile;
-    static constexpr int pring = yring + kRNF * kCyTile;        // [2][hi 8 KiB | lo 8 KiB], slot block sb at sb * 2 KiB
-    static constexpr int stats = pring + 2 * kTileBytes;        // [2][4][32] float2
+    static constexpr int pring = yring + kRNF * kCyTile;        // [2][8 KiB] fp16, slot block sb at sb * 2 KiB (32 pixel rows of 64 B)
+    static constexpr int stats = pring + 2 * kPTile;            // [2][4][32] float2
     static constexpr int c3 = stats + 2 * 4 * 32 * 8;           // [128] float
     static constexpr int total = c3 + 128 * 4;
 };
@@ -185,13 +191,13 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
 
     if (!consumer) {
         // ================================ producer =============================================
-        bf16x8 qfh[16], qfl[16];
+        f16x8 qfh[16], qfl[16];
         {
             const size_t row = ((size_t)t * LP + slot_off + 32 * sb + r) * kD + 8 * h;
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-                qfh[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
-                qfl[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
+                qfh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
+                qfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
             }
         }
         const int slot0 = 32 * sb + 4 * h;                          // accumulator register 4 g + j <-> slot row slot0 + 8 g + j
@@ -250,12 +256,12 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
 
         // first fragment group and (rstd_k, rstd_v) of a tile: requested at the END of the previous iteration (the consumers
         // let a barrier pass only when the batch after the current one has landed), so their latency runs under the barrier
-        bf16x8 kf0[4];
+        f16x8 kf0[4];
         f32x2 rt = {0.f, 0.f};
         constexpr int kOrd[4] = {0, 8, 1, 9};                       // group g: k-steps 2g, 2g + 8, 2g + 1, 2g + 9
         // LDS byte address of this lane's 16-B chunk of k-step ks = 8 a + b in a tile: (tile + lane_row) ^ (b << 5), + 256 a
         auto frag = [&](uint32_t tb, int ks) {
-            return *reinterpret_cast<SVPS_LDS const bf16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
+            return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
         };
         auto prefetch = [&](int tile) {
             const uint32_t slot = (uint32_t)(tile % kRNF);
@@ -292,17 +298,12 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 }
                 if (!live_p) fac = 0.f;                             // pixels past the right edge of the map
             };
-            char* prow = smem + Lds::pring + ((it - 1) & 1) * kTileBytes + sb * 2048 + r * 64 + 8 * h;
-            auto p2_store = [&](int g) {                            // four slots of P(it-1) = e * fac as bf16 hi + lo
-                bf16x4 ph, pl;
+            char* prow = smem + Lds::pring + ((it - 1) & 1) * kPTile + sb * 2048 + r * 64 + 8 * h;
+            auto p2_store = [&](int g) {                            // four slots of P(it-1) = e * fac, fp16
+                f16x4 ph;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float p = e[4 * g + j] * fac;
-                    ph[j] = (__bf16)p;
-                    pl[j] = (__bf16)(p - (float)ph[j]);
-                }
-                *reinterpret_cast<bf16x4*>(prow + ((g ^ key) * 16)) = ph;
-                *reinterpret_cast<bf16x4*>(prow + 8192 + ((g ^ key) * 16)) = pl;
+                for (int j = 0; j < 4; ++j) ph[j] = (_Float16)(e[4 * g + j] * fac);
+                *reinterpret_cast<f16x4*>(prow + ((g ^ key) * 16)) = ph;
             };
             f32x16 s = cinit;
             f32x4 c3v[4];
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             if constexpr (CHAIN) {
                 // row fragments in groups of four, double-buffered: the reads of group g + 1 (after the last group: the c3 terms)
                 // and a part of the softmax finish of tile it-1 run in the shadow of the 8 MFMAs of group g
-                bf16x8 kf[2][4];
+                f16x8 kf[2][4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) kf[0][u] = kf0[u];
 #pragma unroll
@@ -324,8 +325,8 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
                     }
                     if constexpr (P2) {
                         if (grp == 0) p2_factor();
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     // instruction offset or one XOR; per tile the ring slot is added to five per-lane terms.
     //   value  V[pixels 16 ks + 8 h' .. + 8][channel 32 db + n]: rows rowl (+4), chunk (4 db + cl) ^ swz(row)
     //          = vt + 8192 ks + 256 (db >> 2) + (lane_v{0,1} ^ ((db & 3) << 6))
-    //   P      rows rowl (+4) of 64 B, chunk cl ^ ((row >> 1) & 3): pt + 1024 ks (+ 8192 for lo) + lane_p{0,1}
+    //   P      rows rowl (+4) of 64 B, chunk cl ^ ((row >> 1) & 3): pt + 1024 ks + lane_p{0,1}
     //   aux    rows rowl (+4) of 64 B, linear: at + 1024 ks (+ 256) + lane_a
     const int g2 = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
     const int cl = 2 * (g2 & 1) + (pp >> 1), sub = 8 * (pp & 1), rowl = 8 * (g2 >> 1) + qq;
@@ -481,22 +482,23 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const uint32_t lane_p0 = sb * 2048 + sub + rowl * 64 + ((cl ^ (qq >> 1)) << 4);
     const uint32_t lane_p1 = sb * 2048 + sub + (rowl + 4) * 64 + ((cl ^ (qq >> 1) ^ 2) << 4);
     const uint32_t lane_a = rowl * kAuxRow + cl * 16 + sub;
-    auto tr = [](uint32_t a) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(reinterpret_cast<SVPS_LDS bf16x4*>((uintptr_t)a)); };
-    auto cat = [](bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); };
-    // A += P f for one tile: 4 steps (k-step, half of the channel blocks) of 8 MFMA (+ 2 for the aux block), the fragments of
+    auto tr = [](uint32_t a) {
+        return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(reinterpret_cast<SVPS_LDS fp16x4_gcc*>((uintptr_t)a)));
+    };
+    auto cat = [](f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); };
+    // A += P f for one tile: 4 steps (k-step, half of the channel blocks) of 4 MFMA (+ 1 for the aux block), the fragments of
     // step q + 1 requested before the MFMAs of step q; those of step 0 before the LDS-DMA of the iteration is issued
-    bf16x8 ah[2], al[2], af[2], vf[2][4];
+    f16x8 ah[2], af[2], vf[2][4];
     uint32_t p0 = 0, p1 = 0, v0 = 0, v1 = 0, aa = 0;
     auto vfrag = [&](int ks, int db) {
         const uint32_t o_ = 8192 * ks + 256 * (db >> 2);
         return cat(tr((v0 ^ ((db & 3) << 6)) + o_), tr((v1 ^ ((db & 3) << 6)) + o_));
     };
     auto pv_begin = [&](int j) {
-        const uint32_t pt = lds0 + Lds::pring + (j & 1) * kTileBytes, vt = lds0 + Lds::fring + (j % kRNF) * kTileBytes;
+        const uint32_t pt = lds0 + Lds::pring + (j & 1) * kPTile, vt = lds0 + Lds::fring + (j % kRNF) * kTileBytes;
         const uint32_t at = lds0 + Lds::aring + (j % kRNF) * kAuxTile;
         p0 = pt + lane_p0, p1 = pt + lane_p1, v0 = vt + lane_v0, v1 = vt + lane_v1, aa = at + lane_a;
         ah[0] = cat(tr(p0), tr(p1));
-        al[0] = cat(tr(p0 + 8192), tr(p1 + 8192));
         af[0] = cat(tr(aa), tr(aa + 256));
 #pragma unroll
         for (int u = 0; u < 4; ++u) vf[0][u] = vfrag(0, u);
@@ -511,20 +513,34 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             }
             if (q == 1) {
                 ah[1] = cat(tr(p0 + 1024), tr(p1 + 1024));
-                al[1] = cat(tr(p0 + 1024 + 8192), tr(p1 + 1024 + 8192));
                 af[1] = cat(tr(aa + 1024), tr(aa + 1024 + 256));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
-                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
-            }
-            if (half == 0) {
-                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], af[ks], oa, 0, 0, 0);
-                oa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], af[ks], oa, 0, 0, 0);
-            }
+            for (int u = 0; u < 4; ++u)
+                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
+            if (half == 0) oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], af[ks], oa, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // This wave's four pieces of feature tile b, bf16 -> fp16 in place (exact: bf16 values are fp16 values for |f| in
+    // [6.1e-5, 65504]; smaller ones lose bits they cannot influence anything with, larger ones saturate). Every matrix
+    // instruction of the kernel then runs fp16 x fp16: Q'' as fp16 hi + lo carries 22 bits, P * rstd_v ONE fp16 (11 bits,
+    // rounding errors average out over the pixel sum) instead of bf16 hi + lo: half the MFMAs on the value side.
+    auto convert_batch = [&](int b) {
+        if (b >= nt) return;
+        const uint32_t st = lds0 + Lds::fring + (b % kRNF) * kTileBytes + sb * 4096 + lane * 16;
+        u32x4 w_[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w_[i] = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(st + i * 1024));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const fp16x2_t pk = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w_[i][k] << 16), __uint_as_float(w_[i][k] & 0xffff0000u));
+                w_[i][k] = __builtin_bit_cast(uint32_t, pk);
+            }
+            *reinterpret_cast<SVPS_LDS u32x4*>((uintptr_t)(st + i * 1024)) = w_[i];
         }
     };
 
@@ -534,6 +550,8 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         RETR_STAMP(1, 0);
         if (it + A - 1 < nt) wait_vm_dyn(nb * (A - 2));
         else wait_vm<0>();
+        if (it == 0) convert_batch(0);
+        convert_batch(it + 1);
         RETR_STAMP(1, 1);
         wg_barrier();                                            // B(it)
         RETR_STAMP(1, 2);
@@ -590,13 +608,13 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
 
     float* c3l = reinterpret_cast<float*>(smem + Lds::c3);
     if (threadIdx.x < 256) c3l[threadIdx.x] = c3g[(size_t)t * LP + threadIdx.x];
-    bf16x8 qfh[16], qfl[16];
+    f16x8 qfh[16], qfl[16];
     {
         const size_t row = ((size_t)t * LP + 32 * w + r) * kD + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            qfh[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
-            qfl[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
+            qfh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
+            qfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
         }
     }
     wait_vm<0>();
@@ -654,6 +672,18 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
         // for the table loads is free to sink below the barrier (the sums are register arithmetic), which would let other
         // waves read this wave's rows of the tile before they arrive.
         wait_vm<0>();
+        {   // this wave's two pieces of f(it): bf16 -> fp16 in place (the operand format of retr_attn_kernel, same arithmetic)
+            const uint32_t st = lds0 + Lds::ring + (it % NST) * kTileBytes + 4 * w * kRowBytes + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4 w_ = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(st + i * 1024));
+                u32x4 o_;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o_[k] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w_[k] << 16), __uint_as_float(w_[k] & 0xffff0000u)));
+                *reinterpret_cast<SVPS_LDS u32x4*>((uintptr_t)(st + i * 1024)) = o_;
+            }
+        }
         f32x16 s;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -666,20 +696,20 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
         int rr = r, hh = h;
         asm volatile("" : "+v"(rr), "+v"(hh));
         {
-            bf16x8 kf[2][4];
+            f16x8 kf[2][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) kf[0][u] = read_row_frag(kt, u, rr, hh);
+            for (int u = 0; u < 4; ++u) kf[0][u] = __builtin_bit_cast(f16x8, read_row_frag(kt, u, rr, hh));
 #pragma unroll
             for (int grp = 0; grp < 4; ++grp) {
                 if (grp < 3) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = read_row_frag(kt, 4 * (grp + 1) + u, rr, hh);
+                    for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = __builtin_bit_cast(f16x8, read_row_frag(kt, 4 * (grp + 1) + u, rr, hh));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfh[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfl[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -14,7 +14,7 @@
 // non-zero 32 x 32 blocks, so the statistics cost 56 % of the matrix work of the projection itself. Row blocks are paired
 // (j, 7 - j): 9 blocks = 18 v_mfma_f32_32x32x16_bf16 per wave and tile, weights resident in 72 VGPRs.
 //
-// Output per pixel: rstd_k [T, HW] fp32, rstd_v [T, HW] fp32 and a 64-byte "aux" row of 32 bf16 (+ both rstd as raw fp32)
+// Output per pixel: rstd_k [T, HW] fp32, rstd_v [T, HW] fp32 and a 64-byte "aux" row of 32 FP16 (+ both rstd as raw fp32)
 //     { 1, hi(sigma_v), lo(sigma_v), 0 ... }            sigma_v = 1 / rstd_v
 // that the retriever appends to the value tile as a ninth 32-channel block: with A = P * rstd_v on the matrix cores its
 // columns accumulate s1 = sum_p P rstd_v and s0 = sum_p P (needed for the bias terms) at no vector-ALU cost.
@@ -327,13 +327,13 @@ __device__ __forceinline__ void retr_stats_role(
         const int off = mine ? px * 4 : 0x7ffffff0;                      // out of range -> dropped by the hardware range check
         asm volatile("buffer_store_dword %0, %1, %2, 0 offen" : : "v"(rstd), "v"(off), "s"(proj ? vsrd : ksrd) : "memory");
         if (proj) {
-            // aux row: lanes h == 0 store bytes [0, 32) = {1, hi, lo, 0 x 5 | rstd_k, rstd_v as raw fp32, 0 x 4}, lanes h == 1
+            // aux row (FP16): lanes h == 0 store bytes [0, 32) = {1, hi, lo, 0 x 5 | rstd_k, rstd_v as raw fp32, 0 x 4}, lanes h == 1
             // bytes [32, 64) = zeros. Columns 0 .. 2 are the ninth channel block of K1' (s1 / s0 sums); the two fp32 words in
             // columns 8 .. 11 are what K1's producers read from the staged tile instead of two more global loads per tile
-            // (as bf16 columns they are garbage that only reaches accumulator columns nobody stores).
-            const __bf16 sh = (__bf16)sigma;
-            const __bf16 sl = (__bf16)(sigma - (float)sh);
-            const __bf16 one = (__bf16)1.0f;
+            // (as 16-bit columns they are garbage that only reaches accumulator columns nobody stores).
+            const _Float16 sh = (_Float16)sigma;                                 // FP16 hi + lo (K1' runs its value side in fp16)
+            const _Float16 sl = (_Float16)(sigma - (float)sh);
+            const _Float16 one = (_Float16)1.0f;
             const uint32_t w0 = (uint32_t)__builtin_bit_cast(uint16_t, one) | ((uint32_t)__builtin_bit_cast(uint16_t, sh) << 16);
             const uint32_t w1 = (uint32_t)__builtin_bit_cast(uint16_t, sl);
             const float* spk = stats + ((it & 1) * 2 + 0) * 4 * 32 + r;          // the key side's sums of the same tile

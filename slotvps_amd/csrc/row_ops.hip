@@ -99,17 +99,17 @@ __global__ __launch_bounds__(256) void retr_query_prep_kernel(const float* __res
     if (lane == 0) { c3[row] = l < L ? c3v * 1.4426950408889634f : -1.0e30f; a1[row] = a1v; }
 }
 
-// Q'' [rows, 256] fp32 -> bf16 hi and lo = bf16(Q'' - hi), the two A operands of K1'
-__global__ __launch_bounds__(256) void retr_split_kernel(const float* __restrict__ q2, __bf16* __restrict__ hi, __bf16* __restrict__ lo, size_t n4) {
+// Q'' [rows, 256] fp32 -> FP16 hi and lo = fp16(Q'' - hi), the two A operands of K1' (22 bits of mantissa together)
+__global__ __launch_bounds__(256) void retr_split_kernel(const float* __restrict__ q2, _Float16* __restrict__ hi, _Float16* __restrict__ lo, size_t n4) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
     const float4 v = reinterpret_cast<const float4*>(q2)[i];
-    bf16x4_t h, l;
-    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
-    l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]); l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
-    reinterpret_cast<bf16x4_t*>(hi)[i] = h;
-    reinterpret_cast<bf16x4_t*>(lo)[i] = l;
+    f16x4_t h, l;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]); l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+    reinterpret_cast<f16x4_t*>(hi)[i] = h;
+    reinterpret_cast<f16x4_t*>(lo)[i] = l;
 }
 
 // ---- slot self-attention (nn.MultiheadAttention of a stage, dynamic_mask_head.py:346-355) -------------------------------
@@ -280,7 +280,7 @@ extern "C" int svps_retr_split(const float* q2, void* hi, void* lo, size_t n, vo
     if (n == 0 || (n & 3)) return SVPS_ERR_BAD_SHAPE;
     const size_t n4 = n / 4;
     hipLaunchKernelGGL(svps::retr_split_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_), q2,
-                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), n4);
+                       static_cast<_Float16*>(hi), static_cast<_Float16*>(lo), n4);
     return (int)hipGetLastError();
 }
 

@@ -247,7 +247,8 @@ def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=No
 def retr_stats(feat, H, W, pos_tabs, rk, rbk, eps_k, rv, rbv, eps_v):
     """K3': per-pixel reciprocal standard deviations of the key / value LayerNorms (+ the aux rows K1' consumes).
     feat [T, H*W, 256] bf16; rk [256, 256] fp16 / rv [256, 256] bf16: upper-triangular QR factors of the centred
-    projections; rbk / rbv [256] fp32. Returns rstd_k [T, HW], rstd_v [T, HW] fp32, aux [T, HW, 32] bf16."""
+    projections; rbk / rbv [256] fp32. Returns rstd_k [T, HW], rstd_v [T, HW] fp32, aux [T, HW, 32] fp16 (64-byte rows:
+    {1, hi sigma_v, lo sigma_v, 0 x 5, rstd_k and rstd_v as raw fp32, 0 ...})."""
     lib = _lib.load()
     _need(feat, "feat", torch.bfloat16, 3)
     T, HW, D = feat.shape
@@ -268,7 +269,7 @@ def retr_stats(feat, H, W, pos_tabs, rk, rbk, eps_k, rv, rbv, eps_v):
             raise ValueError("pos tables do not match (H, W)")
     rstd_k = torch.empty((T, HW), dtype=torch.float32, device=feat.device)
     rstd_v = torch.empty((T, HW), dtype=torch.float32, device=feat.device)
-    aux = torch.empty((T, HW, 32), dtype=torch.bfloat16, device=feat.device)
+    aux = torch.empty((T, HW, 32), dtype=torch.float16, device=feat.device)
     with _on(feat, ytab, xtab, rk, rbk, rv, rbv) as ctx:
         rc = lib.svps_retr_stats_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(rk), _ptr(rbk), float(eps_k), _ptr(rv), _ptr(rbv),
                                      float(eps_v), _ptr(rstd_k), _ptr(rstd_v), _ptr(aux), T, H, W, D, ctx.stream)
@@ -283,13 +284,13 @@ def retr_slot_pad(L):
 
 def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
     """K1': out_ext [T, L, 272] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
-    rstd_k (Q''.f + cy + cx) + c3. qh / ql [T, LP, 256] bf16, cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
+    rstd_k (Q''.f + cy + cx) + c3. qh / ql [T, LP, 256] fp16 (retr_split), cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
     padded to LP = 128 (L <= 128) or 256 (L <= 256; statistics kernel + two retriever launches)."""
     lib = _lib.load()
-    _need(qh, "qh", torch.bfloat16, 3)
-    _need(ql, "ql", torch.bfloat16, 3)
+    _need(qh, "qh", torch.float16, 3)
+    _need(ql, "ql", torch.float16, 3)
     _need(feat, "feat", torch.bfloat16, 3)
-    _need(aux, "aux", torch.bfloat16, 3)
+    _need(aux, "aux", torch.float16, 3)
     for name, x in (("cy", cy), ("cx", cx)):
         _need(x, name, torch.float32, 3)
     for name, x in (("c3", c3), ("rstd_k", rstd_k), ("rstd_v", rstd_v)):
@@ -330,10 +331,10 @@ def retr_query_prep(x, lnq_w, lnq_b, lnq_eps, lnk_w, lnk_b, bck, LP):
 
 
 def retr_split(q2):
-    """fp32 tensor -> (hi, lo) bf16 with hi + lo = q2 to a 16-bit mantissa."""
+    """fp32 tensor -> (hi, lo) fp16 with hi + lo = q2 to a 22-bit mantissa (the matrix-core operand pair of K1')."""
     lib = _lib.load()
     _need(q2, "q2", torch.float32)
-    hi = torch.empty(q2.shape, dtype=torch.bfloat16, device=q2.device)
+    hi = torch.empty(q2.shape, dtype=torch.float16, device=q2.device)
     lo = torch.empty_like(hi)
     with _on(q2) as ctx:
         _lib.check(lib.svps_retr_split(_ptr(q2), _ptr(hi), _ptr(lo), q2.numel(), ctx.stream), "svps_retr_split")
