@@ -266,12 +266,16 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  * slot side). The fused map is read once per kernel; nothing of size [HW, 256] is written.
  *
  * svps_retr_stats_fwd   (:432-433, the LayerNorm statistics only)
- *   feat  [T, HW, 256] bf16 fused map; pos_y [H, 128] / pos_x [W, 128] fp32 separable sine tables or NULL
- *   rk [256, 256] FP16, rv [256, 256] bf16: the UPPER-TRIANGULAR factor R of  [W~ | b~] = Q [R | r]  for to_k / to_v
- *       (host, float64 QR; the key side runs fp16 x fp16 on fp16(feat + pos): rstd_k needs the three extra mantissa bits);
+ *   feat  [T, HW, 256] bf16 fused map
+ *   rk, rv [256, 256] FP16: the UPPER-TRIANGULAR factor R of  [W~ | b~] = Q [R | r]  for to_k / to_v (host, float64 QR; the
+ *       kernel converts the map tile to fp16 in LDS - exact - and runs fp16 x fp16: rstd_k needs the three extra mantissa bits);
  *   rbk, rbv [256] fp32: the column r.   |R x + r|^2 = |W~ x + b~|^2 = 256 * var.
- *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] FP16 = {1, hi(1/rstd_v), lo(1/rstd_v), 0 x 5,
- *       rstd_k, rstd_v once more as raw fp32 (columns 8 .. 11), 0 x 20}: the 64-byte row svps_retr_attn_fwd stages with every pixel
+ *   ty [H, 256], tx [W, 256] fp32 or both NULL: the separable sine tables ALREADY multiplied by the key factor,
+ *       ty[y] = R_k[:, :128] pos_y[y], tx[x] = R_k[:, 128:] pos_x[x] (R_k (f + pos) = R_k f + ty[y] + tx[x]: the position term
+ *       enters the key accumulators in fp32 and never passes through 16 bits)
+ *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] 16-bit words, 64-byte rows of which the kernel writes
+ *       the first 16 bytes: {1, hi(1/rstd_v), lo(1/rstd_v), 0} FP16, {rstd_k, rstd_v} fp32 - the row svps_retr_attn_fwd stages with
+ *       every pixel (the other 48 bytes are never read as data)
  *
  * svps_retr_attn_fwd    (:435-456)
  *   The slot axis of the inputs is padded to LP = 128 rows (L <= 128) or 256 rows (L <= 256), rows >= L zero:
@@ -287,7 +291,7 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *   (+ [T, HW] x 8 B when L > 128: per-pixel softmax statistics over all slots, written by a first kernel; the retriever then
  *   runs once per half of the slots)
  * ------------------------------------------------------------------------------------------- */
-int svps_retr_stats_fwd(const void* feat, const float* pos_y, const float* pos_x, const void* rk, const float* rbk,
+int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                         float lnk_eps, const void* rv, const float* rbv, float lnv_eps, float* rstd_k, float* rstd_v,
                         void* aux, int T, int H, int W, int D, void* stream);
 size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int chunks);

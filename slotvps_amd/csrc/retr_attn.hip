@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const float* __restrict__ cx,       // [T, W, LP]    Q''[:, 128:256] . xtab[x]
     const float* __restrict__ c3g,      // [T, LP]  log2(e) * q . beta_k; -1e30 in the padded rows
     const __bf16* __restrict__ feat,    // [T, HW, 256]
-    const __bf16* __restrict__ aux,     // [T, HW, 32]   retr_stats.hip: {1, hi sigma_v, lo sigma_v, 0 x 5, rstd_k, rstd_v (fp32), 0 ...}
+    const __bf16* __restrict__ aux,     // [T, HW, 32]   retr_stats.hip: {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32), 48 bytes not written}
     float* __restrict__ partial,        // [T, C, Lrow, 264]
     int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off,
     const float2* __restrict__ ext_stats) {
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             const uint32_t tb = lane_row + slot * kTileBytes;
 #pragma unroll
             for (int u = 0; u < 4; ++u) kf0[u] = frag(tb, kOrd[u]);
-            // (rstd_k, rstd_v) of this lane's pixel: bytes 16 .. 23 of its aux row
-            rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + slot * kAuxTile + r * kAuxRow + 16));
+            // (rstd_k, rstd_v) of this lane's pixel: bytes 8 .. 15 of its aux row
+            rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + slot * kAuxTile + r * kAuxRow + 8));
         };
 
         // One iteration. CHAIN: tile `it` exists (MFMA chain + softmax head); P2: tile it-1 exists (softmax finish).
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         if (slot < L) {
 #pragma unroll
             for (int db = 0; db < 8; ++db) dst[(size_t)slot * kPartRow + 32 * db + r] = o[db][i];
-            if (r < 8) dst[(size_t)slot * kPartRow + 256 + r] = oa[i];
+            if (r < 4) dst[(size_t)slot * kPartRow + 256 + r] = oa[i];     // aux columns 0 .. 2 (column 3 is zero); the rest is not data
         }
     }
 }

@@ -10,43 +10,42 @@
 // side only rstd_k(p), rstd_v(p). This kernel produces them: 8 B per pixel instead of 1024 B.
 //
 //     var(p) = |W~ x_p + b~|^2 / 256 = |R x_p + r|^2 / 256,      [W~ | b~] = Q [R | r]  (QR, R upper triangular)
-// The host factorises once per weight (float64) and hands R as bf16: an upper-triangular 256 x 256 matrix has 36 of 64
+// The host factorises once per weight (float64) and hands R as FP16: an upper-triangular 256 x 256 matrix has 36 of 64
 // non-zero 32 x 32 blocks, so the statistics cost 56 % of the matrix work of the projection itself. Row blocks are paired
-// (j, 7 - j): 9 blocks = 18 v_mfma_f32_32x32x16_bf16 per wave and tile, weights resident in 72 VGPRs.
+// (j, 7 - j): 9 blocks = 18 v_mfma_f32_32x32x16_f16 per wave and tile, weights resident in 72 VGPRs.
 //
-// Output per pixel: rstd_k [T, HW] fp32, rstd_v [T, HW] fp32 and a 64-byte "aux" row of 32 FP16 (+ both rstd as raw fp32)
-//     { 1, hi(sigma_v), lo(sigma_v), 0 ... }            sigma_v = 1 / rstd_v
-// that the retriever appends to the value tile as a ninth 32-channel block: with A = P * rstd_v on the matrix cores its
-// columns accumulate s1 = sum_p P rstd_v and s0 = sum_p P (needed for the bias terms) at no vector-ALU cost.
+// The position term never meets the matrix cores. pos is separable (position_encoding.py:251-255) and R_k is linear:
+//     R_k (f_p + pos_p) + r_k = R_k f_p + Ty[y(p)] + Tx[x(p)] + r_k,     Ty = R_k[:, :128] ytab[y],  Tx = R_k[:, 128:] xtab[x]
+// two small fp32 tables per (stage, level geometry) that the host side computes once (float64 R_k, no rounding of f + pos).
+// They enter as the INITIAL value of the key accumulators. Tiles are 32 consecutive pixels of one image row, walked down a
+// 32-pixel-wide column strip (tile id = strip * H + row, the order retr_attn.hip uses), so Tx of a lane's pixel column sits
+// in registers for a whole strip and the per-tile position data is one 1-KiB row of Ty, staged by LDS-DMA with the tile.
 //
-// Mapping: 8 waves, two per SIMD. Waves 0-3 = key projection (operand bf16(f + pos), built in LDS by themselves for the
-// NEXT tile, double-buffered), waves 4-7 = value projection (operand = the feature tile as it arrives) and all LDS-DMA
-// (feature tiles three ahead in a 4-deep ring, position rows two ahead in a double buffer). One workgroup barrier per tile.
-// Precision. rstd_k multiplies logits of magnitude up to ~80 in front of a sharp softmax: it has to be good to ~1e-4, and
-// with bf16 operands it is not (measured 3e-4 mean / 1e-3 max relative, mostly the rounding of f + pos). The KEY side
-// therefore runs on v_mfma_f32_32x32x16_f16: R_k is handed over as fp16 and the operand is built as fp16(f + pos) - three
-// more mantissa bits on both operands at the same matrix rate (f is stored as bf16, so fp16(f) loses nothing unless
-// |f + pos| >= 65504, which overflows to inf and shows up as NaN downstream - fused maps are O(10)). rstd_v only scales the
-// contribution of its own pixel to a sum over thousands of pixels; the VALUE side stays bf16 x bf16 on the tile as it arrives
-// (1e-4 mean / 4e-4 max). Accumulation and everything after it is fp32.
+// Output per pixel: rstd_k [T, HW] fp32, rstd_v [T, HW] fp32 and a 64-byte "aux" row whose first 16 bytes are
+//     { 1, hi(sigma_v), lo(sigma_v), 0 } FP16, { rstd_k, rstd_v } fp32            sigma_v = 1 / rstd_v
+// (the other 48 bytes are not written). The retriever appends the row to the value tile as a ninth 32-channel block: with
+// A = P * rstd_v on the matrix cores its first three columns accumulate s1 = sum_p P rstd_v and s0 = sum_p P (needed for the
+// bias terms) at no vector-ALU cost, and its producers read the two fp32 words from the staged tile.
+//
+// Mapping: 8 waves, two per SIMD. Waves 0-3 = key projection, waves 4-7 = value projection and all LDS-DMA; BOTH read the
+// same operand: the feature tile converted bf16 -> fp16 in place by the wave that staged the piece (exact for
+// |f| in [6.1e-5, 65504]). Feature tiles four ahead in a 6-deep ring; one workgroup barrier per tile; the first fragment
+// group of the next tile is requested before the barrier.
+// Precision. rstd_k multiplies logits of magnitude up to ~80 in front of a sharp softmax: it has to be good to ~1e-4. The
+// operand f is exact, the position term is fp32, R_k / R_v carry 11 bits (fp16). Accumulation and everything after it is fp32.
 #include <cstdlib>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
 namespace svps {
 
-constexpr int kStNF = 4;                 // feature ring depth: f(it+3) is requested in iteration it
+constexpr int kStA = 3;                  // LDS-DMA distance: tile t+2+A is requested in the light phase of tile t
+constexpr int kStNF = kStA + 3;          // feature ring depth: tiles t .. t+2+A are live
 
 struct StatsPLds {
-    static constexpr int fring = 0;                                       // kStNF x 16 KiB
-    static constexpr int kXkRow = kRowBytes + 16;                          // key operand rows padded to 528 B (conflict-free, no swizzle)
-    static constexpr int kXkTile = kTilePx * kXkRow;
-    static constexpr int xk = kStNF * kTileBytes;                          // [2] key operand tiles
-    static constexpr int posx = xk + 2 * kXkTile;                          // [2][32 px][128] fp32 xtab rows (unaligned: [0] = ytab rows, [1] = xtab rows)
-    static constexpr int posy = posx + 2 * kTileBytes;                     // [2][256] fp32 (aligned tiles only)
-    static constexpr int posx_of(bool aligned, int tile) { return posx + (aligned ? (tile & 1) * kTileBytes : kTileBytes); }
-    static constexpr int posy_of(bool aligned, int tile) { return aligned ? posy + (tile & 1) * 1024 : posx; }
-    static constexpr int stats = posy + 2048;                              // [2 tiles][2 proj][4 waves][32 px] float
+    static constexpr int fring = 0;                                       // kStNF x 16 KiB (multiples of 512 B: fragment address XORs)
+    static constexpr int tyring = kStNF * kTileBytes;                     // kStNF x 1 KiB: Ty row of the tile's image row
+    static constexpr int stats = tyring + kStNF * 1024;                   // [2 tiles][2 proj][4 waves][32 px] float
     static constexpr int total = stats + 2 * 2 * 4 * 32 * 4;
 };
 
@@ -90,317 +89,335 @@ __device__ __forceinline__ void st_dma16x4(u32x4 srd, uint32_t lds_addr, int v0,
 }
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) __fp16 st_fp16x2;
 
 __device__ __forceinline__ float st_half_swap_add(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// ABL: timing-only ablations (env SVPS_STATS_ABLATE), outputs wrong. 1: no MFMA  2: no build of the key operand
-// 4: no position DMA  8: no feature DMA after the prologue  16: no finish (statistics combine + stores)
+#ifdef SVPS_STATS_STAMP
+// diagnostic build only (tools/retr_stamps.py --kernel stats): s_memtime stamps of one workgroup's key wave 0 and value wave 0
+__device__ unsigned long long stats_stamps[2][8][8];     // [key / value][iteration - 8][point]
+#define STATS_STAMP(pt)                                                                               \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && j == 0 && it >= 8 && it < 16 && lane == 0)          \
+            stats_stamps[proj][it - 8][pt] = __builtin_amdgcn_s_memtime();                            \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define STATS_STAMP(pt) do {} while (0)
+#endif
+
+// ABL: timing-only ablations (env SVPS_STATS_ABLATE), outputs wrong. 1: no MFMA  2: no conversion  8: no feature DMA after the
+// prologue  16: no finish (statistics combine + stores)
 template <bool HAS_POS, int PROJ, int J, int ABL = 0>
 __device__ __forceinline__ void retr_stats_role(
     const __bf16* __restrict__ feat,    // [T, HW, 256]
-    const float* __restrict__ pos_y,    // [H, 128] or null
-    const float* __restrict__ pos_x,    // [W, 128] or null
-    const __bf16* __restrict__ rk,      // [256, 256] FP16 bits, upper triangular (row = output row of R_k)
-    const __bf16* __restrict__ rv,      // [256, 256] bf16, upper triangular
+    const float* __restrict__ ty,       // [H, 256] R_k[:, :128] ytab[y] or null
+    const float* __restrict__ tx,       // [W, 256] R_k[:, 128:] xtab[x] or null
+    const _Float16* __restrict__ rk,    // [256, 256] fp16, upper triangular (row = output row of R_k)
+    const _Float16* __restrict__ rv,    // [256, 256] fp16, upper triangular
     const float* __restrict__ rbk,      // [256] r_k (the QR-transformed centred bias)
     const float* __restrict__ rbv,
     float eps_k, float eps_v,
     float* __restrict__ rstd_k,         // [T, HW]
     float* __restrict__ rstd_v,         // [T, HW]
-    __bf16* __restrict__ aux,           // [T, HW, 32]
-    int HW, int W, int tiles_per_chunk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* __restrict__ aux,           // [T, HW, 32] (16-bit words)
+    int HW, int H, int W, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = StatsPLds;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane = threadIdx.x & 63;
     constexpr int proj = PROJ, j = J;            // role of this wave: compile-time, so every fragment index below is static
     const int r = lane & 31, h = lane >> 5;
     const int t = blockIdx.y, c = blockIdx.x;
 
-    const int px_begin = c * tiles_per_chunk * kTilePx;
-    int px_end = px_begin + tiles_per_chunk * kTilePx;
-    px_end = px_end < HW ? px_end : HW;
-    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
-    if (nt <= 0) return;
+    const int tiles = ((W + kTilePx - 1) / kTilePx) * H;
+    const int tid0 = c * tiles_per_chunk;
+    int nt = tiles - tid0;
+    nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;
+    if (nt <= 0) return;                         // (whole workgroup: the grid never has such a chunk)
+    const int strip0 = tid0 / H, row0 = tid0 - strip0 * H;
 
     // ---- weights: row blocks j (column blocks j..7) and 7 - j (column blocks 7-j..7) as A fragments -----------------
     // block (rb, kb), k-step s in {0, 1}: lane (r, h) holds R[32 rb + r][32 kb + 16 s + 8 h .. + 8]
     constexpr int rb0 = j, rb1 = 7 - j;
     constexpr int NK0 = 2 * (8 - j), NK1 = 2 * (j + 1);       // k-steps of the two row blocks: 18 fragments in all
-    bf16x8 wf0[NK0], wf1[NK1];
+    f16x8 wf0[NK0], wf1[NK1];
     {
-        const __bf16* wsrc = proj ? rv : rk;
+        const _Float16* wsrc = proj ? rv : rk;
 #pragma unroll
         for (int i = 0; i < NK0; ++i)
-            wf0[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc + (size_t)(32 * rb0 + r) * kD + 32 * rb0 + 16 * i + 8 * h));
+            wf0[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wsrc + (size_t)(32 * rb0 + r) * kD + 32 * rb0 + 16 * i + 8 * h));
 #pragma unroll
         for (int i = 0; i < NK1; ++i)
-            wf1[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc + (size_t)(32 * rb1 + r) * kD + 32 * rb1 + 16 * i + 8 * h));
+            wf1[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wsrc + (size_t)(32 * rb1 + r) * kD + 32 * rb1 + 16 * i + 8 * h));
     }
-    // bias of this lane's accumulator rows (acc_row(4g + i, h) = 8g + 4h + i)
+    // constant part of this lane's accumulator rows (acc_row(4g + i, h) = 8g + 4h + i): the bias r, plus - key side - Tx of the
+    // lane's pixel column (reloaded when the chunk moves to the next strip)
+    // The loads are asm with their own vmcnt(0): a compiler-visible global load inside the main loop makes hipcc wait for
+    // vmcnt(0) before the accumulators are initialised in EVERY iteration, which drains the LDS-DMA ring each tile.
     f32x16 b0, b1;
-    {
-        const float* bsrc = proj ? rbv : rbk;
+    const u32x4 bsr = st_make_srd(proj ? rbv : rbk, kD * 4u);
+    const u32x4 txs = st_make_srd(tx, (HAS_POS && proj == 0) ? (uint32_t)W * 1024u : 0u);
+    auto ld16 = [](u32x4 srd, int off) {
+        f32x4 v;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(off), "s"(srd) : "memory");
+        return v;
+    };
+    auto load_base = [&](int strip) {
+        int xx = kTilePx * strip + r;
+        xx = xx < W ? xx : W - 1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(bsrc + 32 * rb0 + 8 * g + 4 * h);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(bsrc + 32 * rb1 + 8 * g + 4 * h);
+            f32x4 x0 = ld16(bsr, (32 * rb0 + 8 * g + 4 * h) * 4);
+            f32x4 x1 = ld16(bsr, (32 * rb1 + 8 * g + 4 * h) * 4);
+            if constexpr (HAS_POS && proj == 0) {
+                x0 += ld16(txs, (xx * kD + 32 * rb0 + 8 * g + 4 * h) * 4);
+                x1 += ld16(txs, (xx * kD + 32 * rb1 + 8 * g + 4 * h) * 4);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) { b0[4 * g + i] = x0[i]; b1[4 * g + i] = x1[i]; }
         }
-    }
+    };
+    load_base(strip0);
     wait_vm<0>();
 
     const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
     const u32x4 frs = st_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
-    // value wave j: four DMA pieces (8 pixel rows) of every feature tile
-    int voff[4];
+    const u32x4 tys = st_make_srd(ty, HAS_POS ? (uint32_t)H * 1024u : 0u);
+    // every wave stages (and converts) two DMA pieces = 4 pixel rows of every feature tile; the last wave the Ty row as well
+    constexpr int wv = 4 * proj + j;                            // wave number in the workgroup
+    int voff[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * j + 2 * i + h;
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * wv + 2 * i + h;
         voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
     }
-    auto stage_f = [&](int tile) {
+    constexpr bool kTyWave = HAS_POS && wv == 7;
+    constexpr int nb = 2 + (kTyWave ? 1 : 0);                   // DMA instructions of one batch of this wave
+    // stores of one finish() of this wave (they count in vmcnt too): value wave 0 writes the statistics of every tile
+    constexpr int nst = ((ABL & 16) || wv != 4) ? 0 : 2;
+    int ds = strip0, dy = row0;                                 // strip / image row of the next batch
+    auto stage = [&](int tile) {
         if (tile >= nt) return;
         if constexpr (ABL & 8) { if (tile >= kStNF) return; }
-        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (tile % kStNF) * kTileBytes + j * 4096);
-        const int px0 = px_begin + tile * kTilePx;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (tile % kStNF) * kTileBytes + wv * 2048);
+        const int px0 = dy * W + kTilePx * ds;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
         if (px0 + kTilePx <= HW) {
-            st_dma16x4(frs, st, voff[0], voff[1] - 1024, voff[2] - 2048, voff[3] - 3072, soff);
-        } else {                                       // ragged last tile of the frame: clamp the source rows
+            st_dma16(frs, st, voff[0], soff);
+            st_dma16(frs, st + 1024, voff[1], soff);
+        } else {                                       // last row of a ragged strip: clamp the source rows (their results are not stored)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 8 * j + 2 * i + h;
+            for (int i = 0; i < 2; ++i) {
+                const int row = 4 * wv + 2 * i + h;
                 const int src = px0 + row < HW ? row : HW - 1 - px0;
                 st_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
             }
         }
+        if constexpr (kTyWave)
+            st_dma16(tys, __builtin_amdgcn_readfirstlane(lds0 + Lds::tyring + (tile % kStNF) * 1024), lane * 16,
+                     __builtin_amdgcn_readfirstlane(dy * 1024));
+        ++dy;
+        if (dy == H) { dy = 0; ++ds; }
     };
-    const u32x4 ysrd = st_make_srd(pos_y, HAS_POS ? (uint32_t)((HW + W - 1) / W) * 512u : 0u);
-    const u32x4 xsrd = st_make_srd(pos_x, HAS_POS ? (uint32_t)W * 512u : 0u);
-    const bool aligned_rows = (W & 31) == 0;
-    // position rows of tile `tile`, by the value waves (always the same number of DMA instructions per wave: the counted
-    // waits below rely on it)
-    auto stage_pos = [&](int tile) {
-        if constexpr (!HAS_POS) return;
-        if constexpr (ABL & 4) return;
+    // this wave's two pieces of feature tile `tile`: bf16 -> fp16 in place
+    auto convert = [&](int tile) {
         if (tile >= nt) return;
-        const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::posy_of(aligned_rows, tile) + j * 4096);
-        const uint32_t sx = __builtin_amdgcn_readfirstlane(lds0 + Lds::posx_of(aligned_rows, tile) + j * 4096);
-        if (aligned_rows) {
-            const int px0 = px_begin + tile * kTilePx;
-            const int y0 = __builtin_amdgcn_readfirstlane(px0 / W), x0 = px0 - y0 * W;
-            if (j == 0) st_dma16(ysrd, __builtin_amdgcn_readfirstlane(lds0 + Lds::posy_of(true, tile)), lane * 16, y0 * 512);
-            const int v = j * 4096 + lane * 16;
-            st_dma16x4(xsrd, sx, v, v, v, v, __builtin_amdgcn_readfirstlane(x0 * 512));
-            return;
-        }
-        const int p = px_begin + tile * kTilePx + 8 * j + h;
-        const int yy = p / W, xx = p - yy * W;                 // rows past the image read zeros (buffer bounds)
-        int yo = yy * 512 + (lane & 31) * 16, xo = xx * 512 + (lane & 31) * 16;
-        const int xwrap = W * 512 + (lane & 31) * 16;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            st_dma16(ysrd, sy + i * 1024, yo, 0);
-            st_dma16(xsrd, sx + i * 1024, xo, 0);
-            xo += 1024;                                        // two pixels on; at most two row wraps (W == 1)
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                const bool wrap = xo >= xwrap;
-                xo = wrap ? xo - W * 512 : xo;
-                yo = wrap ? yo + 512 : yo;
-            }
-        }
-    };
-    const int pa = (aligned_rows || !HAS_POS) ? 2 : 1;                   // position rows: tiles ahead
-    const int npos = HAS_POS ? (aligned_rows ? (j == 0 ? 5 : 4) : 8) : 0;
-
-    // xk(tile) = bf16(f(tile) + pos(tile)) by the key waves, LDS only: thread -> 16-byte chunk cpos of pixel rows q + 8u
-    auto build_xk = [&](int tile) {
         if constexpr (ABL & 2) return;
-        int lt = tid;
-        asm volatile("" : "+v"(lt));
-        const int q = lt >> 5, cpos = lt & 31;
-        const int fe = Lds::fring + (tile % kStNF) * kTileBytes + q * kRowBytes + ((cpos ^ swz(q)) << 4);
-        const int fo = fe ^ 32;                                 // swz(8u + q) = swz(q) ^ (2 if u is odd)
-        const bool ypart = cpos < 16;
-        const int pb = (ypart ? Lds::posy_of(aligned_rows, tile) + (aligned_rows ? 0 : q * 512)
-                              : Lds::posx_of(aligned_rows, tile) + q * 512) + (cpos & 15) * 32;
-        const int ps = (ypart && aligned_rows) ? 0 : 8 * 512;
-        const int xo = Lds::xk + (tile & 1) * Lds::kXkTile + q * Lds::kXkRow + cpos * 16;
-        bf16x8 fv[4];
-        f32x4 pv[4][2];
+        const uint32_t st = lds0 + Lds::fring + (tile % kStNF) * kTileBytes + wv * 2048 + lane * 16;
+        u32x4 w_[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            fv[u] = *reinterpret_cast<const bf16x8*>(smem + ((u & 1) ? fo : fe) + u * 8 * kRowBytes);
-            if constexpr (HAS_POS) {
-                const char* pt = smem + pb + u * ps;
-                pv[u][0] = *reinterpret_cast<const f32x4*>(pt);
-                pv[u][1] = *reinterpret_cast<const f32x4*>(pt + 16);
-            } else {
-                pv[u][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                pv[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 2; ++i) w_[i] = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(st + i * 1024));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const st_fp16x2 pk = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w_[i][k] << 16), __uint_as_float(w_[i][k] & 0xffff0000u));
+                w_[i][k] = __builtin_bit_cast(uint32_t, pk);
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            f16x8 o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o[i] = (_Float16)((float)fv[u][i] + pv[u][0][i]);
-                o[4 + i] = (_Float16)((float)fv[u][4 + i] + pv[u][1][i]);
-            }
-            *reinterpret_cast<f16x8*>(smem + xo + u * 8 * Lds::kXkRow) = o;
+            *reinterpret_cast<SVPS_LDS u32x4*>((uintptr_t)(st + i * 1024)) = w_[i];
         }
     };
 
     float* stats = reinterpret_cast<float*>(smem + Lds::stats);          // [tile & 1][proj][wave j][px]
-    const float eps = proj ? eps_v : eps_k;
-    const u32x4 ksrd = st_make_srd(rstd_k + (size_t)t * HW, (uint32_t)px_end * 4u);
-    const u32x4 vsrd = st_make_srd(rstd_v + (size_t)t * HW, (uint32_t)px_end * 4u);
-    const u32x4 asrd = st_make_srd(aux + (size_t)t * HW * 32, (uint32_t)px_end * 64u);
+    const u32x4 asrd = st_make_srd(aux + (size_t)t * HW * 32, (uint32_t)HW * 64u);
 
-    // sum of squares of (R x + r) over this wave's 64 rows, per pixel
+    // fragments: LDS byte address of this lane's 16-B chunk of k-step ks = 8 a + b: (tile + lane_row) ^ (b << 5), + 256 a
+    const uint32_t lane_row = lds0 + Lds::fring + r * kRowBytes + ((h ^ swz(r)) << 4);
+    // k-steps 2j .. 15 for row block j; row block 7-j joins from k-step 2(7-j). Groups of four k-steps {4g .. 4g+3}, double-
+    // buffered: the reads of group g+1 are in flight under the MFMAs of group g; the first group of the NEXT tile is requested
+    // before the barrier
+    constexpr int G0 = (2 * j) / 4;                              // first group that holds a k-step >= 2j
+    f16x8 xf[3][4];                                              // ring of three groups: group g lives in xf[(g - G0) % 3]
+    auto frag = [&](uint32_t tb, int ks) {
+        return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
+    };
+    // the first two groups of a tile are requested in the preceding light phase (an LDS read takes 300 - 500 cycles to come
+    // back while the partner waves convert and stage)
+    auto prefetch = [&](int tile) {
+        const uint32_t tb = lane_row + (uint32_t)(tile % kStNF) * kTileBytes;
+#pragma unroll
+        for (int g = G0; g < (G0 + 2 < 4 ? G0 + 2 : 4); ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xf[(g - G0) % 3][u] = frag(tb, 4 * g + u);
+    };
+    int ts = strip0, tyy = row0;                                 // strip / image row of tile `it`
+
+    // sum of squares of (R x + r [+ Ty + Tx]) over this wave's 64 rows, per pixel
     auto heavy = [&](int it) {
-        constexpr bool padded = proj == 0;                     // key operand: the fp16 tile built by build_xk (padded rows)
-        const char* bt = padded ? smem + Lds::xk + (it & 1) * Lds::kXkTile : smem + Lds::fring + (it % kStNF) * kTileBytes;
-        int rr = r, hh = h;
-        asm volatile("" : "+v"(rr), "+v"(hh));
+        const uint32_t tb = lane_row + (uint32_t)(it % kStNF) * kTileBytes;
         f32x16 a0 = b0, a1 = b1;
-        int o8[8];
-        const int s4 = swz(rr);
+        // key side: the Ty row of the tile, requested now and added AFTER the MFMAs (nothing waits for it)
+        f32x4 y0[4], y1[4];
+        if constexpr (HAS_POS && proj == 0) {
+            const float* tyl = reinterpret_cast<const float*>(smem + Lds::tyring + (it % kStNF) * 1024);
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8)
-            o8[k8] = padded ? rr * Lds::kXkRow + ((2 * k8 + hh) << 4) : rr * kRowBytes + (((2 * k8 + hh) ^ s4) << 4);
-        auto frag = [&](int ks) { return *reinterpret_cast<const bf16x8*>(bt + o8[ks & 7] + (ks >> 3) * 256); };
-        // k-steps 2j .. 15 for row block j; row block 7-j joins from k-step 2(7-j). Fragments in groups of four, double-
-        // buffered: the reads of group g+1 are in flight under the MFMAs of group g (no exposed LDS latency after the first)
-        constexpr int G0 = (2 * j) / 4;                          // first group that holds a k-step >= 2j
-        bf16x8 xf[2][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xf[G0 & 1][u] = frag(4 * G0 + u);
+            for (int g = 0; g < 4; ++g) {
+                y0[g] = *reinterpret_cast<const f32x4*>(tyl + 32 * rb0 + 8 * g + 4 * h);
+                y1[g] = *reinterpret_cast<const f32x4*>(tyl + 32 * rb1 + 8 * g + 4 * h);
+            }
+        }
 #pragma unroll
         for (int grp = G0; grp < 4; ++grp) {
-            if (grp < 3) {
+            if (grp + 2 < 4) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xf[(grp + 1) & 1][u] = frag(4 * (grp + 1) + u);
+                for (int u = 0; u < 4; ++u) xf[(grp + 2 - G0) % 3][u] = frag(tb, 4 * (grp + 2) + u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ks = 4 * grp + u;
                 if constexpr (ABL & 1) continue;
-                if constexpr (proj == 0) {                      // key side: fp16 x fp16
-                    const f16x8 xh = __builtin_bit_cast(f16x8, xf[grp & 1][u]);
-                    if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0]), xh, a0, 0, 0, 0);
-                    if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0]), xh, a1, 0, 0, 0);
-                } else {
-                    if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0], xf[grp & 1][u], a0, 0, 0, 0);
-                    if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0], xf[grp & 1][u], a1, 0, 0, 0);
-                }
+                if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0], xf[(grp - G0) % 3][u], a0, 0, 0, 0);
+                if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0], xf[(grp - G0) % 3][u], a1, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        float s2 = 0.f;
+        STATS_STAMP(6);
+        if constexpr (HAS_POS && proj == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s2 = fmaf(a0[i], a0[i], s2);
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s2 = fmaf(a1[i], a1[i], s2);
-        s2 = st_half_swap_add(s2);
-        if (hh == 0) stats[(((it & 1) * 2 + proj) * 4 + j) * 32 + rr] = s2;
+                for (int i = 0; i < 4; ++i) { a0[4 * g + i] += y0[g][i]; a1[4 * g + i] += y1[g][i]; }
+        }
+        float s2[4] = {0.f, 0.f, 0.f, 0.f};                       // four independent chains
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s2[i & 1] = fmaf(a0[i], a0[i], s2[i & 1]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s2[2 + (i & 1)] = fmaf(a1[i], a1[i], s2[2 + (i & 1)]);
+        const float tot = st_half_swap_add((s2[0] + s2[1]) + (s2[2] + s2[3]));
+        if (h == 0) stats[(((it & 1) * 2 + proj) * 4 + j) * 32 + r] = tot;
     };
 
-    // statistics of tile `it` -> HBM, by wave 0 of each projection (after the barrier that follows heavy(it))
+    // statistics of tile `it` -> HBM, by value wave 0 in its light phase: two store instructions per tile.
+    //   lanes h == 0: rstd_k[px] and the 16 meaningful bytes of the aux row {1, hi sigma_v, lo sigma_v, 0 (fp16) | rstd_k, rstd_v (fp32)}
+    //   lanes h == 1: rstd_v[px]
+    // The other 48 bytes of an aux row are never written: as matrix-core columns they only reach accumulator columns nobody reads.
+    int fs = strip0, fy = row0;
+    const uint64_t rk_base = reinterpret_cast<uint64_t>(rstd_k + (size_t)t * HW), rv_base = reinterpret_cast<uint64_t>(rstd_v + (size_t)t * HW);
+    const uint64_t aux_dummy = reinterpret_cast<uint64_t>(aux + (size_t)t * HW * 32) + 32;
     auto finish = [&](int it) {
-        if (j != 0) return;
+        const int strip = fs, row = fy;
+        if (it >= 0) {
+            ++fy;
+            if (fy == H) { fy = 0; ++fs; }
+        }
+        if constexpr (wv != 4) return;
         if constexpr (ABL & 16) return;
-        const float* sp = stats + ((it & 1) * 2 + proj) * 4 * 32 + r;
-        const float tot = (sp[0] + sp[32]) + (sp[64] + sp[96]);
-        const float sigma = sqrtf(tot * (1.f / kD) + eps);
-        const float rstd = 1.f / sigma;
-        const int px = px_begin + it * kTilePx + r;
-        const bool mine = h == 0 && px < px_end;
-        const int off = mine ? px * 4 : 0x7ffffff0;                      // out of range -> dropped by the hardware range check
-        asm volatile("buffer_store_dword %0, %1, %2, 0 offen" : : "v"(rstd), "v"(off), "s"(proj ? vsrd : ksrd) : "memory");
-        if (proj) {
-            // aux row (FP16): lanes h == 0 store bytes [0, 32) = {1, hi, lo, 0 x 5 | rstd_k, rstd_v as raw fp32, 0 x 4}, lanes h == 1
-            // bytes [32, 64) = zeros. Columns 0 .. 2 are the ninth channel block of K1' (s1 / s0 sums); the two fp32 words in
-            // columns 8 .. 11 are what K1's producers read from the staged tile instead of two more global loads per tile
-            // (as 16-bit columns they are garbage that only reaches accumulator columns nobody stores).
-            const _Float16 sh = (_Float16)sigma;                                 // FP16 hi + lo (K1' runs its value side in fp16)
-            const _Float16 sl = (_Float16)(sigma - (float)sh);
-            const _Float16 one = (_Float16)1.0f;
-            const uint32_t w0 = (uint32_t)__builtin_bit_cast(uint16_t, one) | ((uint32_t)__builtin_bit_cast(uint16_t, sh) << 16);
-            const uint32_t w1 = (uint32_t)__builtin_bit_cast(uint16_t, sl);
-            const float* spk = stats + ((it & 1) * 2 + 0) * 4 * 32 + r;          // the key side's sums of the same tile
-            const float totk = (spk[0] + spk[32]) + (spk[64] + spk[96]);
-            const float rstdk = 1.f / sqrtf(totk * (1.f / kD) + eps_k);          // bit-identical to the key wave's own value
-            u32x4 lo = {h == 0 ? w0 : 0u, h == 0 ? w1 : 0u, 0u, 0u};
-            const u32x4 z = {h == 0 ? __float_as_uint(rstdk) : 0u, h == 0 ? __float_as_uint(rstd) : 0u, 0u, 0u};
-            const int aoff = px < px_end ? px * 64 + h * 32 : 0x7ffffff0;
-            asm volatile("buffer_store_dwordx4 %0, %2, %3, 0 offen\n\ts_nop 1\n\t"
-                         "buffer_store_dwordx4 %1, %2, %3, 0 offen offset:16\n\ts_nop 1"
-                         : : "v"(lo), "v"(z), "v"(aoff), "s"(asrd) : "memory");
+        const int xx = kTilePx * strip + r;
+        const int px = row * W + xx;
+        const bool valid = xx < W && it >= 0;                            // pixels past the right edge of the map: not stored
+        const float* spk = stats + ((it & 1) * 2 + 0) * 4 * 32 + r;
+        const float* spv = stats + ((it & 1) * 2 + 1) * 4 * 32 + r;
+        const float totk = (spk[0] + spk[32]) + (spk[64] + spk[96]);
+        const float totv = (spv[0] + spv[32]) + (spv[64] + spv[96]);
+        // v_rsq_f32 (1 ulp) instead of sqrt + divide: lanes h == 0 need rstd_k and both value terms, lanes h == 1 rstd_v
+        const float vark = totk * (1.f / kD) + eps_k, varv = totv * (1.f / kD) + eps_v;
+        const float rstdk = __builtin_amdgcn_rsqf(vark);
+        const float rstdv = __builtin_amdgcn_rsqf(varv);
+        const float sigma = varv * rstdv;
+        {   // one store instruction for both arrays (per-lane 64-bit addresses); lanes without a pixel write into the unwritten
+            // part of this frame's first aux row, so that the instruction is ALWAYS issued: the counted vmcnt waits rely on it
+            const uint64_t a = valid ? (h ? rv_base : rk_base) + (uint64_t)px * 4u : aux_dummy;
+            const float val = h ? rstdv : rstdk;
+            asm volatile("global_store_dword %0, %1, off" : : "v"(a), "v"(val) : "memory");
+        }
+        const _Float16 sh = (_Float16)sigma;                                     // FP16 hi + lo (K1' runs its value side in fp16)
+        const _Float16 sl = (_Float16)(sigma - (float)sh);
+        const _Float16 one = (_Float16)1.0f;
+        const uint32_t w0 = (uint32_t)__builtin_bit_cast(uint16_t, one) | ((uint32_t)__builtin_bit_cast(uint16_t, sh) << 16);
+        const uint32_t w1 = (uint32_t)__builtin_bit_cast(uint16_t, sl);
+        const u32x4 row16 = {w0, w1, __float_as_uint(rstdk), __float_as_uint(rstdv)};
+        const int aoff = (valid && h == 0) ? px * 64 : 0x7ffffff0;           // out of range -> dropped by the hardware range check
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(row16), "v"(aoff), "s"(asrd) : "memory");
+    };
+
+    // ---- ping-pong schedule: two barriers per tile ---------------------------------------------------------------------
+    //   half-period 2t  : KEY waves   heavy(t)   (fragments + 18 MFMA + sum of squares), alone on their SIMD's matrix pipe
+    //                     VALUE waves light(t)   (own pieces of tile t+1 landed -> fp16, request tile t+2+A, first fragments of tile t)
+    //   half-period 2t+1: VALUE waves heavy(t);   KEY waves light(t) (own pieces of tile t+2 -> fp16, request tile t+2+A, wave 0:
+    //                     statistics of tile t-1 -> HBM, first fragments of tile t+1)
+    // A tile is read first by the key waves in half-period 2 * tile: the value waves converted their pieces two half-periods
+    // before, the key waves three (one tile earlier than strictly needed, so that nobody converts a tile while a key wave
+    // already requests its fragments).
+    auto light = [&](int t) {
+        constexpr int ahead = proj ? 1 : 2;                      // tile t + ahead: this wave's pieces must be fp16 now
+        // landed by now: batch t+ahead - everything except the batches requested after it and the finish() stores issued
+        // after it (value wave 0: two per light phase). Steady state: a constant; first / last tiles: everything.
+        constexpr int maxy = kStA + 1 - ahead;
+        if (t >= maxy + 1 && t + ahead + maxy <= nt - 1) wait_vm<nb * maxy + nst * (maxy + 1)>();
+        else wait_vm<0>();
+        convert(t + ahead);
+        stage(t + 2 + kStA);
+        if constexpr (proj == 0) {
+            ++tyy;
+            if (tyy == H) { tyy = 0; ++ts; if (t + 1 < nt) load_base(ts); }
+            if (t + 1 < nt) prefetch(t + 1);
+        } else {
+            prefetch(t);
+            finish(t - 1);                                       // (t == 0: dummy stores outside the data, same vmcnt count)
         }
     };
-
-    // ---- prologue ---------------------------------------------------------------------------------------------------
-    if (proj) {
-        stage_pos(0);
-        if (pa == 2) stage_pos(1);
-        stage_f(0);
-        stage_f(1);
-        stage_f(2);
-        wait_vm_dyn(4 * ((1 < nt) + (2 < nt)));                 // f(0) and the position rows before it have landed
+    // prologue: batches 0 .. A+1 in flight; tile 0 (key waves: and tile 1) landed and converted before the first barrier
+#pragma unroll
+    for (int b = 0; b < kStA + 2; ++b) stage(b);
+    {
+        int younger = nt - 1 - (proj ? 0 : 1);
+        const int maxy = kStA + 1 - (proj ? 0 : 1);
+        younger = younger < 0 ? 0 : (younger > maxy ? maxy : younger);
+        wait_vm_dyn(nb * younger);
+        convert(0);
+        if constexpr (proj == 0) convert(1);
     }
     wg_barrier();
-    if (!proj) build_xk(0);
-
-    // ---- main loop: one barrier per tile --------------------------------------------------------------------------
-    //   B(it): xk(it) is built; f(it), f(it+1), pos(it+1) have landed; statistics of tile it-1 are in LDS
-    for (int it = 0; it < nt; ++it) {
-        if (proj) {
-            // landed by now: everything except the feature tile requested last (f(it+2), issued in iteration it-1)
-            if constexpr (ABL & 8) wait_vm<0>();
-            else wait_vm_dyn(it + 2 < nt ? 4 : 0);
-        }
-        wg_barrier();
-        if (it >= 1) finish(it - 1);
-        if (proj) {
-            if (pa == 2) stage_pos(it + 2);
-            else stage_pos(it + 1);
-            stage_f(it + 3);
-            if (pa == 1) {                                      // position rows requested one tile ahead: wait for them now
-                wait_vm_dyn(it + 3 < nt ? 4 : 0);               // (unaligned widths: the small levels and the tests)
-            }
-            heavy(it);
-        } else {
-            heavy(it);
-        }
-        if (!proj && it + 1 < nt) {
-            if (pa == 1) wg_barrier();                          // unaligned: pos(it+1) was requested in this iteration
-            build_xk(it + 1);
-        } else if (pa == 1 && it + 1 < nt) {
-            wg_barrier();
-        }
+    if constexpr (proj == 0) prefetch(0);
+    for (int t = 0; t < nt; ++t) {
+        [[maybe_unused]] const int it = t;
+        STATS_STAMP(0);
+        wg_barrier();                                            // start of half-period 2t
+        STATS_STAMP(1);
+        if constexpr (proj == 0) heavy(t); else light(t);
+        STATS_STAMP(2);
+        wg_barrier();                                            // start of half-period 2t+1
+        STATS_STAMP(3);
+        if constexpr (proj == 0) light(t); else heavy(t);
+        STATS_STAMP(7);
     }
     wg_barrier();
     finish(nt - 1);
-    (void)npos;
 }
 
 template <bool HAS_POS, int ABL = 0>
 __global__ __launch_bounds__(512) void retr_stats_kernel(
-    const __bf16* __restrict__ feat, const float* __restrict__ pos_y, const float* __restrict__ pos_x,
-    const __bf16* __restrict__ rk, const __bf16* __restrict__ rv, const float* __restrict__ rbk, const float* __restrict__ rbv,
+    const __bf16* __restrict__ feat, const float* __restrict__ ty, const float* __restrict__ tx,
+    const _Float16* __restrict__ rk, const _Float16* __restrict__ rv, const float* __restrict__ rbk, const float* __restrict__ rbv,
     float eps_k, float eps_v, float* __restrict__ rstd_k, float* __restrict__ rstd_v, __bf16* __restrict__ aux,
-    int HW, int W, int tiles_per_chunk) {
+    int HW, int H, int W, int tiles_per_chunk) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#define SVPS_ROLE(P, JJ) retr_stats_role<HAS_POS, P, JJ, ABL>(feat, pos_y, pos_x, rk, rv, rbk, rbv, eps_k, eps_v, rstd_k, rstd_v, aux, HW, W, tiles_per_chunk)
+#define SVPS_ROLE(P, JJ) retr_stats_role<HAS_POS, P, JJ, ABL>(feat, ty, tx, rk, rv, rbk, rbv, eps_k, eps_v, rstd_k, rstd_v, aux, HW, H, W, tiles_per_chunk)
     switch (w) {                 // every role runs the same sequence of workgroup barriers
         case 0: SVPS_ROLE(0, 0); break;
         case 1: SVPS_ROLE(0, 1); break;
@@ -416,20 +433,20 @@ __global__ __launch_bounds__(512) void retr_stats_kernel(
 
 }  // namespace svps
 
-extern "C" int svps_retr_stats_fwd(const void* feat, const float* pos_y, const float* pos_x, const void* rk, const float* rbk,
+extern "C" int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                                    float lnk_eps, const void* rv, const float* rbv, float lnv_eps, float* rstd_k, float* rstd_v,
                                    void* aux, int T, int H, int W, int D, void* stream_) {
     if (!feat || !rk || !rbk || !rv || !rbv || !rstd_k || !rstd_v || !aux) return SVPS_ERR_BAD_ARG;
-    if ((pos_y == nullptr) != (pos_x == nullptr)) return SVPS_ERR_BAD_ARG;
+    if ((ty == nullptr) != (tx == nullptr)) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     const int HW = H * W;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+    const int tiles = ((W + svps::kTilePx - 1) / svps::kTilePx) * H;
     int chunks = svps_pick_chunks(T, tiles, svps_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
-    const bool has_pos = pos_y != nullptr;
+    const bool has_pos = ty != nullptr;
     auto kern = has_pos ? svps::retr_stats_kernel<true> : svps::retr_stats_kernel<false>;
     int slot = has_pos;
 #ifdef SVPS_STATS_ABLATE
@@ -438,23 +455,28 @@ extern "C" int svps_retr_stats_fwd(const void* feat, const float* pos_y, const f
         switch (abl) {
             case 1: kern = svps::retr_stats_kernel<true, 1>; slot = 2; break;
             case 2: kern = svps::retr_stats_kernel<true, 2>; slot = 3; break;
-            case 4: kern = svps::retr_stats_kernel<true, 4>; slot = 4; break;
-            case 6: kern = svps::retr_stats_kernel<true, 6>; slot = 5; break;
-            case 8: kern = svps::retr_stats_kernel<true, 8>; slot = 6; break;
-            case 16: kern = svps::retr_stats_kernel<true, 16>; slot = 7; break;
-            case 7: kern = svps::retr_stats_kernel<true, 7>; slot = 8; break;
-            case 14: kern = svps::retr_stats_kernel<true, 14>; slot = 9; break;
+            case 8: kern = svps::retr_stats_kernel<true, 8>; slot = 4; break;
+            case 16: kern = svps::retr_stats_kernel<true, 16>; slot = 5; break;
+            case 3: kern = svps::retr_stats_kernel<true, 3>; slot = 6; break;
+            case 11: kern = svps::retr_stats_kernel<true, 11>; slot = 7; break;
+            case 27: kern = svps::retr_stats_kernel<true, 27>; slot = 8; break;
             default: break;
         }
     }
 #endif
-    static SvpsLdsAttr attr[10];
+    static SvpsLdsAttr attr[9];
     if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::StatsPLds::total); ae != hipSuccess)
         return (int)ae;
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::StatsPLds::total, stream, static_cast<const __bf16*>(feat),
-                       pos_y, pos_x, static_cast<const __bf16*>(rk), static_cast<const __bf16*>(rv), rbk, rbv, lnk_eps, lnv_eps,
-                       rstd_k, rstd_v, static_cast<__bf16*>(aux), HW, W, tpc);
+                       ty, tx, static_cast<const _Float16*>(rk), static_cast<const _Float16*>(rv), rbk, rbv, lnk_eps, lnv_eps,
+                       rstd_k, rstd_v, static_cast<__bf16*>(aux), HW, H, W, tpc);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);
     return (int)hipGetLastError();
 }
+
+#ifdef SVPS_STATS_STAMP
+extern "C" int svps_stats_debug_read(unsigned long long* stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::stats_stamps), sizeof(unsigned long long) * 2 * 8 * 8);
+}
+#endif

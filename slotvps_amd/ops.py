@@ -244,29 +244,30 @@ def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=No
 
 
 # ---- statistics-fused retriever (csrc/retr_stats.hip, csrc/retr_attn.hip) -------------------------------------------
-def retr_stats(feat, H, W, pos_tabs, rk, rbk, eps_k, rv, rbv, eps_v):
+def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     """K3': per-pixel reciprocal standard deviations of the key / value LayerNorms (+ the aux rows K1' consumes).
-    feat [T, H*W, 256] bf16; rk [256, 256] fp16 / rv [256, 256] bf16: upper-triangular QR factors of the centred
-    projections; rbk / rbv [256] fp32. Returns rstd_k [T, HW], rstd_v [T, HW] fp32, aux [T, HW, 32] fp16 (64-byte rows:
+    feat [T, H*W, 256] bf16; rk / rv [256, 256] fp16: upper-triangular QR factors of the centred projections; rbk / rbv [256]
+    fp32; pos_proj = (Ty [H, 256], Tx [W, 256]) fp32, the position tables already multiplied by the key factor
+    (MaskDynamicConv.retr_pos_tables), or None. Returns rstd_k [T, HW], rstd_v [T, HW] fp32, aux [T, HW, 32] fp16 (64-byte rows:
     {1, hi sigma_v, lo sigma_v, 0 x 5, rstd_k and rstd_v as raw fp32, 0 ...})."""
     lib = _lib.load()
     _need(feat, "feat", torch.bfloat16, 3)
     T, HW, D = feat.shape
     if HW != H * W:
         raise ValueError("feat rows != H*W")
-    _need(rk, "rk", torch.float16, 2)           # key factor fp16, value factor bf16 (see the kernel header)
-    _need(rv, "rv", torch.bfloat16, 2)
+    _need(rk, "rk", torch.float16, 2)
+    _need(rv, "rv", torch.float16, 2)
     if rk.shape != (D, D) or rv.shape != (D, D):
         raise ValueError("rk / rv must be [256, 256]")
     _need(rbk, "rbk", torch.float32, 1)
     _need(rbv, "rbv", torch.float32, 1)
     ytab = xtab = None
-    if pos_tabs is not None:
-        ytab, xtab = pos_tabs
-        _need(ytab, "pos_y", torch.float32, 2)
-        _need(xtab, "pos_x", torch.float32, 2)
-        if ytab.shape != (H, D // 2) or xtab.shape != (W, D // 2):
-            raise ValueError("pos tables do not match (H, W)")
+    if pos_proj is not None:
+        ytab, xtab = pos_proj
+        _need(ytab, "ty", torch.float32, 2)
+        _need(xtab, "tx", torch.float32, 2)
+        if ytab.shape != (H, D) or xtab.shape != (W, D):
+            raise ValueError("projected position tables do not match (H, W)")
     rstd_k = torch.empty((T, HW), dtype=torch.float32, device=feat.device)
     rstd_v = torch.empty((T, HW), dtype=torch.float32, device=feat.device)
     aux = torch.empty((T, HW, 32), dtype=torch.float16, device=feat.device)

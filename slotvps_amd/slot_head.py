@@ -146,9 +146,12 @@ class MaskDynamicConv(nn.Module):
                 wc = w - w.mean(dim=0, keepdim=True)                    # subtract the mean over OUTPUT channels (rows)
                 bc = b - b.mean()
                 r = torch.linalg.qr(torch.cat([wc, bc[:, None]], dim=1), mode="r").R          # [256, 257] upper trapezoidal
-                # key factor as fp16, value factor as bf16 (csrc/retr_stats.hip, "Precision")
-                out["r" + name] = torch.triu(r[:, :256]).to(dev).to(torch.float16 if name == "k" else BF16).contiguous()
+                # both factors as fp16 (csrc/retr_stats.hip, "Precision"); the float64 key factor stays on the host for the
+                # position tables of retr_pos_tables()
+                out["r" + name] = torch.triu(r[:, :256]).to(dev).to(torch.float16).contiguous()
                 out["rb" + name] = r[:, 256].float().to(dev).contiguous()
+                if name == "k":
+                    out["rk64"] = torch.triu(r[:, :256])
                 out["wc" + name], out["bc" + name] = wc, bc
             out["wck"] = out["wck"].float().to(dev).contiguous()                               # Q'' = (q * gamma_k) @ W~_k
             out["bck"] = out["bck"].float().to(dev).contiguous()
@@ -163,6 +166,23 @@ class MaskDynamicConv(nn.Module):
             return out
         return _cached(self, "fused", srcs, build)
 
+    def retr_pos_tables(self, pos_tabs):
+        """Position term of the key statistics as two fp32 tables (csrc/retr_stats.hip): Ty [H, 256] = ytab R_k[:, :128]^T,
+        Tx [W, 256] = xtab R_k[:, 128:]^T, R_k the float64 QR factor. Derived once per (weights, level geometry)."""
+        if pos_tabs is None:
+            return None
+        c = self._fused_consts()
+        ytab, xtab = pos_tabs
+        cache = c.setdefault("pos_tables", {})
+        key = (ytab.data_ptr(), xtab.data_ptr(), tuple(ytab.shape), tuple(xtab.shape))
+        if key not in cache:
+            rk = c["rk64"]
+            half = rk.shape[1] // 2
+            ty = ytab.detach().double().cpu() @ rk[:, :half].t()
+            tx = xtab.detach().double().cpu() @ rk[:, half:].t()
+            cache[key] = (ty.float().to(ytab.device).contiguous(), tx.float().to(xtab.device).contiguous(), ytab, xtab)
+        return cache[key][:2]
+
     def forward_fused(self, slots, feat_pm, hw, pos_tabs, stats=None):
         """K3' + K1' (csrc/retr_stats.hip, csrc/retr_attn.hip): slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16.
         `stats` = (rstd_k, rstd_v, aux) if already computed for this (map, stage)."""
@@ -170,7 +190,8 @@ class MaskDynamicConv(nn.Module):
         T, L, C = slots.shape
         H, W = hw
         if stats is None:
-            stats = ops.retr_stats(feat_pm, H, W, pos_tabs, c["rk"], c["rbk"], self.norm_k.eps, c["rv"], c["rbv"], self.norm_v.eps)
+            stats = ops.retr_stats(feat_pm, H, W, self.retr_pos_tables(pos_tabs), c["rk"], c["rbk"], self.norm_k.eps, c["rv"], c["rbv"],
+                                   self.norm_v.eps)
         LP = ops.retr_slot_pad(L)
         # :431 q = norm_q(to_q(slots)); g = q * gamma_k (zero rows up to LP), c3 = q . beta_k, a1 = g . b~_k: one launch
         gp, c3, a1 = ops.retr_query_prep(fast_linear(self, "to_q", slots, self.to_q.weight, self.to_q.bias), self.norm_q.weight,

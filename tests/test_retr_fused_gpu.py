@@ -45,7 +45,7 @@ def test_retr_stats(cuda, T, H, W, pos):
     feat = orc.round_bf16(rng.standard_normal((T, HW, 256)).astype(np.float32))
     c = m._fused_consts()
     tabs = ops.pos_embed_sine_tables(H, W, 256, cuda) if pos else None
-    rk, rv, aux = ops.retr_stats(to_bf16_t(feat, cuda), H, W, tabs, c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
+    rk, rv, aux = ops.retr_stats(to_bf16_t(feat, cuda), H, W, m.retr_pos_tables(tabs), c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
     torch.cuda.synchronize()
     aux_raw = aux.cpu().view(torch.int16).numpy().view(np.uint16)               # [T, HW, 32] bf16 bit patterns
     rk, rv, aux = rk.cpu().numpy(), rv.cpu().numpy(), aux.float().cpu().numpy()
@@ -63,9 +63,9 @@ def test_retr_stats(cuda, T, H, W, pos):
             print(f"rstd rel err max {rel.max():.2e} mean {rel.mean():.2e} (bound {bound:.1e})")
             assert rel.max() <= bound, rel.max()
         sig = 1.0 / rv[t].astype(np.float64)
-        assert np.all(aux[t][:, 0] == 1.0) and np.all(aux[t][:, 3:8] == 0.0) and np.all(aux_raw[t][:, 12:] == 0)
-        # columns 8 .. 11 of the row: rstd_k, rstd_v as raw fp32 (what K1's producers read from the staged tile)
-        packed = np.ascontiguousarray(aux_raw[t][:, 8:12]).view(np.float32)
+        assert np.all(aux[t][:, 0] == 1.0) and np.all(aux[t][:, 3] == 0.0)
+        # bytes 8 .. 15 of the row: rstd_k, rstd_v as raw fp32 (what K1's producers read from the staged tile); bytes 16 .. 63 unwritten
+        packed = np.ascontiguousarray(aux_raw[t][:, 4:8]).view(np.float32)
         assert np.array_equal(packed[:, 0], rk[t]) and np.array_equal(packed[:, 1], rv[t])
         assert np.abs(aux[t][:, 1].astype(np.float64) + aux[t][:, 2] - sig).max() <= 3e-5 * sig.max()   # hi + lo: 16-bit mantissa
 
@@ -118,7 +118,7 @@ def test_full_size_sum_over_slots_properties(cuda, name, T, H, W, L):
     tabs = ops.pos_embed_sine_tables(H, W, 256, cuda)
     c = m._fused_consts()
     with torch.no_grad():
-        st = ops.retr_stats(feat, H, W, tabs, c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
+        st = ops.retr_stats(feat, H, W, m.retr_pos_tables(tabs), c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
         q = ops.row_ln(m.to_q(slots), m.norm_q.weight, m.norm_q.bias, m.norm_q.eps)
         # the inputs of K1' exactly as MaskDynamicConv.forward_fused prepares them
         got = {}

@@ -30,7 +30,7 @@ c = m._fused_consts()
 
 def once():
     with torch.no_grad():
-        st = ops.retr_stats(feat, a.H, a.W, tabs, c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
+        st = ops.retr_stats(feat, a.H, a.W, m.retr_pos_tables(tabs), c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
         return m.forward_fused(slots, feat, (a.H, a.W), tabs, stats=st)
 
 

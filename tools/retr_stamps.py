@@ -23,7 +23,7 @@ slots = torch.randn((a.T, a.L, 256), device=dev)
 tabs = ops.pos_embed_sine_tables(a.H, a.W, 256, dev)
 c = m._fused_consts()
 with torch.no_grad():
-    st = ops.retr_stats(feat, a.H, a.W, tabs, c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
+    st = ops.retr_stats(feat, a.H, a.W, m.retr_pos_tables(tabs), c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
     fn = lambda: m.forward_fused(slots, feat, (a.H, a.W), tabs, stats=st)
     t0 = time.time()
     while time.time() - t0 < a.warm_s:                       # >= 2 s of back-to-back launches on random data
@@ -56,3 +56,20 @@ for role in (0, 1):
         print(f"it {it + 8}: " + "  ".join(f"{names[role][k]} +{d[i]}" for i, k in enumerate(order[role])))
 per = (stamps[0, 7, 0].astype(np.int64) - stamps[0, 1, 0].astype(np.int64)) / 6
 print("cycles per tile (producer 0):", per)
+
+# ---- K3' (retr_stats): key wave 0 and value wave 0 of one workgroup
+sst = np.zeros((2, 8, 8), dtype=np.uint64)
+lib.svps_stats_debug_read.argtypes = [ctypes.c_void_p]
+if lib.svps_stats_debug_read(sst.ctypes.data_as(ctypes.c_void_p)) == 0:
+    snames = {0: "loop top", 1: "barrier A done", 2: "first phase (key: heavy, value: light)", 3: "barrier B done",
+              7: "second phase (key: light, value: heavy)"}
+    for role in (0, 1):
+        sorder = [0, 1, 2, 3, 7]
+        print("--- K3' key wave 0" if role == 0 else "--- K3' value wave 0")
+        for it in range(1, 5):
+            row = sst[role, it, sorder].astype(np.int64)
+            if not row.all():
+                continue
+            d = np.diff(np.concatenate([[sst[role, it - 1, 7].astype(np.int64)], row]))
+            print(f"it {it + 8}: " + "  ".join(f"{snames[k]} +{d[i]}" for i, k in enumerate(sorder)))
+    print("cycles per tile (K3' key wave 0):", (sst[0, 7, 0].astype(np.int64) - sst[0, 1, 0].astype(np.int64)) / 6)
