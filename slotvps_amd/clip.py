@@ -160,11 +160,13 @@ class SlotClipRunner:
         }
         if self.retriever_form == "fused":
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
-            out["retr_stats"] = {"bytes": T * ps * (512 + 8 + 64), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
-            # executed matrix work of K1' per pixel (informational): (4 x 32 producer + 4 x 36 consumer) MFMA 32x32x16 per 32-pixel tile
-            # - the hi / lo operand splits a 16-bit mantissa costs; L <= 128 (three passes beyond that are not counted here)
-            out["retr_attn"] = {"bytes": T * (ps * (512 + 8 + 64) + stages * (L * D * 4 + L * 264 * 4) + tabs), "flops": T * ps * 4 * L * D,
-                                "executed_flops": T * ps * (272 * 32768 // 32)}
+            # K3' reads the map (512 B / pixel) and writes rstd_k, rstd_v (8 B) + the 16 written bytes of an aux row
+            out["retr_stats"] = {"bytes": T * ps * (512 + 8 + 16), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
+            # executed matrix work of K1' per pixel (informational): (4 x 32 producer + 4 x 18 consumer) MFMA 32x32x16 per 32-pixel
+            # tile - Q'' is carried as fp16 hi + lo; L <= 128 (the three passes beyond that are not counted here). K1' stages the
+            # whole 64-byte aux row with every pixel.
+            out["retr_attn"] = {"bytes": T * (ps * (512 + 64) + stages * (L * D * 4 + L * 264 * 4) + tabs), "flops": T * ps * 4 * L * D,
+                                "executed_flops": T * ps * (200 * 32768 // 32)}
         else:
             out["kv_project"] = {"bytes": T * ps * 1536, "flops": T * ps * 4 * D * D}
             out["slot_attn"] = {"bytes": self.k1_algorithmic_bytes_per_step(), "flops": T * ps * 4 * L * D}
