@@ -337,7 +337,10 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                     for (int u = 0; u < 8; ++u) {                   // one MFMA, then its share of the other work
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         if (u < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                        // group 0: its vector work (the normalisation factor) hangs on the statistics read issued at the top of
+                        // the iteration - behind the first four MFMAs, so that an in-order wave does not park the chain on it
+                        if (grp == 0) { if (u >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
+                        else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
