@@ -579,38 +579,43 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
 }
 
 // Per-pixel softmax statistics over up to 256 slots (first kernel of the path for more than 128 slots):
-// stats[t, p] = (max_l S[l, p], 1 / sum_l exp(S[l, p] - max)) with S exactly as in retr_attn_kernel. Eight waves = eight slot
-// blocks, each with its Q'' hi / lo block resident; the feature tiles stream through a 4-deep asm LDS-DMA ring (two 1-KiB
-// pieces per wave and tile); reads the map once, writes 8 B per pixel.
+// stats[t, p] = (max_l S[l, p], 1 / sum_l exp(S[l, p] - max)) with S exactly as in retr_attn_kernel (same fp16 operands, same
+// strip tile order, same position-term handling). Eight waves = eight slot blocks, each with its Q'' hi / lo block resident.
+// Every wave stages two 1-KiB pieces of every feature tile (LDS-DMA, 4 tiles ahead in a 6-deep ring) and converts them to
+// fp16 when they land; wave 7 also stages the Cy row of the tile (1 KiB = 256 slots), wave 6 the 32 rstd_k values. ONE
+// barrier per tile: the statistics of the eight blocks are double-buffered and combined at the START of the next
+// iteration (wave w: pixels 4w .. 4w+3). Reads the map once, writes 8 B per pixel. No global load in the main loop.
 struct LStatsLds {
-    static constexpr int kStages = 4;
+    static constexpr int kA = 4;                                // tiles ahead
+    static constexpr int kNF = kA + 2;                          // ring depth: tile it (compute), it+1 (converted), it+2 .. it+A+1 in flight
     static constexpr int ring = 0;
-    static constexpr int stats = kStages * kTileBytes;          // [8][32] float2
-    static constexpr int c3 = stats + 8 * 32 * 8;               // [256] float
-    static constexpr int total = c3 + 256 * 4;
+    static constexpr int yring = kNF * kTileBytes;              // kNF x 1 KiB Cy rows
+    static constexpr int kring = yring + kNF * 1024;            // kNF x 256 B rstd_k of the tile's pixels (64 lanes x 4 B, lanes >= 32 repeat)
+    static constexpr int stats = kring + kNF * 256;             // [2][8][32] float2
+    static constexpr int total = stats + 2 * 8 * 32 * 8;
 };
 
 __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
-    const __bf16* __restrict__ qh, const __bf16* __restrict__ ql,      // [T, 256, 256]
+    const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,  // [T, 256, 256]
     const float* __restrict__ cy, const float* __restrict__ cx,        // [T, H, 256], [T, W, 256]
     const float* __restrict__ c3g,                                     // [T, 256]
     const __bf16* __restrict__ feat, const float* __restrict__ rstd_k,
     float2* __restrict__ out,                                          // [T, HW]
-    int L, int HW, int H, int W, float inv_w, int tiles_per_chunk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int L, int HW, int H, int W, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = LStatsLds;
-    constexpr int NST = Lds::kStages, A = NST - 1, LP = 256;
+    constexpr int NF = Lds::kNF, A = Lds::kA, LP = 256;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int t = blockIdx.y, c = blockIdx.x;
-    const int px_begin = c * tiles_per_chunk * kTilePx;
-    int px_end = px_begin + tiles_per_chunk * kTilePx;
-    px_end = px_end < HW ? px_end : HW;
-    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+    const int tiles = ((W + kTilePx - 1) / kTilePx) * H;
+    const int tid0 = c * tiles_per_chunk;
+    int nt = tiles - tid0;
+    nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;
+    const int strip0 = tid0 / H, row0 = tid0 - strip0 * H;
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
 
-    float* c3l = reinterpret_cast<float*>(smem + Lds::c3);
-    if (threadIdx.x < 256) c3l[threadIdx.x] = c3g[(size_t)t * LP + threadIdx.x];
     f16x8 qfh[16], qfl[16];
     {
         const size_t row = ((size_t)t * LP + 32 * w + r) * kD + 8 * h;
@@ -620,136 +625,191 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
             qfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
         }
     }
-    wait_vm<0>();
     const int slot0 = 32 * w + 4 * h;
-    auto uniform_rsrc = [](const void* p, int bytes) {
-        const uint64_t a = reinterpret_cast<uint64_t>(p);
-        const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
-                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
-        return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-    };
-    const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * LP, H * LP * 4);
-    const __amdgpu_buffer_rsrc_t cxr = uniform_rsrc(cx + (size_t)t * W * LP, W * LP * 4);
-    const __amdgpu_buffer_rsrc_t rkr = uniform_rsrc(rstd_k + (size_t)t * HW, HW * 4);
+    f32x4 c3v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c3v[g] = *reinterpret_cast<const f32x4*>(c3g + (size_t)t * LP + slot0 + 8 * g);
+    wait_vm<0>();
+
+    const u32x4 cys = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
+    const u32x4 cxs = ra_make_srd(cx + (size_t)t * W * LP, (uint32_t)(W * LP) * 4u);
     const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 krs = ra_make_srd(rstd_k + (size_t)t * HW, (uint32_t)HW * 4u);
     const u32x4 ors = ra_make_srd(out + (size_t)t * HW, (uint32_t)HW * 8u);
-    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
-    auto stage = [&](int tile) {                                     // rows 4w .. 4w + 3 of the tile: two pieces
+    auto ld16 = [](u32x4 srd, int off) {                            // asm + its own wait (no compiler-visible load in the loop)
+        f32x4 v;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(off), "s"(srd) : "memory");
+        return v;
+    };
+    f32x4 cxv[4];
+    auto load_cx = [&](int strip) {
+        int xx = kTilePx * strip + r;
+        xx = xx < W ? xx : W - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cxv[g] = ld16(cxs, (xx * LP + slot0 + 8 * g) * 4);
+    };
+    load_cx(strip0);
+
+    // ---- staging: rows 4w .. 4w+3 of every tile (two pieces); wave 7: the Cy row; wave 6: rstd_k of the 32 pixels
+    int voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * w + 2 * i + h;
+        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+    }
+    const int nb = 2 + (w >= 6 ? 1 : 0);                            // DMA instructions of one batch of this wave
+    int ds = strip0, dy = row0;
+    auto stage = [&](int tile) {
         if (tile >= nt) return;
-        const int px0 = px_begin + tile * kTilePx;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NF) * kTileBytes + w * 2048);
+        const int px0 = dy * W + kTilePx * ds;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = 4 * w + 2 * i + h;
-            const int src = px0 + row < HW ? row : HW - 1 - px0;     // ragged last tile: clamp (those pixels are not stored)
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * kTileBytes + (4 * w + 2 * i) * kRowBytes);
-            ra_dma16(frs, dst, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
-        }
-    };
-    // Position terms + rstd_k of this lane's pixel: compiler-visible loads, requested at the END of the previous iteration
-    // and consumed at the top of this one. hipcc waits for them with vmcnt(0), which also drains this wave's feature DMA
-    // (all of it older): the effective prefetch distance of this kernel is one tile, not three.
-    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
-#pragma unroll
-    for (int b = 0; b < A; ++b) stage(b);
-    f32x4 cyv[4], cxv[4];
-    float rk_n;
-    auto request = [&](int tile) {
-        int px = px_begin + tile * kTilePx + r;
-        px = px < HW ? px : HW - 1;
-        int yy = (int)((float)px * inv_w);
-        int xx = px - yy * W;
-        if (xx < 0) { xx += W; --yy; }
-        if (xx >= W) { xx -= W; ++yy; }
-        const int yo = (yy * LP + slot0) * 4, xo = (xx * LP + slot0) * 4;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            cyv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
-            cxv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cxr, xo + 32 * g, 0, 0));
-        }
-        rk_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rkr, px * 4, 0, 0));
-    };
-    request(0);
-    for (int it = 0; it < nt; ++it) {
-        // Explicit drain BEFORE the barrier: this wave's pieces of f(it) (and the table loads) have landed. hipcc's own wait
-        // for the table loads is free to sink below the barrier (the sums are register arithmetic), which would let other
-        // waves read this wave's rows of the tile before they arrive.
-        wait_vm<0>();
-        {   // this wave's two pieces of f(it): bf16 -> fp16 in place (the operand format of retr_attn_kernel, same arithmetic)
-            const uint32_t st = lds0 + Lds::ring + (it % NST) * kTileBytes + 4 * w * kRowBytes + lane * 16;
+        if (px0 + kTilePx <= HW) {
+            ra_dma16(frs, st, voff[0], soff);
+            ra_dma16(frs, st + 1024, voff[1], soff);
+        } else {                                                     // last row of a ragged strip: clamp the source rows (not stored)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const u32x4 w_ = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(st + i * 1024));
-                u32x4 o_;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    o_[k] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w_[k] << 16), __uint_as_float(w_[k] & 0xffff0000u)));
-                *reinterpret_cast<SVPS_LDS u32x4*>((uintptr_t)(st + i * 1024)) = o_;
+                const int row = 4 * w + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
             }
         }
-        f32x16 s;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[g][j] + cxv[g][j];
-        const float rk = rk_n * kLog2e;                              // log2 domain, like retr_attn_kernel
-        wg_barrier();                                                // B_top(it); also: every wave is done with f(it-1)
-        stage(it + A);
-        const char* kt = smem + Lds::ring + (it % NST) * kTileBytes;
-        int rr = r, hh = h;
-        asm volatile("" : "+v"(rr), "+v"(hh));
-        {
-            f16x8 kf[2][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) kf[0][u] = __builtin_bit_cast(f16x8, read_row_frag(kt, u, rr, hh));
-#pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {
-                if (grp < 3) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = __builtin_bit_cast(f16x8, read_row_frag(kt, 4 * (grp + 1) + u, rr, hh));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[4 * grp + u], kf[grp & 1][u], s, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        if (w == 7) {
+            ra_dma16_cached(cys, __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + (tile % NF) * 1024), dy * LP * 4 + lane * 16);
+        } else if (w == 6) {                                         // 4 B per lane: pixels px0 + (lane & 31), clamped into the frame
+            int px = px0 + (lane & 31);
+            px = px < HW ? px : HW - 1;
+            uint32_t keep;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::kring + (tile % NF) * 256);
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %1\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dword %2, %3, 0 offen lds\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "s"(dst), "v"(px * 4), "s"(krs)
+                : "memory");
         }
-        float mloc = kNegBig;
+        ++dy;
+        if (dy == H) { dy = 0; ++ds; }
+    };
+    auto convert = [&](int tile) {
+        if (tile >= nt) return;
+        const uint32_t st = lds0 + Lds::ring + (tile % NF) * kTileBytes + w * 2048 + lane * 16;
+        u32x4 w_[2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 c3v = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
+        for (int i = 0; i < 2; ++i) w_[i] = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(st + i * 1024));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[4 * g + j] = fmaf(rk, s[4 * g + j], c3v[j]);       // padded rows: c3' = -1e30
-                mloc = fmaxf(mloc, s[4 * g + j]);
-            }
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w_[i][k] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w_[i][k] << 16), __uint_as_float(w_[i][k] & 0xffff0000u)));
+            *reinterpret_cast<SVPS_LDS u32x4*>((uintptr_t)(st + i * 1024)) = w_[i];
         }
-        mloc = ra_half_swap_max(mloc);
-        float sloc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sloc += __builtin_amdgcn_exp2f(s[i] - mloc);
-        sloc = ra_half_swap_sum(sloc);
-        if (h == 0) stats[w * 32 + r] = make_float2(mloc, sloc);
-        wg_barrier();                                                // B_stats(it)
+    };
+    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+    // statistics of tile `tile` (strip fs, row fy): wave w combines the eight blocks for pixels 4w .. 4w+3 and stores them. The
+    // store is ALWAYS issued (out-of-range offset when there is nothing to store): the counted vmcnt waits rely on it.
+    int fs = strip0, fy = row0;
+    auto combine = [&](int tile) {
+        const bool have = tile >= 0;
         float mall = kNegBig;
         float2 st_w[8];
 #pragma unroll
         for (int ww = 0; ww < 8; ++ww) {
-            st_w[ww] = stats[ww * 32 + r];
+            st_w[ww] = stats[((tile & 1) * 8 + ww) * 32 + r];
             mall = fmaxf(mall, st_w[ww].x);
         }
         float den = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 8; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
-        const int pxs = px_begin + it * kTilePx + r;
-        const bool mine = h == 0 && (r >> 2) == w && pxs < px_end;   // wave w stores pixels 4w .. 4w + 3
+        const int xx = kTilePx * fs + r;
+        const int pxs = fy * W + xx;
+        const bool mine = have && h == 0 && (r >> 2) == w && xx < W;
         const f32x2 val = {mall, 1.f / den};
-        const int voff = mine ? pxs * 8 : 0x7ffffff0;                // out of range -> dropped by the hardware range check
-        asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(val), "v"(voff), "s"(ors) : "memory");
-        if (it + 1 < nt) request(it + 1);
+        const int so = mine ? pxs * 8 : 0x7ffffff0;                  // out of range -> dropped by the hardware range check
+        asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(val), "v"(so), "s"(ors) : "memory");
+        if (have) {
+            ++fy;
+            if (fy == H) { fy = 0; ++fs; }
+        }
+    };
+
+    // ---- prologue: batches 0 .. A in flight; tile 0 landed, converted and published
+#pragma unroll
+    for (int b = 0; b <= A; ++b) stage(b);
+    {
+        int younger = nt - 1;
+        younger = younger < 0 ? 0 : (younger > A ? A : younger);
+        wait_vm_dyn(nb * younger);
+        convert(0);
+    }
+    const uint32_t lane_row = lds0 + Lds::ring + r * kRowBytes + ((h ^ swz(r)) << 4);
+    auto frag = [&](uint32_t tb, int ks) {
+        return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
+    };
+    constexpr int kOrd[4] = {0, 8, 1, 9};
+    int ts = strip0, ty = row0;
+    for (int it = 0; it <= nt; ++it) {
+        wg_barrier();                                                // B(it): tile it is fp16; the statistics of tile it-1 are in LDS
+        combine(it - 1);
+        if (it == nt) break;
+        const uint32_t tb = lane_row + (uint32_t)(it % NF) * kTileBytes;
+        f16x8 kf[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kf[0][u] = frag(tb, kOrd[u]);
+        // Cy row and rstd_k of the tile (staged with it)
+        f32x16 s;
+        {
+            const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + (it % NF) * 1024) + slot0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 cyv = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j] + cxv[g][j];
+            }
+        }
+        const float rk = *reinterpret_cast<const float*>(smem + Lds::kring + (it % NF) * 256 + r * 4) * kLog2e;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            if (grp < 3) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = frag(tb, 2 * (grp + 1) + kOrd[u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage(it + A + 1);
+        float mloc = kNegBig;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[4 * g + j] = fmaf(rk, s[4 * g + j], c3v[g][j]);    // padded rows: c3' = -1e30
+                mloc = fmaxf(mloc, s[4 * g + j]);
+            }
+        mloc = ra_half_swap_max(mloc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] - mloc);
+        float sl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sl[i] = (s[i] + s[4 + i]) + (s[8 + i] + s[12 + i]);
+        const float sloc = ra_half_swap_sum((sl[0] + sl[1]) + (sl[2] + sl[3]));
+        if (h == 0) stats[((it & 1) * 8 + w) * 32 + r] = make_float2(mloc, sloc);
+        // tile it+1: this wave's pieces landed -> fp16. Younger operations than its batch: the batches it+2 .. it+A+1 and the
+        // stores of combine() of the iterations in between
+        if (it >= A + 1 && it + A + 1 < nt) wait_vm_dyn(A * (nb + 1));
+        else wait_vm<0>();
+        convert(it + 1);
+        ++ty;
+        if (ty == H) { ty = 0; ++ts; if (it + 1 < nt) load_cx(ts); }
     }
 }
 
@@ -792,15 +852,6 @@ RetrPlan plan_retr(int T, int H, int W, int chunks_req) {
     const int tiles = ((W + svps::kTilePx - 1) / svps::kTilePx) * H;
     int chunks = chunks_req;
     if (chunks <= 0) chunks = svps_pick_chunks(T, tiles, svps_num_cus(), 64);
-    if (chunks > tiles) chunks = tiles;
-    const int tpc = (tiles + chunks - 1) / chunks;
-    chunks = (tiles + tpc - 1) / tpc;
-    return {chunks, tpc};
-}
-// logit statistics (more than 128 slots): linear tiles of 32 pixels
-RetrPlan plan_linear(int T, int HW) {
-    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
-    int chunks = svps_pick_chunks(T, tiles, svps_num_cus(), 64);
     if (chunks > tiles) chunks = tiles;
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
@@ -850,14 +901,14 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         // more than 128 slots (padded layouts of 256 rows): softmax statistics over all slots first, then the retriever
         // once per half of the slots with those statistics
         float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);
-        const RetrPlan pl = plan_linear(T, HW);
-        const float inv_w = 1.0f / (float)W;
+        const RetrPlan pl = plan_retr(T, H, W, 0);
         static SvpsLdsAttr attr_s, attr_e;
         if (hipError_t ae = attr_s.ensure(reinterpret_cast<const void*>(svps::retr_logit_stats_kernel), svps::LStatsLds::total); ae != hipSuccess) return (int)ae;
         auto kern = svps::retr_attn_kernel<0, true>;
         if (hipError_t ae = attr_e.ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
-        hipLaunchKernelGGL(svps::retr_logit_stats_kernel, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream, qh_, ql_, cy, cx,
-                           c3, f_, rstd_k, st, L, HW, H, W, inv_w, pl.tiles_per_chunk);
+        hipLaunchKernelGGL(svps::retr_logit_stats_kernel, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream,
+                           static_cast<const _Float16*>(qh), static_cast<const _Float16*>(ql), cy, cx, c3, f_, rstd_k, st, L, HW, H, W,
+                           pl.tiles_per_chunk);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
