@@ -26,7 +26,8 @@ constexpr int kGmRow = kGmK * 2 + 16;       // bytes per row of the staged A til
 
 struct GemmLds {
     static constexpr int buf_bytes = 2 * kGmRows * kGmRow;      // hi | lo
-    static constexpr int total = 2 * buf_bytes;
+    static constexpr int nbuf = 4;                              // K <= 256: every chunk of the A tile is staged up front
+    static constexpr int total = nbuf * buf_bytes;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -49,9 +50,8 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
     const int m0 = blockIdx.x * ROWS, n0 = blockIdx.y * kGmCols;
     const int KS = K / 16, nch = (K + kGmK - 1) / kGmK;
 
-    // A tile staging: thread -> two (row, 4-k group) items per chunk
-    f32x4 av[RBW];
-    auto gather = [&](int ch) {
+    // A tile staging: thread -> RBW (row, 4-k group) items per chunk
+    auto gather = [&](int ch, f32x4 (&av)[RBW]) {
 #pragma unroll
         for (int i = 0; i < RBW; ++i) {
             const int q = tid + 512 * i, row = q >> 4, kg = (q & 15) * 4;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
             av[i] = (m < M && k < K) ? *reinterpret_cast<const f32x4*>(x + (size_t)m * K + k) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto split_store = [&](int buf) {
+    auto split_store = [&](int buf, const f32x4 (&av)[RBW]) {
         char* bh = smem + buf * GemmLds::buf_bytes;
 #pragma unroll
         for (int i = 0; i < RBW; ++i) {
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
     // B fragments of column block cb, k-step ks, part p: u32x4 index ((cb * KS + ks) * 2 + p) * 64 + lane
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpack) + lane;
     const int cb0 = (n0 >> 5) + NB * cg;
-    // weights of one chunk: 4 k-steps x 2 column blocks x (hi, lo) = 16 fragments = 64 registers; the NEXT chunk's set is
-    // requested before this chunk's MFMAs (register double buffer, loop unrolled by two), so that the L2 latency of the
-    // weight stream (one workgroup per CU for the 256-column layers: nobody else to hide it) runs under the matrix work
+    // weights of one chunk: 4 k-steps x NB column blocks x (hi, lo) = 8 NB fragments; with PREF the NEXT chunk's set is
+    // requested before this chunk's MFMAs (register double buffer), so that the L2 latency of the weight stream (one
+    // workgroup per CU for the 256-column layers: nobody else to hide it) runs under the matrix work
     auto load_w = [&](int ch, u32x4 (&wb)[8 * NB]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -100,8 +100,8 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
             }
         }
     };
-    auto mma = [&](int ch, const u32x4 (&wb)[8 * NB]) {
-        const char* ah = smem + (ch & 1) * GemmLds::buf_bytes + (32 * rb + r) * kGmRow + 16 * h;
+    auto mma = [&](int ch, int buf, const u32x4 (&wb)[8 * NB]) {
+        const char* ah = smem + buf * GemmLds::buf_bytes + (32 * rb + r) * kGmRow + 16 * h;
         const char* al = ah + kGmRows * kGmRow;
         const int nks = (KS - ch * 4) < 4 ? (KS - ch * 4) : 4;   // k-steps of this chunk (the last chunk may be short)
 #pragma unroll
@@ -121,33 +121,88 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
         }
     };
     u32x4 w0[8 * NB], w1[PREF ? 8 * NB : 1];
-    gather(0);
-    if constexpr (PREF) load_w(0, w0);
-    split_store(0);
-    __syncthreads();
     if constexpr (!PREF) {
+        // ---- wide layers (more workgroups than CUs, two co-resident per CU hide each other's latencies; 128 registers at most):
+        // two LDS buffers, the A rows of the next chunk requested after this chunk's MFMAs
+        f32x4 av[RBW];
+        gather(0, av);
+        split_store(0, av);
+        __syncthreads();
         for (int ch = 0; ch < nch; ++ch) {
             load_w(ch, w0);
-            mma(ch, w0);
-            if (ch + 1 < nch) {                                 // after the MFMAs
-                gather(ch + 1);
-                split_store((ch + 1) & 1);
+            mma(ch, ch & 1, w0);
+            if (ch + 1 < nch) {
+                gather(ch + 1, av);
+                split_store((ch + 1) & 1, av);
             }
             __syncthreads();
         }
-    } else
-    for (int ch = 0; ch < nch; ch += 2) {
-        // even chunk: weights in w0
-        if (ch + 1 < nch) { gather(ch + 1); if constexpr (PREF) load_w(ch + 1, w1); }
-        mma(ch, w0);
-        if (ch + 1 < nch) split_store((ch + 1) & 1);
+    } else if (nch <= GemmLds::nbuf) {
+        // ---- K <= 256 (every 256-wide layer of the slot side): the whole A tile is requested at once and staged before the
+        // first MFMA - ONE global-memory latency and ONE barrier per launch instead of one of each per chunk (these launches
+        // are a few microseconds of pure latency: 32 x 256 x 256 per workgroup is 48 MFMAs per wave)
+        // (64-row tiles: in two groups of two chunks, 16 registers instead of 32 - the wide layers need two workgroups per CU)
+        constexpr int GS = RBW == 1 ? GemmLds::nbuf : GemmLds::nbuf / 2;
+        load_w(0, w0);
+#pragma unroll
+        for (int g0 = 0; g0 < GemmLds::nbuf; g0 += GS) {
+            f32x4 av[GS][RBW];
+#pragma unroll
+            for (int ch = 0; ch < GS; ++ch)
+                if (g0 + ch < nch) gather(g0 + ch, av[ch]);
+#pragma unroll
+            for (int ch = 0; ch < GS; ++ch)
+                if (g0 + ch < nch) split_store(g0 + ch, av[ch]);
+        }
         __syncthreads();
-        if (ch + 1 >= nch) break;
-        // odd chunk: weights in w1
-        if (ch + 2 < nch) { gather(ch + 2); load_w(ch + 2, w0); }
-        if constexpr (PREF) mma(ch + 1, w1);
-        if (ch + 2 < nch) split_store(ch & 1);
+#pragma unroll
+        for (int ch = 0; ch < GemmLds::nbuf; ch += 2) {
+            if (ch >= nch) break;
+            if constexpr (PREF) {
+                if (ch + 1 < nch) load_w(ch + 1, w1);
+                mma(ch, ch, w0);
+                if (ch + 1 < nch) {
+                    if (ch + 2 < nch) load_w(ch + 2, w0);
+                    mma(ch + 1, ch + 1, w1);
+                }
+            } else {
+                mma(ch, ch, w0);
+                if (ch + 1 < nch) { load_w(ch + 1, w0); mma(ch + 1, ch + 1, w0); }
+                if (ch + 2 < nch) load_w(ch + 2, w0);
+            }
+        }
+    } else {
+        // ---- long K (the second FFN layer, K = 2048): two LDS buffers, the A rows of chunk ch+2 are requested while chunk ch is on
+        // the matrix cores and split into LDS one iteration later (a request issued one chunk ahead was still in flight when
+        // it was needed: every chunk paid a global-memory latency)
+        f32x4 ga[2][RBW];
+        gather(0, ga[0]);
+        load_w(0, w0);
+        gather(1, ga[1]);
+        split_store(0, ga[0]);
+        if (2 < nch) gather(2, ga[0]);
         __syncthreads();
+        for (int ch = 0; ch < nch; ch += 2) {
+            // even chunk ch: A rows in buffer 0, weights in w0; registers: ga[1] = chunk ch+1, ga[0] = chunk ch+2
+            if constexpr (PREF) { if (ch + 1 < nch) load_w(ch + 1, w1); }
+            mma(ch, 0, w0);
+            if (ch + 1 < nch) split_store(1, ga[1]);
+            if (ch + 3 < nch) gather(ch + 3, ga[1]);
+            __syncthreads();
+            if (ch + 1 >= nch) break;
+            // odd chunk ch+1: buffer 1, weights in w1 (PREF) or reloaded into w0
+            if constexpr (PREF) {
+                if (ch + 2 < nch) load_w(ch + 2, w0);
+                mma(ch + 1, 1, w1);
+            } else {
+                load_w(ch + 1, w0);
+                mma(ch + 1, 1, w0);
+                if (ch + 2 < nch) load_w(ch + 2, w0);
+            }
+            if (ch + 2 < nch) split_store(0, ga[0]);
+            if (ch + 4 < nch) gather(ch + 4, ga[0]);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: register i of a block = row (i & 3) + 8 (i >> 2) + 4 h, column = lane r
