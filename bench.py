@@ -467,7 +467,7 @@ def main():
                        "parallelism": f"clip-parallel x{world}", "world_size": world,
                        "gather": f"per step, {gatherers[0].bytes_per_submit} B per rank to rank 0, async on a side stream (RCCL)" if world > 1 else "none (one rank)",
                        "hipgraph": not a.no_graph, "clips_in_flight": cif, "clips_per_launch": cpl,
-                       "k1_split_p": not a.fast_p, "retriever": runner.retriever_form},
+                       "retriever": runner.retriever_form},
             "roofline": roof,
         }
         if a.cpu_baseline and world == 1:
