@@ -6,7 +6,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W          (the driver's form: this process is one rank)
 
 One "step" = one pass of the hot path over one batch of synthetic clips per rank: `--clips-per-launch`
-(default 16) independent T=5 clips of 1024x2048 stacked along the frame axis -> four levels of 128-channel
+(default 32) independent T=5 clips of 1024x2048 stacked along the frame axis -> four levels of 128-channel
 FPN feature maps (32x64 ... 256x512, resident in HBM) -> the 7-stage multi-scale slot head (K4, K3, K1
 once per level / stage for all frames of the batch; temporal slot attention stays inside each clip) ->
 slot->mask decode of all frames (K2). Weights: the R50-FPN Slot-VPS head architecture with seeded synthetic values
@@ -58,7 +58,7 @@ def parse():
                     help="fused: statistics-fused retriever K3' + K1' (default); kv: K3 + K1 through bf16 k / v tensors")
     ap.add_argument("--clips-in-flight", type=int, default=1,
                     help="independent clips per step, each replayed on its own HIP stream (a step then covers that many clips)")
-    ap.add_argument("--clips-per-launch", type=int, default=16,
+    ap.add_argument("--clips-per-launch", type=int, default=32,
                     help="independent clips stacked along the frame axis of every kernel launch (temporal attention stays per clip)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 to skip the CPU oracle leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
@@ -203,7 +203,7 @@ def whole_detector_leg(a, dev):
 
 def single_clip_latency(a, dev):
     """Latency of the hot path on ONE clip (no stacking): the same graph-replayed step as the timed region with
-    clips_per_launch = 1. The headline `value` stacks 16 clips per launch for throughput; this is what one clip waits."""
+    clips_per_launch = 1. The headline `value` stacks 32 clips per launch for throughput; this is what one clip waits."""
     from slotvps_amd.clip import SlotClipRunner
     from slotvps_amd import synth
     r1 = SlotClipRunner(dev, a.frames, a.height, a.width, L=a.slots, param_seed=0, cfg=dict(synth.R50_HEAD_CFG, num_classes=a.num_classes),
