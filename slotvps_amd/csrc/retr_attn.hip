@@ -629,6 +629,13 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
     f32x4 c3v[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) c3v[g] = *reinterpret_cast<const f32x4*>(c3g + (size_t)t * LP + slot0 + 8 * g);
+    // Make hipcc consume (and therefore wait for) every register loaded above HERE: its wait-count pass does not see the asm waits
+    // and otherwise places `s_waitcnt vmcnt(n)` before the first use of each fragment INSIDE the main loop, where a small n
+    // also waits for the LDS-DMA ring.
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(qfh[ks]), "+v"(qfl[ks]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(c3v[g]));
     wait_vm<0>();
 
     const u32x4 cys = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
