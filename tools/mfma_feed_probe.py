@@ -1,0 +1,32 @@
+"""How fast does one wave run a chain of 32 v_mfma_f32_32x32x16_f16 per 32-pixel tile when the B operand comes from LDS (the
+producer loop of K1', the heavy phase of K3')? Needs the diagnostic library:
+    make -C slotvps_amd/csrc stamp
+    SLOTVPS_LIB=slotvps_amd/libslotvps_hip_stamp.so python tools/mfma_feed_probe.py"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slotvps_amd import _lib, ops
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+lib.svps_probe_mfma_feed.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+blocks, tiles = 256, 400
+out = torch.zeros((blocks * 8, 2), dtype=torch.int64, device=dev)
+sink = torch.zeros(512, dtype=torch.float32, device=dev)
+names = {0: "B from LDS, groups of 4 double-buffered, one accumulator", 1: "B in registers (no LDS)", 2: "B from LDS, two accumulators",
+         3: "B from LDS, ring of three groups"}
+for bar in (0, 4):
+    for mode in (1, 0, 2, 3):
+        for nact in (4, 8):
+            for rep in range(3):
+                out.zero_()
+                rc = lib.svps_probe_mfma_feed(mode | bar, tiles, nact, blocks, out.data_ptr(), sink.data_ptr(), ops._stream_ptr(dev))
+                assert rc == 0, rc
+                torch.cuda.synchronize()
+            o = out.cpu().numpy().reshape(blocks, 8, 2)
+            d = (o[:, 0, 1] - o[:, 0, 0]).astype(np.float64)
+            d4 = (o[:, 4, 1] - o[:, 4, 0]).astype(np.float64)
+            span = (o[:, :nact, 1].max(axis=1) - o[:, :nact, 0].min(axis=1)).astype(np.float64)
+            print(f"{names[mode]:58s} barrier/tile={'yes' if bar else 'no '} waves/SIMD={nact // 4}: "
+                  f"{np.median(d) / (tiles * 32):6.1f} cycles per MFMA (wave 0), wave 4 {np.median(d4) / (tiles * 32):6.1f}, "
+                  f"workgroup span {np.median(span) / (tiles * 32):6.1f}", flush=True)
