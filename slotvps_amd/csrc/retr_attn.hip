@@ -980,6 +980,10 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
     constexpr int kOrd[4] = {0, 8, 1, 9};
     constexpr int M = MODE & 3;
     constexpr bool BAR = (MODE & 4) != 0;
+    constexpr int FILL = ((MODE >> 4) & 3) * 2;                  // independent v_fma_f32 after EVERY MFMA (0, 2, 4, 6)
+    float fv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fv[i] = (float)(lane + i);
     f32x16 s, s2;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.f; s2[i] = 0.f; }
@@ -990,7 +994,27 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
     }
     unsigned long long t0 = 0;
     if (lane == 0) t0 = __builtin_amdgcn_s_memtime();
-    if (w < nact || BAR) {
+    if (nact < 0 && w >= 4) {
+        // probe of the arbitration: the younger half runs vector arithmetic / LDS reads only (256 dependent-free FMAs + 8 reads per "tile")
+        // while the older half (nact == -1) runs the MFMA chain, or alone (nact == -2)
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (float)(lane + i);
+        for (int it = 0; it < tiles; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 16; ++rep)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], 1.0001f, 0.5f);
+            const uint32_t tb = lane_row + (uint32_t)(it & 1) * kTileBytes;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) { const f16x8 f = frag(tb, ks); v[ks] += (float)f[0]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] += v[i];
+    } else if ((nact == -2) && w < 4) {
+        // older half idle
+    } else if (w < (nact < 0 ? 4 : nact) || BAR) {
+        if (nact < 0) nact = 4;
         for (int it = 0; it < tiles; ++it) {
             if constexpr (BAR) wg_barrier();
             if (w >= nact) continue;
@@ -1033,8 +1057,18 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                        if constexpr (FILL > 0) {
+#pragma unroll
+                            for (int i = 0; i < FILL; ++i) fv[i] = fmaf(fv[i], 1.0001f, 0.5f);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if constexpr (M == 2) s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s2, 0, 0, 0);
                         else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                        if constexpr (FILL > 0) {
+#pragma unroll
+                            for (int i = 0; i < FILL; ++i) fv[i] = fmaf(fv[i], 0.9999f, 0.25f);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1044,6 +1078,8 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc += s[i] + s2[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += fv[i];
     if (lane == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         out[(blockIdx.x * 8 + w) * 2] = t0;
@@ -1059,6 +1095,7 @@ extern "C" int svps_probe_mfma_feed(int mode, int tiles, int nact, int blocks, u
 #define SVPS_FEED(MD) case MD: hipLaunchKernelGGL(svps::mfma_feed_kernel<MD>, dim3(blocks), dim3(512), lds, stream, out_dev, sink_dev, tiles, nact); break;
     switch (mode) {
         SVPS_FEED(0) SVPS_FEED(1) SVPS_FEED(2) SVPS_FEED(3) SVPS_FEED(4) SVPS_FEED(5) SVPS_FEED(6) SVPS_FEED(7)
+        SVPS_FEED(16) SVPS_FEED(18) SVPS_FEED(32) SVPS_FEED(34) SVPS_FEED(48) SVPS_FEED(50)
         default: return SVPS_ERR_BAD_ARG;
     }
 #undef SVPS_FEED

@@ -30,3 +30,28 @@ for bar in (0, 4):
             print(f"{names[mode]:58s} barrier/tile={'yes' if bar else 'no '} waves/SIMD={nact // 4}: "
                   f"{np.median(d) / (tiles * 32):6.1f} cycles per MFMA (wave 0), wave 4 {np.median(d4) / (tiles * 32):6.1f}, "
                   f"workgroup span {np.median(span) / (tiles * 32):6.1f}", flush=True)
+
+# arbitration between the two waves of a SIMD: the younger half runs 256 FMAs + 8 LDS reads per tile, alone and beside the older
+# half's MFMA chain
+for nact, what in ((-2, "younger half alone (vector + LDS work)"), (-1, "younger half beside the older half's MFMA chain")):
+    for rep in range(3):
+        out.zero_()
+        rc = lib.svps_probe_mfma_feed(0, tiles, nact, blocks, out.data_ptr(), sink.data_ptr(), ops._stream_ptr(dev))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(blocks, 8, 2)
+    d0 = (o[:, 0, 1] - o[:, 0, 0]).astype(np.float64)
+    d4 = (o[:, 4, 1] - o[:, 4, 0]).astype(np.float64)
+    print(f"{what:52s}: wave 4 {np.median(d4) / tiles:7.0f} cycles per tile, wave 0 {np.median(d0) / tiles:7.0f}", flush=True)
+
+# independent vector instructions between the MFMAs of ONE wave's chain (one wave per SIMD): hidden in the matrix shadow or not?
+for fill in (1, 2, 3):
+    for mode, what in ((0, "one accumulator"), (2, "two accumulators")):
+        for rep in range(3):
+            out.zero_()
+            rc = lib.svps_probe_mfma_feed(mode | (fill << 4), tiles, 4, blocks, out.data_ptr(), sink.data_ptr(), ops._stream_ptr(dev))
+            assert rc == 0, rc
+            torch.cuda.synchronize()
+        o = out.cpu().numpy().reshape(blocks, 8, 2)
+        d = (o[:, 0, 1] - o[:, 0, 0]).astype(np.float64)
+        print(f"{2 * fill} v_fma_f32 after every MFMA, {what:16s}: {np.median(d) / (tiles * 32):6.1f} cycles per MFMA", flush=True)
