@@ -273,9 +273,9 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *   ty [H, 256], tx [W, 256] fp32 or both NULL: the separable sine tables ALREADY multiplied by the key factor,
  *       ty[y] = R_k[:, :128] pos_y[y], tx[x] = R_k[:, 128:] pos_x[x] (R_k (f + pos) = R_k f + ty[y] + tx[x]: the position term
  *       enters the key accumulators in fp32 and never passes through 16 bits)
- *   out: rstd_k, rstd_v [T, HW] fp32 = 1 / sqrt(var + eps);  aux [T, HW, 32] 16-bit words, 64-byte rows of which the kernel writes
- *       the first 16 bytes: {1, hi(1/rstd_v), lo(1/rstd_v), 0} FP16, {rstd_k, rstd_v} fp32 - the row svps_retr_attn_fwd stages with
- *       every pixel (the other 48 bytes are never read as data)
+ *   out: aux [T, HW, 8] 16-bit words = ONE 16-byte row per pixel: {1, hi(1/rstd_v), lo(1/rstd_v), 0} FP16, {rstd_k, rstd_v} fp32
+ *       (rstd = 1 / sqrt(var + eps)) - the row svps_retr_attn_fwd stages with every pixel. Nothing else is written: 16 B per
+ *       pixel, whole memory lines (rows written in part cost a third of the kernel's streaming rate in read-modify-write traffic).
  *
  * svps_retr_attn_fwd    (:435-456)
  *   The slot axis of the inputs is padded to LP = 128 rows (L <= 128) or 256 rows (L <= 256), rows >= L zero:
@@ -285,18 +285,17 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *       is what removes them from the softmax: the kernel applies no mask)
  *   out_ext [T, L, 272] fp32: { A_l = sum_p P rstd_v f_p (256), s1_l = sum_p P rstd_v, s0_l = sum_p P, 0 x 14 };
  *       pre-LayerNorm output (:456) = out_ext @ [ (gamma_v * W~_v)^T ; gamma_v * b~_v ; beta_v ; 0 ]
- *   rstd_k / rstd_v: the arrays of svps_retr_stats_fwd (the kernel for L <= 128 takes both values from the aux rows; rstd_k is read
- *       by the statistics kernel of the L > 128 path)
+ *   aux: the rows of svps_retr_stats_fwd
  *   1 <= L <= 256; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 264] fp32
  *   (+ [T, HW] x 8 B when L > 128: per-pixel softmax statistics over all slots, written by a first kernel; the retriever then
  *   runs once per half of the slots)
  * ------------------------------------------------------------------------------------------- */
 int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
-                        float lnk_eps, const void* rv, const float* rbv, float lnv_eps, float* rstd_k, float* rstd_v,
-                        void* aux, int T, int H, int W, int D, void* stream);
+                        float lnk_eps, const void* rv, const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D,
+                        void* stream);
 size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int chunks);
 int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
-                       const void* feat, const float* rstd_k, const float* rstd_v, const void* aux, void* workspace,
+                       const void* feat, const void* aux, void* workspace,
                        size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,
                        void* stream);
 

@@ -142,9 +142,9 @@ class SlotClipRunner:
     def algorithmic_per_step(self):
         """Per library kernel: algorithmic HBM bytes and matrix flops of one step (all frames of the launch), the figures the
         roofline fractions are computed from. Per pixel and stage (D = 256, L slots):
-          retr_stats (K3')  bytes: 512 (map) + 8 (two statistics) + 64 (aux row) out
+          retr_stats (K3')  bytes: 512 (map) in + 16 (the aux row: both statistics) out
                             flops: the two triangular products |R x|^2, 36 of 64 blocks each: 2 * (36/64) * 2 * D^2
-          retr_attn  (K1')  bytes: 512 (map) + 8 + 64 in, + per frame-stage L*D*(2+2) (Q'' hi / lo) + tables (H+W)*128*4 + L*264*4 out
+          retr_attn  (K1')  bytes: 512 (map) + 16 (aux row) in, + per frame-stage L*D*(2+2) (Q'' hi / lo) + tables (H+W)*128*4 + L*264*4 out
                             flops: 4 * L * D (logits + attn.v; the hi / lo splits are not algorithmic)
           kv_project (K3)   bytes: 512 in + 1024 out; flops 4 * D^2
           slot_attn  (K1)   bytes: 1024 in (+ q, out per frame-stage); flops 4 * L * D
@@ -160,12 +160,12 @@ class SlotClipRunner:
         }
         if self.retriever_form == "fused":
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
-            # K3' reads the map (512 B / pixel) and writes rstd_k, rstd_v (8 B) + the 16 written bytes of an aux row
-            out["retr_stats"] = {"bytes": T * ps * (512 + 8 + 16), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
+            # K3' reads the map (512 B / pixel) and writes one 16-byte aux row (both statistics)
+            out["retr_stats"] = {"bytes": T * ps * (512 + 16), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
             # executed matrix work of K1' per pixel (informational): (4 x 32 producer + 4 x 18 consumer) MFMA 32x32x16 per 32-pixel
             # tile - Q'' is carried as fp16 hi + lo; L <= 128 (the three passes beyond that are not counted here). K1' stages the
-            # whole 64-byte aux row with every pixel.
-            out["retr_attn"] = {"bytes": T * (ps * (512 + 64) + stages * (L * D * 4 + L * 264 * 4) + tabs), "flops": T * ps * 4 * L * D,
+            # 16-byte aux row with every pixel.
+            out["retr_attn"] = {"bytes": T * (ps * (512 + 16) + stages * (L * D * 4 + L * 264 * 4) + tabs), "flops": T * ps * 4 * L * D,
                                 "executed_flops": T * ps * (200 * 32768 // 32)}
         else:
             out["kv_project"] = {"bytes": T * ps * 1536, "flops": T * ps * 4 * D * D}

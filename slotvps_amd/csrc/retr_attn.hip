@@ -44,8 +44,8 @@ typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 constexpr int kRPrefetch = 3;
 constexpr int kRNF = kRPrefetch + 3;       // feature / aux / Cy ring depth: tiles it-2 .. it+3 are live in iteration it
-constexpr int kAuxRow = 64;                // bytes per pixel of the aux tensor (32 bf16)
-constexpr int kAuxTile = kTilePx * kAuxRow;
+constexpr int kAuxRow = 16;                // bytes per pixel of the aux tensor (retr_stats.hip)
+constexpr int kAuxTile = 1024;             // LDS per staged aux tile: 512 B of rows (+ 512 B the upper half of the DMA instruction repeats)
 constexpr int kPTile = 8192;               // P tile: 128 slots x 32 pixels fp16
 constexpr int kCyTile = 1024;              // one LDS-DMA piece: the Cy row of the tile's image row (LP = 128: and the next row)
 constexpr int kPartRow = 264;              // floats per slot row of a partial: 256 channels of A + 8 aux columns
@@ -125,6 +125,7 @@ __device__ unsigned long long retr_clock[4096][4];       // [workgroup][memtime0
 #endif
 
 // ABL: timing-only ablations (env SVPS_RETR_ABLATE), outputs wrong. 1: DMA + barriers only  2: producers only  4: consumers only
+//      8: no bf16 -> fp16 conversion
 // EXT (more than 128 slots, LP = 256): the launch covers the `L` slots starting at row `slot_off`; the per-pixel softmax
 // statistics over ALL slots come from `ext_stats` ([T, HW] of (max logit, 1 / sum of exponentials), written by
 // retr_logit_stats_kernel) instead of the exchange between the four producers.
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const float* __restrict__ cx,       // [T, W, LP]    Q''[:, 128:256] . xtab[x]
     const float* __restrict__ c3g,      // [T, LP]  log2(e) * q . beta_k; -1e30 in the padded rows
     const __bf16* __restrict__ feat,    // [T, HW, 256]
-    const __bf16* __restrict__ aux,     // [T, HW, 32]   retr_stats.hip: {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32), 48 bytes not written}
+    const __bf16* __restrict__ aux,     // [T, HW, 8]    retr_stats.hip: 16-byte rows {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32)}
     float* __restrict__ partial,        // [T, C, Lrow, 264]
     int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off,
     const float2* __restrict__ ext_stats) {
@@ -328,10 +329,19 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
                     }
+#ifndef SVPS_P2V
+#define SVPS_P2V 0
+#endif
                     if constexpr (P2) {
-                        if (grp == 0) p2_factor();
-                        if (grp == 1) { p2_store(0); p2_store(1); }
-                        if (grp == 2) { p2_store(2); p2_store(3); }
+                        if constexpr (SVPS_P2V == 0) {
+                            if (grp == 0) p2_factor();
+                            if (grp == 1) { p2_store(0); p2_store(1); }
+                            if (grp == 2) { p2_store(2); p2_store(3); }
+                        } else {
+                            if (grp == 1) p2_factor();
+                            if (grp == 2) { p2_store(0); p2_store(1); }
+                            if (grp == 3) { p2_store(2); p2_store(3); }
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {                   // one MFMA, then its share of the other work
@@ -339,8 +349,14 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                         if (u < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         // group 0: its vector work (the normalisation factor) hangs on the statistics read issued at the top of
                         // the iteration - behind the first four MFMAs, so that an in-order wave does not park the chain on it
-                        if (grp == 0) { if (u >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
-                        else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                        if constexpr (SVPS_P2V == 0) {
+                            if (grp == 0) { if (u >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
+                            else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                        } else if constexpr (SVPS_P2V == 1) {
+                            if (grp >= 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        } else {
+                            if (grp >= 1) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
 
     // =================================== consumer ===============================================
     const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
-    const u32x4 ars = ra_make_srd(aux + (size_t)t * HW * 32, (uint32_t)HW * kAuxRow);
+    const u32x4 ars = ra_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * kAuxRow);
     const u32x4 yrs = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
     int voff[4];
 #pragma unroll
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         const int row = 8 * sb + 2 * i + h;
         voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
     }
-    const int nb = 4 + (sb < 3 ? 1 : 0);                        // DMA instructions of one batch of this wave
+    const int nb = 4 + ((sb == 0 || sb == 2) ? 1 : 0);          // DMA instructions of one batch of this wave
     int ds = strip0, dy = row0;                                 // strip / image row of the next batch
     auto issue_batch = [&](int b) {
         if (b >= nt) return;
@@ -454,9 +470,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         }
         ++dy;
         if (dy == H) { dy = 0; ++ds; }
-        if (sb < 2) {                                            // aux tile: two 1-KiB pieces; rows past the frame read zeros (range check on voff)
-            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % kRNF) * kAuxTile + sb * 1024);
-            ra_dma16(ars, sa, px0 * kAuxRow + sb * 1024 + lane * 16, 0);
+        if (sb == 0) {                                           // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
+            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % kRNF) * kAuxTile);
+            ra_dma16(ars, sa, (px0 + (lane & 31)) * kAuxRow, 0);
         } else if (sb == 2) {                                    // Cy row of tile b + 1 (1 KiB from the start of its image row)
             const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b + 1) % kRNF) * kCyTile);
             ra_dma16_cached(yrs, sy, dy * LP * 4 + lane * 16);
@@ -484,7 +500,10 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const uint32_t lane_v1 = (rowl + 4) * kRowBytes + (((cl ^ (2 * (g2 >> 1) + 1)) + 4 * qq) << 4) + sub;
     const uint32_t lane_p0 = sb * 2048 + sub + rowl * 64 + ((cl ^ (qq >> 1)) << 4);
     const uint32_t lane_p1 = sb * 2048 + sub + (rowl + 4) * 64 + ((cl ^ (qq >> 1) ^ 2) << 4);
-    const uint32_t lane_a = rowl * kAuxRow + cl * 16 + sub;
+    // aux block: the row's FP16 words 0 .. 3 are columns 0 .. 3 of the ninth channel block; the lanes that feed the other 28
+    // columns read words 4 .. 7 (the two fp32 statistics as bit patterns) or repeat words 0 .. 3: those columns only reach
+    // accumulator columns nobody stores
+    const uint32_t lane_a = rowl * kAuxRow + ((cl == 0 && sub != 0) ? 8 : 0);
     auto tr = [](uint32_t a) {
         return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(reinterpret_cast<SVPS_LDS fp16x4_gcc*>((uintptr_t)a)));
     };
@@ -502,7 +521,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         const uint32_t at = lds0 + Lds::aring + (j % kRNF) * kAuxTile;
         p0 = pt + lane_p0, p1 = pt + lane_p1, v0 = vt + lane_v0, v1 = vt + lane_v1, aa = at + lane_a;
         ah[0] = cat(tr(p0), tr(p1));
-        af[0] = cat(tr(aa), tr(aa + 256));
+        af[0] = cat(tr(aa), tr(aa + 4 * kAuxRow));
 #pragma unroll
         for (int u = 0; u < 4; ++u) vf[0][u] = vfrag(0, u);
     };
@@ -516,7 +535,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             }
             if (q == 1) {
                 ah[1] = cat(tr(p0 + 1024), tr(p1 + 1024));
-                af[1] = cat(tr(aa + 1024), tr(aa + 1024 + 256));
+                af[1] = cat(tr(aa + 16 * kAuxRow), tr(aa + 20 * kAuxRow));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -531,7 +550,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     // instruction of the kernel then runs fp16 x fp16: Q'' as fp16 hi + lo carries 22 bits, P * rstd_v ONE fp16 (11 bits,
     // rounding errors average out over the pixel sum) instead of bf16 hi + lo: half the MFMAs on the value side.
     auto convert_batch = [&](int b) {
-        if (b >= nt) return;
+        if (b >= nt || ABL == 8) return;
         const uint32_t st = lds0 + Lds::fring + (b % kRNF) * kTileBytes + sb * 4096 + lane * 16;
         u32x4 w_[4];
 #pragma unroll
@@ -599,7 +618,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,  // [T, 256, 256]
     const float* __restrict__ cy, const float* __restrict__ cx,        // [T, H, 256], [T, W, 256]
     const float* __restrict__ c3g,                                     // [T, 256]
-    const __bf16* __restrict__ feat, const float* __restrict__ rstd_k,
+    const __bf16* __restrict__ feat, const __bf16* __restrict__ aux,   // aux: the 16-byte rows of retr_stats.hip (rstd_k = bytes 8 .. 11)
     float2* __restrict__ out,                                          // [T, HW]
     int L, int HW, int H, int W, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -641,7 +660,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
     const u32x4 cys = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
     const u32x4 cxs = ra_make_srd(cx + (size_t)t * W * LP, (uint32_t)(W * LP) * 4u);
     const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
-    const u32x4 krs = ra_make_srd(rstd_k + (size_t)t * HW, (uint32_t)HW * 4u);
+    const u32x4 krs = ra_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * kAuxRow);
     const u32x4 ors = ra_make_srd(out + (size_t)t * HW, (uint32_t)HW * 8u);
     auto ld16 = [](u32x4 srd, int off) {                            // asm + its own wait (no compiler-visible load in the loop)
         f32x4 v;
@@ -696,7 +715,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
                 "buffer_load_dword %2, %3, 0 offen lds\n\t"
                 "s_mov_b32 m0, %0"
                 : "=&s"(keep)
-                : "s"(dst), "v"(px * 4), "s"(krs)
+                : "s"(dst), "v"(px * kAuxRow + 8), "s"(krs)
                 : "memory");
         }
         ++dy;
@@ -874,10 +893,10 @@ extern "C" size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int
 }
 
 extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
-                                  const void* feat, const float* rstd_k, const float* rstd_v, const void* aux,
+                                  const void* feat, const void* aux,
                                   void* workspace, size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D,
                                   int chunks, void* stream_) {
-    if (!qh || !ql || !cy || !cx || !c3 || !feat || !rstd_k || !rstd_v || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
+    if (!qh || !ql || !cy || !cx || !c3 || !feat || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     const int HW = H * W;
@@ -899,7 +918,8 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         if (ablate == 1) { kern = svps::retr_attn_kernel<1, false>; slot = 1; }
         else if (ablate == 2) { kern = svps::retr_attn_kernel<2, false>; slot = 2; }
         else if (ablate == 4) { kern = svps::retr_attn_kernel<4, false>; slot = 3; }
-        static SvpsLdsAttr attr[4];
+        else if (ablate == 8) { kern = svps::retr_attn_kernel<8, false>; slot = 4; }
+        static SvpsLdsAttr attr[5];
         if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
                            L, HW, H, W, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr);
@@ -914,7 +934,7 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         auto kern = svps::retr_attn_kernel<0, true>;
         if (hipError_t ae = attr_e.ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(svps::retr_logit_stats_kernel, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream,
-                           static_cast<const _Float16*>(qh), static_cast<const _Float16*>(ql), cy, cx, c3, f_, rstd_k, st, L, HW, H, W,
+                           static_cast<const _Float16*>(qh), static_cast<const _Float16*>(ql), cy, cx, c3, f_, a_, st, L, HW, H, W,
                            pl.tiles_per_chunk);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
@@ -981,9 +1001,17 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
     constexpr int M = MODE & 3;
     constexpr bool BAR = (MODE & 4) != 0;
     constexpr int FILL = ((MODE >> 4) & 3) * 2;                  // independent v_fma_f32 after EVERY MFMA (0, 2, 4, 6)
+    constexpr int FKIND = (MODE >> 6) & 3;                       // 1: FILL / 2 v_pk_add_f32 instead; 2: FILL v_exp_f32 instead
     float fv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) fv[i] = (float)(lane + i);
+    float fc1 = 1.0001f, fc2 = 0.25f;
+    asm volatile("" : "+v"(fc1), "+v"(fc2));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t fp[4], fpc = {0.5f, 0.25f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fp[i][0] = (float)lane; fp[i][1] = (float)i; }
+    asm volatile("" : "+v"(fpc));
     f32x16 s, s2;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { s[i] = 0.f; s2[i] = 0.f; }
@@ -1004,7 +1032,7 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
 #pragma unroll
             for (int rep = 0; rep < 16; ++rep)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], 1.0001f, 0.5f);
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(fc1), "v"(fc2));
             const uint32_t tb = lane_row + (uint32_t)(it & 1) * kTileBytes;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) { const f16x8 f = frag(tb, ks); v[ks] += (float)f[0]; }
@@ -1023,7 +1051,25 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) {
                     s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kreg[ks], s, 0, 0, 0);
+                    if constexpr (FILL > 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < FILL; ++i) {
+                            if constexpr (FKIND == 2) asm volatile("v_exp_f32 %0, %1" : "=v"(fv[i]) : "v"(fc1));
+                            else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(fv[i]) : "v"(fc1), "v"(fc2));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[ks], kreg[ks], s, 0, 0, 0);
+                    if constexpr (FILL > 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < FILL; ++i) {
+                            if constexpr (FKIND == 2) asm volatile("v_exp_f32 %0, %1" : "=v"(fv[(i + FILL) & 7]) : "v"(fc2));
+                            else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(fv[(i + FILL) & 7]) : "v"(fc2), "v"(fc1));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             } else if constexpr (M == 3) {
                 f16x8 kf[3][4];
@@ -1058,15 +1104,19 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
                     for (int u = 0; u < 4; ++u) {
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
                         if constexpr (FILL > 0) {
-#pragma unroll
-                            for (int i = 0; i < FILL; ++i) fv[i] = fmaf(fv[i], 1.0001f, 0.5f);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (FKIND == 1) { for (int i = 0; i < FILL / 2; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(fp[i]) : "v"(fpc)); }
+                            else if constexpr (FKIND == 2) { for (int i = 0; i < FILL; ++i) asm volatile("v_exp_f32 %0, %1" : "=v"(fv[i]) : "v"(fc1)); }
+                            else for (int i = 0; i < FILL; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(fv[i]) : "v"(fc1), "v"(fc2));
                             __builtin_amdgcn_sched_barrier(0);
                         }
                         if constexpr (M == 2) s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s2, 0, 0, 0);
                         else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
                         if constexpr (FILL > 0) {
-#pragma unroll
-                            for (int i = 0; i < FILL; ++i) fv[i] = fmaf(fv[i], 0.9999f, 0.25f);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (FKIND == 1) { for (int i = 0; i < FILL / 2; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(fp[(i + FILL / 2) & 3]) : "v"(fpc)); }
+                            else if constexpr (FKIND == 2) { for (int i = 0; i < FILL; ++i) asm volatile("v_exp_f32 %0, %1" : "=v"(fv[(i + FILL) & 7]) : "v"(fc2)); }
+                            else for (int i = 0; i < FILL; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(fv[(i + FILL) & 7]) : "v"(fc2), "v"(fc1));
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -1080,6 +1130,8 @@ __global__ __launch_bounds__(512) void mfma_feed_kernel(unsigned long long* __re
     for (int i = 0; i < 16; ++i) acc += s[i] + s2[i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc += fv[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc += fp[i][0] + fp[i][1];
     if (lane == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
         out[(blockIdx.x * 8 + w) * 2] = t0;
@@ -1096,6 +1148,7 @@ extern "C" int svps_probe_mfma_feed(int mode, int tiles, int nact, int blocks, u
     switch (mode) {
         SVPS_FEED(0) SVPS_FEED(1) SVPS_FEED(2) SVPS_FEED(3) SVPS_FEED(4) SVPS_FEED(5) SVPS_FEED(6) SVPS_FEED(7)
         SVPS_FEED(16) SVPS_FEED(18) SVPS_FEED(32) SVPS_FEED(34) SVPS_FEED(48) SVPS_FEED(50)
+        SVPS_FEED(80) SVPS_FEED(96) SVPS_FEED(112) SVPS_FEED(144) SVPS_FEED(160) SVPS_FEED(17) SVPS_FEED(33) SVPS_FEED(49) SVPS_FEED(145)
         default: return SVPS_ERR_BAD_ARG;
     }
 #undef SVPS_FEED

@@ -7,7 +7,7 @@
 // Both LayerNorms are affine in the projection up to ONE scalar per pixel, the reciprocal standard deviation:
 //     k_p = gamma_k * rstd_k(p) * (W~_k x_p + b~_k) + beta_k        W~ = (I - 11^T/256) W  (centred rows), x_p = f_p + pos_p
 // so the retriever can fold W~_k into the queries and W~_v behind the pixel sum (retr_attn.hip) and needs from the pixel
-// side only rstd_k(p), rstd_v(p). This kernel produces them: 8 B per pixel instead of 1024 B.
+// side only rstd_k(p), rstd_v(p). This kernel produces them: 16 B per pixel instead of 1024 B.
 //
 //     var(p) = |W~ x_p + b~|^2 / 256 = |R x_p + r|^2 / 256,      [W~ | b~] = Q [R | r]  (QR, R upper triangular)
 // The host factorises once per weight (float64) and hands R as FP16: an upper-triangular 256 x 256 matrix has 36 of 64
@@ -21,11 +21,12 @@
 // 32-pixel-wide column strip (tile id = strip * H + row, the order retr_attn.hip uses), so Tx of a lane's pixel column sits
 // in registers for a whole strip and the per-tile position data is one 1-KiB row of Ty, staged by LDS-DMA with the tile.
 //
-// Output per pixel: rstd_k [T, HW] fp32, rstd_v [T, HW] fp32 and a 64-byte "aux" row whose first 16 bytes are
+// Output per pixel: ONE 16-byte "aux" row
 //     { 1, hi(sigma_v), lo(sigma_v), 0 } FP16, { rstd_k, rstd_v } fp32            sigma_v = 1 / rstd_v
-// (the other 48 bytes are not written). The retriever appends the row to the value tile as a ninth 32-channel block: with
-// A = P * rstd_v on the matrix cores its first three columns accumulate s1 = sum_p P rstd_v and s0 = sum_p P (needed for the
-// bias terms) at no vector-ALU cost, and its producers read the two fp32 words from the staged tile.
+// (a tile's 32 rows = 512 contiguous bytes, whole memory lines). The retriever stages the rows with the value tile and uses the
+// four FP16 words as columns of a ninth channel block: with A = P * rstd_v on the matrix cores they accumulate
+// s1 = sum_p P rstd_v and s0 = sum_p P (needed for the bias terms) at no vector-ALU cost; its producers read the two fp32 words
+// from the staged tile.
 //
 // Mapping: 8 waves, two per SIMD. Waves 0-3 = key projection, waves 4-7 = value projection and all LDS-DMA; BOTH read the
 // same operand: the feature tile converted bf16 -> fp16 in place by the wave that staged the piece (exact for
@@ -39,7 +40,13 @@
 
 namespace svps {
 
-constexpr int kStA = 3;                  // LDS-DMA distance: tile t+2+A is requested in the light phase of tile t
+#ifndef SVPS_STNT
+#define SVPS_STNT 0
+#endif
+#ifndef SVPS_STA
+#define SVPS_STA 3
+#endif
+constexpr int kStA = SVPS_STA;                // LDS-DMA distance: tile t+2+A is requested in the light phase of tile t
 constexpr int kStNF = kStA + 3;          // feature ring depth: tiles t .. t+2+A are live
 
 struct StatsPLds {
@@ -66,7 +73,11 @@ __device__ __forceinline__ void st_dma16(u32x4 srd, uint32_t lds_addr, int voff,
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
+#if SVPS_STNT
+        "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
+#else
         "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+#endif
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
@@ -110,7 +121,8 @@ __device__ unsigned long long stats_stamps[2][8][8];     // [key / value][iterat
 #define STATS_STAMP(pt) do {} while (0)
 #endif
 
-// ABL: timing-only ablations (env SVPS_STATS_ABLATE), outputs wrong. 1: no MFMA  2: no conversion  8: no feature DMA after the
+// ABL: timing-only ablations (env SVPS_STATS_ABLATE), outputs wrong. 1: no MFMA  2: no conversion  8: no feature DMA after the prologue  32: no wait for the DMA in the light phase
+//
 // prologue  16: no finish (statistics combine + stores)
 template <bool HAS_POS, int PROJ, int J, int ABL = 0>
 __device__ __forceinline__ void retr_stats_role(
@@ -122,9 +134,7 @@ __device__ __forceinline__ void retr_stats_role(
     const float* __restrict__ rbk,      // [256] r_k (the QR-transformed centred bias)
     const float* __restrict__ rbv,
     float eps_k, float eps_v,
-    float* __restrict__ rstd_k,         // [T, HW]
-    float* __restrict__ rstd_v,         // [T, HW]
-    __bf16* __restrict__ aux,           // [T, HW, 32] (16-bit words)
+    __bf16* __restrict__ aux,           // [T, HW, 8] (16-bit words): 16-byte rows
     int HW, int H, int W, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = StatsPLds;
@@ -198,7 +208,7 @@ __device__ __forceinline__ void retr_stats_role(
     constexpr bool kTyWave = HAS_POS && wv == 7;
     constexpr int nb = 2 + (kTyWave ? 1 : 0);                   // DMA instructions of one batch of this wave
     // stores of one finish() of this wave (they count in vmcnt too): value wave 0 writes the statistics of every tile
-    constexpr int nst = ((ABL & 16) || wv != 4) ? 0 : 2;
+    constexpr int nst = ((ABL & 16) || wv != 4) ? 0 : 1;
     int ds = strip0, dy = row0;                                 // strip / image row of the next batch
     auto stage = [&](int tile) {
         if (tile >= nt) return;
@@ -206,7 +216,14 @@ __device__ __forceinline__ void retr_stats_role(
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (tile % kStNF) * kTileBytes + wv * 2048);
         const int px0 = dy * W + kTilePx * ds;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
-        if (px0 + kTilePx <= HW) {
+        if constexpr ((ABL & 128) != 0) {
+            if constexpr (proj == 0) {
+                st_dma16(frs, st, voff[0], soff);
+                st_dma16(frs, st + 1024, voff[1], soff);
+                st_dma16(frs, st + 8192, voff[0] + 8192, soff);
+                st_dma16(frs, st + 8192 + 1024, voff[1] + 8192, soff);
+            }
+        } else if (px0 + kTilePx <= HW) {
             st_dma16(frs, st, voff[0], soff);
             st_dma16(frs, st + 1024, voff[1], soff);
         } else {                                       // last row of a ragged strip: clamp the source rows (their results are not stored)
@@ -243,7 +260,7 @@ __device__ __forceinline__ void retr_stats_role(
     };
 
     float* stats = reinterpret_cast<float*>(smem + Lds::stats);          // [tile & 1][proj][wave j][px]
-    const u32x4 asrd = st_make_srd(aux + (size_t)t * HW * 32, (uint32_t)HW * 64u);
+    const u32x4 asrd = st_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * 16u);
 
     // fragments: LDS byte address of this lane's 16-B chunk of k-step ks = 8 a + b: (tile + lane_row) ^ (b << 5), + 256 a
     const uint32_t lane_row = lds0 + Lds::fring + r * kRowBytes + ((h ^ swz(r)) << 4);
@@ -251,18 +268,23 @@ __device__ __forceinline__ void retr_stats_role(
     // buffered: the reads of group g+1 are in flight under the MFMAs of group g; the first group of the NEXT tile is requested
     // before the barrier
     constexpr int G0 = (2 * j) / 4;                              // first group that holds a k-step >= 2j
-    f16x8 xf[3][4];                                              // ring of three groups: group g lives in xf[(g - G0) % 3]
+#ifndef SVPS_XFALL
+#define SVPS_XFALL 1
+#endif
+    constexpr int kXR = SVPS_XFALL ? 4 : 3;
+    f16x8 xf[kXR][4];                                            // ring of three groups: group g lives in xf[(g - G0) % 3]
     auto frag = [&](uint32_t tb, int ks) {
         return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
     };
     // the first two groups of a tile are requested in the preceding light phase (an LDS read takes 300 - 500 cycles to come
     // back while the partner waves convert and stage)
     auto prefetch = [&](int tile) {
+        if constexpr (ABL & 64) return;
         const uint32_t tb = lane_row + (uint32_t)(tile % kStNF) * kTileBytes;
 #pragma unroll
-        for (int g = G0; g < (G0 + 2 < 4 ? G0 + 2 : 4); ++g)
+        for (int g = G0; g < (SVPS_XFALL ? 4 : (G0 + 2 < 4 ? G0 + 2 : 4)); ++g)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xf[(g - G0) % 3][u] = frag(tb, 4 * g + u);
+            for (int u = 0; u < 4; ++u) xf[(g - G0) % kXR][u] = frag(tb, 4 * g + u);
     };
     int ts = strip0, tyy = row0;                                 // strip / image row of tile `it`
 
@@ -282,17 +304,17 @@ __device__ __forceinline__ void retr_stats_role(
         }
 #pragma unroll
         for (int grp = G0; grp < 4; ++grp) {
-            if (grp + 2 < 4) {
+            if (!SVPS_XFALL && !(ABL & 64) && grp + 2 < 4) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xf[(grp + 2 - G0) % 3][u] = frag(tb, 4 * (grp + 2) + u);
+                for (int u = 0; u < 4; ++u) xf[(grp + 2 - G0) % kXR][u] = frag(tb, 4 * (grp + 2) + u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int ks = 4 * grp + u;
                 if constexpr (ABL & 1) continue;
-                if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0], xf[(grp - G0) % 3][u], a0, 0, 0, 0);
-                if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0], xf[(grp - G0) % 3][u], a1, 0, 0, 0);
+                if (ks >= 2 * rb0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf0[ks >= 2 * rb0 ? ks - 2 * rb0 : 0], xf[(grp - G0) % kXR][u], a0, 0, 0, 0);
+                if (ks >= 2 * rb1) a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf1[ks >= 2 * rb1 ? ks - 2 * rb1 : 0], xf[(grp - G0) % kXR][u], a1, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -312,13 +334,12 @@ __device__ __forceinline__ void retr_stats_role(
         if (h == 0) stats[(((it & 1) * 2 + proj) * 4 + j) * 32 + r] = tot;
     };
 
-    // statistics of tile `it` -> HBM, by value wave 0 in its light phase: two store instructions per tile.
-    //   lanes h == 0: rstd_k[px] and the 16 meaningful bytes of the aux row {1, hi sigma_v, lo sigma_v, 0 (fp16) | rstd_k, rstd_v (fp32)}
-    //   lanes h == 1: rstd_v[px]
-    // The other 48 bytes of an aux row are never written: as matrix-core columns they only reach accumulator columns nobody reads.
+    // statistics of tile `it` -> HBM, by value wave 0 in its light phase: ONE store instruction per tile, 512 contiguous bytes =
+    // the tile's 32 aux rows of 16 bytes {1, hi sigma_v, lo sigma_v, 0 (fp16) | rstd_k, rstd_v (fp32)}, whole memory lines only.
+    // (Rows written in part - the first layout had 64-byte rows of which 16 were data - make the memory side read each line,
+    // merge and write it back; that read-modify-write traffic in the middle of the feature stream cost a third of the kernel's
+    // streaming rate: 66 -> 96 us in the DMA-only ablation.)
     int fs = strip0, fy = row0;
-    const uint64_t rk_base = reinterpret_cast<uint64_t>(rstd_k + (size_t)t * HW), rv_base = reinterpret_cast<uint64_t>(rstd_v + (size_t)t * HW);
-    const uint64_t aux_dummy = reinterpret_cast<uint64_t>(aux + (size_t)t * HW * 32) + 32;
     auto finish = [&](int it) {
         const int strip = fs, row = fy;
         if (it >= 0) {
@@ -334,24 +355,18 @@ __device__ __forceinline__ void retr_stats_role(
         const float* spv = stats + ((it & 1) * 2 + 1) * 4 * 32 + r;
         const float totk = (spk[0] + spk[32]) + (spk[64] + spk[96]);
         const float totv = (spv[0] + spv[32]) + (spv[64] + spv[96]);
-        // v_rsq_f32 (1 ulp) instead of sqrt + divide: lanes h == 0 need rstd_k and both value terms, lanes h == 1 rstd_v
+        // v_rsq_f32 (1 ulp) instead of sqrt + divide
         const float vark = totk * (1.f / kD) + eps_k, varv = totv * (1.f / kD) + eps_v;
         const float rstdk = __builtin_amdgcn_rsqf(vark);
         const float rstdv = __builtin_amdgcn_rsqf(varv);
         const float sigma = varv * rstdv;
-        {   // one store instruction for both arrays (per-lane 64-bit addresses); lanes without a pixel write into the unwritten
-            // part of this frame's first aux row, so that the instruction is ALWAYS issued: the counted vmcnt waits rely on it
-            const uint64_t a = valid ? (h ? rv_base : rk_base) + (uint64_t)px * 4u : aux_dummy;
-            const float val = h ? rstdv : rstdk;
-            asm volatile("global_store_dword %0, %1, off" : : "v"(a), "v"(val) : "memory");
-        }
         const _Float16 sh = (_Float16)sigma;                                     // FP16 hi + lo (K1' runs its value side in fp16)
         const _Float16 sl = (_Float16)(sigma - (float)sh);
         const _Float16 one = (_Float16)1.0f;
         const uint32_t w0 = (uint32_t)__builtin_bit_cast(uint16_t, one) | ((uint32_t)__builtin_bit_cast(uint16_t, sh) << 16);
         const uint32_t w1 = (uint32_t)__builtin_bit_cast(uint16_t, sl);
         const u32x4 row16 = {w0, w1, __float_as_uint(rstdk), __float_as_uint(rstdv)};
-        const int aoff = (valid && h == 0) ? px * 64 : 0x7ffffff0;           // out of range -> dropped by the hardware range check
+        const int aoff = (valid && h == 0) ? px * 16 : 0x7ffffff0;           // out of range -> dropped by the hardware range check
         asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" : : "v"(row16), "v"(aoff), "s"(asrd) : "memory");
     };
 
@@ -364,13 +379,17 @@ __device__ __forceinline__ void retr_stats_role(
     // before, the key waves three (one tile earlier than strictly needed, so that nobody converts a tile while a key wave
     // already requests its fragments).
     auto light = [&](int t) {
+        [[maybe_unused]] const int it = t;
         constexpr int ahead = proj ? 1 : 2;                      // tile t + ahead: this wave's pieces must be fp16 now
         // landed by now: batch t+ahead - everything except the batches requested after it and the finish() stores issued
         // after it (value wave 0: two per light phase). Steady state: a constant; first / last tiles: everything.
         constexpr int maxy = kStA + 1 - ahead;
-        if (t >= maxy + 1 && t + ahead + maxy <= nt - 1) wait_vm<nb * maxy + nst * (maxy + 1)>();
+        if constexpr (ABL & 32) { if (t + ahead + maxy > nt - 1) wait_vm<0>(); }
+        else if (t >= maxy + 1 && t + ahead + maxy <= nt - 1) wait_vm<nb * maxy + nst * (maxy + 1)>();
         else wait_vm<0>();
+        STATS_STAMP(4);
         convert(t + ahead);
+        STATS_STAMP(5);
         stage(t + 2 + kStA);
         if constexpr (proj == 0) {
             ++tyy;
@@ -414,10 +433,10 @@ template <bool HAS_POS, int ABL = 0>
 __global__ __launch_bounds__(512) void retr_stats_kernel(
     const __bf16* __restrict__ feat, const float* __restrict__ ty, const float* __restrict__ tx,
     const _Float16* __restrict__ rk, const _Float16* __restrict__ rv, const float* __restrict__ rbk, const float* __restrict__ rbv,
-    float eps_k, float eps_v, float* __restrict__ rstd_k, float* __restrict__ rstd_v, __bf16* __restrict__ aux,
+    float eps_k, float eps_v, __bf16* __restrict__ aux,
     int HW, int H, int W, int tiles_per_chunk) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#define SVPS_ROLE(P, JJ) retr_stats_role<HAS_POS, P, JJ, ABL>(feat, ty, tx, rk, rv, rbk, rbv, eps_k, eps_v, rstd_k, rstd_v, aux, HW, H, W, tiles_per_chunk)
+#define SVPS_ROLE(P, JJ) retr_stats_role<HAS_POS, P, JJ, ABL>(feat, ty, tx, rk, rv, rbk, rbv, eps_k, eps_v, aux, HW, H, W, tiles_per_chunk)
     switch (w) {                 // every role runs the same sequence of workgroup barriers
         case 0: SVPS_ROLE(0, 0); break;
         case 1: SVPS_ROLE(0, 1); break;
@@ -434,9 +453,9 @@ __global__ __launch_bounds__(512) void retr_stats_kernel(
 }  // namespace svps
 
 extern "C" int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
-                                   float lnk_eps, const void* rv, const float* rbv, float lnv_eps, float* rstd_k, float* rstd_v,
+                                   float lnk_eps, const void* rv, const float* rbv, float lnv_eps,
                                    void* aux, int T, int H, int W, int D, void* stream_) {
-    if (!feat || !rk || !rbk || !rv || !rbv || !rstd_k || !rstd_v || !aux) return SVPS_ERR_BAD_ARG;
+    if (!feat || !rk || !rbk || !rv || !rbv || !aux) return SVPS_ERR_BAD_ARG;
     if ((ty == nullptr) != (tx == nullptr)) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
@@ -460,17 +479,24 @@ extern "C" int svps_retr_stats_fwd(const void* feat, const float* ty, const floa
             case 3: kern = svps::retr_stats_kernel<true, 3>; slot = 6; break;
             case 11: kern = svps::retr_stats_kernel<true, 11>; slot = 7; break;
             case 27: kern = svps::retr_stats_kernel<true, 27>; slot = 8; break;
+            case 32: kern = svps::retr_stats_kernel<true, 32>; slot = 9; break;
+            case 35: kern = svps::retr_stats_kernel<true, 35>; slot = 10; break;
+            case 51: kern = svps::retr_stats_kernel<true, 51>; slot = 15; break;
+            case 99: kern = svps::retr_stats_kernel<true, 99>; slot = 11; break;
+            case 163: kern = svps::retr_stats_kernel<true, 163>; slot = 12; break;
+            case 227: kern = svps::retr_stats_kernel<true, 227>; slot = 13; break;
+            case 75: kern = svps::retr_stats_kernel<true, 75>; slot = 14; break;
             default: break;
         }
     }
 #endif
-    static SvpsLdsAttr attr[9];
+    static SvpsLdsAttr attr[16];
     if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::StatsPLds::total); ae != hipSuccess)
         return (int)ae;
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::StatsPLds::total, stream, static_cast<const __bf16*>(feat),
                        ty, tx, static_cast<const _Float16*>(rk), static_cast<const _Float16*>(rv), rbk, rbv, lnk_eps, lnv_eps,
-                       rstd_k, rstd_v, static_cast<__bf16*>(aux), HW, H, W, tpc);
+                       static_cast<__bf16*>(aux), HW, H, W, tpc);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);
     return (int)hipGetLastError();
 }

@@ -245,11 +245,11 @@ def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=No
 
 # ---- statistics-fused retriever (csrc/retr_stats.hip, csrc/retr_attn.hip) -------------------------------------------
 def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
-    """K3': per-pixel reciprocal standard deviations of the key / value LayerNorms (+ the aux rows K1' consumes).
+    """K3': per-pixel reciprocal standard deviations of the key / value LayerNorms, as the aux rows K1' consumes.
     feat [T, H*W, 256] bf16; rk / rv [256, 256] fp16: upper-triangular QR factors of the centred projections; rbk / rbv [256]
     fp32; pos_proj = (Ty [H, 256], Tx [W, 256]) fp32, the position tables already multiplied by the key factor
-    (MaskDynamicConv.retr_pos_tables), or None. Returns rstd_k [T, HW], rstd_v [T, HW] fp32, aux [T, HW, 32] fp16 (64-byte rows:
-    {1, hi sigma_v, lo sigma_v, 0 x 5, rstd_k and rstd_v as raw fp32, 0 ...})."""
+    (MaskDynamicConv.retr_pos_tables), or None. Returns aux [T, HW, 8] fp16 = one 16-byte row per pixel:
+    {1, hi sigma_v, lo sigma_v, 0} fp16, {rstd_k, rstd_v} as raw fp32 (retr_stats_unpack gives the two as fp32 views)."""
     lib = _lib.load()
     _need(feat, "feat", torch.bfloat16, 3)
     T, HW, D = feat.shape
@@ -268,14 +268,18 @@ def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
         _need(xtab, "tx", torch.float32, 2)
         if ytab.shape != (H, D) or xtab.shape != (W, D):
             raise ValueError("projected position tables do not match (H, W)")
-    rstd_k = torch.empty((T, HW), dtype=torch.float32, device=feat.device)
-    rstd_v = torch.empty((T, HW), dtype=torch.float32, device=feat.device)
-    aux = torch.empty((T, HW, 32), dtype=torch.float16, device=feat.device)
+    aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat.device)
     with _on(feat, ytab, xtab, rk, rbk, rv, rbv) as ctx:
         rc = lib.svps_retr_stats_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(rk), _ptr(rbk), float(eps_k), _ptr(rv), _ptr(rbv),
-                                     float(eps_v), _ptr(rstd_k), _ptr(rstd_v), _ptr(aux), T, H, W, D, ctx.stream)
+                                     float(eps_v), _ptr(aux), T, H, W, D, ctx.stream)
     _lib.check(rc, "svps_retr_stats_fwd")
-    return rstd_k, rstd_v, aux
+    return aux
+
+
+def retr_stats_unpack(aux):
+    """(rstd_k, rstd_v) [T, HW] fp32: strided views of the two fp32 words of every aux row."""
+    w = aux.view(torch.float32)                                  # [T, HW, 4]
+    return w[..., 2], w[..., 3]
 
 
 def retr_slot_pad(L):
@@ -283,9 +287,9 @@ def retr_slot_pad(L):
     return 128 if L <= 128 else 256
 
 
-def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
+def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0):
     """K1': out_ext [T, L, 272] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
-    rstd_k (Q''.f + cy + cx) + c3. qh / ql [T, LP, 256] fp16 (retr_split), cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
+    rstd_k (Q''.f + cy + cx) + c3 (rstd_k, rstd_v: from the aux rows of retr_stats). qh / ql [T, LP, 256] fp16 (retr_split), cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
     padded to LP = 128 (L <= 128) or 256 (L <= 256; statistics kernel + two retriever launches)."""
     lib = _lib.load()
     _need(qh, "qh", torch.float16, 3)
@@ -294,21 +298,20 @@ def retr_attn(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux, L, H, W, chunks=0):
     _need(aux, "aux", torch.float16, 3)
     for name, x in (("cy", cy), ("cx", cx)):
         _need(x, name, torch.float32, 3)
-    for name, x in (("c3", c3), ("rstd_k", rstd_k), ("rstd_v", rstd_v)):
-        _need(x, name, torch.float32, 2)
+    _need(c3, "c3", torch.float32, 2)
     T, HW, D = feat.shape
     if not 1 <= L <= 256:
         raise ValueError("the fused retriever covers 1 <= L <= 256 slots")
     LP = retr_slot_pad(L)
     if (HW != H * W or qh.shape != (T, LP, D) or ql.shape != (T, LP, D) or cy.shape != (T, H, LP) or cx.shape != (T, W, LP)
-            or c3.shape != (T, LP) or rstd_k.shape != (T, HW) or rstd_v.shape != (T, HW) or aux.shape != (T, HW, 32)):
+            or c3.shape != (T, LP) or aux.shape != (T, HW, 8)):
         raise ValueError("shape mismatch")
     ws_bytes = lib.svps_retr_attn_workspace_bytes(T, L, H, W, chunks)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)
     out = torch.empty((T, L, 272), dtype=torch.float32, device=feat.device)
-    with _on(qh, ql, cy, cx, c3, feat, rstd_k, rstd_v, aux) as ctx:
-        rc = lib.svps_retr_attn_fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(rstd_k), _ptr(rstd_v),
-                                    _ptr(aux), _ptr(ws), ws_bytes, _ptr(out), T, L, H, W, D, chunks, ctx.stream)
+    with _on(qh, ql, cy, cx, c3, feat, aux) as ctx:
+        rc = lib.svps_retr_attn_fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(aux), _ptr(ws), ws_bytes,
+                                    _ptr(out), T, L, H, W, D, chunks, ctx.stream)
     _lib.check(rc, "svps_retr_attn_fwd")
     return out
 

@@ -185,7 +185,7 @@ class MaskDynamicConv(nn.Module):
 
     def forward_fused(self, slots, feat_pm, hw, pos_tabs, stats=None):
         """K3' + K1' (csrc/retr_stats.hip, csrc/retr_attn.hip): slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16.
-        `stats` = (rstd_k, rstd_v, aux) if already computed for this (map, stage)."""
+        `stats` = the aux rows of ops.retr_stats if already computed for this (map, stage)."""
         c = self._fused_consts()
         T, L, C = slots.shape
         H, W = hw
@@ -205,7 +205,7 @@ class MaskDynamicConv(nn.Module):
         else:
             cy = a1[:, None, :].expand(T, H, LP).contiguous()
             cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
-        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats[0], stats[1], stats[2], L, H, W)
+        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W)
         pre = fast_linear(self, "wext", ext, c["wext_lin"])                                          # :456 (value projection after the sum)
         return ops.row_ln(pre, self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)        # :458-459
 

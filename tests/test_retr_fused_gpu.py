@@ -45,10 +45,12 @@ def test_retr_stats(cuda, T, H, W, pos):
     feat = orc.round_bf16(rng.standard_normal((T, HW, 256)).astype(np.float32))
     c = m._fused_consts()
     tabs = ops.pos_embed_sine_tables(H, W, 256, cuda) if pos else None
-    rk, rv, aux = ops.retr_stats(to_bf16_t(feat, cuda), H, W, m.retr_pos_tables(tabs), c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
+    aux = ops.retr_stats(to_bf16_t(feat, cuda), H, W, m.retr_pos_tables(tabs), c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
     torch.cuda.synchronize()
-    aux_raw = aux.cpu().view(torch.int16).numpy().view(np.uint16)               # [T, HW, 32] bf16 bit patterns
-    rk, rv, aux = rk.cpu().numpy(), rv.cpu().numpy(), aux.float().cpu().numpy()
+    assert aux.shape == (T, HW, 8)                                               # ONE 16-byte row per pixel, nothing else is written
+    rk, rv = (x.cpu().numpy() for x in ops.retr_stats_unpack(aux))
+    aux_raw = aux.cpu().view(torch.int16).numpy().view(np.uint16)               # [T, HW, 8] fp16 bit patterns
+    aux = aux.float().cpu().numpy()
     pm = orc.pos_embed_sine(H, W).astype(np.float64) if pos else 0.0
     d = lambda n: P[n].astype(np.float64)
     for t in range(T):
@@ -64,7 +66,7 @@ def test_retr_stats(cuda, T, H, W, pos):
             assert rel.max() <= bound, rel.max()
         sig = 1.0 / rv[t].astype(np.float64)
         assert np.all(aux[t][:, 0] == 1.0) and np.all(aux[t][:, 3] == 0.0)
-        # bytes 8 .. 15 of the row: rstd_k, rstd_v as raw fp32 (what K1's producers read from the staged tile); bytes 16 .. 63 unwritten
+        # bytes 8 .. 15 of the row: rstd_k, rstd_v as raw fp32 (what K1's producers read from the staged tile)
         packed = np.ascontiguousarray(aux_raw[t][:, 4:8]).view(np.float32)
         assert np.array_equal(packed[:, 0], rk[t]) and np.array_equal(packed[:, 1], rv[t])
         assert np.abs(aux[t][:, 1].astype(np.float64) + aux[t][:, 2] - sig).max() <= 3e-5 * sig.max()   # hi + lo: 16-bit mantissa
@@ -135,7 +137,7 @@ def test_full_size_sum_over_slots_properties(cuda, name, T, H, W, L):
             ops.retr_attn = orig
         torch.cuda.synchronize()
         assert torch.equal(out1, out2) and torch.isfinite(out1).all()
-        tau = st[1].double()                                                    # [T, HW]
+        tau = ops.retr_stats_unpack(st)[1].double()                             # rstd_v [T, HW]
         want_a = torch.einsum("tp,tpc->tc", tau, feat.double())                 # sum_p rstd_v f_p
         a_sum = ext1[:, :, :256].double().sum(1)
         scale = want_a.abs().max().item()

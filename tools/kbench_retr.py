@@ -48,6 +48,6 @@ for rep in range(a.reps):
         s_ms, s_n = kt.collect(_lib.KERNEL_RETR_STATS)
         a_ms, a_n = kt.collect(_lib.KERNEL_RETR_ATTN)
     su, au = s_ms / s_n * 1e3, a_ms / a_n * 1e3
-    print(f"rep {rep}: retr_stats {su:7.1f} us ({px * 584 / su / 1e3:6.0f} GB/s, {px * 147456 / su / 1e6:5.0f} TF/s tri)   "
-          f"retr_attn {au:7.1f} us ({px * 584 / au / 1e3:6.0f} GB/s, {px * 4 * a.L * 256 / au / 1e6:5.0f} TF/s alg)   "
+    print(f"rep {rep}: retr_stats {su:7.1f} us ({px * 528 / su / 1e3:6.0f} GB/s, {px * 147456 / su / 1e6:5.0f} TF/s tri)   "
+          f"retr_attn {au:7.1f} us ({px * 528 / au / 1e3:6.0f} GB/s, {px * 4 * a.L * 256 / au / 1e6:5.0f} TF/s alg)   "
           f"abl stats={os.environ.get('SVPS_STATS_ABLATE', '0')} attn={os.environ.get('SVPS_RETR_ABLATE', '0')}", flush=True)

@@ -44,14 +44,20 @@ for nact, what in ((-2, "younger half alone (vector + LDS work)"), (-1, "younger
     d4 = (o[:, 4, 1] - o[:, 4, 0]).astype(np.float64)
     print(f"{what:52s}: wave 4 {np.median(d4) / tiles:7.0f} cycles per tile, wave 0 {np.median(d0) / tiles:7.0f}", flush=True)
 
-# independent vector instructions between the MFMAs of ONE wave's chain (one wave per SIMD): hidden in the matrix shadow or not?
+# independent vector instructions (asm, pinned in place) between the MFMAs of ONE wave's chain, one wave per SIMD: hidden in the
+# matrix shadow or not?
+def run(mode, nact=4):
+    for rep in range(3):
+        out.zero_()
+        rc = lib.svps_probe_mfma_feed(mode, tiles, nact, blocks, out.data_ptr(), sink.data_ptr(), ops._stream_ptr(dev))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(blocks, 8, 2)
+    return np.median((o[:, 0, 1] - o[:, 0, 0]).astype(np.float64)) / (tiles * 32)
+
 for fill in (1, 2, 3):
-    for mode, what in ((0, "one accumulator"), (2, "two accumulators")):
-        for rep in range(3):
-            out.zero_()
-            rc = lib.svps_probe_mfma_feed(mode | (fill << 4), tiles, 4, blocks, out.data_ptr(), sink.data_ptr(), ops._stream_ptr(dev))
-            assert rc == 0, rc
-            torch.cuda.synchronize()
-        o = out.cpu().numpy().reshape(blocks, 8, 2)
-        d = (o[:, 0, 1] - o[:, 0, 0]).astype(np.float64)
-        print(f"{2 * fill} v_fma_f32 after every MFMA, {what:16s}: {np.median(d) / (tiles * 32):6.1f} cycles per MFMA", flush=True)
+    print(f"{2 * fill} v_fma_f32 after every MFMA: B in registers {run(1 | fill << 4):6.1f}, B from LDS one accumulator {run(fill << 4):6.1f}, "
+          f"two accumulators {run(2 | fill << 4):6.1f} cycles per MFMA", flush=True)
+for fill in (1, 2, 3):
+    print(f"{fill} v_pk_add_f32 after every MFMA (B from LDS): {run(64 | fill << 4):6.1f} cycles per MFMA", flush=True)
+print(f"2 v_exp_f32 after every MFMA: B in registers {run(128 | 16 | 1):6.1f}, B from LDS {run(128 | 16):6.1f}; 4 v_exp_f32, B from LDS: {run(128 | 32):6.1f}", flush=True)

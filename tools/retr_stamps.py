@@ -61,10 +61,10 @@ print("cycles per tile (producer 0):", per)
 sst = np.zeros((2, 8, 8), dtype=np.uint64)
 lib.svps_stats_debug_read.argtypes = [ctypes.c_void_p]
 if lib.svps_stats_debug_read(sst.ctypes.data_as(ctypes.c_void_p)) == 0:
-    snames = {0: "loop top", 1: "barrier A done", 2: "first phase (key: heavy, value: light)", 3: "barrier B done",
-              7: "second phase (key: light, value: heavy)"}
+    snames = {0: "loop top", 1: "barrier A done", 2: "first phase (key: heavy, value: light) end", 3: "barrier B done",
+              7: "second phase (key: light, value: heavy) end", 6: "MFMAs done", 4: "own pieces landed", 5: "converted"}
     for role in (0, 1):
-        sorder = [0, 1, 2, 3, 7]
+        sorder = [0, 1, 6, 2, 3, 4, 5, 7] if role == 0 else [0, 1, 4, 5, 2, 3, 6, 7]
         print("--- K3' key wave 0" if role == 0 else "--- K3' value wave 0")
         for it in range(1, 5):
             row = sst[role, it, sorder].astype(np.int64)
