@@ -286,7 +286,7 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
  *   out_ext [T, L, 272] fp32: { A_l = sum_p P rstd_v f_p (256), s1_l = sum_p P rstd_v, s0_l = sum_p P, 0 x 14 };
  *       pre-LayerNorm output (:456) = out_ext @ [ (gamma_v * W~_v)^T ; gamma_v * b~_v ; beta_v ; 0 ]
  *   aux: the rows of svps_retr_stats_fwd
- *   1 <= L <= 256; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 264] fp32
+ *   1 <= L <= 256; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 260] fp32
  *   (+ [T, HW] x 8 B when L > 128: per-pixel softmax statistics over all slots, written by a first kernel; the retriever then
  *   runs once per half of the slots)
  * ------------------------------------------------------------------------------------------- */

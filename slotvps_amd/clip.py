@@ -144,7 +144,7 @@ class SlotClipRunner:
         roofline fractions are computed from. Per pixel and stage (D = 256, L slots):
           retr_stats (K3')  bytes: 512 (map) in + 16 (the aux row: both statistics) out
                             flops: the two triangular products |R x|^2, 36 of 64 blocks each: 2 * (36/64) * 2 * D^2
-          retr_attn  (K1')  bytes: 512 (map) + 16 (aux row) in, + per frame-stage L*D*(2+2) (Q'' hi / lo) + tables (H+W)*128*4 + L*264*4 out
+          retr_attn  (K1')  bytes: 512 (map) + 16 (aux row) in, + per frame-stage L*D*(2+2) (Q'' hi / lo) + tables (H+W)*128*4 + L*260*4 out
                             flops: 4 * L * D (logits + attn.v; the hi / lo splits are not algorithmic)
           kv_project (K3)   bytes: 512 in + 1024 out; flops 4 * D^2
           slot_attn  (K1)   bytes: 1024 in (+ q, out per frame-stage); flops 4 * L * D
@@ -165,7 +165,7 @@ class SlotClipRunner:
             # executed matrix work of K1' per pixel (informational): (4 x 32 producer + 4 x 18 consumer) MFMA 32x32x16 per 32-pixel
             # tile - Q'' is carried as fp16 hi + lo; L <= 128 (the three passes beyond that are not counted here). K1' stages the
             # 16-byte aux row with every pixel.
-            out["retr_attn"] = {"bytes": T * (ps * (512 + 16) + stages * (L * D * 4 + L * 264 * 4) + tabs), "flops": T * ps * 4 * L * D,
+            out["retr_attn"] = {"bytes": T * (ps * (512 + 16) + stages * (L * D * 4 + L * 260 * 4) + tabs), "flops": T * ps * 4 * L * D,
                                 "executed_flops": T * ps * (200 * 32768 // 32)}
         else:
             out["kv_project"] = {"bytes": T * ps * 1536, "flops": T * ps * 4 * D * D}

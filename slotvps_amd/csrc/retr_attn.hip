@@ -48,7 +48,7 @@ constexpr int kAuxRow = 16;                // bytes per pixel of the aux tensor 
 constexpr int kAuxTile = 1024;             // LDS per staged aux tile: 512 B of rows (+ 512 B the upper half of the DMA instruction repeats)
 constexpr int kPTile = 8192;               // P tile: 128 slots x 32 pixels fp16
 constexpr int kCyTile = 1024;              // one LDS-DMA piece: the Cy row of the tile's image row (LP = 128: and the next row)
-constexpr int kPartRow = 264;              // floats per slot row of a partial: 256 channels of A + 8 aux columns
+constexpr int kPartRow = 260;              // floats per slot row of a partial: 256 channels of A + 4 aux columns (every byte of a partial is written)
 constexpr int kExtRow = 272;               // floats per slot row of the finished result: 17 k-steps of 16 for the slot-side product
 
 struct RetrLds {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const float* __restrict__ c3g,      // [T, LP]  log2(e) * q . beta_k; -1e30 in the padded rows
     const __bf16* __restrict__ feat,    // [T, HW, 256]
     const __bf16* __restrict__ aux,     // [T, HW, 8]    retr_stats.hip: 16-byte rows {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32)}
-    float* __restrict__ partial,        // [T, C, Lrow, 264]
+    float* __restrict__ partial,        // [T, C, Lrow, 260]
     int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off,
     const float2* __restrict__ ext_stats) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -329,19 +329,10 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
                     }
-#ifndef SVPS_P2V
-#define SVPS_P2V 0
-#endif
                     if constexpr (P2) {
-                        if constexpr (SVPS_P2V == 0) {
-                            if (grp == 0) p2_factor();
-                            if (grp == 1) { p2_store(0); p2_store(1); }
-                            if (grp == 2) { p2_store(2); p2_store(3); }
-                        } else {
-                            if (grp == 1) p2_factor();
-                            if (grp == 2) { p2_store(0); p2_store(1); }
-                            if (grp == 3) { p2_store(2); p2_store(3); }
-                        }
+                        if (grp == 0) p2_factor();
+                        if (grp == 1) { p2_store(0); p2_store(1); }
+                        if (grp == 2) { p2_store(2); p2_store(3); }
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {                   // one MFMA, then its share of the other work
@@ -349,14 +340,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                         if (u < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         // group 0: its vector work (the normalisation factor) hangs on the statistics read issued at the top of
                         // the iteration - behind the first four MFMAs, so that an in-order wave does not park the chain on it
-                        if constexpr (SVPS_P2V == 0) {
-                            if (grp == 0) { if (u >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
-                            else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                        } else if constexpr (SVPS_P2V == 1) {
-                            if (grp >= 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                        } else {
-                            if (grp >= 1) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                        }
+                        // (placing it a group later, with the stores in groups 2 and 3, measures the same)
+                        if (grp == 0) { if (u >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
+                        else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }

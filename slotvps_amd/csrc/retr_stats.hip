@@ -108,17 +108,26 @@ __device__ __forceinline__ float st_half_swap_add(float x) {
 }
 
 #ifdef SVPS_STATS_STAMP
-// diagnostic build only (tools/retr_stamps.py --kernel stats): s_memtime stamps of one workgroup's key wave 0 and value wave 0
+// diagnostic build only (tools/retr_stamps.py): s_memtime stamps of one workgroup's key wave 0 and value wave 0, kept in LDS
+// (a global store per stamp would count in vmcnt and turn the counted DMA waits into full drains) and copied out at the end
 __device__ unsigned long long stats_stamps[2][8][8];     // [key / value][iteration - 8][point]
 #define STATS_STAMP(pt)                                                                               \
     do {                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         if (blockIdx.x == 3 && blockIdx.y == 2 && j == 0 && it >= 8 && it < 16 && lane == 0)          \
-            stats_stamps[proj][it - 8][pt] = __builtin_amdgcn_s_memtime();                            \
+            reinterpret_cast<unsigned long long*>(smem + StatsPLds::total)[(proj * 8 + (it - 8)) * 8 + pt] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#define STATS_STAMP_DUMP()                                                                            \
+    do {                                                                                              \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && j == 0 && lane < 64) {                              \
+            const unsigned long long* sl_ = reinterpret_cast<const unsigned long long*>(smem + StatsPLds::total); \
+            (&stats_stamps[0][0][0])[proj * 64 + lane] = sl_[proj * 64 + lane];                       \
+        }                                                                                             \
     } while (0)
 #else
 #define STATS_STAMP(pt) do {} while (0)
+#define STATS_STAMP_DUMP() do {} while (0)
 #endif
 
 // ABL: timing-only ablations (env SVPS_STATS_ABLATE), outputs wrong. 1: no MFMA  2: no conversion  8: no feature DMA after the prologue  32: no wait for the DMA in the light phase
@@ -268,10 +277,7 @@ __device__ __forceinline__ void retr_stats_role(
     // buffered: the reads of group g+1 are in flight under the MFMAs of group g; the first group of the NEXT tile is requested
     // before the barrier
     constexpr int G0 = (2 * j) / 4;                              // first group that holds a k-step >= 2j
-#ifndef SVPS_XFALL
-#define SVPS_XFALL 1
-#endif
-    constexpr int kXR = SVPS_XFALL ? 4 : 3;
+    constexpr int kXR = 3;
     f16x8 xf[kXR][4];                                            // ring of three groups: group g lives in xf[(g - G0) % 3]
     auto frag = [&](uint32_t tb, int ks) {
         return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
@@ -282,7 +288,7 @@ __device__ __forceinline__ void retr_stats_role(
         if constexpr (ABL & 64) return;
         const uint32_t tb = lane_row + (uint32_t)(tile % kStNF) * kTileBytes;
 #pragma unroll
-        for (int g = G0; g < (SVPS_XFALL ? 4 : (G0 + 2 < 4 ? G0 + 2 : 4)); ++g)
+        for (int g = G0; g < (G0 + 2 < 4 ? G0 + 2 : 4); ++g)
 #pragma unroll
             for (int u = 0; u < 4; ++u) xf[(g - G0) % kXR][u] = frag(tb, 4 * g + u);
     };
@@ -304,7 +310,7 @@ __device__ __forceinline__ void retr_stats_role(
         }
 #pragma unroll
         for (int grp = G0; grp < 4; ++grp) {
-            if (!SVPS_XFALL && !(ABL & 64) && grp + 2 < 4) {
+            if (!(ABL & 64) && grp + 2 < 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) xf[(grp + 2 - G0) % kXR][u] = frag(tb, 4 * (grp + 2) + u);
             }
@@ -427,6 +433,7 @@ __device__ __forceinline__ void retr_stats_role(
     }
     wg_barrier();
     finish(nt - 1);
+    STATS_STAMP_DUMP();
 }
 
 template <bool HAS_POS, int ABL = 0>
@@ -452,6 +459,11 @@ __global__ __launch_bounds__(512) void retr_stats_kernel(
 
 }  // namespace svps
 
+#ifdef SVPS_STATS_STAMP
+static constexpr int kStampLds = 1024;      // stamps of the diagnostic build behind the kernel's own LDS
+#else
+static constexpr int kStampLds = 0;
+#endif
 extern "C" int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                                    float lnk_eps, const void* rv, const float* rbv, float lnv_eps,
                                    void* aux, int T, int H, int W, int D, void* stream_) {
@@ -491,10 +503,10 @@ extern "C" int svps_retr_stats_fwd(const void* feat, const float* ty, const floa
     }
 #endif
     static SvpsLdsAttr attr[16];
-    if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::StatsPLds::total); ae != hipSuccess)
+    if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::StatsPLds::total + kStampLds); ae != hipSuccess)
         return (int)ae;
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
-    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::StatsPLds::total, stream, static_cast<const __bf16*>(feat),
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::StatsPLds::total + kStampLds, stream, static_cast<const __bf16*>(feat),
                        ty, tx, static_cast<const _Float16*>(rk), static_cast<const _Float16*>(rv), rbk, rbv, lnk_eps, lnv_eps,
                        static_cast<__bf16*>(aux), HW, H, W, tpc);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);

@@ -64,12 +64,12 @@ if lib.svps_stats_debug_read(sst.ctypes.data_as(ctypes.c_void_p)) == 0:
     snames = {0: "loop top", 1: "barrier A done", 2: "first phase (key: heavy, value: light) end", 3: "barrier B done",
               7: "second phase (key: light, value: heavy) end", 6: "MFMAs done", 4: "own pieces landed", 5: "converted"}
     for role in (0, 1):
-        sorder = [0, 1, 6, 2, 3, 4, 5, 7] if role == 0 else [0, 1, 4, 5, 2, 3, 6, 7]
         print("--- K3' key wave 0" if role == 0 else "--- K3' value wave 0")
         for it in range(1, 5):
-            row = sst[role, it, sorder].astype(np.int64)
-            if not row.all():
-                continue
-            d = np.diff(np.concatenate([[sst[role, it - 1, 7].astype(np.int64)], row]))
-            print(f"it {it + 8}: " + "  ".join(f"{snames[k]} +{d[i]}" for i, k in enumerate(sorder)))
+            pts = [k for k in range(8) if sst[role, it, k]]
+            pts.sort(key=lambda k: int(sst[role, it, k]))                       # in time order (the schedule decides it)
+            row = sst[role, it, pts].astype(np.int64)
+            prev = max(int(x) for x in sst[role, it - 1] if x)
+            d = np.diff(np.concatenate([[prev], row]))
+            print(f"it {it + 8}: " + "  ".join(f"{snames[k]} +{d[i]}" for i, k in enumerate(pts)))
     print("cycles per tile (K3' key wave 0):", (sst[0, 7, 0].astype(np.int64) - sst[0, 1, 0].astype(np.int64)) / 6)
