@@ -298,21 +298,24 @@ __device__ __forceinline__ void retr_stats_role(
     auto heavy = [&](int it) {
         const uint32_t tb = lane_row + (uint32_t)(it % kStNF) * kTileBytes;
         f32x16 a0 = b0, a1 = b1;
-        // key side: the Ty row of the tile, requested now and added AFTER the MFMAs (nothing waits for it)
+        // key side: the Ty row of the tile, added AFTER the MFMAs; requested behind the last fragment group (LDS returns in
+        // order: requested first, its eight reads delayed every fragment of the tile)
         f32x4 y0[4], y1[4];
-        if constexpr (HAS_POS && proj == 0) {
-            const float* tyl = reinterpret_cast<const float*>(smem + Lds::tyring + (it % kStNF) * 1024);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                y0[g] = *reinterpret_cast<const f32x4*>(tyl + 32 * rb0 + 8 * g + 4 * h);
-                y1[g] = *reinterpret_cast<const f32x4*>(tyl + 32 * rb1 + 8 * g + 4 * h);
-            }
-        }
 #pragma unroll
         for (int grp = G0; grp < 4; ++grp) {
             if (!(ABL & 64) && grp + 2 < 4) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) xf[(grp + 2 - G0) % kXR][u] = frag(tb, 4 * (grp + 2) + u);
+            }
+            if constexpr (HAS_POS && proj == 0) {
+                if (grp == 1) {                                  // the iteration that requests the last group (G0 <= 1)
+                    const float* tyl = reinterpret_cast<const float*>(smem + Lds::tyring + (it % kStNF) * 1024);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        y0[g] = *reinterpret_cast<const f32x4*>(tyl + 32 * rb0 + 8 * g + 4 * h);
+                        y1[g] = *reinterpret_cast<const f32x4*>(tyl + 32 * rb1 + 8 * g + 4 * h);
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -346,6 +349,17 @@ __device__ __forceinline__ void retr_stats_role(
     // merge and write it back; that read-modify-write traffic in the middle of the feature stream cost a third of the kernel's
     // streaming rate: 66 -> 96 us in the DMA-only ablation.)
     int fs = strip0, fy = row0;
+    // the eight partial sums of this lane's pixel, requested at the top of the light phase that stores them (the LDS latency runs
+    // under the wait for the DMA and the conversion)
+    float fin[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto finish_request = [&](int it) {
+        if constexpr (wv != 4) return;
+        if constexpr (ABL & 16) return;
+        const float* spk = stats + ((it & 1) * 2 + 0) * 4 * 32 + r;
+        const float* spv = stats + ((it & 1) * 2 + 1) * 4 * 32 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { fin[q] = spk[32 * q]; fin[4 + q] = spv[32 * q]; }
+    };
     auto finish = [&](int it) {
         const int strip = fs, row = fy;
         if (it >= 0) {
@@ -357,10 +371,8 @@ __device__ __forceinline__ void retr_stats_role(
         const int xx = kTilePx * strip + r;
         const int px = row * W + xx;
         const bool valid = xx < W && it >= 0;                            // pixels past the right edge of the map: not stored
-        const float* spk = stats + ((it & 1) * 2 + 0) * 4 * 32 + r;
-        const float* spv = stats + ((it & 1) * 2 + 1) * 4 * 32 + r;
-        const float totk = (spk[0] + spk[32]) + (spk[64] + spk[96]);
-        const float totv = (spv[0] + spv[32]) + (spv[64] + spv[96]);
+        const float totk = (fin[0] + fin[1]) + (fin[2] + fin[3]);
+        const float totv = (fin[4] + fin[5]) + (fin[6] + fin[7]);
         // v_rsq_f32 (1 ulp) instead of sqrt + divide
         const float vark = totk * (1.f / kD) + eps_k, varv = totv * (1.f / kD) + eps_v;
         const float rstdk = __builtin_amdgcn_rsqf(vark);
@@ -386,6 +398,7 @@ __device__ __forceinline__ void retr_stats_role(
     // already requests its fragments).
     auto light = [&](int t) {
         [[maybe_unused]] const int it = t;
+        if constexpr (proj == 1) finish_request(t - 1);
         constexpr int ahead = proj ? 1 : 2;                      // tile t + ahead: this wave's pieces must be fp16 now
         // landed by now: batch t+ahead - everything except the batches requested after it and the finish() stores issued
         // after it (value wave 0: two per light phase). Steady state: a constant; first / last tiles: everything.
@@ -432,6 +445,7 @@ __device__ __forceinline__ void retr_stats_role(
         STATS_STAMP(7);
     }
     wg_barrier();
+    finish_request(nt - 1);
     finish(nt - 1);
     STATS_STAMP_DUMP();
 }
