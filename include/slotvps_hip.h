@@ -196,6 +196,18 @@ int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, 
 int svps_slot_gemm(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, int act, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K9 small batched products of the slot side (slotvps_amd/csrc/bgemm.hip), the products K8 does not take because their B
+ * operand is an activation: the slot <-> slot retriever of the temporal head, k q^T and softmax(.)^T v
+ * (dynamic_mask_head.py:550-572), the separable position terms of the fused retriever, the 20-column class projection (:398).
+ *     C[b, m, n] = alpha * sum_k A[b, m, k] B[b, n, k] (+ bias[b, n])
+ * fp32 in / out, split-bf16 products on the matrix cores with fp32 accumulation (fp32-class, as K8).
+ *   sa = {batch, m, k}, sb = {batch, n, k}, sc = {batch, m, n}, sbias = {batch, n}: ELEMENT strides (a transposed operand is a
+ *   stride pattern, batch stride 0 a shared operand); bias / sbias may be NULL. 1 <= batch <= 65535, any M, N, K >= 1.
+ * ------------------------------------------------------------------------------------------- */
+int svps_bgemm(const float* a, const long long* sa, const float* b, const long long* sb, const float* bias,
+               const long long* sbias, float* c, const long long* sc, int batch, int M, int N, int K, float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K6 full-resolution panoptic post-process (PostProcessPanopticInstances.mask_removal / get_ids_area,
  * mmdet/models/detectors/vps_temporal_slots.py:564-657, :697-698, :724-757; argmax + relabel of simple_test
  * :411-435). Bilinear upsampling to H x W is fused into both kernels; the order-dependent part of

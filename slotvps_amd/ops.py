@@ -400,6 +400,51 @@ def slot_gemm(x, wpack, bias=None, act=ACT_NONE, out=None):
     return out
 
 
+def bgemm(a, b, bias=None, alpha=1.0, out=None):
+    """K9: C[g, m, n] = alpha * sum_k a[g, m, k] b[g, n, k] (+ bias[g, n]) for fp32 tensors of ANY strides (views, transposes,
+    expand()ed batch dimensions): a [G, M, K] or [M, K], b [G, N, K] or [N, K], bias [G, N], [N] or None. Split-bf16 matrix-core
+    products with fp32 accumulation (fp32-class; csrc/bgemm.hip). Returns [G, M, N] fp32 (or `out`, any strides)."""
+    lib = _lib.load()
+    _need_any(a, "a")
+    _need_any(b, "b")
+    a3 = a if a.dim() == 3 else a.unsqueeze(0)
+    b3 = b if b.dim() == 3 else b.unsqueeze(0)
+    if a3.dim() != 3 or b3.dim() != 3 or a3.shape[2] != b3.shape[2]:
+        raise ValueError("bgemm: a [G, M, K] and b [G, N, K] must share K")
+    G = max(a3.shape[0], b3.shape[0])
+    if a3.shape[0] not in (1, G) or b3.shape[0] not in (1, G):
+        raise ValueError("bgemm: batch sizes do not broadcast")
+    M, K, N = a3.shape[1], a3.shape[2], b3.shape[1]
+    sa = [a3.stride(0) if a3.shape[0] == G and G > 1 else 0, a3.stride(1), a3.stride(2)]
+    sb = [b3.stride(0) if b3.shape[0] == G and G > 1 else 0, b3.stride(1), b3.stride(2)]
+    if out is None:
+        out = torch.empty((G, M, N), dtype=torch.float32, device=a.device)
+    elif out.shape != (G, M, N) or out.dtype != torch.float32:
+        raise ValueError("bgemm: out must be fp32 [G, M, N]")
+    sc = list(out.stride())
+    sbias = None
+    if bias is not None:
+        _need_any(bias, "bias")
+        b2 = bias if bias.dim() == 2 else bias.unsqueeze(0)
+        if b2.shape[-1] != N or b2.shape[0] not in (1, G):
+            raise ValueError("bgemm: bias must be [G, N] or [N]")
+        sbias = [b2.stride(0) if b2.shape[0] == G and G > 1 else 0, b2.stride(1)]
+    arr = lambda v: (ctypes.c_longlong * len(v))(*v)
+    with _on(a, b, bias, out) as ctx:
+        rc = lib.svps_bgemm(_ptr(a), arr(sa), _ptr(b), arr(sb), _ptr(bias), arr(sbias) if sbias else None, _ptr(out), arr(sc),
+                            G, M, N, K, float(alpha), ctx.stream)
+    _lib.check(rc, "svps_bgemm")
+    return out
+
+
+def _need_any(t, name):
+    """fp32 CUDA tensor of any strides (K9 takes element strides)."""
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float32:
+        raise TypeError(f"{name}: fp32 tensor expected")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP path needs a GPU tensor (no CPU fallback)")
+
+
 # ---- exact mode: fp32 storage, fp32 arithmetic (csrc/exact_f32.hip) ---------------------------------------------
 F32 = torch.float32
 

@@ -200,8 +200,9 @@ class MaskDynamicConv(nn.Module):
         qh, ql = ops.retr_split(q2)
         if pos_tabs is not None:                                           # separable position terms + a' (two small tables per frame)
             ytab, xtab = pos_tabs
-            cy = torch.baddbmm(a1[:, None, :], ytab.expand(T, -1, -1), q2[:, :, :C // 2].transpose(1, 2))
-            cx = torch.matmul(xtab, q2[:, :, C // 2:].transpose(1, 2))
+            # K9: cy[t, y, l] = a'[t, l] + ytab[y] . Q''[t, l, :128], cx[t, x, l] = xtab[x] . Q''[t, l, 128:] (shared tables: batch stride 0)
+            cy = ops.bgemm(ytab, q2[:, :, :C // 2], bias=a1)
+            cx = ops.bgemm(xtab, q2[:, :, C // 2:])
         else:
             cy = a1[:, None, :].expand(T, H, LP).contiguous()
             cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
@@ -302,8 +303,13 @@ class SlotsDynamicConv(nn.Module):
             qkv = ops.row_ln(qkv, g3, e3, self.norm_q.eps, rows_per_group=x.shape[0])
             q, k, v = (qkv[i].view(groups, -1, self.hidden_dim) for i in range(3))
         # softmax over the QUERY axis (dim=1 of [1, Lq, Lk], :562) = last-dim softmax of the transposed logits
-        attn_t = torch.softmax(k @ q.transpose(-1, -2), dim=-1)     # [1, Lk, Lq]
-        out = (attn_t.transpose(-1, -2) @ v).reshape(1, -1, self.hidden_dim)
+        if self.precision != "fp32" and self.use_slot_gemm and q.is_cuda:
+            # K9 (csrc/bgemm.hip): both products on the matrix cores in split bf16; the second one reads attn_t k-major
+            attn_t = torch.softmax(ops.bgemm(k, q), dim=-1)                     # [G, Lk, Lq]
+            out = ops.bgemm(attn_t.transpose(1, 2), v.transpose(1, 2)).view(1, -1, self.hidden_dim)
+        else:
+            attn_t = torch.softmax(k @ q.transpose(-1, -2), dim=-1)     # [1, Lk, Lq]
+            out = (attn_t.transpose(-1, -2) @ v).reshape(1, -1, self.hidden_dim)
         return ops.row_ln(out.contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)
 
 
@@ -433,7 +439,11 @@ class MaskRCNNHead(nn.Module):
             else:
                 y2 = torch.bmm(x, w2)
             x = ops.row_ln(y2, g2, e2, nc.eps, relu=True, rows_per_group=T * L)                             # :394-397
-        return self.class_logits(x[0].reshape(T, L, C)), x[1].reshape(T, L, C)
+        if self.precision != "fp32" and self.use_slot_gemm and x.is_cuda:            # :398 on K9 (20 columns: not a K8 shape)
+            cls = ops.bgemm(x[0], self.class_logits.weight, bias=self.class_logits.bias).view(T, L, -1)
+        else:
+            cls = self.class_logits(x[0].reshape(T, L, C))
+        return cls, x[1].reshape(T, L, C)
 
     def forward_pm(self, slots, feat_pm, hw, pos_tabs, stage_enable, clips=1):
         T, L, C = slots.shape
