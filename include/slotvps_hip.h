@@ -194,6 +194,13 @@ int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, 
  *   bias [N] fp32 or NULL; act 0 none / 1 ReLU / 2 GELU (erf form); y [M, N] fp32.  K % 16 == 0, N % 256 == 0.
  * ------------------------------------------------------------------------------------------- */
 int svps_slot_gemm(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, int act, void* stream);
+/* the same product for N = 256 with the step that follows most dense layers of the slot update fused into the launch
+ * (dynamic_mask_head.py:356-358, :374-376, :384-385, :394-397, :458-459, :515-525):
+ *     y = LN(x W^T + bias [+ pre]) * gamma + beta  (+ReLU if relu)  (+ post)
+ * LayerNorm over the 256 columns, biased variance, two-pass - the arithmetic of svps_row_ln operation for operation, so the
+ * result is bitwise the one of svps_slot_gemm followed by svps_row_ln. pre / post [M, 256] fp32 or NULL. */
+int svps_slot_gemm_ln(const float* x, const void* wpack, const float* bias, const float* pre, const float* post,
+                      const float* gamma, const float* beta, float eps, int relu, float* y, int M, int K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9 small batched products of the slot side (slotvps_amd/csrc/bgemm.hip), the products K8 does not take because their B

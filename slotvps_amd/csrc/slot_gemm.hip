@@ -14,6 +14,10 @@
 // (double-buffered, one barrier per chunk), every wave reads its A fragments from there and streams its B fragments from
 // L2 in fragment order (1 KiB per wave instruction, each byte of the weight once per workgroup).
 // Epilogue: + bias[n], ReLU or GELU (exact erf form, F.gelu's default), fp32 store (32 consecutive columns per half-wave).
+// LN epilogue (svps_slot_gemm_ln, N = 256: the workgroup holds whole rows): the tile goes through LDS instead of HBM and the
+// step that follows most dense layers of the slot update,  y = LN(gemm [+ pre]) * gamma + beta (+ReLU) (+post), runs in the
+// same launch - one wave per row with the arithmetic of svps_row_ln, operation for operation (results bitwise equal to the
+// two-launch form).
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -28,19 +32,36 @@ struct GemmLds {
     static constexpr int buf_bytes = 2 * kGmRows * kGmRow;      // hi | lo
     static constexpr int nbuf = 4;                              // K <= 256: every chunk of the A tile is staged up front
     static constexpr int total = nbuf * buf_bytes;
+    static constexpr int ln_row = kGmCols * 4 + 16;            // LN epilogue: fp32 rows of the output tile, padded (bank spread of the two lane halves)
 };
+static_assert(kGmRows * GemmLds::ln_row <= GemmLds::total, "the LN epilogue reuses the staging buffers");
+
+struct GemmLn {                              // arguments of the LN epilogue
+    const float* pre;                        // [M, 256] added before the LayerNorm, or null
+    const float* post;                       // [M, 256] added after it, or null
+    const float* gamma;
+    const float* beta;
+    float eps;
+    int relu;
+};
+
+__device__ __forceinline__ float gm_wave_sum(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+    return x;
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // ACT: 0 none, 1 ReLU, 2 GELU (erf); RBW: row blocks per workgroup (2 or 1); PREF: weights of the next chunk requested before
 // this chunk's MFMAs (register double buffer, 192 registers: one workgroup per CU - for launches that do not fill the chip
 // several times over; wide layers run several 110-register workgroups per CU instead, which hide the latency by themselves)
-template <int ACT, int RBW, bool PREF>
+template <int ACT, int RBW, bool PREF, bool LN = false>
 __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict__ x,        // [M, K]
                                                         const __bf16* __restrict__ wpack,   // [N/32][K/16][2][64][8]
                                                         const float* __restrict__ bias,     // [N] or null
                                                         float* __restrict__ y,              // [M, N]
-                                                        int M, int K, int N) {
+                                                        int M, int K, int N, GemmLn ln = GemmLn{}) {
     __shared__ __attribute__((aligned(16))) char smem[GemmLds::total];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,6 +226,49 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
         }
     }
 
+    if constexpr (LN) {
+        // ---- LN epilogue (N == 256, ACT == 0): tile -> LDS, then one wave per row exactly as svps_row_ln does it
+        // the residual rows and the affine pair are requested FIRST: their latency (HBM for `pre`) runs under the LDS transpose
+        constexpr int RPW = ROWS / 8;                           // rows per wave
+        float4 pv[RPW], qv[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int m = m0 + w + 8 * j;
+            const size_t base = (size_t)(m < M ? m : M - 1) * 256 + 4 * lane;
+            pv[j] = ln.pre ? *reinterpret_cast<const float4*>(ln.pre + base) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qv[j] = ln.post ? *reinterpret_cast<const float4*>(ln.post + base) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 ww = *reinterpret_cast<const float4*>(ln.gamma + 4 * lane);
+        const float4 bb = *reinterpret_cast<const float4*>(ln.beta + 4 * lane);
+        __syncthreads();                                        // every wave is done with the staged A tile
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int col = 32 * NB * cg + 32 * b + r;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = 32 * rb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                *reinterpret_cast<float*>(smem + row * GemmLds::ln_row + col * 4) = acc[b][i] + bv;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int row = w + 8 * j, m = m0 + row;
+            if (m >= M) break;
+            float4 v = *reinterpret_cast<const float4*>(smem + row * GemmLds::ln_row + 16 * lane);
+            if (ln.pre) { v.x += pv[j].x; v.y += pv[j].y; v.z += pv[j].z; v.w += pv[j].w; }
+            const float mean = gm_wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+            const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+            const float var = gm_wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
+            const float rstd = rsqrtf(var + ln.eps);
+            float4 o = make_float4(dx * rstd * ww.x + bb.x, dy * rstd * ww.y + bb.y, dz * rstd * ww.z + bb.z, dw * rstd * ww.w + bb.w);
+            if (ln.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (ln.post) { o.x += qv[j].x; o.y += qv[j].y; o.z += qv[j].z; o.w += qv[j].w; }
+            *reinterpret_cast<float4*>(y + (size_t)m * 256 + 4 * lane) = o;
+        }
+        return;
+    }
     // ---- epilogue: register i of a block = row (i & 3) + 8 (i >> 2) + 4 h, column = lane r
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -229,9 +293,11 @@ extern "C" int svps_slot_gemm(const float* x, const void* wpack, const float* bi
     if (M <= 0 || K <= 0 || (K & 15) || N <= 0 || (N % svps::kGmCols) || act < 0 || act > 2) return SVPS_ERR_BAD_SHAPE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const __bf16* wp = static_cast<const __bf16*>(wpack);
-    // 64-row tiles unless that leaves most of the chip idle (the 256-column layers on 8 000 rows: 125 workgroups): 32-row tiles then
+    // 32-row tiles (112 registers: two workgroups per CU hide each other's latencies) unless 64-row tiles already give every CU two
+    // workgroups: the 256-column layers on 16 000 rows are 250 tiles of 64 rows - one per CU, a launch of pure latency (27 us
+    // against 20 with 500 tiles of 32 rows; step 37.7 -> 37.2 ms)
     const int wg64 = ((M + 63) / 64) * (N / svps::kGmCols);
-    const bool small = wg64 < (3 * svps_num_cus()) / 4;
+    const bool small = wg64 < 2 * svps_num_cus();
     const int rows = small ? 32 : 64;
     const dim3 grid((M + rows - 1) / rows, N / svps::kGmCols);
 #define SVPS_GEMM(A, R, P) hipLaunchKernelGGL((svps::slot_gemm_kernel<A, R, P>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N)
@@ -244,5 +310,25 @@ extern "C" int svps_slot_gemm(const float* x, const void* wpack, const float* bi
         if (act == 0) SVPS_GEMM(0, 2, true); else if (act == 1) SVPS_GEMM(1, 2, true); else SVPS_GEMM(2, 2, true);
     }
 #undef SVPS_GEMM
+    return (int)hipGetLastError();
+}
+
+extern "C" int svps_slot_gemm_ln(const float* x, const void* wpack, const float* bias, const float* pre, const float* post,
+                                 const float* gamma, const float* beta, float eps, int relu, float* y, int M, int K,
+                                 void* stream_) {
+    if (!x || !wpack || !y || !gamma || !beta) return SVPS_ERR_BAD_ARG;
+    if (M <= 0 || K <= 0 || (K & 15)) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const __bf16* wp = static_cast<const __bf16*>(wpack);
+    const int N = svps::kGmCols;
+    const svps::GemmLn ln{pre, post, gamma, beta, eps, relu};
+    const int wg64 = (M + 63) / 64;
+    const bool small = wg64 < 2 * svps_num_cus();
+    const int rows = small ? 32 : 64;
+    const dim3 grid((M + rows - 1) / rows, 1);
+    const bool wide = wg64 > svps_num_cus();
+#define SVPS_GEMM_LN(R, P) hipLaunchKernelGGL((svps::slot_gemm_kernel<0, R, P, true>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N, ln)
+    if (small) SVPS_GEMM_LN(1, true); else if (wide) SVPS_GEMM_LN(2, false); else SVPS_GEMM_LN(2, true);
+#undef SVPS_GEMM_LN
     return (int)hipGetLastError();
 }

@@ -400,6 +400,37 @@ def slot_gemm(x, wpack, bias=None, act=ACT_NONE, out=None):
     return out
 
 
+def slot_gemm_ln(x, wpack, bias, gamma, beta, eps=1e-5, pre=None, post=None, relu=False, out=None):
+    """K8 with the LayerNorm step fused into the launch: y = LN(x @ W^T + bias [+ pre]) * gamma + beta (+ReLU) (+post) for
+    N = 256; bitwise the result of slot_gemm followed by row_ln."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    _need(wpack, "wpack", torch.bfloat16, 5)
+    K = x.shape[-1]
+    M = x.numel() // K
+    if wpack.shape[0] * 32 != D_MODEL or wpack.shape[1] * 16 != K:
+        raise ValueError(f"slot_gemm_ln: x[..., {K}] does not match the packed weight {tuple(wpack.shape)} or N != 256")
+    shape = x.shape[:-1] + (D_MODEL,)
+    for name, tns in (("pre", pre), ("post", post)):
+        if tns is not None:
+            _need(tns, name, torch.float32)
+            if tns.numel() != M * D_MODEL:
+                raise ValueError(f"{name} shape mismatch")
+    _need(gamma, "gamma", torch.float32, 1)
+    _need(beta, "beta", torch.float32, 1)
+    if bias is not None:
+        _need(bias, "bias", torch.float32, 1)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    elif out.shape != shape or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("slot_gemm_ln: out must be a contiguous fp32 tensor of shape x.shape[:-1] + (256,)")
+    with _on(x, wpack, bias, pre, post, gamma, beta, out) as ctx:
+        rc = lib.svps_slot_gemm_ln(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(pre), _ptr(post), _ptr(gamma), _ptr(beta), float(eps),
+                                   int(bool(relu)), _ptr(out), M, K, ctx.stream)
+    _lib.check(rc, "svps_slot_gemm_ln")
+    return out
+
+
 def bgemm(a, b, bias=None, alpha=1.0, out=None):
     """K9: C[g, m, n] = alpha * sum_k a[g, m, k] b[g, n, k] (+ bias[g, n]) for fp32 tensors of ANY strides (views, transposes,
     expand()ed batch dimensions): a [G, M, K] or [M, K], b [G, N, K] or [N, K], bias [G, N], [N] or None. Split-bf16 matrix-core

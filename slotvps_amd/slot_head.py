@@ -77,6 +77,26 @@ def fast_linear(owner, name, x, weight, bias=None, act=None, out=None):
     return ops.slot_gemm(x.contiguous(), wp, bias, code, out)
 
 
+def fast_linear_ln(owner, name, x, weight, bias, norm, pre=None, post=None, relu=False, out=None):
+    """LN(x @ weight^T + bias [+ pre]) (+ReLU) (+post) for a 256-column layer followed by `norm` (nn.LayerNorm or a
+    (gamma, beta, eps) triple): bf16 mode = ONE launch of K8 with the LayerNorm epilogue (csrc/slot_gemm.hip), bitwise the
+    two-launch form; otherwise fast_linear + K5."""
+    gamma, beta, eps = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else norm
+    N, K = weight.shape
+    if (getattr(owner, "precision", "bf16") == "fp32" or N != 256 or K % 16 or not x.is_cuda or not owner.use_slot_gemm
+            or not getattr(owner, "fuse_ln", True)):
+        y = fast_linear(owner, name, x, weight, bias)
+        y = ops.row_ln(y.contiguous(), gamma, beta, eps, pre=None if pre is None else pre.contiguous().view_as(y),
+                       post=None if post is None else post.contiguous().view_as(y), relu=relu)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    wp = _cached(owner, "wp_" + name, [weight], lambda: ops.pack_b_fragments(weight))
+    return ops.slot_gemm_ln(x.contiguous(), wp, bias, gamma, beta, eps, pre=None if pre is None else pre.contiguous(),
+                            post=None if post is None else post.contiguous(), relu=relu, out=out)
+
+
 def _act_name(fn):
     return "relu" if fn is F.relu else ("gelu" if fn is F.gelu else None)
 
@@ -207,8 +227,8 @@ class MaskDynamicConv(nn.Module):
             cy = a1[:, None, :].expand(T, H, LP).contiguous()
             cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
         ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W)
-        pre = fast_linear(self, "wext", ext, c["wext_lin"])                                          # :456 (value projection after the sum)
-        return ops.row_ln(pre, self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)        # :458-459
+        # :456 (value projection after the sum) + :458-459 (norm1, ReLU) in one launch
+        return fast_linear_ln(self, "wext", ext, c["wext_lin"], None, self.norm1, relu=True)
 
     def project_kv(self, feat_pm, hw, pos_tabs):
         """K3: feat_pm [T, H*W, C] bf16, hw = (H, W), pos_tabs = (ytab, xtab) or None -> k, v bf16."""
@@ -296,11 +316,11 @@ class SlotsDynamicConv(nn.Module):
             e3 = _cached(self, "e3", [m.bias for m in norms], lambda: torch.stack([m.bias for m in norms]).contiguous())
             if self.precision != "fp32" and self.use_slot_gemm and x.is_cuda:
                 qkv = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=x.device)
-                for i, m in enumerate(lins):                                        # three K8 launches into one [3, M, C] buffer
-                    fast_linear(self, f"qkv{i}", x, m.weight, m.bias, out=qkv[i])
+                for i, (m, nm) in enumerate(zip(lins, norms)):                      # three K8 launches (projection + its LayerNorm) into one [3, M, C] buffer
+                    fast_linear_ln(self, f"qkv{i}", x, m.weight, m.bias, nm, out=qkv[i])
             else:
                 qkv = torch.baddbmm(b3, x.unsqueeze(0).expand(3, -1, -1), w3)        # [3, M, C]
-            qkv = ops.row_ln(qkv, g3, e3, self.norm_q.eps, rows_per_group=x.shape[0])
+                qkv = ops.row_ln(qkv, g3, e3, self.norm_q.eps, rows_per_group=x.shape[0])
             q, k, v = (qkv[i].view(groups, -1, self.hidden_dim) for i in range(3))
         # softmax over the QUERY axis (dim=1 of [1, Lq, Lk], :562) = last-dim softmax of the transposed logits
         if self.precision != "fp32" and self.use_slot_gemm and q.is_cuda:
@@ -342,9 +362,8 @@ class TemporalSlotsHead(nn.Module):
         r = self.inst_interact(x, f, pos, groups=groups)
         u = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x.contiguous())          # :515-517
         hid = fast_linear(self, "linear1", u, self.linear1.weight, self.linear1.bias, act=_act_name(self.activation))
-        y = fast_linear(self, "linear2", hid, self.linear2.weight, self.linear2.bias)                         # :520
-        out = ops.row_ln(y, self.norm3.weight, self.norm3.bias, self.norm3.eps, pre=u,
-                         post=x.contiguous() if add_input else None)                                          # :524-525
+        out = fast_linear_ln(self, "linear2", hid, self.linear2.weight, self.linear2.bias, self.norm3, pre=u,
+                             post=x.contiguous() if add_input else None)                                      # :520, :524-525
         return out.squeeze(0)
 
 
@@ -383,8 +402,10 @@ class MaskRCNNHead(nn.Module):
         self.precision = "bf16"
         self.use_slot_gemm = True
 
-    def _self_attention(self, slots):
-        """nn.MultiheadAttention(self_attn)(x, x, x) for frames-as-batch slots [T, L, C] (:346-355), with the module's own
+    def _self_attention(self, slots, residual_norm=False):
+        """residual_norm: return norm1(slots + attention) (:356-358) instead of the attention output - in bf16 mode the
+        LayerNorm then rides in the epilogue of the output projection.
+        nn.MultiheadAttention(self_attn)(x, x, x) for frames-as-batch slots [T, L, C] (:346-355), with the module's own
         parameters but without its sequence-first layout: the packed projection runs on the contiguous [T*L, C] rows and
         the attention kernel reads q / k / v as strided views of its output ([T, L, heads, 32] is the layout that kernel
         uses internally), so no transposed copy is made on the way in or out."""
@@ -399,20 +420,23 @@ class MaskRCNNHead(nn.Module):
         elif C // nh == 32 and L <= 256:
             # the library's own kernel for these tiny (L x L x 32 per head) problems, on the packed projection as it stands
             o = ops.slot_self_attn(qkv.view(T, L, 3 * C), nh)
+            if residual_norm:
+                return fast_linear_ln(self, "out_proj", o, mha.out_proj.weight, mha.out_proj.bias, self.norm1, pre=slots)
             return fast_linear(self, "out_proj", o, mha.out_proj.weight, mha.out_proj.bias)
         else:
             o = F.scaled_dot_product_attention(q, k, v)                     # softmax(q k^T / sqrt(C / heads)) v
-        return F.linear(o.transpose(1, 2).reshape(T, L, C), mha.out_proj.weight, mha.out_proj.bias)
+        a = F.linear(o.transpose(1, 2).reshape(T, L, C), mha.out_proj.weight, mha.out_proj.bias)
+        if residual_norm:
+            return ops.row_ln(a, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre=slots)
+        return a
 
     def forward_till_ffn_pm(self, slots, feat_pm, hw, pos_tabs):
         """:342-388 for all frames at once. slots [T, L, C] fp32 contiguous."""
-        a = self._self_attention(slots)
-        x1 = ops.row_ln(a, self.norm1.weight, self.norm1.bias, self.norm1.eps, pre=slots)                 # :356-358
+        x1 = self._self_attention(slots, residual_norm=True)                                              # :346-358
         r = self.inst_interact.forward_pm(x1, feat_pm, hw, pos_tabs)                                        # :368
         x2 = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x1)                     # :374-376
         hid = fast_linear(self, "linear1", x2, self.linear1.weight, self.linear1.bias, act=_act_name(self.activation))
-        y = fast_linear(self, "linear2", hid, self.linear2.weight, self.linear2.bias)                        # :379
-        return ops.row_ln(y, self.norm3.weight, self.norm3.bias, self.norm3.eps, pre=x2)                   # :384-385
+        return fast_linear_ln(self, "linear2", hid, self.linear2.weight, self.linear2.bias, self.norm3, pre=x2)   # :379, :384-385
 
     def forward_after_ffn_pm(self, obj):
         """:390-400 -> (class_logits [T, L, nc], slot embedding [T, L, C]). The class and the embedding tower
@@ -434,11 +458,11 @@ class MaskRCNNHead(nn.Module):
             e2 = _cached(self, f"te{i}", [nc.bias, nr.bias], lambda: torch.stack([nc.bias, nr.bias]).contiguous())
             if self.precision != "fp32" and self.use_slot_gemm:
                 y2 = torch.empty((2, T * L, C), dtype=torch.float32, device=obj.device)
-                fast_linear(self, f"cls{i}", x[0], lc.weight, out=y2[0])
-                fast_linear(self, f"reg{i}", x[1], lr.weight, out=y2[1])
+                fast_linear_ln(self, f"cls{i}", x[0], lc.weight, None, nc, relu=True, out=y2[0])           # :394-397, layer + LayerNorm + ReLU per launch
+                fast_linear_ln(self, f"reg{i}", x[1], lr.weight, None, nr, relu=True, out=y2[1])
+                x = y2
             else:
-                y2 = torch.bmm(x, w2)
-            x = ops.row_ln(y2, g2, e2, nc.eps, relu=True, rows_per_group=T * L)                             # :394-397
+                x = ops.row_ln(torch.bmm(x, w2), g2, e2, nc.eps, relu=True, rows_per_group=T * L)          # :394-397
         if self.precision != "fp32" and self.use_slot_gemm and x.is_cuda:            # :398 on K9 (20 columns: not a K8 shape)
             cls = ops.bgemm(x[0], self.class_logits.weight, bias=self.class_logits.bias).view(T, L, -1)
         else:

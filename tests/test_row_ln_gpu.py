@@ -110,3 +110,32 @@ def test_slot_gemm_matches_float64_linear(cuda, M, K, N, act, bias):
     err = np.abs(got.cpu().numpy() - ref).max()
     print(f"\nK8 M={M} K={K} N={N} act={act}: max abs err vs float64 {err:.2e} (outputs of order 1)")
     assert err <= 3e-5
+
+
+@pytest.mark.parametrize("M,K,pre,post,relu,bias", [(16000, 256, True, False, False, True), (500, 2048, True, True, False, True),
+                                                    (37, 272, False, False, True, False), (8000, 256, False, False, True, False),
+                                                    (65, 256, True, False, True, True), (40000, 256, True, False, False, True)])
+def test_slot_gemm_ln_is_bitwise_gemm_then_row_ln(cuda, M, K, pre, post, relu, bias):
+    """K8 with the LayerNorm epilogue (svps_slot_gemm_ln) == svps_slot_gemm followed by svps_row_ln, bit for bit (same products,
+    same LayerNorm arithmetic), for the three launch shapes (32-row tiles, 64-row tiles, the wide variant) and the long-K path;
+    and against a float64 LayerNorm of the float64 product."""
+    import torch
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(M + K)
+    x = torch.randn((M, K), generator=g, device=cuda)
+    w = torch.randn((256, K), generator=g, device=cuda) / K ** 0.5
+    b = 0.1 * torch.randn((256,), generator=g, device=cuda) if bias else None
+    gamma = 1.0 + 0.1 * torch.randn((256,), generator=g, device=cuda)
+    beta = 0.1 * torch.randn((256,), generator=g, device=cuda)
+    p1 = torch.randn((M, 256), generator=g, device=cuda) if pre else None
+    p2 = torch.randn((M, 256), generator=g, device=cuda) if post else None
+    wp = ops.pack_b_fragments(w)
+    two = ops.row_ln(ops.slot_gemm(x, wp, b), gamma, beta, 1e-5, pre=p1, post=p2, relu=relu)
+    one = ops.slot_gemm_ln(x, wp, b, gamma, beta, 1e-5, pre=p1, post=p2, relu=relu)
+    assert torch.equal(one, two)
+    y = x.double() @ w.double().t() + (0 if b is None else b.double())
+    y = y + (0 if p1 is None else p1.double())
+    y = (y - y.mean(1, keepdim=True)) / torch.sqrt(y.var(1, unbiased=False, keepdim=True) + 1e-5) * gamma.double() + beta.double()
+    y = torch.relu(y) if relu else y
+    y = y + (0 if p2 is None else p2.double())
+    assert (one.double() - y).abs().max().item() <= 1e-4
