@@ -13,8 +13,8 @@
 // products accumulated in fp32 (the arithmetic of K8: relative error ~1e-5 of the largest term).
 //
 // Mapping: workgroup = 64 x 64 outputs of one batch entry, 4 waves = 2 x 2 blocks of 32 x 32; K in chunks of 32; per chunk the
-// workgroup gathers A[64, 32] and B[64, 32] with strided scalar loads (the thread order follows the contiguous index of each
-// operand), splits them and stages hi / lo in LDS (80-byte rows: conflict-free 16-byte fragment reads), double-buffered, one
+// workgroup gathers A[64, 32] and B[64, 32] (16-byte loads along the contiguous index of each operand where alignment allows,
+// strided scalar loads otherwise), splits them and stages hi / lo in LDS (80-byte rows: conflict-free 16-byte fragment reads), double-buffered, one
 // barrier per chunk. These launches are microseconds of latency each (2 - 8 GFLOP per step in total): the kernel is kept
 // simple and general, it is not a roofline kernel.
 #include "common.h"
@@ -75,20 +75,85 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs g) {
         }
     };
 
+    // 16-byte forms of the two (64 rows x 32 k, 8 elements per thread):
+    //   k contiguous (stride 1):   thread -> (row = e >> 3, k = 4 (e & 7)), e = tid, tid + 256: two float4 along k, two 8-byte LDS stores each (hi, lo)
+    //   row contiguous (stride 1): thread -> (k = 2 (tid >> 4) + i, rows 4 (tid & 15) ..): two float4 along the rows, stored as (k, k + 1) pairs per row
+    // used when every address involved is 16-byte aligned and the sizes are multiples of 4; anything else takes the scalar form
+    auto vec_ok = [&](const float* P, long long sbatch, long long srow, long long sk, int rows) {
+        const bool kcv = sk == 1, rcv = srow == 1;
+        if (!kcv && !rcv) return 0;
+        const long long sother = kcv ? srow : sk;
+        if ((reinterpret_cast<uintptr_t>(P) & 15) || (sother & 3) || (sbatch & 3) || (rows & 3) || (g.K & 3)) return 0;
+        return kcv ? 1 : 2;
+    };
+    const int a_vec = vec_ok(g.a, g.sab, g.sam, g.sak, g.M), b_vec = vec_ok(g.b, g.sbb, g.sbn, g.sbk, g.N);
+    auto gather4 = [&](const float* P, long long srow, long long sk, int row0, int rows, int mode, int ch, float (&v)[8]) {
+        if (mode == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + 256 * i, row = e >> 3, k = 4 * (e & 7);
+                const int gr = row0 + row, gk = ch * kBgK + k;
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (gr < rows && gk < g.K) x = *reinterpret_cast<const f32x4*>(P + (long long)gr * srow + gk);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * i + j] = x[j];
+            }
+        } else {
+            const int kq = tid >> 4, rq = tid & 15;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                            // two float4 (rows 4 rq ..) for k = 2 kq + i
+                const int k = 2 * kq + i, gr = row0 + 4 * rq, gk = ch * kBgK + k;
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (gr < rows && gk < g.K) x = *reinterpret_cast<const f32x4*>(P + (long long)gk * sk + gr);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * i + j] = x[j];
+            }
+        }
+    };
+    auto split_store4 = [&](int buf, int op, int mode, const float (&v)[8]) {
+        char* base = smem + ((buf * 2 + op) * 2) * kBgTile * kBgRow;
+        if (mode == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + 256 * i, row = e >> 3, k = 4 * (e & 7);
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[4 * i + j]; lo[j] = (__bf16)(v[4 * i + j] - (float)hi[j]); }
+                *reinterpret_cast<bf16x4*>(base + row * kBgRow + k * 2) = hi;
+                *reinterpret_cast<bf16x4*>(base + kBgTile * kBgRow + row * kBgRow + k * 2) = lo;
+            }
+        } else {
+            const int kq = tid >> 4, rq = tid & 15;
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                            // row 4 rq + j: the pair (k = 2 kq, 2 kq + 1) as one 4-byte store
+                bf16x2_t hi, lo;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { hi[i] = (__bf16)v[4 * i + j]; lo[i] = (__bf16)(v[4 * i + j] - (float)hi[i]); }
+                *reinterpret_cast<bf16x2_t*>(base + (4 * rq + j) * kBgRow + (2 * kq) * 2) = hi;
+                *reinterpret_cast<bf16x2_t*>(base + kBgTile * kBgRow + (4 * rq + j) * kBgRow + (2 * kq) * 2) = lo;
+            }
+        }
+    };
+    auto load_a = [&](int ch, float (&v)[8]) { if (a_vec) gather4(A, g.sam, g.sak, m0, g.M, a_vec, ch, v); else gather(A, g.sam, g.sak, m0, g.M, a_kc, ch, v); };
+    auto load_b = [&](int ch, float (&v)[8]) { if (b_vec) gather4(B, g.sbn, g.sbk, n0, g.N, b_vec, ch, v); else gather(B, g.sbn, g.sbk, n0, g.N, b_kc, ch, v); };
+    auto put_a = [&](int buf, const float (&v)[8]) { if (a_vec) split_store4(buf, 0, a_vec, v); else split_store(buf, 0, a_kc, v); };
+    auto put_b = [&](int buf, const float (&v)[8]) { if (b_vec) split_store4(buf, 1, b_vec, v); else split_store(buf, 1, b_kc, v); };
+
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float av[8], bv[8];
-    gather(A, g.sam, g.sak, m0, g.M, a_kc, 0, av);
-    gather(B, g.sbn, g.sbk, n0, g.N, b_kc, 0, bv);
-    split_store(0, 0, a_kc, av);
-    split_store(0, 1, b_kc, bv);
+    load_a(0, av);
+    load_b(0, bv);
+    put_a(0, av);
+    put_b(0, bv);
     __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < nch) {                                        // the next chunk's loads fly under this chunk's MFMAs
-            gather(A, g.sam, g.sak, m0, g.M, a_kc, ch + 1, av);
-            gather(B, g.sbn, g.sbk, n0, g.N, b_kc, ch + 1, bv);
+            load_a(ch + 1, av);
+            load_b(ch + 1, bv);
         }
         const char* ah = smem + ((buf * 2 + 0) * 2) * kBgTile * kBgRow + (32 * wm + r) * kBgRow + 16 * h;
         const char* bh = smem + ((buf * 2 + 1) * 2) * kBgTile * kBgRow + (32 * wn + r) * kBgRow + 16 * h;
@@ -103,8 +168,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
         }
         if (ch + 1 < nch) {
-            split_store(buf ^ 1, 0, a_kc, av);
-            split_store(buf ^ 1, 1, b_kc, bv);
+            put_a(buf ^ 1, av);
+            put_b(buf ^ 1, bv);
         }
         __syncthreads();
     }
