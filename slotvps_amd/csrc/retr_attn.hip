@@ -13,21 +13,18 @@
 //                   this kernel accumulates A (and s1, s0 through a ninth "aux" channel block, retr_stats.hip); the
 //                   256 x 256 product with W~_v, norm1 and ReLU (:458-459) follow on [L, 256] tensors (slot side).
 //
-// Q'' is carried as bf16 hi + lo (16-bit mantissa), P * rstd_v as bf16 hi + lo, f is the stored bf16 map itself: the only
-// roundings are those two splits, fp32 accumulation and v_exp_f32. Against a float64 evaluation of the reference formulas
-// on the same bf16 map the slot update agrees to ~2e-4 (bf16 k / v: 1.2e-1).
+// Q'' is carried as FP16 hi + lo (22-bit mantissa), P * rstd_v as ONE FP16, f is the stored bf16 map converted to FP16 in LDS
+// (exact): the only roundings are those, fp32 accumulation and v_exp_f32. Against a float64 evaluation of the reference formulas
+// on the same bf16 map the slot update agrees to ~1e-3 (bf16 k / v: 1.2e-1).
 //
-// Structure = the wave-specialised K1 (slot_attn.hip): 8 waves, producers 0-3 / consumers 4-7, one producer and one
-// consumer per SIMD, two barriers per tile, LDS-DMA ring three tiles ahead.
-//   producer sb: logits of slot block sb: 16 + 16 MFMA (Q'' hi, lo) on the row fragments of f(i); + position terms
-//       (per-lane loads from the two tables, L2-resident); * rstd_k + c3; softmax statistics exchange; P * rstd_v -> LDS
-//   consumer sb: A[sb, 0:256] += P(i-1) f(i-1) and the aux block: 36 MFMA per tile (hi + lo); all LDS-DMA
-// LDS: feature ring 5 x 16 KiB, aux ring 5 x 2 KiB, P ring 2 x 16 KiB (P can no longer overwrite a dead key tile: the
-// feature tile is still needed as the value operand).
-// Measured (finest level, T = 5, 184 us): the producers are the critical path - `s_setprio 1` on the consumers costs 15 %
-// (215 us), on the producers nothing; producers alone 147 us, consumers alone 127 us, DMA + barriers 61 us. Removing the
-// per-element slot masks and the log2(e) multiplies from the producers was worth 6 %; v_rcp_f32 instead of the division
-// nothing.
+// Structure: 8 waves, producers 0-3 / consumers 4-7, one producer and one consumer per SIMD, ONE barrier per tile, LDS-DMA ring
+// three tiles ahead (details above retr_attn_kernel).
+//   producer sb: logits of slot block sb: 16 + 16 MFMA (Q'' hi, lo) on the row fragments of f(t), started from Cy + Cx;
+//       * rstd_k + c3; softmax statistics exchange; P * rstd_v -> LDS (the finish of tile t-1 in the shadow of the chain of tile t)
+//   consumer sb: A[sb, 0:256] += P(t-2) f(t-2) and the aux block: 18 MFMA per tile; all LDS-DMA; bf16 -> fp16 of its pieces
+// LDS: feature ring 6 x 16 KiB, aux ring 6 x 1 KiB (16-byte rows of retr_stats.hip), Cy ring 6 x 1 KiB, P ring 2 x 8 KiB.
+// Measured (finest level, T = 5): 124 - 131 us depending on the box (first version 184); DMA + barriers alone 57 us (the per-CU
+// LDS-DMA fill rate); DESIGN.md 3 and 7 carry the stamps, ablations and what was tried.
 #include <stdlib.h>
 
 #include <type_traits>

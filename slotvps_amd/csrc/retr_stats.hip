@@ -28,10 +28,11 @@
 // s1 = sum_p P rstd_v and s0 = sum_p P (needed for the bias terms) at no vector-ALU cost; its producers read the two fp32 words
 // from the staged tile.
 //
-// Mapping: 8 waves, two per SIMD. Waves 0-3 = key projection, waves 4-7 = value projection and all LDS-DMA; BOTH read the
-// same operand: the feature tile converted bf16 -> fp16 in place by the wave that staged the piece (exact for
-// |f| in [6.1e-5, 65504]). Feature tiles four ahead in a 6-deep ring; one workgroup barrier per tile; the first fragment
-// group of the next tile is requested before the barrier.
+// Mapping: 8 waves, two per SIMD. Waves 0-3 = key projection, waves 4-7 = value projection; every wave stages two 1-KiB pieces
+// of every tile by LDS-DMA and converts them bf16 -> fp16 in place when they have landed (exact for |f| in [6.1e-5, 65504]):
+// BOTH sides read the same fp16 tile. Feature tiles five ahead in a 6-deep ring; ping-pong schedule with two workgroup barriers
+// per tile (key waves heavy while value waves light, then the reverse: see the loop); the first fragment groups of a tile are
+// requested in the light phase before its heavy phase.
 // Precision. rstd_k multiplies logits of magnitude up to ~80 in front of a sharp softmax: it has to be good to ~1e-4. The
 // operand f is exact, the position term is fp32, R_k / R_v carry 11 bits (fp16). Accumulation and everything after it is fp32.
 #include <cstdlib>
