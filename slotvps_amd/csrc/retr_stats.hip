@@ -329,18 +329,43 @@ __device__ __forceinline__ void retr_stats_role(
             __builtin_amdgcn_sched_barrier(0);
         }
         STATS_STAMP(6);
-        if constexpr (HAS_POS && proj == 0) {
+#ifndef SVPS_TAILPK
+#define SVPS_TAILPK 1
+#endif
+        float tot;
+        if constexpr (SVPS_TAILPK != 0) {
+            // PACKED fp32 math (v_pk_add_f32 / v_pk_fma_f32: two lanes of work per instruction) is poison beside MFMAs, but here
+            // none is in flight: this wave's chain has ended (the first add needs its result) and the partner wave on the SIMD
+            // is in its light phase. Half the vector instructions of the tail.
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            f32x2_t q0 = {0.f, 0.f}, q1 = {0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { a0[4 * g + i] += y0[g][i]; a1[4 * g + i] += y1[g][i]; }
+                for (int i = 0; i < 4; i += 2) {
+                    f32x2_t u0 = {a0[4 * g + i], a0[4 * g + i + 1]}, u1 = {a1[4 * g + i], a1[4 * g + i + 1]};
+                    if constexpr (HAS_POS && proj == 0) {
+                        u0 += f32x2_t{y0[g][i], y0[g][i + 1]};
+                        u1 += f32x2_t{y1[g][i], y1[g][i + 1]};
+                    }
+                    q0 = __builtin_elementwise_fma(u0, u0, q0);
+                    q1 = __builtin_elementwise_fma(u1, u1, q1);
+                }
+            tot = st_half_swap_add((q0[0] + q0[1]) + (q1[0] + q1[1]));
+        } else {
+            if constexpr (HAS_POS && proj == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { a0[4 * g + i] += y0[g][i]; a1[4 * g + i] += y1[g][i]; }
+            }
+            float s2[4] = {0.f, 0.f, 0.f, 0.f};                       // four independent chains
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s2[i & 1] = fmaf(a0[i], a0[i], s2[i & 1]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s2[2 + (i & 1)] = fmaf(a1[i], a1[i], s2[2 + (i & 1)]);
+            tot = st_half_swap_add((s2[0] + s2[1]) + (s2[2] + s2[3]));
         }
-        float s2[4] = {0.f, 0.f, 0.f, 0.f};                       // four independent chains
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s2[i & 1] = fmaf(a0[i], a0[i], s2[i & 1]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s2[2 + (i & 1)] = fmaf(a1[i], a1[i], s2[2 + (i & 1)]);
-        const float tot = st_half_swap_add((s2[0] + s2[1]) + (s2[2] + s2[3]));
         if (h == 0) stats[(((it & 1) * 2 + proj) * 4 + j) * 32 + r] = tot;
     };
 
