@@ -1,8 +1,8 @@
 # Collects everything profiles/<round>/ holds from ONE box: bench line, rocprofv3 kernel stats, both PMC passes, VIPER line, whole-detector lines.
-# usage (GPU box): bash tools/collect_profiles.sh   -> gpurun_out/v6/
+# usage (GPU box): bash tools/collect_profiles.sh   -> gpurun_out/v7/
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-V=v6
+V=v7
 O=$R/gpurun_out/$V
 mkdir -p $O
 cd $R
