@@ -201,17 +201,18 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
 //     range check, so every wave issues the same number of stores and the vmcnt arithmetic stays exact;
 //   * the cross-wave part of the fused argmax of tile j runs at the top of tile j + 1 (double-buffered candidates):
 //     two workgroup barriers per tile instead of three.
+template <int NW>
 struct Dec2Lds {
     static constexpr int kStages = 3;
     static constexpr int ring = 0;                                   // 3 feature tiles
     static constexpr int kORow = 144;                                // per wave [32 slots][32 px] fp32, rows padded to 144 B:
     static constexpr int kOWave = 32 * kORow;                        // every epilogue address is lane base + constant
     static constexpr int otile = kStages * kTileBytes;
-    static constexpr int affine = otile + 4 * kOWave;                // scale[256], shift[256]
+    static constexpr int affine = otile + NW * kOWave;               // scale[256], shift[256]
     static constexpr int norm = affine + 2 * kD * 4;                 // [32]
-    static constexpr int cshift = norm + kTilePx * 4;                // [128]
-    static constexpr int amax = cshift + 128 * 4;                    // [2][4][32] float2
-    static constexpr int total = amax + 2 * 4 * kTilePx * 8;
+    static constexpr int cshift = norm + kTilePx * 4;                // [32 NW]
+    static constexpr int amax = cshift + 32 * NW * 4;                // [2][NW][32] float2
+    static constexpr int total = amax + 2 * NW * kTilePx * 8;
 };
 
 __device__ __forceinline__ u32x4 make_srd_d(const void* base, uint32_t bytes) {
@@ -264,14 +265,17 @@ __device__ __forceinline__ void store1_d(int val, u32x4 srd, int voff) {
     asm volatile("buffer_store_byte %0, %1, %2, 0 offen" : : "v"(val), "v"(voff), "s"(srd) : "memory");
 }
 
-template <bool ARGMAX>
-__global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
+// NW waves = 32 NW slots: 4 (L <= 128: two workgroups per CU) or 8 (L <= 256: one workgroup of 512 threads per CU)
+template <bool ARGMAX, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v2(
     const __bf16* __restrict__ feat, const float* __restrict__ embed, const float* __restrict__ bn_scale,
     const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
     uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Lds = Dec2Lds;
+    using Lds = Dec2Lds<NW>;
     constexpr int NST = Lds::kStages;
+    constexpr int NT = 64 * NW;                                  // threads
+    constexpr int PC = 16 / NW;                                  // 1-KiB DMA pieces per wave and tile
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
     float* cs = reinterpret_cast<float*>(smem + Lds::cshift);
     float2* am = reinterpret_cast<float2*>(smem + Lds::amax);
 
-    for (int i = tid; i < kD; i += 256) {
+    for (int i = tid; i < kD; i += NT) {
         aff[i] = bn_scale[i];
         aff[kD + i] = bn_shift[i];
     }
@@ -325,27 +329,32 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
     const u32x4 frs = make_srd_d(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
     const u32x4 ors = make_srd_d(out + (size_t)t * L * HW, (uint32_t)L * (uint32_t)HW * 4u);
     const u32x4 ars = make_srd_d(ARGMAX ? slot_argmax + (size_t)t * HW : nullptr, ARGMAX ? (uint32_t)HW : 0u);
-    auto stage = [&](int tile) {          // exactly four DMA instructions per wave, or none
+    auto stage = [&](int tile) {          // exactly PC DMA instructions per wave, or none
         if (tile >= nt) return;
-        int voff[4];                      // recomputed per tile (a handful of VALU ops) rather than held in VGPRs
+        int voff[PC];                     // recomputed per tile (a handful of VALU ops) rather than held in VGPRs
         {
             int rr = r_, hh = h_;
             asm volatile("" : "+v"(rr), "+v"(hh));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 8 * w + 2 * i + hh;
+            for (int i = 0; i < PC; ++i) {
+                const int row = 2 * PC * w + 2 * i + hh;
                 voff[i] = row * kRowBytes + ((rr ^ swz(row)) * 16);
             }
         }
-        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * kTileBytes + w * 4096);
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * kTileBytes + w * PC * 1024);
         const int px0 = px_begin + tile * kTilePx;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
         if (px0 + kTilePx <= HW) {
-            dma16x4_d(frs, st, voff[0], voff[1] - 1024, voff[2] - 2048, voff[3] - 3072, soff);
+            if constexpr (PC == 4) {
+                dma16x4_d(frs, st, voff[0], voff[1] - 1024, voff[2] - 2048, voff[3] - 3072, soff);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PC; ++i) dma16_d(frs, st + i * 1024, voff[i], soff);
+            }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 8 * w + 2 * i + h;
+            for (int i = 0; i < PC; ++i) {
+                const int row = 2 * PC * w + 2 * i + h;
                 const int src = px0 + row < HW ? row : HW - 1 - px0;
                 dma16_d(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
             }
@@ -357,8 +366,8 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
             float b = -INFINITY;
             int bs = 0x7fffffff;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                const float2 cnd = am[(tile & 1) * 4 * kTilePx + ww * kTilePx + r];
+            for (int ww = 0; ww < NW; ++ww) {
+                const float2 cnd = am[(tile & 1) * NW * kTilePx + ww * kTilePx + r];
                 const int sl = __float_as_int(cnd.y);
                 if (cnd.x > b || (cnd.x == b && sl < bs)) { b = cnd.x; bs = sl; }
             }
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
     for (int it = 0; it < nt; ++it) {
         // tile `it` landed (this wave's pieces). Younger than its DMA, in issue order: argmax(it-3), stores(it-2),
         // DMA(it+1), argmax(it-2), stores(it-1).
-        wait_vm_dyn(4 * ((it >= 2) + (it >= 1)) + 4 * (it + 1 < nt) + amw * ((it >= 3) + (it >= 2)));
+        wait_vm_dyn(4 * ((it >= 2) + (it >= 1)) + PC * (it + 1 < nt) + amw * ((it >= 3) + (it >= 2)));   // (4 = mask stores per wave and tile)
         wg_barrier();
         stage(it + 2);
         int tid_o = tid, lane_o = lane;
@@ -386,12 +395,13 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
         if (ARGMAX && w == 0 && it >= 1) finish_argmax(it - 1);
         const char* ft = smem + Lds::ring + (it % NST) * kTileBytes;
 
-        {   // ||scale * f + shift||^2 per pixel: 8 threads per pixel, 4 chunks each
-            const int npx = tid_o >> 3, nsub = tid_o & 7;
+        {   // ||scale * f + shift||^2 per pixel: 2 NW threads per pixel, 16 / NW chunks each
+            constexpr int TPP = 2 * NW;
+            const int npx = tid_o / TPP, nsub = tid_o % TPP;
             float ss = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int chunk = nsub + 8 * i;
+            for (int i = 0; i < 32 / TPP; ++i) {
+                const int chunk = nsub + TPP * i;
                 const bf16x8 x = *reinterpret_cast<const bf16x8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -403,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
             ss += __shfl_xor(ss, 1);
             ss += __shfl_xor(ss, 2);
             ss += __shfl_xor(ss, 4);
+            if constexpr (TPP == 16) ss += __shfl_xor(ss, 8);
             if (nsub == 0) inv_norm[npx] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
         }
 
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_kernel_v2(
             const float ob = __shfl_xor(best, 32);
             const int os = __shfl_xor(best_slot, 32);
             if (ob > best || (ob == best && os < best_slot)) { best = ob; best_slot = os; }
-            if (h == 0) am[(it & 1) * 4 * kTilePx + w * kTilePx + r] = make_float2(best, __int_as_float(best_slot));
+            if (h == 0) am[(it & 1) * NW * kTilePx + w * kTilePx + r] = make_float2(best, __int_as_float(best_slot));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local transpose: own writes done, no barrier needed
         const int px0 = px_begin + it * kTilePx;
@@ -490,18 +501,19 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
     return hipGetLastError();
 }
 
-template <bool ARGMAX>
+template <bool ARGMAX, int NW>
 hipError_t launch_decode_v2(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
                             float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L, int HW,
                             hipStream_t stream) {
-    auto kern = svps::mask_decode_kernel_v2<ARGMAX>;
+    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW>;
+    using Lds = svps::Dec2Lds<NW>;
     static SvpsLdsAttr attr;
-    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::Dec2Lds::total); ae != hipSuccess) return ae;
-    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;      // two co-resident workgroups per CU (2 x 68 KiB LDS)
-    int chunks = svps_pick_chunks(T, tiles, 2 * dec_num_cus());
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
+    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;      // NW = 4: two co-resident workgroups per CU (2 x 68 KiB LDS); 8: one
+    int chunks = svps_pick_chunks(T, tiles, (NW == 4 ? 2 : 1) * dec_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
-    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(256), svps::Dec2Lds::total, stream, static_cast<const __bf16*>(feat),
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(64 * NW), Lds::total, stream, static_cast<const __bf16*>(feat),
                        embed, bn_scale, bn_shift, fg_scale, fg_shift, static_cast<float*>(out), slot_argmax, L, HW, tpc);
     return hipGetLastError();
 }
@@ -530,16 +542,16 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 0, stream);
     // fast path: 16-byte row-segment stores need 4-pixel alignment of every slot row; L * HW * 4 must fit a buffer descriptor
-    const bool fast = L <= 128 && (HW & 3) == 0 && !(flags & SVPS_FLAG_OUT_BF16) && (size_t)L * HW * 4 < 0x7ffffff0u &&
+    const bool fast = (HW & 3) == 0 && !(flags & SVPS_FLAG_OUT_BF16) && (size_t)L * HW * 4 < 0x7ffffff0u &&
                       getenv("SVPS_K2_LEGACY") == nullptr;
-    hipError_t e = fast ? (slot_argmax ? launch_decode_v2<true>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
-                                                                 slot_argmax, T, L, HW, stream)
-                                       : launch_decode_v2<false>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
-                                                                  slot_argmax, T, L, HW, stream))
+#define SVPS_V2(AM, W) launch_decode_v2<AM, W>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
+    hipError_t e = fast ? (L <= 128 ? (slot_argmax ? SVPS_V2(true, 4) : SVPS_V2(false, 4))
+                                    : (slot_argmax ? SVPS_V2(true, 8) : SVPS_V2(false, 8)))
                    : L <= 128 ? dispatch_decode<4, 4>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
                                                     slot_argmax, T, L, HW, flags, stream)
                             : dispatch_decode<8, 4>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
                                                     slot_argmax, T, L, HW, flags, stream);
+#undef SVPS_V2
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
     return (int)e;
 }

@@ -52,7 +52,10 @@ def _run(cuda, T, L, HW, seed, default_bn):
     (1, 100, 512, True),
     (2, 100, 2145, False),     # ragged tile
     (1, 1, 40, False),
-    (2, 200, 2040, False),     # VIPER slots (8-wave kernel)
+    (2, 200, 2040, False),     # VIPER slots (8-wave form of the fast kernel)
+    (1, 256, 8192, True),      # the most slots the fast kernel takes, several tiles per workgroup
+    (3, 129, 2148, False),     # one slot past four waves, ragged last tile
+    (1, 200, 2050, False),     # more than 128 slots with HW % 4 != 0: first-generation kernel
     (1, 128, 8192, True),
     (20, 100, 6144, False),    # several tiles per workgroup (counted DMA / store ring, deferred argmax), fast path
     (20, 100, 6148, False),    # the same with a ragged last tile
