@@ -312,6 +312,15 @@ int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
 int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                         float lnk_eps, const void* rv, const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D,
                         void* stream);
+/* svps_retr_stats_level_fwd: the statistics of ALL retriever stages of one pyramid level (n_stages = 1 or 2; the stages of a level
+ * read the same fused map, MultiScaleDynamicMaskHead.forward :190-215) in ONE read of the map (slotvps_amd/csrc/retr_stats4.hip:
+ * four waves of 512 registers hold both stages' factors). Arguments as svps_retr_stats_fwd, as HOST arrays of n_stages device
+ * pointers / values; ty, tx must be given (zero tables for "no position embedding"); aux[s] receives stage s's rows, bit-for-bit
+ * the format svps_retr_stats_fwd writes. */
+int svps_retr_stats_level_fwd(const void* feat, int n_stages, const float* const* ty, const float* const* tx,
+                              const void* const* rk, const float* const* rbk, const float* lnk_eps,
+                              const void* const* rv, const float* const* rbv, const float* lnv_eps,
+                              void* const* aux, int T, int H, int W, int D, void* stream);
 size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int chunks);
 int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
                        const void* feat, const void* aux, void* workspace,

@@ -160,8 +160,14 @@ class SlotClipRunner:
         }
         if self.retriever_form == "fused":
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
-            # K3' reads the map (512 B / pixel) and writes one 16-byte aux row (both statistics)
-            out["retr_stats"] = {"bytes": T * ps * (512 + 16), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
+            # K3' reads the map (512 B / pixel) and writes one 16-byte aux row (both statistics) per stage; K3'' (ops.RETR_STATS_FORM
+            # "level", the default) reads the map once per LEVEL and writes the rows of all its stages
+            from . import ops as _ops
+            if _ops.RETR_STATS_FORM == "level":
+                sbytes = T * sum(hw * (512 + 16 * n) if n == 2 else n * hw * (512 + 16) for hw, n in self.k1_launch_shapes())
+            else:
+                sbytes = T * ps * (512 + 16)
+            out["retr_stats"] = {"bytes": sbytes, "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
             # executed matrix work of K1' per pixel (informational): (4 x 32 producer + 4 x 18 consumer) MFMA 32x32x16 per 32-pixel
             # tile - Q'' is carried as fp16 hi + lo; L <= 128 (the three passes beyond that are not counted here). K1' stages the
             # 16-byte aux row with every pixel.

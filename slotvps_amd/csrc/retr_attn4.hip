@@ -359,6 +359,8 @@ __device__ __forceinline__ void role(const Args& A) {
     // runs its logits on a tile that does not exist (stale LDS): its exponentials are never finished. Iteration 0 runs the P.f MFMAs
     // of a tile that does not exist either: with P = 0 (e = 0 and a finite factor) against a zero-filled tile.
     // off_l / off_f: ring offsets of tiles it / it-1; off_c: tile it+2 (converted here); off_d, px0_d, yrow_d: batch it+kA.
+    f32x16 s;                                   // logits of tile it: starts from Cy + Cx (set before the barrier)
+    f32x2 rt = {0.f, 0.f};                      // (rstd_k, rstd_v) of this lane's pixel in tile it
     auto body = [&](int it, uint32_t off_l, uint32_t off_f, uint32_t off_c, uint32_t off_d, int px0_d, int yrow_d) {
         const uint32_t tb_l = lane_row + off_l;
         const uint32_t par_l = (it & 1) * 1024, par_f = 1024 - par_l;
@@ -370,22 +372,9 @@ __device__ __forceinline__ void role(const Args& A) {
 
         R4_STAMP_AT(0);
         // ================= phase 1: logits(it) || finish(it-1), conversion of tile it+2, DMA of tile it+kA ======================
-        f32x16 s;
         float fac = 0.f, mall = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-        // finish: (max, sum) of the four slot blocks for this lane's pixel
+        // finish: (max, sum) of the four slot blocks for this lane's pixel (written by the other waves before the barrier)
         const f32x4 stA = lds4(x2_lane + par_f), stB = lds4(x2_lane + par_f + 16);
-        {
-            // (the first three fragments were requested before the barrier)
-            const uint32_t cya = cy_lane + (off_l >> 4);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 a = lds4(cya + 32 * g), b = lds4(cx_lane + 32 * g);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s[4 * g + j] = a[j] + b[j];
-            }
-        }
-        // (rstd_k, rstd_v) of this lane's pixel: bytes 8 .. 15 of its aux row
-        const f32x2 rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(rt_lane + (off_l >> 4)));
         f16x8 ah0, ah1, af, vf[kVR];
         uint32_t vx0[4], vx1[4];
         const uint32_t aa = lane_a + (off_f >> 4);
@@ -558,7 +547,19 @@ __device__ __forceinline__ void role(const Args& A) {
         uint32_t off_l = 0, off_f = (kFN - 1) * kTileBytes, off_c = 2 * kTileBytes, off_d = kA * kTileBytes;
         int px0_d = (y0 + kA) * W + x0, yrow_d = y0 + kA;
         for (int it = 0; it <= nt; ++it) {
-            {   // the first row fragments of tile it (its pieces became fp16 one iteration - or the prologue - ago): requested BEFORE the
+            {   // what tile it needs and no other wave writes in this iteration, read BEFORE the barrier: the accumulator's start value
+                // Cy + Cx and the pixel's statistics (staged with the tile, landed iterations ago) ...
+                const uint32_t cya = cy_lane + (off_l >> 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 a = lds4(cya + 32 * g), b = lds4(cx_lane + 32 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[4 * g + j] = a[j] + b[j];
+                }
+                rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(rt_lane + (off_l >> 4)));
+                asm volatile("" : "+v"(rt));
+            }
+            {   // ... and the first row fragments of tile it (its pieces became fp16 one iteration - or the prologue - ago): requested BEFORE the
                 // barrier and still in flight behind it. LDS operations of a wave complete in order, so "all but the kFB - 1
                 // youngest" covers every LDS write of the iteration (block statistics, converted pieces) that the barrier publishes.
                 const uint32_t tb = lane_row + off_l;

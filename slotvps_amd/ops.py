@@ -276,6 +276,55 @@ def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     return aux
 
 
+RETR_STATS_FORM = "level"  # "level": csrc/retr_stats4.hip, every stage of a pyramid level in one read of the map; "stage": csrc/retr_stats.hip per stage
+
+_ZERO_TABLES = {}
+
+
+def retr_stats_level(feat, H, W, stages):
+    """K3'': the aux rows (see retr_stats) of every retriever stage of one pyramid level from ONE read of the fused map.
+    stages: list (1 or 2 entries) of (pos_proj, rk, rbk, eps_k, rv, rbv, eps_v) with the meaning of retr_stats' arguments
+    (pos_proj = (Ty [H, 256], Tx [W, 256]) or None). Returns the list of aux tensors [T, HW, 8] fp16."""
+    import ctypes
+    lib = _lib.load()
+    _need(feat, "feat", torch.bfloat16, 3)
+    T, HW, D = feat.shape
+    if HW != H * W:
+        raise ValueError("feat rows != H*W")
+    if not 1 <= len(stages) <= 2:
+        raise ValueError("a level has one or two retriever stages")
+    n = len(stages)
+    tys, txs, rks, rbks, rvs, rbvs, auxs, keep = [], [], [], [], [], [], [], []
+    for (pos_proj, rk, rbk, eps_k, rv, rbv, eps_v) in stages:
+        _need(rk, "rk", torch.float16, 2)
+        _need(rv, "rv", torch.float16, 2)
+        _need(rbk, "rbk", torch.float32, 1)
+        _need(rbv, "rbv", torch.float32, 1)
+        if rk.shape != (D, D) or rv.shape != (D, D):
+            raise ValueError("rk / rv must be [256, 256]")
+        if pos_proj is None:
+            key = (H, W, D, feat.device)
+            if key not in _ZERO_TABLES:
+                _ZERO_TABLES[key] = (torch.zeros((H, D), dtype=torch.float32, device=feat.device),
+                                     torch.zeros((W, D), dtype=torch.float32, device=feat.device))
+            pos_proj = _ZERO_TABLES[key]
+        ty, tx = pos_proj
+        _need(ty, "ty", torch.float32, 2)
+        _need(tx, "tx", torch.float32, 2)
+        if ty.shape != (H, D) or tx.shape != (W, D):
+            raise ValueError("projected position tables do not match (H, W)")
+        aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat.device)
+        tys.append(ty); txs.append(tx); rks.append(rk); rbks.append(rbk); rvs.append(rv); rbvs.append(rbv); auxs.append(aux)
+        keep += [ty, tx, rk, rbk, rv, rbv]
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    fl = lambda i: (ctypes.c_float * n)(*[float(st[i]) for st in stages])
+    with _on(feat, *keep) as ctx:
+        rc = lib.svps_retr_stats_level_fwd(_ptr(feat), n, arr(tys), arr(txs), arr(rks), arr(rbks), fl(3), arr(rvs), arr(rbvs), fl(6),
+                                           arr(auxs), T, H, W, D, ctx.stream)
+    _lib.check(rc, "svps_retr_stats_level_fwd")
+    return auxs
+
+
 def retr_stats_unpack(aux):
     """(rstd_k, rstd_v) [T, HW] fp32: strided views of the two fp32 words of every aux row."""
     w = aux.view(torch.float32)                                  # [T, HW, 4]

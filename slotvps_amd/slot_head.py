@@ -203,6 +203,11 @@ class MaskDynamicConv(nn.Module):
             cache[key] = (ty.float().to(ytab.device).contiguous(), tx.float().to(xtab.device).contiguous(), ytab, xtab)
         return cache[key][:2]
 
+    def stats_args(self, pos_tabs):
+        """(pos_proj, rk, rbk, eps_k, rv, rbv, eps_v): this stage's arguments of ops.retr_stats / one entry of ops.retr_stats_level."""
+        c = self._fused_consts()
+        return (self.retr_pos_tables(pos_tabs), c["rk"], c["rbk"], self.norm_k.eps, c["rv"], c["rbv"], self.norm_v.eps)
+
     def forward_fused(self, slots, feat_pm, hw, pos_tabs, stats=None):
         """K3' + K1' (csrc/retr_stats.hip, csrc/retr_attn.hip): slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16.
         `stats` = the aux rows of ops.retr_stats if already computed for this (map, stage)."""
@@ -210,8 +215,13 @@ class MaskDynamicConv(nn.Module):
         T, L, C = slots.shape
         H, W = hw
         if stats is None:
-            stats = ops.retr_stats(feat_pm, H, W, self.retr_pos_tables(pos_tabs), c["rk"], c["rbk"], self.norm_k.eps, c["rv"], c["rbv"],
-                                   self.norm_v.eps)
+            # statistics already computed for this map by the level pass (MultiScaleDynamicMaskHead.forward_clip)?
+            pending = getattr(self, "_level_stats", None)
+            self._level_stats = None
+            if pending is not None and pending[0] is feat_pm:
+                stats = pending[1]
+        if stats is None:
+            stats = ops.retr_stats(feat_pm, H, W, *self.stats_args(pos_tabs))
         LP = ops.retr_slot_pad(L)
         # :431 q = norm_q(to_q(slots)); g = q * gamma_k (zero rows up to LP), c3 = q . beta_k, a1 = g . b~_k: one launch
         gp, c3, a1 = ops.retr_query_prep(fast_linear(self, "to_q", slots, self.to_q.weight, self.to_q.bias), self.norm_q.weight,
@@ -621,7 +631,17 @@ class MultiScaleDynamicMaskHead(nn.Module):
             else:
                 h, w = hws[i]
             f_pm = self.fuse_level(feats[i], prev, (h, w))
-            for stage in getattr(self, f"head_series_{i}"):
+            series = getattr(self, f"head_series_{i}")
+            mdcs = [stage.inst_interact for stage in series]
+            if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype == BF16
+                    and all(m.precision != "fp32" and m.retriever == "fused" for m in mdcs)):
+                # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats4.hip;
+                # measured 204 against 2 x 115 us at the finest level); each stage's retriever picks its rows up in forward_fused.
+                # A level with a single stage keeps K3' (107 against 115 - 125 us)
+                tabs_i = None if pos_tabs is None else pos_tabs[i]
+                for m, aux in zip(mdcs, ops.retr_stats_level(f_pm, h, w, [m.stats_args(tabs_i) for m in mdcs])):
+                    m._level_stats = (f_pm, aux)
+            for stage in series:
                 enable = stage_idx in self.apply_temporal_query_atten_stages
                 logits, slots = stage.forward_pm(slots, f_pm, (h, w), None if pos_tabs is None else pos_tabs[i], enable, clips)
                 slots = slots.detach()

@@ -194,3 +194,36 @@ def test_four_wave_form_matches_eight_wave_form(cuda, T, H, W, L):
     # (2^-12 each); measured 6e-5 of the scale on the sums, 1e-3 behind the slot-side product + LayerNorm (each form sits 1e-3 ...
     # 1.6e-3 from the float64 oracle, test above)
     assert d_ext <= 3e-4 * max(scale, 1.0) and d_out <= 3e-3
+
+
+@pytest.mark.parametrize("T,H,W,pos,ns", [(2, 8, 32, True, 2), (1, 5, 20, True, 1), (1, 3, 64, False, 2), (2, 34, 60, True, 2),
+                                          (1, 7, 9, True, 2), (3, 70, 96, True, 2), (8, 40, 64, True, 1)])
+def test_level_statistics_equal_per_stage_statistics(cuda, T, H, W, pos, ns):
+    """csrc/retr_stats4.hip (all stages of a level from one read of the map, four waves of 512 registers) against
+    csrc/retr_stats.hip (one launch per stage): the same fp16 operands and fp32 tables; the partial sums of a wave cover the same 64
+    rows in both kernels, so the two statistics agree to the order of the fp32 additions inside a wave (and bitwise in the fp16
+    words derived from them almost everywhere)."""
+    import torch
+    from slotvps_amd import ops
+    mods = [make_module(cuda, 100 * s + H * W)[0] for s in range(ns)]
+    g = torch.Generator(device=cuda).manual_seed(W + ns)
+    feat = torch.randn((T, H * W, 256), generator=g, device=cuda).to(torch.bfloat16)
+    tabs = ops.pos_embed_sine_tables(H, W, 256, cuda) if pos else None
+    with torch.no_grad():
+        ref = [ops.retr_stats(feat, H, W, *m.stats_args(tabs)) for m in mods]
+        got = ops.retr_stats_level(feat, H, W, [m.stats_args(tabs) for m in mods])
+        again = ops.retr_stats_level(feat, H, W, [m.stats_args(tabs) for m in mods])
+    torch.cuda.synchronize()
+    for s in range(ns):
+        assert torch.equal(got[s].view(torch.int16), again[s].view(torch.int16))      # (bit patterns: the fp32 words are not fp16 numbers)
+        rk0, rv0 = (x.double() for x in ops.retr_stats_unpack(ref[s]))
+        rk1, rv1 = (x.double() for x in ops.retr_stats_unpack(got[s]))
+        ek = ((rk1 - rk0).abs() / rk0).max().item()
+        ev = ((rv1 - rv0).abs() / rv0).max().item()
+        print(f"\nstage {s}: rstd_k rel diff {ek:.2e}, rstd_v rel diff {ev:.2e}")
+        assert ek <= 2e-6 and ev <= 2e-6                       # fp32 summation order of 64 squares only
+        a0, a1 = ref[s].float(), got[s].float()
+        assert torch.equal(a0[..., 0], a1[..., 0]) and torch.equal(a0[..., 3], a1[..., 3])          # the constant words 1, 0
+        sig0 = a0[..., 1].double() + a0[..., 2].double()
+        sig1 = a1[..., 1].double() + a1[..., 2].double()
+        assert ((sig1 - sig0).abs() / sig0).max().item() <= 4e-5                                    # hi + lo of sigma_v: 16-bit mantissa
