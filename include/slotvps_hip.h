@@ -96,7 +96,8 @@ int svps_slot_attn_fwd(const void* q, const void* k, const void* v, const float*
  *   embed    [T, L, D]  fp32 last-stage slot embeddings
  *   bn_scale, bn_shift [D] fp32: gamma/sqrt(var+eps), beta - mean*gamma/sqrt(var+eps)
  *   fg_scale, fg_shift: the scalar affine of fg_bn folded the same way
- *   out      [T, L, HW] fp32 (or bf16 with SVPS_FLAG_OUT_BF16)
+ *   out      [T, L, HW] fp32 (or bf16 with SVPS_FLAG_OUT_BF16); NULL = argmax-only mode (slot_argmax required): the logits are
+ *            computed exactly as otherwise but not stored - 512 B in, 1 B out per pixel
  *   slot_argmax optional [T, HW] uint8: argmax over slots of the logits (first max wins), NULL to skip
  * ------------------------------------------------------------------------------------------- */
 int svps_mask_decode_fwd(const void* feat, const float* embed, const float* bn_scale,

@@ -30,10 +30,13 @@ class SlotClipRunner:
     hipGraph of one clip step. All tensors live on `device`."""
 
     def __init__(self, device, T, H, W, L=100, param_seed=0, cfg=None, split_p=True, use_graph=True, n_slots=1,
-                 clips_per_launch=1):
+                 clips_per_launch=1, decode_logits=True):
         if torch.device(device).type != "cuda":
             raise RuntimeError("SlotClipRunner runs on the GPU only; there is no CPU fallback")
         self.device = torch.device(device)
+        # decode_logits=False: K2 in argmax-only mode - the step returns the per-pixel slot assignment (uint8) and the class logits,
+        # not the [T, L, HW] fp32 mask logits (a clip driver that post-processes decodes the kept slots only, detector.clip_test)
+        self.decode_logits = decode_logits
         self.clip_frames, self.clips_per_launch = T, clips_per_launch
         T = T * clips_per_launch                  # clips stacked along the frame axis: one launch covers them all
         self.T, self.H, self.W, self.L = T, H, W, L
@@ -78,8 +81,11 @@ class SlotClipRunner:
         logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs,
                                                        clip_frames=self.clip_frames)
         masks, amax = ops.mask_decode(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift,
-                                      self.fg_scale, self.fg_shift, want_argmax=True)
-        return dict(class_logits=logits, slot_embeds=embeds, mask_logits=masks, slot_argmax=amax)
+                                      self.fg_scale, self.fg_shift, want_argmax=True, want_logits=self.decode_logits)
+        out = dict(class_logits=logits, slot_embeds=embeds, slot_argmax=amax)
+        if masks is not None:
+            out["mask_logits"] = masks
+        return out
 
     def load_clip(self, feats, slot=0):
         for dst, src in zip(self.slots_feats[slot], feats):
@@ -156,7 +162,7 @@ class SlotClipRunner:
         stages = sum(n for _, n in self.k1_launch_shapes())
         out = {
             "level_fuse": {"bytes": T * sum(hw * (1024 + (128 if i else 0)) for i, hw in enumerate(px)), "flops": T * sum(px) * 2 * 384 * D},
-            "mask_decode": {"bytes": T * px[-1] * (512 + 4 * L + 1), "flops": T * px[-1] * 2 * L * D},
+            "mask_decode": {"bytes": T * px[-1] * (512 + (4 * L if self.decode_logits else 0) + 1), "flops": T * px[-1] * 2 * L * D},
         }
         if self.retriever_form == "fused":
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))

@@ -266,7 +266,9 @@ __device__ __forceinline__ void store1_d(int val, u32x4 srd, int voff) {
 }
 
 // NW waves = 32 NW slots: 4 (L <= 128: two workgroups per CU) or 8 (L <= 256: one workgroup of 512 threads per CU)
-template <bool ARGMAX, int NW = 4>
+// LOGITS = false: argmax-only mode (out == NULL) - the [T, L, HW] logits are neither transposed nor stored: per pixel 512 B in and
+// 1 B out instead of 512 + 4 L + 1 (a consumer that only needs the per-pixel slot id, e.g. the clip driver's assignment map)
+template <bool ARGMAX, int NW = 4, bool LOGITS = true>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v2(
     const __bf16* __restrict__ feat, const float* __restrict__ embed, const float* __restrict__ bn_scale,
     const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
@@ -327,7 +329,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
     __syncthreads();
     const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
     const u32x4 frs = make_srd_d(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
-    const u32x4 ors = make_srd_d(out + (size_t)t * L * HW, (uint32_t)L * (uint32_t)HW * 4u);
+    const u32x4 ors = make_srd_d(LOGITS ? out + (size_t)t * L * HW : nullptr, LOGITS ? (uint32_t)L * (uint32_t)HW * 4u : 0u);
+    constexpr int kMS = LOGITS ? 4 : 0;                          // mask stores per wave and tile
     const u32x4 ars = make_srd_d(ARGMAX ? slot_argmax + (size_t)t * HW : nullptr, ARGMAX ? (uint32_t)HW : 0u);
     auto stage = [&](int tile) {          // exactly PC DMA instructions per wave, or none
         if (tile >= nt) return;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
     for (int it = 0; it < nt; ++it) {
         // tile `it` landed (this wave's pieces). Younger than its DMA, in issue order: argmax(it-3), stores(it-2),
         // DMA(it+1), argmax(it-2), stores(it-1).
-        wait_vm_dyn(4 * ((it >= 2) + (it >= 1)) + PC * (it + 1 < nt) + amw * ((it >= 3) + (it >= 2)));   // (4 = mask stores per wave and tile)
+        wait_vm_dyn(kMS * ((it >= 2) + (it >= 1)) + PC * (it + 1 < nt) + amw * ((it >= 3) + (it >= 2)));
         wg_barrier();
         stage(it + 2);
         int tid_o = tid, lane_o = lane;
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
             f32x4 c4;
             if ((i & 3) == 0) c4 = *reinterpret_cast<const f32x4*>(cs + 32 * w + sl);   // e . shift of slots sl .. sl + 3
             const float m = (s[i] + c4[i & 3]) * inr * fg_scale + fg_shift;
-            *reinterpret_cast<float*>(ot + sl * Lds::kORow + r * 4) = m;
+            if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + r * 4) = m;
             if constexpr (ARGMAX) {
                 if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
             }
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local transpose: own writes done, no barrier needed
         const int px0 = px_begin + it * kTilePx;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kMS; ++u) {
             const int sl = 8 * u + (lane_o >> 3), cc = lane_o & 7;
             const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * Lds::kORow + cc * 16);
             const int slot = 32 * w + sl, px = px0 + 4 * cc;
@@ -501,11 +504,11 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
     return hipGetLastError();
 }
 
-template <bool ARGMAX, int NW>
+template <bool ARGMAX, int NW, bool LOGITS = true>
 hipError_t launch_decode_v2(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
                             float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L, int HW,
                             hipStream_t stream) {
-    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW>;
+    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW, LOGITS>;
     using Lds = svps::Dec2Lds<NW>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
@@ -536,7 +539,7 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
                                     const float* bn_shift, float fg_scale, float fg_shift, void* out,
                                     uint8_t* slot_argmax, int T, int L, int HW, int D, int flags,
                                     void* stream_) {
-    if (!feat || !embed || !bn_scale || !bn_shift || !out) return SVPS_ERR_BAD_ARG;
+    if (!feat || !embed || !bn_scale || !bn_shift || (!out && !slot_argmax)) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || HW <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)HW > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;       // 32-bit buffer offsets inside a frame
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -544,6 +547,13 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
     // fast path: 16-byte row-segment stores need 4-pixel alignment of every slot row; L * HW * 4 must fit a buffer descriptor
     const bool fast = (HW & 3) == 0 && !(flags & SVPS_FLAG_OUT_BF16) && (size_t)L * HW * 4 < 0x7ffffff0u &&
                       getenv("SVPS_K2_LEGACY") == nullptr;
+    if (!out) {                                          // argmax-only mode: the fast kernel without its logit stores
+        if ((flags & SVPS_FLAG_OUT_BF16) || getenv("SVPS_K2_LEGACY")) return SVPS_ERR_BAD_ARG;
+        hipError_t e0 = L <= 128 ? launch_decode_v2<true, 4, false>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, nullptr, slot_argmax, T, L, HW, stream)
+                                 : launch_decode_v2<true, 8, false>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, nullptr, slot_argmax, T, L, HW, stream);
+        svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
+        return (int)e0;
+    }
 #define SVPS_V2(AM, W) launch_decode_v2<AM, W>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
     hipError_t e = fast ? (L <= 128 ? (slot_argmax ? SVPS_V2(true, 4) : SVPS_V2(false, 4))
                                     : (slot_argmax ? SVPS_V2(true, 8) : SVPS_V2(false, 8)))

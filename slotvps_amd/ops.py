@@ -99,9 +99,10 @@ def slot_attn(q, k, v, ln_w, ln_b, eps=1e-5, split_p=True, chunks=0, return_pre_
     return (out, pre) if return_pre_ln else out
 
 
-def mask_decode(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out_bf16=False, want_argmax=False):
+def mask_decode(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out_bf16=False, want_argmax=False, want_logits=True):
     """K2: mask logits [T, L, HW] from the finest fused feature map [T, HW, 256] bf16 and the
-    last-stage slot embeddings [T, L, 256] fp32 (generate_final_outputs, vps_temporal_slots.py:144-160)."""
+    last-stage slot embeddings [T, L, 256] fp32 (generate_final_outputs, vps_temporal_slots.py:144-160).
+    want_logits=False (with want_argmax): only the per-pixel slot argmax [T, HW] uint8 is written (returns (None, amax))."""
     lib = _lib.load()
     _need(feat, "feat", torch.bfloat16, 3)
     _need(embed, "embed", torch.float32, 3)
@@ -111,7 +112,9 @@ def mask_decode(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out_bf16=Fa
     L = embed.shape[1]
     if embed.shape != (T, L, D) or bn_scale.numel() != D or bn_shift.numel() != D:
         raise ValueError("shape mismatch")
-    out = torch.empty((T, L, HW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=feat.device)
+    if not want_logits and not want_argmax:
+        raise ValueError("nothing to compute")
+    out = torch.empty((T, L, HW), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=feat.device) if want_logits else None
     amax = torch.empty((T, HW), dtype=torch.uint8, device=feat.device) if want_argmax else None
     with _on(feat, embed, bn_scale, bn_shift) as ctx:
         rc = lib.svps_mask_decode_fwd(_ptr(feat), _ptr(embed), _ptr(bn_scale), _ptr(bn_shift), float(fg_scale),

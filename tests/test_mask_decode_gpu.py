@@ -32,6 +32,12 @@ def _run(cuda, T, L, HW, seed, default_bn):
                            torch.from_numpy(shift.astype(np.float32)).to(cuda), float(fgs), float(fgb))
     torch.cuda.synchronize()
     assert torch.equal(out, out2), "argmax variant changed the logits"
+    if HW % 4 == 0:                                  # argmax-only mode (out == NULL, the fast kernel without its logit stores)
+        none, amax_only = ops.mask_decode(tf, te, torch.from_numpy(scale.astype(np.float32)).to(cuda),
+                                          torch.from_numpy(shift.astype(np.float32)).to(cuda), float(fgs), float(fgb),
+                                          want_argmax=True, want_logits=False)
+        torch.cuda.synchronize()
+        assert none is None and torch.equal(amax_only, amax), "argmax-only mode differs from the argmax of the full mode"
     out, amax = out.cpu().numpy(), amax.cpu().numpy()
     ff = bf16_t_to_np(tf).astype(np.float64)
     s32, h32 = scale.astype(np.float32).astype(np.float64), shift.astype(np.float32).astype(np.float64)

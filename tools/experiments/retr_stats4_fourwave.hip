@@ -55,6 +55,25 @@ struct Lds {
 
 #define S4_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+#ifdef S4_STAMP
+// diagnostic build only (make stamp4, tools/retr4_stamps.py --stats): s_memtime stamps of the four waves of ONE workgroup, iterations
+// 8 .. 15, kept in LDS behind the kernel's own data and copied out at the end; (s_memtime, s_memrealtime) around every workgroup's loop
+__device__ unsigned long long s4_stamps[4][8][8];
+__device__ unsigned long long s4_clock[4096][4];
+#define S4_STAMP_AT(pt)                                                                                          \
+    do {                                                                                                         \
+        S4_FENCE();                                                                                              \
+        if (stamp_wg && it >= 8 && it < 16) {                                                                    \
+            unsigned long long t_;                                                                               \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+            if (lane == 0) reinterpret_cast<unsigned long long*>(smem + L::total)[(sb * 8 + (it - 8)) * 8 + (pt)] = t_; \
+        }                                                                                                        \
+        S4_FENCE();                                                                                              \
+    } while (0)
+#else
+#define S4_STAMP_AT(pt) do {} while (0)
+#endif
+
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (I < N) {
@@ -144,7 +163,7 @@ template <int NS, int SB>
 __device__ __forceinline__ constexpr bool in_agpr(int s, int proj, int j, int idx) {
     constexpr int NK0 = 2 * (8 - SB), NK1 = 2 * (SB + 1);
     const int within = j == 0 ? idx : NK0 + idx;                      // 0 .. 17 inside the factor
-    int ord;
+    int ord = 0;
     if (s == 0) ord = (proj == 0 ? 0 : 18) + within;
     else ord = 36 + (proj == 1 ? 0 : 18) + within;
     (void)NK1;
@@ -167,6 +186,9 @@ __device__ __forceinline__ void role(const Args& A) {
     int nt = H - y0;
     nt = nt < A.tiles_per_chunk ? nt : A.tiles_per_chunk;           // >= 1 by construction of the grid
     const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+#ifdef S4_STAMP
+    const bool stamp_wg = blockIdx.x == 3 && blockIdx.y == 2;
+#endif
     const int x0 = kTilePx * strip;
     const bool live = x0 + r < W;                                   // pixels past the right edge of the map: not stored
 
@@ -321,6 +343,7 @@ __device__ __forceinline__ void role(const Args& A) {
             fv = lds4(x1_r + x1r_fin + SB * 1024 + 512);
         }
 
+        S4_STAMP_AT(0);
         sfor<0, NPH>([&](auto P) {
             constexpr int p = decltype(P)::value;
             constexpr int j = p / NS, s = p % NS;                    // row-block slot and stage of this phase
@@ -432,6 +455,7 @@ __device__ __forceinline__ void role(const Args& A) {
                     }
                 },
                 step);
+            S4_STAMP_AT(p + 1);
         });
     };
 
@@ -461,6 +485,13 @@ __device__ __forceinline__ void role(const Args& A) {
         for (int i = 0; i < 4; ++i) { convert_load(b * kTileBytes, i); convert_store(b * kTileBytes, i); }
     }
     wg_barrier();
+#ifdef S4_STAMP
+    const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && wg_lin < 4096) {
+        s4_clock[wg_lin][0] = __builtin_amdgcn_s_memtime();
+        s4_clock[wg_lin][1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     {
         uint32_t off_l = 0, yoff_l = 0, off_c = 2 * kTileBytes, off_d = kA * kTileBytes, yoff_d = kA * NS * 1024;
         int px0_d = (y0 + kA) * W + x0, yrow_d = y0 + kA;
@@ -473,7 +504,12 @@ __device__ __forceinline__ void role(const Args& A) {
                 for (int f = 0; f < kFB - 1; ++f) fb[f] = frag(tb, 2 * rb0 + f);
                 S4_FENCE();
             }
+            S4_STAMP_AT(NPH + 1);
+#ifdef S4_STAMP
+            wg_barrier();
+#else
             asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(kFB - 1) : "memory");       // B(it)
+#endif
             body(it, off_l, yoff_l, off_c, off_d, yoff_d, px0_d, yrow_d, x1w_cur, x1w_prev, x1r_fin);
             off_l = ring_next(off_l);
             off_c = ring_next(off_c);
@@ -489,6 +525,13 @@ __device__ __forceinline__ void role(const Args& A) {
         }
     }
     wait_vm<0>();
+#ifdef S4_STAMP
+    if (threadIdx.x == 0 && wg_lin < 4096) {
+        s4_clock[wg_lin][2] = __builtin_amdgcn_s_memtime();
+        s4_clock[wg_lin][3] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (stamp_wg && lane < 64) (&s4_stamps[sb][0][0])[lane] = reinterpret_cast<const unsigned long long*>(smem + L::total)[sb * 64 + lane];
+#endif
 }
 
 template <int NS>
@@ -554,14 +597,27 @@ extern "C" int svps_retr_stats_level_fwd(const void* feat, int n_stages, const f
     a.HW = H * W; a.H = H; a.W = W; a.tiles_per_chunk = p.tpc; a.chunks_per_strip = p.cps;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static SvpsLdsAttr attr1, attr2;
+#ifdef S4_STAMP
+    constexpr int kStampBytes = 2048;
+#else
+    constexpr int kStampBytes = 0;
+#endif
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
     if (n_stages == 1) {
-        if (hipError_t ae = attr1.ensure(reinterpret_cast<const void*>(svps::s4::retr_stats4_kernel<1>), svps::s4::Lds<1>::total); ae != hipSuccess) return (int)ae;
-        hipLaunchKernelGGL(svps::s4::retr_stats4_kernel<1>, dim3(p.chunks(), T), dim3(256), svps::s4::Lds<1>::total, stream, a);
+        if (hipError_t ae = attr1.ensure(reinterpret_cast<const void*>(svps::s4::retr_stats4_kernel<1>), svps::s4::Lds<1>::total + kStampBytes); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(svps::s4::retr_stats4_kernel<1>, dim3(p.chunks(), T), dim3(256), svps::s4::Lds<1>::total + kStampBytes, stream, a);
     } else {
-        if (hipError_t ae = attr2.ensure(reinterpret_cast<const void*>(svps::s4::retr_stats4_kernel<2>), svps::s4::Lds<2>::total); ae != hipSuccess) return (int)ae;
-        hipLaunchKernelGGL(svps::s4::retr_stats4_kernel<2>, dim3(p.chunks(), T), dim3(256), svps::s4::Lds<2>::total, stream, a);
+        if (hipError_t ae = attr2.ensure(reinterpret_cast<const void*>(svps::s4::retr_stats4_kernel<2>), svps::s4::Lds<2>::total + kStampBytes); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(svps::s4::retr_stats4_kernel<2>, dim3(p.chunks(), T), dim3(256), svps::s4::Lds<2>::total + kStampBytes, stream, a);
     }
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);
     return (int)hipGetLastError();
 }
+
+#ifdef S4_STAMP
+extern "C" int svps_stats4_debug_read(unsigned long long* stamps, unsigned long long* clock) {
+    hipError_t e = hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::s4::s4_stamps), sizeof(unsigned long long) * 4 * 8 * 8);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemcpyFromSymbol(clock, HIP_SYMBOL(svps::s4::s4_clock), sizeof(unsigned long long) * 4096 * 4);
+}
+#endif
