@@ -65,6 +65,11 @@ def parse():
     ap.add_argument("--latency-leg", type=int, default=1, help="0 to skip the single-clip latency leg (profiling runs)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / rendezvous / gather rehearsal without kernels (gloo on CPU; used by tests/test_parallel_cpu.py)")
+    ap.add_argument("--decode-logits", type=int, default=0,
+                    help="1: K2 also writes the fp32 mask logits of all slots [T, L, HW] (round-1/2 workload); 0: argmax-only mode "
+                         "(the step's result is the per-pixel slot assignment + class logits; nothing in the step reads the logits)")
+    ap.add_argument("--exact-leg", type=int, default=1, help="0 to skip the exact-mode (fp32) leg")
+    ap.add_argument("--viper-leg", type=int, default=1, help="0 to skip the informational VIPER (1088x1920 T=10 200 slots) leg")
     ap.add_argument("--whole-detector", type=int, default=1,
                     help="0 to skip the informational whole-detector leg (PyTorch trunk + this path + post-process + tracker)")
     return ap.parse_args()
@@ -101,11 +106,23 @@ def host_cores():
     return n
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(a):
     """the PyTorch-CPU restatement of the slot head + mask decode (oracle/torch_cpu_head.py; the
     reference's own files do not travel) on the host cores of this box: one T-frame clip per iteration, fp32,
-    torch.set_num_threads(all cores) - 1 warm-up, then timed iterations until ~cpu_seconds (at least 3, at most 10), median -
-    and one timed iteration at 8 threads for comparability with the survey container."""
+    torch.set_num_threads(all cores) - 3 warm-up + 10 timed iterations, median (the timed loop stops early, never below 5
+    iterations, once it has used 4 x --cpu-seconds: a slow box must not turn the bench into a CPU benchmark) - and one timed
+    iteration at 8 threads for comparability with the survey container."""
     import statistics
     import numpy as np
     from oracle import slotvps_oracle as orc
@@ -130,9 +147,10 @@ def cpu_baseline(a):
     def timed(n_threads, budget, lo, hi, warm):
         torch.set_num_threads(n_threads)
         ts, t_all = [], time.perf_counter()
-        if warm:
+        for i in range(warm):
+            t_w = time.perf_counter()
             clip()
-            note(f"cpu_baseline: warm-up clip at {n_threads} threads took {time.perf_counter() - t_all:.1f} s")
+            note(f"cpu_baseline: warm-up clip {i + 1} of {warm} at {n_threads} threads took {time.perf_counter() - t_w:.1f} s")
         t_all = time.perf_counter()
         while len(ts) < hi and (len(ts) < lo or time.perf_counter() - t_all < budget):
             t0 = time.perf_counter()
@@ -142,15 +160,15 @@ def cpu_baseline(a):
         return ts
 
     keep = torch.get_num_threads()
-    ts = timed(cores, a.cpu_seconds, 2, 10, True)
-    ts8 = timed(min(8, cores), 0.0, 1, 1, False)
+    ts = timed(cores, 4 * a.cpu_seconds, 5, 10, 3)
+    ts8 = timed(min(8, cores), 0.0, 1, 1, 0)
     torch.set_num_threads(keep)
     med = statistics.median(ts)
-    return {"value": round(T / med, 4), "unit": "frames/s", "cores": int(cores), "kind": "port",
+    return {"value": round(T / med, 4), "unit": "frames/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model(),
             "value_8_threads": round(T / ts8[0], 4), "median_s_per_clip": round(med, 3), "min_s_per_clip": round(min(ts), 3),
             "iterations": len(ts),
             "sample": f"{len(ts)} timed {a.height}x{a.width} T={T} L={a.slots} clips (7-stage head + mask decode of every frame) "
-                      f"after 1 warm-up, PyTorch CPU fp32 restatement of the reference's head (oracle/torch_cpu_head.py, "
+                      f"after 3 warm-up clips, PyTorch CPU fp32 restatement of the reference's head (oracle/torch_cpu_head.py, "
                       f"frames looped in Python like the reference), torch.set_num_threads({cores}); median reported; "
                       f"plus 1 clip at {min(8, cores)} threads"}
 
@@ -218,6 +236,28 @@ def single_clip_latency(a, dev):
         r1.run()
     torch.cuda.synchronize(dev)
     return round((time.perf_counter() - t0) / 20 * 1e3, 3)
+
+
+def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, precision="bf16"):
+    """frames/s of the same graph-replayed step on another configuration (informational legs of the default line)."""
+    from slotvps_amd.clip import SlotClipRunner
+    from slotvps_amd import synth
+    r1 = SlotClipRunner(dev, frames, height, width, L=slots, param_seed=0, cfg=dict(synth.R50_HEAD_CFG, num_classes=num_classes),
+                        use_graph=True, n_slots=1, clips_per_launch=cpl, decode_logits=bool(a.decode_logits))
+    r1.head.set_retriever(a.retriever)
+    if precision == "fp32":
+        r1.head.set_precision("fp32")
+    r1.load_clip(r1.random_clip(7))
+    for _ in range(2):
+        r1.run()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r1.run()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(frames * cpl / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "clips_per_launch": cpl}
 
 
 def launch_ranks(a, argv):
@@ -304,7 +344,7 @@ def main():
     from slotvps_amd import synth
     head_cfg = dict(synth.R50_HEAD_CFG, num_classes=a.num_classes)
     runner = SlotClipRunner(dev, T, a.height, a.width, L=a.slots, param_seed=0, cfg=head_cfg, split_p=not a.fast_p,
-                            use_graph=not a.no_graph, n_slots=n_pool, clips_per_launch=cpl)
+                            use_graph=not a.no_graph, n_slots=n_pool, clips_per_launch=cpl, decode_logits=bool(a.decode_logits))
     runner.head.set_retriever(a.retriever)
     HWf = runner.sizes[-1][0] * runner.sizes[-1][1]
     ncls = runner.cfg["num_classes"]
@@ -403,14 +443,14 @@ def main():
         d = per[dom]
         hbm = d["bound"] == "hbm"
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
         wkey = f"{a.height}x{a.width} T={a.frames} L={a.slots} cpl={cpl}"
         if os.path.exists(pmc):
             with open(pmc) as fh:
                 rec = json.load(fh)
             if rec.get("workload_key") == wkey and dom in rec.get("kernels", {}):
                 traffic = int(rec["kernels"][dom]["traffic_bytes_per_launch"])
-                traffic_src = ("from the stored profile profiles/r02/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                traffic_src = ("from the stored profile profiles/r03/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                f"separate passes, calibrated on a known-bytes copy in the same pass; bench {rec.get('bench_sha', '?')}), not measured in this run")
         # measured on-box ceilings next to the vendor peak: 1 GiB device-to-device, bytes read + written, (a) the
         # runtime's copy, (b) the library's own 16-B-per-lane streaming kernel (also the calibration kernel of the PMC passes)
@@ -459,10 +499,13 @@ def main():
             "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"slot-retriever decode hot path: R50-FPN Slot-VPS head (7 stages over 4 FPN "
-                                   f"levels) + slot->mask decode, {a.height}x{a.width} T={T} clips, {a.slots} slots, "
+            "config": {"workload": f"HOT PATH ONLY (backbone / FPN / post-process are NOT in the step; whole_detector below carries the "
+                                   f"detector figure): R50-FPN Slot-VPS slot-retriever head (7 stages over 4 FPN levels) + slot->mask "
+                                   f"decode with fused per-pixel slot argmax ({'argmax-only: the [T, L, HW] fp32 logits are not written' if not a.decode_logits else 'fp32 logits of all slots written'}), "
+                                   f"{a.height}x{a.width} T={T} clips, {a.slots} slots, "
                                    f"{cpl} independent clips stacked per launch x {cif} in flight per step, "
-                                   f"synthetic FPN features resident in HBM; backbone/FPN not in the step",
+                                   f"synthetic FPN features resident in HBM",
+                       "decode_logits": bool(a.decode_logits),
                        "clip_frames": T, "slots": a.slots, "levels": [list(s) for s in runner.sizes],
                        "parallelism": f"clip-parallel x{world}", "world_size": world,
                        "gather": f"per step, {gatherers[0].bytes_per_submit} B per rank to rank 0, async on a side stream (RCCL)" if world > 1 else "none (one rank)",
@@ -482,6 +525,24 @@ def main():
             except Exception as e:
                 line["single_clip_latency_ms"] = None
                 note(f"single-clip latency leg failed: {type(e).__name__}: {e}")
+        if world == 1 and a.exact_leg:
+            note("exact-mode leg (fp32 storage and arithmetic, one clip per launch) ...")
+            try:
+                ex = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, 1, 3, precision="fp32")
+                ex["what"] = ("head.set_precision('fp32'): fp32 storage + fp32 vector-ALU arithmetic on the whole pixel side (csrc/exact_f32.hip) - "
+                              "the mode that meets 1e-4 on the mask logits and a bit-identical slot argmax against the reference's own fp32 "
+                              "outputs (tests/test_exact_mode_gpu.py); one clip per launch, hipGraph")
+                line["exact_mode"] = ex
+            except Exception as e:
+                line["exact_mode"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+        if world == 1 and a.viper_leg:
+            note("VIPER leg (1088x1920 T=10, 200 slots, 24 classes; informational) ...")
+            try:
+                vp = side_leg(a, dev, 10, 1088, 1920, 200, 24, 8, 3)
+                vp["what"] = "BASELINE config 5 geometry on one GPU: 1088x1920 (1080 padded) T=10 clips, 200 slots, 24 classes, 8 clips stacked per launch, hipGraph"
+                line["other_configs"] = {"viper_1088x1920_T10_L200": vp}
+            except Exception as e:
+                line["other_configs"] = {"viper_1088x1920_T10_L200": {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}}
         if a.whole_detector and world == 1:
             note("whole_detector leg (informational) ...")
             try:

@@ -301,13 +301,10 @@ extern "C" int svps_slot_gemm(const float* x, const void* wpack, const float* bi
     const int rows = small ? 32 : 64;
     const dim3 grid((M + rows - 1) / rows, N / svps::kGmCols);
 #define SVPS_GEMM(A, R, P) hipLaunchKernelGGL((svps::slot_gemm_kernel<A, R, P>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N)
-    const bool wide = wg64 > svps_num_cus();                   // more workgroups than CUs: light variant, several co-resident workgroups per CU
-    if (small) {
+    if (small) {                                               // (not small = at least two 64-row workgroups per CU: the light variant)
         if (act == 0) SVPS_GEMM(0, 1, true); else if (act == 1) SVPS_GEMM(1, 1, true); else SVPS_GEMM(2, 1, true);
-    } else if (wide) {
-        if (act == 0) SVPS_GEMM(0, 2, false); else if (act == 1) SVPS_GEMM(1, 2, false); else SVPS_GEMM(2, 2, false);
     } else {
-        if (act == 0) SVPS_GEMM(0, 2, true); else if (act == 1) SVPS_GEMM(1, 2, true); else SVPS_GEMM(2, 2, true);
+        if (act == 0) SVPS_GEMM(0, 2, false); else if (act == 1) SVPS_GEMM(1, 2, false); else SVPS_GEMM(2, 2, false);
     }
 #undef SVPS_GEMM
     return (int)hipGetLastError();
@@ -326,9 +323,8 @@ extern "C" int svps_slot_gemm_ln(const float* x, const void* wpack, const float*
     const bool small = wg64 < 2 * svps_num_cus();
     const int rows = small ? 32 : 64;
     const dim3 grid((M + rows - 1) / rows, 1);
-    const bool wide = wg64 > svps_num_cus();
 #define SVPS_GEMM_LN(R, P) hipLaunchKernelGGL((svps::slot_gemm_kernel<0, R, P, true>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N, ln)
-    if (small) SVPS_GEMM_LN(1, true); else if (wide) SVPS_GEMM_LN(2, false); else SVPS_GEMM_LN(2, true);
+    if (small) SVPS_GEMM_LN(1, true); else SVPS_GEMM_LN(2, false);
 #undef SVPS_GEMM_LN
     return (int)hipGetLastError();
 }

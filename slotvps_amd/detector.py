@@ -331,7 +331,14 @@ class VPS_Temporal_Slots(nn.Module):
         """The slot head on one clip's level maps; with `use_graph` the whole head (about 200 launches) is captured once per
         input geometry into a hipGraph and replayed on static buffers (the returned tensors are then valid until the next call)."""
         im = self.image_model
-        key = tuple(tuple(f.shape) for f in feats) + (str(feats[0].device),)
+        head = im.dynamic_mask_head
+        # The captured graph bakes in pointers to weight-DERIVED tensors (packed K8 weights, QR factors, position tables) and the
+        # kernel choices of the current modes: key it on the identity + version of every head parameter and on the mode switches,
+        # so load_state_dict / in-place edits / set_precision / set_retriever / set_slot_gemm / the ops-level forms re-capture.
+        wkey = tuple((p_.data_ptr(), p_._version) for p_ in head.parameters()) + (im.init_mask_query.weight.data_ptr(), im.init_mask_query.weight._version)
+        modes = tuple(sorted({(type(m).__name__, getattr(m, "precision", None), getattr(m, "retriever", None), getattr(m, "use_slot_gemm", None))
+                              for m in head.modules() if hasattr(m, "precision")})) + (ops.RETR_ATTN_FORM, ops.RETR_STATS_FORM)
+        key = tuple(tuple(f.shape) for f in feats) + (str(feats[0].device), hash(wkey), modes)
         ent = self._head_cache.get(key)
         if ent is None:
             D = im.init_mask_query.weight.shape[1]
@@ -347,13 +354,23 @@ class VPS_Temporal_Slots(nn.Module):
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(2):                           # lazy initialisations, weight-derived constants, allocator
-                    run(ent["static"])
+                    eager = run(ent["static"])
+                eager = [eager[0].clone(), eager[1].clone()] + [f.clone() for f in eager[2]]
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 ent["out"] = run(ent["static"])
             ent["graph"] = g
+            # a launch the runtime refuses during capture is simply missing from the graph: validate the FIRST replay against the
+            # eager step on the same inputs (every kernel is deterministic), as SlotClipRunner.run does
+            g.replay()
+            torch.cuda.synchronize(dev)
+            got = [ent["out"][0], ent["out"][1]] + list(ent["out"][2])
+            for i, (a_, b_) in enumerate(zip(got, eager)):
+                if not torch.equal(a_, b_):
+                    raise RuntimeError(f"hipGraph replay of the slot head differs from the eager step (output {i}): "
+                                       "a launch was refused or reordered during capture")
         for dst, src in zip(ent["static"], feats):
             dst.copy_(src)
         ent["graph"].replay()

@@ -28,9 +28,10 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
-        if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
-            torch.cuda.set_device(local_rank)            # also for gloo ranks that compute on a GPU
-        if backend == "nccl":
+        if backend == "nccl":                            # (gloo ranks make no HIP call here: `bench.py --dry-run-cpu` must not touch the GPU)
+            if local_rank >= torch.cuda.device_count():
+                raise RuntimeError(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
+            torch.cuda.set_device(local_rank)
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world

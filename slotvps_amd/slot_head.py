@@ -98,7 +98,13 @@ def fast_linear_ln(owner, name, x, weight, bias, norm, pre=None, post=None, relu
 
 
 def _act_name(fn):
-    return "relu" if fn is F.relu else ("gelu" if fn is F.gelu else None)
+    """Epilogue name of K8 for the FFN activation; anything else than relu / gelu (the reference also accepts "glu",
+    dynamic_mask_head.py:575-583) has no fused form here and must not be dropped silently."""
+    if fn is F.relu:
+        return "relu"
+    if fn is F.gelu:
+        return "gelu"
+    raise NotImplementedError(f"FFN activation {getattr(fn, '__name__', fn)!r}: the slot-side kernels implement relu and gelu (the released configs)")
 
 
 class ConvModule(nn.Module):

@@ -20,6 +20,11 @@ from util import orc, GOLDEN
 pytestmark = pytest.mark.gpu
 
 
+# per-pixel slot argmax of the FREE-running head (its own embeddings through all seven stages) against the argmax of the reference's
+# fp32 mask logits, last frame: measured minimum over the fixture cases, asserted with a margin
+SAME_FREE_MIN = {"fused": 0.85, "kv": 0.80}      # measured 87.1 / 91.0 % (fused), 85.0 / 83.2 % (kv)
+
+
 def build_head(cuda, params):
     import torch
     from slotvps_amd.slot_head import MultiScaleDynamicMaskHead
@@ -162,6 +167,7 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
           f"{100 * same:.2f} % of the pixels (free-running head: {100 * same_free:.2f} %)")
     # mask logits = fg_scale * e . normalize(bn(f)): the bf16 map moves them by ~1e-3 of their O(0.1) range
     assert m_err <= 2e-3 and same >= 0.97
+    assert same_free >= SAME_FREE_MIN[form], same_free          # free-running: seven stages of bf16-map rounding through sharp softmaxes
 
 
 def test_reference_signature_roundtrip(cuda):
@@ -286,3 +292,69 @@ def test_stacked_clips_equal_separate_clips(cuda):
             t[Tc:] = t[Tc:].flip(0)                                        # permute the frames of the OTHER clips
         lg2, em2, _ = head.forward_clip(tf2, slots, tabs, clip_frames=Tc)
     assert torch.equal(em2[:, :Tc], em[:, :Tc]) and torch.equal(lg2[:, :Tc], lg[:, :Tc])
+
+
+@pytest.mark.parametrize("tag", ["T2_64x128", "T3_64x64"])
+def test_free_running_bf16_head_to_panoptic_ids(cuda, tag):
+    """End-to-end INTEGER parity of the fast (bf16, fused-retriever) path: free-running head -> K2 -> K6 post-process -> relabel
+    (vps_temporal_slots.py:284-299 -> 411-435), against the panoptic ids the ORACLE pipeline produces from the REFERENCE's own fp32
+    head outputs (class logits + mask logits of the fixture, tests/golden/head_small.npz). Both sides get the same fixed
+    slot -> class bias (random-init slots all predict "no object") and the same scalar gain on the mask logits (the
+    fixture's fg_bn weight 0.1 leaves them in a +-0.1 range where no slot reaches the 0.4 pixel threshold).
+    The bf16 storage of the fused maps moves slot embeddings by up to 6e-2 per stage (test above), so the ids cannot be bit-equal:
+    the measured pixel agreement is asserted."""
+    import sys
+    import torch
+    from util import ROOT
+    sys.path.insert(0, ROOT)
+    from oracle import postprocess_oracle as po
+    from slotvps_amd import ops
+    from slotvps_amd.slot_head import generate_final_outputs
+    from slotvps_amd.postprocess import PostProcessPanopticInstances
+    z = np.load(os.path.join(GOLDEN, "head_small.npz"))
+    T, H, W, L, seed = (int(x) for x in z[f"{tag}_meta"])
+    params = synth.make_params(synth.head_shapes(), seed)
+    feats = synth.make_clip_features(seed + 1, T, H, W)
+    slots = synth.make_slots(seed + 2, L)
+    sizes = synth.level_sizes(H, W)
+    h, w = sizes[-1]
+    head = build_head(cuda, params)
+    wb, bb, mu, var = z[f"{tag}_bn"]
+    fg = z[f"{tag}_fg"]
+    feat_bn = torch.nn.BatchNorm2d(256).to(cuda).eval()
+    fg_bn = torch.nn.BatchNorm2d(1).to(cuda).eval()
+    gain = 400.0
+    bias = np.zeros((L, 20), dtype=np.float32)
+    bias[np.arange(L), np.arange(L) % 19] = 12.0
+    cfg = dict(is_thing_map={i: i > 10 for i in range(20)}, threshold=0.85, fraction_threshold=0.03, pixel_threshold=0.4,
+               apply_mask_removal=True, apply_mask_removal_only_ins=True, use_mask_low_constant=False)
+    with torch.no_grad():
+        feat_bn.weight.copy_(torch.from_numpy(wb)); feat_bn.bias.copy_(torch.from_numpy(bb))
+        feat_bn.running_mean.copy_(torch.from_numpy(mu)); feat_bn.running_var.copy_(torch.from_numpy(var))
+        fg_bn.weight.fill_(float(fg[0])); fg_bn.bias.fill_(float(fg[1]))
+        fg_bn.running_mean.fill_(float(fg[2])); fg_bn.running_var.fill_(float(fg[3]))
+        tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
+        pos_tabs = [ops.pos_embed_sine_tables(hh, ww, 256, cuda) for (hh, ww) in sizes]
+        logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(slots).to(cuda), pos_tabs)
+        masks = generate_final_outputs(fused[3], embeds[6].contiguous(), feat_bn, fg_bn)
+        pp = PostProcessPanopticInstances(**cfg)
+        t = T - 1
+        res = pp.forward_tensors(logits[6, t] + torch.from_numpy(bias).to(cuda), (gain * masks[t]).view(L, h, w).contiguous(), (4 * h, 4 * w))
+        ids, cls_inds, _ = pp.panoptic_ids(res)
+        torch.cuda.synchronize()
+    ids = ids.cpu().numpy().astype(np.int64).reshape(4 * h, 4 * w)
+    # the reference's fp32 outputs through the oracle pipeline
+    o = po.postprocess(z[f"{tag}_logits_{t}"][6] + bias, (gain * z[f"{tag}_mask"]).reshape(L, h, w), (4 * h, 4 * w))
+    want_ids, want_cls, _ = po.panoptic_relabel(o["masks"], o["labels"])
+    want_ids = np.asarray(want_ids).reshape(4 * h, 4 * w)
+    agree = float((ids == want_ids).mean())
+    # semantic agreement (class of the pixel's segment; instance numbering can permute when two scores are within rounding)
+    def sem(x):
+        return np.where(x >= 1000, x // 1000, x)
+    agree_sem = float((sem(ids) == sem(want_ids)).mean())
+    print(f"\n[{tag}] free-running bf16 head -> K2 -> K6 -> relabel vs oracle pipeline on the reference's fp32 outputs: panoptic ids equal on "
+          f"{100 * agree:.2f} % of the pixels (semantic class: {100 * agree_sem:.2f} %); segments {len(cls_inds)} vs {len(want_cls)}")
+    assert len(np.unique(want_ids)) > 3, "degenerate case: the reference side kept (almost) nothing"
+    assert len(cls_inds) == len(want_cls)                     # the same segments survive
+    # measured on MI355X: 86.2 % (T2_64x128: seven kept segments, the last stages' embeddings are 0.4 - 1.9 apart) and 98.4 % (T3_64x64)
+    assert agree >= {"T2_64x128": 0.84, "T3_64x64": 0.97}[tag], agree
