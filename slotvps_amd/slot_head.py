@@ -97,6 +97,9 @@ def fast_linear_ln(owner, name, x, weight, bias, norm, pre=None, post=None, relu
                             post=None if post is None else post.contiguous(), relu=relu, out=out)
 
 
+FP16_MAX = 65504.0
+
+
 def _act_name(fn):
     """Epilogue name of K8 for the FFN activation; anything else than relu / gelu (the reference also accepts "glu",
     dynamic_mask_head.py:575-583) has no fused form here and must not be dropped silently."""
@@ -146,6 +149,12 @@ class MaskDynamicConv(nn.Module):
         # K3' + K1' - no k / v tensors, the map is read once per kernel; "kv": K3 writes bf16 k / v, K1 streams them
         self.retriever = "fused"
         self.use_slot_gemm = True   # K8 for the dense layers (bf16 mode)
+        # The fused form converts the stored bf16 map to fp16 in LDS: exact for |f| in [6.1e-5, 65504]; smaller values lose bits
+        # (down to 6e-8, then zero), larger ones SATURATE at +-65504 (v_cvt_pkrtz). range_check = True looks at the map's
+        # maximum before every fused call (one device -> host sync) and runs the kv form - another HIP kernel pair, bf16
+        # arithmetic, no fp16 staging - for a map that exceeds the range, with a one-time warning. Off by default: maps behind
+        # the level-fusion conv of batch-normalised features are O(1) ... O(100).
+        self.range_check = False
 
     def _bf16_weights(self):
         """to_k / to_v weight matrices rounded to bf16 once (re-derived if the parameters change)."""
@@ -264,7 +273,15 @@ class MaskDynamicConv(nn.Module):
                                       self.norm_v.bias, self.norm_v.eps)
             return ops.slot_attn_f32(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
         if self.retriever == "fused":
-            return self.forward_fused(slots, feat_pm, hw, pos_tabs)
+            if self.range_check and float(feat_pm.abs().max()) > FP16_MAX:
+                if not getattr(MaskDynamicConv, "_warned_range", False):
+                    MaskDynamicConv._warned_range = True
+                    import warnings
+                    warnings.warn("fused retriever: the feature map exceeds the fp16 range (|f| > 65504); running the kv form "
+                                  "(bf16 k / v tensors, csrc/kv_project.hip + csrc/slot_attn.hip) for such maps")
+                self._level_stats = None
+            else:
+                return self.forward_fused(slots, feat_pm, hw, pos_tabs)
         q = ops.row_ln(self.to_q(slots), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps, out_bf16=True)
         k, v = self.project_kv(feat_pm, hw, pos_tabs)
         return ops.slot_attn(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps, split_p=self.split_p)
