@@ -238,6 +238,56 @@ def single_clip_latency(a, dev):
     return round((time.perf_counter() - t0) / 20 * 1e3, 3)
 
 
+def bind_rank_cpus(local_rank, world):
+    """Give rank `local_rank` of `world` its own slice of the CPUs the job may run on (affinity) and size torch's intra-op pool to
+    it. Returns what was done, for the bench line."""
+    info = {"threads": torch.get_num_threads(), "cpus": None}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        n = max(1, min(len(allowed), host_cores()) // max(1, world))
+        mine = allowed[local_rank * n:(local_rank + 1) * n] or allowed
+        if world > 1:
+            os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, len(mine) if world > 1 else torch.get_num_threads()))
+        info = {"threads": torch.get_num_threads(), "cpus": [mine[0], mine[-1]] if world > 1 else None}
+    except (AttributeError, OSError) as e:
+        info["error"] = f"{type(e).__name__}: {e}"[:80]
+    return info
+
+
+def rank_detector_leg(a, dev, iters=3):
+    """Informational, every rank at N > 1, after the timed region: ms per clip of the WHOLE detector on this rank (PyTorch trunk,
+    this library, GPU post-process, tracker + its HOST part) - the per-rank host work the hot-path step does not contain. No
+    collective inside: a failure on one rank cannot hang the others (-1 is reported for it)."""
+    try:
+        from slotvps_amd.config import Config
+        from slotvps_amd.registry import build_detector
+        cfg = Config.fromfile(os.path.join(ROOT, "configs", "r50_fpn_slotvps_mi355x.py"))
+        torch.manual_seed(0)
+        det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
+        T, H, W = a.frames, a.height, a.width
+        imgs = torch.randn(T, 3, H, W, device=dev)
+        table = torch.zeros(a.slots, 20, device=dev)
+        table[torch.arange(a.slots), torch.arange(a.slots) % 19] = 12.0
+        with torch.no_grad():
+            det.image_model.fg_bn.weight.fill_(40.0)
+        base = det.head_path
+        det.head_path = lambda f: (lambda lg, em, mk: (lg + table, em, mk))(*base(f))
+        metas = [dict(iid=10001 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png") for t in range(T)]
+        det.use_graph = True
+        with torch.no_grad():
+            det.clip_test(imgs, metas)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                det.clip_test(imgs, metas)
+            torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / iters * 1e3
+    except Exception as e:                                   # informational: never costs the bench line
+        note(f"rank detector leg failed: {type(e).__name__}: {e}")
+        return -1.0
+
+
 def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, precision="bf16"):
     """frames/s of the same graph-replayed step on another configuration (informational legs of the default line)."""
     from slotvps_amd.clip import SlotClipRunner
@@ -289,24 +339,34 @@ def dry_run_cpu(a):
     rank, local_rank, world = parallel.init_distributed(backend="gloo")
     dev = torch.device("cpu")
     T, cpl = a.frames, max(1, a.clips_per_launch)
-    tmpl = {"slot_argmax": torch.zeros((cpl * T, 64), dtype=torch.uint8), "class_logits": torch.zeros((cpl * T, a.slots, 20))}
+    tmpl = {"slot_argmax": torch.zeros((cpl * T, 64), dtype=torch.uint8), "class_logits": torch.zeros((cpl * T, a.slots, 20)),
+            "checksum": torch.zeros((2,), dtype=torch.float64)}
     gat = parallel.ClipResultGatherer(tmpl, depth=2)
     parallel.barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        out = {"slot_argmax": torch.full_like(tmpl["slot_argmax"], (rank * 16 + i) % 251),
-               "class_logits": torch.full_like(tmpl["class_logits"], float(rank))}
+        am = torch.full_like(tmpl["slot_argmax"], (rank * 16 + i) % 251)
+        cl = torch.full_like(tmpl["class_logits"], float(rank) + 0.5)
+        out = {"slot_argmax": am, "class_logits": cl,
+               "checksum": torch.stack([am.sum(dtype=torch.float64), cl.abs().sum(dtype=torch.float64)])}
         d = gat.submit(out)
     gat.drain()
     parallel.barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    own = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(own, dev)
+    per_rank_ms = parallel.gather_to_rank0(torch.tensor([own / max(1, a.steps) * 1e3], dtype=torch.float64))
     ok = True
     if rank == 0 and a.steps > 0:
         got = gat.last(d)
-        ok = all(int(got["slot_argmax"][r][0, 0]) == (r * 16 + a.steps - 1) % 251 and float(got["class_logits"][r][0, 0, 0]) == r
+        ok = all(int(got["slot_argmax"][r][0, 0]) == (r * 16 + a.steps - 1) % 251 and float(got["class_logits"][r][0, 0, 0]) == r + 0.5
                  for r in range(world))
+        for r in range(world):                               # the same self-check the GPU path runs: payload vs the sender's sums
+            c_am, c_cl = (float(x) for x in got["checksum"][r])
+            ok = ok and float(got["slot_argmax"][r].sum(dtype=torch.float64)) == c_am
+            ok = ok and abs(float(got["class_logits"][r].abs().sum(dtype=torch.float64)) - c_cl) <= 1e-9 * max(1.0, c_cl)
         print(json.dumps({"metric": "dry run (no kernels)", "value": 0.0, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "dry_run": True, "gather_ok": bool(ok), "world_size": world,
+                          "per_rank_ms_per_step": [round(float(x[0]), 3) for x in per_rank_ms],
                           "backend": "gloo", "ms_per_step": round(elapsed / max(1, a.steps) * 1e3, 3)}), flush=True)
     if world > 1:
         parallel.barrier()
@@ -336,6 +396,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     _lib.load()
+    # host side of a rank (launch loop, staging copies, the informational detector leg): a disjoint slice of the cores this job may
+    # use, so that N ranks do not time-share one set of cores (SURVEY 8e names the host side as the scaling risk)
+    binding = bind_rank_cpus(local_rank, world)
 
     T = a.frames
     cif = max(1, a.clips_in_flight)
@@ -353,12 +416,16 @@ def main():
         runner.load_clip(runner.random_clip(1234 + rank * 1000 + i), slot=i)
     # per-step results of this rank's clips -> rank 0, overlapped with the next step (one gatherer per stream)
     tmpl = {"slot_argmax": torch.zeros((cpl * T, HWf), dtype=torch.uint8, device=dev),
-            "class_logits": torch.zeros((cpl * T, a.slots, ncls), dtype=torch.float32, device=dev)}
+            "class_logits": torch.zeros((cpl * T, a.slots, ncls), dtype=torch.float32, device=dev),
+            # what the sender saw: rank 0 recomputes both sums from the payload it received from EVERY rank (gather_ok)
+            "checksum": torch.zeros((2,), dtype=torch.float64, device=dev)}
     gatherers = [parallel.ClipResultGatherer(tmpl, depth=2) for _ in range(cif)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(cif)] if cif > 1 else None
 
     def result_of(out):
-        return {"slot_argmax": out["slot_argmax"], "class_logits": out["class_logits"][-1]}
+        am, cl = out["slot_argmax"], out["class_logits"][-1]
+        return {"slot_argmax": am, "class_logits": cl,
+                "checksum": torch.stack([am.sum(dtype=torch.float64), cl.abs().sum(dtype=torch.float64)])}
 
     def step(i, record):
         if cif == 1:
@@ -395,11 +462,23 @@ def main():
     torch.cuda.synchronize(dev)
     parallel.barrier()
     torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(elapsed, dev)
+    elapsed_own = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(elapsed_own, dev)
+    per_rank_ms = parallel.gather_to_rank0(torch.tensor([elapsed_own / max(1, a.steps) * 1e3], dtype=torch.float64, device=dev))
+    gather_ok, rank_sums = None, None
     if rank == 0 and a.steps > 0:
         got = gatherers[0].last((gatherers[0].n - 1) % gatherers[0].depth)
         assert len(got["slot_argmax"]) == world and got["slot_argmax"][0].shape == tmpl["slot_argmax"].shape
+        rank_sums, gather_ok = [], True
+        for r_ in range(world):                              # the payload of EVERY rank against the sums its sender computed
+            s_am = float(got["slot_argmax"][r_].sum(dtype=torch.float64))
+            s_cl = float(got["class_logits"][r_].abs().sum(dtype=torch.float64))
+            c_am, c_cl = (float(x) for x in got["checksum"][r_])
+            ok_r = s_am == c_am and abs(s_cl - c_cl) <= 1e-9 * max(1.0, abs(c_cl)) and s_cl > 0.0
+            gather_ok = gather_ok and ok_r
+            rank_sums.append({"rank": r_, "slot_argmax_sum": s_am, "ok": bool(ok_r)})
+        if not gather_ok:
+            note(f"GATHER CHECK FAILED: {rank_sums}")
 
     if rank == 0:
         note(f"timed region done: {elapsed / max(1, a.steps) * 1e3:.2f} ms per step; roofline leg ...")
@@ -508,6 +587,9 @@ def main():
                        "decode_logits": bool(a.decode_logits),
                        "clip_frames": T, "slots": a.slots, "levels": [list(s) for s in runner.sizes],
                        "parallelism": f"clip-parallel x{world}", "world_size": world,
+                       "backend": (torch.distributed.get_backend() + " (RCCL)") if world > 1 else "none",
+                       "per_rank_ms_per_step": [round(float(x[0]), 3) for x in per_rank_ms] if per_rank_ms is not None else None,
+                       "gather_ok": gather_ok, "gathered_payloads": rank_sums, "host_cpu_binding_rank0": binding,
                        "gather": f"per step, {gatherers[0].bytes_per_submit} B per rank to rank 0, async on a side stream (RCCL)" if world > 1 else "none (one rank)",
                        "hipgraph": not a.no_graph, "clips_in_flight": cif, "clips_per_launch": cpl,
                        "retriever": runner.retriever_form},
@@ -549,6 +631,26 @@ def main():
                 line["whole_detector"] = whole_detector_leg(a, dev)
             except Exception as e:                       # informational leg: never costs the bench line
                 line["whole_detector"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    if world > 1 and a.whole_detector:
+        # informational: the whole detector per rank (trunk + this path + post-process + HOST tracker work), one clip at a time, all
+        # ranks at once; independent per rank, then one gather of a number
+        if rank == 0:
+            note("per-rank whole-detector leg (informational) ...")
+        ms = rank_detector_leg(a, dev)
+        allms = parallel.gather_to_rank0(torch.tensor([ms], dtype=torch.float64, device=dev))
+        if rank == 0:
+            vals = [float(x[0]) for x in allms]
+            good = [v for v in vals if v > 0]
+            line["whole_detector_per_rank"] = {
+                "ms_per_clip": [round(v, 2) for v in vals],
+                "value": round(len(good) * a.frames / (max(good) * 1e-3), 2) if good else None, "unit": "frames/s",
+                "what": f"every rank runs the whole detector (PyTorch fp32 trunk + this library + GPU post-process + tracker) on its own "
+                        f"{a.height}x{a.width} T={a.frames} clips at the same time, 3 timed clips each; value = ranks x T / slowest rank's "
+                        f"time per clip; informational, never part of `value`"}
+    if rank == 0:
+        line["notes"] = ("multi-GPU: tests/test_parallel_gpu.py::test_two_rank_rccl_gather needs two GPUs and is SKIPPED on the one-GPU "
+                         "boxes the builder can use (RCCL refuses two ranks on one device); the N > 1 path is covered by two-rank gloo "
+                         "tests on CPU (tests/test_parallel_cpu.py) and verified at run time by gather_ok above")
         print(json.dumps(line), flush=True)
     if world > 1:
         parallel.barrier()

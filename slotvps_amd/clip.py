@@ -80,8 +80,14 @@ class SlotClipRunner:
     def _step(self, slot=0):
         logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs,
                                                        clip_frames=self.clip_frames)
-        masks, amax = ops.mask_decode(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift,
-                                      self.fg_scale, self.fg_shift, want_argmax=True, want_logits=self.decode_logits)
+        if fused[-1].dtype == torch.float32:                 # exact mode (head.set_precision("fp32")): fp32 map, fp32 decode kernel
+            masks = ops.mask_decode_f32(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift, self.fg_scale, self.fg_shift)
+            amax = masks.argmax(dim=1).to(torch.uint8)
+            if not self.decode_logits:
+                masks = None
+        else:
+            masks, amax = ops.mask_decode(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift,
+                                          self.fg_scale, self.fg_shift, want_argmax=True, want_logits=self.decode_logits)
         out = dict(class_logits=logits, slot_embeds=embeds, slot_argmax=amax)
         if masks is not None:
             out["mask_logits"] = masks

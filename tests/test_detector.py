@@ -228,6 +228,52 @@ def test_hip_slot_path_is_deterministic():
 
 
 @pytest.mark.gpu
+def test_head_graph_follows_weight_and_mode_changes():
+    """detector._head_clip with use_graph=True: the captured hipGraph bakes in weight-derived tensors (packed K8 weights, QR
+    factors) and the kernel choices of the current modes. After an in-place weight edit, a load_state_dict and a mode switch the
+    graph path must return what the eager path returns for the NEW state (the cache is keyed on parameter versions + modes)."""
+    from slotvps_amd import ops
+    dev = torch.device("cuda:0")
+    det = _make_detector(dev)
+    im = det.image_model
+    g = torch.Generator(device=dev).manual_seed(3)
+    sizes = [(4, 8), (8, 16), (16, 32), (32, 64)]
+    feats = [torch.randn(2, 128, h, w, device=dev, generator=g) for h, w in sizes]
+
+    def both():
+        det.use_graph = True
+        a = det._head_clip(feats)
+        a = [a[0].clone(), a[1].clone()] + [f.clone() for f in a[2]]
+        det.use_graph = False
+        b = det._head_clip(feats)
+        b = [b[0], b[1]] + list(b[2])
+        torch.cuda.synchronize()
+        return a, b
+
+    with torch.no_grad():
+        a, b = both()
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+        first = a[1].clone()
+        lin = im.dynamic_mask_head.head_series_1[0].inst_interact.to_k          # feeds the QR factor of the statistics kernel
+        lin.weight.mul_(1.5)                                                    # in-place edit: _version changes, data_ptr does not
+        a, b = both()
+        assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[1], first)
+        sd = {k: v.clone() for k, v in im.dynamic_mask_head.state_dict().items()}
+        sd["head_series_2.0.linear1.weight"] = sd["head_series_2.0.linear1.weight"] * 0.5     # packed K8 weight
+        im.dynamic_mask_head.load_state_dict(sd)
+        second = a[1].clone()
+        a, b = both()
+        assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[1], second)
+        saved = ops.RETR_STATS_FORM
+        try:
+            ops.RETR_STATS_FORM = "stage"                                       # an ops-level mode switch re-captures as well
+            a, b = both()
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
+        finally:
+            ops.RETR_STATS_FORM = saved
+
+
+@pytest.mark.gpu
 def test_baseline_config0_512x1024_first_frame():
     """BASELINE config 0: the reference's own r50 config, one 512x1024 frame paired with itself (first frame of a
     video, tools/dataset/cityscapes_vps.py:262), random init. The head sees two identical frames; with random weights no
