@@ -398,7 +398,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         if (ARGMAX && w == 0 && it >= 1) finish_argmax(it - 1);
         const char* ft = smem + Lds::ring + (it % NST) * kTileBytes;
 
-        {   // ||scale * f + shift||^2 per pixel: 2 NW threads per pixel, 16 / NW chunks each
+        // Argmax-only mode: m = (s + c) * inr * fg_scale + fg_shift is a monotone function of s + c for a pixel (inr > 0), so
+        // the per-pixel norm is not needed to order the slots - the argmax is taken over sgn(fg_scale) * (s + c). It equals the
+        // full mode's argmax except where two slots' logits round to the SAME fp32 value (the full mode then reports the lower
+        // slot, this mode the larger s + c): pixels without a decision at fp32 resolution.
+        if constexpr (LOGITS) {   // ||scale * f + shift||^2 per pixel: 2 NW threads per pixel, 16 / NW chunks each
             constexpr int TPP = 2 * NW;
             const int npx = tid_o / TPP, nsub = tid_o % TPP;
             float ss = 0.f;
@@ -438,9 +442,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        wg_barrier();                                    // inv_norm of this tile visible
-
-        const float inr = inv_norm[r];
+        float inr = 1.f;
+        if constexpr (LOGITS) {
+            wg_barrier();                                // inv_norm of this tile visible
+            inr = inv_norm[r];
+        }
+        const float ksgn = fg_scale > 0.f ? 1.f : (fg_scale < 0.f ? -1.f : 0.f);
         float best = -INFINITY;
         int best_slot = 0x7fffffff;
 #pragma unroll
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
             const int sl = acc_row(i, h);                // slot inside this wave's block of 32
             f32x4 c4;
             if ((i & 3) == 0) c4 = *reinterpret_cast<const f32x4*>(cs + 32 * w + sl);   // e . shift of slots sl .. sl + 3
-            const float m = (s[i] + c4[i & 3]) * inr * fg_scale + fg_shift;
+            const float m = LOGITS ? (s[i] + c4[i & 3]) * inr * fg_scale + fg_shift : (s[i] + c4[i & 3]) * ksgn;
             if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + r * 4) = m;
             if constexpr (ARGMAX) {
                 if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane

@@ -49,3 +49,5 @@ for lv in a.levels.split(","):
         e = torch.relu(torch.randn((a.T, 100, 256), generator=g, device=dev))
         timeit(lambda: ops.mask_decode(f, e, torch.ones(256, device=dev), bc, 0.1, 0.0, want_argmax=True),
                _lib.KERNEL_MASK_DECODE, a.T * HW * (512 + 400 + 1), f"K2 {lv:>8} fp32 out + argmax")
+        timeit(lambda: ops.mask_decode(f, e, torch.ones(256, device=dev), bc, 0.1, 0.0, want_argmax=True, want_logits=False),
+               _lib.KERNEL_MASK_DECODE, a.T * HW * (512 + 1), f"K2 {lv:>8} argmax only      ")
