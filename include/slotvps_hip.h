@@ -155,6 +155,11 @@ int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, 
 int svps_row_ln(const float* x, const float* pre, const float* post, const float* w, const float* b, float eps,
                 int relu, int rows, int rows_per_group, int D, float* out_f32, void* out_bf16, void* stream);
 
+/* Softmax over the last index of x [rows, cols] fp32 -> y (y may be x): the temporal retriever's softmax over the query axis
+ * (mmdet/models/detectors/dynamic_mask_head.py:559-567: F.softmax(attn, dim=1) of [1, Lq, Lk], applied here to the transposed
+ * logits [Lk, Lq]); max / exp / sum / divide in fp32 like torch.softmax. */
+int svps_row_softmax(const float* x, float* y, int rows, int cols, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K7' deformable convolution forward without a column buffer (slotvps_amd/csrc/deform_conv_fused.hip): replaces
  * deform_conv_forward_cuda (mmdet/ops/dcn/src/deform_conv_cuda.cpp:152-258 = deformable_im2col,

@@ -63,6 +63,26 @@ __global__ __launch_bounds__(256) void row_ln_kernel(const float* __restrict__ x
     }
 }
 
+// ---- softmax over the last index of [rows, cols] fp32 (the temporal retriever's softmax over the query axis,
+// dynamic_mask_head.py:559-567, applied to the transposed logits): one wavefront per row, torch.softmax's arithmetic
+// (max, exp(x - max), sum, divide), in place if y == x. Rows are 2 KB: the second and third read come from L1 / L2.
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * cols;
+    float* yr = y + (size_t)row * cols;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += expf(xr[c] - m);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int c = lane; c < cols; c += 64) yr[c] = expf(xr[c] - m) * inv;
+}
+
 // ---- query side of the statistics-fused retriever (retr_attn.hip) -------------------------------------------------
 // One wavefront per (frame, padded slot row). From x = to_q(slots) (the GEMM stays a library call):
 //     q = norm_q(x)                         MaskDynamicConv.forward :431
@@ -304,5 +324,12 @@ extern "C" int svps_row_ln(const float* x, const float* pre, const float* post, 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(svps::row_ln_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, pre, post, w, b, eps, relu,
                        rows, rows_per_group, out_f32, static_cast<__bf16*>(out_bf16));
+    return (int)hipGetLastError();
+}
+
+extern "C" int svps_row_softmax(const float* x, float* y, int rows, int cols, void* stream_) {
+    if (!x || !y) return SVPS_ERR_BAD_ARG;
+    if (rows <= 0 || cols <= 0) return SVPS_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(svps::row_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), x, y, rows, cols);
     return (int)hipGetLastError();
 }

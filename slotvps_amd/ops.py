@@ -246,6 +246,19 @@ def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=No
     return out
 
 
+def row_softmax(x, inplace=False):
+    """Softmax over the last index of a contiguous fp32 tensor (csrc/row_ops.hip), one wavefront per row."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    out = x if inplace else torch.empty_like(x)
+    with _on(x, out) as ctx:
+        rc = lib.svps_row_softmax(_ptr(x), _ptr(out), rows, cols, ctx.stream)
+    _lib.check(rc, "svps_row_softmax")
+    return out
+
+
 # ---- statistics-fused retriever (csrc/retr_stats.hip, csrc/retr_attn.hip) -------------------------------------------
 def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     """K3': per-pixel reciprocal standard deviations of the key / value LayerNorms, as the aux rows K1' consumes.

@@ -358,7 +358,7 @@ class SlotsDynamicConv(nn.Module):
         # softmax over the QUERY axis (dim=1 of [1, Lq, Lk], :562) = last-dim softmax of the transposed logits
         if self.precision != "fp32" and self.use_slot_gemm and q.is_cuda:
             # K9 (csrc/bgemm.hip): both products on the matrix cores in split bf16; the second one reads attn_t k-major
-            attn_t = torch.softmax(ops.bgemm(k, q), dim=-1)                     # [G, Lk, Lq]
+            attn_t = ops.row_softmax(ops.bgemm(k, q), inplace=True)            # [G, Lk, Lq]
             out = ops.bgemm(attn_t.transpose(1, 2), v.transpose(1, 2)).view(1, -1, self.hidden_dim)
         else:
             attn_t = torch.softmax(k @ q.transpose(-1, -2), dim=-1)     # [1, Lk, Lq]
@@ -471,9 +471,10 @@ class MaskRCNNHead(nn.Module):
         hid = fast_linear(self, "linear1", x2, self.linear1.weight, self.linear1.bias, act=_act_name(self.activation))
         return fast_linear_ln(self, "linear2", hid, self.linear2.weight, self.linear2.bias, self.norm3, pre=x2)   # :379, :384-385
 
-    def forward_after_ffn_pm(self, obj):
+    def forward_after_ffn_pm(self, obj, out_cls=None, out_emb=None):
         """:390-400 -> (class_logits [T, L, nc], slot embedding [T, L, C]). The class and the embedding tower
-        have the same shape, so layer i of both runs as one batched GEMM + one K5 launch."""
+        have the same shape, so layer i of both runs as one batched GEMM + one K5 launch. out_cls / out_emb: contiguous fp32
+        buffers the two results are written into by the kernels that produce them (the clip entry stacks the stages' outputs)."""
         T, L, C = obj.shape
         if len(self.cls_module) != len(self.reg_module):
             c = r = obj
@@ -483,6 +484,7 @@ class MaskRCNNHead(nn.Module):
                 r = layer(r)
             return self.class_logits(c), r
         x = obj.reshape(1, T * L, C).expand(2, -1, -1)
+        last = len(self.cls_module) - 3
         for i in range(0, len(self.cls_module), 3):
             lc, lr = self.cls_module[i], self.reg_module[i]
             nc, nr = self.cls_module[i + 1], self.reg_module[i + 1]
@@ -490,19 +492,24 @@ class MaskRCNNHead(nn.Module):
             g2 = _cached(self, f"tg{i}", [nc.weight, nr.weight], lambda: torch.stack([nc.weight, nr.weight]).contiguous())
             e2 = _cached(self, f"te{i}", [nc.bias, nr.bias], lambda: torch.stack([nc.bias, nr.bias]).contiguous())
             if self.precision != "fp32" and self.use_slot_gemm:
-                y2 = torch.empty((2, T * L, C), dtype=torch.float32, device=obj.device)
+                if i == last and out_emb is not None:
+                    y2 = (torch.empty((T * L, C), dtype=torch.float32, device=obj.device), out_emb.view(T * L, C))
+                else:
+                    y2 = torch.empty((2, T * L, C), dtype=torch.float32, device=obj.device)
                 fast_linear_ln(self, f"cls{i}", x[0], lc.weight, None, nc, relu=True, out=y2[0])           # :394-397, layer + LayerNorm + ReLU per launch
                 fast_linear_ln(self, f"reg{i}", x[1], lr.weight, None, nr, relu=True, out=y2[1])
                 x = y2
             else:
                 x = ops.row_ln(torch.bmm(x, w2), g2, e2, nc.eps, relu=True, rows_per_group=T * L)          # :394-397
-        if self.precision != "fp32" and self.use_slot_gemm and x.is_cuda:            # :398 on K9 (20 columns: not a K8 shape)
-            cls = ops.bgemm(x[0], self.class_logits.weight, bias=self.class_logits.bias).view(T, L, -1)
+        if self.precision != "fp32" and self.use_slot_gemm and x[0].is_cuda:         # :398 on K9 (20 columns: not a K8 shape)
+            nc_ = self.class_logits.weight.shape[0]
+            cls = ops.bgemm(x[0], self.class_logits.weight, bias=self.class_logits.bias,
+                            out=None if out_cls is None else out_cls.view(1, T * L, nc_)).view(T, L, -1)
         else:
             cls = self.class_logits(x[0].reshape(T, L, C))
         return cls, x[1].reshape(T, L, C)
 
-    def forward_pm(self, slots, feat_pm, hw, pos_tabs, stage_enable, clips=1):
+    def forward_pm(self, slots, feat_pm, hw, pos_tabs, stage_enable, clips=1, out_cls=None, out_emb=None):
         T, L, C = slots.shape
         obj = self.forward_till_ffn_pm(slots.contiguous(), feat_pm, hw, pos_tabs)
         if stage_enable:
@@ -511,7 +518,7 @@ class MaskRCNNHead(nn.Module):
                                            groups=clips).reshape(T, L, C)                                     # :313-322
         else:
             assert self.temporal_query_head is None
-        return self.forward_after_ffn_pm(obj)
+        return self.forward_after_ffn_pm(obj, out_cls, out_emb)
 
     def forward(self, features, mask_query, pad_mask, pos=None, query_pos=None, gt_non_void_mask=None,
                 stage_enable=True):
@@ -644,7 +651,12 @@ class MultiScaleDynamicMaskHead(nn.Module):
         clips = 1 if clip_frames is None else T // clip_frames
         if clip_frames is not None and clips * clip_frames != T:
             raise ValueError(f"T={T} is not a multiple of clip_frames={clip_frames}")
-        slots = init_slots.float().unsqueeze(0).expand(T, -1, -1).contiguous()
+        # the initial slots of every frame: a broadcast of a parameter, made once per (parameter version, T) and never written
+        slots = _cached(self, f"init_slots_T{T}", [init_slots], lambda: init_slots.float().unsqueeze(0).expand(T, -1, -1).contiguous())
+        n_stages = sum(self.per_dh_num_heads[:self.feat_num_levels])
+        direct = self.precision != "fp32"                # the stages' producers write straight into the stacked results
+        out_logits = torch.empty((n_stages, T, init_slots.shape[0], self.num_classes), dtype=torch.float32, device=slots.device) if direct else None
+        out_embeds = torch.empty((n_stages, T, init_slots.shape[0], self.dh_dim), dtype=torch.float32, device=slots.device) if direct else None
         all_logits, all_embeds, fused = [], [], []
         prev = None
         stage_idx = 0
@@ -658,21 +670,26 @@ class MultiScaleDynamicMaskHead(nn.Module):
             mdcs = [stage.inst_interact for stage in series]
             if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype == BF16
                     and all(m.precision != "fp32" and m.retriever == "fused" for m in mdcs)):
-                # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats4.hip;
-                # measured 204 against 2 x 115 us at the finest level); each stage's retriever picks its rows up in forward_fused.
-                # A level with a single stage keeps K3' (107 against 115 - 125 us)
+                # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats2.hip;
+                # measured 195 against 2 x 116 us at the finest level); each stage's retriever picks its rows up in forward_fused.
+                # A level with a single stage keeps K3'
                 tabs_i = None if pos_tabs is None else pos_tabs[i]
                 for m, aux in zip(mdcs, ops.retr_stats_level(f_pm, h, w, [m.stats_args(tabs_i) for m in mdcs])):
                     m._level_stats = (f_pm, aux)
             for stage in series:
                 enable = stage_idx in self.apply_temporal_query_atten_stages
-                logits, slots = stage.forward_pm(slots, f_pm, (h, w), None if pos_tabs is None else pos_tabs[i], enable, clips)
+                logits, slots = stage.forward_pm(slots, f_pm, (h, w), None if pos_tabs is None else pos_tabs[i], enable, clips,
+                                                 out_cls=out_logits[stage_idx] if direct else None,
+                                                 out_emb=out_embeds[stage_idx] if direct else None)
                 slots = slots.detach()
                 all_logits.append(logits)
                 all_embeds.append(slots)
                 stage_idx += 1
             prev = f_pm
             fused.append(f_pm)
+        if direct and all(t.data_ptr() == out_logits[j].data_ptr() for j, t in enumerate(all_logits)) \
+                and all(t.data_ptr() == out_embeds[j].data_ptr() for j, t in enumerate(all_embeds)):
+            return out_logits, out_embeds, fused
         return torch.stack(all_logits), torch.stack(all_embeds), fused
 
     def forward(self, features, init_masks, pad_mask, pos=None, query_pos=None, gt_non_void_mask=None):

@@ -139,3 +139,18 @@ def test_slot_gemm_ln_is_bitwise_gemm_then_row_ln(cuda, M, K, pre, post, relu, b
     y = torch.relu(y) if relu else y
     y = y + (0 if p2 is None else p2.double())
     assert (one.double() - y).abs().max().item() <= 1e-4
+
+
+def test_row_softmax_matches_torch(cuda):
+    """The temporal retriever's softmax over the query axis (dynamic_mask_head.py:559-567) as the library's own kernel."""
+    import torch
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(3)
+    for shape in ((32, 500, 500), (3, 7, 1), (5, 64), (2, 3, 1000)):
+        x = 20.0 * torch.randn(shape, generator=g, device=cuda)
+        ref = torch.softmax(x.double(), dim=-1)
+        y = ops.row_softmax(x)
+        assert float((y.double() - ref).abs().max()) < 5e-7
+        assert float((y.sum(-1) - 1).abs().max()) < 1e-5
+        z = x.clone()
+        assert ops.row_softmax(z, inplace=True) is z and torch.equal(z, y)
