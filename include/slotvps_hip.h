@@ -207,6 +207,13 @@ int svps_slot_gemm(const float* x, const void* wpack, const float* bias, float* 
  * result is bitwise the one of svps_slot_gemm followed by svps_row_ln. pre / post [M, 256] fp32 or NULL. */
 int svps_slot_gemm_ln(const float* x, const void* wpack, const float* bias, const float* pre, const float* post,
                       const float* gamma, const float* beta, float eps, int relu, float* y, int M, int K, void* stream);
+/* The feed-forward block of a stage in ONE launch (slotvps_amd/csrc/slot_ffn.hip; dynamic_mask_head.py:379-385 and :519-525):
+ *     y = LN( pre + W2 act(W1 x + b1) + b2 ) * gamma + beta  (+ post)
+ * x, pre, post, y [M, 256] fp32 (pre / post may be NULL; the reference's residual is pre = x); w1pack / w2pack = the fragment-order
+ * packs of W1 [H, 256] and W2 [256, H] (H % 256 == 0); act 1 ReLU / 2 GELU (erf). The hidden tensor never leaves the CU; the
+ * arithmetic is svps_slot_gemm (act) followed by svps_slot_gemm_ln operation for operation - bitwise the same result. */
+int svps_slot_ffn(const float* x, const void* w1pack, const float* b1, const void* w2pack, const float* b2, const float* pre,
+                  const float* post, const float* gamma, const float* beta, float eps, int act, float* y, int M, int H, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9 small batched products of the slot side (slotvps_amd/csrc/bgemm.hip), the products K8 does not take because their B

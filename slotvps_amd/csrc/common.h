@@ -140,6 +140,15 @@ static inline int svps_num_cus() {
     }
     return n[d];
 }
+// GELU, exact erf form (F.gelu's default). No contraction of its own products and sums: the value must not depend on the kernel
+// the function is inlined into (svps_slot_ffn is tested bit for bit against svps_slot_gemm + svps_slot_gemm_ln).
+__device__ __forceinline__ float svps_gelu_erf(float x) {
+#pragma clang fp contract(off)
+    const float e = erff(x * 0.70710678118654752f);
+    const float t = 0.5f * x;
+    return t * (1.0f + e);
+}
+
 struct SvpsLdsAttr {          // one static instance per launch site (= per kernel instantiation)
     bool done[64] = {};
     hipError_t ensure(const void* kernel, int lds_bytes) {

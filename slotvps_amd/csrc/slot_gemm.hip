@@ -51,7 +51,6 @@ __device__ __forceinline__ float gm_wave_sum(float x) {
     return x;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 // ACT: 0 none, 1 ReLU, 2 GELU (erf); RBW: row blocks per workgroup (2 or 1); PREF: weights of the next chunk requested before
 // this chunk's MFMAs (register double buffer, 192 registers: one workgroup per CU - for launches that do not fill the chip
@@ -279,7 +278,7 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
             const int m = m0 + 32 * rb + (i & 3) + 8 * (i >> 2) + 4 * h;
             float v = acc[b][i] + bv;
             if constexpr (ACT == 1) v = v > 0.f ? v : 0.f;
-            if constexpr (ACT == 2) v = gelu_erf(v);
+            if constexpr (ACT == 2) v = svps_gelu_erf(v);
             if (m < M) y[(size_t)m * N + n] = v;
         }
     }

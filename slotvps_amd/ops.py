@@ -503,6 +503,43 @@ def slot_gemm_ln(x, wpack, bias, gamma, beta, eps=1e-5, pre=None, post=None, rel
     return out
 
 
+def slot_ffn(x, w1pack, b1, w2pack, b2, gamma, beta, eps=1e-5, act=ACT_RELU, pre=None, post=None, out=None):
+    """The feed-forward block in one launch (csrc/slot_ffn.hip): y = LN(pre + W2 act(W1 x + b1) + b2) * gamma + beta (+ post);
+    x [..., 256] fp32, w1pack = pack_b_fragments(W1 [H, 256]), w2pack = pack_b_fragments(W2 [256, H]), H % 256 == 0.
+    Bitwise slot_gemm(act) followed by slot_gemm_ln; the [M, H] hidden tensor is never written."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    _need(w1pack, "w1pack", torch.bfloat16, 5)
+    _need(w2pack, "w2pack", torch.bfloat16, 5)
+    if x.shape[-1] != D_MODEL:
+        raise ValueError("slot_ffn works on rows of 256 values")
+    M = x.numel() // D_MODEL
+    H = w1pack.shape[0] * 32
+    if w1pack.shape[1] * 16 != D_MODEL or w2pack.shape[0] * 32 != D_MODEL or w2pack.shape[1] * 16 != H or H % 256:
+        raise ValueError(f"slot_ffn: packed weights {tuple(w1pack.shape)} / {tuple(w2pack.shape)} are not a 256 -> H -> 256 pair with H % 256 == 0")
+    if act not in (ACT_RELU, ACT_GELU):
+        raise ValueError("slot_ffn: act must be ACT_RELU or ACT_GELU")
+    for name, tns in (("pre", pre), ("post", post)):
+        if tns is not None:
+            _need(tns, name, torch.float32)
+            if tns.numel() != M * D_MODEL:
+                raise ValueError(f"{name} shape mismatch")
+    for name, tns, n in (("b1", b1, H), ("b2", b2, D_MODEL), ("gamma", gamma, D_MODEL), ("beta", beta, D_MODEL)):
+        if tns is not None:
+            _need(tns, name, torch.float32, 1)
+            if tns.numel() != n:
+                raise ValueError(f"{name}: {n} values expected")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    elif out.shape != x.shape or not out.is_contiguous() or out.dtype != torch.float32:
+        raise ValueError("slot_ffn: out must be a contiguous fp32 tensor of x's shape")
+    with _on(x, w1pack, b1, w2pack, b2, pre, post, gamma, beta, out) as ctx:
+        rc = lib.svps_slot_ffn(_ptr(x), _ptr(w1pack), _ptr(b1), _ptr(w2pack), _ptr(b2), _ptr(pre), _ptr(post), _ptr(gamma),
+                               _ptr(beta), float(eps), int(act), _ptr(out), M, H, ctx.stream)
+    _lib.check(rc, "svps_slot_ffn")
+    return out
+
+
 def bgemm(a, b, bias=None, alpha=1.0, out=None):
     """K9: C[g, m, n] = alpha * sum_k a[g, m, k] b[g, n, k] (+ bias[g, n]) for fp32 tensors of ANY strides (views, transposes,
     expand()ed batch dimensions): a [G, M, K] or [M, K], b [G, N, K] or [N, K], bias [G, N], [N] or None. Split-bf16 matrix-core

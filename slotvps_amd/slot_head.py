@@ -97,6 +97,39 @@ def fast_linear_ln(owner, name, x, weight, bias, norm, pre=None, post=None, relu
                             post=None if post is None else post.contiguous(), relu=relu, out=out)
 
 
+_CU_COUNT = {}
+
+
+def _num_cus(device):
+    idx = torch.device(device).index or 0
+    if idx not in _CU_COUNT:
+        _CU_COUNT[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    return _CU_COUNT[idx]
+
+
+def fast_ffn(owner, x, lin1, lin2, norm, act, post=None):
+    """LN(x + lin2(act(lin1(x)))) (+ post): the feed-forward block of a stage (dynamic_mask_head.py:379-385, :519-525). bf16 mode:
+    ONE launch (csrc/slot_ffn.hip, the hidden tensor stays on the CU), bitwise the two K8 launches it replaces; otherwise those."""
+    H, K = lin1.weight.shape
+    if (getattr(owner, "precision", "bf16") == "fp32" or K != 256 or lin2.weight.shape[0] != 256 or H % 256 or not x.is_cuda
+            or not owner.use_slot_gemm or not getattr(owner, "fuse_ffn", True) or not getattr(owner, "fuse_ln", True)
+            or lin1.bias is None or lin2.bias is None):
+        hid = fast_linear(owner, "linear1", x, lin1.weight, lin1.bias, act=act)
+        return fast_linear_ln(owner, "linear2", hid, lin2.weight, lin2.bias, norm, pre=x, post=post)
+    rows = x.numel() // K
+    if -(-rows // 64) * 2 < _num_cus(x.device):
+        # a workgroup of the one-launch form walks the whole hidden dimension for its 64 rows (~95 us): it pays once the launch
+        # covers at least half the chip (measured: 16 000 rows 124 vs 179 us, 8 000 rows 97 vs 102, 500 rows 94 vs 47)
+        hid = fast_linear(owner, "linear1", x, lin1.weight, lin1.bias, act=act)
+        return fast_linear_ln(owner, "linear2", hid, lin2.weight, lin2.bias, norm, pre=x, post=post)
+    w1 = _cached(owner, "wp_linear1", [lin1.weight], lambda: ops.pack_b_fragments(lin1.weight))
+    w2 = _cached(owner, "wp_linear2", [lin2.weight], lambda: ops.pack_b_fragments(lin2.weight))
+    xc = x.contiguous()
+    return ops.slot_ffn(xc, w1, lin1.bias, w2, lin2.bias, norm.weight, norm.bias, norm.eps,
+                        act={"relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act], pre=xc,
+                        post=None if post is None else post.contiguous())
+
+
 FP16_MAX = 65504.0
 
 
@@ -394,9 +427,8 @@ class TemporalSlotsHead(nn.Module):
         f = x if features is mask_query else features.view(1, -1, self.d_model)
         r = self.inst_interact(x, f, pos, groups=groups)
         u = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x.contiguous())          # :515-517
-        hid = fast_linear(self, "linear1", u, self.linear1.weight, self.linear1.bias, act=_act_name(self.activation))
-        out = fast_linear_ln(self, "linear2", hid, self.linear2.weight, self.linear2.bias, self.norm3, pre=u,
-                             post=x.contiguous() if add_input else None)                                      # :520, :524-525
+        out = fast_ffn(self, u, self.linear1, self.linear2, self.norm3, _act_name(self.activation),
+                       post=x.contiguous() if add_input else None)                                            # :519-520, :524-525
         return out.squeeze(0)
 
 
@@ -468,8 +500,7 @@ class MaskRCNNHead(nn.Module):
         x1 = self._self_attention(slots, residual_norm=True)                                              # :346-358
         r = self.inst_interact.forward_pm(x1, feat_pm, hw, pos_tabs)                                        # :368
         x2 = ops.row_ln(r, self.norm2.weight, self.norm2.bias, self.norm2.eps, pre=x1)                     # :374-376
-        hid = fast_linear(self, "linear1", x2, self.linear1.weight, self.linear1.bias, act=_act_name(self.activation))
-        return fast_linear_ln(self, "linear2", hid, self.linear2.weight, self.linear2.bias, self.norm3, pre=x2)   # :379, :384-385
+        return fast_ffn(self, x2, self.linear1, self.linear2, self.norm3, _act_name(self.activation))       # :379, :384-385
 
     def forward_after_ffn_pm(self, obj, out_cls=None, out_emb=None):
         """:390-400 -> (class_logits [T, L, nc], slot embedding [T, L, C]). The class and the embedding tower

@@ -154,3 +154,40 @@ def test_row_softmax_matches_torch(cuda):
         assert float((y.sum(-1) - 1).abs().max()) < 1e-5
         z = x.clone()
         assert ops.row_softmax(z, inplace=True) is z and torch.equal(z, y)
+
+
+@pytest.mark.parametrize("M,H,act,post", [
+    (1000, 2048, "gelu", False),     # MaskRCNNHead's block (dynamic_mask_head.py:379-385); 1000 rows: a ragged last 64-row tile
+    (1000, 1024, "relu", True),      # TemporalSlotsHead's block with the caller's residual (:519-525, :317)
+    (64, 256, "relu", False),        # one hidden chunk, one tile
+    (3, 512, "gelu", True),
+])
+def test_slot_ffn_is_bitwise_the_two_launch_form(cuda, M, H, act, post):
+    """The one-launch feed-forward block (csrc/slot_ffn.hip) against svps_slot_gemm (activation) + svps_slot_gemm_ln on the same
+    packed weights - bit for bit - and against a float64 evaluation of LN(x + W2 act(W1 x + b1) + b2)."""
+    import torch
+    import torch.nn.functional as F
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(M + H)
+    x = torch.randn((M, 256), generator=g, device=cuda)
+    w1 = torch.randn((H, 256), generator=g, device=cuda) / 16.0
+    b1 = 0.1 * torch.randn((H,), generator=g, device=cuda)
+    w2 = torch.randn((256, H), generator=g, device=cuda) / H ** 0.5
+    b2 = 0.1 * torch.randn((256,), generator=g, device=cuda)
+    gamma = torch.rand((256,), generator=g, device=cuda) + 0.5
+    beta = 0.1 * torch.randn((256,), generator=g, device=cuda)
+    q = torch.randn((M, 256), generator=g, device=cuda) if post else None
+    p1, p2 = ops.pack_b_fragments(w1), ops.pack_b_fragments(w2)
+    code = ops.ACT_RELU if act == "relu" else ops.ACT_GELU
+    hid = ops.slot_gemm(x, p1, b1, code)
+    two = ops.slot_gemm_ln(hid, p2, b2, gamma, beta, 1e-5, pre=x, post=q)
+    one = ops.slot_ffn(x, p1, b1, p2, b2, gamma, beta, 1e-5, act=code, pre=x, post=q)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), f"fused FFN differs from the two-launch form: {float((one - two).abs().max())}"
+    f = F.relu if act == "relu" else F.gelu
+    xd = x.double()
+    ref = F.layer_norm(xd + F.linear(f(F.linear(xd, w1.double(), b1.double())), w2.double(), b2.double()), (256,),
+                       gamma.double(), beta.double(), 1e-5)
+    if post:
+        ref = ref + q.double()
+    assert float((one.double() - ref).abs().max()) < 1e-4
