@@ -550,6 +550,20 @@ def main():
             return 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
         copy_gbs = copy_rate(lambda: dst.copy_(src))
         probe_gbs = copy_rate(lambda: _lib.check(lib.svps_probe_copy(ops._ptr(src), ops._ptr(dst), 1 << 30, sp), "svps_probe_copy"))
+
+        def mix_rate(ri, ro):                            # the read : write mix of a kernel without its arithmetic (K4: 640 B in : 512 B out)
+            units = (1 << 30) // (1024 * max(ri, ro))
+            call = lambda: _lib.check(lib.svps_probe_mix(ops._ptr(src), ops._ptr(dst), units, ri, ro, sp), "svps_probe_mix")
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                call()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return 10 * units * 1024 * (ri + ro) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        mix_k4, mix_rd, mix_wr = mix_rate(5, 4), mix_rate(1, 0), mix_rate(0, 1)
         del src, dst
         roof = {"bound": d["bound"], "achieved": d["hbm_gbs"] if hbm else d["mfma_tflops"],
                 "peak": HBM_PEAK_GBS if hbm else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm else "TFLOP/s",
@@ -560,7 +574,10 @@ def main():
                 "algorithmic_flops_per_launch_avg": d["algorithmic_flops_per_launch"],
                 "retriever_form": runner.retriever_form,
                 "copy_kernel_ceiling": {"gbps": round(copy_gbs, 1), "own_streaming_kernel_gbps": round(probe_gbs, 1),
-                                        "what": "1 GiB device-to-device, bytes read + written: torch copy / the library's 16-B-per-lane streaming kernel"},
+                                        "mix_5_read_4_write_gbps": round(mix_k4, 1), "read_only_gbps": round(mix_rd, 1),
+                                        "write_only_gbps": round(mix_wr, 1),
+                                        "what": "1 GiB device-to-device, bytes read + written: torch copy / the library's 16-B-per-lane streaming kernel; "
+                                                "svps_probe_mix: level_fuse's 640 B in : 512 B out mix without its arithmetic, and the one-way streams"},
                 "per_kernel": per}
         pair = [k for k in ("retr_stats", "retr_attn") if k in per] or [k for k in ("kv_project", "slot_attn") if k in per]
         if len(pair) == 2:                              # the retriever as a pair (the yardstick of VERDICT r01 item 1b)

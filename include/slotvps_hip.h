@@ -288,6 +288,10 @@ int svps_probe_tile(const void* x, void* rows, void* cols, void* stream);
 /* svps_probe_copy: dst[0:bytes] = src[0:bytes] with 16 B per lane streaming loads / stores (bytes a multiple of 16): the
  * known-bytes kernel the HBM counters are calibrated on and the hand-written copy ceiling of bench.py */
 int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
+/* svps_probe_mix: mixed-traffic streaming probe - per unit ri KiB are read from src and ro KiB written to dst (src >= units * ri
+ * KiB, dst >= units * ro KiB, at least 1 KiB), every byte once: the read : write mix of a kernel without its arithmetic, to state
+ * the box's ceiling for that mix (K4: 5 : 4). (ri, ro) in {(5,4), (1,1), (1,0), (0,1), (4,1), (2,1)}. */
+int svps_probe_mix(const void* src, void* dst, size_t units, int ri, int ro, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Statistics-fused retriever (K3' + K1'): MaskDynamicConv.forward (dynamic_mask_head.py:423-461) without k / v tensors.

@@ -400,7 +400,8 @@ def deform_conv(x, offset, weight, stride=1, padding=0, dilation=1, deformable_g
     PARITY UNPINNED for this function: the reference's op is CUDA-only (deform_conv.py:44-45) and cannot run in the build
     container, and the reference holds no vectors for it; what the tests check are properties of the published DCNv1
     formula (zero offsets == conv2d, integer offsets == shifted conv, fractional offsets == the hand-computed bilinear
-    blend). The semantic-tower fixture that uses it is therefore not an independent pin either."""
+    blend, and nine hand-worked samples on and around the image border for the rules of deform_conv_cuda_kernel.cu:82-114 /
+    :224 - tests/test_deform_conv.py). The semantic-tower fixture that uses it is therefore not an independent pin either."""
     x = np.asarray(x)
     C, H, W = x.shape
     O, _, kh, kw = weight.shape

@@ -74,6 +74,7 @@ SIGNATURES = {
     "svps_probe_mfma": (_i, [_vp, _vp, _vp, _vp]),
     "svps_probe_tile": (_i, [_vp, _vp, _vp, _vp]),
     "svps_probe_copy": (_i, [_vp, _vp, _sz, _vp]),
+    "svps_probe_mix": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
 }
 
 _lib = None

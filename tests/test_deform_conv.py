@@ -39,6 +39,66 @@ def test_oracle_half_pixel_offset_is_average_of_neighbours():
     assert np.abs(got - want).max() < 1e-12
 
 
+# ---- hand-computed vectors for the border rules of deform_conv_cuda_kernel.cu:82-114 (bilinear taps, corners outside the image
+# read as zero) and :224 (a sample is taken only for h in the OPEN interval (-1, H), w in (-1, W)). Image I[h][w] = 1 .. 9 on a
+# 3 x 3 grid, a single centre tap of weight 1, so every output pixel is the sample at (y + dy, x + dx) of its own offset.
+# Worked by hand from the published formula, not produced by any implementation:
+#   pixel (0,0) -> (-0.5,  0.0): rows -1 | 0, lh = 0.5; row -1 is outside -> 0.5 * I[0][0]                     = 0.5
+#   pixel (0,1) -> (-1.0,  1.0): h = -1 is not > -1 -> no sample                                                = 0
+#   pixel (0,2) -> ( 2.5,  2.5): rows 2 | 3, cols 2 | 3; only (2,2) inside -> 0.5 * 0.5 * I[2][2]               = 2.25
+#   pixel (1,0) -> ( 3.0,  1.0): h = 3 is not < 3 -> no sample                                                  = 0
+#   pixel (1,1) -> (-0.25,-0.75): rows -1 | 0 (lh = .75), cols -1 | 0 (lw = .25); only (0,0) -> .75 * .25 * 1    = 0.1875
+#   pixel (1,2) -> ( 0.5,  1.25): .5*.75*I[0][1] + .5*.25*I[0][2] + .5*.75*I[1][1] + .5*.25*I[1][2]             = 3.75
+#   pixel (2,0) -> ( 2.0, -0.5): row 2 exactly (lh = 0), cols -1 | 0 (lw = .5) -> 1 * .5 * I[2][0]               = 3.5
+#   pixel (2,1) -> ( 1.0,  2.999..): not used (no exact binary value); instead (1.0, 2.75): cols 2 | 3, lw = .75 -> .25 * I[1][2] = 1.5
+#   pixel (2,2) -> ( 2.0,  2.0): the pixel itself                                                               = 9
+_HAND_TARGETS = [[(-0.5, 0.0), (-1.0, 1.0), (2.5, 2.5)], [(3.0, 1.0), (-0.25, -0.75), (0.5, 1.25)], [(2.0, -0.5), (1.0, 2.75), (2.0, 2.0)]]
+_HAND_EXPECT = np.array([[0.5, 0.0, 2.25], [0.0, 0.1875, 3.75], [3.5, 1.5, 9.0]])
+
+
+def _hand_case(C, O, kernel=3):
+    x = np.zeros((C, 3, 3), dtype=np.float64)
+    x[0] = np.arange(1, 10, dtype=np.float64).reshape(3, 3)
+    w = np.zeros((O, C, kernel, kernel), dtype=np.float64)
+    w[0, 0, kernel // 2, kernel // 2] = 1.0
+    off = np.zeros((2 * kernel * kernel, 3, 3), dtype=np.float64)
+    t = (kernel // 2) * kernel + kernel // 2                      # centre tap: samples at (y + dy, x + dx) with padding = kernel // 2
+    for y in range(3):
+        for xx in range(3):
+            off[2 * t, y, xx] = _HAND_TARGETS[y][xx][0] - y
+            off[2 * t + 1, y, xx] = _HAND_TARGETS[y][xx][1] - xx
+    return x, off, w
+
+
+def test_oracle_border_rules_match_hand_computed_vectors():
+    for kernel in (1, 3):
+        x, off, w = _hand_case(2, 2, kernel)
+        got = orc.deform_conv(x, off, w, 1, kernel // 2, 1)
+        assert np.array_equal(got[0], _HAND_EXPECT), got[0]
+        assert not got[1].any()
+
+
+@pytest.mark.gpu
+def test_hip_deform_conv_border_rules_match_hand_computed_vectors(cuda):
+    """Both HIP forms (K7 column buffer + GEMM, K7' fused) on the hand-computed border vectors: every value is a short dyadic
+    sum, so the fp32 results are exact."""
+    import torch
+    from slotvps_amd.dcn import DeformConv, deform_conv
+    x, off, w = _hand_case(64, 128)
+    tx, to, tw = (torch.from_numpy(a.astype(np.float32)).to(cuda) for a in (x[None], off[None], w))
+    out = deform_conv(tx, to, tw, 1, 1, 1, 1, 1)
+    m = DeformConv(64, 128, 3, padding=1).to(cuda)
+    with torch.no_grad():
+        m.weight.copy_(tw)
+        assert m.fused
+        out_f = m(tx, to)
+    torch.cuda.synchronize()
+    for o in (out, out_f):
+        got = o[0].cpu().numpy()
+        assert np.array_equal(got[0], _HAND_EXPECT.astype(np.float32)), got[0]
+        assert not got[1:].any()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C,O,H,W,dg", [(1, 16, 8, 9, 11, 1), (2, 256, 128, 16, 32, 1), (1, 32, 16, 12, 10, 2)])
 def test_hip_deform_conv_matches_oracle(cuda, N, C, O, H, W, dg):
