@@ -822,6 +822,434 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
     }
 }
 
+// ============================== more than 128 slots: the two-pass form ===============================================
+// (round 3) The softmax runs over ALL slots of a pixel, so a workgroup must see the logits of every slot block before it can
+// normalise any of them; Q'' hi / lo for 256 slots plus the accumulators of 256 slots do not fit one CU's registers. The first
+// form of this path (kept below: retr_logit_stats_kernel + two EXT launches of retr_attn_kernel) computed every logit TWICE and
+// read the map three times. Here the probabilities go through HBM instead:
+//   pass 1  retr_probs_kernel   eight waves = eight slot blocks with Q'' hi / lo resident: logits, per-pixel softmax over all 256
+//                               rows, P * rstd_v as fp16 -> workspace, one 16-KiB block per tile in EXACTLY the byte layout of
+//                               retr_attn_kernel's LDS P tile (slot block sb at sb * 2 KiB, 32 pixel rows of 64 B, chunk swizzle)
+//   pass 2  retr_pv_kernel      eight waves = eight slot blocks of accumulators (A[32 sb .., 0:256] + the aux block): feature
+//                               tile + P block + aux rows arrive by LDS-DMA, 18 MFMA per wave and tile, no softmax, no Q''
+// Matrix work per tile: 256 + 144 MFMAs instead of 256 + 2 x (128 + 72); bytes per pixel: 512 + 512 (P out) in pass 1,
+// 512 + 512 + 16 in pass 2. Same operands and roundings as retr_attn_kernel (P * rstd_v is ONE fp16 there as well).
+struct ProbsLds {
+    static constexpr int kA = 4;                                // tiles ahead
+    static constexpr int kNF = kA + 2;
+    static constexpr int ring = 0;
+    static constexpr int yring = kNF * kTileBytes;              // kNF x 1 KiB Cy rows (256 slots)
+    static constexpr int aring = yring + kNF * 1024;            // kNF x 1 KiB aux rows of the tile's pixels
+    static constexpr int stats = aring + kNF * kAuxTile;        // [2][8][32] float2
+    static constexpr int ptile = stats + 2 * 8 * 32 * 8;        // [8 waves][2 KiB]: this wave's block of the P tile on its way out
+    static constexpr int total = ptile + 8 * 2048;
+};
+static_assert(ProbsLds::total <= 160 * 1024, "LDS layout");
+constexpr int kPBlock = 16384;                                  // bytes of P per tile in the workspace: 256 slots x 32 pixels fp16
+
+__global__ __launch_bounds__(512) void retr_probs_kernel(
+    const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,  // [T, 256, 256]
+    const float* __restrict__ cy, const float* __restrict__ cx,        // [T, H, 256], [T, W, 256]
+    const float* __restrict__ c3g,                                     // [T, 256]
+    const __bf16* __restrict__ feat, const __bf16* __restrict__ aux,   // aux: the 16-byte rows of retr_stats.hip
+    char* __restrict__ pout,                                           // [T, tiles, 16 KiB]
+    int HW, int H, int W, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    using Lds = ProbsLds;
+    constexpr int NF = Lds::kNF, A = Lds::kA, LP = 256;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x;
+    const int tiles = ((W + kTilePx - 1) / kTilePx) * H;
+    const int tid0 = c * tiles_per_chunk;
+    int nt = tiles - tid0;
+    nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;
+    const int strip0 = tid0 / H, row0 = tid0 - strip0 * H;
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+
+    f16x8 qfh[16], qfl[16];
+    {
+        const size_t row = ((size_t)t * LP + 32 * w + r) * kD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            qfh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
+            qfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
+        }
+    }
+    const int slot0 = 32 * w + 4 * h;
+    f32x4 c3v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c3v[g] = *reinterpret_cast<const f32x4*>(c3g + (size_t)t * LP + slot0 + 8 * g);
+    // consume every register loaded above HERE (see retr_logit_stats_kernel)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(qfh[ks]), "+v"(qfl[ks]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(c3v[g]));
+    wait_vm<0>();
+
+    const u32x4 cys = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
+    const u32x4 cxs = ra_make_srd(cx + (size_t)t * W * LP, (uint32_t)(W * LP) * 4u);
+    const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 ars = ra_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * kAuxRow);
+    const u32x4 prs = ra_make_srd(pout + ((size_t)t * tiles + tid0) * kPBlock, (uint32_t)nt * (uint32_t)kPBlock);
+    auto ld16 = [](u32x4 srd, int off) {                            // asm + its own wait (no compiler-visible load in the loop)
+        f32x4 v;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(off), "s"(srd) : "memory");
+        return v;
+    };
+    f32x4 cxv[4];
+    auto load_cx = [&](int strip) {
+        int xx = kTilePx * strip + r;
+        xx = xx < W ? xx : W - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cxv[g] = ld16(cxs, (xx * LP + slot0 + 8 * g) * 4);
+    };
+    load_cx(strip0);
+
+    // ---- staging: rows 4w .. 4w+3 of every tile (two pieces); wave 7: the Cy row; wave 6: the aux rows of the 32 pixels
+    int voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * w + 2 * i + h;
+        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+    }
+    const int nb = 2 + (w >= 6 ? 1 : 0);                            // DMA instructions of one batch of this wave
+    int ds = strip0, dy = row0;
+    auto stage = [&](int tile) {
+        if (tile >= nt) return;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NF) * kTileBytes + w * 2048);
+        const int px0 = dy * W + kTilePx * ds;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + kTilePx <= HW) {
+            ra_dma16(frs, st, voff[0], soff);
+            ra_dma16(frs, st + 1024, voff[1], soff);
+        } else {                                                     // last row of a ragged strip: clamp the source rows (their P is 0)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 4 * w + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+            }
+        }
+        if (w == 7) {
+            ra_dma16_cached(cys, __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + (tile % NF) * 1024), dy * LP * 4 + lane * 16);
+        } else if (w == 6) {                                         // 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
+            ra_dma16(ars, __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (tile % NF) * kAuxTile), (px0 + (lane & 31)) * kAuxRow, 0);
+        }
+        ++dy;
+        if (dy == H) { dy = 0; ++ds; }
+    };
+    auto convert = [&](int tile) {
+        if (tile >= nt) return;
+        const uint32_t st = lds0 + Lds::ring + (tile % NF) * kTileBytes + w * 2048 + lane * 16;
+        u32x4 w_[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w_[i] = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(st + i * 1024));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w_[i][k] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w_[i][k] << 16), __uint_as_float(w_[i][k] & 0xffff0000u)));
+            *reinterpret_cast<SVPS_LDS u32x4*>((uintptr_t)(st + i * 1024)) = w_[i];
+        }
+    };
+    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+    // P of the previous tile: exponentials relative to this wave's block maximum, the block maximum, rstd_v and "inside the map"
+    f32x16 e;
+    float mloc_p = 0.f, tau_p = 0.f;
+    bool live_p = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e[i] = 0.f;
+    const int key = (r >> 1) & 3;
+    char* prow = smem + Lds::ptile + w * 2048 + r * 64 + 8 * h;     // retr_attn_kernel's P tile layout, this wave's block
+    const uint32_t pback = lds0 + Lds::ptile + w * 2048 + lane * 16;
+    // finish of tile `tile` = it - 1: normalise over the eight blocks, P * rstd_v -> fp16 -> this wave's 2 KiB of the tile's block.
+    // The two stores are ALWAYS issued (out-of-range offset when there is nothing to store): the counted vmcnt waits rely on them.
+    auto finish = [&](int tile) {
+        const bool have = tile >= 0;
+        float mall = kNegBig;
+        float2 st_w[8];
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) {
+            st_w[ww] = stats[((tile & 1) * 8 + ww) * 32 + r];
+            mall = fmaxf(mall, st_w[ww].x);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
+        float fac = __builtin_amdgcn_exp2f(mloc_p - mall) * __builtin_amdgcn_rcpf(den) * tau_p;
+        if (!live_p || !have) fac = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f16x4 ph;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ph[j] = (_Float16)(e[4 * g + j] * fac);
+            *reinterpret_cast<f16x4*>(prow + ((g ^ key) * 16)) = ph;
+        }
+        // the wave's own LDS operations complete in order: the read-back below sees the writes above
+        const u32x4 b0 = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)pback);
+        const u32x4 b1 = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(pback + 1024));
+        const int so = have ? tile * kPBlock + w * 2048 + lane * 16 : 0x7ffffff0;
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt" : : "v"(b0), "v"(so), "s"(prs) : "memory");
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:1024 nt" : : "v"(b1), "v"(so), "s"(prs) : "memory");
+    };
+
+    // ---- prologue: batches 0 .. A in flight; tile 0 landed, converted and published
+#pragma unroll
+    for (int b = 0; b <= A; ++b) stage(b);
+    {
+        int younger = nt - 1;
+        younger = younger < 0 ? 0 : (younger > A ? A : younger);
+        wait_vm_dyn(nb * younger);
+        convert(0);
+    }
+    const uint32_t lane_row = lds0 + Lds::ring + r * kRowBytes + ((h ^ swz(r)) << 4);
+    auto frag = [&](uint32_t tb, int ks) {
+        return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
+    };
+    constexpr int kOrd[4] = {0, 8, 1, 9};
+    int ts = strip0, ty = row0;
+    for (int it = 0; it <= nt; ++it) {
+        wg_barrier();                                                // B(it): tile it is fp16; the statistics of tile it-1 are in LDS
+        finish(it - 1);
+        if (it == nt) break;
+        const uint32_t tb = lane_row + (uint32_t)(it % NF) * kTileBytes;
+        f16x8 kf[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kf[0][u] = frag(tb, kOrd[u]);
+        f32x16 s;
+        {
+            const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + (it % NF) * 1024) + slot0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 cyv = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j] + cxv[g][j];
+            }
+        }
+        // (rstd_k, rstd_v) of this lane's pixel: bytes 8 .. 15 of its aux row
+        const f32x2 rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + (it % NF) * kAuxTile + r * kAuxRow + 8));
+        const float rk = rt[0] * kLog2e;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            if (grp < 3) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = frag(tb, 2 * (grp + 1) + kOrd[u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[2 * grp + kOrd[u]], kf[grp & 1][u], s, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage(it + A + 1);
+        float mloc = kNegBig;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[4 * g + j] = fmaf(rk, s[4 * g + j], c3v[g][j]);    // padded rows: c3' = -1e30
+                mloc = fmaxf(mloc, s[4 * g + j]);
+            }
+        mloc = ra_half_swap_max(mloc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] - mloc);
+        float sl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sl[i] = (s[i] + s[4 + i]) + (s[8 + i] + s[12 + i]);
+        const float sloc = ra_half_swap_sum((sl[0] + sl[1]) + (sl[2] + sl[3]));
+        if (h == 0) stats[((it & 1) * 8 + w) * 32 + r] = make_float2(mloc, sloc);
+        e = s;
+        mloc_p = mloc;
+        tau_p = rt[1];
+        live_p = kTilePx * ts + r < W;
+        // tile it+1: this wave's pieces landed -> fp16. Younger operations than its batch: the batches it+2 .. it+A+1 and the
+        // two stores of finish() of each iteration in between
+        if (it >= A + 1 && it + A + 1 < nt) wait_vm_dyn(A * (nb + 2));
+        else wait_vm<0>();
+        convert(it + 1);
+        ++ty;
+        if (ty == H) { ty = 0; ++ts; if (it + 1 < nt) load_cx(ts); }
+    }
+}
+
+struct PvLds {
+    static constexpr int kA = 3;                                // batches ahead
+    static constexpr int kNF = kA + 1;                          // ring depth: tile it (compute), it+1 (converted), it+2, it+3 in flight
+    static constexpr int fring = 0;
+    static constexpr int pring = kNF * kTileBytes;
+    static constexpr int aring = pring + kNF * kPBlock;
+    static constexpr int total = aring + kNF * kAuxTile;
+};
+static_assert(PvLds::total <= 160 * 1024, "LDS layout");
+
+__global__ __launch_bounds__(512) void retr_pv_kernel(
+    const __bf16* __restrict__ feat,    // [T, HW, 256]
+    const __bf16* __restrict__ aux,     // [T, HW, 8]
+    const char* __restrict__ pin,       // [T, tiles, 16 KiB]  retr_probs_kernel
+    float* __restrict__ partial,        // [T, C, L, 260]
+    int L, int HW, int H, int W, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    using Lds = PvLds;
+    constexpr int A = Lds::kA, NF = Lds::kNF;
+    const int lane = threadIdx.x & 63;
+    const int sb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // slot block 0 .. 7
+    const int r = lane & 31, h = lane >> 5;
+    const int C = gridDim.x;
+    int t = blockIdx.y, c = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {                                  // XCD-aware frame placement (see retr_attn_kernel)
+        const int b = blockIdx.y * C + blockIdx.x;
+        const int n = b >> 3;
+        t = (b & 7) + 8 * (n / C);
+        c = n % C;
+    }
+    const int tiles = ((W + kTilePx - 1) / kTilePx) * H;
+    const int tid0 = c * tiles_per_chunk;
+    int nt = tiles - tid0;
+    nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;
+    const int strip0 = tid0 / H, row0 = tid0 - strip0 * H;
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+
+    const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 ars = ra_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * kAuxRow);
+    const u32x4 prs = ra_make_srd(pin + ((size_t)t * tiles + tid0) * kPBlock, (uint32_t)nt * (uint32_t)kPBlock);
+    int voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * sb + 2 * i + h;
+        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+    }
+    const int nb = 4 + (sb == 0 ? 1 : 0);                        // DMA instructions of one batch of this wave
+    int ds = strip0, dy = row0;
+    auto issue_batch = [&](int b) {
+        if (b >= nt) return;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % NF) * kTileBytes + sb * 2048);
+        const int px0 = dy * W + kTilePx * ds;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + kTilePx <= HW) {
+            ra_dma16(frs, st, voff[0], soff);
+            ra_dma16(frs, st + 1024, voff[1], soff);
+        } else {                                                 // last row of a ragged strip: clamp the source rows (their P is 0)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 4 * sb + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+            }
+        }
+        // this wave's 2 KiB of the tile's P block, byte for byte
+        const uint32_t sp = __builtin_amdgcn_readfirstlane(lds0 + Lds::pring + (b % NF) * kPBlock + sb * 2048);
+        const int poff = __builtin_amdgcn_readfirstlane(b * kPBlock + sb * 2048);
+        ra_dma16(prs, sp, lane * 16, poff);
+        ra_dma16(prs, sp + 1024, lane * 16 + 1024, poff);
+        if (sb == 0) {                                           // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
+            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % NF) * kAuxTile);
+            ra_dma16(ars, sa, (px0 + (lane & 31)) * kAuxRow, 0);
+        }
+        ++dy;
+        if (dy == H) { dy = 0; ++ds; }
+    };
+#pragma unroll
+    for (int b = 0; b < A; ++b) issue_batch(b);
+
+    f32x16 o[8], oa;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        oa[i] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[db][i] = 0.f;
+    }
+    // fragment addresses: retr_attn_kernel's consumer, with eight slot blocks in the P tile
+    const int g2 = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int cl = 2 * (g2 & 1) + (pp >> 1), sub = 8 * (pp & 1), rowl = 8 * (g2 >> 1) + qq;
+    const uint32_t lane_v0 = rowl * kRowBytes + (((cl ^ (2 * (g2 >> 1))) + 4 * qq) << 4) + sub;
+    const uint32_t lane_v1 = (rowl + 4) * kRowBytes + (((cl ^ (2 * (g2 >> 1) + 1)) + 4 * qq) << 4) + sub;
+    const uint32_t lane_p0 = sb * 2048 + sub + rowl * 64 + ((cl ^ (qq >> 1)) << 4);
+    const uint32_t lane_p1 = sb * 2048 + sub + (rowl + 4) * 64 + ((cl ^ (qq >> 1) ^ 2) << 4);
+    const uint32_t lane_a = rowl * kAuxRow + ((cl == 0 && sub != 0) ? 8 : 0);
+    auto tr = [](uint32_t a) {
+        return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(reinterpret_cast<SVPS_LDS fp16x4_gcc*>((uintptr_t)a)));
+    };
+    auto cat = [](f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); };
+    f16x8 ah[2], af[2], vf[2][4];
+    uint32_t p0 = 0, p1 = 0, v0 = 0, v1 = 0, aa = 0;
+    auto vfrag = [&](int ks, int db) {
+        const uint32_t o_ = 8192 * ks + 256 * (db >> 2);
+        return cat(tr((v0 ^ ((db & 3) << 6)) + o_), tr((v1 ^ ((db & 3) << 6)) + o_));
+    };
+    auto pv_begin = [&](int j) {
+        const uint32_t pt = lds0 + Lds::pring + (j % NF) * kPBlock, vt = lds0 + Lds::fring + (j % NF) * kTileBytes;
+        const uint32_t at = lds0 + Lds::aring + (j % NF) * kAuxTile;
+        p0 = pt + lane_p0, p1 = pt + lane_p1, v0 = vt + lane_v0, v1 = vt + lane_v1, aa = at + lane_a;
+        ah[0] = cat(tr(p0), tr(p1));
+        af[0] = cat(tr(aa), tr(aa + 4 * kAuxRow));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vf[0][u] = vfrag(0, u);
+    };
+    auto pv_rest = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ks = q >> 1, half = q & 1;
+            if (q < 3) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vf[(q + 1) & 1][u] = vfrag((q + 1) >> 1, 4 * ((q + 1) & 1) + u);
+            }
+            if (q == 1) {
+                ah[1] = cat(tr(p0 + 1024), tr(p1 + 1024));
+                af[1] = cat(tr(aa + 16 * kAuxRow), tr(aa + 20 * kAuxRow));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
+            if (half == 0) oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], af[ks], oa, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto convert_batch = [&](int b) {                            // this wave's two pieces of feature tile b, bf16 -> fp16 in place
+        if (b >= nt) return;
+        const uint32_t st = lds0 + Lds::fring + (b % NF) * kTileBytes + sb * 2048 + lane * 16;
+        u32x4 w_[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w_[i] = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(st + i * 1024));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const fp16x2_t pk = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w_[i][k] << 16), __uint_as_float(w_[i][k] & 0xffff0000u));
+                w_[i][k] = __builtin_bit_cast(uint32_t, pk);
+            }
+            *reinterpret_cast<SVPS_LDS u32x4*>((uintptr_t)(st + i * 1024)) = w_[i];
+        }
+    };
+
+    for (int it = 0; it < nt; ++it) {
+        // batches <= it+1 landed for this wave: all but the A - 2 youngest of the batches 0 .. it+A-1 issued so far
+        if (it + A - 1 < nt) wait_vm_dyn(nb * (A - 2));
+        else wait_vm<0>();
+        if (it == 0) convert_batch(0);
+        convert_batch(it + 1);
+        wg_barrier();                                            // B(it): tile it is complete (every wave's pieces, fp16) and tile it-1 is free
+        pv_begin(it);
+        issue_batch(it + A);
+        pv_rest();
+    }
+
+    float* dst = partial + ((size_t)t * C + c) * L * kPartRow;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int slot = 32 * sb + acc_row(i, h);
+        if (slot < L) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db) dst[(size_t)slot * kPartRow + 32 * db + r] = o[db][i];
+            if (r < 4) dst[(size_t)slot * kPartRow + 256 + r] = oa[i];
+        }
+    }
+}
+
 // Sum of the C partials of every (frame, slot) row in chunk order (bitwise reproducible, no float atomics):
 // out row (272 floats) = { A[0:256], s1, s0, 0 x 14 }, the operand of the slot-side product with
 // [ (gamma_v W~_v)^T ; gamma_v b~_v ; beta_v ; 0 ].
@@ -866,13 +1294,22 @@ RetrPlan plan_retr(int T, int H, int W, int chunks_req) {
     chunks = (tiles + tpc - 1) / tpc;
     return {chunks, tpc};
 }
-size_t retr_stats_bytes(int T, int L, int HW) { return L > 128 ? (size_t)T * HW * sizeof(float2) : 0; }
+// more than 128 slots: the P blocks of the two-pass form (16 KiB per tile), or the per-pixel statistics of the three-launch form
+bool retr_three_launch() {
+    static const bool v = getenv("SVPS_RETR_L256_THREE_LAUNCH") != nullptr;      // comparison runs only (tools/kbench_retr.py)
+    return v;
+}
+size_t retr_stats_bytes(int T, int L, int H, int W) {
+    if (L <= 128) return 0;
+    const size_t tiles = (size_t)((W + svps::kTilePx - 1) / svps::kTilePx) * H;
+    return retr_three_launch() ? (size_t)T * H * W * sizeof(float2) : (size_t)T * tiles * svps::kPBlock;
+}
 }  // namespace
 
 extern "C" size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int chunks) {
     if (T <= 0 || L <= 0 || H <= 0 || W <= 0) return 0;
     const RetrPlan p = plan_retr(T, H, W, chunks);
-    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float) + retr_stats_bytes(T, L, H * W);
+    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float) + retr_stats_bytes(T, L, H, W);
 }
 
 extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
@@ -885,7 +1322,7 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
     const int HW = H * W;
     const RetrPlan p = plan_retr(T, H, W, chunks);
     const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
-    if (workspace_bytes < partial_bytes + retr_stats_bytes(T, L, HW)) return SVPS_ERR_WORKSPACE;
+    if (workspace_bytes < partial_bytes + retr_stats_bytes(T, L, H, W)) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
     const __bf16* qh_ = static_cast<const __bf16*>(qh);
@@ -910,9 +1347,24 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
                            L, HW, H, W, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr);
         e = hipGetLastError();
+    } else if (!retr_three_launch()) {
+        // more than 128 slots (padded layouts of 256 rows), two passes: probabilities of all slots -> workspace, then P f
+        char* pws = static_cast<char*>(workspace) + partial_bytes;       // partial_bytes is a multiple of 16 (260 floats per row)
+        const RetrPlan pl = plan_retr(T, H, W, 0);
+        static SvpsLdsAttr attr_p, attr_v;
+        if (hipError_t ae = attr_p.ensure(reinterpret_cast<const void*>(svps::retr_probs_kernel), svps::ProbsLds::total); ae != hipSuccess) return (int)ae;
+        if (hipError_t ae = attr_v.ensure(reinterpret_cast<const void*>(svps::retr_pv_kernel), svps::PvLds::total); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(svps::retr_probs_kernel, dim3(pl.chunks, T), dim3(512), svps::ProbsLds::total, stream,
+                           static_cast<const _Float16*>(qh), static_cast<const _Float16*>(ql), cy, cx, c3, f_, a_, pws, HW, H, W,
+                           pl.tiles_per_chunk);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(svps::retr_pv_kernel, dim3(p.chunks, T), dim3(512), svps::PvLds::total, stream, f_, a_, (const char*)pws,
+                           partial, L, HW, H, W, p.tiles_per_chunk);
+        e = hipGetLastError();
     } else {
-        // more than 128 slots (padded layouts of 256 rows): softmax statistics over all slots first, then the retriever
-        // once per half of the slots with those statistics
+        // the first form of this path (comparison runs): softmax statistics over all slots, then the retriever once per half of
+        // the slots with those statistics
         float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);
         const RetrPlan pl = plan_retr(T, H, W, 0);
         static SvpsLdsAttr attr_s, attr_e;
