@@ -323,15 +323,16 @@ int svps_probe_mix(const void* src, void* dst, size_t units, int ri, int ro, voi
  *       pre-LayerNorm output (:456) = out_ext @ [ (gamma_v * W~_v)^T ; gamma_v * b~_v ; beta_v ; 0 ]
  *   aux: the rows of svps_retr_stats_fwd
  *   1 <= L <= 256; workspace svps_retr_attn_workspace_bytes() = per-workgroup partials [T, chunks, L, 260] fp32
- *   (+ [T, HW] x 8 B when L > 128: per-pixel softmax statistics over all slots, written by a first kernel; the retriever then
- *   runs once per half of the slots)
+ *   (+ [T, tiles, 16 KiB] when L > 128, tiles = ceil(W / 32) * H: the softmax runs over all 256 slot rows of a pixel, which one
+ *   workgroup cannot hold together with their accumulators - a first kernel writes P * rstd_v of every slot block as fp16 into
+ *   the workspace, a second one forms sum_p P f from it: every logit is computed once, the map is read twice)
  * ------------------------------------------------------------------------------------------- */
 int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                         float lnk_eps, const void* rv, const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D,
                         void* stream);
 /* svps_retr_stats_level_fwd: the statistics of ALL retriever stages of one pyramid level (n_stages = 1 or 2; the stages of a level
- * read the same fused map, MultiScaleDynamicMaskHead.forward :190-215) in ONE read of the map (slotvps_amd/csrc/retr_stats4.hip:
- * four waves of 512 registers hold both stages' factors). Arguments as svps_retr_stats_fwd, as HOST arrays of n_stages device
+ * read the same fused map, MultiScaleDynamicMaskHead.forward :190-215) in ONE read of the map (slotvps_amd/csrc/retr_stats2.hip:
+ * eight waves, stage s on waves 4 s .. 4 s + 3, factors in AGPRs). Arguments as svps_retr_stats_fwd, as HOST arrays of n_stages device
  * pointers / values; ty, tx must be given (zero tables for "no position embedding"); aux[s] receives stage s's rows, bit-for-bit
  * the format svps_retr_stats_fwd writes. */
 int svps_retr_stats_level_fwd(const void* feat, int n_stages, const float* const* ty, const float* const* tx,

@@ -181,10 +181,12 @@ class SlotClipRunner:
                 sbytes = T * ps * (512 + 16)
             out["retr_stats"] = {"bytes": sbytes, "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
             # executed matrix work of K1' per pixel (informational): (4 x 32 producer + 4 x 18 consumer) MFMA 32x32x16 per 32-pixel
-            # tile - Q'' is carried as fp16 hi + lo; L <= 128 (the three passes beyond that are not counted here). K1' stages the
-            # 16-byte aux row with every pixel.
+            # tile - Q'' is carried as fp16 hi + lo. K1' stages the 16-byte aux row with every pixel. More than 128 slots (two
+            # passes, the probabilities of 256 slot rows through HBM): pass 1 reads map + aux and writes 512 B of P per pixel,
+            # pass 2 reads map + aux + P; 256 + 144 MFMAs per tile. The ALGORITHMIC bytes stay those of one read of the map.
+            mf = 200 if L <= 128 else 400
             out["retr_attn"] = {"bytes": T * (ps * (512 + 16) + stages * (L * D * 4 + L * 260 * 4) + tabs), "flops": T * ps * 4 * L * D,
-                                "executed_flops": T * ps * (200 * 32768 // 32)}
+                                "executed_flops": T * ps * (mf * 32768 // 32)}
         else:
             out["kv_project"] = {"bytes": T * ps * 1536, "flops": T * ps * 4 * D * D}
             out["slot_attn"] = {"bytes": self.k1_algorithmic_bytes_per_step(), "flops": T * ps * 4 * L * D}

@@ -292,7 +292,7 @@ def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     return aux
 
 
-RETR_STATS_FORM = "level"  # "level": csrc/retr_stats4.hip, every stage of a pyramid level in one read of the map; "stage": csrc/retr_stats.hip per stage
+RETR_STATS_FORM = "level"  # "level": csrc/retr_stats2.hip, every stage of a pyramid level in one read of the map; "stage": csrc/retr_stats.hip per stage
 
 _ZERO_TABLES = {}
 
@@ -358,7 +358,7 @@ def retr_slot_pad(L):
 def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0):
     """K1': out_ext [T, L, 272] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
     rstd_k (Q''.f + cy + cx) + c3 (rstd_k, rstd_v: from the aux rows of retr_stats). qh / ql [T, LP, 256] fp16 (retr_split), cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
-    padded to LP = 128 (L <= 128) or 256 (L <= 256; statistics kernel + two retriever launches)."""
+    padded to LP = 128 (L <= 128) or 256 (L <= 256: two passes - probabilities of all slots through the workspace, then P f)."""
     lib = _lib.load()
     _need(qh, "qh", torch.float16, 3)
     _need(ql, "ql", torch.float16, 3)
