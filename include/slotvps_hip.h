@@ -215,6 +215,16 @@ int svps_slot_gemm_ln(const float* x, const void* wpack, const float* bias, cons
 int svps_slot_ffn(const float* x, const void* w1pack, const float* b1, const void* w2pack, const float* b2, const float* pre,
                   const float* post, const float* gamma, const float* beta, float eps, int act, float* y, int M, int H, void* stream);
 
+/* A chain of up to 6 layers  y_l = LN(src_l W_l^T + b_l [+ pre_l]) * gamma_l + beta_l (+ReLU if relu_l) (+ post_l)  on the same
+ * [M, 256] rows in ONE launch (slotvps_amd/csrc/slot_chain.hip): the class / embedding towers (dynamic_mask_head.py:394-397), the
+ * q / k / v projections of the temporal retriever (:555-557), out_proj + norm1 followed by to_q + norm_q (:356-358, :431).
+ * src_l = 0: the chain's input x; 1: the result of layer l - 1 (kept on the CU as the next operand). All arguments are HOST arrays
+ * of n_layers entries: wpack_l = the fragment-order pack of W_l [256, 256]; bias_l / pre_l / post_l / out_l may be NULL (out_l NULL:
+ * the result only feeds the next layer; the last layer must have an out). Arithmetic: svps_slot_gemm_ln per layer, bit for bit. */
+int svps_slot_chain(const float* x, int M, int n_layers, const void* const* wpack, const float* const* bias,
+                    const float* const* gamma, const float* const* beta, const float* eps, const int* relu,
+                    const float* const* pre, const float* const* post, float* const* out, const int* src, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K9 small batched products of the slot side (slotvps_amd/csrc/bgemm.hip), the products K8 does not take because their B
  * operand is an activation: the slot <-> slot retriever of the temporal head, k q^T and softmax(.)^T v

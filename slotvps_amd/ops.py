@@ -540,6 +540,61 @@ def slot_ffn(x, w1pack, b1, w2pack, b2, gamma, beta, eps=1e-5, act=ACT_RELU, pre
     return out
 
 
+def slot_chain(x, layers):
+    """Up to 6 chained 256 -> 256 layers with LayerNorm in ONE launch (csrc/slot_chain.hip). x [..., 256] fp32; layers: list of
+    dicts with keys wpack (pack_b_fragments of W [256, 256]), gamma, beta (LayerNorm), and optionally bias, eps (1e-5), relu, pre,
+    post ([M, 256] fp32), out (contiguous fp32 [M, 256] or True to allocate; None: the result only feeds the next layer),
+    src ("x": the chain's input, "prev": the previous layer's result; default "x" for the first layer, "prev" after).
+    Returns the list of results (None where a layer's result was not stored). Bitwise the per-layer slot_gemm_ln launches."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32)
+    if x.shape[-1] != D_MODEL:
+        raise ValueError("slot_chain works on rows of 256 values")
+    M = x.numel() // D_MODEL
+    n = len(layers)
+    if not 1 <= n <= 6:
+        raise ValueError("slot_chain: 1 .. 6 layers")
+    keep, outs = [x], []
+    cols = {k: [] for k in ("wpack", "bias", "gamma", "beta", "pre", "post", "out")}
+    eps, relu, src = [], [], []
+    for i, L in enumerate(layers):
+        wp = L["wpack"]
+        _need(wp, "wpack", torch.bfloat16, 5)
+        if wp.shape[0] * 32 != D_MODEL or wp.shape[1] * 16 != D_MODEL:
+            raise ValueError("slot_chain: every layer is 256 -> 256")
+        for k in ("gamma", "beta"):
+            _need(L[k], k, torch.float32, 1)
+        for k in ("bias", "pre", "post"):
+            t = L.get(k)
+            if t is not None:
+                _need(t, k, torch.float32)
+                if t.numel() != (D_MODEL if k == "bias" else M * D_MODEL):
+                    raise ValueError(f"slot_chain: layer {i} {k} has the wrong size")
+        o = L.get("out")
+        if o is True or (o is None and i == n - 1):
+            o = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        if o is not None and (o.numel() != M * D_MODEL or not o.is_contiguous() or o.dtype != torch.float32):
+            raise ValueError("slot_chain: out must be a contiguous fp32 tensor of x's size")
+        s_ = L.get("src", "x" if i == 0 else "prev")
+        if s_ not in ("x", "prev") or (i == 0 and s_ != "x"):
+            raise ValueError("slot_chain: src is 'x' or 'prev' (the first layer reads x)")
+        outs.append(o)
+        for k, v in (("wpack", wp), ("bias", L.get("bias")), ("gamma", L["gamma"]), ("beta", L["beta"]), ("pre", L.get("pre")),
+                     ("post", L.get("post")), ("out", o)):
+            cols[k].append(_ptr(v))
+            keep.append(v)
+        eps.append(float(L.get("eps", 1e-5)))
+        relu.append(int(bool(L.get("relu", False))))
+        src.append(0 if s_ == "x" else 1)
+    vp = lambda v: (ctypes.c_void_p * n)(*v)
+    with _on(*[t for t in keep if isinstance(t, torch.Tensor)]) as ctx:
+        rc = lib.svps_slot_chain(_ptr(x), M, n, vp(cols["wpack"]), vp(cols["bias"]), vp(cols["gamma"]), vp(cols["beta"]),
+                                 (ctypes.c_float * n)(*eps), (ctypes.c_int * n)(*relu), vp(cols["pre"]), vp(cols["post"]),
+                                 vp(cols["out"]), (ctypes.c_int * n)(*src), ctx.stream)
+    _lib.check(rc, "svps_slot_chain")
+    return outs
+
+
 def bgemm(a, b, bias=None, alpha=1.0, out=None):
     """K9: C[g, m, n] = alpha * sum_k a[g, m, k] b[g, n, k] (+ bias[g, n]) for fp32 tensors of ANY strides (views, transposes,
     expand()ed batch dimensions): a [G, M, K] or [M, K], b [G, N, K] or [N, K], bias [G, N], [N] or None. Split-bf16 matrix-core

@@ -191,3 +191,44 @@ def test_slot_ffn_is_bitwise_the_two_launch_form(cuda, M, H, act, post):
     if post:
         ref = ref + q.double()
     assert float((one.double() - ref).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("M", [1000, 64, 5])
+def test_slot_chain_is_bitwise_the_per_layer_launches(cuda, M):
+    """csrc/slot_chain.hip on the three chain shapes of the slot update - a tower (cls layer and three embedding layers off one
+    input, dynamic_mask_head.py:394-397), three projections of one input (:555-557), out_proj + residual + norm followed by a
+    projection + norm (:356-358, :431) - against svps_slot_gemm_ln launched per layer on the same packed weights, bit for bit."""
+    import torch
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(M)
+    rnd = lambda *s: torch.randn(s, generator=g, device=cuda)
+    x, res, post = rnd(M, 256), rnd(M, 256), rnd(M, 256)
+    W = [ops.pack_b_fragments(rnd(256, 256) / 16.0) for _ in range(4)]
+    B = [0.1 * rnd(256) for _ in range(4)]
+    G = [torch.rand(256, generator=g, device=cuda) + 0.5 for _ in range(4)]
+    E = [0.1 * rnd(256) for _ in range(4)]
+    # tower: reg0 -> reg1 -> reg2 (stored), cls0 off the input (stored)
+    r0 = ops.slot_gemm_ln(x, W[0], None, G[0], E[0], 1e-5, relu=True)
+    r1 = ops.slot_gemm_ln(r0, W[1], None, G[1], E[1], 1e-5, relu=True)
+    r2 = ops.slot_gemm_ln(r1, W[2], None, G[2], E[2], 1e-5, relu=True)
+    c0 = ops.slot_gemm_ln(x, W[3], None, G[3], E[3], 1e-5, relu=True)
+    outs = ops.slot_chain(x, [dict(wpack=W[0], gamma=G[0], beta=E[0], relu=True),
+                              dict(wpack=W[1], gamma=G[1], beta=E[1], relu=True),
+                              dict(wpack=W[2], gamma=G[2], beta=E[2], relu=True, out=True),
+                              dict(wpack=W[3], gamma=G[3], beta=E[3], relu=True, src="x")])
+    torch.cuda.synchronize()
+    assert outs[0] is None and outs[1] is None
+    assert torch.equal(outs[2], r2) and torch.equal(outs[3], c0)
+    # three projections of one input, with bias
+    ref = [ops.slot_gemm_ln(x, W[i], B[i], G[i], E[i], 1e-5) for i in range(3)]
+    qkv = torch.empty((3, M, 256), device=cuda)
+    ops.slot_chain(x, [dict(wpack=W[i], bias=B[i], gamma=G[i], beta=E[i], src="x", out=qkv[i]) for i in range(3)])
+    torch.cuda.synchronize()
+    assert all(torch.equal(qkv[i], ref[i]) for i in range(3))
+    # projection + residual + norm (stored), then projection + norm + post of that result
+    a1 = ops.slot_gemm_ln(x, W[0], B[0], G[0], E[0], 1e-5, pre=res)
+    a2 = ops.slot_gemm_ln(a1, W[1], B[1], G[1], E[1], 1e-6, post=post)
+    o = ops.slot_chain(x, [dict(wpack=W[0], bias=B[0], gamma=G[0], beta=E[0], pre=res, out=True),
+                           dict(wpack=W[1], bias=B[1], gamma=G[1], beta=E[1], eps=1e-6, post=post)])
+    torch.cuda.synchronize()
+    assert torch.equal(o[0], a1) and torch.equal(o[1], a2)
