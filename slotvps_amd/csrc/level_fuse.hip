@@ -565,346 +565,9 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
 }
 
 
-// K4 v3 (round 3): the same tile pipeline with FOUR MORE WAVES that own every vector-memory instruction of the workgroup.
-// In v2 each of the eight waves issued its share of the 34 LDS-DMA requests of a tile (an LDS-DMA instruction blocks its wave
-// until the path accepts it: 100 - 170 cycles apiece) and of the out-tile stores in front of its own matrix work; the ablations
-// priced that at 37 + 17 of 195 us. Here waves 8 - 11 (one per SIMD, next to two matrix waves) issue the requests of tile it+2
-// and store the out tile of tile it-1 while waves 0 - 7 run the 24 MFMAs of tile it; the two barriers per tile are shared.
-template <bool NCHW_F32>
-__global__ __launch_bounds__(768) void level_fuse_kernel_v3(
-    const void* __restrict__ cur_, const __bf16* __restrict__ prev, const __bf16* __restrict__ wc,
-    const float* __restrict__ bc, __bf16* __restrict__ out, int H, int W, int tiles_per_chunk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Lds = Fuse2Lds;
-    constexpr int ABL = 0;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool helper = w >= 8;                                     // waves 8 - 11: requests and stores only
-    const int hw = w - 8, ht = tid - 512;
-    const int r_ = lane & 31, h_ = lane >> 5;
-    const int t = blockIdx.y, c = blockIdx.x;
-    const int HW = H * W;
-    const int Hp = H >> 1, Wp = W >> 1;
-    const int tiles = HW / kTilePx;                                  // W % 32 == 0: no ragged tile
-    const int tile_begin = c * tiles_per_chunk;
-    int tile_end = tile_begin + tiles_per_chunk;
-    tile_end = tile_end < tiles ? tile_end : tiles;
-    const int nt = tile_end - tile_begin;
-    // Tile order = COLUMN STRIPS: the g-th tile of the frame is strip g / H (32 output columns), row g % H, so a workgroup
-    // walks DOWN a strip. Consecutive tiles then share their tap rows (output rows 2m+1 and 2m+2 read the same two source
-    // rows, 2m+3 one of them): with row-major order the second use came a whole image row of streaming later
-    // (32 workgroups x 0.5 MB against a 4 MB L2) and was fetched again - 1.33x the algorithmic bytes left L2; now it comes
-    // one tile later. The out tile is still one contiguous 16 KiB block, the incoming map is read as before.
-    const int tiles_per_row = W / kTilePx;
-    (void)tiles_per_row;
-    auto tile_px0 = [&](int tile) {
-        const int g = tile_begin + tile;
-        const int strip = g / H;
-        return (g - strip * H) * W + strip * kTilePx;
-    };
-
-    bf16x8 wf[24];
-    if (!helper) {
-        const __bf16* row = wc + (size_t)(32 * w + r_) * kFuseIn + 8 * h_;
-#pragma unroll
-        for (int ks = 0; ks < 24; ++ks)
-            wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
-    }
-    // the bias of this wave's 32 output channels lives in LDS (16 registers fewer in the matrix waves: three waves per SIMD
-    // leave 168): written once here, read as the accumulator's initial value of every tile
-    float* bias_l = reinterpret_cast<float*>(smem + Lds::total);
-    if (tid < 256) bias_l[tid] = bc[tid];
-
-    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
-    u32x4 psrd;
-    {
-        const uint64_t a = reinterpret_cast<uint64_t>(prev + (size_t)t * Hp * Wp * kD);
-        psrd[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
-        psrd[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
-        psrd[2] = __builtin_amdgcn_readfirstlane((uint32_t)(Hp * Wp) * kRowBytes);
-        psrd[3] = 0x00020000u;
-    }
-    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(out + (size_t)t * HW * kD), 0, HW * kRowBytes, 0x00020000);
-
-    // horizontal blend weights as MFMA B fragments (tile-invariant: a tile starts at an even column, the staged columns
-    // start one source pixel to its left and are clamped into the row when they are read from memory): pixel n takes
-    // staged columns c0 = (n + 1) >> 1 and c0 + 1 with weights (1 - lx, lx), lx = 0.25 for odd n, 0.75 for even n.
-    // Lane (n, h) holds taps 16 ks + 8 h + j, j = 0..7.
-    bf16x8 bwx[2];
-    {
-        const int c0 = (r_ + 1) >> 1;
-        const float lx = (r_ & 1) ? 0.25f : 0.75f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int kk = 16 * ks + 8 * h_ + j;
-                bwx[ks][j] = (__bf16)(kk == c0 ? 1.f - lx : (kk == c0 + 1 ? lx : 0.f));
-            }
-    }
-    // A fragments = staged taps transposed, channels 32w .. 32w+31: byte offsets of the two transposed reads of k-step ks
-    // inside one staged source row (see read_col_frag in common.h); taps past column 17 carry weight 0 and are clamped
-    // onto column 17 so that they read finite data.
-    int tap_off[2][2];
-    {
-        const int gq = lane >> 4, i = lane & 15, q = i >> 2, p4 = i & 3;
-        const int chunk = 4 * w + 2 * (gq & 1) + (p4 >> 1), sub = 8 * (p4 & 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                int row = 16 * ks + 8 * (gq >> 1) + q + 4 * half;
-                row = row < Fuse2Lds::kStageCols ? row : Fuse2Lds::kStageCols - 1;
-                tap_off[ks][half] = row * kRowBytes + ((chunk ^ swz(row)) * 16) + sub;
-            }
-    }
-
-    // tile geometry (wave-uniform): output row y, first column x0; source rows ys0 / ys1 with weight wy of ys1;
-    // staged columns xs_base .. xs_base + 17 (clamped into the row when read from memory)
-    struct Geo { int ys0, ys1, xs_base, x0; float wy; };
-    auto geometry = [&](int tile) {
-        Geo g;
-        const int px0 = tile_px0(tile);
-        const int y = px0 / W;
-        g.x0 = px0 - y * W;
-        const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
-        g.ys0 = (int)sy;
-        g.ys1 = g.ys0 + 1 < Hp ? g.ys0 + 1 : Hp - 1;
-        g.wy = sy - (float)g.ys0;
-        g.xs_base = (g.x0 >> 1) - 1;
-        return g;
-    };
-    // DMA instruction q (0..17) of a tile: source row q / 9, staged columns 2 (q % 9) and 2 (q % 9) + 1; helper hw issues q = hw, hw + 4, ..
-    auto stage_taps = [&](int tile) {
-        if constexpr (ABL & 8) return;
-        const Geo g = geometry(tile);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int q = hw + 4 * k;
-            if (q >= 18) break;
-            const int row = q / 9, cp = q - 9 * row;
-            int col = g.xs_base + 2 * cp + h_;
-            col = col < 0 ? 0 : (col < Wp ? col : Wp - 1);
-            const int ys = row ? g.ys1 : g.ys0;
-            // 16-byte chunks XOR-swizzled by the staged column index (on the source side, as in K1): the transposed
-            // fragment reads of the blend then touch distinct banks
-            const int voff = (ys * Wp + col) * kRowBytes + (((lane & 31) ^ swz(2 * cp + h_)) * 16);
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::stage + (tile & 1) * Lds::stage_bytes +
-                                                                (row * Lds::kStageCols + 2 * cp) * kRowBytes);
-            uint32_t keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %1\n\t"
-                "s_nop 0\n\t"
-                "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "s"(dst), "v"(voff), "s"(psrd)
-                : "memory");
-        }
-    };
-
-    // incoming map of a tile -> LDS by DMA, in its memory layout. NCHW fp32: one instruction = 8 channels x 32 pixels
-    // (lane = (channel, pixel quad)), 16 per tile, wave w issues channels 8w.. and 64 + 8w..; pixel-major bf16: the tile is
-    // one contiguous 8 KiB block, one instruction per wave.
-    u32x4 csrd;
-    {
-        const size_t frame = NCHW_F32 ? (size_t)128 * HW * 4 : (size_t)HW * 256;
-        const uint64_t a = reinterpret_cast<uint64_t>(static_cast<const char*>(cur_) + (size_t)t * frame);
-        csrd[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
-        csrd[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
-        csrd[2] = __builtin_amdgcn_readfirstlane((uint32_t)frame);
-        csrd[3] = 0x00020000u;
-    }
-    constexpr int kCurDma = NCHW_F32 ? 4 : 2;            // map DMA instructions per helper wave and tile
-    auto stage_cur = [&](int tile) {
-        if constexpr (ABL & 8) return;
-        const int px0 = tile_px0(tile);
-        const uint32_t base = lds0 + Lds::cur + (tile & 1) * Lds::cur_bytes;
-#pragma unroll
-        for (int k = 0; k < kCurDma; ++k) {
-            int voff, soff;
-            uint32_t dst;
-            if constexpr (NCHW_F32) {
-                const int ch = 8 * (hw + 4 * k) + (lane >> 3);
-                voff = (ch * HW + 4 * (lane & 7)) * 4;
-                soff = __builtin_amdgcn_readfirstlane(px0 * 4);
-                dst = __builtin_amdgcn_readfirstlane(base + 8 * (hw + 4 * k) * kTilePx * 4);
-            } else {
-                voff = (hw + 4 * k) * 1024 + lane * 16;
-                soff = __builtin_amdgcn_readfirstlane(px0 * 256);
-                dst = __builtin_amdgcn_readfirstlane(base + (hw + 4 * k) * 1024);
-            }
-            uint32_t keep;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %1\n\t"
-                "s_nop 0\n\t"
-                "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "s"(dst), "v"(voff), "s"(csrd), "s"(soff)
-                : "memory");
-        }
-    };
-    auto commit = [&](int tile) {
-        char* at = smem + Lds::atile;
-        const char* cs = smem + Lds::cur + (tile & 1) * Lds::cur_bytes;
-        struct { f32x4 c0, c1; u32x4 cb; } p;
-        if constexpr (NCHW_F32) {
-            const int cp = tid >> 3, pq = tid & 7;                     // channels 2cp, 2cp + 1; pixels 4pq .. 4pq + 3
-            p.c0 = *reinterpret_cast<const f32x4*>(cs + (2 * cp) * kTilePx * 4 + pq * 16);
-            p.c1 = *reinterpret_cast<const f32x4*>(cs + (2 * cp + 1) * kTilePx * 4 + pq * 16);
-            const int chunk = 32 + (cp >> 2), sub = (cp & 3) * 4;      // 16-byte chunk of channels 256 + 2cp, byte inside it
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-                bf16x2 v2;
-                v2[0] = (__bf16)p.c0[j];
-                v2[1] = (__bf16)p.c1[j];
-                *reinterpret_cast<bf16x2*>(at + (4 * pq + j) * Lds::kARow + chunk * 16 + sub) = v2;
-            }
-        } else {
-            const int px = tid >> 4, ck = tid & 15;
-            p.cb = *reinterpret_cast<const u32x4*>(cs + px * 256 + ck * 16);
-            *reinterpret_cast<u32x4*>(at + px * Lds::kARow + (32 + ck) * 16) = p.cb;
-        }
-        // bilinear x2 on the matrix cores: up[c][px] = h0 * (Wx . row0)[c][px] + h1 * (Wx . row1)[c][px], where Wx[tap][px]
-        // holds the two horizontal weights of pixel px (bwx, the same for every tile). Wave w blends channels 32w .. 32w+31
-        // of all 32 pixels: A = staged taps transposed (hardware-transposed LDS reads), 2 k-steps of 16 taps per source row.
-        // The products (bf16 tap x {0, .25, .75, 1}) are exact and at most two are non-zero per sum, so each row sum is
-        // round(w0 a + w1 b) - torch's upsample_bilinear2d expression  (1-ly) ((1-lx) a + lx b) + ly ((1-lx) c + lx d).
-        if constexpr (!(ABL & 4)) {
-            const Geo g = geometry(tile);
-            const float h1 = g.wy, h0 = 1.f - g.wy;
-            const int so = Lds::stage + (tile & 1) * Lds::stage_bytes;
-            f32x16 up[2];
-#pragma unroll
-            for (int row = 0; row < 2; ++row) {
-                bf16x8 af[2];
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const char* base = smem + so + row * Lds::kStageCols * kRowBytes;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(base + tap_off[ks][0]));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(base + tap_off[ks][1]));
-                    af[ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-                f32x16 z;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = 0.f;
-                z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bwx[0], z, 0, 0, 0);
-                up[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bwx[1], z, 0, 0, 0);
-            }
-            const f32x2 h0v = {h0, h0}, h1v = {h1, h1};
-            const int wo = Lds::atile + r_ * Lds::kARow + (32 * w + 4 * h_) * 2;      // pixel row r_, channels 32w + 8g + 4h ..
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                bf16x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    const f32x2 top = {up[0][4 * gq + j], up[0][4 * gq + j + 1]}, bot = {up[1][4 * gq + j], up[1][4 * gq + j + 1]};
-                    const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
-                    o[j] = (__bf16)y[0];
-                    o[j + 1] = (__bf16)y[1];
-                }
-                *reinterpret_cast<bf16x4*>(smem + wo + 16 * gq) = o;
-            }
-        }
-    };
-    auto store_out = [&](int tile) {                                  // helpers: 16 KiB per tile, 4 x 16 B per thread, linear in HBM
-        const int base = tile_px0(tile) * kRowBytes + ht * 16;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = 8 * u + (ht >> 5), gc = ht & 31;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(smem + Lds::otile + row * Lds::kORow + gc * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(val, osrd, base + u * 4096, 0, 0);
-        }
-    };
-
-    // Two tiles ahead: taps and map of tile it+2 are requested at the top of iteration it and consumed by commit(it+2)
-    // at the end of iteration it+1, so a full tile of work covers their latency. All requests are asm LDS-DMA (invisible
-    // to hipcc, which would otherwise wait for them early); the only compiler-visible vector-memory operations are the
-    // two buffer stores per thread and tile, which hipcc never waits for.
-    const int n_req = (hw < 2 ? 5 : 4) + kCurDma;        // DMA instructions of this helper wave per tile (18 tap pieces over 4 waves)
-    constexpr int kSt = 4;                               // stores of a helper thread per tile
-    if (helper) {
-        stage_taps(0);
-        stage_cur(0);
-        if (nt > 1) {
-            stage_taps(1);
-            stage_cur(1);
-            wait_vm_dyn(n_req);                          // tile 0 landed; tile 1 may still fly
-        } else {
-            wait_vm<0>();
-        }
-        __syncthreads();                                 // (1) tile 0's requests visible
-        for (int it = 0; it < nt; ++it) {
-            __syncthreads();                             // a(it): out tile it-1 complete, requests of tile it consumed
-            if (it + 2 < nt) {
-                stage_taps(it + 2);
-                stage_cur(it + 2);
-            }
-            if (it >= 1) store_out(it - 1);
-            // tile it+1 landed. Younger, in issue order: stores(it-2) [issued in iteration it-1 after the requests of tile
-            // it+1], requests of tile it+2, stores(it-1).
-            if (it + 1 < nt) wait_vm_dyn((it >= 2 ? kSt : 0) + (it + 2 < nt ? n_req : 0) + (it >= 1 ? kSt : 0));
-            __syncthreads();                             // b(it): tile it+1's requests visible to the waves that build its operand tile
-        }
-        __syncthreads();                                 // (2) out tile nt-1 complete
-        store_out(nt - 1);
-        return;
-    }
-    __syncthreads();                                     // (1)
-    commit(0);
-    for (int it = 0; it < nt; ++it) {
-        __syncthreads();                                   // a(it): operand tile it built
-        int r = r_, h = h_;
-        asm volatile("" : "+v"(r), "+v"(h));
-        const char* at = smem + Lds::atile;
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {                      // accumulator register 4 g + j <-> channel 32 w + 8 g + 4 h + j
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + 32 * w + 8 * g + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[4 * g + j] = b4[j];
-        }
-        bf16x8 xf[2][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xf[0][u] = *reinterpret_cast<const bf16x8*>(at + r * Lds::kARow + (2 * u + h) * 16);
-#pragma unroll
-        for (int grp = 0; grp < 6; ++grp) {                // fragments of group grp + 1 requested before the MFMAs of group grp
-            if (grp < 5) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    xf[(grp + 1) & 1][u] = *reinterpret_cast<const bf16x8*>(at + r * Lds::kARow + (2 * (4 * (grp + 1) + u) + h) * 16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[4 * grp + u], xf[grp & 1][u], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                                   // b(it): every wave is done reading operand tile it; tile it+1's requests visible
-        char* ot = smem + Lds::otile;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bf16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[4 * g + j];
-            const int ch0 = 32 * w + 8 * g + 4 * h;
-            *reinterpret_cast<bf16x4*>(ot + r * Lds::kORow + (ch0 >> 3) * 16 + (ch0 & 7) * 2) = o;
-        }
-        if (it + 1 < nt) commit(it + 1);
-    }
-    __syncthreads();                                       // (2)
-}
-
-
-
 // ---------------------------------------------------------------------------------------------------------------
-// K4 v4 (round 3): wave-specialised form of the fast path. The SQ counters and the v3 experiment (four extra waves that took
-// over every vector-memory instruction: -5 %) say what bounds v2: LDS bandwidth. With 8 waves x 32 output channels every wave
+// K4 v4 (round 3): wave-specialised form of the fast path. The SQ counters and an experiment with four extra waves that took over
+// every vector-memory instruction of v2 (-5 %) point at LDS traffic: With 8 waves x 32 output channels every wave
 // reads the whole 32 x 384 operand tile - 196 KiB of LDS reads per tile for 24 KiB of data, 1 KiB per MFMA, which is exactly
 // the LDS peak (128 B / clk) at the full matrix rate - on top of the DMA landing, the operand build and the out tile.
 //   waves 0 - 3 ("matrix"): 64 output channels each (weights in 192 registers), every operand fragment feeds TWO MFMAs:
@@ -977,20 +640,20 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[b][4 * g + j] = b4[j];
                 }
-            bf16x8 xf[2][2];
+            bf16x8 xf[2][3];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) xf[0][u] = *reinterpret_cast<const bf16x8*>(at + 32 * u);
+            for (int u = 0; u < 3; ++u) xf[0][u] = *reinterpret_cast<const bf16x8*>(at + 32 * u);
 #pragma unroll
-            for (int grp = 0; grp < 12; ++grp) {                     // fragments of group grp + 1 requested before the MFMAs of group grp
-                if (grp < 11) {
+            for (int grp = 0; grp < 8; ++grp) {                      // fragments of group grp + 1 requested before the MFMAs of group grp
+                if (grp < 7) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) xf[(grp + 1) & 1][u] = *reinterpret_cast<const bf16x8*>(at + 32 * (2 * (grp + 1) + u));
+                    for (int u = 0; u < 3; ++u) xf[(grp + 1) & 1][u] = *reinterpret_cast<const bf16x8*>(at + 32 * (3 * (grp + 1) + u));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][2 * grp + u], xf[grp & 1][u], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][2 * grp + u], xf[grp & 1][u], acc[1], 0, 0, 0);
+                for (int u = 0; u < 3; ++u) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][3 * grp + u], xf[grp & 1][u], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][3 * grp + u], xf[grp & 1][u], acc[1], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1075,14 +738,22 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     };
     constexpr int kTapDma = 5;                                       // tap DMA instructions per helper wave and tile, at most (18 over 4 waves)
     constexpr int kSt = 4;                                           // out-tile stores per helper thread and tile
-    constexpr int kOor = 0x7ffffff0;                                 // out-of-range offset: the request is issued (constant vmcnt bookkeeping) and dropped
-    // every helper issues exactly kTapDma + kCurDma requests and kSt stores per iteration, in this order
+    // Taps are shared between consecutive tiles of a strip: output rows 2m+1 and 2m+2 (and 0, 1, 2) blend the SAME two source rows,
+    // only the vertical weight differs - a tile whose (strip, first source row) equals its predecessor's re-uses the staged taps
+    // (half the tap requests of a tile on average). Returns the staging buffer (0 / 1) that holds the taps of `tile`.
+    int req_key = -1, req_buf = 1;
     auto stage_requests = [&](int tile) {
         const bool live = tile < nt;
         const Geo g = geometry(live ? tile : 0);
-        const int px0 = tile_px0(live ? tile : 0);
+        const int key = ((tile_begin + (live ? tile : 0)) / H) * Hp + g.ys0;
+        const bool fresh = live && key != req_key;
+        if (fresh) {
+            req_key = key;
+            req_buf ^= 1;
+        }
 #pragma unroll
         for (int k = 0; k < kTapDma; ++k) {
+            if (!fresh) break;
             const int q = hw + 4 * k;                                // DMA instruction q (0..17): source row q / 9, staged columns 2 (q % 9), + 1
             if (q >= 18) break;                                      // helpers 2, 3 issue four (wave-uniform: n_req below)
             const int row = q / 9, cp = q - 9 * row;
@@ -1090,8 +761,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
             col = col < 0 ? 0 : (col < Wp ? col : Wp - 1);
             const int ys = row ? g.ys1 : g.ys0;
             int voff = (ys * Wp + col) * kRowBytes + (((lane & 31) ^ swz(2 * cp + h_)) * 16);
-            if (!live) voff = kOor;
-            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::stage + (tile & 1) * Lds::stage_bytes +
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::stage + req_buf * Lds::stage_bytes +
                                                                 (row * Lds::kStageCols + 2 * cp) * kRowBytes);
             uint32_t keep;
             asm volatile(
@@ -1104,6 +774,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 : "s"(dst), "v"(voff), "s"(psrd)
                 : "memory");
         }
+        return req_buf;
     };
     // incoming map of a tile -> registers of the helper threads (compiler-visible loads: hipcc waits for them at their first use,
     // one iteration later). NCHW fp32: item (channel pair cp, pixel quad pq) = two 16-byte loads; pixel-major bf16: 16 B of a pixel row.
@@ -1112,8 +783,11 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         (void*)(static_cast<const char*>(cur_) + (size_t)t * (NCHW_F32 ? (size_t)128 * HW * 4 : (size_t)HW * 256)), 0,
         (int)(NCHW_F32 ? (size_t)128 * HW * 4 : (size_t)HW * 256), 0x00020000);
     auto load_cur = [&](int tile, CurRegs& cr) {
-        const bool live = tile < nt;
-        const int px0 = tile_px0(live ? tile : 0);
+        // wave-uniform "dropped" bit OR-ed into the offsets, in unsigned arithmetic (a select between two offsets made hipcc issue
+        // each load twice under complementary exec masks with s_waitcnt vmcnt(0) in between; frames are below 2 GiB, so bit 31
+        // alone puts an offset out of range and nothing added to it can wrap)
+        const uint32_t dead = (uint32_t)__builtin_amdgcn_readfirstlane(tile < nt ? 0 : (int)0x80000000u);
+        const int px0 = tile_px0(tile < nt ? tile : 0);
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2) {
             const int idx = ht + 256 * j2;
@@ -1121,29 +795,30 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 const int cp = idx >> 3, pq = idx & 7;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int off = live ? ((2 * cp + e) * HW + px0 + 4 * pq) * 4 : kOor;
+                    const int off = (int)((uint32_t)(((2 * cp + e) * HW + px0 + 4 * pq) * 4) | dead);
                     cr.v[j2][e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, off, 0, 0));
                 }
             } else {
                 const int px = idx >> 4, ck = idx & 15;
-                const int off = live ? (px0 + px) * 256 + ck * 16 : kOor;
+                const int off = (int)((uint32_t)((px0 + px) * 256 + ck * 16) | dead);
                 cr.v[j2][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, off, 0, 0));
             }
         }
     };
     auto store_out = [&](int tile) {                                 // 16 KiB per tile, 4 x 16 B per helper thread, linear in HBM
         const bool live = tile >= 0 && tile < nt;
-        const int base = live ? tile_px0(tile) * kRowBytes + ht * 16 : kOor;
+        const uint32_t dead = (uint32_t)__builtin_amdgcn_readfirstlane(live ? 0 : (int)0x80000000u);
+        const uint32_t base = (uint32_t)(tile_px0(live ? tile : 0) * kRowBytes + ht * 16) | dead;
         const char* ot = smem + Lds::otile + (tile & 1) * Lds::o_bytes;
 #pragma unroll
         for (int u = 0; u < kSt; ++u) {
             const int row = 8 * u + (ht >> 5), gc = ht & 31;
             const u32x4 val = *reinterpret_cast<const u32x4*>(ot + row * Lds::kORow + gc * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(val, osrd, live ? base + u * 4096 : kOor, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(val, osrd, (int)(base + (uint32_t)u * 4096u), 0, 0);
         }
     };
     // operand tile of `tile`: incoming map -> channels 256 .. 383 (conversion / copy), blended taps -> channels 0 .. 255
-    auto build = [&](int tile, const CurRegs& cr) {
+    auto build = [&](int tile, const CurRegs& cr, int tap_buf) {
         char* at = smem + Lds::atile + (tile & 1) * Lds::a_bytes;
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2) {
@@ -1170,7 +845,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         const Geo g = geometry(tile);
         const float h1 = g.wy, h0 = 1.f - g.wy;
         const f32x2 h0v = {h0, h0}, h1v = {h1, h1};
-        const int so = Lds::stage + (tile & 1) * Lds::stage_bytes;
+        const int so = Lds::stage + tap_buf * Lds::stage_bytes;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             f32x16 up[2];
@@ -1209,21 +884,22 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     constexpr int kCur = NCHW_F32 ? 4 : 2;                           // map loads per helper thread and tile
     CurRegs cx, cy;
     // prologue: tiles 0 and 1 requested, everything landed (once per workgroup)
-    stage_requests(0);
+    const int buf0 = stage_requests(0);
     load_cur(0, cx);
-    stage_requests(1);
+    int buf_next = stage_requests(1);                                // staging buffer of the taps of tile it+1
     load_cur(1, cy);
     wait_vm<0>();
     __syncthreads();                                                 // P: every helper's tap pieces of tiles 0 and 1 visible
-    build(0, cx);
+    build(0, cx, buf0);
     // iteration it: requests of tile it+2 (its buffers were consumed by build(it) before B(it)), stores of out tile it-1, operand
     // tile it+1 from the registers loaded one iteration ago; issue order taps DMA, map loads, stores
     auto iter = [&](int it, const CurRegs& use, CurRegs& load) {
         __syncthreads();                                             // B(it): operand tile it complete; out tile it-1 complete; taps of tile it+1 visible
-        stage_requests(it + 2);
+        const int buf_new = stage_requests(it + 2);                  // (a fresh group's buffer was last read by build(it) before B(it))
         load_cur(it + 2, load);
         store_out(it - 1);
-        if (it + 1 < nt) build(it + 1, use);
+        if (it + 1 < nt) build(it + 1, use, buf_next);
+        buf_next = buf_new;
         wait_vm_dyn(kCur + kSt);                                     // the tap requests of tile it+2 landed (younger: its map loads, the stores)
     };
     for (int it = 0; it < nt; it += 2) {
@@ -1289,22 +965,6 @@ hipError_t launch_fuse_v2(const void* cur, const void* prev, const void* wc, con
     return hipGetLastError();
 }
 template <bool NCHW>
-hipError_t launch_fuse_v3(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
-                          int W, hipStream_t stream) {
-    auto kern = svps::level_fuse_kernel_v3<NCHW>;
-    static SvpsLdsAttr attr;
-    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), (svps::Fuse2Lds::total + 1024)); ae != hipSuccess) return ae;
-    const int tiles = H * W / svps::kTilePx;
-    int chunks = svps_pick_chunks(T, tiles, fuse_num_cus());
-    const int tpc = (tiles + chunks - 1) / chunks;
-    chunks = (tiles + tpc - 1) / tpc;
-    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(768), (svps::Fuse2Lds::total + 1024), stream, cur,
-                       static_cast<const __bf16*>(prev), static_cast<const __bf16*>(wc), bc,
-                       static_cast<__bf16*>(out), H, W, tpc);
-    return hipGetLastError();
-}
-
-template <bool NCHW>
 hipError_t launch_fuse_v4(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
                           int W, hipStream_t stream) {
     auto kern = svps::level_fuse_kernel_v4<NCHW>;
@@ -1333,13 +993,9 @@ extern "C" int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const v
     // fast path: tiles inside one output row, frame sizes inside a buffer descriptor
     const bool fast = prev && (W & 31) == 0 && (size_t)H * W * 512 < 0x7fffffffu && getenv("SVPS_K4_LEGACY") == nullptr;
     static const bool v2 = getenv("SVPS_K4_V2") != nullptr;          // comparison runs: the eight-wave form of round 2
-    static const bool v3 = getenv("SVPS_K4_V3") != nullptr;          // comparison runs: v2 + four request / store waves
-    if (fast && !v2 && !v3)
+    if (fast && !v2)
         e = cur_is_nchw_f32 ? launch_fuse_v4<true>(cur, prev, wc, bc, out, T, H, W, stream)
                             : launch_fuse_v4<false>(cur, prev, wc, bc, out, T, H, W, stream);
-    else if (fast && !v2)
-        e = cur_is_nchw_f32 ? launch_fuse_v3<true>(cur, prev, wc, bc, out, T, H, W, stream)
-                            : launch_fuse_v3<false>(cur, prev, wc, bc, out, T, H, W, stream);
     else if (fast)
         e = cur_is_nchw_f32 ? launch_fuse_v2<true>(cur, prev, wc, bc, out, T, H, W, stream)
                             : launch_fuse_v2<false>(cur, prev, wc, bc, out, T, H, W, stream);

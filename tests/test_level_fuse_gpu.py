@@ -95,3 +95,24 @@ def test_level_fuse_full_size_properties(cuda):
     full = ops.level_fuse(cur_r, prev_r, wc, bc, H, W)
     one = ops.level_fuse(cur_r[2:3].contiguous(), prev_r[2:3].contiguous(), wc, bc, H, W)
     assert torch.equal(one[0], full[2])
+
+
+@pytest.mark.parametrize("T,H,W", [(2, 16, 32), (9, 32, 64), (5, 64, 128)])
+def test_level_fuse_is_bitwise_reproducible(cuda, T, H, W):
+    """Five launches on the same (non-smooth) inputs give the same bytes: a request or store that lands where it should not - the
+    wave-specialised fast path issues out-of-range "dropped" requests past the end of a chunk - shows up as a run-to-run difference
+    (it did once: a signed overflow in a dropped store's offset made it land in range)."""
+    import torch
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(H + W)
+    cur = torch.randn((T, 128, H, W), generator=g, device=cuda)
+    prev = torch.randn((T, (H // 2) * (W // 2), 256), generator=g, device=cuda).to(torch.bfloat16)
+    wc = (torch.randn((256, 384), generator=g, device=cuda) * 0.05).to(torch.bfloat16)
+    bc = torch.randn(256, generator=g, device=cuda)
+    runs = []
+    for _ in range(5):
+        o = ops.level_fuse(cur, prev, wc, bc, H, W)
+        torch.cuda.synchronize()
+        runs.append(o.view(torch.int16).cpu())
+        del o
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
