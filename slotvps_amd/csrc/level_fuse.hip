@@ -741,7 +741,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     // Taps are shared between consecutive tiles of a strip: output rows 2m+1 and 2m+2 (and 0, 1, 2) blend the SAME two source rows,
     // only the vertical weight differs - a tile whose (strip, first source row) equals its predecessor's re-uses the staged taps
     // (half the tap requests of a tile on average). Returns the staging buffer (0 / 1) that holds the taps of `tile`.
-    int req_key = -1, req_buf = 1;
+    int req_key = -1, req_buf = 1, last_dma = 0;
     auto stage_requests = [&](int tile) {
         const bool live = tile < nt;
         const Geo g = geometry(live ? tile : 0);
@@ -751,6 +751,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
             req_key = key;
             req_buf ^= 1;
         }
+        last_dma = fresh ? (hw < 2 ? 5 : 4) : 0;                     // tap requests this call issues (wave-uniform)
 #pragma unroll
         for (int k = 0; k < kTapDma; ++k) {
             if (!fresh) break;
@@ -776,12 +777,25 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         }
         return req_buf;
     };
-    // incoming map of a tile -> registers of the helper threads (compiler-visible loads: hipcc waits for them at their first use,
-    // one iteration later). NCHW fp32: item (channel pair cp, pixel quad pq) = two 16-byte loads; pixel-major bf16: 16 B of a pixel row.
+    // incoming map of a tile -> registers of the helper threads, consumed one iteration later. The loads are asm with COUNTED waits
+    // (wait_map below): as compiler-visible loads hipcc waited for them with a count that does not know the LDS-DMA requests in
+    // between, i.e. for most of the PREVIOUS iteration's stores as well (vmcnt retires in order) - a store acknowledgement per tile on
+    // the critical path. NCHW fp32: item (channel pair cp, pixel quad pq) = two 16-byte loads; pixel-major bf16: 16 B of a pixel row.
     struct CurRegs { u32x4 v[2][2]; };
-    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(static_cast<const char*>(cur_) + (size_t)t * (NCHW_F32 ? (size_t)128 * HW * 4 : (size_t)HW * 256)), 0,
-        (int)(NCHW_F32 ? (size_t)128 * HW * 4 : (size_t)HW * 256), 0x00020000);
+    u32x4 crs;
+    {
+        const size_t frame = NCHW_F32 ? (size_t)128 * HW * 4 : (size_t)HW * 256;
+        const uint64_t a = reinterpret_cast<uint64_t>(static_cast<const char*>(cur_) + (size_t)t * frame);
+        crs[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+        crs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+        crs[2] = __builtin_amdgcn_readfirstlane((uint32_t)frame);
+        crs[3] = 0x00020000u;
+    }
+    auto ld16 = [&](int off) {
+        u32x4 v;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(crs) : "memory");
+        return v;
+    };
     auto load_cur = [&](int tile, CurRegs& cr) {
         // wave-uniform "dropped" bit OR-ed into the offsets, in unsigned arithmetic (a select between two offsets made hipcc issue
         // each load twice under complementary exec masks with s_waitcnt vmcnt(0) in between; frames are below 2 GiB, so bit 31
@@ -796,12 +810,12 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int off = (int)((uint32_t)(((2 * cp + e) * HW + px0 + 4 * pq) * 4) | dead);
-                    cr.v[j2][e] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, off, 0, 0));
+                    cr.v[j2][e] = ld16(off);
                 }
             } else {
                 const int px = idx >> 4, ck = idx & 15;
                 const int off = (int)((uint32_t)((px0 + px) * 256 + ck * 16) | dead);
-                cr.v[j2][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(crs, off, 0, 0));
+                cr.v[j2][0] = ld16(off);
             }
         }
     };
@@ -818,8 +832,12 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         }
     };
     // operand tile of `tile`: incoming map -> channels 256 .. 383 (conversion / copy), blended taps -> channels 0 .. 255
-    auto build = [&](int tile, const CurRegs& cr, int tap_buf) {
+    auto build = [&](int tile, CurRegs& cr, int tap_buf) {
         char* at = smem + Lds::atile + (tile & 1) * Lds::a_bytes;
+#pragma unroll
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+            for (int e = 0; e < (NCHW_F32 ? 2 : 1); ++e) asm volatile("" : "+v"(cr.v[j2][e]));   // defined by the counted wait above the call
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2) {
             const int idx = ht + 256 * j2;
@@ -846,32 +864,45 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         const float h1 = g.wy, h0 = 1.f - g.wy;
         const f32x2 h0v = {h0, h0}, h1v = {h1, h1};
         const int so = Lds::stage + tap_buf * Lds::stage_bytes;
+        // both channel blocks of this helper in lock-step (all sixteen transposed reads, then the eight MFMAs, then the vector work):
+        // one block after the other was two dependent chains of ~700 cycles each
+        bf16x8 af[2][2][2];                                          // [block][source row][k-step]
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            f32x16 up[2];
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int row = 0; row < 2; ++row) {
-                bf16x8 af[2];
+            for (int row = 0; row < 2; ++row)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const char* base = smem + so + row * Lds::kStageCols * kRowBytes;
                     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(base + tap_off[b][ks][0]));
                     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(base + tap_off[b][ks][1]));
-                    af[ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    af[b][row][ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-                f32x16 z;
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 up[2][2];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) z[i] = 0.f;
-                z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bwx[0], z, 0, 0, 0);
-                up[row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bwx[1], z, 0, 0, 0);
-            }
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int row = 0; row < 2; ++row)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) up[b][row][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int row = 0; row < 2; ++row)
+                    up[b][row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[b][row][ks], bwx[ks], up[b][row], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
             const int wo = r_ * Lds::kARow + (32 * (2 * hw + b) + 4 * h_) * 2;       // pixel row r_, channels 32 cb + 8 g + 4 h ..
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 bf16x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
-                    const f32x2 top = {up[0][4 * gq + j], up[0][4 * gq + j + 1]}, bot = {up[1][4 * gq + j], up[1][4 * gq + j + 1]};
+                    const f32x2 top = {up[b][0][4 * gq + j], up[b][0][4 * gq + j + 1]}, bot = {up[b][1][4 * gq + j], up[b][1][4 * gq + j + 1]};
                     const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
                     o[j] = (__bf16)y[0];
                     o[j + 1] = (__bf16)y[1];
@@ -893,11 +924,14 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     build(0, cx, buf0);
     // iteration it: requests of tile it+2 (its buffers were consumed by build(it) before B(it)), stores of out tile it-1, operand
     // tile it+1 from the registers loaded one iteration ago; issue order taps DMA, map loads, stores
-    auto iter = [&](int it, const CurRegs& use, CurRegs& load) {
+    auto iter = [&](int it, CurRegs& use, CurRegs& load) {
         __syncthreads();                                             // B(it): operand tile it complete; out tile it-1 complete; taps of tile it+1 visible
         const int buf_new = stage_requests(it + 2);                  // (a fresh group's buffer was last read by build(it) before B(it))
         load_cur(it + 2, load);
         store_out(it - 1);
+        // the map loads of tile it+1 (issued one iteration ago) landed. Younger, in issue order: the stores of that iteration, then
+        // this iteration's tap requests, map loads and stores
+        wait_vm_dyn(kSt + last_dma + kCur + kSt);
         if (it + 1 < nt) build(it + 1, use, buf_next);
         buf_next = buf_new;
         wait_vm_dyn(kCur + kSt);                                     // the tap requests of tile it+2 landed (younger: its map loads, the stores)
