@@ -575,6 +575,20 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v2(
 //   waves 4 - 7 ("helpers"): everything else - LDS-DMA requests of tile it+2 (taps + incoming map), stores of out tile it-1,
 //       operand tile of tile it+1 (conversion of the incoming map, bilinear blend of the taps on the matrix cores)
 // one workgroup barrier per tile; operand and out tiles double-buffered (154 KiB of LDS).
+#ifdef SVPS_K4_STAMP
+// diagnostic build only (tools/k4_stamps.py): s_memtime stamps of one workgroup's matrix wave 0 and helper wave 0, iterations 8 .. 15
+__device__ unsigned long long k4_stamps[2][8][8];            // [matrix / helper][iteration - 8][point]
+#define K4_STAMP(role, pt)                                                                               \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && it >= 8 && it < 16 && (threadIdx.x & 255) == 0)        \
+            k4_stamps[role][it - 8][pt] = __builtin_amdgcn_s_memtime();                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define K4_STAMP(role, pt) do {} while (0)
+#endif
+
 struct Fuse4Lds {
     static constexpr int kARow = kFuseRowBytes + 16;
     static constexpr int kORow = kRowBytes + 16;
@@ -627,7 +641,9 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         }
         __syncthreads();                                             // P: bias in LDS; the helpers' tile-0 requests visible to each other
         for (int it = 0; it < nt; ++it) {
+            K4_STAMP(0, 0);
             __syncthreads();                                         // B(it): operand tile it built, out tile it-2 stored
+            K4_STAMP(0, 1);
             int r = r_, h = h_;
             asm volatile("" : "+v"(r), "+v"(h));
             const char* at = smem + Lds::atile + (it & 1) * Lds::a_bytes + r * Lds::kARow + h * 16;
@@ -657,6 +673,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            K4_STAMP(0, 2);
             char* ot = smem + Lds::otile + (it & 1) * Lds::o_bytes + r * Lds::kORow;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -724,34 +741,36 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         }
     }
     struct Geo { int ys0, ys1, xs_base, x0; float wy; };
-    auto geometry = [&](int tile) {
-        Geo g;
-        const int px0 = tile_px0(tile);
-        const int y = px0 / W;
-        g.x0 = px0 - y * W;
-        const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
-        g.ys0 = (int)sy;
-        g.ys1 = g.ys0 + 1 < Hp ? g.ys0 + 1 : Hp - 1;
-        g.wy = sy - (float)g.ys0;
-        g.xs_base = (g.x0 >> 1) - 1;
-        return g;
-    };
     constexpr int kTapDma = 5;                                       // tap DMA instructions per helper wave and tile, at most (18 over 4 waves)
     constexpr int kSt = 4;                                           // out-tile stores per helper thread and tile
     // Taps are shared between consecutive tiles of a strip: output rows 2m+1 and 2m+2 (and 0, 1, 2) blend the SAME two source rows,
     // only the vertical weight differs - a tile whose (strip, first source row) equals its predecessor's re-uses the staged taps
     // (half the tap requests of a tile on average). Returns the staging buffer (0 / 1) that holds the taps of `tile`.
+    // Tile geometry without divisions (an integer division is ~40 scalar / vector instructions, and the old code paid five per
+    // iteration - the stamps showed 500 cycles of address arithmetic per tile): the request stream walks (strip, row) incrementally.
+    struct Req { int buf, px0; float wy; };
     int req_key = -1, req_buf = 1, last_dma = 0;
+    int rq_strip = tile_begin / H, rq_y = tile_begin - (tile_begin / H) * H;   // tile 0 of this workgroup
     auto stage_requests = [&](int tile) {
         const bool live = tile < nt;
-        const Geo g = geometry(live ? tile : 0);
-        const int key = ((tile_begin + (live ? tile : 0)) / H) * Hp + g.ys0;
+        Geo g;
+        g.x0 = rq_strip * kTilePx;
+        g.ys0 = rq_y > 0 ? (rq_y - 1) >> 1 : 0;                      // floor(max((y + 0.5) / 2 - 0.5, 0))
+        g.ys1 = g.ys0 + 1 < Hp ? g.ys0 + 1 : Hp - 1;
+        g.wy = rq_y == 0 ? 0.f : ((rq_y & 1) ? 0.25f : 0.75f);
+        g.xs_base = (g.x0 >> 1) - 1;
+        const int px0 = rq_y * W + g.x0;
+        const int key = rq_strip * Hp + g.ys0;
         const bool fresh = live && key != req_key;
         if (fresh) {
             req_key = key;
             req_buf ^= 1;
         }
         last_dma = fresh ? (hw < 2 ? 5 : 4) : 0;                     // tap requests this call issues (wave-uniform)
+        if (live) {                                                  // next tile of the walk (column strips)
+            ++rq_y;
+            if (rq_y == H) { rq_y = 0; ++rq_strip; }
+        }
 #pragma unroll
         for (int k = 0; k < kTapDma; ++k) {
             if (!fresh) break;
@@ -775,7 +794,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 : "s"(dst), "v"(voff), "s"(psrd)
                 : "memory");
         }
-        return req_buf;
+        return Req{req_buf, px0, g.wy};
     };
     // incoming map of a tile -> registers of the helper threads, consumed one iteration later. The loads are asm with COUNTED waits
     // (wait_map below): as compiler-visible loads hipcc waited for them with a count that does not know the LDS-DMA requests in
@@ -796,12 +815,11 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(off), "s"(crs) : "memory");
         return v;
     };
-    auto load_cur = [&](int tile, CurRegs& cr) {
+    auto load_cur = [&](int tile, int px0, CurRegs& cr) {
         // wave-uniform "dropped" bit OR-ed into the offsets, in unsigned arithmetic (a select between two offsets made hipcc issue
         // each load twice under complementary exec masks with s_waitcnt vmcnt(0) in between; frames are below 2 GiB, so bit 31
         // alone puts an offset out of range and nothing added to it can wrap)
         const uint32_t dead = (uint32_t)__builtin_amdgcn_readfirstlane(tile < nt ? 0 : (int)0x80000000u);
-        const int px0 = tile_px0(tile < nt ? tile : 0);
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2) {
             const int idx = ht + 256 * j2;
@@ -819,10 +837,10 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
             }
         }
     };
-    auto store_out = [&](int tile) {                                 // 16 KiB per tile, 4 x 16 B per helper thread, linear in HBM
+    auto store_out = [&](int tile, int px0) {                        // 16 KiB per tile, 4 x 16 B per helper thread, linear in HBM
         const bool live = tile >= 0 && tile < nt;
         const uint32_t dead = (uint32_t)__builtin_amdgcn_readfirstlane(live ? 0 : (int)0x80000000u);
-        const uint32_t base = (uint32_t)(tile_px0(live ? tile : 0) * kRowBytes + ht * 16) | dead;
+        const uint32_t base = (uint32_t)(px0 * kRowBytes + ht * 16) | dead;
         const char* ot = smem + Lds::otile + (tile & 1) * Lds::o_bytes;
 #pragma unroll
         for (int u = 0; u < kSt; ++u) {
@@ -832,7 +850,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         }
     };
     // operand tile of `tile`: incoming map -> channels 256 .. 383 (conversion / copy), blended taps -> channels 0 .. 255
-    auto build = [&](int tile, CurRegs& cr, int tap_buf) {
+    auto build = [&](int tile, CurRegs& cr, int tap_buf, float wy) {
         char* at = smem + Lds::atile + (tile & 1) * Lds::a_bytes;
 #pragma unroll
         for (int j2 = 0; j2 < 2; ++j2)
@@ -860,8 +878,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
             }
         }
         // bilinear x2 on the matrix cores (v2's arithmetic: each row sum is round(w0 a + w1 b), then h0 top + h1 bottom)
-        const Geo g = geometry(tile);
-        const float h1 = g.wy, h0 = 1.f - g.wy;
+        const float h1 = wy, h0 = 1.f - wy;
         const f32x2 h0v = {h0, h0}, h1v = {h1, h1};
         const int so = Lds::stage + tap_buf * Lds::stage_bytes;
         // both channel blocks of this helper in lock-step (all sixteen transposed reads, then the eight MFMAs, then the vector work):
@@ -915,33 +932,44 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     constexpr int kCur = NCHW_F32 ? 4 : 2;                           // map loads per helper thread and tile
     CurRegs cx, cy;
     // prologue: tiles 0 and 1 requested, everything landed (once per workgroup)
-    const int buf0 = stage_requests(0);
-    load_cur(0, cx);
-    int buf_next = stage_requests(1);                                // staging buffer of the taps of tile it+1
-    load_cur(1, cy);
+    const Req r0 = stage_requests(0);
+    load_cur(0, r0.px0, cx);
+    Req r_next = stage_requests(1);                                  // tile it+1: staging buffer of its taps, first pixel, vertical weight
+    load_cur(1, r_next.px0, cy);
     wait_vm<0>();
     __syncthreads();                                                 // P: every helper's tap pieces of tiles 0 and 1 visible
-    build(0, cx, buf0);
+    build(0, cx, r0.buf, r0.wy);
+    int px_cur = r0.px0, px_prev = 0;                                // first pixel of tile it / tile it-1
     // iteration it: requests of tile it+2 (its buffers were consumed by build(it) before B(it)), stores of out tile it-1, operand
     // tile it+1 from the registers loaded one iteration ago; issue order taps DMA, map loads, stores
     auto iter = [&](int it, CurRegs& use, CurRegs& load) {
+        K4_STAMP(1, 0);
         __syncthreads();                                             // B(it): operand tile it complete; out tile it-1 complete; taps of tile it+1 visible
-        const int buf_new = stage_requests(it + 2);                  // (a fresh group's buffer was last read by build(it) before B(it))
-        load_cur(it + 2, load);
-        store_out(it - 1);
+        K4_STAMP(1, 1);
+        const Req r_new = stage_requests(it + 2);                    // (a fresh group's buffer was last read by build(it) before B(it))
+        K4_STAMP(1, 2);
+        load_cur(it + 2, r_new.px0, load);
+        K4_STAMP(1, 3);
+        store_out(it - 1, px_prev);
+        K4_STAMP(1, 4);
         // the map loads of tile it+1 (issued one iteration ago) landed. Younger, in issue order: the stores of that iteration, then
         // this iteration's tap requests, map loads and stores
         wait_vm_dyn(kSt + last_dma + kCur + kSt);
-        if (it + 1 < nt) build(it + 1, use, buf_next);
-        buf_next = buf_new;
+        K4_STAMP(1, 5);
+        if (it + 1 < nt) build(it + 1, use, r_next.buf, r_next.wy);
+        K4_STAMP(1, 6);
+        px_prev = px_cur;
+        px_cur = r_next.px0;
+        r_next = r_new;
         wait_vm_dyn(kCur + kSt);                                     // the tap requests of tile it+2 landed (younger: its map loads, the stores)
+        K4_STAMP(1, 7);
     };
     for (int it = 0; it < nt; it += 2) {
         iter(it, cy, cx);
         if (it + 1 < nt) iter(it + 1, cx, cy);
     }
     __syncthreads();                                                 // F: out tile nt-1 complete
-    store_out(nt - 1);
+    store_out(nt - 1, px_prev);
 }
 
 }  // namespace svps
@@ -1014,6 +1042,12 @@ hipError_t launch_fuse_v4(const void* cur, const void* prev, const void* wc, con
     return hipGetLastError();
 }
 }  // namespace
+
+#ifdef SVPS_K4_STAMP
+extern "C" int svps_k4_debug_read(unsigned long long* stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::k4_stamps), sizeof(unsigned long long) * 2 * 8 * 8);
+}
+#endif
 
 extern "C" int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, const void* wc,
                                    const float* bc, void* out, int T, int H, int W, void* stream_) {
