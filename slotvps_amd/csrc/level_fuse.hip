@@ -622,11 +622,6 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     int tile_end = tile_begin + tiles_per_chunk;
     tile_end = tile_end < tiles ? tile_end : tiles;
     const int nt = tile_end - tile_begin;
-    auto tile_px0 = [&](int tile) {                                  // column strips (see v2)
-        const int g = tile_begin + tile;
-        const int strip = g / H;
-        return (g - strip * H) * W + strip * kTilePx;
-    };
     float* bias_l = reinterpret_cast<float*>(smem + Lds::bias);
     if (tid < 256) bias_l[tid] = bc[tid];
 
