@@ -593,10 +593,11 @@ struct Fuse4Lds {
     static constexpr int kARow = kFuseRowBytes + 16;
     static constexpr int kORow = kRowBytes + 16;
     static constexpr int a_bytes = kTilePx * kARow;                 // 25 088
-    static constexpr int o_bytes = kTilePx * kORow;                 // 16 896
+    static constexpr int kOWRow = 128 + 16;                         // one pixel's 64 channels of a matrix wave, padded
+    static constexpr int o_wave = kTilePx * kOWRow;                 // 4 608: wave-private out block
     static constexpr int atile = 0;                                 // [2][32][384] bf16 operand tiles
-    static constexpr int otile = 2 * a_bytes;                       // [2][32][256] bf16 out tiles
-    static constexpr int stage = otile + 2 * o_bytes;               // [2][2 rows][18 px][512 B] taps
+    static constexpr int otile = 2 * a_bytes;                       // [4 matrix waves][32 px][64 channels] bf16
+    static constexpr int stage = otile + 4 * o_wave;                // [2][2 rows][18 px][512 B] taps
     static constexpr int kStageCols = 18;
     static constexpr int stage_bytes = 2 * kStageCols * kRowBytes;
     static constexpr int bias = stage + 2 * stage_bytes;            // [256] float
@@ -634,10 +635,16 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 #pragma unroll
             for (int ks = 0; ks < 24; ++ks) wf[b][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
         }
+        // Each matrix wave stores its OWN 64 channels of the out tile (128-byte lines, line-aligned): accumulators -> a wave-private
+        // LDS block [32 px][128 B + pad] -> four 16-byte reads per lane in line order -> four buffer stores (8 whole lines each).
+        // No other vector-memory operation lives on these waves, so nothing ever waits for the stores; the helper waves lose their
+        // store duty (the stamps: 340 - 680 cycles of their ~3 300 per tile, with the matrix waves idle ~1 000 at the barrier).
+        const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)t * HW * kD), 0, HW * kRowBytes, 0x00020000);
+        int st_strip = tile_begin / H, st_y = tile_begin - (tile_begin / H) * H;       // tile `it` of the walk (column strips)
         __syncthreads();                                             // P: bias in LDS; the helpers' tile-0 requests visible to each other
         for (int it = 0; it < nt; ++it) {
             K4_STAMP(0, 0);
-            __syncthreads();                                         // B(it): operand tile it built, out tile it-2 stored
+            __syncthreads();                                         // B(it): operand tile it built
             K4_STAMP(0, 1);
             int r = r_, h = h_;
             asm volatile("" : "+v"(r), "+v"(h));
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 __builtin_amdgcn_sched_barrier(0);
             }
             K4_STAMP(0, 2);
-            char* ot = smem + Lds::otile + (it & 1) * Lds::o_bytes + r * Lds::kORow;
+            char* ot = smem + Lds::otile + w * Lds::o_wave;
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -677,8 +684,19 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                     bf16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[b][4 * g + j];
-                    *reinterpret_cast<bf16x4*>(ot + (64 * w + 32 * b + 8 * g + 4 * h) * 2) = o;
+                    *reinterpret_cast<bf16x4*>(ot + r * Lds::kOWRow + (32 * b + 8 * g + 4 * h) * 2) = o;
                 }
+            // the wave's own LDS operations complete in order: the read-back sees the writes above
+            const int px0 = st_y * W + st_strip * kTilePx;
+            const int lane_o = r + 32 * h;
+            const int sbase = (px0 + (lane_o >> 3)) * kRowBytes + 128 * w + 16 * (lane_o & 7);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u32x4 val = *reinterpret_cast<const u32x4*>(ot + (8 * u + (lane_o >> 3)) * Lds::kOWRow + 16 * (lane_o & 7));
+                __builtin_amdgcn_raw_buffer_store_b128(val, osrd, sbase + u * 8 * kRowBytes, 0, 0);
+            }
+            ++st_y;
+            if (st_y == H) { st_y = 0; ++st_strip; }
         }
         __syncthreads();                                             // F
         return;
@@ -695,7 +713,6 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         psrd[2] = __builtin_amdgcn_readfirstlane((uint32_t)(Hp * Wp) * kRowBytes);
         psrd[3] = 0x00020000u;
     }
-    const __amdgpu_buffer_rsrc_t osrd = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (size_t)t * HW * kD), 0, HW * kRowBytes, 0x00020000);
     u32x4 csrd;
     {
         const size_t frame = NCHW_F32 ? (size_t)128 * HW * 4 : (size_t)HW * 256;
@@ -737,7 +754,6 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     }
     struct Geo { int ys0, ys1, xs_base, x0; float wy; };
     constexpr int kTapDma = 5;                                       // tap DMA instructions per helper wave and tile, at most (18 over 4 waves)
-    constexpr int kSt = 4;                                           // out-tile stores per helper thread and tile
     // Taps are shared between consecutive tiles of a strip: output rows 2m+1 and 2m+2 (and 0, 1, 2) blend the SAME two source rows,
     // only the vertical weight differs - a tile whose (strip, first source row) equals its predecessor's re-uses the staged taps
     // (half the tap requests of a tile on average). Returns the staging buffer (0 / 1) that holds the taps of `tile`.
@@ -832,18 +848,6 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
             }
         }
     };
-    auto store_out = [&](int tile, int px0) {                        // 16 KiB per tile, 4 x 16 B per helper thread, linear in HBM
-        const bool live = tile >= 0 && tile < nt;
-        const uint32_t dead = (uint32_t)__builtin_amdgcn_readfirstlane(live ? 0 : (int)0x80000000u);
-        const uint32_t base = (uint32_t)(px0 * kRowBytes + ht * 16) | dead;
-        const char* ot = smem + Lds::otile + (tile & 1) * Lds::o_bytes;
-#pragma unroll
-        for (int u = 0; u < kSt; ++u) {
-            const int row = 8 * u + (ht >> 5), gc = ht & 31;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(ot + row * Lds::kORow + gc * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(val, osrd, (int)(base + (uint32_t)u * 4096u), 0, 0);
-        }
-    };
     // operand tile of `tile`: incoming map -> channels 256 .. 383 (conversion / copy), blended taps -> channels 0 .. 255
     auto build = [&](int tile, CurRegs& cr, int tap_buf, float wy) {
         char* at = smem + Lds::atile + (tile & 1) * Lds::a_bytes;
@@ -934,9 +938,8 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     wait_vm<0>();
     __syncthreads();                                                 // P: every helper's tap pieces of tiles 0 and 1 visible
     build(0, cx, r0.buf, r0.wy);
-    int px_cur = r0.px0, px_prev = 0;                                // first pixel of tile it / tile it-1
-    // iteration it: requests of tile it+2 (its buffers were consumed by build(it) before B(it)), stores of out tile it-1, operand
-    // tile it+1 from the registers loaded one iteration ago; issue order taps DMA, map loads, stores
+    // iteration it: requests of tile it+2 (its buffers were consumed by build(it) before B(it)), operand tile it+1 from the registers
+    // loaded one iteration ago; issue order taps DMA, map loads
     auto iter = [&](int it, CurRegs& use, CurRegs& load) {
         K4_STAMP(1, 0);
         __syncthreads();                                             // B(it): operand tile it complete; out tile it-1 complete; taps of tile it+1 visible
@@ -945,26 +948,21 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         K4_STAMP(1, 2);
         load_cur(it + 2, r_new.px0, load);
         K4_STAMP(1, 3);
-        store_out(it - 1, px_prev);
         K4_STAMP(1, 4);
-        // the map loads of tile it+1 (issued one iteration ago) landed. Younger, in issue order: the stores of that iteration, then
-        // this iteration's tap requests, map loads and stores
-        wait_vm_dyn(kSt + last_dma + kCur + kSt);
+        // the map loads of tile it+1 (issued one iteration ago) landed. Younger, in issue order: this iteration's tap requests and map loads
+        wait_vm_dyn(last_dma + kCur);
         K4_STAMP(1, 5);
         if (it + 1 < nt) build(it + 1, use, r_next.buf, r_next.wy);
         K4_STAMP(1, 6);
-        px_prev = px_cur;
-        px_cur = r_next.px0;
         r_next = r_new;
-        wait_vm_dyn(kCur + kSt);                                     // the tap requests of tile it+2 landed (younger: its map loads, the stores)
+        wait_vm_dyn(kCur);                                           // the tap requests of tile it+2 landed (younger: its map loads)
         K4_STAMP(1, 7);
     };
     for (int it = 0; it < nt; it += 2) {
         iter(it, cy, cx);
         if (it + 1 < nt) iter(it + 1, cx, cy);
     }
-    __syncthreads();                                                 // F: out tile nt-1 complete
-    store_out(nt - 1, px_prev);
+    __syncthreads();                                                 // F
 }
 
 }  // namespace svps
