@@ -288,15 +288,18 @@ def rank_detector_leg(a, dev, iters=3):
         return -1.0
 
 
-def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, precision="bf16"):
+def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, precision="bf16", decode_logits=None):
     """frames/s of the same graph-replayed step on another configuration (informational legs of the default line)."""
     from slotvps_amd.clip import SlotClipRunner
     from slotvps_amd import synth
     r1 = SlotClipRunner(dev, frames, height, width, L=slots, param_seed=0, cfg=dict(synth.R50_HEAD_CFG, num_classes=num_classes),
-                        use_graph=True, n_slots=1, clips_per_launch=cpl, decode_logits=bool(a.decode_logits))
+                        use_graph=True, n_slots=1, clips_per_launch=cpl,
+                        decode_logits=bool(a.decode_logits) if decode_logits is None else decode_logits)
     r1.head.set_retriever(a.retriever)
     if precision == "fp32":
         r1.head.set_precision("fp32")
+    elif precision == "tight":
+        r1.head.set_statistics("tight")
     r1.load_clip(r1.random_clip(7))
     for _ in range(2):
         r1.run()
@@ -624,6 +627,26 @@ def main():
             except Exception as e:
                 line["single_clip_latency_ms"] = None
                 note(f"single-clip latency leg failed: {type(e).__name__}: {e}")
+        if world == 1 and a.exact_leg and not a.decode_logits:
+            # the same step with the reference's full decode output (fp32 mask logits of ALL slots written, + the fused argmax): what
+            # `value` would be if a caller insisted on the [T, L, HW] tensor (round 2's workload)
+            try:
+                fl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, decode_logits=True)
+                fl["what"] = "the default step with the fp32 mask logits of all slots written (generate_final_outputs' full output), hipGraph"
+                line["with_fp32_mask_logits"] = fl
+            except Exception as e:
+                line["with_fp32_mask_logits"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+        if world == 1 and a.exact_leg and a.slots <= 128:
+            note("precision-form leg (bf16 storage, fp16 hi + lo statistics factors and probabilities) ...")
+            try:
+                tl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, precision="tight")
+                tl["what"] = ("head.set_statistics('tight'): the fused retriever's precision form - QR factors of both LayerNorm statistics and "
+                              "P * rstd_v as fp16 hi + lo, query side in fp32 GEMMs - agrees with a float64 evaluation of the reference's "
+                              "retriever on the same bf16 map to 5e-5 ... 1.3e-4 (default form: 1.0e-3 ... 1.7e-3; "
+                              "tests/test_retr_fused_gpu.py::test_tight_precision_form); same step, hipGraph")
+                line["precision_form"] = tl
+            except Exception as e:
+                line["precision_form"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and a.exact_leg:
             note("exact-mode leg (fp32 storage and arithmetic, one clip per launch) ...")
             try:

@@ -48,16 +48,18 @@ constexpr int kCyTile = 1024;              // one LDS-DMA piece: the Cy row of t
 constexpr int kPartRow = 260;              // floats per slot row of a partial: 256 channels of A + 4 aux columns (every byte of a partial is written)
 constexpr int kExtRow = 272;               // floats per slot row of the finished result: 17 k-steps of 16 for the slot-side product
 
-struct RetrLds {
+template <int PT>    // PT = 1: P * rstd_v as one fp16 tile; 2: hi and lo tiles (the precision form, retr_attn_kernel<.., PHL = true>)
+struct RetrLdsT {
     static constexpr int fring = 0;                             // tile bases are multiples of 512 B (fragment address XORs)
     static constexpr int aring = kRNF * kTileBytes;
     static constexpr int yring = aring + kRNF * kAuxTile;
     static constexpr int pring = yring + kRNF * kCyTile;        // [2][8 KiB] fp16, slot block sb at sb * 2 KiB (32 pixel rows of 64 B)
-    static constexpr int stats = pring + 2 * kPTile;            // [2][4][32] float2
+    static constexpr int stats = pring + 2 * PT * kPTile;       // [2][4][32] float2
     static constexpr int c3 = stats + 2 * 4 * 32 * 8;           // [128] float
     static constexpr int total = c3 + 128 * 4;
 };
-static_assert(RetrLds::pring % 512 == 0 && RetrLds::total <= 160 * 1024, "LDS layout");
+using RetrLds = RetrLdsT<1>;
+static_assert(RetrLds::pring % 512 == 0 && RetrLds::total <= 160 * 1024 && RetrLdsT<2>::total <= 160 * 1024, "LDS layout");
 
 __device__ __forceinline__ u32x4 ra_make_srd(const void* base, uint32_t bytes) {
     const uint64_t a = reinterpret_cast<uint64_t>(base);
@@ -138,7 +140,9 @@ __device__ unsigned long long retr_clock[4096][4];       // [workgroup][memtime0
 //                            then the softmax head of tile it: logits, block maximum, exponentials, block sum -> stats(it)
 //   consumer, iteration it:  LDS-DMA of batch it+3;  A += P(it-2) f(it-2) (36 MFMA)
 // The exponentials of a tile stay in 16 registers across the barrier; the statistics buffer and the P ring are double-buffered.
-template <int ABL = 0, bool EXT = false>
+// PHL (precision form, L <= 128): P * rstd_v carried as fp16 hi + lo - a second P tile per buffer, the consumers' 18 MFMAs per tile
+// twice. Carried as ONE fp16 it is the largest term of the fused retriever's error against float64 (8.7e-4 of 1.1e-3).
+template <int ABL = 0, bool EXT = false, bool PHL = false>
 __global__ __launch_bounds__(512) void retr_attn_kernel(
     const __bf16* __restrict__ qh,      // [T, LP, 256]  hi(Q''), rows >= the real slot count zero
     const __bf16* __restrict__ ql,      // [T, LP, 256]  lo(Q'')
@@ -151,8 +155,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off,
     const float2* __restrict__ ext_stats) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    using Lds = RetrLds;
+    using Lds = RetrLdsT<PHL ? 2 : 1>;
     constexpr int A = kRPrefetch;
+    constexpr int kPBuf = (PHL ? 2 : 1) * kPTile;               // one P buffer: the hi tile (and the lo tile behind it)
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -296,11 +301,22 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 }
                 if (!live_p) fac = 0.f;                             // pixels past the right edge of the map
             };
-            char* prow = smem + Lds::pring + ((it - 1) & 1) * kPTile + sb * 2048 + r * 64 + 8 * h;
+            char* prow = smem + Lds::pring + ((it - 1) & 1) * kPBuf + sb * 2048 + r * 64 + 8 * h;
             auto p2_store = [&](int g) {                            // four slots of P(it-1) = e * fac, fp16
                 f16x4 ph;
+                if constexpr (PHL) {
+                    f16x4 pl;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ph[j] = (_Float16)(e[4 * g + j] * fac);
+                    for (int j = 0; j < 4; ++j) {
+                        const float x = e[4 * g + j] * fac;
+                        ph[j] = (_Float16)x;
+                        pl[j] = (_Float16)(x - (float)ph[j]);
+                    }
+                    *reinterpret_cast<f16x4*>(prow + kPTile + ((g ^ key) * 16)) = pl;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ph[j] = (_Float16)(e[4 * g + j] * fac);
+                }
                 *reinterpret_cast<f16x4*>(prow + ((g ^ key) * 16)) = ph;
             };
             f32x16 s = cinit;
@@ -493,17 +509,18 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     auto cat = [](f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); };
     // A += P f for one tile: 4 steps (k-step, half of the channel blocks) of 4 MFMA (+ 1 for the aux block), the fragments of
     // step q + 1 requested before the MFMAs of step q; those of step 0 before the LDS-DMA of the iteration is issued
-    f16x8 ah[2], af[2], vf[2][4];
+    f16x8 ah[2], al[2], af[2], vf[2][4];
     uint32_t p0 = 0, p1 = 0, v0 = 0, v1 = 0, aa = 0;
     auto vfrag = [&](int ks, int db) {
         const uint32_t o_ = 8192 * ks + 256 * (db >> 2);
         return cat(tr((v0 ^ ((db & 3) << 6)) + o_), tr((v1 ^ ((db & 3) << 6)) + o_));
     };
     auto pv_begin = [&](int j) {
-        const uint32_t pt = lds0 + Lds::pring + (j & 1) * kPTile, vt = lds0 + Lds::fring + (j % kRNF) * kTileBytes;
+        const uint32_t pt = lds0 + Lds::pring + (j & 1) * kPBuf, vt = lds0 + Lds::fring + (j % kRNF) * kTileBytes;
         const uint32_t at = lds0 + Lds::aring + (j % kRNF) * kAuxTile;
         p0 = pt + lane_p0, p1 = pt + lane_p1, v0 = vt + lane_v0, v1 = vt + lane_v1, aa = at + lane_a;
         ah[0] = cat(tr(p0), tr(p1));
+        if constexpr (PHL) al[0] = cat(tr(p0 + kPTile), tr(p1 + kPTile));
         af[0] = cat(tr(aa), tr(aa + 4 * kAuxRow));
 #pragma unroll
         for (int u = 0; u < 4; ++u) vf[0][u] = vfrag(0, u);
@@ -518,13 +535,19 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             }
             if (q == 1) {
                 ah[1] = cat(tr(p0 + 1024), tr(p1 + 1024));
+                if constexpr (PHL) al[1] = cat(tr(p0 + kPTile + 1024), tr(p1 + kPTile + 1024));
                 af[1] = cat(tr(aa + 16 * kAuxRow), tr(aa + 20 * kAuxRow));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
                 o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
-            if (half == 0) oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], af[ks], oa, 0, 0, 0);
+                if constexpr (PHL) o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
+            }
+            if (half == 0) {
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], af[ks], oa, 0, 0, 0);
+                if constexpr (PHL) oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], af[ks], oa, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -1384,6 +1407,37 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
                            L - 128, HW, H, W, p.tiles_per_chunk, 256, L, 128, (const float2*)st);
         e = hipGetLastError();
     }
+    svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
+    if (e != hipSuccess) return (int)e;
+    svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 0, stream);
+    hipLaunchKernelGGL(svps::retr_finish_kernel, dim3(L, T), dim3(256), 0, stream, partial, out_ext, L, p.chunks);
+    svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 1, stream);
+    return (int)hipGetLastError();
+}
+
+// Precision form of svps_retr_attn_fwd for L <= 128: P * rstd_v as fp16 hi + lo (retr_attn_kernel<0, false, true>). Same contract
+// and workspace.
+extern "C" int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
+                                        const void* feat, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext,
+                                        int T, int L, int H, int W, int D, int chunks, void* stream_) {
+    if (!qh || !ql || !cy || !cx || !c3 || !feat || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
+    if (D != svps::kD || T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
+    const int HW = H * W;
+    const RetrPlan p = plan_retr(T, H, W, chunks);
+    const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
+    if (workspace_bytes < partial_bytes) return SVPS_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* partial = static_cast<float*>(workspace);
+    auto kern = svps::retr_attn_kernel<0, false, true>;
+    using Lds = svps::RetrLdsT<2>;
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
+    svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
+    hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream, static_cast<const __bf16*>(qh), static_cast<const __bf16*>(ql),
+                       cy, cx, c3, static_cast<const __bf16*>(feat), static_cast<const __bf16*>(aux), partial, L, HW, H, W,
+                       p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr);
+    hipError_t e = hipGetLastError();
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
     if (e != hipSuccess) return (int)e;
     svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 0, stream);

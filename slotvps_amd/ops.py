@@ -292,6 +292,35 @@ def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     return aux
 
 
+def retr_stats_tight(feat, H, W, pos_proj, rk_hi, rk_lo, rbk, eps_k, rv_hi, rv_lo, rbv, eps_v):
+    """K3t (csrc/retr_stats_t.hip): retr_stats with both factors as fp16 hi + lo (hi + lo = R to 22 bits): rstd_k, rstd_v to ~2e-7
+    relative instead of ~3e-5 / ~5e-5 - the statistics of the fused retriever's precision mode. Same aux rows."""
+    lib = _lib.load()
+    _need(feat, "feat", torch.bfloat16, 3)
+    T, HW, D = feat.shape
+    if HW != H * W:
+        raise ValueError("feat rows != H*W")
+    for name, m in (("rk_hi", rk_hi), ("rk_lo", rk_lo), ("rv_hi", rv_hi), ("rv_lo", rv_lo)):
+        _need(m, name, torch.float16, 2)
+        if m.shape != (D, D):
+            raise ValueError(f"{name} must be [256, 256]")
+    _need(rbk, "rbk", torch.float32, 1)
+    _need(rbv, "rbv", torch.float32, 1)
+    ytab = xtab = None
+    if pos_proj is not None:
+        ytab, xtab = pos_proj
+        _need(ytab, "ty", torch.float32, 2)
+        _need(xtab, "tx", torch.float32, 2)
+        if ytab.shape != (H, D) or xtab.shape != (W, D):
+            raise ValueError("projected position tables do not match (H, W)")
+    aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat.device)
+    with _on(feat, ytab, xtab, rk_hi, rk_lo, rbk, rv_hi, rv_lo, rbv) as ctx:
+        rc = lib.svps_retr_stats_tight_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(rk_hi), _ptr(rk_lo), _ptr(rbk), float(eps_k),
+                                           _ptr(rv_hi), _ptr(rv_lo), _ptr(rbv), float(eps_v), _ptr(aux), T, H, W, D, ctx.stream)
+    _lib.check(rc, "svps_retr_stats_tight_fwd")
+    return aux
+
+
 RETR_STATS_FORM = "level"  # "level": csrc/retr_stats2.hip, every stage of a pyramid level in one read of the map; "stage": csrc/retr_stats.hip per stage
 
 _ZERO_TABLES = {}
@@ -355,7 +384,7 @@ def retr_slot_pad(L):
     return 128 if L <= 128 else 256
 
 
-def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0):
+def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0, tight=False):
     """K1': out_ext [T, L, 272] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
     rstd_k (Q''.f + cy + cx) + c3 (rstd_k, rstd_v: from the aux rows of retr_stats). qh / ql [T, LP, 256] fp16 (retr_split), cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
     padded to LP = 128 (L <= 128) or 256 (L <= 256: two passes - probabilities of all slots through the workspace, then P f)."""
@@ -375,8 +404,11 @@ def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0):
             or c3.shape != (T, LP) or aux.shape != (T, HW, 8)):
         raise ValueError("shape mismatch")
     # RETR_ATTN_FORM "w4" and L <= 128: the four-wave form (csrc/retr_attn4.hip); `chunks` then counts chunks per column strip
-    four = L <= 128 and RETR_ATTN_FORM == "w4"
+    four = L <= 128 and RETR_ATTN_FORM == "w4" and not tight
+    if tight and L > 128:
+        raise NotImplementedError("the precision form of the fused retriever (P * rstd_v as fp16 hi + lo) covers L <= 128")
     ws_fn, fwd, name = ((lib.svps_retr_attn4_workspace_bytes, lib.svps_retr_attn4_fwd, "svps_retr_attn4_fwd") if four else
+                        (lib.svps_retr_attn_workspace_bytes, lib.svps_retr_attn_tight_fwd, "svps_retr_attn_tight_fwd") if tight else
                         (lib.svps_retr_attn_workspace_bytes, lib.svps_retr_attn_fwd, "svps_retr_attn_fwd"))
     ws_bytes = ws_fn(T, L, H, W, chunks)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)

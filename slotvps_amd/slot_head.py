@@ -188,6 +188,10 @@ class MaskDynamicConv(nn.Module):
         # arithmetic, no fp16 staging - for a map that exceeds the range, with a one-time warning. Off by default: maps behind
         # the level-fusion conv of batch-normalised features are O(1) ... O(100).
         self.range_check = False
+        # precision form of the fused retriever (bf16 mode, L <= 128; head.set_statistics("tight")): both QR factors of the statistics
+        # as fp16 hi + lo (csrc/retr_stats_t.hip) and P * rstd_v as fp16 hi + lo (retr_attn_kernel<.., PHL>): the error against float64
+        # drops from the 1e-3 class to the 1e-4 class; the statistics cost ~2x, the retriever ~1.2x
+        self.tight_stats = False
 
     def _bf16_weights(self):
         """to_k / to_v weight matrices rounded to bf16 once (re-derived if the parameters change)."""
@@ -218,6 +222,8 @@ class MaskDynamicConv(nn.Module):
                 # position tables of retr_pos_tables()
                 out["r" + name] = torch.triu(r[:, :256]).to(dev).to(torch.float16).contiguous()
                 out["rb" + name] = r[:, 256].float().to(dev).contiguous()
+                # precision mode (csrc/retr_stats_t.hip): R = hi + lo, two fp16 matrices
+                out["r" + name + "_lo"] = (torch.triu(r[:, :256]) - out["r" + name].double().cpu()).to(dev).to(torch.float16).contiguous()
                 if name == "k":
                     out["rk64"] = torch.triu(r[:, :256])
                 out["wc" + name], out["bc" + name] = wc, bc
@@ -268,23 +274,36 @@ class MaskDynamicConv(nn.Module):
             self._level_stats = None
             if pending is not None and pending[0] is feat_pm:
                 stats = pending[1]
-        if stats is None:
+        if self.tight_stats:
+            # precision form: both statistics from factors carried as fp16 hi + lo (K3t)
+            pp, rk, rbk, ek, rv, rbv, ev = self.stats_args(pos_tabs)
+            stats = ops.retr_stats_tight(feat_pm, H, W, pp, rk, c["rk_lo"], rbk, ek, rv, c["rv_lo"], rbv, ev)
+        elif stats is None:
             stats = ops.retr_stats(feat_pm, H, W, *self.stats_args(pos_tabs))
         LP = ops.retr_slot_pad(L)
         # :431 q = norm_q(to_q(slots)); g = q * gamma_k (zero rows up to LP), c3 = q . beta_k, a1 = g . b~_k: one launch
-        gp, c3, a1 = ops.retr_query_prep(fast_linear(self, "to_q", slots, self.to_q.weight, self.to_q.bias), self.norm_q.weight,
-                                         self.norm_q.bias, self.norm_q.eps, self.norm_k.weight, self.norm_k.bias, c["bck"], LP)
-        q2 = fast_linear(self, "wck", gp, c["wck_lin"])                    # Q'' [T, LP, 256] = gp @ W~_k: the key projection folded into the queries
+        # precision form: the query side in the GEMM library's fp32 (the split-bf16 products of K8 / K9 carry 16-bit operands, ~1e-5
+        # relative on Q'' - 5e-4 on the slot update through logits that are sums of 256 terms of magnitude ~5 with heavy cancellation)
+        tight = self.tight_stats
+        xq = F.linear(slots, self.to_q.weight, self.to_q.bias) if tight else fast_linear(self, "to_q", slots, self.to_q.weight, self.to_q.bias)
+        gp, c3, a1 = ops.retr_query_prep(xq.contiguous(), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps, self.norm_k.weight,
+                                         self.norm_k.bias, c["bck"], LP)
+        # Q'' [T, LP, 256] = gp @ W~_k: the key projection folded into the queries
+        q2 = F.linear(gp, c["wck_lin"]).contiguous() if tight else fast_linear(self, "wck", gp, c["wck_lin"])
         qh, ql = ops.retr_split(q2)
         if pos_tabs is not None:                                           # separable position terms + a' (two small tables per frame)
             ytab, xtab = pos_tabs
             # K9: cy[t, y, l] = a'[t, l] + ytab[y] . Q''[t, l, :128], cx[t, x, l] = xtab[x] . Q''[t, l, 128:] (shared tables: batch stride 0)
-            cy = ops.bgemm(ytab, q2[:, :, :C // 2], bias=a1)
-            cx = ops.bgemm(xtab, q2[:, :, C // 2:])
+            if tight:
+                cy = (torch.matmul(ytab, q2[:, :, :C // 2].transpose(1, 2)) + a1[:, None, :]).contiguous()
+                cx = torch.matmul(xtab, q2[:, :, C // 2:].transpose(1, 2)).contiguous()
+            else:
+                cy = ops.bgemm(ytab, q2[:, :, :C // 2], bias=a1)
+                cx = ops.bgemm(xtab, q2[:, :, C // 2:])
         else:
             cy = a1[:, None, :].expand(T, H, LP).contiguous()
             cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
-        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W)
+        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W, tight=self.tight_stats)
         # :456 (value projection after the sum) + :458-459 (norm1, ReLU) in one launch
         return fast_linear_ln(self, "wext", ext, c["wext_lin"], None, self.norm1, relu=True)
 
@@ -649,6 +668,15 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 m.use_slot_gemm = bool(on)
         return self
 
+    def set_statistics(self, mode):
+        """bf16 mode, fused retriever: "fast" (default: K3' / K3'', fp16 key factor) or "tight" (K3t, fp16 hi + lo key factor)."""
+        if mode not in ("fast", "tight"):
+            raise ValueError(f"statistics must be 'fast' or 'tight', not {mode!r}")
+        for m in self.modules():
+            if hasattr(m, "tight_stats"):
+                m.tight_stats = mode == "tight"
+        return self
+
     def set_retriever(self, form):
         """bf16 mode only: "fused" (K3' + K1', default) or "kv" (K3 + K1 through bf16 k / v tensors)."""
         if form not in ("fused", "kv"):
@@ -720,7 +748,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
             series = getattr(self, f"head_series_{i}")
             mdcs = [stage.inst_interact for stage in series]
             if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype == BF16
-                    and all(m.precision != "fp32" and m.retriever == "fused" for m in mdcs)):
+                    and all(m.precision != "fp32" and m.retriever == "fused" and not m.tight_stats for m in mdcs)):
                 # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats2.hip;
                 # measured 195 against 2 x 116 us at the finest level); each stage's retriever picks its rows up in forward_fused.
                 # A level with a single stage keeps K3'

@@ -227,3 +227,72 @@ def test_level_statistics_equal_per_stage_statistics(cuda, T, H, W, pos, ns):
         sig0 = a0[..., 1].double() + a0[..., 2].double()
         sig1 = a1[..., 1].double() + a1[..., 2].double()
         assert ((sig1 - sig0).abs() / sig0).max().item() <= 4e-5                                    # hi + lo of sigma_v: 16-bit mantissa
+
+
+def test_tight_precision_form(cuda):
+    """The precision form of the fused retriever (MaskDynamicConv.tight_stats; csrc/retr_stats_t.hip + retr_attn_kernel<.., PHL>):
+    both QR factors of the statistics as fp16 hi + lo, P * rstd_v as fp16 hi + lo. rstd_k / rstd_v against a float64 evaluation of the
+    reference's LayerNorm statistics: <= 1e-6 relative (fp16 factors of K3': ~3e-5 / ~7e-5); the fused retriever against the float64
+    oracle on the same bf16 map: <= 2e-4 (fast form: <= 2e-3, measured 1.0e-3 ... 1.3e-3)."""
+    import torch
+    from slotvps_amd import ops
+    from slotvps_amd.slot_head import MaskDynamicConv
+    rng = np.random.default_rng(7)
+    m = MaskDynamicConv(256).to(cuda).eval()
+    P = {}
+    with torch.no_grad():
+        for n in ("to_q", "to_k", "to_v"):
+            lim = float(np.sqrt(6.0 / 512))
+            P[f"{n}.weight"] = rng.uniform(-lim, lim, (256, 256)).astype(np.float32)
+            P[f"{n}.bias"] = (0.1 * rng.standard_normal(256)).astype(np.float32)
+            getattr(m, n).weight.copy_(torch.from_numpy(P[f"{n}.weight"]))
+            getattr(m, n).bias.copy_(torch.from_numpy(P[f"{n}.bias"]))
+        for n in ("norm_q", "norm_k", "norm_v", "norm1"):
+            P[f"{n}.weight"] = rng.uniform(0.5, 1.5, 256).astype(np.float32)
+            P[f"{n}.bias"] = (0.1 * rng.standard_normal(256)).astype(np.float32)
+            getattr(m, n).weight.copy_(torch.from_numpy(P[f"{n}.weight"]))
+            getattr(m, n).bias.copy_(torch.from_numpy(P[f"{n}.bias"]))
+    worst = {}
+    for (H, W, L) in ((12, 40, 100), (32, 64, 100), (9, 33, 37), (16, 64, 128)):
+        feat = orc.round_bf16(rng.standard_normal((2, H * W, 256)).astype(np.float32))
+        slots = rng.standard_normal((2, L, 256)).astype(np.float32)
+        tabs = ops.pos_embed_sine_tables(H, W, 256, cuda)
+        ft = torch.from_numpy(feat).to(cuda).to(torch.bfloat16)
+        pos = orc.pos_embed_sine(H, W).astype(np.float64)                                      # [HW, 256]
+        with torch.no_grad():
+            c = m._fused_consts()
+            pp, rk, rbk, ek, rv, rbv, ev = m.stats_args(tabs)
+            aux_t = ops.retr_stats_tight(ft, H, W, pp, rk, c["rk_lo"], rbk, ek, rv, c["rv_lo"], rbv, ev)
+            aux_f = ops.retr_stats(ft, H, W, pp, rk, rbk, ek, rv, rbv, ev)
+            torch.cuda.synchronize()
+            rk_t, rv_t = (x.cpu().numpy().astype(np.float64) for x in ops.retr_stats_unpack(aux_t))
+            rk_f, rv_f = (x.cpu().numpy().astype(np.float64) for x in ops.retr_stats_unpack(aux_f))
+            # the fp16 words of the aux rows ({1, sigma_v hi, sigma_v lo, 0}) must be those of the fast kernel's layout
+            a16 = aux_t.cpu().numpy()
+            assert (a16[..., 0] == 1.0).all() and (a16[..., 3] == 0.0).all()
+            sig = a16[..., 1].astype(np.float64) + a16[..., 2].astype(np.float64)
+            assert np.abs(sig * rv_t - 1).max() < 1e-6
+        for t in range(2):
+            x = feat[t].astype(np.float64)
+            k = (x + pos) @ P["to_k.weight"].astype(np.float64).T + P["to_k.bias"].astype(np.float64)
+            v = x @ P["to_v.weight"].astype(np.float64).T + P["to_v.bias"].astype(np.float64)
+            ref_k = 1.0 / np.sqrt(k.var(axis=1) + 1e-5)
+            ref_v = 1.0 / np.sqrt(v.var(axis=1) + 1e-5)
+            for name, got, ref in (("rstd_k tight", rk_t[t], ref_k), ("rstd_k fast", rk_f[t], ref_k), ("rstd_v tight", rv_t[t], ref_v),
+                                   ("rstd_v fast", rv_f[t], ref_v)):
+                worst[name] = max(worst.get(name, 0), float(np.abs(got / ref - 1).max()))
+        with torch.no_grad():
+            for mode in (True, False):
+                m.tight_stats = mode
+                got = m.forward_fused(torch.from_numpy(slots).to(cuda), ft, (H, W), tabs).cpu().numpy()
+                key = "retriever tight" if mode else "retriever fast"
+                for t in range(2):
+                    ref = orc.retriever(slots[t], feat[t], orc.pos_embed_sine(H, W), P, "", st=orc.Storage.exact(), dt=np.float64)
+                    err = float(np.abs(got[t] - ref).max())
+                    print(f"  [{H}x{W} L={L} frame {t}] {key}: {err:.2e}")
+                    worst[key] = max(worst.get(key, 0), err)
+            m.tight_stats = False
+    print("\n[precision form] " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    assert worst["rstd_k tight"] <= 1e-6 and worst["rstd_v tight"] <= 1e-6, worst
+    assert worst["retriever tight"] <= 2e-4, worst
+    assert worst["retriever fast"] <= 2e-3, worst
