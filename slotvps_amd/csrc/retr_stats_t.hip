@@ -8,7 +8,7 @@
 // products v_mfma_f32_32x32x16_f16 R_hi x and R_lo x run into ONE fp32 accumulator, everything else as in K3' (f exact in FP16,
 // position terms as fp32 tables in the accumulator's initial value, fp32 sums of squares, v_rsq_f32): rstd to ~2e-7.
 //
-// This is a PRECISION mode, not the fast path: a plain kernel (three barriers per tile, no LDS-DMA ring, hipcc's schedule), launched
+// This is a PRECISION mode, not the fast path: a plain kernel (one barrier per tile, register-staged tiles, hipcc's schedule), launched
 // once per projection (key, value: the map is read twice), one row block of the hi and lo factor resident per wave (128 registers).
 // Output: the 16-byte aux rows of K3' (same layout, consumed by retr_attn.hip unchanged); the key launch writes bytes 8 .. 11, the
 // value launch the rest.
@@ -22,9 +22,10 @@ typedef __attribute__((ext_vector_type(2))) uint32_t st_u32x2;
 
 constexpr int kTtRow = 256 * 2 + 16;                 // staged pixel row: 256 fp16 + pad (conflict-free 16-byte fragment reads)
 struct StatsTLds {
-    static constexpr int xt = 0;                     // [32 px][528 B]
-    static constexpr int part = kTilePx * kTtRow;    // [8 waves][32 px] float: sum of squares of the wave's 32 rows
-    static constexpr int total = part + 8 * 32 * 4;
+    static constexpr int xt = 0;                     // [2][32 px][528 B]
+    static constexpr int x_bytes = kTilePx * kTtRow;
+    static constexpr int part = 2 * x_bytes;         // [2][8 waves][32 px] float: sum of squares of the wave's 32 rows
+    static constexpr int total = part + 2 * 8 * 32 * 4;
 };
 
 struct StatsTArgs {
@@ -63,21 +64,32 @@ __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem
     tile1 = tile1 < tiles ? tile1 : tiles;
     const __bf16* F = a.feat + (size_t)t * a.HW * 256;
     float* part = reinterpret_cast<float*>(smem + StatsTLds::part);
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int px0 = tile * kTilePx;
-        __syncthreads();                                             // the previous tile's fragments and partial sums are consumed
-        {   // stage: thread -> (pixel tid >> 4, 32 bytes = 16 channels), bf16 -> fp16 (exact for |f| in [6.1e-5, 65504])
-            const int px = tid >> 4, c16 = tid & 15;
-            int gp = px0 + px;
-            gp = gp < a.HW ? gp : a.HW - 1;                          // ragged last tile: repeat the last pixel (not stored)
-            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(F + (size_t)gp * 256 + 16 * c16);
-            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(F + (size_t)gp * 256 + 16 * c16 + 8);
-            st_f16x8 o0, o1;
+    // staging: thread -> (pixel tid >> 4, 32 bytes = 16 channels); bf16 -> fp16 is exact for |f| in [6.1e-5, 65504]
+    const int spx = tid >> 4, sc16 = tid & 15;
+    bf16x8 v0, v1;
+    auto fetch = [&](int tile) {
+        int gp = tile * kTilePx + spx;
+        gp = gp < a.HW ? gp : a.HW - 1;                              // ragged last tile / past the chunk: a valid pixel (not stored)
+        v0 = *reinterpret_cast<const bf16x8*>(F + (size_t)gp * 256 + 16 * sc16);
+        v1 = *reinterpret_cast<const bf16x8*>(F + (size_t)gp * 256 + 16 * sc16 + 8);
+    };
+    auto stage = [&](int buf) {
+        st_f16x8 o0, o1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { o0[j] = (_Float16)(float)v0[j]; o1[j] = (_Float16)(float)v1[j]; }
-            *reinterpret_cast<st_f16x8*>(smem + StatsTLds::xt + px * kTtRow + 32 * c16) = o0;
-            *reinterpret_cast<st_f16x8*>(smem + StatsTLds::xt + px * kTtRow + 32 * c16 + 16) = o1;
-        }
+        for (int j = 0; j < 8; ++j) { o0[j] = (_Float16)(float)v0[j]; o1[j] = (_Float16)(float)v1[j]; }
+        char* dst = smem + StatsTLds::xt + buf * StatsTLds::x_bytes + spx * kTtRow + 32 * sc16;
+        *reinterpret_cast<st_f16x8*>(dst) = o0;
+        *reinterpret_cast<st_f16x8*>(dst + 16) = o1;
+    };
+    fetch(tile0);
+    stage(0);
+    __syncthreads();
+    // one barrier per tile: the next tile is fetched under this tile's MFMAs and staged into the other buffer behind them; wave 0
+    // finishes a tile from the (double-buffered) partial sums after the barrier while the others go on
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int cur = (tile - tile0) & 1;
+        const int px0 = tile * kTilePx;
+        if (tile + 1 < tile1) fetch(tile + 1);
         // initial value: the column r (+ the projected position terms of this lane's pixel, key launch)
         f32x16 ak;
         {
@@ -97,8 +109,7 @@ __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem
                 for (int j = 0; j < 4; ++j) ak[4 * g + j] = p[j];
             }
         }
-        __syncthreads();                                             // the tile is staged
-        const char* xrow = smem + StatsTLds::xt + r * kTtRow + 16 * h;
+        const char* xrow = smem + StatsTLds::xt + cur * StatsTLds::x_bytes + r * kTtRow + 16 * h;
 #pragma unroll
         for (int i = 0; i < NKS; ++i) {
             const st_f16x8 xf = *reinterpret_cast<const st_f16x8*>(xrow + 32 * (KS0 + i));
@@ -109,12 +120,13 @@ __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem
 #pragma unroll
         for (int i = 0; i < 16; ++i) sk += ak[i] * ak[i];
         sk += __shfl_xor(sk, 32);
-        if (h == 0) part[w * 32 + r] = sk;
-        __syncthreads();                                             // the eight partial sums of every pixel
+        if (h == 0) part[cur * 256 + w * 32 + r] = sk;
+        if (tile + 1 < tile1) stage(cur ^ 1);
+        __syncthreads();                                             // partial sums of this tile complete; the next tile is staged
         if (w == 0 && h == 0) {
             float tk = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) tk += part[ww * 32 + r];
+            for (int ww = 0; ww < 8; ++ww) tk += part[cur * 256 + ww * 32 + r];
             const float var = tk * (1.f / 256.f) + a.eps;
             const float rstd = __builtin_amdgcn_rsqf(var);
             const int gp = px0 + r;
