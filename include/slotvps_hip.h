@@ -174,6 +174,18 @@ int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const v
                                int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * GroupNorm + ReLU on pixel-major fp32 activations (slotvps_amd/csrc/gn_relu.hip): the normalisation between the deformable
+ * convolutions of the semantic tower (mmdet/models/panoptic/upsnetFPN.py:36-49: nn.GroupNorm(32, C) + nn.ReLU), in the layout
+ * svps_deform_conv_fused_fwd reads and writes.
+ *   x, y [N, HW, C] fp32 pixel-major; y_nchw [N, C, HW] fp32 or NULL (the same result in the layout the framework's
+ *   convolutions take); gamma, beta [C]; C % 4 == 0, C % groups == 0, C in {32, 64, 128, 256, 512, 1024}.
+ *   workspace: svps_group_norm_relu_workspace_bytes(N, HW, C).
+ * ------------------------------------------------------------------------------------------- */
+size_t svps_group_norm_relu_workspace_bytes(int N, int HW, int C);
+int svps_group_norm_relu_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y,
+                             float* y_nchw, void* workspace, size_t workspace_bytes, int N, int HW, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Slot-side helpers (slotvps_amd/csrc/row_ops.hip), rows of D = 256 fp32 values.
  *
  * svps_retr_query_prep: the query side of the fused retriever from x = to_q(slots) [T, L, D] (dynamic_mask_head.py:431):

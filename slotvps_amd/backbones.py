@@ -160,9 +160,43 @@ class UPSNetFPN(nn.Module):
                 m.conv_offset.weight.data.zero_()
                 m.conv_offset.bias.data.zero_()
 
+    fuse_norm = True        # pixel-major tower: K7' -> GroupNorm + ReLU (csrc/gn_relu.hip) without layout copies between the layers
+
+    def _tower(self, x):
+        """The shared tower on one level. Where every layer runs K7' (fp32-class, C % 64 == 0, 128 / 256 output channels) the
+        activations stay pixel-major between the layers: K7' reads and writes that layout, GroupNorm + ReLU is the library's kernel
+        on it (which also emits the NCHW copy the next layer's offset convolution and the tower's consumers take). Otherwise: the
+        module sequence as it stands (reference structure, upsnetFPN.py:36-49)."""
+        from . import ops
+        from .dcn import deform_conv_fused_pm, fused_applicable
+        seq = list(self.deform_convs[0])
+        ok = (self.fuse_norm and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and len(seq) % 3 == 0)
+        if ok:
+            for i in range(0, len(seq), 3):
+                dc, gn, act = seq[i], seq[i + 1], seq[i + 2]
+                ok = ok and (isinstance(dc, DeformConvWithOffset) and isinstance(gn, nn.GroupNorm) and isinstance(act, nn.ReLU)
+                             and dc.conv.fused and not dc.conv.bf16_operands
+                             and fused_applicable(x, dc.conv.weight, dc.conv.stride, dc.conv.padding, dc.conv.dilation, dc.conv.groups,
+                                                  dc.conv.deformable_groups)
+                             and dc.conv.stride == (1, 1) and dc.conv.padding == (1, 1) and dc.conv.dilation == (1, 1)
+                             and gn.num_channels % 4 == 0 and 256 % (gn.num_channels // 4) == 0)
+        if not ok:
+            return self.deform_convs[0](x)
+        N, _, H, W = x.shape
+        cur_nchw = x.contiguous()
+        cur_pm = x.permute(0, 2, 3, 1).contiguous()                       # [N, H, W, C]
+        for i in range(0, len(seq), 3):
+            dc, gn = seq[i], seq[i + 1]
+            O = dc.conv.weight.shape[0]
+            off = dc.conv_offset(cur_nchw)                                # framework 3 x 3 convolution (NCHW in, [N, 18, H, W] out)
+            y = deform_conv_fused_pm(cur_pm, off, dc.conv._weight_pack(), O, 1, 1, 1)          # [N, HW, O]
+            y_pm, y_nchw = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=True)
+            cur_pm, cur_nchw = y_pm.view(N, H, W, O), y_nchw.view(N, O, H, W)
+        return cur_nchw
+
     def forward(self, inputs):
         assert len(inputs) == self.num_levels
-        px = [self.deform_convs[0](inputs[i]) for i in range(self.num_levels)]
+        px = [self._tower(inputs[i]) for i in range(self.num_levels)]
         feat_before = [px[3], px[2], px[1], px[0]] if self.return_feat_levels == 4 else [px[2], px[1], px[0]]
         ups = [px[0]] + [F.interpolate(px[i], None, 2 ** i, mode="bilinear", align_corners=False) for i in (1, 2, 3)]
         fcn_score = self.conv_pred(torch.cat(ups, dim=1))

@@ -1,0 +1,180 @@
+// GroupNorm + ReLU on pixel-major (NHWC) fp32 activations, for the semantic tower.
+//
+// UPSNetFPN's tower (mmdet/models/panoptic/upsnetFPN.py:36-49) is three [deformable conv 3x3 -> GroupNorm(32) -> ReLU] per pyramid
+// level. K7' (deform_conv_fused.hip) reads and writes pixel-major fp32; the framework's GroupNorm wants NCHW, so every layer paid a
+// pixel-major -> NCHW copy inside GroupNorm, the moments kernel, the normalisation kernels and an NCHW -> pixel-major copy in front
+// of the next K7' (profiles: 8.5 of the tower's 24 ms per T = 5 clip). Here:
+//   gn_stats_kernel     per (frame, chunk of pixels): per-CHANNEL sums and sums of squares, one float4 (four channels) per thread
+//   gn_finalize_kernel  per frame: chunks -> channels -> groups in float64; per-channel scale a = rstd_g gamma_c and
+//                       shift b = beta_c - mean_g rstd_g gamma_c
+//   gn_apply_kernel     y = max(a x + b, 0) pixel-major (the next K7' reads it) AND, if asked, NCHW (the offset-producing 3x3 conv of
+//                       the next layer and the tower's consumers are framework convolutions): 32-pixel tiles transposed through LDS,
+//                       128-byte rows per channel
+// fp32 arithmetic, float64 only where sums over ~1e6 elements are combined. Any C with C % 4 == 0 and C % groups == 0.
+#include "common.h"
+#include "../../include/slotvps_hip.h"
+
+namespace svps {
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ partial, int HW, int C,
+                                                       int px_per_chunk) {
+    __shared__ float red[2 * 256 * 4];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int cols = C >> 2;                                   // float4 columns of a pixel row
+    const int rows = 256 / cols;                               // pixels per sweep of the workgroup (cols <= 256: C <= 1024)
+    const int pr = tid / cols, cc = tid - pr * cols;
+    const int p0 = chunk * px_per_chunk;
+    int p1 = p0 + px_per_chunk;
+    p1 = p1 < HW ? p1 : HW;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    if (pr < rows) {
+        const float* base = x + ((size_t)n * HW) * C + 4 * cc;
+        for (int p = p0 + pr; p < p1; p += rows) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += v[j]; ss[j] += v[j] * v[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[tid * 4 + j] = s[j]; red[1024 + tid * 4 + j] = ss[j]; }
+    __syncthreads();
+    if (tid < cols) {                                          // column tid: sum over the pixel rows of the sweep
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < rows; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] += red[(q * cols + tid) * 4 + j]; b[j] += red[1024 + (q * cols + tid) * 4 + j]; }
+        float* dst = partial + (((size_t)n * gridDim.x + chunk) * 2) * C + 4 * tid;
+        *reinterpret_cast<f32x4*>(dst) = a;
+        *reinterpret_cast<f32x4*>(dst + C) = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float2* __restrict__ ab, int HW, int C,
+                                                          int groups, int chunks, float eps) {
+    __shared__ double cs[1024], css[1024];
+    __shared__ double gm[256], gr[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const float* src = partial + (((size_t)n * chunks + k) * 2) * C;
+            a += (double)src[c];
+            b += (double)src[C + c];
+        }
+        cs[c] = a;
+        css[c] = b;
+    }
+    __syncthreads();
+    const int cpg = C / groups;
+    for (int g = tid; g < groups; g += 256) {
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < cpg; ++j) { a += cs[g * cpg + j]; b += css[g * cpg + j]; }
+        const double cnt = (double)HW * cpg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        gm[g] = mean;
+        gr[g] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const double sc = gr[g] * (double)gamma[c];
+        ab[(size_t)n * C + c] = make_float2((float)sc, (float)((double)beta[c] - gm[g] * sc));
+    }
+}
+
+// tile = 32 consecutive pixels x C channels; LDS [32][C + 1] floats for the NCHW copy
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float2* __restrict__ ab, float* __restrict__ y,
+                                                       float* __restrict__ y_nchw, int HW, int C, int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int cols = C >> 2, rows = 256 / cols;
+    const int pr = tid / cols, cc = tid - pr * cols;
+    const int tiles = (HW + 31) >> 5;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    int t1 = t0 + tiles_per_wg;
+    t1 = t1 < tiles ? t1 : tiles;
+    f32x4 a4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
+    if (pr < rows) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float2 v = ab[(size_t)n * C + 4 * cc + j];
+            a4[j] = v.x;
+            b4[j] = v.y;
+        }
+    }
+    const int ldc = C + 1;
+    for (int t = t0; t < t1; ++t) {
+        const int p0 = t << 5;
+        if (pr < rows) {
+            for (int q = pr; q < 32; q += rows) {
+                const int p = p0 + q;
+                if (p < HW) {
+                    const size_t off = ((size_t)n * HW + p) * C + 4 * cc;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(a4[j], v[j], b4[j]), 0.f);
+                    *reinterpret_cast<f32x4*>(y + off) = o;
+                    if (y_nchw) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tile[q * ldc + 4 * cc + j] = o[j];
+                    }
+                }
+            }
+        }
+        if (y_nchw) {
+            __syncthreads();
+            // thread -> (channel, pixel quad): 8 quads per channel row of the tile
+            for (int e = tid; e < C * 8; e += 256) {
+                const int c = e >> 3, q4 = (e & 7) * 4;
+                const int p = p0 + q4;
+                float* dst = y_nchw + ((size_t)n * C + c) * HW + p;
+                if (p + 3 < HW && ((HW & 3) == 0)) {
+                    const f32x4 o = {tile[(q4 + 0) * ldc + c], tile[(q4 + 1) * ldc + c], tile[(q4 + 2) * ldc + c], tile[(q4 + 3) * ldc + c]};
+                    *reinterpret_cast<f32x4*>(dst) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (p + j < HW) dst[j] = tile[(q4 + j) * ldc + c];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace svps
+
+extern "C" size_t svps_group_norm_relu_workspace_bytes(int N, int HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    const int chunks = (HW + 2047) / 2048;
+    return (size_t)N * chunks * 2 * C * sizeof(float) + (size_t)N * C * sizeof(float2);
+}
+
+extern "C" int svps_group_norm_relu_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y,
+                                        float* y_nchw, void* workspace, size_t workspace_bytes, int N, int HW, int C, void* stream_) {
+    if (!x || !gamma || !beta || !y || !workspace) return SVPS_ERR_BAD_ARG;
+    if (N <= 0 || HW <= 0 || C <= 0 || (C & 3) || C > 1024 || groups <= 0 || groups > 256 || C % groups) return SVPS_ERR_BAD_SHAPE;
+    if (256 % (C >> 2)) return SVPS_ERR_BAD_SHAPE;                           // float4 columns of a pixel row must divide the workgroup
+    if (workspace_bytes < svps_group_norm_relu_workspace_bytes(N, HW, C)) return SVPS_ERR_WORKSPACE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int chunks = (HW + 2047) / 2048;
+    float* partial = static_cast<float*>(workspace);
+    float2* ab = reinterpret_cast<float2*>(partial + (size_t)N * chunks * 2 * C);
+    hipLaunchKernelGGL(svps::gn_stats_kernel, dim3(chunks, N), dim3(256), 0, stream, x, partial, HW, C, 2048);
+    hipLaunchKernelGGL(svps::gn_finalize_kernel, dim3(N), dim3(256), 0, stream, partial, gamma, beta, ab, HW, C, groups, chunks, eps);
+    const int tiles = (HW + 31) / 32;
+    int wgs = (2048 + N - 1) / N;                                           // ~2048 workgroups per launch
+    wgs = wgs < tiles ? wgs : tiles;
+    const int tpw = (tiles + wgs - 1) / wgs;
+    wgs = (tiles + tpw - 1) / tpw;
+    const size_t lds = y_nchw ? (size_t)32 * (C + 1) * sizeof(float) : 0;
+    static SvpsLdsAttr attr;
+    if (lds > 48 * 1024)
+        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(svps::gn_apply_kernel), (int)lds); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(svps::gn_apply_kernel, dim3(wgs, N), dim3(256), lds, stream, x, (const float2*)ab, y, y_nchw, HW, C, tpw);
+    return (int)hipGetLastError();
+}

@@ -35,6 +35,26 @@ def fused_applicable(x, weight, stride, padding, dilation, groups, deformable_gr
             and _pair(dilation)[0] == _pair(dilation)[1] and x.shape[2] * x.shape[3] * C < 2 ** 31)
 
 
+def deform_conv_fused_pm(x_nhwc, offset, wpack, O, stride=1, padding=0, dilation=1):
+    """K7' on pixel-major tensors: x_nhwc [N, H, W, C] fp32 contiguous, offset [N, 18, Ho, Wo] fp32 -> [N, Ho*Wo, O] fp32."""
+    if not x_nhwc.is_cuda:
+        raise RuntimeError("deform_conv runs on the GPU only; there is no CPU fallback")
+    lib = _lib.load()
+    s, p_, d = _pair(stride)[0], _pair(padding)[0], _pair(dilation)[0]
+    N, H, W, C = x_nhwc.shape
+    Ho = (H + 2 * p_ - (d * 2 + 1)) // s + 1
+    Wo = (W + 2 * p_ - (d * 2 + 1)) // s + 1
+    offset = offset.float().contiguous()
+    if offset.shape != (N, 18, Ho, Wo) or not x_nhwc.is_contiguous() or x_nhwc.dtype != torch.float32:
+        raise ValueError("deform_conv_fused_pm: x [N, H, W, C] fp32 contiguous and offset [N, 18, Ho, Wo] expected")
+    out = torch.empty((N, Ho * Wo, O), dtype=torch.float32, device=x_nhwc.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    with ops._on(x_nhwc, offset, wpack, out) as ctx:
+        rc = lib.svps_deform_conv_fused_fwd(p(x_nhwc), p(offset), p(wpack), p(out), N, C, H, W, O, 3, 3, p_, s, d, Ho, Wo, ctx.stream)
+    _lib.check(rc, "svps_deform_conv_fused_fwd")
+    return out
+
+
 def deform_conv_fused(x, offset, wpack, O, stride=1, padding=0, dilation=1):
     """K7': x [N, C, H, W] fp32, offset [N, 18, Ho, Wo], wpack = pack_weight_fragments(weight) -> [N, O, Ho, Wo] fp32."""
     if not x.is_cuda:

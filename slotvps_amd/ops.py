@@ -259,6 +259,28 @@ def row_softmax(x, inplace=False):
     return out
 
 
+def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False):
+    """relu(GroupNorm(groups)(x)) for pixel-major fp32 activations x [N, HW, C] (csrc/gn_relu.hip) -> (y [N, HW, C], y_nchw [N, C, HW]
+    or None): the normalisation of the semantic tower in the layout of the deformable-convolution kernel, optionally also in the
+    layout the framework's convolutions take."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32, 3)
+    N, HW, C = x.shape
+    _need(gamma, "gamma", torch.float32, 1)
+    _need(beta, "beta", torch.float32, 1)
+    if gamma.numel() != C or beta.numel() != C:
+        raise ValueError("group_norm_relu_pm: affine parameters do not match C")
+    y = torch.empty_like(x)
+    yn = torch.empty((N, C, HW), dtype=torch.float32, device=x.device) if want_nchw else None
+    ws_bytes = lib.svps_group_norm_relu_workspace_bytes(N, HW, C)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
+    with _on(x, gamma, beta, y, yn, ws) as ctx:
+        rc = lib.svps_group_norm_relu_fwd(_ptr(x), _ptr(gamma), _ptr(beta), int(groups), float(eps), _ptr(y), _ptr(yn), _ptr(ws),
+                                          ws_bytes, N, HW, C, ctx.stream)
+    _lib.check(rc, "svps_group_norm_relu_fwd")
+    return y, yn
+
+
 # ---- statistics-fused retriever (csrc/retr_stats.hip, csrc/retr_attn.hip) -------------------------------------------
 def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     """K3': per-pixel reciprocal standard deviations of the key / value LayerNorms, as the aux rows K1' consumes.

@@ -252,3 +252,51 @@ def test_semantic_tower_matches_reference_structure(cuda):
             d = np.abs(got.float().cpu().numpy() - ref)
             scale = max(1.0, np.abs(ref).max())
             assert got.shape == ref.shape and d.max() <= tol_max * scale and d.mean() <= tol_mean * scale, (bf16, d.max(), d.mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,HW,C,groups", [(2, 1000, 256, 32), (1, 4096, 128, 32), (3, 77, 32, 32), (1, 131, 64, 8)])
+def test_group_norm_relu_pixel_major(cuda, N, HW, C, groups):
+    """csrc/gn_relu.hip against torch's GroupNorm + ReLU (the modules of the reference's tower, upsnetFPN.py:36-49) on the same data:
+    pixel-major result and its NCHW copy, ragged pixel counts."""
+    import torch
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(N + HW + C)
+    x = 2.0 * torch.randn((N, HW, C), generator=g, device=cuda) + 0.7
+    gamma = torch.rand(C, generator=g, device=cuda) + 0.5
+    beta = 0.3 * torch.randn(C, generator=g, device=cuda)
+    ref = torch.relu(torch.nn.functional.group_norm(x.double().transpose(1, 2), groups, gamma.double(), beta.double(), 1e-5))   # [N, C, HW]
+    y, yn = ops.group_norm_relu_pm(x, gamma, beta, groups, 1e-5, want_nchw=True)
+    y2, none = ops.group_norm_relu_pm(x, gamma, beta, groups, 1e-5)
+    torch.cuda.synchronize()
+    assert none is None and torch.equal(y, y2)
+    assert torch.equal(yn, y.transpose(1, 2).contiguous())
+    assert float((yn.double() - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_pixel_major_tower_equals_module_sequence(cuda):
+    """UPSNetFPN._tower with the pixel-major path (K7' -> GroupNorm + ReLU kernel, no layout copies) against the module sequence
+    (K7' per layer, torch GroupNorm / ReLU) on a 256 -> 256 -> 128 -> 128 tower, non-zero offsets."""
+    import torch
+    from slotvps_amd.backbones import UPSNetFPN
+    torch.manual_seed(0)
+    tower = UPSNetFPN(in_channels=256, out_channels=128, num_levels=4, num_things_classes=8, num_classes=19, ignore_label=255,
+                      loss_weight=1.0).cuda().eval()
+    with torch.no_grad():
+        for m in tower.modules():
+            if hasattr(m, "conv_offset"):
+                m.conv_offset.weight.normal_(0, 0.02)
+                m.conv_offset.bias.normal_(0, 0.5)
+            if isinstance(m, torch.nn.GroupNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    x = torch.randn(2, 256, 24, 40, device=cuda)
+    with torch.no_grad():
+        tower.fuse_norm = True
+        a = tower._tower(x)
+        tower.fuse_norm = False
+        b = tower._tower(x)
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (2, 128, 24, 40)
+    assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max()))
