@@ -17,6 +17,7 @@
 // tiles by LDS-DMA into a 4-stage ring, wave w owns slots [32w, 32w+32), pixel = lane), so the
 // logits leave the accumulators as 128-B pixel-contiguous row segments of the [T, L, HW] output.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -201,16 +202,16 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
 //     range check, so every wave issues the same number of stores and the vmcnt arithmetic stays exact;
 //   * the cross-wave part of the fused argmax of tile j runs at the top of tile j + 1 (double-buffered candidates):
 //     two workgroup barriers per tile instead of three.
-template <int NW>
+template <int NW, bool LOGITS = true, int NSTG = 0>
 struct Dec2Lds {
-    static constexpr int kStages = 3;
-    static constexpr int ring = 0;                                   // 3 feature tiles
+    static constexpr int kStages = NSTG ? NSTG : (LOGITS ? 3 : 4);   // argmax-only mode has no transpose tiles: one more feature tile in flight
+    static constexpr int ring = 0;                                   // kStages feature tiles
     static constexpr int kORow = 144;                                // per wave [32 slots][32 px] fp32, rows padded to 144 B:
     static constexpr int kOWave = 32 * kORow;                        // every epilogue address is lane base + constant
     static constexpr int otile = kStages * kTileBytes;
-    static constexpr int affine = otile + NW * kOWave;               // scale[256], shift[256]
+    static constexpr int affine = otile + (LOGITS ? NW * kOWave : 0);   // scale[256], shift[256]
     static constexpr int norm = affine + 2 * kD * 4;                 // [32]
-    static constexpr int cshift = norm + kTilePx * 4;                // [32 NW]
+    static constexpr int cshift = norm + 2 * kTilePx * 4;            // [32 NW]   (norm: [2][32], by tile parity)
     static constexpr int amax = cshift + 32 * NW * 4;                // [2][NW][32] float2
     static constexpr int total = amax + 2 * NW * kTilePx * 8;
 };
@@ -265,19 +266,36 @@ __device__ __forceinline__ void store1_d(int val, u32x4 srd, int voff) {
     asm volatile("buffer_store_byte %0, %1, %2, 0 offen" : : "v"(val), "v"(voff), "s"(srd) : "memory");
 }
 
+#ifdef SVPS_K2_STAMP
+// diagnostic build only (tools/k2_stamps.py): s_memtime stamps of the four waves of one workgroup, iterations 8 .. 15
+__device__ unsigned long long k2_stamps[4][8][8];            // [wave][iteration - 8][point]
+#define K2_STAMP(pt)                                                                                     \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && it >= 8 && it < 16 && w < 4 && (threadIdx.x & 63) == 0) \
+            k2_stamps[w][it - 8][pt] = __builtin_amdgcn_s_memtime();                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define K2_STAMP(pt) do {} while (0)
+#endif
+
 // NW waves = 32 NW slots: 4 (L <= 128: two workgroups per CU) or 8 (L <= 256: one workgroup of 512 threads per CU)
 // LOGITS = false: argmax-only mode (out == NULL) - the [T, L, HW] logits are neither transposed nor stored: per pixel 512 B in and
 // 1 B out instead of 512 + 4 L + 1 (a consumer that only needs the per-pixel slot id, e.g. the clip driver's assignment map)
-template <bool ARGMAX, int NW = 4, bool LOGITS = true>
+// ABL (timing-only builds, -DSVPS_K2_ABLATE + tools/ablate_k2.sh): 1 no MFMAs, 2 no fragment reads either, 4 no argmax epilogue, 8 no DMA
+template <bool ARGMAX, int NW = 4, bool LOGITS = true, int ABL = 0, int NSTG = 0>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v2(
     const __bf16* __restrict__ feat, const float* __restrict__ embed, const float* __restrict__ bn_scale,
     const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
     uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Lds = Dec2Lds<NW>;
+    using Lds = Dec2Lds<NW, LOGITS, NSTG>;
     constexpr int NST = Lds::kStages;
+    constexpr int kAhead = NST - 1;                              // tiles requested ahead of the one in work
     constexpr int NT = 64 * NW;                                  // threads
     constexpr int PC = 16 / NW;                                  // 1-KiB DMA pieces per wave and tile
+    constexpr int PCW = (ABL & 8) ? 0 : PC;                      // ... that are in flight (vmcnt arithmetic)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -321,6 +339,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                 eh[ks][j] = hi;
                 el[ks][j] = (__bf16)(xs - (float)hi);
             }
+            // four k-steps of loads in flight, not sixteen: with all 128 loaded floats live next to the 128 operand registers hipcc
+            // spills lane constants, reloads one inside the tile loop and guards it with s_waitcnt vmcnt(0) - which drains the
+            // LDS-DMA ring (invisible to the compiler) once per tile
+            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         dot = wave_half_xor_sum(dot);
         if (h == 0) cs[32 * w + r] = dot;
@@ -333,7 +355,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
     constexpr int kMS = LOGITS ? 4 : 0;                          // mask stores per wave and tile
     const u32x4 ars = make_srd_d(ARGMAX ? slot_argmax + (size_t)t * HW : nullptr, ARGMAX ? (uint32_t)HW : 0u);
     auto stage = [&](int tile) {          // exactly PC DMA instructions per wave, or none
-        if (tile >= nt) return;
+        if (tile >= nt || (ABL & 8)) return;
         int voff[PC];                     // recomputed per tile (a handful of VALU ops) rather than held in VGPRs
         {
             int rr = r_, hh = h_;
@@ -381,28 +403,163 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         }
     };
 
-    stage(0);
-    stage(1);
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) stage(i);
 
     char* ot = smem + Lds::otile + w * Lds::kOWave;
 
-    for (int it = 0; it < nt; ++it) {
-        // tile `it` landed (this wave's pieces). Younger than its DMA, in issue order: argmax(it-3), stores(it-2),
-        // DMA(it+1), argmax(it-2), stores(it-1).
-        wait_vm_dyn(kMS * ((it >= 2) + (it >= 1)) + PC * (it + 1 < nt) + amw * ((it >= 3) + (it >= 2)));
+    if constexpr (ABL & 32) {   // the un-skewed loop (round 2 / start of round 3), kept in ablation builds for same-box A/B
+        for (int it = 0; it < nt; ++it) {
+            // tile `it` landed (this wave's pieces). Younger than its DMA, in issue order (kAhead = 2): argmax(it-3), stores(it-2),
+            // DMA(it+1), argmax(it-2), stores(it-1); in general the stores of the last kAhead iterations and the DMA of kAhead - 1 tiles.
+            {
+                int younger = 0;
+    #pragma unroll
+                for (int j = 1; j <= kAhead; ++j)
+                    younger += kMS * (it >= j) + amw * (it >= j + 1) + (j < kAhead ? PCW * (it + j < nt) : 0);
+                wait_vm_dyn(younger);
+            }
+            wg_barrier();
+            stage(it + kAhead);
+            int tid_o = tid, lane_o = lane;
+            r = r_; h = h_;
+            asm volatile("" : "+v"(r), "+v"(h), "+v"(tid_o), "+v"(lane_o));   // opaque per tile: no loop-invariant address tables in VGPRs
+            if (ARGMAX && w == 0 && it >= 1) finish_argmax(it - 1);
+            const char* ft = smem + Lds::ring + (it % NST) * kTileBytes;
+
+            // Argmax-only mode: m = (s + c) * inr * fg_scale + fg_shift is a monotone function of s + c for a pixel (inr > 0), so
+            // the per-pixel norm is not needed to order the slots - the argmax is taken over sgn(fg_scale) * (s + c). It equals the
+            // full mode's argmax except where two slots' logits round to the SAME fp32 value (the full mode then reports the lower
+            // slot, this mode the larger s + c): pixels without a decision at fp32 resolution.
+            if constexpr (LOGITS) {   // ||scale * f + shift||^2 per pixel: 2 NW threads per pixel, 16 / NW chunks each
+                constexpr int TPP = 2 * NW;
+                const int npx = tid_o / TPP, nsub = tid_o % TPP;
+                float ss = 0.f;
+    #pragma unroll
+                for (int i = 0; i < 32 / TPP; ++i) {
+                    const int chunk = nsub + TPP * i;
+                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float g = (float)x[j] * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
+                        ss += g * g;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // one chunk at a time: the affine rows are not worth 64 VGPRs
+                }
+                ss += __shfl_xor(ss, 1);
+                ss += __shfl_xor(ss, 2);
+                ss += __shfl_xor(ss, 4);
+                if constexpr (TPP == 16) ss += __shfl_xor(ss, 8);
+                if (nsub == 0) inv_norm[npx] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+            }
+
+            f32x16 s;
+    #pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            {
+    #pragma unroll
+                for (int grp = 0; grp < ((ABL & 2) ? 0 : 4); ++grp) {   // four operand fragments in flight (register budget: 128 hold e)
+                    bf16x8 ff[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) ff[u] = read_row_frag(ft, 4 * grp + u, r, h);
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if constexpr (ABL & 1) {
+                            asm volatile("" : : "v"(ff[u]), "v"(el[4 * grp + u]), "v"(eh[4 * grp + u]));
+                        } else {
+                            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el[4 * grp + u], ff[u], s, 0, 0, 0);
+                            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh[4 * grp + u], ff[u], s, 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            float inr = 1.f;
+            if constexpr (LOGITS) {
+                wg_barrier();                                // inv_norm of this tile visible
+                inr = inv_norm[r];
+            }
+            const float ksgn = fg_scale > 0.f ? 1.f : (fg_scale < 0.f ? -1.f : 0.f);
+            float best = -INFINITY;
+            int best_slot = 0x7fffffff;
+    #pragma unroll
+            for (int i = 0; i < ((ABL & 4) ? 1 : 16); ++i) {
+                const int sl = acc_row(i, h);                // slot inside this wave's block of 32
+                f32x4 c4;
+                if ((i & 3) == 0) c4 = *reinterpret_cast<const f32x4*>(cs + 32 * w + sl);   // e . shift of slots sl .. sl + 3
+                const float m = LOGITS ? (s[i] + c4[i & 3]) * inr * fg_scale + fg_shift : (s[i] + c4[i & 3]) * ksgn;
+                if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + r * 4) = m;
+                if constexpr (ARGMAX) {
+                    if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
+                }
+            }
+            if constexpr (ARGMAX) {
+                const float ob = __shfl_xor(best, 32);
+                const int os = __shfl_xor(best_slot, 32);
+                if (ob > best || (ob == best && os < best_slot)) { best = ob; best_slot = os; }
+                if (h == 0) am[(it & 1) * NW * kTilePx + w * kTilePx + r] = make_float2(best, __int_as_float(best_slot));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local transpose: own writes done, no barrier needed
+            const int px0 = px_begin + it * kTilePx;
+    #pragma unroll
+            for (int u = 0; u < kMS; ++u) {
+                const int sl = 8 * u + (lane_o >> 3), cc = lane_o & 7;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * Lds::kORow + cc * 16);
+                const int slot = 32 * w + sl, px = px0 + 4 * cc;
+                const bool ok = slot < L && px < px_end;
+                store16_d(val, ors, ok ? (slot * HW + px) * 4 : 0x7ffffff0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (ARGMAX) {
+            wg_barrier();
+            if (w == 0) finish_argmax(nt - 1);
+        }
+        return;
+    }
+
+    // Skewed loop: the epilogue of tile it - 1 (constants, scale, argmax candidates, transpose writes) rides in the shadow of the
+    // MFMA chain of tile it - one accumulator element per MFMA pair - and the operand fragments of group g + 1 are requested before
+    // the MFMAs of group g. One barrier per tile in either mode (the per-pixel norms of tile it are published by the barrier of
+    // iteration it + 1, double-buffered by parity). Iteration 0 has no epilogue, iteration nt no chain.
+    f32x16 sp;                                            // accumulators of the previous tile
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sp[i] = 0.f;
+    const float ksgn = fg_scale > 0.f ? 1.f : (fg_scale < 0.f ? -1.f : 0.f);
+    constexpr int kAS = (ARGMAX && !(ABL & 4)) ? 1 : 0;                    // argmax stores per wave and iteration (only wave 0's lanes are in range)
+    auto body = [&](const int it, auto has_chain, auto has_epi) {
+        constexpr bool CH = decltype(has_chain)::value, EP = decltype(has_epi)::value && !(ABL & 4);
+        // Per iteration it >= 1, in issue order: DMA(it + kAhead), argmax store of tile it - 2, mask stores of tile it - 1.
+        // Younger than DMA(it): the stores of the last kAhead iterations and the DMA of kAhead - 1 tiles.
+        K2_STAMP(0);
+        if constexpr (CH) {
+            constexpr int kSteady = kAhead * (kMS + kAS) + (kAhead - 1) * PCW;
+            if (it > kAhead && it + kAhead <= nt) {        // steady state: a constant, no branch tree
+                wait_vm<kSteady>();
+            } else {
+                int younger = 0;
+#pragma unroll
+                for (int m = 1; m <= kAhead; ++m)
+                    younger += (kMS + kAS) * (it - m >= 1) + (m < kAhead ? PCW * (it - m + kAhead < nt) : 0);
+                wait_vm_dyn(younger);
+            }
+        }
+        K2_STAMP(1);
         wg_barrier();
-        stage(it + 2);
+        K2_STAMP(2);
+        if constexpr (CH) stage(it + kAhead);
+        K2_STAMP(3);
         int tid_o = tid, lane_o = lane;
         r = r_; h = h_;
         asm volatile("" : "+v"(r), "+v"(h), "+v"(tid_o), "+v"(lane_o));   // opaque per tile: no loop-invariant address tables in VGPRs
-        if (ARGMAX && w == 0 && it >= 1) finish_argmax(it - 1);
         const char* ft = smem + Lds::ring + (it % NST) * kTileBytes;
 
         // Argmax-only mode: m = (s + c) * inr * fg_scale + fg_shift is a monotone function of s + c for a pixel (inr > 0), so
         // the per-pixel norm is not needed to order the slots - the argmax is taken over sgn(fg_scale) * (s + c). It equals the
         // full mode's argmax except where two slots' logits round to the SAME fp32 value (the full mode then reports the lower
         // slot, this mode the larger s + c): pixels without a decision at fp32 resolution.
-        if constexpr (LOGITS) {   // ||scale * f + shift||^2 per pixel: 2 NW threads per pixel, 16 / NW chunks each
+        if constexpr (LOGITS && CH) {   // ||scale * f + shift||^2 per pixel: 2 NW threads per pixel, 16 / NW chunks each
             constexpr int TPP = 2 * NW;
             const int npx = tid_o / TPP, nsub = tid_o % TPP;
             float ss = 0.f;
@@ -421,64 +578,124 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
             ss += __shfl_xor(ss, 2);
             ss += __shfl_xor(ss, 4);
             if constexpr (TPP == 16) ss += __shfl_xor(ss, 8);
-            if (nsub == 0) inv_norm[npx] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+            if (nsub == 0) inv_norm[(it & 1) * kTilePx + npx] = 1.f / fmaxf(sqrtf(ss), 1e-12f);
         }
 
+        constexpr bool FR = CH && !(ABL & 2);            // fragments are read
+        bf16x8 ff[2][4];
+        if constexpr (FR) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ff[0][u] = read_row_frag(ft, u, r, h);
+        }
+        // Cross-wave part of the argmax of tile it - 2 (its candidates were written in iteration it - 1): every wave reads them and
+        // runs the comparison in the shadow of its first MFMAs - nobody is late at the next barrier; only wave 0's offsets are in
+        // range, the other waves' stores (and iteration 1's) are dropped by the range check.
+        float2 cnd[NW];
+        if constexpr (ARGMAX && EP) {
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) cnd[ww] = am[(it & 1) * NW * kTilePx + ww * kTilePx + r];
+        }
+        float inr = 1.f;
+        f32x4 c4[2];                                     // e . shift of slots sl .. sl + 3, one group ahead
+        if constexpr (EP) {
+            if constexpr (LOGITS) inr = inv_norm[((it - 1) & 1) * kTilePx + r];
+            c4[0] = *reinterpret_cast<const f32x4*>(cs + 32 * w + acc_row(0, h));
+        }
         f32x16 s;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
-        {
+        float best = -INFINITY;
+        int best_slot = 0x7fffffff;
 #pragma unroll
-            for (int grp = 0; grp < 4; ++grp) {          // four operand fragments in flight (register budget: 128 hold e)
-                bf16x8 ff[4];
+        for (int grp = 0; grp < 4; ++grp) {
+            if constexpr (FR) {
+                if (grp < 3) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ff[u] = read_row_frag(ft, 4 * grp + u, r, h);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int u = 0; u < 4; ++u) ff[(grp + 1) & 1][u] = read_row_frag(ft, 4 * (grp + 1) + u, r, h);
+                }
+            }
+            if constexpr (EP) {
+                if (grp < 3) c4[(grp + 1) & 1] = *reinterpret_cast<const f32x4*>(cs + 32 * w + acc_row(4 * (grp + 1), h));
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el[4 * grp + u], ff[u], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh[4 * grp + u], ff[u], s, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (FR) {
+                    if constexpr (ABL & 1) {
+                        asm volatile("" : : "v"(ff[grp & 1][u]), "v"(el[4 * grp + u]), "v"(eh[4 * grp + u]));
+                    } else {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el[4 * grp + u], ff[grp & 1][u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh[4 * grp + u], ff[grp & 1][u], s, 0, 0, 0);
+                    }
+                }
+                if constexpr (ARGMAX && EP) {
+                    if (grp == 0 && u == 1) {
+                        float b = -INFINITY;
+                        int bs = 0x7fffffff;
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) {
+                            const int sl = __float_as_int(cnd[ww].y);
+                            if (cnd[ww].x > b || (cnd[ww].x == b && sl < bs)) { b = cnd[ww].x; bs = sl; }
+                        }
+                        const int px = px_begin + (it - 2) * kTilePx + r;
+                        const bool ok = w == 0 && h == 0 && it >= 2 && px < px_end;
+                        store1_d(bs, ars, ok ? px : 0x7ffffff0);
+                    }
+                }
+                if constexpr (EP) {
+                    const int i = 4 * grp + u;
+                    const int sl = acc_row(i, h);        // slot inside this wave's block of 32
+                    const float m = LOGITS ? (sp[i] + c4[grp & 1][u]) * inr * fg_scale + fg_shift : (sp[i] + c4[grp & 1][u]) * ksgn;
+                    if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + r * 4) = m;
+                    if constexpr (ARGMAX) {
+                        if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        float inr = 1.f;
-        if constexpr (LOGITS) {
-            wg_barrier();                                // inv_norm of this tile visible
-            inr = inv_norm[r];
-        }
-        const float ksgn = fg_scale > 0.f ? 1.f : (fg_scale < 0.f ? -1.f : 0.f);
-        float best = -INFINITY;
-        int best_slot = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int sl = acc_row(i, h);                // slot inside this wave's block of 32
-            f32x4 c4;
-            if ((i & 3) == 0) c4 = *reinterpret_cast<const f32x4*>(cs + 32 * w + sl);   // e . shift of slots sl .. sl + 3
-            const float m = LOGITS ? (s[i] + c4[i & 3]) * inr * fg_scale + fg_shift : (s[i] + c4[i & 3]) * ksgn;
-            if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + r * 4) = m;
+        K2_STAMP(5);
+        if constexpr (EP) {
             if constexpr (ARGMAX) {
-                if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
+                // v_permlane32_swap: [0] = the value of lane r, [1] = of lane r + 32, in both lanes (no address register, no LDS trip)
+                const auto pb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                const auto ps = __builtin_amdgcn_permlane32_swap((uint32_t)best_slot, (uint32_t)best_slot, false, false);
+                best = __uint_as_float(pb[0]);
+                best_slot = (int)ps[0];
+                const float ob = __uint_as_float(pb[1]);
+                const int os = (int)ps[1];
+                if (ob > best || (ob == best && os < best_slot)) { best = ob; best_slot = os; }
+#ifdef SVPS_K2_STAMP
+                asm volatile("" : "+v"(best), "+v"(best_slot));
+                K2_STAMP(4);
+#endif
+                if (h == 0) am[((it - 1) & 1) * NW * kTilePx + w * kTilePx + r] = make_float2(best, __int_as_float(best_slot));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local transpose: own writes done, no barrier needed
+            const int px0 = px_begin + (it - 1) * kTilePx;
+#pragma unroll
+            for (int u = 0; u < kMS; ++u) {
+                const int sl = 8 * u + (lane_o >> 3), cc = lane_o & 7;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * Lds::kORow + cc * 16);
+                const int slot = 32 * w + sl, px = px0 + 4 * cc;
+                const bool ok = slot < L && px < px_end;
+                store16_d(val, ors, ok ? (slot * HW + px) * 4 : 0x7ffffff0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (ARGMAX) {
-            const float ob = __shfl_xor(best, 32);
-            const int os = __shfl_xor(best_slot, 32);
-            if (ob > best || (ob == best && os < best_slot)) { best = ob; best_slot = os; }
-            if (h == 0) am[(it & 1) * NW * kTilePx + w * kTilePx + r] = make_float2(best, __int_as_float(best_slot));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local transpose: own writes done, no barrier needed
-        const int px0 = px_begin + it * kTilePx;
-#pragma unroll
-        for (int u = 0; u < kMS; ++u) {
-            const int sl = 8 * u + (lane_o >> 3), cc = lane_o & 7;
-            const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * Lds::kORow + cc * 16);
-            const int slot = 32 * w + sl, px = px0 + 4 * cc;
-            const bool ok = slot < L && px < px_end;
-            store16_d(val, ors, ok ? (slot * HW + px) * 4 : 0x7ffffff0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+        K2_STAMP(6);
+        if constexpr (CH) sp = s;
+#ifdef SVPS_K2_STAMP
+        asm volatile("" : "+v"(sp));
+#endif
+        K2_STAMP(7);
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    body(0, T_{}, F_{});
+#pragma clang loop unroll(disable)
+    for (int it = 1; it < nt; ++it) body(it, T_{}, T_{});
+    body(nt, F_{}, T_{});
     if constexpr (ARGMAX) {
         wg_barrier();
         if (w == 0) finish_argmax(nt - 1);
@@ -511,12 +728,12 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
     return hipGetLastError();
 }
 
-template <bool ARGMAX, int NW, bool LOGITS = true>
+template <bool ARGMAX, int NW, bool LOGITS = true, int ABL = 0, int NSTG = 0>
 hipError_t launch_decode_v2(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
                             float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L, int HW,
                             hipStream_t stream) {
-    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW, LOGITS>;
-    using Lds = svps::Dec2Lds<NW>;
+    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW, LOGITS, ABL, NSTG>;
+    using Lds = svps::Dec2Lds<NW, LOGITS, NSTG>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;      // NW = 4: two co-resident workgroups per CU (2 x 68 KiB LDS); 8: one
@@ -542,6 +759,12 @@ hipError_t dispatch_decode(const void* feat, const float* embed, const float* bn
 
 }  // namespace
 
+#ifdef SVPS_K2_STAMP
+extern "C" int svps_k2_debug_read(unsigned long long* stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::k2_stamps), sizeof(unsigned long long) * 4 * 8 * 8);
+}
+#endif
+
 extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const float* bn_scale,
                                     const float* bn_shift, float fg_scale, float fg_shift, void* out,
                                     uint8_t* slot_argmax, int T, int L, int HW, int D, int flags,
@@ -556,6 +779,22 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
                       getenv("SVPS_K2_LEGACY") == nullptr;
     if (!out) {                                          // argmax-only mode: the fast kernel without its logit stores
         if ((flags & SVPS_FLAG_OUT_BF16) || getenv("SVPS_K2_LEGACY")) return SVPS_ERR_BAD_ARG;
+#ifdef SVPS_K2_ABLATE
+        if (const char* ae = getenv("SVPS_K2_ABLATE"); ae && L <= 128) {
+#define SVPS_K2A(N) case N: ea = launch_decode_v2<true, 4, false, N>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, nullptr, slot_argmax, T, L, HW, stream); break;
+            hipError_t ea = hipErrorUnknown;
+            switch (atoi(ae)) {
+                SVPS_K2A(1) SVPS_K2A(2) SVPS_K2A(4) SVPS_K2A(5) SVPS_K2A(6) SVPS_K2A(8) SVPS_K2A(14) SVPS_K2A(32)
+                case 16: ea = launch_decode_v2<true, 4, false, 0, 3>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, nullptr, slot_argmax, T, L, HW, stream); break;
+                default: break;
+            }
+#undef SVPS_K2A
+            if (ea != hipErrorUnknown) {
+                svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
+                return (int)ea;
+            }
+        }
+#endif
         hipError_t e0 = L <= 128 ? launch_decode_v2<true, 4, false>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, nullptr, slot_argmax, T, L, HW, stream)
                                  : launch_decode_v2<true, 8, false>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, nullptr, slot_argmax, T, L, HW, stream);
         svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
