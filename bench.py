@@ -298,8 +298,8 @@ def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, prec
     r1.head.set_retriever(a.retriever)
     if precision == "fp32":
         r1.head.set_precision("fp32")
-    elif precision == "tight":
-        r1.head.set_statistics("tight")
+    elif precision in ("tight", "balanced"):
+        r1.head.set_statistics(precision)
     r1.load_clip(r1.random_clip(7))
     for _ in range(2):
         r1.run()
@@ -647,6 +647,15 @@ def main():
                 line["precision_form"] = tl
             except Exception as e:
                 line["precision_form"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+        if world == 1 and a.exact_leg and a.slots <= 128:
+            try:
+                bl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, precision="balanced")
+                bl["what"] = ("head.set_statistics('balanced'): the default statistics kernels, P * rstd_v as fp16 hi + lo and the query side in "
+                              "fp32 GEMMs - 2.4e-4 against the float64 evaluation of the reference's retriever on the same bf16 map "
+                              "(tests/test_retr_fused_gpu.py::test_tight_precision_form); same step, hipGraph")
+                line["balanced_form"] = bl
+            except Exception as e:
+                line["balanced_form"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and a.exact_leg:
             note("exact-mode leg (fp32 storage and arithmetic, one clip per launch) ...")
             try:

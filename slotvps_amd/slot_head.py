@@ -192,6 +192,10 @@ class MaskDynamicConv(nn.Module):
         # as fp16 hi + lo (csrc/retr_stats_t.hip) and P * rstd_v as fp16 hi + lo (retr_attn_kernel<.., PHL>): the error against float64
         # drops from the 1e-3 class to the 1e-4 class; the statistics cost ~2x, the retriever ~1.2x
         self.tight_stats = False
+        # the two cheap parts of the precision form on their own (head.set_statistics("balanced")): P * rstd_v as fp16 hi + lo and
+        # the query side in fp32, with the default statistics kernels (K3' / K3''): what is left is the fp16 rounding of the QR
+        # factors (rstd_v 7e-5, rstd_k 5e-5 relative) - 2e-4 ... 3e-4 against float64 for a few percent of the step
+        self.precise_query_p = False
 
     def _bf16_weights(self):
         """to_k / to_v weight matrices rounded to bf16 once (re-derived if the parameters change)."""
@@ -284,7 +288,7 @@ class MaskDynamicConv(nn.Module):
         # :431 q = norm_q(to_q(slots)); g = q * gamma_k (zero rows up to LP), c3 = q . beta_k, a1 = g . b~_k: one launch
         # precision form: the query side in the GEMM library's fp32 (the split-bf16 products of K8 / K9 carry 16-bit operands, ~1e-5
         # relative on Q'' - 5e-4 on the slot update through logits that are sums of 256 terms of magnitude ~5 with heavy cancellation)
-        tight = self.tight_stats
+        tight = self.tight_stats or self.precise_query_p
         xq = F.linear(slots, self.to_q.weight, self.to_q.bias) if tight else fast_linear(self, "to_q", slots, self.to_q.weight, self.to_q.bias)
         gp, c3, a1 = ops.retr_query_prep(xq.contiguous(), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps, self.norm_k.weight,
                                          self.norm_k.bias, c["bck"], LP)
@@ -303,7 +307,7 @@ class MaskDynamicConv(nn.Module):
         else:
             cy = a1[:, None, :].expand(T, H, LP).contiguous()
             cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
-        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W, tight=self.tight_stats)
+        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W, tight=tight)
         # :456 (value projection after the sum) + :458-459 (norm1, ReLU) in one launch
         return fast_linear_ln(self, "wext", ext, c["wext_lin"], None, self.norm1, relu=True)
 
@@ -669,12 +673,15 @@ class MultiScaleDynamicMaskHead(nn.Module):
         return self
 
     def set_statistics(self, mode):
-        """bf16 mode, fused retriever: "fast" (default: K3' / K3'', fp16 key factor) or "tight" (K3t, fp16 hi + lo key factor)."""
-        if mode not in ("fast", "tight"):
-            raise ValueError(f"statistics must be 'fast' or 'tight', not {mode!r}")
+        """bf16 mode, fused retriever. "fast" (default): K3' / K3'' statistics from fp16 QR factors, P * rstd_v as one fp16, query side on
+        K8 / K9 (1e-3 class against float64). "balanced": the same statistics, P * rstd_v as fp16 hi + lo and the query side in fp32
+        (2e-4 ... 3e-4). "tight": K3t statistics from fp16 hi + lo factors on top of that (<= 1.3e-4)."""
+        if mode not in ("fast", "balanced", "tight"):
+            raise ValueError(f"statistics must be 'fast', 'balanced' or 'tight', not {mode!r}")
         for m in self.modules():
             if hasattr(m, "tight_stats"):
                 m.tight_stats = mode == "tight"
+                m.precise_query_p = mode == "balanced"
         return self
 
     def set_retriever(self, form):

@@ -233,7 +233,8 @@ def test_tight_precision_form(cuda):
     """The precision form of the fused retriever (MaskDynamicConv.tight_stats; csrc/retr_stats_t.hip + retr_attn_kernel<.., PHL>):
     both QR factors of the statistics as fp16 hi + lo, P * rstd_v as fp16 hi + lo. rstd_k / rstd_v against a float64 evaluation of the
     reference's LayerNorm statistics: <= 1e-6 relative (fp16 factors of K3': ~3e-5 / ~7e-5); the fused retriever against the float64
-    oracle on the same bf16 map: <= 2e-4 (fast form: <= 2e-3, measured 1.0e-3 ... 1.3e-3)."""
+    oracle on the same bf16 map: <= 2e-4 (fast form: <= 2e-3, measured 1.0e-3 ... 1.7e-3). The "balanced" form in between
+    (MaskDynamicConv.precise_query_p: default statistics kernels, hi + lo probabilities, fp32 query side): <= 3e-4, measured 2.4e-4."""
     import torch
     from slotvps_amd import ops
     from slotvps_amd.slot_head import MaskDynamicConv
@@ -282,17 +283,19 @@ def test_tight_precision_form(cuda):
                                    ("rstd_v fast", rv_f[t], ref_v)):
                 worst[name] = max(worst.get(name, 0), float(np.abs(got / ref - 1).max()))
         with torch.no_grad():
-            for mode in (True, False):
-                m.tight_stats = mode
+            for mode in ("tight", "balanced", "fast"):
+                m.tight_stats = mode == "tight"
+                m.precise_query_p = mode == "balanced"
                 got = m.forward_fused(torch.from_numpy(slots).to(cuda), ft, (H, W), tabs).cpu().numpy()
-                key = "retriever tight" if mode else "retriever fast"
+                key = "retriever " + mode
                 for t in range(2):
                     ref = orc.retriever(slots[t], feat[t], orc.pos_embed_sine(H, W), P, "", st=orc.Storage.exact(), dt=np.float64)
                     err = float(np.abs(got[t] - ref).max())
                     print(f"  [{H}x{W} L={L} frame {t}] {key}: {err:.2e}")
                     worst[key] = max(worst.get(key, 0), err)
-            m.tight_stats = False
+            m.tight_stats = m.precise_query_p = False
     print("\n[precision form] " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
     assert worst["rstd_k tight"] <= 1e-6 and worst["rstd_v tight"] <= 1e-6, worst
     assert worst["retriever tight"] <= 2e-4, worst
+    assert worst["retriever balanced"] <= 3e-4, worst          # measured 2.4e-4: what the fp16 QR factors of K3' / K3'' leave (rstd_v 7e-5 relative)
     assert worst["retriever fast"] <= 2e-3, worst
