@@ -75,6 +75,10 @@ def _run(cuda, T, L, HW, seed, default_bn):
     (20, 100, 6144, False),    # several tiles per workgroup (counted DMA / store ring, deferred argmax), fast path
     (20, 100, 6148, False),    # the same with a ragged last tile
     (3, 100, 2050, False),     # HW % 4 != 0: scalar-store kernel
+    (40, 100, 768, False),     # two tiles per workgroup: shorter than the DMA ring's prologue (skewed loop: first + last iteration only)
+    (40, 100, 1152, True),     # three tiles per workgroup
+    (40, 100, 1540, False),    # five tiles per workgroup, last chunk short and ragged
+    (24, 200, 1540, False),    # the same for the 8-wave form
 ])
 def test_mask_decode_matches_oracle(cuda, T, L, HW, default_bn):
     worst = _run(cuda, T, L, HW, seed=L + HW, default_bn=default_bn)
