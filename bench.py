@@ -521,6 +521,15 @@ def main():
                 if "executed_flops" in alg[name]:           # informational: matrix work actually issued (operand splits included)
                     e["mfma_frac_executed"] = round(alg[name]["executed_flops"] * nsteps / sec / 1e12 / MFMA_PEAK_TFLOPS, 4)
             per[name] = e
+        # the matrix pipe's SUSTAINED rate on this part (a stored probe result, like the PMC traffic): executed matrix work against it
+        sustain = None
+        sfile = os.path.join(ROOT, "profiles", "r03", "mfma_sustain.json")
+        if os.path.exists(sfile):
+            with open(sfile) as fh:
+                sustain = json.load(fh)
+            for e in per.values():
+                if "mfma_frac_executed" in e:
+                    e["mfma_frac_executed_of_sustained"] = round(e["mfma_frac_executed"] * MFMA_PEAK_TFLOPS / sustain["register_operands"]["tflops"], 4)
         dom = max((k for k in per if k in alg), key=lambda k: timed[k][0])
         d = per[dom]
         hbm = d["bound"] == "hbm"
@@ -582,6 +591,11 @@ def main():
                                         "what": "1 GiB device-to-device, bytes read + written: torch copy / the library's 16-B-per-lane streaming kernel; "
                                                 "svps_probe_mix: level_fuse's 640 B in : 512 B out mix without its arithmetic, and the one-way streams"},
                 "per_kernel": per}
+        if sustain is not None:
+            roof["matrix_pipe_sustained"] = {"tflops": sustain["register_operands"]["tflops"],
+                                             "clock_mhz_under_load": sustain["register_operands"]["clock_mhz_under_load"],
+                                             "source": "profiles/r03/mfma_sustain.json (tools/mfma_sustain_probe.py): 32.0 cycles per v_mfma_f32_32x32x16_f16 at the "
+                                                       "clock a dense MFMA stream is given; `peak` above stays the guide's 2.5 PFLOP/s at 2.4 GHz"}
         pair = [k for k in ("retr_stats", "retr_attn") if k in per] or [k for k in ("kv_project", "slot_attn") if k in per]
         if len(pair) == 2:                              # the retriever as a pair (the yardstick of VERDICT r01 item 1b)
             ms = sum(timed[k][0] for k in pair)

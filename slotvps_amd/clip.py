@@ -168,7 +168,9 @@ class SlotClipRunner:
         stages = sum(n for _, n in self.k1_launch_shapes())
         out = {
             "level_fuse": {"bytes": T * sum(hw * (1024 + (128 if i else 0)) for i, hw in enumerate(px)), "flops": T * sum(px) * 2 * 384 * D},
-            "mask_decode": {"bytes": T * px[-1] * (512 + (4 * L if self.decode_logits else 0) + 1), "flops": T * px[-1] * 2 * L * D},
+            # executed: 32 MFMA 32x32x16 per 32-pixel tile and wave (e as bf16 hi + lo), 4 waves (8 for more than 128 slots)
+            "mask_decode": {"bytes": T * px[-1] * (512 + (4 * L if self.decode_logits else 0) + 1), "flops": T * px[-1] * 2 * L * D,
+                            "executed_flops": T * px[-1] * ((4 if L <= 128 else 8) * 32 * 32768 // 32)},
         }
         if self.retriever_form == "fused":
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
@@ -179,7 +181,8 @@ class SlotClipRunner:
                 sbytes = T * sum(hw * (512 + 16 * n) if n == 2 else n * hw * (512 + 16) for hw, n in self.k1_launch_shapes())
             else:
                 sbytes = T * ps * (512 + 16)
-            out["retr_stats"] = {"bytes": sbytes, "flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}
+            out["retr_stats"] = {"bytes": sbytes, "flops": T * ps * int(2 * 36 / 64 * 2 * D * D),
+                                 "executed_flops": T * ps * int(2 * 36 / 64 * 2 * D * D)}     # the triangular products are all it executes
             # executed matrix work of K1' per pixel (informational): (4 x 32 producer + 4 x 18 consumer) MFMA 32x32x16 per 32-pixel
             # tile - Q'' is carried as fp16 hi + lo. K1' stages the 16-byte aux row with every pixel. More than 128 slots (two
             # passes, the probabilities of 256 slot rows through HBM): pass 1 reads map + aux and writes 512 B of P per pixel,
