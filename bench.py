@@ -625,7 +625,8 @@ def main():
                        "per_rank_ms_per_step": [round(float(x[0]), 3) for x in per_rank_ms] if per_rank_ms is not None else None,
                        "gather_ok": gather_ok, "gathered_payloads": rank_sums, "host_cpu_binding_rank0": binding,
                        "gather": f"per step, {gatherers[0].bytes_per_submit} B per rank to rank 0, async on a side stream (RCCL)" if world > 1 else "none (one rank)",
-                       "hipgraph": not a.no_graph, "clips_in_flight": cif, "clips_per_launch": cpl,
+                       "hipgraph": not a.no_graph, "graph_validation_repeats": len(runner.validation_reports),
+                       "clips_in_flight": cif, "clips_per_launch": cpl,
                        "retriever": runner.retriever_form},
             "roofline": roof,
         }
