@@ -42,7 +42,7 @@ def build_head(cuda, params):
     return head.to(cuda).eval()
 
 
-@pytest.mark.parametrize("form", ["fused", "kv"])
+@pytest.mark.parametrize("form", ["fused", "kv", "balanced"])
 @pytest.mark.parametrize("tag", ["T2_64x128", "T3_64x64"])
 def test_head_matches_oracle_and_reference(cuda, tag, form):
     import torch
@@ -54,7 +54,12 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     feats = synth.make_clip_features(seed + 1, T, H, W)
     slots = synth.make_slots(seed + 2, L)
     sizes = synth.level_sizes(H, W)
+    balanced = form == "balanced"                   # the fused retriever with hi + lo probabilities and an fp32 query side
+    if balanced:
+        form = "fused"
     head = build_head(cuda, params).set_retriever(form)
+    if balanced:
+        head.set_statistics("balanced")
     with torch.no_grad():
         tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
         pos_tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in sizes]
@@ -99,7 +104,12 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     # Per-stage bound on identical inputs, slot embeddings are O(1). kv form: bf16 rounding flips of single q / k / v
     # elements seen through one sharp softmax (measured <= 9e-3). fused form: nothing is rounded as a tensor; what is left
     # are the 16-bit splits of Q'' and P and the fp16 statistics (measured <= 2e-3).
-    bound = 4e-3 if form == "fused" else 2e-2
+    # balanced form: the probability split and the query-side products are out of the budget - the early stages (coarse levels) improve
+    # 2 - 5x (measured 6.7e-5 1.7e-4 1.7e-4 4.1e-4 ... against 3.7e-4 3.5e-4 8.0e-4 4.0e-4), the late ones are the slot side's own
+    # split-bf16 layers in either form (1.2e-3 at stage 6)
+    bound = (2e-3 if balanced else 4e-3) if form == "fused" else 2e-2
+    if balanced:
+        assert stage_err[0] <= 2e-4 and max(stage_err[:3]) <= 4e-4, stage_err
     assert max(stage_err) <= bound and max(logit_err) <= bound, (stage_err, logit_err)
     assert free[0] <= 5e-3 and free_mean <= 5e-2
 
