@@ -117,6 +117,15 @@ __device__ __forceinline__ bf16x8 read_col_frag(const char* lds_tile, int ks, in
 __device__ __forceinline__ float wave_half_xor_max(float x) { return fmaxf(x, __shfl_xor(x, 32)); }
 __device__ __forceinline__ float wave_half_xor_sum(float x) { return x + __shfl_xor(x, 32); }
 
+// The probabilities of the fused retriever travel as fp16 (P * rstd_v, csrc/retr_attn.hip): below 6.1e-5 fp16 is subnormal, below
+// 6e-8 zero - a slot that owns almost no pixel (P ~ 1e-7 everywhere; common once the softmax over slots is sharp) lost its whole
+// contribution, and norm1 behind the retriever scales such a row up by up to 1 / sqrt(eps). The kernels therefore carry
+// 2^7 * P * rstd_v (exact: a power of two) and retr_finish_kernel takes the factor out again: seven more binades at the bottom.
+// Upper end: P <= 1 and rstd_v <= 1 / sqrt(eps_v), so 2^7 * P * rstd_v <= 40 477 < 65 504 for eps_v >= 1e-5 (the host side refuses
+// eps_v < 4e-6, slot_head.MaskDynamicConv.forward_fused).
+constexpr float kPScale = 128.f;
+constexpr float kPScaleInv = 1.f / 128.f;
+
 // row (slot) index of accumulator register `reg` inside a 32 x 32 C/D tile
 __device__ __forceinline__ constexpr int acc_row(int reg, int h) {
     return (reg & 3) + 8 * (reg >> 2) + 4 * h;

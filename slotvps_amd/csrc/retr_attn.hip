@@ -321,7 +321,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             };
             f32x16 s = cinit;
             f32x4 c3v[4];
-            const float rk_c = rt[0] * kLog2e, tau_c = rt[1];
+            const float rk_c = rt[0] * kLog2e, tau_c = rt[1] * kPScale;      // common.h: the probabilities carry 2^7
             if constexpr (CHAIN) {
                 // row fragments in groups of four, double-buffered: the reads of group g + 1 (after the last group: the c3 terms)
                 // and a part of the softmax finish of tile it-1 run in the shadow of the 8 MFMAs of group g
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(512) void retr_probs_kernel(
         if (h == 0) stats[((it & 1) * 8 + w) * 32 + r] = make_float2(mloc, sloc);
         e = s;
         mloc_p = mloc;
-        tau_p = rt[1];
+        tau_p = rt[1] * kPScale;
         live_p = kTilePx * ts + r < W;
         // tile it+1: this wave's pieces landed -> fp16. Younger operations than its batch: the batches it+2 .. it+A+1 and the
         // two stores of finish() of each iteration in between
@@ -1292,11 +1292,11 @@ __global__ __launch_bounds__(256) void retr_finish_kernel(const float* __restric
         return ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     };
     float* o = out + ((size_t)t * L + l) * kExtRow;
-    o[d] = colsum(d);
+    o[d] = colsum(d) * kPScaleInv;                           // the probabilities carried 2^7 (common.h)
     if (d < kExtRow - 256) {
         float v = 0.f;
-        if (d == 0) v = colsum(256);                         // s1 = sum_p P rstd_v
-        else if (d == 1) v = colsum(257) + colsum(258);      // s0 = sum_p P  (sigma_v carried as hi + lo)
+        if (d == 0) v = colsum(256) * kPScaleInv;                         // s1 = sum_p P rstd_v
+        else if (d == 1) v = (colsum(257) + colsum(258)) * kPScaleInv;    // s0 = sum_p P  (sigma_v carried as hi + lo)
         o[256 + d] = v;
     }
 }

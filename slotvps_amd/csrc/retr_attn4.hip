@@ -452,7 +452,7 @@ __device__ __forceinline__ void role(const Args& A) {
         R4_STAMP_AT(2);
 
         // ================= phase 2: P.f(it-1) || head(it) ===================================================================
-        const float rk_c = rt[0] * kLog2e, tau_c = rt[1];
+        const float rk_c = rt[0] * kLog2e, tau_c = rt[1] * kPScale;          // common.h: the probabilities carry 2^7
         float mloc = kNegBig, sloc = 0.f;
         f32x4 c3v[4];
 #pragma unroll
@@ -632,11 +632,11 @@ __global__ __launch_bounds__(256) void retr_finish4_kernel(const float* __restri
         return ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     };
     float* o = out + ((size_t)t * L + l) * kExtRow;
-    o[d] = colsum(d);
+    o[d] = colsum(d) * kPScaleInv;                           // the probabilities carried 2^7 (common.h)
     if (d < kExtRow - 256) {
         float v = 0.f;
-        if (d == 0) v = colsum(256);                         // s1 = sum_p P rstd_v
-        else if (d == 1) v = colsum(257) + colsum(258);      // s0 = sum_p P  (sigma_v carried as hi + lo)
+        if (d == 0) v = colsum(256) * kPScaleInv;                         // s1 = sum_p P rstd_v
+        else if (d == 1) v = (colsum(257) + colsum(258)) * kPScaleInv;    // s0 = sum_p P  (sigma_v carried as hi + lo)
         o[256 + d] = v;
     }
 }

@@ -272,6 +272,10 @@ class MaskDynamicConv(nn.Module):
         c = self._fused_consts()
         T, L, C = slots.shape
         H, W = hw
+        if self.norm_v.eps < 4e-6:
+            # the kernels carry 2^7 * P * rstd_v as fp16 (csrc/common.h, kPScale): rstd_v <= 1 / sqrt(eps_v) must stay below 511
+            raise ValueError(f"fused retriever: norm_v.eps = {self.norm_v.eps} < 4e-6 is outside the fp16 range of the probabilities; "
+                             "use set_retriever('kv') or set_precision('fp32')")
         if stats is None:
             # statistics already computed for this map by the level pass (MultiScaleDynamicMaskHead.forward_clip)?
             pending = getattr(self, "_level_stats", None)

@@ -60,6 +60,23 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     head = build_head(cuda, params).set_retriever(form)
     if balanced:
         head.set_statistics("balanced")
+    if os.environ.get("SVPS_TEST_SLOT_GEMM") == "0":          # experiment switches: the slot side's dense layers in library fp32,
+        head.set_slot_gemm(False)
+    if os.environ.get("SVPS_TEST_STATS"):                     # another statistics mode
+        head.set_statistics(os.environ["SVPS_TEST_STATS"])
+    if os.environ.get("SVPS_TEST_BGEMM") == "torch":          # K9 replaced by float64 matmuls (which layer limits a stage's parity?)
+        def _bg(a_, b_, bias=None, alpha=1.0, out=None):
+            a3 = a_ if a_.dim() == 3 else a_.unsqueeze(0)
+            b3 = b_ if b_.dim() == 3 else b_.unsqueeze(0)
+            r = alpha * torch.matmul(a3.double(), b3.double().transpose(1, 2))
+            if bias is not None:
+                r = r + (bias if bias.dim() == 2 else bias.unsqueeze(0)).double()[:, None, :]
+            r = r.float()
+            if out is not None:
+                out.copy_(r)
+                return out
+            return r
+        ops.bgemm = _bg
     with torch.no_grad():
         tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
         pos_tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in sizes]
@@ -89,8 +106,9 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     for lvl, n in enumerate(cfg["per_level_stages"]):
         for j in range(n):
             s_in = [slots.astype(np.float32)] * T if sidx == 0 else [embeds[sidx - 1, t] for t in range(T)]
+            # float64: a float32 evaluation of the same stage is itself 1e-4 ... 1e-3 away at the fine levels (sharp softmax over 8192 pixels)
             lg, em = orc.stage(s_in, [g_fused[t][lvl] for t in range(T)], [pos[lvl]] * T, params,
-                               f"head_series_{lvl}.{j}.", sidx in cfg["temporal_stages"], cfg, st)
+                               f"head_series_{lvl}.{j}.", sidx in cfg["temporal_stages"], cfg, st, dt=np.float64)
             stage_err.append(max(np.abs(embeds[sidx, t] - em[t]).max() for t in range(T)))
             logit_err.append(max(np.abs(logits[sidx, t] - lg[t]).max() for t in range(T)))
             sidx += 1
@@ -104,12 +122,10 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     # Per-stage bound on identical inputs, slot embeddings are O(1). kv form: bf16 rounding flips of single q / k / v
     # elements seen through one sharp softmax (measured <= 9e-3). fused form: nothing is rounded as a tensor; what is left
     # are the 16-bit splits of Q'' and P and the fp16 statistics (measured <= 2e-3).
-    # balanced form: the probability split and the query-side products are out of the budget - the early stages (coarse levels) improve
-    # 2 - 5x (measured 6.7e-5 1.7e-4 1.7e-4 4.1e-4 ... against 3.7e-4 3.5e-4 8.0e-4 4.0e-4), the late ones are the slot side's own
-    # split-bf16 layers in either form (1.2e-3 at stage 6)
-    bound = (2e-3 if balanced else 4e-3) if form == "fused" else 2e-2
-    if balanced:
-        assert stage_err[0] <= 2e-4 and max(stage_err[:3]) <= 4e-4, stage_err
+    # Since the probabilities travel as 2^7 * P * rstd_v (csrc/common.h: slots that own almost no pixel no longer fall into fp16's
+    # subnormal range) the whole stage measures 2.2e-4 ... 9.6e-4 in the default form (1.2e-3 before, growing with the level) and
+    # 4e-5 ... 2.7e-4 in the balanced form (probability split and query-side products out of the budget; 1.2e-3 before).
+    bound = (5e-4 if balanced else 2e-3) if form == "fused" else 2e-2
     assert max(stage_err) <= bound and max(logit_err) <= bound, (stage_err, logit_err)
     assert free[0] <= 5e-3 and free_mean <= 5e-2
 
@@ -263,7 +279,7 @@ def test_head_variants_per_stage_parity(cuda, name):
             errs.append(max(max(np.abs(embeds[sidx, t] - em[t]).max(), np.abs(logits[sidx, t] - lg[t]).max()) for t in range(T)))
             sidx += 1
     print(f"\n[{name}] fused {f_err:.2e} | per-stage (identical inputs) " + " ".join(f"{e:.1e}" for e in errs))
-    assert max(errs) <= 2e-2, errs                                 # same bound as the R50 case above
+    assert max(errs) <= 4e-3, errs                                 # fused form (default): measured <= 9.6e-4 (Swin-L head), <= 4.8e-4 (VIPER geometry)
 
 
 def test_stacked_clips_equal_separate_clips(cuda):

@@ -296,6 +296,6 @@ def test_tight_precision_form(cuda):
             m.tight_stats = m.precise_query_p = False
     print("\n[precision form] " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
     assert worst["rstd_k tight"] <= 1e-6 and worst["rstd_v tight"] <= 1e-6, worst
-    assert worst["retriever tight"] <= 2e-4, worst
-    assert worst["retriever balanced"] <= 3e-4, worst          # measured 2.4e-4: what the fp16 QR factors of K3' / K3'' leave (rstd_v 7e-5 relative)
+    assert worst["retriever tight"] <= 1.5e-4, worst           # measured 8.2e-5 (1.27e-4 before the probabilities carried 2^7)
+    assert worst["retriever balanced"] <= 3e-4, worst          # measured 2.0e-4: what the fp16 QR factors of K3' / K3'' leave (rstd_v 7e-5 relative)
     assert worst["retriever fast"] <= 2e-3, worst
