@@ -212,6 +212,10 @@ int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, 
  *   bias [N] fp32 or NULL; act 0 none / 1 ReLU / 2 GELU (erf form); y [M, N] fp32.  K % 16 == 0, N % 256 == 0.
  * ------------------------------------------------------------------------------------------- */
 int svps_slot_gemm(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, int act, void* stream);
+/* The same product with both operands split into fp16 hi + lo (22 bits of mantissa for the same three MFMAs; |x|, |w| < 65 504):
+ * the query side of the fused retriever, MaskDynamicConv.forward's to_q (dynamic_mask_head.py:431) and the folded key projection.
+ * wpack: fp16 fragments (pack_b_fragments(weight, split="fp16")). No activation. */
+int svps_slot_gemm_f16(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, void* stream);
 /* the same product for N = 256 with the step that follows most dense layers of the slot update fused into the launch
  * (dynamic_mask_head.py:356-358, :374-376, :384-385, :394-397, :458-459, :515-525):
  *     y = LN(x W^T + bias [+ pre]) * gamma + beta  (+ReLU if relu)  (+ post)
@@ -248,6 +252,10 @@ int svps_slot_chain(const float* x, int M, int n_layers, const void* const* wpac
  * ------------------------------------------------------------------------------------------- */
 int svps_bgemm(const float* a, const long long* sa, const float* b, const long long* sb, const float* bias,
                const long long* sbias, float* c, const long long* sc, int batch, int M, int N, int K, float alpha, void* stream);
+/* The same product with both operands split into fp16 hi + lo (22 bits of mantissa, |a|, |b| < 65 504): the separable position terms
+ * Cy, Cx of the fused retriever (sine tables x folded queries), which end up inside logits that cancel. */
+int svps_bgemm_f16(const float* a, const long long* sa, const float* b, const long long* sb, const float* bias,
+                   const long long* sbias, float* c, const long long* sc, int batch, int M, int N, int K, float alpha, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6 full-resolution panoptic post-process (PostProcessPanopticInstances.mask_removal / get_ids_area,

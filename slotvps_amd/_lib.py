@@ -56,6 +56,7 @@ SIGNATURES = {
     "svps_slot_chain": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svps_slot_ffn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _vp]),
     "svps_bgemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "svps_bgemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "svps_retr_stats_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "svps_retr_stats_level_fwd": (_i, [_vp, _i] + [_vp] * 9 + [_i, _i, _i, _i, _vp]),
     "svps_retr_stats_tight_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "svps_mask_decode_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _i, _i, _i, _vp]),
     "svps_deform_conv_fused_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "svps_slot_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "svps_slot_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

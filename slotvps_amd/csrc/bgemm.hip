@@ -39,7 +39,13 @@ struct BgArgs {
     float alpha;
 };
 
+// ST: the 16-bit type both operands are split into, hi + lo: __bf16 (16 bits of mantissa, fp32's range) or _Float16 (22 bits; |x| <
+// 65 504, absolute resolution 6e-8 below 6.1e-5: svps_bgemm_f16, the position terms of the fused retriever)
+template <typename ST>
 __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs g) {
+    typedef ST st_x8 __attribute__((ext_vector_type(8)));
+    typedef ST st_x4 __attribute__((ext_vector_type(4)));
+    typedef ST st_x2 __attribute__((ext_vector_type(2)));
     // [buffer][operand A / B][hi / lo][64 rows][80 B]
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 2 * kBgTile * kBgRow];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,10 +74,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs g) {
         for (int i = 0; i < 8; ++i) {
             const int e = tid + 256 * i;
             const int row = kc ? (e >> 5) : (e & 63), k = kc ? (e & 31) : (e >> 6);
-            const __bf16 hi = (__bf16)v[i];
-            const __bf16 lo = (__bf16)(v[i] - (float)hi);
-            *reinterpret_cast<__bf16*>(base + row * kBgRow + k * 2) = hi;
-            *reinterpret_cast<__bf16*>(base + kBgTile * kBgRow + row * kBgRow + k * 2) = lo;
+            const ST hi = (ST)v[i];
+            const ST lo = (ST)(v[i] - (float)hi);
+            *reinterpret_cast<ST*>(base + row * kBgRow + k * 2) = hi;
+            *reinterpret_cast<ST*>(base + kBgTile * kBgRow + row * kBgRow + k * 2) = lo;
         }
     };
 
@@ -116,22 +122,21 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs g) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int e = tid + 256 * i, row = e >> 3, k = 4 * (e & 7);
-                bf16x4 hi, lo;
+                st_x4 hi, lo;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[4 * i + j]; lo[j] = (__bf16)(v[4 * i + j] - (float)hi[j]); }
-                *reinterpret_cast<bf16x4*>(base + row * kBgRow + k * 2) = hi;
-                *reinterpret_cast<bf16x4*>(base + kBgTile * kBgRow + row * kBgRow + k * 2) = lo;
+                for (int j = 0; j < 4; ++j) { hi[j] = (ST)v[4 * i + j]; lo[j] = (ST)(v[4 * i + j] - (float)hi[j]); }
+                *reinterpret_cast<st_x4*>(base + row * kBgRow + k * 2) = hi;
+                *reinterpret_cast<st_x4*>(base + kBgTile * kBgRow + row * kBgRow + k * 2) = lo;
             }
         } else {
             const int kq = tid >> 4, rq = tid & 15;
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                            // row 4 rq + j: the pair (k = 2 kq, 2 kq + 1) as one 4-byte store
-                bf16x2_t hi, lo;
+                st_x2 hi, lo;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { hi[i] = (__bf16)v[4 * i + j]; lo[i] = (__bf16)(v[4 * i + j] - (float)hi[i]); }
-                *reinterpret_cast<bf16x2_t*>(base + (4 * rq + j) * kBgRow + (2 * kq) * 2) = hi;
-                *reinterpret_cast<bf16x2_t*>(base + kBgTile * kBgRow + (4 * rq + j) * kBgRow + (2 * kq) * 2) = lo;
+                for (int i = 0; i < 2; ++i) { hi[i] = (ST)v[4 * i + j]; lo[i] = (ST)(v[4 * i + j] - (float)hi[i]); }
+                *reinterpret_cast<st_x2*>(base + (4 * rq + j) * kBgRow + (2 * kq) * 2) = hi;
+                *reinterpret_cast<st_x2*>(base + kBgTile * kBgRow + (4 * rq + j) * kBgRow + (2 * kq) * 2) = lo;
             }
         }
     };
@@ -159,13 +164,19 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs g) {
         const char* bh = smem + ((buf * 2 + 1) * 2) * kBgTile * kBgRow + (32 * wn + r) * kBgRow + 16 * h;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + 32 * u);
-            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(ah + kBgTile * kBgRow + 32 * u);
-            const bf16x8 yh = *reinterpret_cast<const bf16x8*>(bh + 32 * u);
-            const bf16x8 yl = *reinterpret_cast<const bf16x8*>(bh + kBgTile * kBgRow + 32 * u);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+            const st_x8 xh = *reinterpret_cast<const st_x8*>(ah + 32 * u);
+            const st_x8 xl = *reinterpret_cast<const st_x8*>(ah + kBgTile * kBgRow + 32 * u);
+            const st_x8 yh = *reinterpret_cast<const st_x8*>(bh + 32 * u);
+            const st_x8 yl = *reinterpret_cast<const st_x8*>(bh + kBgTile * kBgRow + 32 * u);
+            if constexpr (sizeof(ST) == 2 && __is_same(ST, _Float16)) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc, 0, 0, 0);
+            }
         }
         if (ch + 1 < nch) {
             put_a(buf ^ 1, av);
@@ -189,9 +200,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BgArgs g) {
 
 }  // namespace svps
 
-extern "C" int svps_bgemm(const float* a, const long long* sa, const float* b, const long long* sb, const float* bias,
-                          const long long* sbias, float* c, const long long* sc, int batch, int M, int N, int K, float alpha,
-                          void* stream_) {
+namespace {
+template <typename ST>
+int bgemm_launch(const float* a, const long long* sa, const float* b, const long long* sb, const float* bias,
+                 const long long* sbias, float* c, const long long* sc, int batch, int M, int N, int K, float alpha,
+                 void* stream_) {
     if (!a || !b || !c || !sa || !sb || !sc || (bias && !sbias)) return SVPS_ERR_BAD_ARG;
     if (batch <= 0 || M <= 0 || N <= 0 || K <= 0 || batch > 65535) return SVPS_ERR_BAD_SHAPE;
     svps::BgArgs g;
@@ -203,6 +216,19 @@ extern "C" int svps_bgemm(const float* a, const long long* sa, const float* b, c
     g.M = M; g.N = N; g.K = K; g.alpha = alpha;
     const dim3 grid((M + svps::kBgTile - 1) / svps::kBgTile, (N + svps::kBgTile - 1) / svps::kBgTile, batch);
     if (grid.y > 65535) return SVPS_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(svps::bgemm_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), g);
+    hipLaunchKernelGGL(svps::bgemm_kernel<ST>, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), g);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int svps_bgemm(const float* a, const long long* sa, const float* b, const long long* sb, const float* bias,
+                          const long long* sbias, float* c, const long long* sc, int batch, int M, int N, int K, float alpha,
+                          void* stream_) {
+    return bgemm_launch<__bf16>(a, sa, b, sb, bias, sbias, c, sc, batch, M, N, K, alpha, stream_);
+}
+
+extern "C" int svps_bgemm_f16(const float* a, const long long* sa, const float* b, const long long* sb, const float* bias,
+                              const long long* sbias, float* c, const long long* sc, int batch, int M, int N, int K, float alpha,
+                              void* stream_) {
+    return bgemm_launch<_Float16>(a, sa, b, sb, bias, sbias, c, sc, batch, M, N, K, alpha, stream_);
 }

@@ -55,7 +55,13 @@ __device__ __forceinline__ float gm_wave_sum(float x) {
 // ACT: 0 none, 1 ReLU, 2 GELU (erf); RBW: row blocks per workgroup (2 or 1); PREF: weights of the next chunk requested before
 // this chunk's MFMAs (register double buffer, 192 registers: one workgroup per CU - for launches that do not fill the chip
 // several times over; wide layers run several 110-register workgroups per CU instead, which hide the latency by themselves)
-template <int ACT, int RBW, bool PREF, bool LN = false>
+// F16: both operands split into fp16 hi + lo instead of bf16 hi + lo (22 instead of 16 bits of mantissa for the same three MFMAs;
+// fp16's range: |x| < 65 504, absolute resolution 6e-8 below 6.1e-5) - the query side of the fused retriever (to_q, the key fold),
+// whose operands are LayerNorm outputs and O(0.1) weights and whose result goes through logits that cancel (svps_slot_gemm_f16)
+typedef __attribute__((ext_vector_type(8))) _Float16 gm_f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 gm_f16x4;
+
+template <int ACT, int RBW, bool PREF, bool LN = false, bool F16 = false>
 __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict__ x,        // [M, K]
                                                         const __bf16* __restrict__ wpack,   // [N/32][K/16][2][64][8]
                                                         const float* __restrict__ bias,     // [N] or null
@@ -84,14 +90,25 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < RBW; ++i) {
             const int q = tid + 512 * i, row = q >> 4, kg = (q & 15) * 4;
-            bf16x4 vh, vl;
+            if constexpr (F16) {
+                gm_f16x4 vh, vl;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vh[e] = (__bf16)av[i][e];
-                vl[e] = (__bf16)(av[i][e] - (float)vh[e]);
+                for (int e = 0; e < 4; ++e) {
+                    vh[e] = (_Float16)av[i][e];
+                    vl[e] = (_Float16)(av[i][e] - (float)vh[e]);
+                }
+                *reinterpret_cast<gm_f16x4*>(bh + row * kGmRow + kg * 2) = vh;
+                *reinterpret_cast<gm_f16x4*>(bh + kGmRows * kGmRow + row * kGmRow + kg * 2) = vl;
+            } else {
+                bf16x4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vh[e] = (__bf16)av[i][e];
+                    vl[e] = (__bf16)(av[i][e] - (float)vh[e]);
+                }
+                *reinterpret_cast<bf16x4*>(bh + row * kGmRow + kg * 2) = vh;
+                *reinterpret_cast<bf16x4*>(bh + kGmRows * kGmRow + row * kGmRow + kg * 2) = vl;
             }
-            *reinterpret_cast<bf16x4*>(bh + row * kGmRow + kg * 2) = vh;
-            *reinterpret_cast<bf16x4*>(bh + kGmRows * kGmRow + row * kGmRow + kg * 2) = vl;
         }
     };
 
@@ -127,15 +144,28 @@ __global__ __launch_bounds__(512) void slot_gemm_kernel(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (u < nks) {
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + 32 * u);
-                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + 32 * u);
+                if constexpr (F16) {
+                    const gm_f16x8 xh = *reinterpret_cast<const gm_f16x8*>(ah + 32 * u);
+                    const gm_f16x8 xl = *reinterpret_cast<const gm_f16x8*>(al + 32 * u);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[2 * NB * u + 2 * b]);
-                    const bf16x8 wl = __builtin_bit_cast(bf16x8, wb[2 * NB * u + 2 * b + 1]);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[b], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b) {
+                        const gm_f16x8 wh = __builtin_bit_cast(gm_f16x8, wb[2 * NB * u + 2 * b]);
+                        const gm_f16x8 wl = __builtin_bit_cast(gm_f16x8, wb[2 * NB * u + 2 * b + 1]);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, wh, acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[b], 0, 0, 0);
+                    }
+                } else {
+                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + 32 * u);
+                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(al + 32 * u);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[2 * NB * u + 2 * b]);
+                        const bf16x8 wl = __builtin_bit_cast(bf16x8, wb[2 * NB * u + 2 * b + 1]);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[b], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -306,6 +336,20 @@ extern "C" int svps_slot_gemm(const float* x, const void* wpack, const float* bi
         if (act == 0) SVPS_GEMM(0, 2, false); else if (act == 1) SVPS_GEMM(1, 2, false); else SVPS_GEMM(2, 2, false);
     }
 #undef SVPS_GEMM
+    return (int)hipGetLastError();
+}
+
+extern "C" int svps_slot_gemm_f16(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, void* stream_) {
+    if (!x || !wpack || !y) return SVPS_ERR_BAD_ARG;
+    if (M <= 0 || K <= 0 || (K & 15) || N <= 0 || (N % svps::kGmCols)) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const __bf16* wp = static_cast<const __bf16*>(wpack);      // raw 16-bit words: fp16 hi / lo fragments (ops.pack_b_fragments(..., split="fp16"))
+    const int wg64 = ((M + 63) / 64) * (N / svps::kGmCols);
+    const bool small = wg64 < 2 * svps_num_cus();
+    const int rows = small ? 32 : 64;
+    const dim3 grid((M + rows - 1) / rows, N / svps::kGmCols);
+    if (small) hipLaunchKernelGGL((svps::slot_gemm_kernel<0, 1, true, false, true>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N);
+    else hipLaunchKernelGGL((svps::slot_gemm_kernel<0, 2, false, false, true>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N);
     return (int)hipGetLastError();
 }
 

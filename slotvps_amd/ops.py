@@ -486,15 +486,19 @@ def slot_self_attn(qkv, nheads):
     return out
 
 
-def pack_b_fragments(weight):
+def pack_b_fragments(weight, split="bf16"):
     """nn.Linear weight [N, K] fp32 -> bf16 [N/32, K/16, 2, 64, 8]: hi / lo halves in MFMA B-fragment order (the layout
-    svps_slot_gemm streams: one 1-KiB wave instruction per fragment). N % 32 == 0, K % 16 == 0."""
+    svps_slot_gemm streams: one 1-KiB wave instruction per fragment). N % 32 == 0, K % 16 == 0.
+    split="fp16": fp16 hi / lo halves (22 bits of mantissa; svps_slot_gemm_f16), |w| < 65 504."""
     N, K = weight.shape
     if N % 32 or K % 16:
         raise ValueError("pack_b_fragments: N % 32 == 0 and K % 16 == 0 required")
     w = weight.detach().float().contiguous()
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[split]
+    if split == "fp16" and float(w.abs().max()) >= 65504.0:
+        raise ValueError("pack_b_fragments(split='fp16'): weight outside the fp16 range")
+    hi = w.to(dt)
+    lo = (w - hi.float()).to(dt)
 
     def frag(m):                                   # (cb, r, ks, h, j) -> (cb, ks, h, r, j): lane = 32 h + r
         return m.view(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(N // 32, K // 16, 64, 8)
@@ -506,10 +510,14 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 def slot_gemm(x, wpack, bias=None, act=ACT_NONE, out=None):
     """K8: y = act(x @ W^T + bias) for x [..., K] fp32 and wpack = pack_b_fragments(W [N, K]); N % 256 == 0, K % 16 == 0.
-    Split-bf16 matrix-core products with fp32 accumulation (fp32-class; see csrc/slot_gemm.hip)."""
+    Split-bf16 matrix-core products with fp32 accumulation (fp32-class; see csrc/slot_gemm.hip). A weight packed with split="fp16"
+    runs the fp16 hi + lo form (no activation; operands within the fp16 range)."""
     lib = _lib.load()
     _need(x, "x", torch.float32)
-    _need(wpack, "wpack", torch.bfloat16, 5)
+    f16 = wpack.dtype == torch.float16
+    _need(wpack, "wpack", torch.float16 if f16 else torch.bfloat16, 5)
+    if f16 and act != ACT_NONE:
+        raise ValueError("slot_gemm: the fp16-split form has no activation")
     K = x.shape[-1]
     M = x.numel() // K
     N = wpack.shape[0] * 32
@@ -522,7 +530,10 @@ def slot_gemm(x, wpack, bias=None, act=ACT_NONE, out=None):
     elif out.shape != x.shape[:-1] + (N,) or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("slot_gemm: out must be a contiguous fp32 tensor of shape x.shape[:-1] + (N,)")
     with _on(x, wpack, bias, out) as ctx:
-        _lib.check(lib.svps_slot_gemm(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), M, K, N, int(act), ctx.stream), "svps_slot_gemm")
+        if f16:
+            _lib.check(lib.svps_slot_gemm_f16(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), M, K, N, ctx.stream), "svps_slot_gemm_f16")
+        else:
+            _lib.check(lib.svps_slot_gemm(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), M, K, N, int(act), ctx.stream), "svps_slot_gemm")
     return out
 
 
@@ -649,10 +660,11 @@ def slot_chain(x, layers):
     return outs
 
 
-def bgemm(a, b, bias=None, alpha=1.0, out=None):
+def bgemm(a, b, bias=None, alpha=1.0, out=None, split="bf16"):
     """K9: C[g, m, n] = alpha * sum_k a[g, m, k] b[g, n, k] (+ bias[g, n]) for fp32 tensors of ANY strides (views, transposes,
     expand()ed batch dimensions): a [G, M, K] or [M, K], b [G, N, K] or [N, K], bias [G, N], [N] or None. Split-bf16 matrix-core
-    products with fp32 accumulation (fp32-class; csrc/bgemm.hip). Returns [G, M, N] fp32 (or `out`, any strides)."""
+    products with fp32 accumulation (fp32-class; csrc/bgemm.hip). Returns [G, M, N] fp32 (or `out`, any strides).
+    split="fp16": operands as fp16 hi + lo (22 bits of mantissa; values within the fp16 range)."""
     lib = _lib.load()
     _need_any(a, "a")
     _need_any(b, "b")
@@ -680,8 +692,9 @@ def bgemm(a, b, bias=None, alpha=1.0, out=None):
         sbias = [b2.stride(0) if b2.shape[0] == G and G > 1 else 0, b2.stride(1)]
     arr = lambda v: (ctypes.c_longlong * len(v))(*v)
     with _on(a, b, bias, out) as ctx:
-        rc = lib.svps_bgemm(_ptr(a), arr(sa), _ptr(b), arr(sb), _ptr(bias), arr(sbias) if sbias else None, _ptr(out), arr(sc),
-                            G, M, N, K, float(alpha), ctx.stream)
+        fn = lib.svps_bgemm_f16 if split == "fp16" else lib.svps_bgemm
+        rc = fn(_ptr(a), arr(sa), _ptr(b), arr(sb), _ptr(bias), arr(sbias) if sbias else None, _ptr(out), arr(sc),
+                G, M, N, K, float(alpha), ctx.stream)
     _lib.check(rc, "svps_bgemm")
     return out
 

@@ -59,7 +59,7 @@ def _cached(module, name, params, build):
     return store[name][1]
 
 
-def fast_linear(owner, name, x, weight, bias=None, act=None, out=None):
+def fast_linear(owner, name, x, weight, bias=None, act=None, out=None, split="bf16"):
     """y = act(x @ weight^T + bias) for the dense layers of the slot update. bf16 mode: K8 (csrc/slot_gemm.hip: matrix cores,
     split-bf16 products, fp32 accumulation - fp32-class) with the weight packed once per version into fragment order;
     exact mode (owner.precision == "fp32") or shapes K8 does not cover: the GEMM library in fp32.
@@ -72,7 +72,8 @@ def fast_linear(owner, name, x, weight, bias=None, act=None, out=None):
             out.copy_(y)
             return out
         return y
-    wp = _cached(owner, "wp_" + name, [weight], lambda: ops.pack_b_fragments(weight))
+    # split="fp16": operands as fp16 hi + lo (22 bits) instead of bf16 hi + lo (16): the query side of the fused retriever
+    wp = _cached(owner, "wp_" + name + ("_f16" if split == "fp16" else ""), [weight], lambda: ops.pack_b_fragments(weight, split))
     code = {None: ops.ACT_NONE, "relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act]
     return ops.slot_gemm(x.contiguous(), wp, bias, code, out)
 
@@ -192,10 +193,12 @@ class MaskDynamicConv(nn.Module):
         # as fp16 hi + lo (csrc/retr_stats_t.hip) and P * rstd_v as fp16 hi + lo (retr_attn_kernel<.., PHL>): the error against float64
         # drops from the 1e-3 class to the 1e-4 class; the statistics cost ~2x, the retriever ~1.2x
         self.tight_stats = False
-        # the two cheap parts of the precision form on their own (head.set_statistics("balanced")): P * rstd_v as fp16 hi + lo and
-        # the query side in fp32, with the default statistics kernels (K3' / K3''): what is left is the fp16 rounding of the QR
-        # factors (rstd_v 7e-5, rstd_k 5e-5 relative) - 2e-4 ... 3e-4 against float64 for a few percent of the step
+        # the cheap part of the precision form on its own (head.set_statistics("balanced")): P * rstd_v as fp16 hi + lo with the
+        # default statistics kernels (K3' / K3''): what is left is the fp16 rounding of the QR factors (rstd_v 7e-5, rstd_k 5e-5
+        # relative) - 1e-4 ... 2.5e-4 against float64 for 7 % of the step
         self.precise_query_p = False
+        # operands of the query-side products (to_q, the key fold, the position terms): "fp16" hi + lo (default), "bf16" hi + lo, "fp32" library
+        self.query_side = "fp16"
 
     def _bf16_weights(self):
         """to_k / to_v weight matrices rounded to bf16 once (re-derived if the parameters change)."""
@@ -290,24 +293,30 @@ class MaskDynamicConv(nn.Module):
             stats = ops.retr_stats(feat_pm, H, W, *self.stats_args(pos_tabs))
         LP = ops.retr_slot_pad(L)
         # :431 q = norm_q(to_q(slots)); g = q * gamma_k (zero rows up to LP), c3 = q . beta_k, a1 = g . b~_k: one launch
-        # precision form: the query side in the GEMM library's fp32 (the split-bf16 products of K8 / K9 carry 16-bit operands, ~1e-5
-        # relative on Q'' - 5e-4 on the slot update through logits that are sums of 256 terms of magnitude ~5 with heavy cancellation)
+        # The query side ends up inside logits that are sums of 256 terms of magnitude ~5 cancelling to <= 80: bf16 hi + lo operands
+        # (16 bits, ~1e-5 relative on Q'') cost ~5e-4 on the slot update. query_side = "fp16" (default): the same K8 / K9 launches
+        # with fp16 hi + lo operands (22 bits; LayerNorm outputs, O(0.1) weights and sine tables are well inside fp16's range);
+        # "bf16": round 2's operands; "fp32": the GEMM library.
         tight = self.tight_stats or self.precise_query_p
-        xq = F.linear(slots, self.to_q.weight, self.to_q.bias) if tight else fast_linear(self, "to_q", slots, self.to_q.weight, self.to_q.bias)
+        qs = self.query_side if self.use_slot_gemm else "fp32"
+        if qs == "fp32":
+            xq = F.linear(slots, self.to_q.weight, self.to_q.bias)
+        else:
+            xq = fast_linear(self, "to_q", slots, self.to_q.weight, self.to_q.bias, split=qs)
         gp, c3, a1 = ops.retr_query_prep(xq.contiguous(), self.norm_q.weight, self.norm_q.bias, self.norm_q.eps, self.norm_k.weight,
                                          self.norm_k.bias, c["bck"], LP)
         # Q'' [T, LP, 256] = gp @ W~_k: the key projection folded into the queries
-        q2 = F.linear(gp, c["wck_lin"]).contiguous() if tight else fast_linear(self, "wck", gp, c["wck_lin"])
+        q2 = F.linear(gp, c["wck_lin"]).contiguous() if qs == "fp32" else fast_linear(self, "wck", gp, c["wck_lin"], split=qs)
         qh, ql = ops.retr_split(q2)
         if pos_tabs is not None:                                           # separable position terms + a' (two small tables per frame)
             ytab, xtab = pos_tabs
             # K9: cy[t, y, l] = a'[t, l] + ytab[y] . Q''[t, l, :128], cx[t, x, l] = xtab[x] . Q''[t, l, 128:] (shared tables: batch stride 0)
-            if tight:
+            if qs == "fp32":
                 cy = (torch.matmul(ytab, q2[:, :, :C // 2].transpose(1, 2)) + a1[:, None, :]).contiguous()
                 cx = torch.matmul(xtab, q2[:, :, C // 2:].transpose(1, 2)).contiguous()
             else:
-                cy = ops.bgemm(ytab, q2[:, :, :C // 2], bias=a1)
-                cx = ops.bgemm(xtab, q2[:, :, C // 2:])
+                cy = ops.bgemm(ytab, q2[:, :, :C // 2], bias=a1, split=qs)
+                cx = ops.bgemm(xtab, q2[:, :, C // 2:], split=qs)
         else:
             cy = a1[:, None, :].expand(T, H, LP).contiguous()
             cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
@@ -677,9 +686,10 @@ class MultiScaleDynamicMaskHead(nn.Module):
         return self
 
     def set_statistics(self, mode):
-        """bf16 mode, fused retriever. "fast" (default): K3' / K3'' statistics from fp16 QR factors, P * rstd_v as one fp16, query side on
-        K8 / K9 (1e-3 class against float64). "balanced": the same statistics, P * rstd_v as fp16 hi + lo and the query side in fp32
-        (2e-4 ... 3e-4). "tight": K3t statistics from fp16 hi + lo factors on top of that (<= 1.3e-4)."""
+        """bf16 mode, fused retriever. "fast" (default): K3' / K3'' statistics from fp16 QR factors, P * rstd_v as one fp16 (1e-3 class
+        against float64). "balanced": the same statistics, P * rstd_v as fp16 hi + lo (1e-4 ... 2.5e-4). "tight": K3t statistics from
+        fp16 hi + lo factors on top of that (3e-5 ... 8e-5: a float32 evaluation of the reference's formulas measures 4e-5). The query
+        side runs on K8 / K9 with fp16 hi + lo operands in every form (MaskDynamicConv.query_side)."""
         if mode not in ("fast", "balanced", "tight"):
             raise ValueError(f"statistics must be 'fast', 'balanced' or 'tight', not {mode!r}")
         for m in self.modules():

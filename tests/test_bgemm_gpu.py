@@ -39,6 +39,22 @@ def test_bgemm_contiguous(cuda, G, M, N, K):
     print("rel err", _check(ops.bgemm(a, b), a, b, None, 1.0), _check(ops.bgemm(a, b, bias=bias, alpha=0.5), a, b, bias, 0.5))
 
 
+def test_bgemm_fp16_split(cuda):
+    """svps_bgemm_f16: the position terms of the fused retriever (sine tables x folded queries) with fp16 hi + lo operands."""
+    import torch
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(7)
+    tab = torch.sin(torch.randn((64, 128), generator=g, device=cuda))             # shared table: batch stride 0
+    q2 = 3.0 * torch.randn((6, 128, 256), generator=g, device=cuda)
+    a1 = torch.randn((6, 128), generator=g, device=cuda)
+    for split, bound in (("fp16", 3e-7), ("bf16", 4e-5)):
+        got = ops.bgemm(tab, q2[:, :, :128], bias=a1, split=split)
+        want = torch.matmul(tab.double(), q2[:, :, :128].double().transpose(1, 2)) + a1.double()[:, None, :]
+        err = (got.double() - want).abs().max().item() / want.abs().max().item()
+        print(f"bgemm split {split}: rel err {err:.2e}")
+        assert err <= bound, (split, err)
+
+
 def test_bgemm_strides_and_broadcast(cuda):
     import torch
     from slotvps_amd import ops

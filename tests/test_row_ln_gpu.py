@@ -112,6 +112,31 @@ def test_slot_gemm_matches_float64_linear(cuda, M, K, N, act, bias):
     assert err <= 3e-5
 
 
+@pytest.mark.parametrize("M,K,N", [(16000, 256, 256), (300, 256, 256), (37, 272, 512)])
+def test_slot_gemm_fp16_split_is_fp32_class(cuda, M, K, N):
+    """K8 with both operands split into fp16 hi + lo (svps_slot_gemm_f16: the query side of the fused retriever): 22 bits of
+    mantissa for the same three MFMAs - against float64 an order of magnitude closer than the bf16 split, and closer than an fp32
+    GEMM accumulating in fp32."""
+    import torch
+    from slotvps_amd import ops
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    tx, tb = torch.from_numpy(x).to(cuda), torch.from_numpy(b).to(cuda)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b.astype(np.float64)
+    got16 = ops.slot_gemm(tx, ops.pack_b_fragments(torch.from_numpy(w).to(cuda), split="fp16"), tb)
+    gotbf = ops.slot_gemm(tx, ops.pack_b_fragments(torch.from_numpy(w).to(cuda)), tb)
+    assert torch.equal(got16, ops.slot_gemm(tx, ops.pack_b_fragments(torch.from_numpy(w).to(cuda), split="fp16"), tb))
+    e16, ebf = np.abs(got16.cpu().numpy() - ref).max(), np.abs(gotbf.cpu().numpy() - ref).max()
+    print(f"\nK8 M={M} K={K} N={N}: fp16 split {e16:.2e}, bf16 split {ebf:.2e} (outputs of order 1)")
+    assert e16 <= 5e-6 and e16 < 0.3 * ebf                       # measured 2.8e-6 against 2.5e-5: what is left is the fp32 accumulation
+    with pytest.raises(ValueError):
+        ops.slot_gemm(tx, ops.pack_b_fragments(torch.from_numpy(w).to(cuda), split="fp16"), tb, ops.ACT_RELU)
+    with pytest.raises(ValueError):
+        ops.pack_b_fragments(torch.full((256, 256), 7e4, device=cuda), split="fp16")
+
+
 @pytest.mark.parametrize("M,K,pre,post,relu,bias", [(16000, 256, True, False, False, True), (500, 2048, True, True, False, True),
                                                     (37, 272, False, False, True, False), (8000, 256, False, False, True, False),
                                                     (65, 256, True, False, True, True), (40000, 256, True, False, False, True)])

@@ -29,6 +29,9 @@ for (H, W, L) in ((16, 32, 100), (32, 64, 100), (64, 128, 100), (128, 256, 100))
     with torch.no_grad():
         for mode in ("fast", "balanced", "tight"):
             m.tight_stats = mode == "tight"; m.precise_query_p = mode == "balanced"
-            got = m.forward_fused(torch.from_numpy(slots).to(cuda), ft, (H, W), tabs).cpu().numpy()
-            line += f" {mode} {np.abs(got[0] - ref).max():.2e}"
+            for qs in ("fp16", "bf16", "fp32"):                     # operands of the query-side products
+                m.query_side = qs
+                got = m.forward_fused(torch.from_numpy(slots).to(cuda), ft, (H, W), tabs).cpu().numpy()
+                line += f" {mode}/{qs} {np.abs(got[0] - ref).max():.2e}"
+        m.query_side = "fp16"
     print(line, flush=True)
