@@ -37,6 +37,7 @@ extern "C" {
 
 /* flags of svps_mask_decode_fwd */
 #define SVPS_FLAG_OUT_BF16 1 /* write mask logits as bf16 instead of fp32 */
+#define SVPS_FLAG_MAP_F16 2  /* the fused map `feat` is fp16, not bf16 (MultiScaleDynamicMaskHead.map_dtype = "fp16") */
 
 /* kernel ids for the profiling hooks */
 #define SVPS_KERNEL_SLOT_ATTN 0
@@ -359,7 +360,7 @@ int svps_probe_mix(const void* src, void* dst, size_t units, int ri, int ro, voi
  * ------------------------------------------------------------------------------------------- */
 int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                         float lnk_eps, const void* rv, const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D,
-                        void* stream);
+                        int flags, void* stream);
 /* svps_retr_stats_tight_fwd: the same statistics with BOTH factors as FP16 hi + lo (hi + lo = R to 22 bits;
  * slotvps_amd/csrc/retr_stats_t.hip): rstd_k (in front of logits of magnitude up to ~80, dynamic_mask_head.py:431-435) and rstd_v to
  * ~2e-7 relative instead of ~3e-5 / ~5e-5 - the statistics of the fused retriever's precision mode
@@ -367,7 +368,7 @@ int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, cons
  * ty / tx both NULL: no position term. */
 int svps_retr_stats_tight_fwd(const void* feat, const float* ty, const float* tx, const void* rk_hi, const void* rk_lo,
                               const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo, const float* rbv,
-                              float lnv_eps, void* aux, int T, int H, int W, int D, void* stream);
+                              float lnv_eps, void* aux, int T, int H, int W, int D, int flags, void* stream);
 /* svps_retr_stats_level_fwd: the statistics of ALL retriever stages of one pyramid level (n_stages = 1 or 2; the stages of a level
  * read the same fused map, MultiScaleDynamicMaskHead.forward :190-215) in ONE read of the map (slotvps_amd/csrc/retr_stats2.hip:
  * eight waves, stage s on waves 4 s .. 4 s + 3, factors in AGPRs). Arguments as svps_retr_stats_fwd, as HOST arrays of n_stages device
@@ -376,19 +377,19 @@ int svps_retr_stats_tight_fwd(const void* feat, const float* ty, const float* tx
 int svps_retr_stats_level_fwd(const void* feat, int n_stages, const float* const* ty, const float* const* tx,
                               const void* const* rk, const float* const* rbk, const float* lnk_eps,
                               const void* const* rv, const float* const* rbv, const float* lnv_eps,
-                              void* const* aux, int T, int H, int W, int D, void* stream);
+                              void* const* aux, int T, int H, int W, int D, int flags, void* stream);
 size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int chunks);
 int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
                        const void* feat, const void* aux, void* workspace,
                        size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,
-                       void* stream);
+                       int flags, void* stream);
 /* svps_retr_attn_tight_fwd: the precision form for L <= 128 (P * rstd_v carried as fp16 hi + lo: the consumers' matrix work
  * twice; with svps_retr_stats_tight_fwd the fused retriever agrees with a float64 evaluation of dynamic_mask_head.py:423-461 to the
  * 1e-4 class instead of 1e-3). Same contract and workspace as svps_retr_attn_fwd. */
 int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
                        const void* feat, const void* aux, void* workspace,
                        size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,
-                       void* stream);
+                       int flags, void* stream);
 
 /* svps_retr_attn4_fwd: the same function (:435-456), inputs, outputs and padding conventions as svps_retr_attn_fwd for
  * 1 <= L <= 128, as FOUR waves of 512 registers (one per SIMD) that each own a slot block end to end

@@ -54,10 +54,11 @@ class Storage:
     LayerNorm statistics and everything on the slot side stay fp32. ``torch_conv`` additionally models
     the interim PyTorch level-fusion conv of the HIP path (a bf16 conv also rounds its bias)."""
 
-    def __init__(self, bf16, torch_conv=False, kv_bf16=True):
+    def __init__(self, bf16, torch_conv=False, kv_bf16=True, fmt="bf16"):
         self.bf16 = bool(bf16)
         self.torch_conv = bool(torch_conv)
         self.kv_bf16 = bool(kv_bf16)
+        self.fmt = fmt                 # the 16-bit format of the rounding points: "bf16" or "fp16" (same bytes, 3 more mantissa bits)
 
     @classmethod
     def exact(cls):
@@ -74,14 +75,24 @@ class Storage:
         bf16; nothing on the projection / q / k / v side is rounded as a tensor."""
         return cls(True, False, kv_bf16=False)
 
+    @classmethod
+    def fused_fp16_policy(cls):
+        """fused_policy with fp16 instead of bf16 level maps and level-fusion operands (MultiScaleDynamicMaskHead.map_dtype = "fp16")."""
+        return cls(True, False, kv_bf16=False, fmt="fp16")
+
+    def _round(self, x):
+        if self.fmt == "fp16":
+            return np.asarray(x).astype(np.float16).astype(x.dtype)
+        return round_bf16(x).astype(x.dtype)
+
     def _r(self, x):
-        return round_bf16(x).astype(x.dtype) if self.bf16 else x
+        return self._round(x) if self.bf16 else x
 
     def _rt(self, x):
-        return round_bf16(x).astype(x.dtype) if (self.bf16 and self.torch_conv) else x
+        return self._round(x) if (self.bf16 and self.torch_conv) else x
 
     def _rk(self, x):
-        return round_bf16(x).astype(x.dtype) if (self.bf16 and self.kv_bf16) else x
+        return self._round(x) if (self.bf16 and self.kv_bf16) else x
 
     feat = _r        # fused level feature map f (input of the projections, the decode, the next level)
     conv_in = _r     # concat(upsampled previous level, current 128-ch map): operand of the 1x1 conv

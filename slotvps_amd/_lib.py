@@ -13,6 +13,7 @@ ERR_NAMES = {-1: "SVPS_ERR_BAD_ARG", -2: "SVPS_ERR_BAD_SHAPE", -3: "SVPS_ERR_WOR
 
 FLAG_SPLIT_P = 1
 FLAG_OUT_BF16 = 1
+FLAG_MAP_F16 = 2          # the fused map is fp16, not bf16 (SVPS_FLAG_MAP_F16)
 
 KERNEL_SLOT_ATTN = 0
 KERNEL_SLOT_ATTN_FINISH = 1
@@ -57,12 +58,12 @@ SIGNATURES = {
     "svps_slot_ffn": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _vp]),
     "svps_bgemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "svps_bgemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
-    "svps_retr_stats_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
-    "svps_retr_stats_level_fwd": (_i, [_vp, _i] + [_vp] * 9 + [_i, _i, _i, _i, _vp]),
-    "svps_retr_stats_tight_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
+    "svps_retr_stats_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "svps_retr_stats_level_fwd": (_i, [_vp, _i] + [_vp] * 9 + [_i, _i, _i, _i, _i, _vp]),
+    "svps_retr_stats_tight_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "svps_retr_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "svps_retr_attn_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "svps_retr_attn_tight_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "svps_retr_attn_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "svps_retr_attn_tight_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_retr_attn4_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "svps_retr_attn4_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_level_fuse_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -17,6 +17,8 @@ namespace svps {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -97,6 +99,11 @@ __device__ __forceinline__ bf16x8 read_row_frag(const char* lds_tile, int ks, in
     const int chunk = (2 * ks + h) ^ swz(r);
     return *reinterpret_cast<const bf16x8*>(lds_tile + r * kRowBytes + chunk * 16);
 }
+template <typename V>                                          // the same fragment as 8 x bf16 or 8 x fp16 (map element type)
+__device__ __forceinline__ V read_row_frag_as(const char* lds_tile, int ks, int r, int h) {
+    const int chunk = (2 * ks + h) ^ swz(r);
+    return *reinterpret_cast<const V*>(lds_tile + r * kRowBytes + chunk * 16);
+}
 
 // B-operand fragment of V for O += P * V (contraction over pixels): lane (n, h) gets
 // V[pixels 16 ks + 8 h .. + 8][channel 32 db + n], via two hardware-transposed LDS reads.
@@ -116,6 +123,16 @@ __device__ __forceinline__ bf16x8 read_col_frag(const char* lds_tile, int ks, in
 
 __device__ __forceinline__ float wave_half_xor_max(float x) { return fmaxf(x, __shfl_xor(x, 32)); }
 __device__ __forceinline__ float wave_half_xor_sum(float x) { return x + __shfl_xor(x, 32); }
+
+// The fused level maps are 16-bit in HBM: bf16 (default, BASELINE's storage) or fp16 (MultiScaleDynamicMaskHead.map_dtype = "fp16":
+// three more mantissa bits for the same bytes, |f| < 65 504). Kernels templated on the map's element type use these overloads.
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x4 ds_tr16(SVPS_LDS bf16x4* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p); }
+typedef __fp16 svps_h4 __attribute__((ext_vector_type(4)));       // the builtin's own element type
+__device__ __forceinline__ f16x4 ds_tr16(SVPS_LDS f16x4* p) {
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((SVPS_LDS svps_h4*)p));
+}
 
 // The probabilities of the fused retriever travel as fp16 (P * rstd_v, csrc/retr_attn.hip): below 6.1e-5 fp16 is subnormal, below
 // 6e-8 zero - a slot that owns almost no pixel (P ~ 1e-7 everywhere; common once the softmax over slots is sharp) lost its whole

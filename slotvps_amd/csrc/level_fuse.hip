@@ -44,15 +44,18 @@ __device__ __forceinline__ int a_off(int row, int chunk) {
     return row * kFuseRowBytes + (((chunk & ~15) | ((chunk ^ swz(row)) & 15)) * 16);
 }
 
-template <bool NCHW_F32, bool LEVEL0>
+template <typename MT, bool NCHW_F32, bool LEVEL0>
 __global__ __launch_bounds__(512) void level_fuse_kernel(
     const void* __restrict__ cur_,        // [T, 128, H, W] fp32 (NCHW_F32) or [T, H*W, 128] bf16
-    const __bf16* __restrict__ prev,      // [T, (H/2)*(W/2), 256] bf16 pixel-major (unused for LEVEL0)
-    const __bf16* __restrict__ wc,        // [256, 384] bf16 (conv weight, row = output channel)
+    const MT* __restrict__ prev,      // [T, (H/2)*(W/2), 256] bf16 pixel-major (unused for LEVEL0)
+    const MT* __restrict__ wc,        // [256, 384] bf16 (conv weight, row = output channel)
     const float* __restrict__ bc,         // [256]
-    __bf16* __restrict__ out,             // [T, H*W, 256]
+    MT* __restrict__ out,             // [T, H*W, 256]
     int H, int W, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the maps and of the conv operands (common.h)
+    typedef MT mx4 __attribute__((ext_vector_type(4)));
+    static_assert(NCHW_F32 || __is_same(MT, __bf16), "a pixel-major 16-bit incoming map is bf16");
     using Lds = FuseLds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,12 +71,12 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
     const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
 
     // ---- weight block of this wave: rows 32w .. 32w+31, 24 k-steps ----------------------------------
-    bf16x8 wf[24];
+    mx8 wf[24];
     {
-        const __bf16* row = wc + (size_t)(32 * w + r_) * kFuseIn + 8 * h_;
+        const MT* row = wc + (size_t)(32 * w + r_) * kFuseIn + 8 * h_;
 #pragma unroll
         for (int ks = 0; ks < 24; ++ks)
-            wf[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
+            wf[ks] = __builtin_bit_cast(mx8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
     }
     float bias[16];
 #pragma unroll
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
             const int px = tid >> 4, ck = tid & 15;
             int pp = px0 + px;
             pp = pp < HW ? pp : HW - 1;
-            p.cb = *reinterpret_cast<const u32x4*>(static_cast<const __bf16*>(cur_) + ((size_t)t * HW + pp) * 128 + 8 * ck);
+            p.cb = *reinterpret_cast<const u32x4*>(static_cast<const MT*>(cur_) + ((size_t)t * HW + pp) * 128 + 8 * ck);
         }
         if constexpr (!LEVEL0) {
             const int px = tid >> 4, ck = tid & 15;                    // chunks ck and ck + 16
@@ -122,11 +125,11 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
             const int y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1, x1 = x0 + 1 < Wp ? x0 + 1 : Wp - 1;
             p.wy = sy - (float)y0;
             p.wx = sx - (float)x0;
-            const __bf16* pb = prev + (size_t)t * Hp * Wp * kD;
-            const __bf16* t00 = pb + ((size_t)y0 * Wp + x0) * kD;
-            const __bf16* t01 = pb + ((size_t)y0 * Wp + x1) * kD;
-            const __bf16* t10 = pb + ((size_t)y1 * Wp + x0) * kD;
-            const __bf16* t11 = pb + ((size_t)y1 * Wp + x1) * kD;
+            const MT* pb = prev + (size_t)t * Hp * Wp * kD;
+            const MT* t00 = pb + ((size_t)y0 * Wp + x0) * kD;
+            const MT* t01 = pb + ((size_t)y0 * Wp + x1) * kD;
+            const MT* t10 = pb + ((size_t)y1 * Wp + x0) * kD;
+            const MT* t11 = pb + ((size_t)y1 * Wp + x1) * kD;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int co = 8 * (ck + 16 * u);
@@ -144,12 +147,12 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = 8 * pg + j;
-                const __bf16 val = (__bf16)(j < 4 ? p.c0[j] : p.c1[j - 4]);
+                const MT val = (MT)(j < 4 ? p.c0[j] : p.c1[j - 4]);
                 const int chunk = 32 + (ch >> 3);
-                *reinterpret_cast<__bf16*>(at + a_off(row, chunk) + (ch & 7) * 2) = val;
+                *reinterpret_cast<MT*>(at + a_off(row, chunk) + (ch & 7) * 2) = val;
                 if constexpr (LEVEL0) {
-                    *reinterpret_cast<__bf16*>(at + a_off(row, chunk - 32) + (ch & 7) * 2) = val;
-                    *reinterpret_cast<__bf16*>(at + a_off(row, chunk - 16) + (ch & 7) * 2) = val;
+                    *reinterpret_cast<MT*>(at + a_off(row, chunk - 32) + (ch & 7) * 2) = val;
+                    *reinterpret_cast<MT*>(at + a_off(row, chunk - 16) + (ch & 7) * 2) = val;
                 }
             }
         } else {
@@ -166,13 +169,13 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
             const float h1 = p.wy, h0 = 1.f - p.wy, w1 = p.wx, w0 = 1.f - p.wx;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, p.tap[u][0]), b = __builtin_bit_cast(bf16x8, p.tap[u][1]);
-                const bf16x8 cc = __builtin_bit_cast(bf16x8, p.tap[u][2]), d = __builtin_bit_cast(bf16x8, p.tap[u][3]);
-                bf16x8 o;
+                const mx8 a = __builtin_bit_cast(mx8, p.tap[u][0]), b = __builtin_bit_cast(mx8, p.tap[u][1]);
+                const mx8 cc = __builtin_bit_cast(mx8, p.tap[u][2]), d = __builtin_bit_cast(mx8, p.tap[u][3]);
+                mx8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    o[j] = (__bf16)(h0 * (w0 * (float)a[j] + w1 * (float)b[j]) + h1 * (w0 * (float)cc[j] + w1 * (float)d[j]));
-                *reinterpret_cast<bf16x8*>(at + a_off(px, ck + 16 * u)) = o;
+                    o[j] = (MT)(h0 * (w0 * (float)a[j] + w1 * (float)b[j]) + h1 * (w0 * (float)cc[j] + w1 * (float)d[j]));
+                *reinterpret_cast<mx8*>(at + a_off(px, ck + 16 * u)) = o;
             }
         }
     };
@@ -205,23 +208,23 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
         for (int i = 0; i < 16; ++i) acc[i] = bias[i];
 #pragma unroll
         for (int grp = 0; grp < 3; ++grp) {
-            bf16x8 xf[8];
+            mx8 xf[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xf[u] = *reinterpret_cast<const bf16x8*>(at + a_off(r, 2 * (8 * grp + u) + h));
+            for (int u = 0; u < 8; ++u) xf[u] = *reinterpret_cast<const mx8*>(at + a_off(r, 2 * (8 * grp + u) + h));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[8 * grp + u], xf[u], acc, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) acc = mfma16(wf[8 * grp + u], xf[u], acc);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();                                   // b(it): every wave is done reading operand tile it
         char* ot = smem + Lds::otile;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            bf16x4 o;
+            mx4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[4 * g + j];
+            for (int j = 0; j < 4; ++j) o[j] = (MT)acc[4 * g + j];
             const int ch0 = 32 * w + 8 * g + 4 * h;
-            *reinterpret_cast<bf16x4*>(ot + r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
+            *reinterpret_cast<mx4*>(ot + r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
         }
         if (it + 1 < nt) commit(pre);
     }
@@ -605,11 +608,14 @@ struct Fuse4Lds {
 };
 static_assert(Fuse4Lds::total <= 160 * 1024, "LDS layout");
 
-template <bool NCHW_F32>
+template <typename MT, bool NCHW_F32>
 __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
-    const void* __restrict__ cur_, const __bf16* __restrict__ prev, const __bf16* __restrict__ wc,
-    const float* __restrict__ bc, __bf16* __restrict__ out, int H, int W, int tiles_per_chunk) {
+    const void* __restrict__ cur_, const MT* __restrict__ prev, const MT* __restrict__ wc,
+    const float* __restrict__ bc, MT* __restrict__ out, int H, int W, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the maps and of the conv operands (common.h)
+    typedef MT mx4 __attribute__((ext_vector_type(4)));
+    static_assert(NCHW_F32 || __is_same(MT, __bf16), "a pixel-major 16-bit incoming map is bf16");
     using Lds = Fuse4Lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -628,12 +634,12 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 
     if (w < 4) {
         // ======================================= matrix waves =======================================
-        bf16x8 wf[2][24];
+        mx8 wf[2][24];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const __bf16* row = wc + (size_t)(64 * w + 32 * b + r_) * kFuseIn + 8 * h_;
+            const MT* row = wc + (size_t)(64 * w + 32 * b + r_) * kFuseIn + 8 * h_;
 #pragma unroll
-            for (int ks = 0; ks < 24; ++ks) wf[b][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
+            for (int ks = 0; ks < 24; ++ks) wf[b][ks] = __builtin_bit_cast(mx8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
         }
         // Each matrix wave stores its OWN 64 channels of the out tile (128-byte lines, line-aligned): accumulators -> a wave-private
         // LDS block [32 px][128 B + pad] -> four 16-byte reads per lane in line order -> four buffer stores (8 whole lines each).
@@ -658,20 +664,20 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[b][4 * g + j] = b4[j];
                 }
-            bf16x8 xf[2][3];
+            mx8 xf[2][3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) xf[0][u] = *reinterpret_cast<const bf16x8*>(at + 32 * u);
+            for (int u = 0; u < 3; ++u) xf[0][u] = *reinterpret_cast<const mx8*>(at + 32 * u);
 #pragma unroll
             for (int grp = 0; grp < 8; ++grp) {                      // fragments of group grp + 1 requested before the MFMAs of group grp
                 if (grp < 7) {
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) xf[(grp + 1) & 1][u] = *reinterpret_cast<const bf16x8*>(at + 32 * (3 * (grp + 1) + u));
+                    for (int u = 0; u < 3; ++u) xf[(grp + 1) & 1][u] = *reinterpret_cast<const mx8*>(at + 32 * (3 * (grp + 1) + u));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][3 * grp + u], xf[grp & 1][u], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][3 * grp + u], xf[grp & 1][u], acc[1], 0, 0, 0);
+                    acc[0] = mfma16(wf[0][3 * grp + u], xf[grp & 1][u], acc[0]);
+                    acc[1] = mfma16(wf[1][3 * grp + u], xf[grp & 1][u], acc[1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -681,10 +687,10 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    bf16x4 o;
+                    mx4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)acc[b][4 * g + j];
-                    *reinterpret_cast<bf16x4*>(ot + r * Lds::kOWRow + (32 * b + 8 * g + 4 * h) * 2) = o;
+                    for (int j = 0; j < 4; ++j) o[j] = (MT)acc[b][4 * g + j];
+                    *reinterpret_cast<mx4*>(ot + r * Lds::kOWRow + (32 * b + 8 * g + 4 * h) * 2) = o;
                 }
             // the wave's own LDS operations complete in order: the read-back sees the writes above
             const int px0 = st_y * W + st_strip * kTilePx;
@@ -724,7 +730,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     }
     // horizontal blend weights as MFMA B fragments and the transposed tap reads: see v2 (same staging layout); this helper blends
     // channel blocks 2 hw and 2 hw + 1
-    bf16x8 bwx[2];
+    mx8 bwx[2];
     {
         const int c0 = (r_ + 1) >> 1;
         const float lx = (r_ & 1) ? 0.25f : 0.75f;
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int kk = 16 * ks + 8 * h_ + j;
-                bwx[ks][j] = (__bf16)(kk == c0 ? 1.f - lx : (kk == c0 + 1 ? lx : 0.f));
+                bwx[ks][j] = (MT)(kk == c0 ? 1.f - lx : (kk == c0 + 1 ? lx : 0.f));
             }
     }
     int tap_off[2][2][2];                                            // [block][k-step][half]
@@ -865,10 +871,10 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 const int chunk = 32 + (cp >> 2), sub = (cp & 3) * 4;  // 16-byte chunk of channels 256 + 2cp, byte inside it
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                    typedef MT bf16x2 __attribute__((ext_vector_type(2)));
                     bf16x2 v2;
-                    v2[0] = (__bf16)c0[j];
-                    v2[1] = (__bf16)c1[j];
+                    v2[0] = (MT)c0[j];
+                    v2[1] = (MT)c1[j];
                     *reinterpret_cast<bf16x2*>(at + (4 * pq + j) * Lds::kARow + chunk * 16 + sub) = v2;
                 }
             } else {
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
         const int so = Lds::stage + tap_buf * Lds::stage_bytes;
         // both channel blocks of this helper in lock-step (all sixteen transposed reads, then the eight MFMAs, then the vector work):
         // one block after the other was two dependent chains of ~700 cycles each
-        bf16x8 af[2][2][2];                                          // [block][source row][k-step]
+        mx8 af[2][2][2];                                          // [block][source row][k-step]
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -890,8 +896,8 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const char* base = smem + so + row * Lds::kStageCols * kRowBytes;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(base + tap_off[b][ks][0]));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((SVPS_LDS bf16x4*)(base + tap_off[b][ks][1]));
+                    const mx4 lo = ds_tr16((SVPS_LDS mx4*)(base + tap_off[b][ks][0]));
+                    const mx4 hi = ds_tr16((SVPS_LDS mx4*)(base + tap_off[b][ks][1]));
                     af[b][row][ks] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
         __builtin_amdgcn_sched_barrier(0);
@@ -908,22 +914,22 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int row = 0; row < 2; ++row)
-                    up[b][row] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[b][row][ks], bwx[ks], up[b][row], 0, 0, 0);
+                    up[b][row] = mfma16(af[b][row][ks], bwx[ks], up[b][row]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int wo = r_ * Lds::kARow + (32 * (2 * hw + b) + 4 * h_) * 2;       // pixel row r_, channels 32 cb + 8 g + 4 h ..
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                bf16x4 o;
+                mx4 o;
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const f32x2 top = {up[b][0][4 * gq + j], up[b][0][4 * gq + j + 1]}, bot = {up[b][1][4 * gq + j], up[b][1][4 * gq + j + 1]};
                     const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
-                    o[j] = (__bf16)y[0];
-                    o[j + 1] = (__bf16)y[1];
+                    o[j] = (MT)y[0];
+                    o[j + 1] = (MT)y[1];
                 }
-                *reinterpret_cast<bf16x4*>(at + wo + 16 * gq) = o;
+                *reinterpret_cast<mx4*>(at + wo + 16 * gq) = o;
             }
         }
     };
@@ -970,18 +976,18 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 namespace {
 int fuse_num_cus() { return svps_num_cus(); }
 
-template <bool NCHW, bool L0>
+template <typename MT, bool NCHW, bool L0>
 hipError_t launch_fuse(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
                        int W, hipStream_t stream) {
-    auto kern = svps::level_fuse_kernel<NCHW, L0>;
+    auto kern = svps::level_fuse_kernel<MT, NCHW, L0>;
     const int HW = H * W;
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
     int chunks = svps_pick_chunks(T, tiles, fuse_num_cus());   // one resident 8-wave workgroup per CU
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::FuseLds::total, stream, cur,
-                       static_cast<const __bf16*>(prev), static_cast<const __bf16*>(wc), bc,
-                       static_cast<__bf16*>(out), H, W, tpc);
+                       static_cast<const MT*>(prev), static_cast<const MT*>(wc), bc,
+                       static_cast<MT*>(out), H, W, tpc);
     return hipGetLastError();
 }
 
@@ -1019,10 +1025,10 @@ hipError_t launch_fuse_v2(const void* cur, const void* prev, const void* wc, con
                        static_cast<__bf16*>(out), H, W, tpc);
     return hipGetLastError();
 }
-template <bool NCHW>
+template <typename MT, bool NCHW>
 hipError_t launch_fuse_v4(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
                           int W, hipStream_t stream) {
-    auto kern = svps::level_fuse_kernel_v4<NCHW>;
+    auto kern = svps::level_fuse_kernel_v4<MT, NCHW>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::Fuse4Lds::total); ae != hipSuccess) return ae;
     const int tiles = H * W / svps::kTilePx;
@@ -1030,8 +1036,8 @@ hipError_t launch_fuse_v4(const void* cur, const void* prev, const void* wc, con
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::Fuse4Lds::total, stream, cur,
-                       static_cast<const __bf16*>(prev), static_cast<const __bf16*>(wc), bc,
-                       static_cast<__bf16*>(out), H, W, tpc);
+                       static_cast<const MT*>(prev), static_cast<const MT*>(wc), bc,
+                       static_cast<MT*>(out), H, W, tpc);
     return hipGetLastError();
 }
 }  // namespace
@@ -1042,9 +1048,12 @@ extern "C" int svps_k4_debug_read(unsigned long long* stamps) {
 }
 #endif
 
-extern "C" int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, const void* wc,
+extern "C" int svps_level_fuse_fwd(const void* cur, int cur_flags, const void* prev, const void* wc,
                                    const float* bc, void* out, int T, int H, int W, void* stream_) {
     if (!cur || !wc || !bc || !out) return SVPS_ERR_BAD_ARG;
+    const bool cur_is_nchw_f32 = cur_flags & 1;
+    const bool maps_f16 = cur_flags & 2;                       // prev, wc and out are fp16 (three more mantissa bits in the same bytes)
+    if (maps_f16 && !cur_is_nchw_f32) return SVPS_ERR_BAD_ARG;    // a 16-bit pixel-major incoming map is bf16
     if (T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;   // 32-bit buffer offsets inside a frame
     if (prev && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;   // x2 upsampling: even sizes
@@ -1054,18 +1063,22 @@ extern "C" int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const v
     // fast path: tiles inside one output row, frame sizes inside a buffer descriptor
     const bool fast = prev && (W & 31) == 0 && (size_t)H * W * 512 < 0x7fffffffu && getenv("SVPS_K4_LEGACY") == nullptr;
     static const bool v2 = getenv("SVPS_K4_V2") != nullptr;          // comparison runs: the eight-wave form of round 2
-    if (fast && !v2)
-        e = cur_is_nchw_f32 ? launch_fuse_v4<true>(cur, prev, wc, bc, out, T, H, W, stream)
-                            : launch_fuse_v4<false>(cur, prev, wc, bc, out, T, H, W, stream);
+    if (maps_f16)
+        e = fast ? launch_fuse_v4<_Float16, true>(cur, prev, wc, bc, out, T, H, W, stream)
+            : prev ? launch_fuse<_Float16, true, false>(cur, prev, wc, bc, out, T, H, W, stream)
+                   : launch_fuse<_Float16, true, true>(cur, prev, wc, bc, out, T, H, W, stream);
+    else if (fast && !v2)
+        e = cur_is_nchw_f32 ? launch_fuse_v4<__bf16, true>(cur, prev, wc, bc, out, T, H, W, stream)
+                            : launch_fuse_v4<__bf16, false>(cur, prev, wc, bc, out, T, H, W, stream);
     else if (fast)
         e = cur_is_nchw_f32 ? launch_fuse_v2<true>(cur, prev, wc, bc, out, T, H, W, stream)
                             : launch_fuse_v2<false>(cur, prev, wc, bc, out, T, H, W, stream);
     else if (prev)
-        e = cur_is_nchw_f32 ? launch_fuse<true, false>(cur, prev, wc, bc, out, T, H, W, stream)
-                            : launch_fuse<false, false>(cur, prev, wc, bc, out, T, H, W, stream);
+        e = cur_is_nchw_f32 ? launch_fuse<__bf16, true, false>(cur, prev, wc, bc, out, T, H, W, stream)
+                            : launch_fuse<__bf16, false, false>(cur, prev, wc, bc, out, T, H, W, stream);
     else
-        e = cur_is_nchw_f32 ? launch_fuse<true, true>(cur, prev, wc, bc, out, T, H, W, stream)
-                            : launch_fuse<false, true>(cur, prev, wc, bc, out, T, H, W, stream);
+        e = cur_is_nchw_f32 ? launch_fuse<__bf16, true, true>(cur, prev, wc, bc, out, T, H, W, stream)
+                            : launch_fuse<__bf16, false, true>(cur, prev, wc, bc, out, T, H, W, stream);
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 1, stream);
     return (int)e;
 }

@@ -33,9 +33,9 @@ struct DecLds {
     static constexpr int total = amax + NW * kTilePx * 8;
 };
 
-template <int NW, int NST, bool ARGMAX, typename OutT>
+template <int NW, int NST, bool ARGMAX, typename OutT, typename MT = __bf16>
 __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
-    const __bf16* __restrict__ feat,     // [T, HW, 256]
+    const MT* __restrict__ feat,     // [T, HW, 256]
     const float* __restrict__ embed,     // [T, L, 256]
     const float* __restrict__ bn_scale,  // [256]
     const float* __restrict__ bn_shift,  // [256]
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
     uint8_t* __restrict__ slot_argmax,   // [T, HW] or null
     int L, int HW, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the fused map, bf16 or fp16 (common.h)
     using Lds = DecLds<NW, NST>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
     __syncthreads();
 
     // ---- slot operand (e * scale) as bf16 hi/lo A fragments; per-slot constant e . shift ------
-    bf16x8 eh[16], el[16];
+    mx8 eh[16], el[16];
     {
         const int slot = 32 * w + r;
         const float* erow = embed + ((size_t)t * L + (slot < L ? slot : 0)) * kD + 8 * h;
@@ -83,10 +84,13 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
                 float x = j < 4 ? x0[j] : x1[j - 4];
                 if (slot >= L) x = 0.f;
                 dot += x * aff[kD + ch];
-                const float xs = x * aff[ch];
-                const __bf16 hi = (__bf16)xs;
+                float xs = x * aff[ch];
+                // xs is ONE fp32 value for both halves: left to itself hipcc rounds hi from the fp32 product (v_cvt_pk_f16_f32) and lo from
+                // the exact product (v_fma_mixlo_f16 x, a, -hi') with its own hi' - at a tie the two differ by an fp16 ulp (seen: 2.5e-5 on a logit)
+                asm volatile("" : "+v"(xs));
+                const MT hi = (MT)xs;
                 eh[ks][j] = hi;
-                el[ks][j] = (__bf16)(xs - (float)hi);
+                el[ks][j] = (MT)(xs - (float)hi);
             }
         }
         dot = wave_half_xor_sum(dot);
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
 #pragma unroll
             for (int i = 0; i < CPT; ++i) {
                 const int chunk = nsub + TPP * i;
-                const bf16x8 x = *reinterpret_cast<const bf16x8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
+                const mx8 x = *reinterpret_cast<const mx8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float g = (float)x[j] * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
@@ -147,9 +151,9 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
         for (int i = 0; i < 16; ++i) s[i] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const bf16x8 ff = read_row_frag(ft, ks, r, h);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el[ks], ff, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh[ks], ff, s, 0, 0, 0);
+            const mx8 ff = read_row_frag_as<mx8>(ft, ks, r, h);
+            s = mfma16(el[ks], ff, s);
+            s = mfma16(eh[ks], ff, s);
         }
         wg_barrier();  // inv_norm of this tile visible
 
@@ -284,12 +288,13 @@ __device__ unsigned long long k2_stamps[4][8][8];            // [wave][iteration
 // LOGITS = false: argmax-only mode (out == NULL) - the [T, L, HW] logits are neither transposed nor stored: per pixel 512 B in and
 // 1 B out instead of 512 + 4 L + 1 (a consumer that only needs the per-pixel slot id, e.g. the clip driver's assignment map)
 // ABL (timing-only builds, -DSVPS_K2_ABLATE + tools/ablate_k2.sh): 1 no MFMAs, 2 no fragment reads either, 4 no argmax epilogue, 8 no DMA
-template <bool ARGMAX, int NW = 4, bool LOGITS = true, int ABL = 0, int NSTG = 0>
+template <bool ARGMAX, int NW = 4, bool LOGITS = true, int ABL = 0, int NSTG = 0, typename MT = __bf16>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v2(
-    const __bf16* __restrict__ feat, const float* __restrict__ embed, const float* __restrict__ bn_scale,
+    const MT* __restrict__ feat, const float* __restrict__ embed, const float* __restrict__ bn_scale,
     const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
     uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the fused map, bf16 or fp16 (common.h)
     using Lds = Dec2Lds<NW, LOGITS, NSTG>;
     constexpr int NST = Lds::kStages;
     constexpr int kAhead = NST - 1;                              // tiles requested ahead of the one in work
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
     }
     __syncthreads();
 
-    bf16x8 eh[16], el[16];
+    mx8 eh[16], el[16];
     {
         const int slot = 32 * w + r;
         const float* erow = embed + ((size_t)t * L + (slot < L ? slot : 0)) * kD + 8 * h;
@@ -334,10 +339,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                 float x = j < 4 ? x0[j] : x1[j - 4];
                 if (slot >= L) x = 0.f;
                 dot += x * aff[kD + ch];
-                const float xs = x * aff[ch];
-                const __bf16 hi = (__bf16)xs;
+                float xs = x * aff[ch];
+                // xs is ONE fp32 value for both halves: left to itself hipcc rounds hi from the fp32 product (v_cvt_pk_f16_f32) and lo from
+                // the exact product (v_fma_mixlo_f16 x, a, -hi') with its own hi' - at a tie the two differ by an fp16 ulp (seen: 2.5e-5 on a logit)
+                asm volatile("" : "+v"(xs));
+                const MT hi = (MT)xs;
                 eh[ks][j] = hi;
-                el[ks][j] = (__bf16)(xs - (float)hi);
+                el[ks][j] = (MT)(xs - (float)hi);
             }
             // four k-steps of loads in flight, not sixteen: with all 128 loaded floats live next to the 128 operand registers hipcc
             // spills lane constants, reloads one inside the tile loop and guards it with s_waitcnt vmcnt(0) - which drains the
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
     #pragma unroll
                 for (int i = 0; i < 32 / TPP; ++i) {
                     const int chunk = nsub + TPP * i;
-                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
+                    const mx8 x = *reinterpret_cast<const mx8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
     #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float g = (float)x[j] * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
@@ -459,17 +467,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
             {
     #pragma unroll
                 for (int grp = 0; grp < ((ABL & 2) ? 0 : 4); ++grp) {   // four operand fragments in flight (register budget: 128 hold e)
-                    bf16x8 ff[4];
+                    mx8 ff[4];
     #pragma unroll
-                    for (int u = 0; u < 4; ++u) ff[u] = read_row_frag(ft, 4 * grp + u, r, h);
+                    for (int u = 0; u < 4; ++u) ff[u] = read_row_frag_as<mx8>(ft, 4 * grp + u, r, h);
                     __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if constexpr (ABL & 1) {
                             asm volatile("" : : "v"(ff[u]), "v"(el[4 * grp + u]), "v"(eh[4 * grp + u]));
                         } else {
-                            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el[4 * grp + u], ff[u], s, 0, 0, 0);
-                            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh[4 * grp + u], ff[u], s, 0, 0, 0);
+                            s = mfma16(el[4 * grp + u], ff[u], s);
+                            s = mfma16(eh[4 * grp + u], ff[u], s);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
 #pragma unroll
             for (int i = 0; i < 32 / TPP; ++i) {
                 const int chunk = nsub + TPP * i;
-                const bf16x8 x = *reinterpret_cast<const bf16x8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
+                const mx8 x = *reinterpret_cast<const mx8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float g = (float)x[j] * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
@@ -582,10 +590,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         }
 
         constexpr bool FR = CH && !(ABL & 2);            // fragments are read
-        bf16x8 ff[2][4];
+        mx8 ff[2][4];
         if constexpr (FR) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ff[0][u] = read_row_frag(ft, u, r, h);
+            for (int u = 0; u < 4; ++u) ff[0][u] = read_row_frag_as<mx8>(ft, u, r, h);
         }
         // Cross-wave part of the argmax of tile it - 2 (its candidates were written in iteration it - 1): every wave reads them and
         // runs the comparison in the shadow of its first MFMAs - nobody is late at the next barrier; only wave 0's offsets are in
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
             if constexpr (FR) {
                 if (grp < 3) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ff[(grp + 1) & 1][u] = read_row_frag(ft, 4 * (grp + 1) + u, r, h);
+                    for (int u = 0; u < 4; ++u) ff[(grp + 1) & 1][u] = read_row_frag_as<mx8>(ft, 4 * (grp + 1) + u, r, h);
                 }
             }
             if constexpr (EP) {
@@ -624,8 +632,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                     if constexpr (ABL & 1) {
                         asm volatile("" : : "v"(ff[grp & 1][u]), "v"(el[4 * grp + u]), "v"(eh[4 * grp + u]));
                     } else {
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(el[4 * grp + u], ff[grp & 1][u], s, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(eh[4 * grp + u], ff[grp & 1][u], s, 0, 0, 0);
+                        s = mfma16(el[4 * grp + u], ff[grp & 1][u], s);
+                        s = mfma16(eh[4 * grp + u], ff[grp & 1][u], s);
                     }
                 }
                 if constexpr (ARGMAX && EP) {
@@ -708,12 +716,12 @@ namespace {
 
 int dec_num_cus() { return svps_num_cus(); }
 
-template <int NW, int NST, bool ARGMAX, typename OutT>
+template <int NW, int NST, bool ARGMAX, typename OutT, typename MT = __bf16>
 hipError_t launch_decode(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
                          float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L,
                          int HW, hipStream_t stream) {
     using Lds = svps::DecLds<NW, NST>;
-    auto kern = svps::mask_decode_kernel<NW, NST, ARGMAX, OutT>;
+    auto kern = svps::mask_decode_kernel<NW, NST, ARGMAX, OutT, MT>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
     // sized for two workgroups per CU by LDS (2 x ~70 KiB); this first kernel needs 297 registers per lane, so in practice
@@ -723,16 +731,16 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(NW * 64), Lds::total, stream,
-                       static_cast<const __bf16*>(feat), embed, bn_scale, bn_shift, fg_scale, fg_shift,
+                       static_cast<const MT*>(feat), embed, bn_scale, bn_shift, fg_scale, fg_shift,
                        static_cast<OutT*>(out), slot_argmax, L, HW, tpc);
     return hipGetLastError();
 }
 
-template <bool ARGMAX, int NW, bool LOGITS = true, int ABL = 0, int NSTG = 0>
+template <bool ARGMAX, int NW, bool LOGITS = true, int ABL = 0, int NSTG = 0, typename MT = __bf16>
 hipError_t launch_decode_v2(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
                             float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L, int HW,
                             hipStream_t stream) {
-    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW, LOGITS, ABL, NSTG>;
+    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW, LOGITS, ABL, NSTG, MT>;
     using Lds = svps::Dec2Lds<NW, LOGITS, NSTG>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
@@ -740,7 +748,7 @@ hipError_t launch_decode_v2(const void* feat, const float* embed, const float* b
     int chunks = svps_pick_chunks(T, tiles, (NW == 4 ? 2 : 1) * dec_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
-    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(64 * NW), Lds::total, stream, static_cast<const __bf16*>(feat),
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(64 * NW), Lds::total, stream, static_cast<const MT*>(feat),
                        embed, bn_scale, bn_shift, fg_scale, fg_shift, static_cast<float*>(out), slot_argmax, L, HW, tpc);
     return hipGetLastError();
 }
@@ -774,6 +782,26 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
     if ((size_t)HW > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;       // 32-bit buffer offsets inside a frame
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 0, stream);
+    if (flags & SVPS_FLAG_MAP_F16) {                       // fp16 fused map: fp32 logits (fast kernel, or the first one for ragged HW) / argmax only
+        if ((flags & SVPS_FLAG_OUT_BF16) || (size_t)L * HW * 4 >= 0x7ffffff0u) return SVPS_ERR_BAD_ARG;
+        using H = _Float16;
+        hipError_t eh;
+#define SVPS_H2(AM, W, LG) launch_decode_v2<AM, W, LG, 0, 0, H>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
+#define SVPS_H1(W, AM) launch_decode<W, 4, AM, float, H>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
+        if (!out) {
+            if (HW & 3) return SVPS_ERR_BAD_SHAPE;
+            eh = L <= 128 ? SVPS_H2(true, 4, false) : SVPS_H2(true, 8, false);
+        } else if ((HW & 3) == 0) {
+            eh = L <= 128 ? (slot_argmax ? SVPS_H2(true, 4, true) : SVPS_H2(false, 4, true))
+                          : (slot_argmax ? SVPS_H2(true, 8, true) : SVPS_H2(false, 8, true));
+        } else {
+            eh = L <= 128 ? (slot_argmax ? SVPS_H1(4, true) : SVPS_H1(4, false)) : (slot_argmax ? SVPS_H1(8, true) : SVPS_H1(8, false));
+        }
+#undef SVPS_H2
+#undef SVPS_H1
+        svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
+        return (int)eh;
+    }
     // fast path: 16-byte row-segment stores need 4-pixel alignment of every slot row; L * HW * 4 must fit a buffer descriptor
     const bool fast = (HW & 3) == 0 && !(flags & SVPS_FLAG_OUT_BF16) && (size_t)L * HW * 4 < 0x7ffffff0u &&
                       getenv("SVPS_K2_LEGACY") == nullptr;

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const __bf16* __restrict__ aux,     // [T, HW, 8]    retr_stats.hip: 16-byte rows {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32)}
     float* __restrict__ partial,        // [T, C, Lrow, 260]
     int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off,
-    const float2* __restrict__ ext_stats) {
+    const float2* __restrict__ ext_stats, int map_f16) {        // map_f16: the map is fp16 already (no conversion in LDS)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = RetrLdsT<PHL ? 2 : 1>;
     constexpr int A = kRPrefetch;
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     // instruction of the kernel then runs fp16 x fp16: Q'' as fp16 hi + lo carries 22 bits, P * rstd_v ONE fp16 (11 bits,
     // rounding errors average out over the pixel sum) instead of bf16 hi + lo: half the MFMAs on the value side.
     auto convert_batch = [&](int b) {
-        if (b >= nt || ABL == 8) return;
+        if (b >= nt || ABL == 8 || map_f16) return;
         const uint32_t st = lds0 + Lds::fring + (b % kRNF) * kTileBytes + sb * 4096 + lane * 16;
         u32x4 w_[4];
 #pragma unroll
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
     const float* __restrict__ c3g,                                     // [T, 256]
     const __bf16* __restrict__ feat, const __bf16* __restrict__ aux,   // aux: the 16-byte rows of retr_stats.hip (rstd_k = bytes 8 .. 11)
     float2* __restrict__ out,                                          // [T, HW]
-    int L, int HW, int H, int W, int tiles_per_chunk) {
+    int L, int HW, int H, int W, int tiles_per_chunk, int map_f16) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = LStatsLds;
     constexpr int NF = Lds::kNF, A = Lds::kA, LP = 256;
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
         if (dy == H) { dy = 0; ++ds; }
     };
     auto convert = [&](int tile) {
-        if (tile >= nt) return;
+        if (tile >= nt || map_f16) return;
         const uint32_t st = lds0 + Lds::ring + (tile % NF) * kTileBytes + w * 2048 + lane * 16;
         u32x4 w_[2];
 #pragma unroll
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(512) void retr_probs_kernel(
     const float* __restrict__ c3g,                                     // [T, 256]
     const __bf16* __restrict__ feat, const __bf16* __restrict__ aux,   // aux: the 16-byte rows of retr_stats.hip
     char* __restrict__ pout,                                           // [T, tiles, 16 KiB]
-    int HW, int H, int W, int tiles_per_chunk) {
+    int HW, int H, int W, int tiles_per_chunk, int map_f16) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = ProbsLds;
     constexpr int NF = Lds::kNF, A = Lds::kA, LP = 256;
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(512) void retr_probs_kernel(
         if (dy == H) { dy = 0; ++ds; }
     };
     auto convert = [&](int tile) {
-        if (tile >= nt) return;
+        if (tile >= nt || map_f16) return;
         const uint32_t st = lds0 + Lds::ring + (tile % NF) * kTileBytes + w * 2048 + lane * 16;
         u32x4 w_[2];
 #pragma unroll
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(512) void retr_pv_kernel(
     const __bf16* __restrict__ aux,     // [T, HW, 8]
     const char* __restrict__ pin,       // [T, tiles, 16 KiB]  retr_probs_kernel
     float* __restrict__ partial,        // [T, C, L, 260]
-    int L, int HW, int H, int W, int tiles_per_chunk) {
+    int L, int HW, int H, int W, int tiles_per_chunk, int map_f16) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = PvLds;
     constexpr int A = Lds::kA, NF = Lds::kNF;
@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(512) void retr_pv_kernel(
         }
     };
     auto convert_batch = [&](int b) {                            // this wave's two pieces of feature tile b, bf16 -> fp16 in place
-        if (b >= nt) return;
+        if (b >= nt || map_f16) return;
         const uint32_t st = lds0 + Lds::fring + (b % NF) * kTileBytes + sb * 2048 + lane * 16;
         u32x4 w_[2];
 #pragma unroll
@@ -1338,7 +1338,8 @@ extern "C" size_t svps_retr_attn_workspace_bytes(int T, int L, int H, int W, int
 extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
                                   const void* feat, const void* aux,
                                   void* workspace, size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D,
-                                  int chunks, void* stream_) {
+                                  int chunks, int flags, void* stream_) {
+    const int mf = (flags & SVPS_FLAG_MAP_F16) ? 1 : 0;              // the map is fp16: the kernels skip their bf16 -> fp16 pass
     if (!qh || !ql || !cy || !cx || !c3 || !feat || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
@@ -1368,7 +1369,7 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         static SvpsLdsAttr attr[5];
         if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
-                           L, HW, H, W, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr);
+                           L, HW, H, W, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, mf);
         e = hipGetLastError();
     } else if (!retr_three_launch()) {
         // more than 128 slots (padded layouts of 256 rows), two passes: probabilities of all slots -> workspace, then P f
@@ -1379,11 +1380,11 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         if (hipError_t ae = attr_v.ensure(reinterpret_cast<const void*>(svps::retr_pv_kernel), svps::PvLds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(svps::retr_probs_kernel, dim3(pl.chunks, T), dim3(512), svps::ProbsLds::total, stream,
                            static_cast<const _Float16*>(qh), static_cast<const _Float16*>(ql), cy, cx, c3, f_, a_, pws, HW, H, W,
-                           pl.tiles_per_chunk);
+                           pl.tiles_per_chunk, mf);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(svps::retr_pv_kernel, dim3(p.chunks, T), dim3(512), svps::PvLds::total, stream, f_, a_, (const char*)pws,
-                           partial, L, HW, H, W, p.tiles_per_chunk);
+                           partial, L, HW, H, W, p.tiles_per_chunk, mf);
         e = hipGetLastError();
     } else {
         // the first form of this path (comparison runs): softmax statistics over all slots, then the retriever once per half of
@@ -1396,15 +1397,15 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         if (hipError_t ae = attr_e.ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(svps::retr_logit_stats_kernel, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream,
                            static_cast<const _Float16*>(qh), static_cast<const _Float16*>(ql), cy, cx, c3, f_, a_, st, L, HW, H, W,
-                           pl.tiles_per_chunk);
+                           pl.tiles_per_chunk, mf);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
-                           128, HW, H, W, p.tiles_per_chunk, 256, L, 0, (const float2*)st);
+                           128, HW, H, W, p.tiles_per_chunk, 256, L, 0, (const float2*)st, mf);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
-                           L - 128, HW, H, W, p.tiles_per_chunk, 256, L, 128, (const float2*)st);
+                           L - 128, HW, H, W, p.tiles_per_chunk, 256, L, 128, (const float2*)st, mf);
         e = hipGetLastError();
     }
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
@@ -1419,7 +1420,7 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
 // and workspace.
 extern "C" int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
                                         const void* feat, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext,
-                                        int T, int L, int H, int W, int D, int chunks, void* stream_) {
+                                        int T, int L, int H, int W, int D, int chunks, int flags, void* stream_) {
     if (!qh || !ql || !cy || !cx || !c3 || !feat || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
@@ -1436,7 +1437,7 @@ extern "C" int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const fl
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
     hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream, static_cast<const __bf16*>(qh), static_cast<const __bf16*>(ql),
                        cy, cx, c3, static_cast<const __bf16*>(feat), static_cast<const __bf16*>(aux), partial, L, HW, H, W,
-                       p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr);
+                       p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, (flags & SVPS_FLAG_MAP_F16) ? 1 : 0);
     hipError_t e = hipGetLastError();
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
     if (e != hipSuccess) return (int)e;

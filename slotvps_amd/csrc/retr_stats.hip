@@ -145,7 +145,7 @@ __device__ __forceinline__ void retr_stats_role(
     const float* __restrict__ rbv,
     float eps_k, float eps_v,
     __bf16* __restrict__ aux,           // [T, HW, 8] (16-bit words): 16-byte rows
-    int HW, int H, int W, int tiles_per_chunk) {
+    int HW, int H, int W, int tiles_per_chunk, int map_f16) {   // map_f16: the map is fp16 already (no conversion in LDS)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = StatsPLds;
     const int lane = threadIdx.x & 63;
@@ -252,7 +252,7 @@ __device__ __forceinline__ void retr_stats_role(
     };
     // this wave's two pieces of feature tile `tile`: bf16 -> fp16 in place
     auto convert = [&](int tile) {
-        if (tile >= nt) return;
+        if (tile >= nt || map_f16) return;
         if constexpr (ABL & 2) return;
         const uint32_t st = lds0 + Lds::fring + (tile % kStNF) * kTileBytes + wv * 2048 + lane * 16;
         u32x4 w_[2];
@@ -481,9 +481,9 @@ __global__ __launch_bounds__(512) void retr_stats_kernel(
     const __bf16* __restrict__ feat, const float* __restrict__ ty, const float* __restrict__ tx,
     const _Float16* __restrict__ rk, const _Float16* __restrict__ rv, const float* __restrict__ rbk, const float* __restrict__ rbv,
     float eps_k, float eps_v, __bf16* __restrict__ aux,
-    int HW, int H, int W, int tiles_per_chunk) {
+    int HW, int H, int W, int tiles_per_chunk, int map_f16) {
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#define SVPS_ROLE(P, JJ) retr_stats_role<HAS_POS, P, JJ, ABL>(feat, ty, tx, rk, rv, rbk, rbv, eps_k, eps_v, aux, HW, H, W, tiles_per_chunk)
+#define SVPS_ROLE(P, JJ) retr_stats_role<HAS_POS, P, JJ, ABL>(feat, ty, tx, rk, rv, rbk, rbv, eps_k, eps_v, aux, HW, H, W, tiles_per_chunk, map_f16)
     switch (w) {                 // every role runs the same sequence of workgroup barriers
         case 0: SVPS_ROLE(0, 0); break;
         case 1: SVPS_ROLE(0, 1); break;
@@ -506,7 +506,7 @@ static constexpr int kStampLds = 0;
 #endif
 extern "C" int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                                    float lnk_eps, const void* rv, const float* rbv, float lnv_eps,
-                                   void* aux, int T, int H, int W, int D, void* stream_) {
+                                   void* aux, int T, int H, int W, int D, int flags, void* stream_) {
     if (!feat || !rk || !rbk || !rv || !rbv || !aux) return SVPS_ERR_BAD_ARG;
     if ((ty == nullptr) != (tx == nullptr)) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
@@ -548,7 +548,7 @@ extern "C" int svps_retr_stats_fwd(const void* feat, const float* ty, const floa
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::StatsPLds::total + kStampLds, stream, static_cast<const __bf16*>(feat),
                        ty, tx, static_cast<const _Float16*>(rk), static_cast<const _Float16*>(rv), rbk, rbv, lnk_eps, lnv_eps,
-                       static_cast<__bf16*>(aux), HW, H, W, tpc);
+                       static_cast<__bf16*>(aux), HW, H, W, tpc, (flags & SVPS_FLAG_MAP_F16) ? 1 : 0);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);
     return (int)hipGetLastError();
 }

@@ -33,7 +33,7 @@
 
 extern "C" int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                                    float lnk_eps, const void* rv, const float* rbv, float lnv_eps,
-                                   void* aux, int T, int H, int W, int D, void* stream_);
+                                   void* aux, int T, int H, int W, int D, int flags, void* stream_);
 
 namespace svps {
 namespace s2 {
@@ -131,6 +131,7 @@ struct Args {
     const __bf16* feat;      // [T, HW, 256]
     StageArgs st[2];
     int HW, H, W, tiles_per_chunk, chunks_per_strip;
+    int map_f16;             // the map is fp16 already: no conversion in LDS
 };
 
 // 256 registers per wave = 128 AGPRs (32 of the 36 resident fragments) + 128 VGPRs: the last two k-steps of row block 7 - sb of both
@@ -340,12 +341,14 @@ __device__ __forceinline__ void role(const Args& A) {
         }
     }
     wait_vm<nb * (kA - 2) + nst * (kA - 3)>();                       // batches 0 and 1
+    if (!A.map_f16) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < 2; ++b) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            u32x4 w_ = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(cv_lane + b * kTileBytes + i * 1024));
-            convert_piece(b * kTileBytes, w_, i);
+            for (int i = 0; i < 2; ++i) {
+                u32x4 w_ = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(cv_lane + b * kTileBytes + i * 1024));
+                convert_piece(b * kTileBytes, w_, i);
+            }
         }
     }
     wg_barrier();
@@ -405,10 +408,12 @@ __device__ __forceinline__ void role(const Args& A) {
         }
         {   // this wave's pieces of tile it+2 have landed: everything but the batches it+3 .. it+kA-1 and the aux stores issued since
             wait_vm<nb * (kA - 3) + nst * (kA - 2)>();
-            u32x4 w0_ = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(cv_lane + off_c));
-            u32x4 w1_ = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(cv_lane + off_c + 1024));
-            convert_piece(off_c, w0_, 0);
-            convert_piece(off_c, w1_, 1);
+            if (!A.map_f16) {
+                u32x4 w0_ = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(cv_lane + off_c));
+                u32x4 w1_ = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(cv_lane + off_c + 1024));
+                convert_piece(off_c, w0_, 0);
+                convert_piece(off_c, w1_, 1);
+            }
         }
         dma_batch(off_d, yoff_d, px0_d, yrow_d, it + kA < nt);
         off_l = ring_next(off_l);
@@ -468,7 +473,7 @@ PlanS2 plan_s2(int T, int H, int W) {
 extern "C" int svps_retr_stats_level_fwd(const void* feat, int n_stages, const float* const* ty, const float* const* tx,
                                          const void* const* rk, const float* const* rbk, const float* lnk_eps,
                                          const void* const* rv, const float* const* rbv, const float* lnv_eps,
-                                         void* const* aux, int T, int H, int W, int D, void* stream_) {
+                                         void* const* aux, int T, int H, int W, int D, int flags, void* stream_) {
     if (!feat || !ty || !tx || !rk || !rbk || !lnk_eps || !rv || !rbv || !lnv_eps || !aux) return SVPS_ERR_BAD_ARG;
     if (n_stages < 1 || n_stages > 2) return SVPS_ERR_BAD_SHAPE;
     if (D != svps::kD || T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
@@ -476,7 +481,7 @@ extern "C" int svps_retr_stats_level_fwd(const void* feat, int n_stages, const f
     for (int s = 0; s < n_stages; ++s)
         if (!ty[s] || !tx[s] || !rk[s] || !rbk[s] || !rv[s] || !rbv[s] || !aux[s]) return SVPS_ERR_BAD_ARG;
     if (n_stages == 1)           // a level with a single stage: the per-stage kernel (retr_stats.hip)
-        return svps_retr_stats_fwd(feat, ty[0], tx[0], rk[0], rbk[0], lnk_eps[0], rv[0], rbv[0], lnv_eps[0], aux[0], T, H, W, D, stream_);
+        return svps_retr_stats_fwd(feat, ty[0], tx[0], rk[0], rbk[0], lnk_eps[0], rv[0], rbv[0], lnv_eps[0], aux[0], T, H, W, D, flags, stream_);
     svps::s2::Args a;
     a.feat = static_cast<const __bf16*>(feat);
     for (int s = 0; s < 2; ++s) {
@@ -488,6 +493,7 @@ extern "C" int svps_retr_stats_level_fwd(const void* feat, int n_stages, const f
     }
     const PlanS2 p = plan_s2(T, H, W);
     a.HW = H * W; a.H = H; a.W = W; a.tiles_per_chunk = p.tpc; a.chunks_per_strip = p.cps;
+    a.map_f16 = (flags & SVPS_FLAG_MAP_F16) ? 1 : 0;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(svps::s2::retr_stats2_kernel), svps::s2::Lds::total); ae != hipSuccess) return (int)ae;

@@ -39,6 +39,7 @@ struct StatsTArgs {
     float eps;
     int HW, H, W, tiles_per_wg;
     int value;                 // 0: key launch (writes rstd_k), 1: value launch (writes {1, sigma_v hi, lo, 0} and rstd_v)
+    int map_f16;               // the map is fp16 (staged as it is)
 };
 
 // one wave = row block RB (rows 32 RB .. 32 RB + 31) of the three factors; R is upper triangular: k-steps 2 RB .. 15 only
@@ -77,6 +78,7 @@ __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem
         st_f16x8 o0, o1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { o0[j] = (_Float16)(float)v0[j]; o1[j] = (_Float16)(float)v1[j]; }
+        if (a.map_f16) { o0 = __builtin_bit_cast(st_f16x8, v0); o1 = __builtin_bit_cast(st_f16x8, v1); }
         char* dst = smem + StatsTLds::xt + buf * StatsTLds::x_bytes + spx * kTtRow + 32 * sc16;
         *reinterpret_cast<st_f16x8*>(dst) = o0;
         *reinterpret_cast<st_f16x8*>(dst + 16) = o1;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(512) void retr_stats_tight_kernel(StatsTArgs a) {
 
 extern "C" int svps_retr_stats_tight_fwd(const void* feat, const float* ty, const float* tx, const void* rk_hi, const void* rk_lo,
                                          const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo, const float* rbv,
-                                         float lnv_eps, void* aux, int T, int H, int W, int D, void* stream_) {
+                                         float lnv_eps, void* aux, int T, int H, int W, int D, int flags, void* stream_) {
     if (!feat || !rk_hi || !rk_lo || !rbk || !rv_hi || !rv_lo || !rbv || !aux || ((ty == nullptr) != (tx == nullptr))) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
@@ -180,10 +182,10 @@ extern "C" int svps_retr_stats_tight_fwd(const void* feat, const float* ty, cons
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
     const svps::StatsTArgs ak{static_cast<const __bf16*>(feat), ty, tx, static_cast<const _Float16*>(rk_hi),
-                              static_cast<const _Float16*>(rk_lo), rbk, static_cast<__bf16*>(aux), lnk_eps, HW, H, W, tpw, 0};
+                              static_cast<const _Float16*>(rk_lo), rbk, static_cast<__bf16*>(aux), lnk_eps, HW, H, W, tpw, 0, (flags & SVPS_FLAG_MAP_F16) ? 1 : 0};
     hipLaunchKernelGGL(svps::retr_stats_tight_kernel, dim3(chunks, T), dim3(512), svps::StatsTLds::total, stream, ak);
     const svps::StatsTArgs av{static_cast<const __bf16*>(feat), nullptr, nullptr, static_cast<const _Float16*>(rv_hi),
-                              static_cast<const _Float16*>(rv_lo), rbv, static_cast<__bf16*>(aux), lnv_eps, HW, H, W, tpw, 1};
+                              static_cast<const _Float16*>(rv_lo), rbv, static_cast<__bf16*>(aux), lnv_eps, HW, H, W, tpw, 1, (flags & SVPS_FLAG_MAP_F16) ? 1 : 0};
     hipLaunchKernelGGL(svps::retr_stats_tight_kernel, dim3(chunks, T), dim3(512), svps::StatsTLds::total, stream, av);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);
     return (int)hipGetLastError();

@@ -48,6 +48,16 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _map_flag(feat, name="feat", ndim=3):
+    """The fused level maps are 16-bit: bf16 (default) or fp16 (MultiScaleDynamicMaskHead.map_dtype = "fp16": three more mantissa
+    bits in the same bytes, |f| < 65 504). Returns the C flag (0 / SVPS_FLAG_MAP_F16) after the usual checks."""
+    if isinstance(feat, torch.Tensor) and feat.dtype == torch.float16:
+        _need(feat, name, torch.float16, ndim)
+        return _lib.FLAG_MAP_F16
+    _need(feat, name, torch.bfloat16, ndim)
+    return 0
+
+
 def _need(t, name, dtype, ndim=None):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"{name}: the slot-retriever ops run on the GPU only (got "
@@ -104,7 +114,9 @@ def mask_decode(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out_bf16=Fa
     last-stage slot embeddings [T, L, 256] fp32 (generate_final_outputs, vps_temporal_slots.py:144-160).
     want_logits=False (with want_argmax): only the per-pixel slot argmax [T, HW] uint8 is written (returns (None, amax))."""
     lib = _lib.load()
-    _need(feat, "feat", torch.bfloat16, 3)
+    mflag = _map_flag(feat)
+    if mflag and out_bf16:
+        raise ValueError("mask_decode: bf16 logits are not built for an fp16 map")
     _need(embed, "embed", torch.float32, 3)
     _need(bn_scale, "bn_scale", torch.float32, 1)
     _need(bn_shift, "bn_shift", torch.float32, 1)
@@ -119,7 +131,7 @@ def mask_decode(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out_bf16=Fa
     with _on(feat, embed, bn_scale, bn_shift) as ctx:
         rc = lib.svps_mask_decode_fwd(_ptr(feat), _ptr(embed), _ptr(bn_scale), _ptr(bn_shift), float(fg_scale),
                                       float(fg_shift), _ptr(out), _ptr(amax), T, L, HW, D,
-                                      _lib.FLAG_OUT_BF16 if out_bf16 else 0, ctx.stream)
+                                      (_lib.FLAG_OUT_BF16 if out_bf16 else 0) | mflag, ctx.stream)
     _lib.check(rc, "svps_mask_decode_fwd")
     return (out, amax) if want_argmax else out
 
@@ -185,7 +197,8 @@ def level_fuse(cur, prev, wc, bc, H, W):
     """K4: fused level map [T, H*W, 256] bf16 = conv1x1(cat(bilinear_x2(prev), cur)) (+ level-0 form when
     prev is None). cur: [T, 128, H, W] fp32 (NCHW, the reference's layout) or [T, H*W, 128] bf16;
     prev: [T, (H/2)*(W/2), 256] bf16; wc [256, 384] bf16; bc [256] fp32.
-    (MultiScaleDynamicMaskHead.forward lines 171-188 of the reference's dynamic_mask_head.py.)"""
+    (MultiScaleDynamicMaskHead.forward lines 171-188 of the reference's dynamic_mask_head.py.)
+    wc (and prev) fp16: the fp16 form - operands, previous level and result fp16 (cur must be the fp32 NCHW map)."""
     lib = _lib.load()
     if not isinstance(cur, torch.Tensor) or not cur.is_cuda:
         raise RuntimeError("level_fuse: GPU tensors only; there is no CPU fallback")
@@ -201,18 +214,21 @@ def level_fuse(cur, prev, wc, bc, H, W):
         if cur.shape != (T, H * W, 128):
             raise ValueError(f"cur {tuple(cur.shape)} != [T, {H * W}, 128]")
         nchw = 0
-    _need(wc, "wc", torch.bfloat16, 2)
+    mdt = torch.float16 if wc.dtype == torch.float16 else torch.bfloat16
+    if mdt == torch.float16 and not nchw:
+        raise ValueError("level_fuse: the fp16 form takes the fp32 NCHW incoming map")
+    _need(wc, "wc", mdt, 2)
     _need(bc, "bc", torch.float32, 1)
     if wc.shape != (256, 384):
         raise ValueError("wc must be [256, 384]")
     if prev is not None:
-        _need(prev, "prev", torch.bfloat16, 3)
+        _need(prev, "prev", mdt, 3)
         if prev.shape != (T, (H // 2) * (W // 2), 256) or H % 2 or W % 2:
             raise ValueError(f"prev {tuple(prev.shape)} does not match an {H}x{W} level")
-    out = torch.empty((T, H * W, 256), dtype=torch.bfloat16, device=cur.device)
+    out = torch.empty((T, H * W, 256), dtype=mdt, device=cur.device)
     with _on(cur, prev, wc, bc) as ctx:
-        _lib.check(lib.svps_level_fuse_fwd(_ptr(cur), nchw, _ptr(prev), _ptr(wc), _ptr(bc), _ptr(out), T, H, W,
-                                           ctx.stream), "svps_level_fuse_fwd")
+        _lib.check(lib.svps_level_fuse_fwd(_ptr(cur), nchw | (2 if mdt == torch.float16 else 0), _ptr(prev), _ptr(wc), _ptr(bc),
+                                           _ptr(out), T, H, W, ctx.stream), "svps_level_fuse_fwd")
     return out
 
 
@@ -289,7 +305,7 @@ def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     (MaskDynamicConv.retr_pos_tables), or None. Returns aux [T, HW, 8] fp16 = one 16-byte row per pixel:
     {1, hi sigma_v, lo sigma_v, 0} fp16, {rstd_k, rstd_v} as raw fp32 (retr_stats_unpack gives the two as fp32 views)."""
     lib = _lib.load()
-    _need(feat, "feat", torch.bfloat16, 3)
+    mflag = _map_flag(feat)
     T, HW, D = feat.shape
     if HW != H * W:
         raise ValueError("feat rows != H*W")
@@ -309,7 +325,7 @@ def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat.device)
     with _on(feat, ytab, xtab, rk, rbk, rv, rbv) as ctx:
         rc = lib.svps_retr_stats_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(rk), _ptr(rbk), float(eps_k), _ptr(rv), _ptr(rbv),
-                                     float(eps_v), _ptr(aux), T, H, W, D, ctx.stream)
+                                     float(eps_v), _ptr(aux), T, H, W, D, mflag, ctx.stream)
     _lib.check(rc, "svps_retr_stats_fwd")
     return aux
 
@@ -318,7 +334,7 @@ def retr_stats_tight(feat, H, W, pos_proj, rk_hi, rk_lo, rbk, eps_k, rv_hi, rv_l
     """K3t (csrc/retr_stats_t.hip): retr_stats with both factors as fp16 hi + lo (hi + lo = R to 22 bits): rstd_k, rstd_v to ~2e-7
     relative instead of ~3e-5 / ~5e-5 - the statistics of the fused retriever's precision mode. Same aux rows."""
     lib = _lib.load()
-    _need(feat, "feat", torch.bfloat16, 3)
+    mflag = _map_flag(feat)
     T, HW, D = feat.shape
     if HW != H * W:
         raise ValueError("feat rows != H*W")
@@ -338,7 +354,7 @@ def retr_stats_tight(feat, H, W, pos_proj, rk_hi, rk_lo, rbk, eps_k, rv_hi, rv_l
     aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat.device)
     with _on(feat, ytab, xtab, rk_hi, rk_lo, rbk, rv_hi, rv_lo, rbv) as ctx:
         rc = lib.svps_retr_stats_tight_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(rk_hi), _ptr(rk_lo), _ptr(rbk), float(eps_k),
-                                           _ptr(rv_hi), _ptr(rv_lo), _ptr(rbv), float(eps_v), _ptr(aux), T, H, W, D, ctx.stream)
+                                           _ptr(rv_hi), _ptr(rv_lo), _ptr(rbv), float(eps_v), _ptr(aux), T, H, W, D, mflag, ctx.stream)
     _lib.check(rc, "svps_retr_stats_tight_fwd")
     return aux
 
@@ -354,7 +370,7 @@ def retr_stats_level(feat, H, W, stages):
     (pos_proj = (Ty [H, 256], Tx [W, 256]) or None). Returns the list of aux tensors [T, HW, 8] fp16."""
     import ctypes
     lib = _lib.load()
-    _need(feat, "feat", torch.bfloat16, 3)
+    mflag = _map_flag(feat)
     T, HW, D = feat.shape
     if HW != H * W:
         raise ValueError("feat rows != H*W")
@@ -387,7 +403,7 @@ def retr_stats_level(feat, H, W, stages):
     fl = lambda i: (ctypes.c_float * n)(*[float(st[i]) for st in stages])
     with _on(feat, *keep) as ctx:
         rc = lib.svps_retr_stats_level_fwd(_ptr(feat), n, arr(tys), arr(txs), arr(rks), arr(rbks), fl(3), arr(rvs), arr(rbvs), fl(6),
-                                           arr(auxs), T, H, W, D, ctx.stream)
+                                           arr(auxs), T, H, W, D, mflag, ctx.stream)
     _lib.check(rc, "svps_retr_stats_level_fwd")
     return auxs
 
@@ -413,7 +429,7 @@ def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0, tight=False):
     lib = _lib.load()
     _need(qh, "qh", torch.float16, 3)
     _need(ql, "ql", torch.float16, 3)
-    _need(feat, "feat", torch.bfloat16, 3)
+    mflag = _map_flag(feat)
     _need(aux, "aux", torch.float16, 3)
     for name, x in (("cy", cy), ("cx", cx)):
         _need(x, name, torch.float32, 3)
@@ -427,6 +443,8 @@ def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0, tight=False):
         raise ValueError("shape mismatch")
     # RETR_ATTN_FORM "w4" and L <= 128: the four-wave form (csrc/retr_attn4.hip); `chunks` then counts chunks per column strip
     four = L <= 128 and RETR_ATTN_FORM == "w4" and not tight
+    if four and mflag:
+        raise NotImplementedError("the four-wave form of the fused retriever takes bf16 maps only")
     if tight and L > 128:
         raise NotImplementedError("the precision form of the fused retriever (P * rstd_v as fp16 hi + lo) covers L <= 128")
     ws_fn, fwd, name = ((lib.svps_retr_attn4_workspace_bytes, lib.svps_retr_attn4_fwd, "svps_retr_attn4_fwd") if four else
@@ -436,8 +454,12 @@ def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0, tight=False):
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)
     out = torch.empty((T, L, 272), dtype=torch.float32, device=feat.device)
     with _on(qh, ql, cy, cx, c3, feat, aux) as ctx:
-        rc = fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(aux), _ptr(ws), ws_bytes,
-                 _ptr(out), T, L, H, W, D, chunks, ctx.stream)
+        if four:
+            rc = fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(aux), _ptr(ws), ws_bytes,
+                     _ptr(out), T, L, H, W, D, chunks, ctx.stream)
+        else:
+            rc = fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(aux), _ptr(ws), ws_bytes,
+                     _ptr(out), T, L, H, W, D, chunks, mflag, ctx.stream)
     _lib.check(rc, name)
     return out
 

@@ -341,8 +341,10 @@ class MaskDynamicConv(nn.Module):
                                       self.norm_k.bias, self.norm_k.eps, wvT, self.to_v.bias, self.norm_v.weight,
                                       self.norm_v.bias, self.norm_v.eps)
             return ops.slot_attn_f32(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
+        if feat_pm.dtype == torch.float16 and self.retriever != "fused":
+            raise NotImplementedError("fp16 level maps (map_dtype='fp16') go with the fused retriever")
         if self.retriever == "fused":
-            if self.range_check and float(feat_pm.abs().max()) > FP16_MAX:
+            if self.range_check and feat_pm.dtype != torch.float16 and float(feat_pm.abs().max()) > FP16_MAX:
                 if not getattr(MaskDynamicConv, "_warned_range", False):
                     MaskDynamicConv._warned_range = True
                     import warnings
@@ -639,6 +641,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
             raise NotImplementedError("the released configs use merge_operation='concat'")
         self.per_dh_num_heads = list(per_dh_num_heads)
         self.dh_dim = dh_dim
+        self.map_dtype = "bf16"                          # storage of the fused level maps: "bf16" or "fp16" (set_map_dtype)
         self.trans_in_dim = trans_in_dim
         self.apply_temporal_query_atten_stages = apply_temporal_query_atten_stages
         self.other_config = other_config
@@ -717,11 +720,23 @@ class MultiScaleDynamicMaskHead(nn.Module):
     # ------------------------------------------------------------------------------------------
     def _conv_weights(self):
         conv = self.conv_trans.conv
-        key = (conv.weight._version, conv.weight.data_ptr())
+        mdt = torch.float16 if getattr(self, "map_dtype", "bf16") == "fp16" else BF16
+        key = (conv.weight._version, conv.weight.data_ptr(), mdt)
         if getattr(self, "_cw_key", None) != key:
-            self._cw = conv.weight.detach().reshape(self.dh_dim, self.trans_in_dim).to(BF16).contiguous()
+            self._cw = conv.weight.detach().reshape(self.dh_dim, self.trans_in_dim).to(mdt).contiguous()
             self._cw_key = key
         return self._cw, conv.bias
+
+    def set_map_dtype(self, dtype):
+        """bf16 mode: storage of the fused level maps (and operand type of the level-fusion conv). "bf16" (default, BASELINE's
+        storage) or "fp16": the same 16 bits with three more of mantissa - K4 runs its conv and its bilinear blend on fp16 operands,
+        the statistics / retriever kernels skip their bf16 -> fp16 pass, K2 runs fp16 MFMAs. The maps then sit 8x closer to the
+        reference's fp32 maps (what limits the distance of the whole head from the reference's own outputs); |f| must stay below
+        65 504 (as for the fused retriever). Fused retriever only (the kv form and the four-wave form take bf16 maps)."""
+        if dtype not in ("bf16", "fp16"):
+            raise ValueError(f"map_dtype must be 'bf16' or 'fp16', not {dtype!r}")
+        self.map_dtype = dtype
+        return self
 
     def fuse_level(self, cur, prev_pm, hw):
         """K4 (:171-188). cur [T, 128, H, W] fp32 (the reference's layout) or [T, H*W, 128] bf16;
@@ -732,8 +747,10 @@ class MultiScaleDynamicMaskHead(nn.Module):
             wT = _cached(self, "cwT", [conv.weight], lambda: conv.weight.reshape(self.dh_dim, self.trans_in_dim).t().contiguous())
             return ops.level_fuse_f32(cur.float().contiguous(), prev_pm, wT, conv.bias, hw[0], hw[1])
         wc, bc = self._conv_weights()
-        if cur.dtype not in (torch.float32, BF16):
+        if cur.dtype not in (torch.float32, BF16) or (wc.dtype == torch.float16 and cur.dtype != torch.float32):
             cur = cur.float()
+        if wc.dtype == torch.float16 and cur.dim() != 4:
+            raise NotImplementedError("map_dtype='fp16' takes the incoming maps as [T, 128, H, W] (NCHW)")
         return ops.level_fuse(cur.contiguous(), prev_pm, wc, bc, hw[0], hw[1])
 
     def forward_clip(self, feats, init_slots, pos_tabs, hws=None, clip_frames=None):
@@ -768,7 +785,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
             f_pm = self.fuse_level(feats[i], prev, (h, w))
             series = getattr(self, f"head_series_{i}")
             mdcs = [stage.inst_interact for stage in series]
-            if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype == BF16
+            if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16)
                     and all(m.precision != "fp32" and m.retriever == "fused" and not m.tight_stats for m in mdcs)):
                 # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats2.hip;
                 # measured 195 against 2 x 116 us at the finest level); each stage's retriever picks its rows up in forward_fused.

@@ -116,3 +116,47 @@ def test_level_fuse_is_bitwise_reproducible(cuda, T, H, W):
         runs.append(o.view(torch.int16).cpu())
         del o
     assert all(torch.equal(runs[0], r) for r in runs[1:])
+
+
+@pytest.mark.parametrize("T,H,W,level0", [(2, 8, 16, True), (2, 16, 32, False), (2, 68, 120, False), (9, 32, 64, False), (3, 64, 128, False)])
+def test_level_fuse_fp16_maps_match_oracle(cuda, T, H, W, level0):
+    """map_dtype = "fp16": incoming map, previous level, conv weight and result as fp16 (three more mantissa bits in the same bytes)
+    against the oracle under the fp16 storage policy: every element within one fp16 ulp; and 8x closer to the unrounded conv than
+    the bf16 form."""
+    import torch
+    from slotvps_amd import ops
+    seed = 31 * H + W + T
+    rng = np.random.default_rng(seed)
+    params = synth.make_params({"conv_trans.conv.weight": (256, 384, 1, 1), "conv_trans.conv.bias": (256,)}, seed)
+    wc = params["conv_trans.conv.weight"].reshape(256, 384)
+    bc = params["conv_trans.conv.bias"]
+    cur = np.stack([synth.smooth_features(rng, 128, H, W) for _ in range(T)])
+    prev_pm = None
+    if not level0:
+        prev_pm = np.stack([synth.smooth_features(rng, 256, H // 2, W // 2).reshape(256, -1).T * 1.5 for _ in range(T)])
+    st = orc.Storage.fused_fp16_policy()
+    t_prev16 = torch.from_numpy(prev_pm).to(cuda).to(torch.float16).contiguous() if prev_pm is not None else None
+    t_prevbf = to_bf16_t(prev_pm, cuda) if prev_pm is not None else None
+    t_cur = torch.from_numpy(cur).to(cuda)
+    twc = torch.from_numpy(wc).to(cuda)
+    out16 = ops.level_fuse(t_cur, t_prev16, twc.to(torch.float16).contiguous(), torch.from_numpy(bc).to(cuda), H, W)
+    outbf = ops.level_fuse(t_cur, t_prevbf, twc.to(torch.bfloat16).contiguous(), torch.from_numpy(bc).to(cuda), H, W)
+    again = ops.level_fuse(t_cur, t_prev16, twc.to(torch.float16).contiguous(), torch.from_numpy(bc).to(cuda), H, W)
+    torch.cuda.synchronize()
+    assert out16.dtype == torch.float16 and torch.equal(out16, again)
+    o16, obf = out16.float().cpu().numpy(), bf16_t_to_np(outbf)
+    e16 = ebf = 0.0
+    for t in range(T):
+        prev16 = t_prev16[t].float().cpu().numpy().T.reshape(256, H // 2, W // 2) if not level0 else None
+        ref = orc.fuse_level(cur[t].astype(np.float32), prev16, wc, bc, st)
+        d = np.abs(o16[t] - ref)
+        ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.maximum(np.abs(o16[t]), np.abs(ref)), 2.0 ** -14))) - 10)
+        ij = np.unravel_index(np.argmax(d - ulp), d.shape)
+        assert (d <= ulp * 1.001 + 1e-5).all(), f"more than one fp16 ulp (+ 1e-5: fp32 summation order near zero) off at {ij}: got {o16[t][ij]!r} ref {ref[ij]!r}"
+        assert (d > 0).mean() < 0.02
+        exact = orc.fuse_level(cur[t].astype(np.float64), None if level0 else prev_pm[t].T.reshape(256, H // 2, W // 2).astype(np.float64),
+                               wc.astype(np.float64), bc.astype(np.float64), orc.Storage.exact())
+        e16 = max(e16, float(np.abs(o16[t] - exact).max()))
+        ebf = max(ebf, float(np.abs(obf[t] - exact).max()))
+    print(f"\n[level_fuse fp16 T{T} {H}x{W} level0={level0}] against the unrounded conv: fp16 form {e16:.2e}, bf16 form {ebf:.2e}")
+    assert e16 < 0.25 * ebf

@@ -130,3 +130,33 @@ def test_argmax_only_mode_follows_the_sign_of_the_foreground_scale(cuda, fg_scal
     assert float(diff.float().mean()) < 1e-3
     if bool(diff.any()):
         assert float(((a - b).abs() / a.abs().clamp_min(1e-30))[diff].max()) <= 2.5e-7
+
+
+@pytest.mark.parametrize("T,L,HW", [(2, 100, 2048), (1, 200, 2040), (2, 100, 2145), (20, 100, 6144)])
+def test_mask_decode_fp16_map(cuda, T, L, HW):
+    """An fp16 fused map (MultiScaleDynamicMaskHead.map_dtype = "fp16"): fp16 MFMAs, the slot operand as fp16 hi + lo; against the
+    oracle on the same fp16 values <= 1e-4, argmax-only mode included."""
+    import torch
+    from slotvps_amd import ops
+    rng = np.random.default_rng(L + HW)
+    feat = rng.standard_normal((T, HW, 256)).astype(np.float32)
+    emb = np.maximum(rng.standard_normal((T, L, 256)), 0).astype(np.float32)
+    scale, shift = orc.bn_eval_affine(rng.uniform(0.5, 1.5, 256), 0.2 * rng.standard_normal(256), 0.3 * rng.standard_normal(256), rng.uniform(0.5, 2.0, 256))
+    fgs, fgb = orc.bn_eval_affine(np.float64(0.37), np.float64(-0.11), np.float64(0.8), np.float64(2.5))
+    tf = torch.from_numpy(feat).to(cuda).to(torch.float16).contiguous()
+    te = torch.from_numpy(emb).to(cuda)
+    ts, th = torch.from_numpy(scale.astype(np.float32)).to(cuda), torch.from_numpy(shift.astype(np.float32)).to(cuda)
+    out, amax = ops.mask_decode(tf, te, ts, th, float(fgs), float(fgb), want_argmax=True)
+    torch.cuda.synchronize()
+    ff = tf.float().cpu().numpy().astype(np.float64)
+    s32, h32 = scale.astype(np.float32).astype(np.float64), shift.astype(np.float32).astype(np.float64)
+    worst = 0.0
+    for t in range(T):
+        ref = orc.mask_decode(ff[t], emb[t].astype(np.float64), s32, h32, float(np.float32(fgs)), float(np.float32(fgb)))
+        worst = max(worst, float(np.abs(out[t].cpu().numpy() - ref).max()))
+        np.testing.assert_array_equal(amax[t].cpu().numpy(), orc.slot_argmax(out[t].cpu().numpy()))
+    print(f"K2 fp16 map T={T} L={L} HW={HW}: {worst:.2e}")
+    assert worst <= TOL, worst
+    if HW % 4 == 0:
+        none, amax_only = ops.mask_decode(tf, te, ts, th, float(fgs), float(fgb), want_argmax=True, want_logits=False)
+        assert none is None and float((amax_only != amax).float().mean()) < 1e-3

@@ -299,3 +299,40 @@ def test_tight_precision_form(cuda):
     assert worst["retriever tight"] <= 1.5e-4, worst           # measured 8.2e-5 (1.27e-4 before the probabilities carried 2^7)
     assert worst["retriever balanced"] <= 3e-4, worst          # measured 2.0e-4: what the fp16 QR factors of K3' / K3'' leave (rstd_v 7e-5 relative)
     assert worst["retriever fast"] <= 2e-3, worst
+
+
+@pytest.mark.parametrize("H,W,L", [(12, 40, 100), (32, 64, 100), (9, 33, 37), (16, 64, 200)])
+def test_fp16_map_equals_bf16_map_on_bf16_values(cuda, H, W, L):
+    """An fp16 level map (MultiScaleDynamicMaskHead.map_dtype = "fp16") makes the statistics / retriever kernels skip their bf16 -> fp16
+    pass in LDS. With map values that are exactly representable in both formats the LDS tiles are the same bits: the aux rows of K3',
+    K3'', K3t and the retriever's result must be bit-identical to the bf16-map run (every form)."""
+    import torch
+    from slotvps_amd import ops
+    from slotvps_amd.slot_head import MaskDynamicConv
+    rng = np.random.default_rng(H * W + L)
+    torch.manual_seed(5)
+    m = MaskDynamicConv(256).to(cuda).eval()
+    m2 = MaskDynamicConv(256).to(cuda).eval()
+    feat = orc.round_bf16(rng.standard_normal((2, H * W, 256)).astype(np.float32))
+    feat[np.abs(feat) < 2.0 ** -13] = 0.0                  # below fp16's normal range a bf16 value is not an fp16 value (or a subnormal one)
+    slots = torch.from_numpy(rng.standard_normal((2, L, 256)).astype(np.float32)).to(cuda)
+    tabs = ops.pos_embed_sine_tables(H, W, 256, cuda)
+    fb = torch.from_numpy(feat).to(cuda).to(torch.bfloat16)
+    fh = torch.from_numpy(feat).to(cuda).to(torch.float16)
+    assert torch.equal(fb.float(), fh.float())
+    with torch.no_grad():
+        c = m._fused_consts()
+        args = m.stats_args(tabs)
+        bits = lambda t: t.view(torch.int16)                   # the aux rows carry raw fp32 words: compare bits, not fp16 values (NaN patterns)
+        assert torch.equal(bits(ops.retr_stats(fb, H, W, *args)), bits(ops.retr_stats(fh, H, W, *args)))
+        pair_b = ops.retr_stats_level(fb, H, W, [m.stats_args(tabs), m2.stats_args(tabs)])
+        pair_h = ops.retr_stats_level(fh, H, W, [m.stats_args(tabs), m2.stats_args(tabs)])
+        assert all(torch.equal(bits(a), bits(b)) for a, b in zip(pair_b, pair_h))
+        pp, rk, rbk, ek, rv, rbv, ev = args
+        assert torch.equal(bits(ops.retr_stats_tight(fb, H, W, pp, rk, c["rk_lo"], rbk, ek, rv, c["rv_lo"], rbv, ev)),
+                           bits(ops.retr_stats_tight(fh, H, W, pp, rk, c["rk_lo"], rbk, ek, rv, c["rv_lo"], rbv, ev)))
+        for mode in (("fast", "balanced", "tight") if L <= 128 else ("fast",)):
+            m.tight_stats = mode == "tight"
+            m.precise_query_p = mode == "balanced"
+            assert torch.equal(m.forward_fused(slots, fb, (H, W), tabs), m.forward_fused(slots, fh, (H, W), tabs)), mode
+        m.tight_stats = m.precise_query_p = False
