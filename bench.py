@@ -300,6 +300,10 @@ def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, prec
         r1.head.set_precision("fp32")
     elif precision in ("tight", "balanced"):
         r1.head.set_statistics(precision)
+    elif precision == "fp16_maps":
+        r1.head.set_map_dtype("fp16")
+    elif precision == "fp16_maps_balanced":
+        r1.head.set_map_dtype("fp16").set_statistics("balanced")
     r1.load_clip(r1.random_clip(7))
     for _ in range(2):
         r1.run()
@@ -671,6 +675,20 @@ def main():
                 line["balanced_form"] = bl
             except Exception as e:
                 line["balanced_form"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+        if world == 1 and a.exact_leg and a.slots <= 128:
+            for key, prec, what in (
+                    ("fp16_level_maps", "fp16_maps",
+                     "head.set_map_dtype('fp16'): the fused level maps and the operands of the level-fusion conv as fp16 instead of bf16 (the same "
+                     "bytes, three more mantissa bits; |f| < 65 504) - against the REFERENCE's own fp32 outputs the mask logits measure 0.8 - 1.0e-4 "
+                     "instead of 0.6 - 1.0e-3, the slot argmax 100 % instead of 99.6 % (free-running head 97 - 98 % instead of 87 - 91 %; "
+                     "tests/test_head_gpu.py::test_fp16_level_maps_against_the_reference); same step, hipGraph"),
+                    ("fp16_level_maps_balanced", "fp16_maps_balanced", "fp16 level maps with the balanced retriever (hi + lo probabilities); same step, hipGraph")):
+                try:
+                    fl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, precision=prec)
+                    fl["what"] = what
+                    line[key] = fl
+                except Exception as e:
+                    line[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and a.exact_leg:
             note("exact-mode leg (fp32 storage and arithmetic, one clip per launch) ...")
             try:

@@ -136,13 +136,15 @@ int svps_kv_project_fwd(const void* feat, const float* pos_y, const float* pos_x
  * frames of a level per launch:
  *     level i > 0:  f_i = conv_trans( cat( interpolate(f_{i-1}, x2, bilinear, align_corners=False), x_i ) )
  *     level 0   :   f_0 = conv_trans( cat( x_0, x_0, x_0 ) )               (prev == NULL)
- *   cur   the incoming 128-channel map: [T, 128, H, W] fp32 NCHW (cur_is_nchw_f32 != 0, the reference's
+ *   cur   the incoming 128-channel map: [T, 128, H, W] fp32 NCHW (cur_flags & 1, the reference's
  *         layout) or [T, H*W, 128] bf16 pixel-major
  *   prev  [T, (H/2)*(W/2), 256] bf16 pixel-major fused map of the previous (coarser) level, or NULL
  *   wc    [256, 384] bf16 conv_trans weight (row = output channel), bc [256] fp32 bias
  *   out   [T, H*W, 256] bf16 pixel-major
+ *   cur_flags & 2: prev, wc and out are FP16 (needs the fp32 NCHW `cur`): the conv and the bilinear blend run on fp16 operands - the
+ *         same bytes with three more mantissa bits; every consumer of the map then takes SVPS_FLAG_MAP_F16.
  * ------------------------------------------------------------------------------------------- */
-int svps_level_fuse_fwd(const void* cur, int cur_is_nchw_f32, const void* prev, const void* wc,
+int svps_level_fuse_fwd(const void* cur, int cur_flags, const void* prev, const void* wc,
                         const float* bc, void* out, int T, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

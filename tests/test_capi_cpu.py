@@ -39,12 +39,12 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.svps_slot_attn_fwd(one, one, one, one, one, 1e-5, one, 16, one, None, 1, 100, 4096, 256, 1, 0, None) == -3
     assert lib.svps_mask_decode_fwd(one, one, one, one, 1.0, 0.0, one, None, 1, 100, big, 256, 0, None) == -2
     # the round-2 entry points: statistics-fused retriever, K8 with the LayerNorm epilogue, K9
-    assert lib.svps_retr_stats_fwd(None, None, None, None, None, 1e-5, None, None, 1e-5, None, 1, 4, 32, 256, None) == -1
-    assert lib.svps_retr_stats_fwd(one, one, None, one, one, 1e-5, one, one, 1e-5, one, 1, 4, 32, 256, None) == -1      # ty without tx
-    assert lib.svps_retr_stats_fwd(one, None, None, one, one, 1e-5, one, one, 1e-5, one, 1, 4, 32, 128, None) == -2     # D != 256
-    assert lib.svps_retr_attn_fwd(one, one, one, one, one, one, None, one, 1 << 30, one, 1, 100, 4, 32, 256, 0, None) == -1
-    assert lib.svps_retr_attn_fwd(one, one, one, one, one, one, one, one, 1 << 30, one, 1, 257, 4, 32, 256, 0, None) == -2
-    assert lib.svps_retr_attn_fwd(one, one, one, one, one, one, one, one, 16, one, 1, 100, 4, 32, 256, 0, None) == -3   # workspace too small
+    assert lib.svps_retr_stats_fwd(None, None, None, None, None, 1e-5, None, None, 1e-5, None, 1, 4, 32, 256, 0, None) == -1
+    assert lib.svps_retr_stats_fwd(one, one, None, one, one, 1e-5, one, one, 1e-5, one, 1, 4, 32, 256, 0, None) == -1   # ty without tx
+    assert lib.svps_retr_stats_fwd(one, None, None, one, one, 1e-5, one, one, 1e-5, one, 1, 4, 32, 128, 0, None) == -2  # D != 256
+    assert lib.svps_retr_attn_fwd(one, one, one, one, one, one, None, one, 1 << 30, one, 1, 100, 4, 32, 256, 0, 0, None) == -1
+    assert lib.svps_retr_attn_fwd(one, one, one, one, one, one, one, one, 1 << 30, one, 1, 257, 4, 32, 256, 0, 0, None) == -2
+    assert lib.svps_retr_attn_fwd(one, one, one, one, one, one, one, one, 16, one, 1, 100, 4, 32, 256, 0, 2, None) == -3   # workspace too small (flags: fp16 map)
     assert lib.svps_retr_attn_workspace_bytes(1, 100, 4, 32, 0) > 0 and lib.svps_retr_attn_workspace_bytes(0, 100, 4, 32, 0) == 0
     assert lib.svps_slot_gemm_ln(one, one, None, None, None, None, one, 1e-5, 0, one, 8, 256, None) == -1             # no gamma
     assert lib.svps_slot_gemm_ln(one, one, None, None, None, one, one, 1e-5, 0, one, 8, 250, None) == -2              # K % 16
