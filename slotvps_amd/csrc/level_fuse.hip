@@ -40,6 +40,14 @@ struct FuseLds {
 
 // chunk swizzle of the 48-chunk operand rows: XOR on the low four bits keeps chunks inside their
 // 16-chunk group, conflict-free for ds_read_b128 over 16 rows
+// fp32 accumulator -> map element. fp16 maps SATURATE at +-65 504 (an overflow to inf would turn into NaN in every consumer; the bf16
+// form's consumers saturate when they convert the map to fp16 in LDS - same behaviour either way)
+template <typename MT>
+__device__ __forceinline__ MT to_map(float x) {
+    if constexpr (__is_same(MT, _Float16)) x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    return (MT)x;
+}
+
 __device__ __forceinline__ int a_off(int row, int chunk) {
     return row * kFuseRowBytes + (((chunk & ~15) | ((chunk ^ swz(row)) & 15)) * 16);
 }
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
         for (int g = 0; g < 4; ++g) {
             mx4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (MT)acc[4 * g + j];
+            for (int j = 0; j < 4; ++j) o[j] = to_map<MT>(acc[4 * g + j]);
             const int ch0 = 32 * w + 8 * g + 4 * h;
             *reinterpret_cast<mx4*>(ot + r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
         }
@@ -689,7 +697,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 for (int g = 0; g < 4; ++g) {
                     mx4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (MT)acc[b][4 * g + j];
+                    for (int j = 0; j < 4; ++j) o[j] = to_map<MT>(acc[b][4 * g + j]);
                     *reinterpret_cast<mx4*>(ot + r * Lds::kOWRow + (32 * b + 8 * g + 4 * h) * 2) = o;
                 }
             // the wave's own LDS operations complete in order: the read-back sees the writes above

@@ -160,3 +160,18 @@ def test_level_fuse_fp16_maps_match_oracle(cuda, T, H, W, level0):
         ebf = max(ebf, float(np.abs(obf[t] - exact).max()))
     print(f"\n[level_fuse fp16 T{T} {H}x{W} level0={level0}] against the unrounded conv: fp16 form {e16:.2e}, bf16 form {ebf:.2e}")
     assert e16 < 0.25 * ebf
+
+
+def test_level_fuse_fp16_maps_saturate(cuda):
+    """A result beyond fp16's range is stored as +-65 504, not as inf (which every consumer would turn into NaN)."""
+    import torch
+    from slotvps_amd import ops
+    T, H, W = 1, 16, 32
+    cur = torch.full((T, 128, H, W), 3.0e3, device=cuda)
+    cur[:, :, :, ::2] *= -1.0
+    wc = torch.ones((256, 384), device=cuda).to(torch.float16)
+    prev = torch.zeros((T, (H // 2) * (W // 2), 256), dtype=torch.float16, device=cuda)
+    out = ops.level_fuse(cur, prev, wc, torch.zeros(256, device=cuda), H, W).float()
+    assert torch.isfinite(out).all() and float(out.max()) == 65504.0 and float(out.min()) == -65504.0
+    out0 = ops.level_fuse(cur, None, wc, torch.zeros(256, device=cuda), H, W).float()           # level-0 form (first kernel)
+    assert torch.isfinite(out0).all() and float(out0.abs().max()) == 65504.0
