@@ -641,7 +641,10 @@ class MultiScaleDynamicMaskHead(nn.Module):
             raise NotImplementedError("the released configs use merge_operation='concat'")
         self.per_dh_num_heads = list(per_dh_num_heads)
         self.dh_dim = dh_dim
-        self.map_dtype = "bf16"                          # storage of the fused level maps: "bf16" or "fp16" (set_map_dtype)
+        # storage of the fused level maps: "bf16" or "fp16" (set_map_dtype); a config selects it with other_config=dict(map_dtype="fp16")
+        self.map_dtype = "bf16"
+        if isinstance(other_config, dict) and other_config.get("map_dtype") is not None:
+            self.set_map_dtype(other_config["map_dtype"])
         self.trans_in_dim = trans_in_dim
         self.apply_temporal_query_atten_stages = apply_temporal_query_atten_stages
         self.other_config = other_config
