@@ -308,7 +308,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                     f16x4 pl;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float x = e[4 * g + j] * fac;
+                        float x = e[4 * g + j] * fac;
+                        asm volatile("" : "+v"(x));          // ONE fp32 value for both halves (hipcc otherwise rounds hi from the fp32
+                                                             // product and lo from the exact product minus its own hi: v_fma_mixlo_f16)
                         ph[j] = (_Float16)x;
                         pl[j] = (_Float16)(x - (float)ph[j]);
                     }

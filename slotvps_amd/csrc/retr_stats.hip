@@ -403,7 +403,8 @@ __device__ __forceinline__ void retr_stats_role(
         const float vark = totk * (1.f / kD) + eps_k, varv = totv * (1.f / kD) + eps_v;
         const float rstdk = __builtin_amdgcn_rsqf(vark);
         const float rstdv = __builtin_amdgcn_rsqf(varv);
-        const float sigma = varv * rstdv;
+        float sigma = varv * rstdv;
+        asm volatile("" : "+v"(sigma));                                          // one fp32 value for both halves (see retr_attn.hip, p2_store)
         const _Float16 sh = (_Float16)sigma;                                     // FP16 hi + lo (K1' runs its value side in fp16)
         const _Float16 sl = (_Float16)(sigma - (float)sh);
         const _Float16 one = (_Float16)1.0f;

@@ -397,7 +397,8 @@ __device__ __forceinline__ void role(const Args& A) {
             const float totk = (fk[0] + fk[1]) + (fk[2] + fk[3]), totv = (fv[0] + fv[1]) + (fv[2] + fv[3]);
             const float vark = totk * (1.f / kD) + eps_k, varv = totv * (1.f / kD) + eps_v;
             const float rstdk = __builtin_amdgcn_rsqf(vark), rstdv = __builtin_amdgcn_rsqf(varv);
-            const float sigma = varv * rstdv;
+            float sigma = varv * rstdv;
+            asm volatile("" : "+v"(sigma));                                  // one fp32 value for both halves (see retr_attn.hip, p2_store)
             const _Float16 sh = (_Float16)sigma;
             const _Float16 sl = (_Float16)(sigma - (float)sh);
             const _Float16 one = (_Float16)1.0f;

@@ -137,7 +137,8 @@ __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem
                 if (!a.value) {
                     *reinterpret_cast<float*>(row + 8) = rstd;
                 } else {
-                    const float sigma = var * rstd;
+                    float sigma = var * rstd;
+                    asm volatile("" : "+v"(sigma));                  // one fp32 value for both halves (see retr_attn.hip, p2_store)
                     const _Float16 sh = (_Float16)sigma, sl = (_Float16)(sigma - (float)sh), one = (_Float16)1.0f;
                     const uint32_t w0 = (uint32_t)__builtin_bit_cast(uint16_t, one) | ((uint32_t)__builtin_bit_cast(uint16_t, sh) << 16);
                     const uint32_t w1 = (uint32_t)__builtin_bit_cast(uint16_t, sl);
