@@ -413,13 +413,15 @@ def test_fp16_level_maps_against_the_reference(cuda, tag):
         fg_bn.weight.fill_(float(fg[0])); fg_bn.bias.fill_(float(fg[1]))
         fg_bn.running_mean.fill_(float(fg[2])); fg_bn.running_var.fill_(float(fg[3]))
     res = {}
-    for md in ("bf16", "fp16"):
-        head = build_head(cuda, params).set_retriever("fused").set_map_dtype(md)
+    for md in ("bf16", "fp16", "fp16+balanced"):
+        head = build_head(cuda, params).set_retriever("fused").set_map_dtype(md.split("+")[0])
+        if md.endswith("balanced"):
+            head.set_statistics("balanced")
         with torch.no_grad():
             tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
             pos_tabs = [ops.pos_embed_sine_tables(h, w_, 256, cuda) for (h, w_) in sizes]
             logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(slots).to(cuda), pos_tabs)
-            assert fused[3].dtype == (torch.float16 if md == "fp16" else torch.bfloat16)
+            assert fused[3].dtype == (torch.float16 if md.startswith("fp16") else torch.bfloat16)
             r_f3 = max(np.abs(fused[3][t].float().cpu().numpy() - z[f"{tag}_fused3_{t}"]).max() for t in range(T))
             tf_err, sidx = [], 0
             for lvl, n in enumerate(cfg["per_level_stages"]):
