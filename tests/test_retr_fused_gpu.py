@@ -102,10 +102,11 @@ def test_fused_retriever_matches_float64_oracle(cuda, T, H, W, L, pos):
     assert worst <= 2e-3
 
 
+@pytest.mark.parametrize("map_dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("name,T,H,W,L", [("R50 finest level, BASELINE config 1", 5, 256, 512, 100),
                                           ("VIPER finest level, BASELINE config 4", 10, 272, 480, 200),
                                           ("VIPER level 2 (width no multiple of the tile)", 10, 136, 240, 200)])
-def test_full_size_sum_over_slots_properties(cuda, name, T, H, W, L):
+def test_full_size_sum_over_slots_properties(cuda, name, T, H, W, L, map_dtype):
     """Size-independent properties at the BASELINE sizes (the oracle does not finish there in seconds). The softmax runs
     over slots, so every pixel's column sums to one:
         sum_l A_l = sum_p rstd_v(p) f_p      sum_l s1_l = sum_p rstd_v(p)      sum_l s0_l = HW
@@ -115,7 +116,7 @@ def test_full_size_sum_over_slots_properties(cuda, name, T, H, W, L):
     m, _ = make_module(cuda, 3)
     g = torch.Generator(device=cuda).manual_seed(5)
     HW = H * W
-    feat = torch.randn((T, HW, 256), generator=g, device=cuda).to(torch.bfloat16)
+    feat = torch.randn((T, HW, 256), generator=g, device=cuda).to(torch.float16 if map_dtype == "fp16" else torch.bfloat16)   # fp16 level maps: no conversion pass
     slots = torch.randn((T, L, 256), generator=g, device=cuda)
     tabs = ops.pos_embed_sine_tables(H, W, 256, cuda)
     c = m._fused_consts()
