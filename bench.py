@@ -705,6 +705,12 @@ def main():
                 vp = side_leg(a, dev, 10, 1088, 1920, 200, 24, 8, 3)
                 vp["what"] = "BASELINE config 5 geometry on one GPU: 1088x1920 (1080 padded) T=10 clips, 200 slots, 24 classes, 8 clips stacked per launch, hipGraph"
                 line["other_configs"] = {"viper_1088x1920_T10_L200": vp}
+                try:
+                    vh = side_leg(a, dev, 10, 1088, 1920, 200, 24, 8, 3, precision="fp16_maps")
+                    vh["what"] = "the same with fp16 level maps (head.set_map_dtype('fp16'))"
+                    line["other_configs"]["viper_1088x1920_T10_L200_fp16_level_maps"] = vh
+                except Exception as e:
+                    line["other_configs"]["viper_1088x1920_T10_L200_fp16_level_maps"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
             except Exception as e:
                 line["other_configs"] = {"viper_1088x1920_T10_L200": {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}}
         if a.whole_detector and world == 1:
