@@ -360,7 +360,7 @@ class MaskDynamicConv(nn.Module):
     def forward(self, pro_features, features, pos, gt_non_void_mask=None):
         assert gt_non_void_mask is None
         n, c, h, w = features.shape
-        store = torch.float32 if self.precision == "fp32" else BF16
+        store = torch.float32 if self.precision == "fp32" else (torch.float16 if getattr(self, "map_dtype", "bf16") == "fp16" else BF16)
         feat_pm = features.permute(0, 2, 3, 1).reshape(n, h * w, c).to(store).contiguous()
         return self.forward_pm(pro_features.float(), feat_pm, (h, w), pos_tables_from_map(pos))
 
@@ -615,7 +615,7 @@ class MaskRCNNHead(nn.Module):
         assert pad_mask is None and query_pos is None and gt_non_void_mask is None
         T = len(features)
         _, c, h, w = features[0].shape
-        store = torch.float32 if self.precision == "fp32" else BF16
+        store = torch.float32 if self.precision == "fp32" else (torch.float16 if getattr(self, "map_dtype", "bf16") == "fp16" else BF16)
         feat_pm = torch.cat(features, 0).permute(0, 2, 3, 1).reshape(T, h * w, c).to(store).contiguous()
         tabs = pos_tables_from_map(pos[0]) if pos is not None else None
         logits, emb = self.forward_pm(torch.cat(mask_query, 0).float(), feat_pm, (h, w), tabs, stage_enable)
@@ -738,6 +738,9 @@ class MultiScaleDynamicMaskHead(nn.Module):
         65 504 (as for the fused retriever). Fused retriever only (the kv form and the four-wave form take bf16 maps)."""
         if dtype not in ("bf16", "fp16"):
             raise ValueError(f"map_dtype must be 'bf16' or 'fp16', not {dtype!r}")
+        for m in self.modules():                         # the stages' reference-signature entry points store their maps the same way
+            if hasattr(m, "precision"):
+                m.map_dtype = dtype
         self.map_dtype = dtype
         return self
 

@@ -196,12 +196,13 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     assert same_free >= SAME_FREE_MIN[form], same_free          # free-running: seven stages of bf16-map rounding through sharp softmaxes
 
 
-def test_reference_signature_roundtrip(cuda):
-    """The reference-style list-of-frames call returns the reference's structure."""
+@pytest.mark.parametrize("map_dtype", ["bf16", "fp16"])
+def test_reference_signature_roundtrip(cuda, map_dtype):
+    """The reference-style list-of-frames call returns the reference's structure (with either storage of the level maps)."""
     import torch
     from slotvps_amd.position_encoding import PositionEmbeddingSine, nested_tensor_from_tensor_list
     params = synth.make_params(synth.head_shapes(), 7)
-    head = build_head(cuda, params)
+    head = build_head(cuda, params).set_map_dtype(map_dtype)
     T, H, W, L = 2, 64, 64, 100
     feats = synth.make_clip_features(8, T, H, W)
     pe = PositionEmbeddingSine(128, normalize=True)
@@ -214,6 +215,12 @@ def test_reference_signature_roundtrip(cuda):
     assert tuple(embeds[1].shape) == (7, 1, L, 256)
     assert tuple(fused[0][3].shape) == (1, 256, 16, 16) and tuple(init[0].shape) == (1, L, 256)
     assert torch.isfinite(embeds[0]).all()
+    # a stage through its own reference-signature entry point (MaskRCNNHead.forward): the map is stored the way the head stores it
+    stage = head.head_series_3[0]
+    with torch.no_grad():
+        lg, em, _, _ = stage(features=[fused[t][3] for t in range(T)], mask_query=[embeds[t][4] for t in range(T)], pad_mask=None,
+                             pos=[pos[t][3] for t in range(T)])
+    assert len(lg) == T and tuple(em[0].shape) == (1, L, 256) and torch.isfinite(em[0]).all()
 
 
 def test_head_rejects_cpu():
