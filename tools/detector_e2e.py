@@ -14,12 +14,14 @@ ap.add_argument("--frames", type=int, default=0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--profile-tower", type=int, default=0)
+ap.add_argument("--map-dtype", default="bf16", help="storage of the fused level maps: bf16 or fp16 (head.set_map_dtype)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = Config.fromfile(a.config)
 torch.manual_seed(0)
 det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
 det.use_graph = bool(a.graph)
+det.image_model.dynamic_mask_head.set_map_dtype(a.map_dtype)
 T = a.frames or cfg.clip["frames"]
 H, W = cfg.clip["height"], cfg.clip["width"]
 L = det.image_model.init_mask_query.weight.shape[0]
@@ -55,7 +57,7 @@ with torch.no_grad():
     det.trunk_bf16 = True
     t_all16, _ = timed(lambda: det.clip_test(imgs, metas))
     det.trunk_bf16 = False
-print(json.dumps({"config": os.path.basename(a.config), "backbone": type(im.backbone).__name__, "clip": [T, H, W], "slots": L,
+print(json.dumps({"config": os.path.basename(a.config), "map_dtype": a.map_dtype, "backbone": type(im.backbone).__name__, "clip": [T, H, W], "slots": L,
                   "frames_per_s": round(T / t_all * 1e3, 2), "ms_per_clip": round(t_all, 1), "trunk_ms": round(t_trunk, 1),
                   "backbone_ms": round(t_bb, 1), "fpn_ms": round(t_neck, 1), "semantic_tower_ms": round(t_ups, 1),
                   "slot_head_ms": round(t_head, 1), "post_process_and_tracker_ms": round(t_all - t_trunk - t_head, 1),
