@@ -660,7 +660,7 @@ def main():
             try:
                 tl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, precision="tight")
                 tl["what"] = ("head.set_statistics('tight'): the fused retriever's precision form - QR factors of both LayerNorm statistics and "
-                              "P * rstd_v as fp16 hi + lo, query side in fp32 GEMMs - agrees with a float64 evaluation of the reference's "
+                              "P * rstd_v as fp16 hi + lo - agrees with a float64 evaluation of the reference's "
                               "retriever on the same bf16 map to 3e-5 ... 8e-5 (default form: 0.7e-3 ... 1.7e-3; "
                               "tests/test_retr_fused_gpu.py::test_tight_precision_form); same step, hipGraph")
                 line["precision_form"] = tl
@@ -669,8 +669,8 @@ def main():
         if world == 1 and a.exact_leg and a.slots <= 128:
             try:
                 bl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, precision="balanced")
-                bl["what"] = ("head.set_statistics('balanced'): the default statistics kernels, P * rstd_v as fp16 hi + lo and the query side in "
-                              "fp32 GEMMs - 2.0e-4 against the float64 evaluation of the reference's retriever on the same bf16 map "
+                bl["what"] = ("head.set_statistics('balanced'): the default statistics kernels and P * rstd_v as fp16 hi + lo "
+                              "- 1e-4 ... 2.5e-4 against the float64 evaluation of the reference's retriever on the same bf16 map "
                               "(tests/test_retr_fused_gpu.py::test_tight_precision_form); same step, hipGraph")
                 line["balanced_form"] = bl
             except Exception as e:

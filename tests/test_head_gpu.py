@@ -54,7 +54,7 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     feats = synth.make_clip_features(seed + 1, T, H, W)
     slots = synth.make_slots(seed + 2, L)
     sizes = synth.level_sizes(H, W)
-    balanced = form == "balanced"                   # the fused retriever with hi + lo probabilities and an fp32 query side
+    balanced = form == "balanced"                   # the fused retriever with hi + lo probabilities
     if balanced:
         form = "fused"
     head = build_head(cuda, params).set_retriever(form)
