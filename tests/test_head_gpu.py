@@ -327,8 +327,9 @@ def test_stacked_clips_equal_separate_clips(cuda):
     assert torch.equal(em2[:, :Tc], em[:, :Tc]) and torch.equal(lg2[:, :Tc], lg[:, :Tc])
 
 
+@pytest.mark.parametrize("map_dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("tag", ["T2_64x128", "T3_64x64"])
-def test_free_running_bf16_head_to_panoptic_ids(cuda, tag):
+def test_free_running_bf16_head_to_panoptic_ids(cuda, tag, map_dtype):
     """End-to-end INTEGER parity of the fast (bf16, fused-retriever) path: free-running head -> K2 -> K6 post-process -> relabel
     (vps_temporal_slots.py:284-299 -> 411-435), against the panoptic ids the ORACLE pipeline produces from the REFERENCE's own fp32
     head outputs (class logits + mask logits of the fixture, tests/golden/head_small.npz). Both sides get the same fixed
@@ -351,7 +352,7 @@ def test_free_running_bf16_head_to_panoptic_ids(cuda, tag):
     slots = synth.make_slots(seed + 2, L)
     sizes = synth.level_sizes(H, W)
     h, w = sizes[-1]
-    head = build_head(cuda, params)
+    head = build_head(cuda, params).set_map_dtype(map_dtype)       # 16-bit storage of the level maps: bf16 (default) or fp16
     wb, bb, mu, var = z[f"{tag}_bn"]
     fg = z[f"{tag}_fg"]
     feat_bn = torch.nn.BatchNorm2d(256).to(cuda).eval()
@@ -385,12 +386,14 @@ def test_free_running_bf16_head_to_panoptic_ids(cuda, tag):
     def sem(x):
         return np.where(x >= 1000, x // 1000, x)
     agree_sem = float((sem(ids) == sem(want_ids)).mean())
-    print(f"\n[{tag}] free-running bf16 head -> K2 -> K6 -> relabel vs oracle pipeline on the reference's fp32 outputs: panoptic ids equal on "
+    print(f"\n[{tag}] free-running head ({map_dtype} level maps) -> K2 -> K6 -> relabel vs oracle pipeline on the reference's fp32 outputs: panoptic ids equal on "
           f"{100 * agree:.2f} % of the pixels (semantic class: {100 * agree_sem:.2f} %); segments {len(cls_inds)} vs {len(want_cls)}")
     assert len(np.unique(want_ids)) > 3, "degenerate case: the reference side kept (almost) nothing"
     assert len(cls_inds) == len(want_cls)                     # the same segments survive
     # measured on MI355X: 86.2 % (T2_64x128: seven kept segments, the last stages' embeddings are 0.4 - 1.9 apart) and 98.4 % (T3_64x64)
-    assert agree >= {"T2_64x128": 0.84, "T3_64x64": 0.97}[tag], agree
+    # fp16 level maps: 98.24 % and 99.63 % (the storage rounding of the maps is what separates the free-running head from the reference)
+    bound = {"bf16": {"T2_64x128": 0.84, "T3_64x64": 0.97}, "fp16": {"T2_64x128": 0.97, "T3_64x64": 0.99}}[map_dtype][tag]
+    assert agree >= bound, agree
 
 
 @pytest.mark.parametrize("tag", ["T2_64x128", "T3_64x64"])
