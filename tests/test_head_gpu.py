@@ -453,3 +453,28 @@ def test_fp16_level_maps_against_the_reference(cuda, tag):
               + f"; mask logits {res[md]['mask']:.2e}, slot argmax equal {100 * res[md]['same']:.2f} % (free-running head {100 * res[md]['free']:.2f} %)")
     b16, f16 = res["bf16"], res["fp16"]
     assert f16["map"] <= 0.25 * b16["map"] and f16["tf"] <= 0.4 * b16["tf"] and f16["mask"] <= 0.3 * b16["mask"], (b16, f16)
+
+
+def test_map_dtype_switch_is_checked(cuda):
+    """set_map_dtype accepts "bf16" / "fp16" only; fp16 level maps go with the fused retriever (the kv form's K3 takes bf16 operands)."""
+    import torch
+    from slotvps_amd import ops
+    params = synth.make_params(synth.head_shapes(), 7)
+    head = build_head(cuda, params)
+    with pytest.raises(ValueError):
+        head.set_map_dtype("fp8")
+    head.set_map_dtype("fp16").set_retriever("kv")
+    T, H, W, L = 1, 64, 64, 100
+    feats = synth.make_clip_features(8, T, H, W)
+    tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
+    tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in synth.level_sizes(H, W)]
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
+    head.set_retriever("fused")
+    with torch.no_grad():
+        logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
+    assert all(f.dtype == torch.float16 for f in fused) and torch.isfinite(embeds).all()
+    head.set_map_dtype("bf16")
+    with torch.no_grad():
+        _, _, fused = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
+    assert all(f.dtype == torch.bfloat16 for f in fused)
