@@ -105,3 +105,20 @@ def test_map_beyond_fp16_range_falls_back_to_kv_form(cuda):
     m.range_check = False
     sat = run_case(cuda, m, P, feat, slots, H, W)                # saturating fused form: finite (asserted inside), error reported
     print(f"|f| ~ 1e5 without range_check (fp16 saturation at 65504): max abs err {sat:.2e}")
+
+
+
+def test_tiny_norm_v_eps_is_refused(cuda):
+    """The fp16 probabilities carry 2^7 (csrc/common.h; slots that own almost no pixel - P ~ 1e-7 everywhere - no longer fall below
+    fp16's range: tests/test_head_gpu.py, the fine levels of the fixture). The guard that goes with the scale: 2^7 * P * rstd_v must
+    stay inside fp16, rstd_v <= 1 / sqrt(eps_v) < 511, so the fused form refuses eps_v < 4e-6 instead of overflowing."""
+    m, P = make_module(cuda, 61)
+    rng = np.random.default_rng(13)
+    T, H, W, L = 1, 8, 32, 100
+    feat = orc.round_bf16(rng.standard_normal((T, H * W, 256)).astype(np.float32))
+    slots = rng.standard_normal((T, L, 256)).astype(np.float32)
+    assert run_case(cuda, m, P, feat, slots, H, W) <= 2e-3
+    m.norm_v.eps = 1e-6
+    with pytest.raises(ValueError):
+        run_case(cuda, m, P, feat, slots, H, W)
+    m.norm_v.eps = 1e-5
