@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--num-classes", type=int, default=20, help="head classes incl. no-object (20 Cityscapes-VPS, 24 VIPER)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--fast-p", action="store_true", help="bf16 P without the hi/lo split inside K1")
+    ap.add_argument("--map-dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="16-bit storage of the fused level maps in the MAIN leg: bf16 (BASELINE's storage, default) or fp16 "
+                         "(head.set_map_dtype: same bytes, three more mantissa bits, no conversion pass in K1' / K3''; the default line "
+                         "carries it as the fp16_level_maps leg)")
     ap.add_argument("--retriever", choices=["fused", "kv"], default="fused",
                     help="fused: statistics-fused retriever K3' + K1' (default); kv: K3 + K1 through bf16 k / v tensors")
     ap.add_argument("--clips-in-flight", type=int, default=1,
@@ -416,6 +420,7 @@ def main():
     runner = SlotClipRunner(dev, T, a.height, a.width, L=a.slots, param_seed=0, cfg=head_cfg, split_p=not a.fast_p,
                             use_graph=not a.no_graph, n_slots=n_pool, clips_per_launch=cpl, decode_logits=bool(a.decode_logits))
     runner.head.set_retriever(a.retriever)
+    runner.head.set_map_dtype(a.map_dtype)
     HWf = runner.sizes[-1][0] * runner.sizes[-1][1]
     ncls = runner.cfg["num_classes"]
     # synthetic clips, resident in HBM (in the runner's input slots) before the timed region
@@ -615,7 +620,7 @@ def main():
             "metric": f"frames/sec (whole node), {a.height}x{a.width} T={T} clip, R50-FPN Slot-VPS inference",
             "value": round(frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": a.map_dtype, "data": "synthetic",
             "config": {"workload": f"HOT PATH ONLY (backbone / FPN / post-process are NOT in the step; whole_detector below carries the "
                                    f"detector figure): R50-FPN Slot-VPS slot-retriever head (7 stages over 4 FPN levels) + slot->mask "
                                    f"decode with fused per-pixel slot argmax ({'argmax-only: the [T, L, HW] fp32 logits are not written' if not a.decode_logits else 'fp32 logits of all slots written'}), "
