@@ -42,9 +42,15 @@ struct FuseLds {
 // 16-chunk group, conflict-free for ds_read_b128 over 16 rows
 // fp32 accumulator -> map element. fp16 maps SATURATE at +-65 504 (an overflow to inf would turn into NaN in every consumer; the bf16
 // form's consumers saturate when they convert the map to fp16 in LDS - same behaviour either way)
-template <typename MT>
+// BP ("bf16 precision", fp16 maps only): the value is rounded to bf16 FIRST and then stored in the fp16 encoding - the storage policy
+// of the bf16 form (the same values, bit for bit, above fp16's subnormal range) in the encoding every consumer's matrix instructions
+// take directly, so that their bf16 -> fp16 pass over the tile in LDS disappears (MultiScaleDynamicMaskHead.map_dtype = "bf16").
+template <typename MT, bool BP = false>
 __device__ __forceinline__ MT to_map(float x) {
-    if constexpr (__is_same(MT, _Float16)) x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    if constexpr (__is_same(MT, _Float16)) {
+        if constexpr (BP) x = (float)(__bf16)x;
+        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    }
     return (MT)x;
 }
 
@@ -52,7 +58,7 @@ __device__ __forceinline__ int a_off(int row, int chunk) {
     return row * kFuseRowBytes + (((chunk & ~15) | ((chunk ^ swz(row)) & 15)) * 16);
 }
 
-template <typename MT, bool NCHW_F32, bool LEVEL0>
+template <typename MT, bool NCHW_F32, bool LEVEL0, bool BP = false>
 __global__ __launch_bounds__(512) void level_fuse_kernel(
     const void* __restrict__ cur_,        // [T, 128, H, W] fp32 (NCHW_F32) or [T, H*W, 128] bf16
     const MT* __restrict__ prev,      // [T, (H/2)*(W/2), 256] bf16 pixel-major (unused for LEVEL0)
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int row = 8 * pg + j;
-                const MT val = (MT)(j < 4 ? p.c0[j] : p.c1[j - 4]);
+                const MT val = to_map<MT, BP>(j < 4 ? p.c0[j] : p.c1[j - 4]);
                 const int chunk = 32 + (ch >> 3);
                 *reinterpret_cast<MT*>(at + a_off(row, chunk) + (ch & 7) * 2) = val;
                 if constexpr (LEVEL0) {
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
                 mx8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    o[j] = (MT)(h0 * (w0 * (float)a[j] + w1 * (float)b[j]) + h1 * (w0 * (float)cc[j] + w1 * (float)d[j]));
+                    o[j] = to_map<MT, BP>(h0 * (w0 * (float)a[j] + w1 * (float)b[j]) + h1 * (w0 * (float)cc[j] + w1 * (float)d[j]));
                 *reinterpret_cast<mx8*>(at + a_off(px, ck + 16 * u)) = o;
             }
         }
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
         for (int g = 0; g < 4; ++g) {
             mx4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = to_map<MT>(acc[4 * g + j]);
+            for (int j = 0; j < 4; ++j) o[j] = to_map<MT, BP>(acc[4 * g + j]);
             const int ch0 = 32 * w + 8 * g + 4 * h;
             *reinterpret_cast<mx4*>(ot + r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2) = o;
         }
@@ -616,7 +622,7 @@ struct Fuse4Lds {
 };
 static_assert(Fuse4Lds::total <= 160 * 1024, "LDS layout");
 
-template <typename MT, bool NCHW_F32>
+template <typename MT, bool NCHW_F32, bool BP = false>
 __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     const void* __restrict__ cur_, const MT* __restrict__ prev, const MT* __restrict__ wc,
     const float* __restrict__ bc, MT* __restrict__ out, int H, int W, int tiles_per_chunk) {
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 for (int g = 0; g < 4; ++g) {
                     mx4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = to_map<MT>(acc[b][4 * g + j]);
+                    for (int j = 0; j < 4; ++j) o[j] = to_map<MT, BP>(acc[b][4 * g + j]);
                     *reinterpret_cast<mx4*>(ot + r * Lds::kOWRow + (32 * b + 8 * g + 4 * h) * 2) = o;
                 }
             // the wave's own LDS operations complete in order: the read-back sees the writes above
@@ -881,8 +887,8 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 for (int j = 0; j < 4; ++j) {
                     typedef MT bf16x2 __attribute__((ext_vector_type(2)));
                     bf16x2 v2;
-                    v2[0] = (MT)c0[j];
-                    v2[1] = (MT)c1[j];
+                    v2[0] = to_map<MT, BP>(c0[j]);
+                    v2[1] = to_map<MT, BP>(c1[j]);
                     *reinterpret_cast<bf16x2*>(at + (4 * pq + j) * Lds::kARow + chunk * 16 + sub) = v2;
                 }
             } else {
@@ -934,8 +940,8 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 for (int j = 0; j < 4; j += 2) {
                     const f32x2 top = {up[b][0][4 * gq + j], up[b][0][4 * gq + j + 1]}, bot = {up[b][1][4 * gq + j], up[b][1][4 * gq + j + 1]};
                     const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
-                    o[j] = (MT)y[0];
-                    o[j + 1] = (MT)y[1];
+                    o[j] = to_map<MT, BP>(y[0]);
+                    o[j + 1] = to_map<MT, BP>(y[1]);
                 }
                 *reinterpret_cast<mx4*>(at + wo + 16 * gq) = o;
             }
@@ -984,10 +990,10 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 namespace {
 int fuse_num_cus() { return svps_num_cus(); }
 
-template <typename MT, bool NCHW, bool L0>
+template <typename MT, bool NCHW, bool L0, bool BP = false>
 hipError_t launch_fuse(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
                        int W, hipStream_t stream) {
-    auto kern = svps::level_fuse_kernel<MT, NCHW, L0>;
+    auto kern = svps::level_fuse_kernel<MT, NCHW, L0, BP>;
     const int HW = H * W;
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
     int chunks = svps_pick_chunks(T, tiles, fuse_num_cus());   // one resident 8-wave workgroup per CU
@@ -1033,10 +1039,10 @@ hipError_t launch_fuse_v2(const void* cur, const void* prev, const void* wc, con
                        static_cast<__bf16*>(out), H, W, tpc);
     return hipGetLastError();
 }
-template <typename MT, bool NCHW>
+template <typename MT, bool NCHW, bool BP = false>
 hipError_t launch_fuse_v4(const void* cur, const void* prev, const void* wc, const float* bc, void* out, int T, int H,
                           int W, hipStream_t stream) {
-    auto kern = svps::level_fuse_kernel_v4<MT, NCHW>;
+    auto kern = svps::level_fuse_kernel_v4<MT, NCHW, BP>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::Fuse4Lds::total); ae != hipSuccess) return ae;
     const int tiles = H * W / svps::kTilePx;
@@ -1071,7 +1077,12 @@ extern "C" int svps_level_fuse_fwd(const void* cur, int cur_flags, const void* p
     // fast path: tiles inside one output row, frame sizes inside a buffer descriptor
     const bool fast = prev && (W & 31) == 0 && (size_t)H * W * 512 < 0x7fffffffu && getenv("SVPS_K4_LEGACY") == nullptr;
     static const bool v2 = getenv("SVPS_K4_V2") != nullptr;          // comparison runs: the eight-wave form of round 2
-    if (maps_f16)
+    const bool bf16_values = cur_flags & 4;                    // fp16 encoding, bf16 rounding points (the bf16 storage policy; see to_map)
+    if (maps_f16 && bf16_values)
+        e = fast ? launch_fuse_v4<_Float16, true, true>(cur, prev, wc, bc, out, T, H, W, stream)
+            : prev ? launch_fuse<_Float16, true, false, true>(cur, prev, wc, bc, out, T, H, W, stream)
+                   : launch_fuse<_Float16, true, true, true>(cur, prev, wc, bc, out, T, H, W, stream);
+    else if (maps_f16)
         e = fast ? launch_fuse_v4<_Float16, true>(cur, prev, wc, bc, out, T, H, W, stream)
             : prev ? launch_fuse<_Float16, true, false>(cur, prev, wc, bc, out, T, H, W, stream)
                    : launch_fuse<_Float16, true, true>(cur, prev, wc, bc, out, T, H, W, stream);

@@ -193,12 +193,14 @@ def kv_project(feat, H, W, pos_tabs, wk, bk, lnk_w, lnk_b, lnk_eps, wv, bv, lnv_
     return k, v
 
 
-def level_fuse(cur, prev, wc, bc, H, W):
+def level_fuse(cur, prev, wc, bc, H, W, bf16_values=False):
     """K4: fused level map [T, H*W, 256] bf16 = conv1x1(cat(bilinear_x2(prev), cur)) (+ level-0 form when
     prev is None). cur: [T, 128, H, W] fp32 (NCHW, the reference's layout) or [T, H*W, 128] bf16;
     prev: [T, (H/2)*(W/2), 256] bf16; wc [256, 384] bf16; bc [256] fp32.
     (MultiScaleDynamicMaskHead.forward lines 171-188 of the reference's dynamic_mask_head.py.)
-    wc (and prev) fp16: the fp16 form - operands, previous level and result fp16 (cur must be the fp32 NCHW map)."""
+    wc (and prev) fp16: the fp16 form - operands, previous level and result fp16 (cur must be the fp32 NCHW map).
+    bf16_values (fp16 form only): every rounding point rounds to bf16 and the value is stored in the fp16 encoding - the bf16 storage
+    policy, bit for bit above fp16's subnormal range, in the encoding the consumers' matrix instructions take directly."""
     lib = _lib.load()
     if not isinstance(cur, torch.Tensor) or not cur.is_cuda:
         raise RuntimeError("level_fuse: GPU tensors only; there is no CPU fallback")
@@ -227,7 +229,9 @@ def level_fuse(cur, prev, wc, bc, H, W):
             raise ValueError(f"prev {tuple(prev.shape)} does not match an {H}x{W} level")
     out = torch.empty((T, H * W, 256), dtype=mdt, device=cur.device)
     with _on(cur, prev, wc, bc) as ctx:
-        _lib.check(lib.svps_level_fuse_fwd(_ptr(cur), nchw | (2 if mdt == torch.float16 else 0), _ptr(prev), _ptr(wc), _ptr(bc),
+        if bf16_values and mdt != torch.float16:
+            raise ValueError("level_fuse: bf16_values goes with the fp16 form")
+        _lib.check(lib.svps_level_fuse_fwd(_ptr(cur), nchw | (2 if mdt == torch.float16 else 0) | (4 if bf16_values else 0), _ptr(prev), _ptr(wc), _ptr(bc),
                                            _ptr(out), T, H, W, ctx.stream), "svps_level_fuse_fwd")
     return out
 

@@ -643,6 +643,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
         self.dh_dim = dh_dim
         # storage of the fused level maps: "bf16" or "fp16" (set_map_dtype); a config selects it with other_config=dict(map_dtype="fp16")
         self.map_dtype = "bf16"
+        self.map_encoding = "auto"                       # "bf16": plain bf16 tensors for the bf16 policy (see _map_form)
         if isinstance(other_config, dict) and other_config.get("map_dtype") is not None:
             self.set_map_dtype(other_config["map_dtype"])
         self.trans_in_dim = trans_in_dim
@@ -721,12 +722,32 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 nn.init.constant_(p, self.bias_value)
 
     # ------------------------------------------------------------------------------------------
-    def _conv_weights(self):
+    def _map_form(self, cur=None):
+        """How the fused level maps are stored: "fp16" (map_dtype "fp16"), "bf16" (bf16 tensors) or "bf16_in_fp16" - the bf16 storage
+        policy (every rounding point rounds to bf16: the same values) in the fp16 ENCODING, which the matrix instructions of every
+        consumer take directly, so that the bf16 -> fp16 pass over each tile in LDS disappears from K1' / K3'' (11 % of K1'). Chosen
+        whenever every consumer is such a kernel: fused retriever, eight-wave form, fp32 NCHW incoming maps, no range_check (which has
+        to see the unsaturated map); map_encoding = "bf16" forces plain bf16 tensors."""
+        if getattr(self, "map_dtype", "bf16") == "fp16":
+            return "fp16"
+        mdcs = [m for m in self.modules() if hasattr(m, "retriever")]
+        if (self.map_encoding == "bf16" or ops.RETR_ATTN_FORM == "w4" or (cur is not None and (cur.dim() != 4 or cur.dtype == BF16))
+                or any(m.retriever != "fused" or m.range_check or m.norm_v.eps < 4e-6 for m in mdcs)):
+            return "bf16"
+        return "bf16_in_fp16"
+
+    def _conv_weights(self, form=None):
         conv = self.conv_trans.conv
-        mdt = torch.float16 if getattr(self, "map_dtype", "bf16") == "fp16" else BF16
-        key = (conv.weight._version, conv.weight.data_ptr(), mdt)
+        form = form or self._map_form()
+        key = (conv.weight._version, conv.weight.data_ptr(), form)
         if getattr(self, "_cw_key", None) != key:
-            self._cw = conv.weight.detach().reshape(self.dh_dim, self.trans_in_dim).to(mdt).contiguous()
+            w = conv.weight.detach().reshape(self.dh_dim, self.trans_in_dim)
+            if form == "fp16":
+                self._cw = w.to(torch.float16).contiguous()
+            elif form == "bf16_in_fp16":
+                self._cw = w.to(BF16).to(torch.float16).contiguous()          # the bf16-rounded weights, fp16 encoding
+            else:
+                self._cw = w.to(BF16).contiguous()
             self._cw_key = key
         return self._cw, conv.bias
 
@@ -752,12 +773,15 @@ class MultiScaleDynamicMaskHead(nn.Module):
             conv = self.conv_trans.conv
             wT = _cached(self, "cwT", [conv.weight], lambda: conv.weight.reshape(self.dh_dim, self.trans_in_dim).t().contiguous())
             return ops.level_fuse_f32(cur.float().contiguous(), prev_pm, wT, conv.bias, hw[0], hw[1])
-        wc, bc = self._conv_weights()
+        form = self._map_form(cur)
+        if prev_pm is not None and form != "fp16":                       # a level follows the encoding of the level below it
+            form = "bf16_in_fp16" if prev_pm.dtype == torch.float16 else "bf16"
+        wc, bc = self._conv_weights(form)
         if cur.dtype not in (torch.float32, BF16) or (wc.dtype == torch.float16 and cur.dtype != torch.float32):
             cur = cur.float()
         if wc.dtype == torch.float16 and cur.dim() != 4:
             raise NotImplementedError("map_dtype='fp16' takes the incoming maps as [T, 128, H, W] (NCHW)")
-        return ops.level_fuse(cur.contiguous(), prev_pm, wc, bc, hw[0], hw[1])
+        return ops.level_fuse(cur.contiguous(), prev_pm, wc, bc, hw[0], hw[1], bf16_values=form == "bf16_in_fp16")
 
     def forward_clip(self, feats, init_slots, pos_tabs, hws=None, clip_frames=None):
         """Batched clip entry. clip_frames: frames per clip when several clips of equal length are stacked along T

@@ -431,7 +431,9 @@ def test_fp16_level_maps_against_the_reference(cuda, tag):
             tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
             pos_tabs = [ops.pos_embed_sine_tables(h, w_, 256, cuda) for (h, w_) in sizes]
             logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(slots).to(cuda), pos_tabs)
-            assert fused[3].dtype == (torch.float16 if md.startswith("fp16") else torch.bfloat16)
+            assert fused[3].dtype == torch.float16          # fp16 values, or (bf16 policy) bf16 values in the fp16 encoding
+            if md == "bf16":
+                assert torch.equal(fused[3].float(), fused[3].to(torch.bfloat16).float())
             r_f3 = max(np.abs(fused[3][t].float().cpu().numpy() - z[f"{tag}_fused3_{t}"]).max() for t in range(T))
             tf_err, sidx = [], 0
             for lvl, n in enumerate(cfg["per_level_stages"]):
@@ -474,7 +476,18 @@ def test_map_dtype_switch_is_checked(cuda):
     with torch.no_grad():
         logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
     assert all(f.dtype == torch.float16 for f in fused) and torch.isfinite(embeds).all()
+    # the bf16 policy: bf16 VALUES; in the fp16 encoding by default (no conversion pass in the consumers), as bf16 tensors on request -
+    # the same values and the same result
     head.set_map_dtype("bf16")
     with torch.no_grad():
-        _, _, fused = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
-    assert all(f.dtype == torch.bfloat16 for f in fused)
+        lg_c, em_c, fused_c = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
+        head.map_encoding = "bf16"
+        lg_b, em_b, fused_b = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
+        head.map_encoding = "auto"
+    assert all(f.dtype == torch.float16 for f in fused_c) and all(f.dtype == torch.bfloat16 for f in fused_b)
+    for fc, fb in zip(fused_c, fused_b):
+        assert torch.equal(fc.float(), fc.to(torch.bfloat16).float())                 # bf16 values
+        big = fb.float().abs() >= 2.0 ** -13                                              # (below that fp16 is subnormal)
+        assert torch.equal(fc.float()[big], fb.float()[big])
+    print(f"\nbf16 policy, fp16 encoding against bf16 tensors: slot embeddings differ by {float((em_c - em_b).abs().max()):.2e}")
+    assert float((em_c - em_b).abs().max()) <= 1e-3
