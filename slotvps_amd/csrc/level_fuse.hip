@@ -53,6 +53,23 @@ __device__ __forceinline__ MT to_map(float x) {
     }
     return (MT)x;
 }
+// two at a time. BP form: ONE v_cvt_pk_bf16_f32 for the pair, two unpack instructions, one v_cvt_pkrtz_f16_f32 - round-to-zero is exact on
+// bf16 values inside fp16's normal range and saturates at 65 504 by itself (four instructions per pair instead of seven)
+template <typename MT, bool BP = false>
+__device__ __forceinline__ void to_map2(float a, float b, MT& ra, MT& rb) {
+    if constexpr (__is_same(MT, _Float16) && BP) {
+        typedef __fp16 hf2_t __attribute__((ext_vector_type(2)));
+        uint32_t w;                                              // (hipcc converts the two halves with two instructions if left to itself)
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(a), "v"(b));
+        const hf2_t h2 = __builtin_amdgcn_cvt_pkrtz(__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u));
+        const uint32_t hw = __builtin_bit_cast(uint32_t, h2);
+        ra = __builtin_bit_cast(_Float16, (uint16_t)(hw & 0xffffu));
+        rb = __builtin_bit_cast(_Float16, (uint16_t)(hw >> 16));
+    } else {
+        ra = to_map<MT, BP>(a);
+        rb = to_map<MT, BP>(b);
+    }
+}
 
 __device__ __forceinline__ int a_off(int row, int chunk) {
     return row * kFuseRowBytes + (((chunk & ~15) | ((chunk ^ swz(row)) & 15)) * 16);
@@ -703,7 +720,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 for (int g = 0; g < 4; ++g) {
                     mx4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = to_map<MT, BP>(acc[b][4 * g + j]);
+                    for (int j = 0; j < 4; j += 2) { MT q0, q1; to_map2<MT, BP>(acc[b][4 * g + j], acc[b][4 * g + j + 1], q0, q1); o[j] = q0; o[j + 1] = q1; }
                     *reinterpret_cast<mx4*>(ot + r * Lds::kOWRow + (32 * b + 8 * g + 4 * h) * 2) = o;
                 }
             // the wave's own LDS operations complete in order: the read-back sees the writes above
@@ -887,8 +904,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 for (int j = 0; j < 4; ++j) {
                     typedef MT bf16x2 __attribute__((ext_vector_type(2)));
                     bf16x2 v2;
-                    v2[0] = to_map<MT, BP>(c0[j]);
-                    v2[1] = to_map<MT, BP>(c1[j]);
+                    { MT q0, q1; to_map2<MT, BP>(c0[j], c1[j], q0, q1); v2[0] = q0; v2[1] = q1; }
                     *reinterpret_cast<bf16x2*>(at + (4 * pq + j) * Lds::kARow + chunk * 16 + sub) = v2;
                 }
             } else {
@@ -940,8 +956,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 for (int j = 0; j < 4; j += 2) {
                     const f32x2 top = {up[b][0][4 * gq + j], up[b][0][4 * gq + j + 1]}, bot = {up[b][1][4 * gq + j], up[b][1][4 * gq + j + 1]};
                     const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
-                    o[j] = to_map<MT, BP>(y[0]);
-                    o[j + 1] = to_map<MT, BP>(y[1]);
+                    { MT q0, q1; to_map2<MT, BP>(y[0], y[1], q0, q1); o[j] = q0; o[j + 1] = q1; }
                 }
                 *reinterpret_cast<mx4*>(at + wo + 16 * gq) = o;
             }
