@@ -143,6 +143,9 @@ int svps_kv_project_fwd(const void* feat, const float* pos_y, const float* pos_x
  *   out   [T, H*W, 256] bf16 pixel-major
  *   cur_flags & 2: prev, wc and out are FP16 (needs the fp32 NCHW `cur`): the conv and the bilinear blend run on fp16 operands - the
  *         same bytes with three more mantissa bits; every consumer of the map then takes SVPS_FLAG_MAP_F16.
+ *   cur_flags & 4 (together with & 2): the bf16 storage POLICY in the fp16 ENCODING - wc is bf16, the conv runs on bf16 operands exactly as
+ *         in the bf16 form, every value of `out` is rounded to bf16 first and stored as the fp16 number it equals (prev likewise holds bf16
+ *         values in the fp16 encoding): bit-identical maps above fp16's subnormal range, and no consumer converts a tile any more.
  * ------------------------------------------------------------------------------------------- */
 int svps_level_fuse_fwd(const void* cur, int cur_flags, const void* prev, const void* wc,
                         const float* bc, void* out, int T, int H, int W, void* stream);

@@ -24,6 +24,7 @@
 // Roofline: HBM - per output pixel 512 B (fp32 NCHW input) or 256 B (bf16) in, 512 B out; the four
 // upsampling taps come from the 4x smaller previous level (L2 / Infinity Cache resident).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -79,7 +80,7 @@ template <typename MT, bool NCHW_F32, bool LEVEL0, bool BP = false>
 __global__ __launch_bounds__(512) void level_fuse_kernel(
     const void* __restrict__ cur_,        // [T, 128, H, W] fp32 (NCHW_F32) or [T, H*W, 128] bf16
     const MT* __restrict__ prev,      // [T, (H/2)*(W/2), 256] bf16 pixel-major (unused for LEVEL0)
-    const MT* __restrict__ wc,        // [256, 384] bf16 (conv weight, row = output channel)
+    const MT* __restrict__ wc,        // [256, 384] conv weight (row = output channel), element type MT - BP: bf16 (converted on load)
     const float* __restrict__ bc,         // [256]
     MT* __restrict__ out,             // [T, H*W, 256]
     int H, int W, int tiles_per_chunk) {
@@ -106,8 +107,15 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
     {
         const MT* row = wc + (size_t)(32 * w + r_) * kFuseIn + 8 * h_;
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks)
-            wf[ks] = __builtin_bit_cast(mx8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
+        for (int ks = 0; ks < 24; ++ks) {
+            if constexpr (BP) {      // the weights of the bf16-in-fp16 form are bf16 (level_fuse_kernel_v4 uses them as they are): re-encoded once
+                const bf16x8 wb = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wf[ks][j] = (MT)(float)wb[j];
+            } else {
+                wf[ks] = __builtin_bit_cast(mx8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
+            }
+        }
     }
     float bias[16];
 #pragma unroll
@@ -641,11 +649,17 @@ static_assert(Fuse4Lds::total <= 160 * 1024, "LDS layout");
 
 template <typename MT, bool NCHW_F32, bool BP = false>
 __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
-    const void* __restrict__ cur_, const MT* __restrict__ prev, const MT* __restrict__ wc,
+    const void* __restrict__ cur_, const MT* __restrict__ prev, const void* __restrict__ wc_,
     const float* __restrict__ bc, MT* __restrict__ out, int H, int W, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the maps and of the conv operands (common.h)
+    typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the maps (taps of the previous level, result)
     typedef MT mx4 __attribute__((ext_vector_type(4)));
+    // OT: element type of the conv's operands (operand tile in LDS, weights). BP (bf16 values in the fp16 encoding): the operands ARE
+    // bf16 - one rounding, the conv on bf16 MFMAs as in the bf16 form - and only the result is re-encoded (matrix waves, which have slack)
+    using OT = typename std::conditional<BP, __bf16, MT>::type;
+    typedef OT ox8 __attribute__((ext_vector_type(8)));
+    typedef OT ox4 __attribute__((ext_vector_type(4)));
+    const OT* wc = static_cast<const OT*>(wc_);
     static_assert(NCHW_F32 || __is_same(MT, __bf16), "a pixel-major 16-bit incoming map is bf16");
     using Lds = Fuse4Lds;
     const int tid = threadIdx.x;
@@ -665,12 +679,12 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 
     if (w < 4) {
         // ======================================= matrix waves =======================================
-        mx8 wf[2][24];
+        ox8 wf[2][24];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const MT* row = wc + (size_t)(64 * w + 32 * b + r_) * kFuseIn + 8 * h_;
+            const OT* row = wc + (size_t)(64 * w + 32 * b + r_) * kFuseIn + 8 * h_;
 #pragma unroll
-            for (int ks = 0; ks < 24; ++ks) wf[b][ks] = __builtin_bit_cast(mx8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
+            for (int ks = 0; ks < 24; ++ks) wf[b][ks] = __builtin_bit_cast(ox8, *reinterpret_cast<const u32x4*>(row + 16 * ks));
         }
         // Each matrix wave stores its OWN 64 channels of the out tile (128-byte lines, line-aligned): accumulators -> a wave-private
         // LDS block [32 px][128 B + pad] -> four 16-byte reads per lane in line order -> four buffer stores (8 whole lines each).
@@ -695,14 +709,14 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[b][4 * g + j] = b4[j];
                 }
-            mx8 xf[2][3];
+            ox8 xf[2][3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) xf[0][u] = *reinterpret_cast<const mx8*>(at + 32 * u);
+            for (int u = 0; u < 3; ++u) xf[0][u] = *reinterpret_cast<const ox8*>(at + 32 * u);
 #pragma unroll
             for (int grp = 0; grp < 8; ++grp) {                      // fragments of group grp + 1 requested before the MFMAs of group grp
                 if (grp < 7) {
 #pragma unroll
-                    for (int u = 0; u < 3; ++u) xf[(grp + 1) & 1][u] = *reinterpret_cast<const mx8*>(at + 32 * (3 * (grp + 1) + u));
+                    for (int u = 0; u < 3; ++u) xf[(grp + 1) & 1][u] = *reinterpret_cast<const ox8*>(at + 32 * (3 * (grp + 1) + u));
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -902,9 +916,10 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
                 const int chunk = 32 + (cp >> 2), sub = (cp & 3) * 4;  // 16-byte chunk of channels 256 + 2cp, byte inside it
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    typedef MT bf16x2 __attribute__((ext_vector_type(2)));
+                    typedef OT bf16x2 __attribute__((ext_vector_type(2)));
                     bf16x2 v2;
-                    { MT q0, q1; to_map2<MT, BP>(c0[j], c1[j], q0, q1); v2[0] = q0; v2[1] = q1; }
+                    if constexpr (BP) { v2[0] = (OT)c0[j]; v2[1] = (OT)c1[j]; }
+                    else { MT q0, q1; to_map2<MT, false>(c0[j], c1[j], q0, q1); v2[0] = q0; v2[1] = q1; }
                     *reinterpret_cast<bf16x2*>(at + (4 * pq + j) * Lds::kARow + chunk * 16 + sub) = v2;
                 }
             } else {
@@ -951,14 +966,15 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
             const int wo = r_ * Lds::kARow + (32 * (2 * hw + b) + 4 * h_) * 2;       // pixel row r_, channels 32 cb + 8 g + 4 h ..
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                mx4 o;
+                ox4 o;
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const f32x2 top = {up[b][0][4 * gq + j], up[b][0][4 * gq + j + 1]}, bot = {up[b][1][4 * gq + j], up[b][1][4 * gq + j + 1]};
                     const f32x2 y = __builtin_elementwise_fma(h1v, bot, h0v * top);
-                    { MT q0, q1; to_map2<MT, BP>(y[0], y[1], q0, q1); o[j] = q0; o[j + 1] = q1; }
+                    if constexpr (BP) { o[j] = (OT)y[0]; o[j + 1] = (OT)y[1]; }
+                    else { MT q0, q1; to_map2<MT, false>(y[0], y[1], q0, q1); o[j] = q0; o[j + 1] = q1; }
                 }
-                *reinterpret_cast<mx4*>(at + wo + 16 * gq) = o;
+                *reinterpret_cast<ox4*>(at + wo + 16 * gq) = o;
             }
         }
     };
@@ -1065,7 +1081,7 @@ hipError_t launch_fuse_v4(const void* cur, const void* prev, const void* wc, con
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), svps::Fuse4Lds::total, stream, cur,
-                       static_cast<const MT*>(prev), static_cast<const MT*>(wc), bc,
+                       static_cast<const MT*>(prev), wc, bc,
                        static_cast<MT*>(out), H, W, tpc);
     return hipGetLastError();
 }

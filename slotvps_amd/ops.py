@@ -216,10 +216,11 @@ def level_fuse(cur, prev, wc, bc, H, W, bf16_values=False):
         if cur.shape != (T, H * W, 128):
             raise ValueError(f"cur {tuple(cur.shape)} != [T, {H * W}, 128]")
         nchw = 0
-    mdt = torch.float16 if wc.dtype == torch.float16 else torch.bfloat16
+    # bf16_values: bf16 weights, fp16-ENCODED previous level and result (bf16 values); otherwise the maps have the weight's type
+    mdt = torch.float16 if (wc.dtype == torch.float16 or bf16_values) else torch.bfloat16
     if mdt == torch.float16 and not nchw:
         raise ValueError("level_fuse: the fp16 form takes the fp32 NCHW incoming map")
-    _need(wc, "wc", mdt, 2)
+    _need(wc, "wc", torch.bfloat16 if bf16_values else mdt, 2)
     _need(bc, "bc", torch.float32, 1)
     if wc.shape != (256, 384):
         raise ValueError("wc must be [256, 384]")
@@ -229,8 +230,6 @@ def level_fuse(cur, prev, wc, bc, H, W, bf16_values=False):
             raise ValueError(f"prev {tuple(prev.shape)} does not match an {H}x{W} level")
     out = torch.empty((T, H * W, 256), dtype=mdt, device=cur.device)
     with _on(cur, prev, wc, bc) as ctx:
-        if bf16_values and mdt != torch.float16:
-            raise ValueError("level_fuse: bf16_values goes with the fp16 form")
         _lib.check(lib.svps_level_fuse_fwd(_ptr(cur), nchw | (2 if mdt == torch.float16 else 0) | (4 if bf16_values else 0), _ptr(prev), _ptr(wc), _ptr(bc),
                                            _ptr(out), T, H, W, ctx.stream), "svps_level_fuse_fwd")
     return out

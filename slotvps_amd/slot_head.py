@@ -744,9 +744,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
             w = conv.weight.detach().reshape(self.dh_dim, self.trans_in_dim)
             if form == "fp16":
                 self._cw = w.to(torch.float16).contiguous()
-            elif form == "bf16_in_fp16":
-                self._cw = w.to(BF16).to(torch.float16).contiguous()          # the bf16-rounded weights, fp16 encoding
-            else:
+            else:                                                             # (bf16 weights in the bf16-in-fp16 form as well)
                 self._cw = w.to(BF16).contiguous()
             self._cw_key = key
         return self._cw, conv.bias
@@ -777,9 +775,9 @@ class MultiScaleDynamicMaskHead(nn.Module):
         if prev_pm is not None and form != "fp16":                       # a level follows the encoding of the level below it
             form = "bf16_in_fp16" if prev_pm.dtype == torch.float16 else "bf16"
         wc, bc = self._conv_weights(form)
-        if cur.dtype not in (torch.float32, BF16) or (wc.dtype == torch.float16 and cur.dtype != torch.float32):
+        if cur.dtype not in (torch.float32, BF16) or (form != "bf16" and cur.dtype != torch.float32):
             cur = cur.float()
-        if wc.dtype == torch.float16 and cur.dim() != 4:
+        if form != "bf16" and cur.dim() != 4:
             raise NotImplementedError("map_dtype='fp16' takes the incoming maps as [T, 128, H, W] (NCHW)")
         return ops.level_fuse(cur.contiguous(), prev_pm, wc, bc, hw[0], hw[1], bf16_values=form == "bf16_in_fp16")
 
