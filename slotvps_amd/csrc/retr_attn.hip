@@ -39,7 +39,10 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
 typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-constexpr int kRPrefetch = 3;
+#ifndef SVPS_RETR_PREFETCH
+#define SVPS_RETR_PREFETCH 3        // tiles requested ahead (tools/variants.sh retr_attn SVPS_RETR_PREFETCH 2 3 4)
+#endif
+constexpr int kRPrefetch = SVPS_RETR_PREFETCH;
 constexpr int kRNF = kRPrefetch + 3;       // feature / aux / Cy ring depth: tiles it-2 .. it+3 are live in iteration it
 constexpr int kAuxRow = 16;                // bytes per pixel of the aux tensor (retr_stats.hip)
 constexpr int kAuxTile = 1024;             // LDS per staged aux tile: 512 B of rows (+ 512 B the upper half of the DMA instruction repeats)

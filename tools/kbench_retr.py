@@ -16,6 +16,7 @@ ap.add_argument("--L", type=int, default=100)
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--warm-ms", type=float, default=400.0)
+ap.add_argument("--map-dtype", default="bf16", help="bf16 or fp16 (fp16: the kernels skip their conversion pass, as on the default path)")
 ap.add_argument("--form", default="w4", help="w4: csrc/retr_attn4.hip, w8: csrc/retr_attn.hip")
 a = ap.parse_args()
 ops.RETR_ATTN_FORM = a.form
@@ -24,7 +25,7 @@ torch.manual_seed(0)
 m = MaskDynamicConv(256).to(dev).eval()
 g = torch.Generator(device=dev).manual_seed(0)
 HW = a.H * a.W
-feat = torch.randn((a.T, HW, 256), generator=g, device=dev).to(torch.bfloat16)
+feat = torch.randn((a.T, HW, 256), generator=g, device=dev).to(torch.float16 if a.map_dtype == "fp16" else torch.bfloat16)
 slots = torch.randn((a.T, a.L, 256), generator=g, device=dev)
 tabs = ops.pos_embed_sine_tables(a.H, a.W, 256, dev)
 c = m._fused_consts()
