@@ -13,12 +13,13 @@ ap.add_argument("--H", type=int, default=256)
 ap.add_argument("--W", type=int, default=512)
 ap.add_argument("--L", type=int, default=100)
 ap.add_argument("--warm-s", type=float, default=2.0)
+ap.add_argument("--map-dtype", default="fp16", help="fp16 (as on the default path: no conversion pass) or bf16")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = MaskDynamicConv(256).to(dev).eval()
 HW = a.H * a.W
-feat = torch.randn((a.T, HW, 256), device=dev).to(torch.bfloat16)
+feat = torch.randn((a.T, HW, 256), device=dev).to(torch.float16 if a.map_dtype == "fp16" else torch.bfloat16)
 slots = torch.randn((a.T, a.L, 256), device=dev)
 tabs = ops.pos_embed_sine_tables(a.H, a.W, 256, dev)
 c = m._fused_consts()
