@@ -69,9 +69,10 @@ def parse():
     ap.add_argument("--latency-leg", type=int, default=1, help="0 to skip the single-clip latency leg (profiling runs)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / rendezvous / gather rehearsal without kernels (gloo on CPU; used by tests/test_parallel_cpu.py)")
-    ap.add_argument("--decode-logits", type=int, default=0,
-                    help="1: K2 also writes the fp32 mask logits of all slots [T, L, HW] (round-1/2 workload); 0: argmax-only mode "
-                         "(the step's result is the per-pixel slot assignment + class logits; nothing in the step reads the logits)")
+    ap.add_argument("--decode-logits", type=int, default=1,
+                    help="1 (default): K2 writes the fp32 mask logits of all slots [T, L, HW] - the tensor generate_final_outputs returns "
+                         "(vps_temporal_slots.py:144-160) - next to the fused per-pixel slot argmax; 0: argmax-only mode (the step's result is "
+                         "the per-pixel slot assignment + class logits; carried by the default line as the `argmax_only` leg)")
     ap.add_argument("--exact-leg", type=int, default=1, help="0 to skip the exact-mode (fp32) leg")
     ap.add_argument("--viper-leg", type=int, default=1, help="0 to skip the informational VIPER (1088x1920 T=10 200 slots) leg")
     ap.add_argument("--whole-detector", type=int, default=1,
@@ -375,8 +376,9 @@ def dry_run_cpu(a):
             c_am, c_cl = (float(x) for x in got["checksum"][r])
             ok = ok and float(got["slot_argmax"][r].sum(dtype=torch.float64)) == c_am
             ok = ok and abs(float(got["class_logits"][r].abs().sum(dtype=torch.float64)) - c_cl) <= 1e-9 * max(1.0, c_cl)
+        ok = ok and len(got["slot_argmax"]) == world         # a payload from every rank of the job
         print(json.dumps({"metric": "dry run (no kernels)", "value": 0.0, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
-                          "warmup": a.warmup, "dry_run": True, "gather_ok": bool(ok), "world_size": world,
+                          "warmup": a.warmup, "dry_run": True, "gather_ok": bool(ok), "world_size": world, "payload_ranks": len(got["slot_argmax"]),
                           "per_rank_ms_per_step": [round(float(x[0]), 3) for x in per_rank_ms],
                           "backend": "gloo", "ms_per_step": round(elapsed / max(1, a.steps) * 1e3, 3)}), flush=True)
     if world > 1:
@@ -480,7 +482,10 @@ def main():
     gather_ok, rank_sums = None, None
     if rank == 0 and a.steps > 0:
         got = gatherers[0].last((gatherers[0].n - 1) % gatherers[0].depth)
-        assert len(got["slot_argmax"]) == world and got["slot_argmax"][0].shape == tmpl["slot_argmax"].shape
+        dist_world = torch.distributed.get_world_size() if world > 1 else 1
+        assert len(got["slot_argmax"]) == world == dist_world, (f"gathered payloads from {len(got['slot_argmax'])} ranks, WORLD_SIZE {world}, "
+                                                                 f"torch.distributed world {dist_world}")
+        assert got["slot_argmax"][0].shape == tmpl["slot_argmax"].shape
         rank_sums, gather_ok = [], True
         for r_ in range(world):                              # the payload of EVERY rank against the sums its sender computed
             s_am = float(got["slot_argmax"][r_].sum(dtype=torch.float64))
@@ -489,6 +494,7 @@ def main():
             ok_r = s_am == c_am and abs(s_cl - c_cl) <= 1e-9 * max(1.0, abs(c_cl)) and s_cl > 0.0
             gather_ok = gather_ok and ok_r
             rank_sums.append({"rank": r_, "slot_argmax_sum": s_am, "ok": bool(ok_r)})
+        assert len({r_["rank"] for r_ in rank_sums}) == dist_world           # one distinct payload per rank of the job
         if not gather_ok:
             note(f"GATHER CHECK FAILED: {rank_sums}")
 
@@ -651,15 +657,19 @@ def main():
             except Exception as e:
                 line["single_clip_latency_ms"] = None
                 note(f"single-clip latency leg failed: {type(e).__name__}: {e}")
-        if world == 1 and a.exact_leg and not a.decode_logits:
-            # the same step with the reference's full decode output (fp32 mask logits of ALL slots written, + the fused argmax): what
-            # `value` would be if a caller insisted on the [T, L, HW] tensor (round 2's workload)
+        if world == 1 and a.exact_leg:
+            # the other decode mode of the same step: decode_logits -> the argmax-only step (K2 writes one byte per pixel, round 3's headline
+            # workload); argmax-only main leg -> the step with generate_final_outputs' full output
+            other = not a.decode_logits
+            key = "with_fp32_mask_logits" if other else "argmax_only"
             try:
-                fl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, decode_logits=True)
-                fl["what"] = "the default step with the fp32 mask logits of all slots written (generate_final_outputs' full output), hipGraph"
-                line["with_fp32_mask_logits"] = fl
+                fl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, decode_logits=other)
+                fl["what"] = ("the same step with the fp32 mask logits of all slots written (generate_final_outputs' full output), hipGraph" if other else
+                              "the same step with K2 in argmax-only mode: per-pixel slot assignment (uint8) + class logits, the [T, L, HW] fp32 logits "
+                              "are not written (round 3's headline workload; NOT what generate_final_outputs returns), hipGraph")
+                line[key] = fl
             except Exception as e:
-                line["with_fp32_mask_logits"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+                line[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and a.exact_leg and a.slots <= 128:
             note("precision-form leg (bf16 storage, fp16 hi + lo statistics factors and probabilities) ...")
             try:
@@ -741,6 +751,21 @@ def main():
                         f"{a.height}x{a.width} T={a.frames} clips at the same time, 3 timed clips each; value = ranks x T / slowest rank's "
                         f"time per clip; informational, never part of `value`"}
     if rank == 0:
+        # the driver's record of a round keeps `config` and `roofline` in full but only the NAMES of other keys: every informational
+        # leg's figure is repeated here as a flat number (frames/s unless the key says otherwise)
+        legs = {}
+        for key in ("argmax_only", "with_fp32_mask_logits", "reference_precision", "precision_form", "balanced_form", "fp16_level_maps",
+                    "fp16_level_maps_balanced", "exact_mode", "whole_detector", "whole_detector_per_rank"):
+            if isinstance(line.get(key), dict) and line[key].get("value") is not None:
+                legs[key + "_frames_per_s"] = line[key]["value"]
+        for key, leg in (line.get("other_configs") or {}).items():
+            if isinstance(leg, dict) and leg.get("value") is not None:
+                legs[key + "_frames_per_s"] = leg["value"]
+        if line.get("single_clip_latency_ms") is not None:
+            legs["single_clip_latency_ms"] = line["single_clip_latency_ms"]
+        if isinstance(line.get("cpu_baseline"), dict):
+            legs["cpu_baseline_frames_per_s"] = line["cpu_baseline"].get("value")
+        line["config"]["legs"] = legs
         line["notes"] = ("multi-GPU: tests/test_parallel_gpu.py::test_two_rank_rccl_gather needs two GPUs and is SKIPPED on the one-GPU "
                          "boxes the builder can use (RCCL refuses two ranks on one device); the N > 1 path is covered by two-rank gloo "
                          "tests on CPU (tests/test_parallel_cpu.py) and verified at run time by gather_ok above")

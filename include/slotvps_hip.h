@@ -396,17 +396,6 @@ int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, co
                        size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,
                        int flags, void* stream);
 
-/* svps_retr_attn4_fwd: the same function (:435-456), inputs, outputs and padding conventions as svps_retr_attn_fwd for
- * 1 <= L <= 128, as FOUR waves of 512 registers (one per SIMD) that each own a slot block end to end
- * (slotvps_amd/csrc/retr_attn4.hip) instead of eight producer / consumer waves. Chunks never leave a 32-pixel column strip:
- * `chunks_per_strip` = 0 lets the library plan them; workspace = per-workgroup partials [T, strips * chunks_per_strip, L, 260]
- * fp32 (svps_retr_attn4_workspace_bytes). Results agree with svps_retr_attn_fwd to fp32 summation order. */
-size_t svps_retr_attn4_workspace_bytes(int T, int L, int H, int W, int chunks_per_strip);
-int svps_retr_attn4_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
-                        const void* feat, const void* aux, void* workspace,
-                        size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks_per_strip,
-                        void* stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Exact mode: fp32 storage and fp32 arithmetic for the whole pixel side (slotvps_amd/csrc/exact_f32.hip).
  * The reference runs this path in fp32 (fp16_enabled = False, mmdet/models/detectors/vps_temporal_slots.py:55);

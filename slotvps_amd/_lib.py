@@ -64,8 +64,6 @@ SIGNATURES = {
     "svps_retr_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "svps_retr_attn_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_retr_attn_tight_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "svps_retr_attn4_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "svps_retr_attn4_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_level_fuse_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "svps_kv_project_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp,
                                      _i, _i, _i, _i, _vp]),

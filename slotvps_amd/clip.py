@@ -51,7 +51,9 @@ class SlotClipRunner:
         for m in self.head.modules():
             if hasattr(m, "split_p"):
                 m.split_p = split_p
-        self.init_slots = torch.from_numpy(synth.make_slots(param_seed + 1, L)).to(self.device)
+        # the slot initialisation is a model parameter in the detector (VPS_Capsule.init_mask_query.weight): as a Parameter here too, so
+        # that the head caches its broadcast over the frames (forward_clip) instead of launching a copy kernel inside every step
+        self.init_slots = nn.Parameter(torch.from_numpy(synth.make_slots(param_seed + 1, L)).to(self.device), requires_grad=False)
         # decode BatchNorms at the reference's initial values (vps_capsule.py:129-133): fg_bn weight 0.1
         self.feat_bn = nn.BatchNorm2d(self.cfg["dh_dim"]).to(self.device).eval()
         self.fg_bn = nn.BatchNorm2d(1).to(self.device).eval()

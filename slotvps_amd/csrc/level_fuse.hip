@@ -1106,7 +1106,8 @@ extern "C" int svps_level_fuse_fwd(const void* cur, int cur_flags, const void* p
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 0, stream);
     hipError_t e;
     // fast path: tiles inside one output row, frame sizes inside a buffer descriptor
-    const bool fast = prev && (W & 31) == 0 && (size_t)H * W * 512 < 0x7fffffffu && getenv("SVPS_K4_LEGACY") == nullptr;
+    static const bool legacy = getenv("SVPS_K4_LEGACY") != nullptr;   // comparison runs: the first-generation kernel
+    const bool fast = prev && (W & 31) == 0 && (size_t)H * W * 512 < 0x7fffffffu && !legacy;
     static const bool v2 = getenv("SVPS_K4_V2") != nullptr;          // comparison runs: the eight-wave form of round 2
     const bool bf16_values = cur_flags & 4;                    // fp16 encoding, bf16 rounding points (the bf16 storage policy; see to_map)
     if (maps_f16 && bf16_values)

@@ -803,10 +803,10 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
         return (int)eh;
     }
     // fast path: 16-byte row-segment stores need 4-pixel alignment of every slot row; L * HW * 4 must fit a buffer descriptor
-    const bool fast = (HW & 3) == 0 && !(flags & SVPS_FLAG_OUT_BF16) && (size_t)L * HW * 4 < 0x7ffffff0u &&
-                      getenv("SVPS_K2_LEGACY") == nullptr;
+    static const bool legacy = getenv("SVPS_K2_LEGACY") != nullptr;   // comparison runs: the first-generation kernel
+    const bool fast = (HW & 3) == 0 && !(flags & SVPS_FLAG_OUT_BF16) && (size_t)L * HW * 4 < 0x7ffffff0u && !legacy;
     if (!out) {                                          // argmax-only mode: the fast kernel without its logit stores
-        if ((flags & SVPS_FLAG_OUT_BF16) || getenv("SVPS_K2_LEGACY")) return SVPS_ERR_BAD_ARG;
+        if ((flags & SVPS_FLAG_OUT_BF16) || legacy) return SVPS_ERR_BAD_ARG;
 #ifdef SVPS_K2_ABLATE
         if (const char* ae = getenv("SVPS_K2_ABLATE"); ae && L <= 128) {
 #define SVPS_K2A(N) case N: ea = launch_decode_v2<true, 4, false, N>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, nullptr, slot_argmax, T, L, HW, stream); break;

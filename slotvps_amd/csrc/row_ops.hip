@@ -65,8 +65,10 @@ __global__ __launch_bounds__(256) void row_ln_kernel(const float* __restrict__ x
 
 // ---- softmax over the last index of [rows, cols] fp32 (the temporal retriever's softmax over the query axis,
 // dynamic_mask_head.py:559-567, applied to the transposed logits): one wavefront per row, torch.softmax's arithmetic
-// (max, exp(x - max), sum, divide), in place if y == x. Rows are 2 KB: the second and third read come from L1 / L2.
-__global__ __launch_bounds__(256) void row_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+// (max, exp(x - max), sum), the division as a multiplication by the reciprocal of the sum (<= 1 ulp from torch's divide). y may BE x
+// (ops.row_softmax(inplace=True)): the pointers are not declared __restrict__, and a lane only ever re-reads the element it writes.
+// Rows are 2 KB: the second and third read come from L1 / L2.
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* x, float* y, int rows, int cols) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;

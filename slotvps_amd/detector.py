@@ -338,7 +338,7 @@ class VPS_Temporal_Slots(nn.Module):
         # so load_state_dict / in-place edits / set_precision / set_retriever / set_slot_gemm / the ops-level forms re-capture.
         wkey = tuple((p_.data_ptr(), p_._version) for p_ in head.parameters()) + (im.init_mask_query.weight.data_ptr(), im.init_mask_query.weight._version)
         modes = tuple(sorted({(type(m).__name__, getattr(m, "precision", None), getattr(m, "retriever", None), getattr(m, "use_slot_gemm", None), getattr(m, "tight_stats", None), getattr(m, "precise_query_p", None), getattr(m, "query_side", None), getattr(m, "map_dtype", None), getattr(m, "map_encoding", None), getattr(m, "range_check", None))
-                              for m in head.modules() if hasattr(m, "precision")})) + (ops.RETR_ATTN_FORM, ops.RETR_STATS_FORM)
+                              for m in head.modules() if hasattr(m, "precision")})) + (ops.RETR_STATS_FORM,)
         key = tuple(tuple(f.shape) for f in feats) + (str(feats[0].device), hash(wkey), modes)
         ent = self._head_cache.get(key)
         if ent is None:

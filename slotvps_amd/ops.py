@@ -417,9 +417,6 @@ def retr_stats_unpack(aux):
     return w[..., 2], w[..., 3]
 
 
-RETR_ATTN_FORM = "w8"     # "w8": csrc/retr_attn.hip (every L); "w4": csrc/retr_attn4.hip for L <= 128 (same results, measured within 5 % of w8)
-
-
 def retr_slot_pad(L):
     """Rows of the slot axis in the layouts K1' takes: 128 for L <= 128, 256 for L <= 256."""
     return 128 if L <= 128 else 256
@@ -444,25 +441,15 @@ def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0, tight=False):
     if (HW != H * W or qh.shape != (T, LP, D) or ql.shape != (T, LP, D) or cy.shape != (T, H, LP) or cx.shape != (T, W, LP)
             or c3.shape != (T, LP) or aux.shape != (T, HW, 8)):
         raise ValueError("shape mismatch")
-    # RETR_ATTN_FORM "w4" and L <= 128: the four-wave form (csrc/retr_attn4.hip); `chunks` then counts chunks per column strip
-    four = L <= 128 and RETR_ATTN_FORM == "w4" and not tight
-    if four and mflag:
-        raise NotImplementedError("the four-wave form of the fused retriever takes bf16 maps only")
     if tight and L > 128:
         raise NotImplementedError("the precision form of the fused retriever (P * rstd_v as fp16 hi + lo) covers L <= 128")
-    ws_fn, fwd, name = ((lib.svps_retr_attn4_workspace_bytes, lib.svps_retr_attn4_fwd, "svps_retr_attn4_fwd") if four else
-                        (lib.svps_retr_attn_workspace_bytes, lib.svps_retr_attn_tight_fwd, "svps_retr_attn_tight_fwd") if tight else
-                        (lib.svps_retr_attn_workspace_bytes, lib.svps_retr_attn_fwd, "svps_retr_attn_fwd"))
-    ws_bytes = ws_fn(T, L, H, W, chunks)
+    fwd, name = ((lib.svps_retr_attn_tight_fwd, "svps_retr_attn_tight_fwd") if tight else (lib.svps_retr_attn_fwd, "svps_retr_attn_fwd"))
+    ws_bytes = lib.svps_retr_attn_workspace_bytes(T, L, H, W, chunks)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)
     out = torch.empty((T, L, 272), dtype=torch.float32, device=feat.device)
     with _on(qh, ql, cy, cx, c3, feat, aux) as ctx:
-        if four:
-            rc = fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(aux), _ptr(ws), ws_bytes,
-                     _ptr(out), T, L, H, W, D, chunks, ctx.stream)
-        else:
-            rc = fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(aux), _ptr(ws), ws_bytes,
-                     _ptr(out), T, L, H, W, D, chunks, mflag, ctx.stream)
+        rc = fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat), _ptr(aux), _ptr(ws), ws_bytes,
+                 _ptr(out), T, L, H, W, D, chunks, mflag, ctx.stream)
     _lib.check(rc, name)
     return out
 

@@ -731,7 +731,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
         if getattr(self, "map_dtype", "bf16") == "fp16":
             return "fp16"
         mdcs = [m for m in self.modules() if hasattr(m, "retriever")]
-        if (self.map_encoding == "bf16" or ops.RETR_ATTN_FORM == "w4" or (cur is not None and (cur.dim() != 4 or cur.dtype == BF16))
+        if (self.map_encoding == "bf16" or (cur is not None and (cur.dim() != 4 or cur.dtype == BF16))
                 or any(m.retriever != "fused" or m.range_check or m.norm_v.eps < 4e-6 for m in mdcs)):
             return "bf16"
         return "bf16_in_fp16"
@@ -754,7 +754,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
         storage) or "fp16": the same 16 bits with three more of mantissa - K4 runs its conv and its bilinear blend on fp16 operands,
         the statistics / retriever kernels skip their bf16 -> fp16 pass, K2 runs fp16 MFMAs. The maps then sit 8x closer to the
         reference's fp32 maps (what limits the distance of the whole head from the reference's own outputs); |f| must stay below
-        65 504 (as for the fused retriever). Fused retriever only (the kv form and the four-wave form take bf16 maps)."""
+        65 504 (as for the fused retriever). Fused retriever only (the kv form takes bf16 maps)."""
         if dtype not in ("bf16", "fp16"):
             raise ValueError(f"map_dtype must be 'bf16' or 'fp16', not {dtype!r}")
         for m in self.modules():                         # the stages' reference-signature entry points store their maps the same way
@@ -796,8 +796,13 @@ class MultiScaleDynamicMaskHead(nn.Module):
         clips = 1 if clip_frames is None else T // clip_frames
         if clip_frames is not None and clips * clip_frames != T:
             raise ValueError(f"T={T} is not a multiple of clip_frames={clip_frames}")
-        # the initial slots of every frame: a broadcast of a parameter, made once per (parameter version, T) and never written
-        slots = _cached(self, f"init_slots_T{T}", [init_slots], lambda: init_slots.float().unsqueeze(0).expand(T, -1, -1).contiguous())
+        # the initial slots of every frame: a broadcast, never written. Cached per (parameter version, T) only when the caller hands
+        # over a model PARAMETER (the detector's init_mask_query.weight): (data_ptr, _version) does not identify a temporary - a second
+        # temporary with other values can land on the same allocator address at version 0
+        if isinstance(init_slots, nn.Parameter):
+            slots = _cached(self, f"init_slots_T{T}", [init_slots], lambda: init_slots.float().unsqueeze(0).expand(T, -1, -1).contiguous())
+        else:
+            slots = init_slots.detach().float().unsqueeze(0).expand(T, -1, -1).contiguous()
         n_stages = sum(self.per_dh_num_heads[:self.feat_num_levels])
         direct = self.precision != "fp32"                # the stages' producers write straight into the stacked results
         out_logits = torch.empty((n_stages, T, init_slots.shape[0], self.num_classes), dtype=torch.float32, device=slots.device) if direct else None

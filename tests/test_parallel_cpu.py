@@ -65,12 +65,12 @@ def test_single_process_helpers():
     assert [int(m) for m in merged] == [0, 1, 2]
 
 
-def _gather_worker(rank, world, port, q):
+def _gather_worker(rank, world, port, q, T=3, H=16, W=32):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     from slotvps_amd import parallel
     parallel.init_distributed(backend="gloo")
-    T, H, W = 3, 16, 32
     tmpl = parallel.clip_result_template(T, H, W, torch.device("cpu"), max_segments=100)
     gat = parallel.ClipResultGatherer(tmpl, depth=2)
     last = None
@@ -90,7 +90,8 @@ def _gather_worker(rank, world, port, q):
                "fcn": [int(got["fcn_outputs"][r][2, 0, 0]) for r in range(world)],
                "nseg": [got["num_segments"][r].tolist() for r in range(world)],
                "ids": [got["segments"][r][2, :, 2].tolist()[:3] for r in range(world)],
-               "bytes": gat.bytes_per_submit})
+               "uniform": [bool((got["panoptic_outputs"][r] == got["panoptic_outputs"][r][0, 0, 0]).all()) for r in range(world)],
+               "ranks_seen": len(got["panoptic_outputs"]), "bytes": gat.bytes_per_submit})
     parallel.barrier()
     torch.distributed.destroy_process_group()
 
@@ -113,6 +114,45 @@ def test_per_clip_gather_overlapped_two_ranks():
     assert out["nseg"] == [[(0 + 4 + t) % 4 for t in range(3)], [(1 + 4 + t) % 4 for t in range(3)]]
     assert out["ids"][1][:3] == [100.0, 101.0, 102.0]                       # rank 1, frame 2: k = (1 + 4 + 2) % 4 = 3 segments
     assert out["bytes"] == 3 * 16 * 32 * 2 + 3 * 100 * 3 * 4 + 3 * 4
+
+
+def test_per_clip_gather_eight_ranks_full_size_payload():
+    """The N = 8 job of BASELINE config 3 on CPU ranks: eight gloo ranks, five clips each through the double-buffered gatherer with
+    the SURVEY 8e payload at its real size (T = 5, 1024 x 2048: 2 x 10.5 MB of uint8 maps + the segment triples per clip and rank);
+    rank 0 must hold the LAST clip of every one of the eight ranks, intact."""
+    world, T, H, W = 8, 5, 1024, 2048
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q, T, H, W)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert out["ranks_seen"] == world
+    assert out["pan"] == [10 * r + 4 for r in range(world)] and out["fcn"] == [2] * world and all(out["uniform"])
+    assert out["nseg"] == [[(r + 4 + t) % 4 for t in range(T)] for r in range(world)]
+    assert out["bytes"] == T * H * W * 2 + T * 100 * 3 * 4 + T * 4
+
+
+def test_bench_launcher_eight_ranks_dry_run():
+    """`python bench.py --gpus 8 --dry-run-cpu`: the launcher, rendezvous, per-step gather with per-rank checksums and rank 0's line for
+    the N = 8 job (gloo, no kernels): n_gpus = 8, a payload from each of the eight ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--clips-per-launch", "2",
+                        "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["world_size"] == 8 and line["gather_ok"] is True and line["payload_ranks"] == 8
+    assert len(line["per_rank_ms_per_step"]) == 8
 
 
 def test_bench_launcher_starts_the_ranks_itself():

@@ -6,5 +6,5 @@ cd "$(dirname "$0")/.."
 make -C slotvps_amd/csrc ablate 2>&1 | grep -i "error"
 for a in "$@"; do
   s=${a%%:*}; r=${a##*:}
-  echo "$(SLOTVPS_LIB=$PWD/slotvps_amd/libslotvps_hip_ablate.so SVPS_STATS_ABLATE=$s SVPS_RETR_ABLATE=$r timeout -k 10 120 python tools/kbench_retr.py --form w8 2>&1 | tail -1)"
+  echo "$(SLOTVPS_LIB=$PWD/slotvps_amd/libslotvps_hip_ablate.so SVPS_STATS_ABLATE=$s SVPS_RETR_ABLATE=$r timeout -k 10 120 python tools/kbench_retr.py 2>&1 | tail -1)"
 done

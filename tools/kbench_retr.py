@@ -17,9 +17,7 @@ ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--warm-ms", type=float, default=400.0)
 ap.add_argument("--map-dtype", default="bf16", help="bf16 or fp16 (fp16: the kernels skip their conversion pass, as on the default path)")
-ap.add_argument("--form", default="w4", help="w4: csrc/retr_attn4.hip, w8: csrc/retr_attn.hip")
 a = ap.parse_args()
-ops.RETR_ATTN_FORM = a.form
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = MaskDynamicConv(256).to(dev).eval()
@@ -53,4 +51,4 @@ for rep in range(a.reps):
     su, au = s_ms / s_n * 1e3, a_ms / a_n * 1e3
     print(f"rep {rep}: retr_stats {su:7.1f} us ({px * 528 / su / 1e3:6.0f} GB/s, {px * 147456 / su / 1e6:5.0f} TF/s tri)   "
           f"retr_attn {au:7.1f} us ({px * 528 / au / 1e3:6.0f} GB/s, {px * 4 * a.L * 256 / au / 1e6:5.0f} TF/s alg)   "
-          f"form={a.form} abl stats={os.environ.get('SVPS_STATS_ABLATE', '0')} attn={os.environ.get('SVPS_RETR_ABLATE', '0')}", flush=True)
+          f"abl stats={os.environ.get('SVPS_STATS_ABLATE', '0')} attn={os.environ.get('SVPS_RETR_ABLATE', '0')}", flush=True)

@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-KERNELS = {"retr_attn4_kernel": "retr_attn (four-wave form)", "retr_attn_kernel": "retr_attn", "retr_stats2_kernel": "retr_stats (level form, 2 stages)",
+KERNELS = {"retr_attn_kernel": "retr_attn", "retr_stats2_kernel": "retr_stats (level form, 2 stages)",
            "retr_stats_kernel": "retr_stats", "level_fuse": "level_fuse", "mask_decode": "mask_decode", "slot_ffn_kernel": "slot_ffn",
            "slot_chain_kernel": "slot_chain", "slot_gemm_kernel": "slot_gemm", "bgemm_kernel": "bgemm"}
 
@@ -54,7 +54,10 @@ def main():
         res[k] = d
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     with open(dst, "w") as fh:
-        json.dump({"command": "rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python3 tools/kbench_retr.py ... (two passes)", "kernels": res}, fh, indent=1)
+        cmd = sys.argv[4] if len(sys.argv) > 4 else ("rocprofv3 --kernel-trace --pmc <8 SQ counters per pass, two passes> -- python3 bench.py --steps 2 --warmup 1 "
+                                                     "--cpu-baseline 0 --whole-detector 0 --latency-leg 0 --exact-leg 0 --viper-leg 0 --no-graph "
+                                                     "(tools/collect_profiles.sh, passes [7a] / [7b])")
+        json.dump({"command": cmd, "kernels": res}, fh, indent=1)
     print(json.dumps({k: v.get("wave_cycles_share") for k, v in res.items()}))
 
 
