@@ -165,6 +165,9 @@ int svps_row_ln(const float* x, const float* pre, const float* post, const float
  * (mmdet/models/detectors/dynamic_mask_head.py:559-567: F.softmax(attn, dim=1) of [1, Lq, Lk], applied here to the transposed
  * logits [Lk, Lq]); max / exp / sum / divide in fp32 like torch.softmax. */
 int svps_row_softmax(const float* x, float* y, int rows, int cols, void* stream);
+/* the same times `scale` (> 0, a power of two): probabilities for a consumer that carries them as fp16 hi + lo (svps_bgemm_f16 with
+ * alpha = 1 / scale) - keeps near-zero probabilities out of fp16's subnormal range (precision "fp16x2", the temporal retriever) */
+int svps_row_softmax_scaled(const float* x, float* y, int rows, int cols, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K7' deformable convolution forward without a column buffer (slotvps_amd/csrc/deform_conv_fused.hip): replaces
@@ -395,6 +398,36 @@ int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, co
                        const void* feat, const void* aux, void* workspace,
                        size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,
                        int flags, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Reference precision ON THE MATRIX CORES (round 4; head.set_precision("fp16x2")): the reference runs this path in fp32
+ * (fp16_enabled = False, mmdet/models/detectors/vps_temporal_slots.py:55). gfx950's fp32 matrix instructions run at the vector
+ * rate, so these entry points carry every 16-bit matrix operand as FP16 hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 bits of
+ * mantissa, |x| < 65 504) and spend three MFMAs per product (hi hi + lo hi + hi lo) into one fp32 accumulator. The fused level maps
+ * are TWO fp16 planes [T, H*W, 256] (hi, lo): 1 KiB per pixel, the size of an fp32 map, in the operand form of the consumers.
+ * Against the reference's own fp32 outputs the free-running head then sits at the reference's own reproducibility (mask logits
+ * <= 1e-4, slot argmax identical wherever decidable: tests/test_refprec_gpu.py) - the bounds only the vector-ALU exact mode below met.
+ *   svps_level_fuse_hl_fwd   = svps_level_fuse_fwd (dynamic_mask_head.py:171-188): cur [T, 128, H, W] fp32 NCHW; prev_hi / prev_lo the
+ *                              coarser level's planes (both NULL: level 0); wc_hi / wc_lo [256, 384] fp16; out_hi / out_lo the planes
+ *   svps_retr_stats_hl_fwd   = svps_retr_stats_tight_fwd (:432-433, the two LayerNorm statistics) on the planes; same aux rows
+ *   svps_retr_attn_hl_fwd    = svps_retr_attn_tight_fwd (:435-456) on the planes, L <= 128; tiles of 16 pixels (hi rows + lo rows of
+ *                              the same pixels share one LDS tile); workspace svps_retr_attn_hl_workspace_bytes()
+ *   svps_mask_decode_hl_fwd  = svps_mask_decode_fwd (vps_temporal_slots.py:144-160) on the planes: fp32 logits [T, L, HW] (required),
+ *                              optional fused slot argmax [T, HW]; any HW, L <= 256
+ * Same rules as everywhere: no allocation, no synchronisation, launched on `stream`, 0 or an error code.
+ * ------------------------------------------------------------------------------------------- */
+int svps_level_fuse_hl_fwd(const float* cur, const void* prev_hi, const void* prev_lo, const void* wc_hi, const void* wc_lo,
+                           const float* bc, void* out_hi, void* out_lo, int T, int H, int W, void* stream);
+int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* ty, const float* tx, const void* rk_hi,
+                           const void* rk_lo, const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo,
+                           const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D, void* stream);
+size_t svps_retr_attn_hl_workspace_bytes(int T, int L, int H, int W, int chunks);
+int svps_retr_attn_hl_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
+                          const void* feat_hi, const void* feat_lo, const void* aux, void* workspace, size_t workspace_bytes,
+                          float* out_ext, int T, int L, int H, int W, int D, int chunks, void* stream);
+int svps_mask_decode_hl_fwd(const void* feat_hi, const void* feat_lo, const float* embed, const float* bn_scale,
+                            const float* bn_shift, float fg_scale, float fg_shift, float* out, uint8_t* slot_argmax,
+                            int T, int L, int HW, int D, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Exact mode: fp32 storage and fp32 arithmetic for the whole pixel side (slotvps_amd/csrc/exact_f32.hip).

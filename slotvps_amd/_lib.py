@@ -44,6 +44,7 @@ SIGNATURES = {
     "svps_level_fuse_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "svps_row_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp]),
     "svps_row_softmax": (_i, [_vp, _vp, _i, _i, _vp]),
+    "svps_row_softmax_scaled": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "svps_group_norm_relu_workspace_bytes": (_sz, [_i, _i, _i]),
     "svps_group_norm_relu_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "svps_retr_query_prep": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -64,6 +65,11 @@ SIGNATURES = {
     "svps_retr_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "svps_retr_attn_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_retr_attn_tight_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "svps_level_fuse_hl_fwd": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),
+    "svps_retr_stats_hl_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
+    "svps_retr_attn_hl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "svps_retr_attn_hl_fwd": (_i, [_vp] * 9 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "svps_mask_decode_hl_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_level_fuse_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "svps_kv_project_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp,
                                      _i, _i, _i, _i, _vp]),

@@ -84,7 +84,12 @@ class SlotClipRunner:
     def _step(self, slot=0):
         logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs,
                                                        clip_frames=self.clip_frames)
-        if fused[-1].dtype == torch.float32:                 # exact mode (head.set_precision("fp32")): fp32 map, fp32 decode kernel
+        if fused[-1].dim() == 4:                             # precision "fp16x2": the map as fp16 hi + lo planes; the logits are always written
+            masks, amax = ops.mask_decode_hl(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift, self.fg_scale, self.fg_shift,
+                                             want_argmax=True)
+            if not self.decode_logits:
+                masks = None
+        elif fused[-1].dtype == torch.float32:               # exact mode (head.set_precision("fp32")): fp32 map, fp32 decode kernel
             masks = ops.mask_decode_f32(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift, self.fg_scale, self.fg_shift)
             amax = masks.argmax(dim=1).to(torch.uint8)
             if not self.decode_logits:

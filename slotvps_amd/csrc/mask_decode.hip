@@ -23,17 +23,21 @@
 
 namespace svps {
 
-template <int NW, int NST>
+template <int NW, int NST, bool HL = false>
 struct DecLds {
     static constexpr int ring = 0;                         // NST feature tiles
-    static constexpr int affine = NST * kTileBytes;        // scale[256], shift[256] fp32
+    static constexpr int lo_ring = NST * kTileBytes;       // HL: NST tiles of the map's lo plane
+    static constexpr int affine = (HL ? 2 : 1) * NST * kTileBytes;   // scale[256], shift[256] fp32
     static constexpr int norm = affine + 2 * kD * 4;       // inv-norm per tile pixel [32]
     static constexpr int cshift = norm + kTilePx * 4;      // per-slot constant [NW * 32]
     static constexpr int amax = cshift + NW * 32 * 4;      // per-wave argmax candidates [NW][32] float2
     static constexpr int total = amax + NW * kTilePx * 8;
 };
 
-template <int NW, int NST, bool ARGMAX, typename OutT, typename MT = __bf16>
+// HL (round 4, the reference-precision mode: svps_mask_decode_hl_fwd): the map arrives as fp16 hi + lo planes (f = hi + lo to 22 bits,
+// svps_level_fuse_hl_fwd); both planes of a tile are staged, the norm runs on hi + lo in fp32 and the logits take three MFMAs per
+// k-step: e_hi f_hi + e_lo f_hi + e_hi f_lo (e . scale as fp16 hi + lo).
+template <int NW, int NST, bool ARGMAX, typename OutT, typename MT = __bf16, bool HL = false>
 __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
     const MT* __restrict__ feat,     // [T, HW, 256]
     const float* __restrict__ embed,     // [T, L, 256]
@@ -42,10 +46,11 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
     float fg_scale, float fg_shift,
     OutT* __restrict__ out,              // [T, L, HW]
     uint8_t* __restrict__ slot_argmax,   // [T, HW] or null
-    int L, int HW, int tiles_per_chunk) {
+    int L, int HW, int tiles_per_chunk,
+    const MT* __restrict__ feat_lo = nullptr) {   // HL: the lo plane [T, HW, 256]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the fused map, bf16 or fp16 (common.h)
-    using Lds = DecLds<NW, NST>;
+    using Lds = DecLds<NW, NST, HL>;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,11 +108,15 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
     for (int i = 0; i < 16; ++i) csr[i] = cs[32 * w + acc_row(i, h)];
 
     const char* fb = reinterpret_cast<const char*>(feat) + (size_t)t * HW * kRowBytes;
+    const char* fbl = HL ? reinterpret_cast<const char*>(feat_lo) + (size_t)t * HW * kRowBytes : nullptr;
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
-        if (s < nt) dma_tile<NW>(fb, px_begin + s * kTilePx, HW - 1, smem + Lds::ring + s * kTileBytes, w, lane);
+        if (s < nt) {
+            dma_tile<NW>(fb, px_begin + s * kTilePx, HW - 1, smem + Lds::ring + s * kTileBytes, w, lane);
+            if constexpr (HL) dma_tile<NW>(fbl, px_begin + s * kTilePx, HW - 1, smem + Lds::lo_ring + s * kTileBytes, w, lane);
+        }
 
-    constexpr int PIECES = kTilePx / 2 / NW;
+    constexpr int PIECES = (HL ? 2 : 1) * (kTilePx / 2 / NW);   // DMA instructions per wave and tile
     // thread -> (pixel, channel octet set) for the norm pass: 8 * NW / 4 threads per pixel
     constexpr int TPP = NW * 64 / kTilePx;       // threads per pixel (8 or 16)
     constexpr int CPT = 32 / TPP;                // 16-B chunks per thread (4 or 2)
@@ -122,10 +131,15 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
             wait_vm<0>();
         }
         wg_barrier();
-        if (it + NST - 1 < nt)
+        if (it + NST - 1 < nt) {
             dma_tile<NW>(fb, px_begin + (it + NST - 1) * kTilePx, HW - 1,
                          smem + Lds::ring + ((it + NST - 1) % NST) * kTileBytes, w, lane);
+            if constexpr (HL)
+                dma_tile<NW>(fbl, px_begin + (it + NST - 1) * kTilePx, HW - 1,
+                             smem + Lds::lo_ring + ((it + NST - 1) % NST) * kTileBytes, w, lane);
+        }
         const char* ft = smem + Lds::ring + (it % NST) * kTileBytes;
+        const char* ftl = smem + Lds::lo_ring + (it % NST) * kTileBytes;
 
         // -- ||scale * f + shift||^2 per pixel -------------------------------------------------
         {
@@ -134,9 +148,12 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
             for (int i = 0; i < CPT; ++i) {
                 const int chunk = nsub + TPP * i;
                 const mx8 x = *reinterpret_cast<const mx8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
+                mx8 xl;
+                if constexpr (HL) xl = *reinterpret_cast<const mx8*>(ftl + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float g = (float)x[j] * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
+                    const float xv = HL ? (float)x[j] + (float)xl[j] : (float)x[j];
+                    const float g = xv * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
                     ss += g * g;
                 }
             }
@@ -153,6 +170,7 @@ __global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
         for (int ks = 0; ks < 16; ++ks) {
             const mx8 ff = read_row_frag_as<mx8>(ft, ks, r, h);
             s = mfma16(el[ks], ff, s);
+            if constexpr (HL) s = mfma16(eh[ks], read_row_frag_as<mx8>(ftl, ks, r, h), s);
             s = mfma16(eh[ks], ff, s);
         }
         wg_barrier();  // inv_norm of this tile visible
@@ -716,12 +734,12 @@ namespace {
 
 int dec_num_cus() { return svps_num_cus(); }
 
-template <int NW, int NST, bool ARGMAX, typename OutT, typename MT = __bf16>
+template <int NW, int NST, bool ARGMAX, typename OutT, typename MT = __bf16, bool HL = false>
 hipError_t launch_decode(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
                          float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L,
-                         int HW, hipStream_t stream) {
-    using Lds = svps::DecLds<NW, NST>;
-    auto kern = svps::mask_decode_kernel<NW, NST, ARGMAX, OutT, MT>;
+                         int HW, hipStream_t stream, const void* feat_lo = nullptr) {
+    using Lds = svps::DecLds<NW, NST, HL>;
+    auto kern = svps::mask_decode_kernel<NW, NST, ARGMAX, OutT, MT, HL>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
     // sized for two workgroups per CU by LDS (2 x ~70 KiB); this first kernel needs 297 registers per lane, so in practice
@@ -732,7 +750,7 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(NW * 64), Lds::total, stream,
                        static_cast<const MT*>(feat), embed, bn_scale, bn_shift, fg_scale, fg_shift,
-                       static_cast<OutT*>(out), slot_argmax, L, HW, tpc);
+                       static_cast<OutT*>(out), slot_argmax, L, HW, tpc, static_cast<const MT*>(feat_lo));
     return hipGetLastError();
 }
 
@@ -836,6 +854,24 @@ extern "C" int svps_mask_decode_fwd(const void* feat, const float* embed, const 
                             : dispatch_decode<8, 4>(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift, out,
                                                     slot_argmax, T, L, HW, flags, stream);
 #undef SVPS_V2
+    svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
+    return (int)e;
+}
+
+// The decode of the reference-precision mode: the finest fused map as fp16 hi + lo planes (svps_level_fuse_hl_fwd), fp32 logits
+// [T, L, HW] and / or the fused per-pixel slot argmax; the first-generation kernel (any HW, L <= 256) with both planes staged.
+extern "C" int svps_mask_decode_hl_fwd(const void* feat_hi, const void* feat_lo, const float* embed, const float* bn_scale,
+                                       const float* bn_shift, float fg_scale, float fg_shift, float* out, uint8_t* slot_argmax,
+                                       int T, int L, int HW, int D, void* stream_) {
+    if (!feat_hi || !feat_lo || !embed || !bn_scale || !bn_shift || !out) return SVPS_ERR_BAD_ARG;
+    if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || HW <= 0) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)HW > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    using H = _Float16;
+    svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 0, stream);
+#define SVPS_HL(W, AM) launch_decode<W, 4, AM, float, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)
+    const hipError_t e = L <= 128 ? (slot_argmax ? SVPS_HL(4, true) : SVPS_HL(4, false)) : (slot_argmax ? SVPS_HL(8, true) : SVPS_HL(8, false));
+#undef SVPS_HL
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
     return (int)e;
 }

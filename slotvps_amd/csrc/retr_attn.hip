@@ -145,7 +145,17 @@ __device__ unsigned long long retr_clock[4096][4];       // [workgroup][memtime0
 // The exponentials of a tile stay in 16 registers across the barrier; the statistics buffer and the P ring are double-buffered.
 // PHL (precision form, L <= 128): P * rstd_v carried as fp16 hi + lo - a second P tile per buffer, the consumers' 18 MFMAs per tile
 // twice. Carried as ONE fp16 it is the largest term of the fused retriever's error against float64 (8.7e-4 of 1.1e-3).
-template <int ABL = 0, bool EXT = false, bool PHL = false>
+// HL (round 4, reference precision on the matrix cores; with PHL): the level map itself is fp16 hi + lo (two planes, f = hi + lo to 22
+// bits). A tile is then SIXTEEN pixels: rows 0 .. 15 of the 16-KiB LDS tile are their hi rows, rows 16 .. 31 their lo rows - the ring,
+// the swizzle, every fragment address and the barrier schedule stay those of the 32-pixel form (a 32-pixel tile of both planes would
+// need twice the ring, which the 160 KiB do not have next to the two P buffers). What changes:
+//   producers: the chain yields [Q''.f_hi | Q''.f_lo] in the two column halves of the accumulator; one v_permlane16_swap + add per
+//              register folds them (both halves then hold the logits of the same 16 pixels, so the P tile's rows 16 .. 31 repeat rows
+//              0 .. 15 - exactly the A operand the consumers' lo k-step needs); Cy + Cx start in the hi half only
+//   consumers: k-step 0 = hi rows (P_hi f_hi + P_lo f_hi + the aux block), k-step 1 = lo rows (P_hi f_lo only): 26 MFMAs per tile;
+//              waves 0, 1 stage the hi rows, waves 2, 3 the lo rows
+// Matrix work per pixel: producers 2 x, consumers 2.9 x the default form - the price of the reference's precision.
+template <int ABL = 0, bool EXT = false, bool PHL = false, bool HL = false>
 __global__ __launch_bounds__(512) void retr_attn_kernel(
     const __bf16* __restrict__ qh,      // [T, LP, 256]  hi(Q''), rows >= the real slot count zero
     const __bf16* __restrict__ ql,      // [T, LP, 256]  lo(Q'')
@@ -156,10 +166,13 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const __bf16* __restrict__ aux,     // [T, HW, 8]    retr_stats.hip: 16-byte rows {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32)}
     float* __restrict__ partial,        // [T, C, Lrow, 260]
     int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off,
-    const float2* __restrict__ ext_stats, int map_f16) {        // map_f16: the map is fp16 already (no conversion in LDS)
+    const float2* __restrict__ ext_stats, int map_f16,          // map_f16: the map is fp16 already (no conversion in LDS)
+    const __bf16* __restrict__ feat_lo) {                       // HL: the lo plane [T, HW, 256] fp16 (feat is the hi plane)
+    static_assert(!HL || (PHL && !EXT), "the hi + lo map form goes with hi + lo probabilities, L <= 128");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = RetrLdsT<PHL ? 2 : 1>;
     constexpr int A = kRPrefetch;
+    constexpr int TPX = HL ? 16 : kTilePx;                      // pixels per tile
     constexpr int kPBuf = (PHL ? 2 : 1) * kPTile;               // one P buffer: the hi tile (and the lo tile behind it)
 
     const int lane = threadIdx.x & 63;
@@ -167,6 +180,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const int sb = w & 3;
     const bool consumer = w >= 4;
     const int r = lane & 31, h = lane >> 5;
+    const int rp = HL ? (r & 15) : r;                           // this lane's pixel inside the tile
     const int C = gridDim.x;
     int t = blockIdx.y, c = blockIdx.x;
     if ((gridDim.y & 7) == 0) {
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         t = (b & 7) + 8 * (n / C);
         c = n % C;
     }
-    const int tiles = ((W + kTilePx - 1) / kTilePx) * H;
+    const int tiles = ((W + TPX - 1) / TPX) * H;
     const int tid0 = c * tiles_per_chunk;
     int nt = tiles - tid0;
     nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;           // >= 1 by construction of the grid
@@ -224,12 +238,16 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         // Cx of this lane's pixel column: constant down a strip (clamped past the right edge: those pixels are masked)
         f32x4 cxv[4];
         auto load_cx = [&](int strip) {
-            int xx = kTilePx * strip + r;
+            int xx = TPX * strip + rp;
             xx = xx < W ? xx : W - 1;
             const int xo = (xx * LP + slot0) * 4;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) cxv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cxr, xo + 32 * g, 0, 0));
+            for (int g = 0; g < 4; ++g) {
+                cxv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cxr, xo + 32 * g, 0, 0));
+                if (HL && (r & 16)) cxv[g] = f32x4{0.f, 0.f, 0.f, 0.f};       // the lo half of the accumulator starts from zero
+            }
         };
+        const float cy_on = (HL && (r & 16)) ? 0.f : 1.f;
         int ts = strip0, ty = row0;                                 // strip / image row of tile `it`
         f32x16 cinit;                                               // Cy + Cx of tile `it`: the initial value of its accumulator
         f32x2 ext_n = {0.f, 0.f};                                   // EXT: statistics of this lane's pixel, requested one tile ahead
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             for (int g = 0; g < 4; ++g) {
                 const f32x4 cyv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cinit[4 * g + j] = cyv[j] + cxv[g][j];
+                for (int j = 0; j < 4; ++j) cinit[4 * g + j] = cyv[j] * cy_on + cxv[g][j];
             }
         }
         request_ext(ts, ty);
@@ -371,10 +389,20 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             }
             RETR_STAMP(0, 2);
             if constexpr (!CHAIN) return;
+            if constexpr (HL) {
+                // columns r < 16: Q''.f_hi + Cy + Cx of pixel r; columns r >= 16: Q''.f_lo of pixel r - 16. Fold the halves: afterwards
+                // both hold the full sum (v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of
+                // its second: with the same value in both, the two results are [row0, row0, row2, row2] and [row1, row1, row3, row3])
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[i]), __float_as_uint(s[i]), false, false);
+                    s[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                }
+            }
             // ---- softmax head of tile it
             // log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no masking: their
             // Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep), so they come out as -1e30 and exp2 to exactly 0.
-            live_p = kTilePx * ts + r < W;
+            live_p = TPX * ts + rp < W;
             ++ty;
             if (ty == H) { ty = 0; ++ts; if (it + 1 < nt) load_cx(ts); }
             const bool more = it + 1 < nt;
@@ -417,7 +445,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cinit[4 * g + j] = cyv[g][j] + cxv[g][j];
+                for (int j = 0; j < 4; ++j) cinit[4 * g + j] = cyv[g][j] * cy_on + cxv[g][j];
             if (more) prefetch(it + 1);
             RETR_STAMP(0, 5);
         };
@@ -445,38 +473,41 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     }
 
     // =================================== consumer ===============================================
-    const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    // HL: tile rows 0 .. 15 come from the hi plane (waves 0, 1), rows 16 .. 31 from the lo plane (waves 2, 3), same 16 pixels
+    const u32x4 frs = ra_make_srd((HL && sb >= 2 ? feat_lo : feat) + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
     const u32x4 ars = ra_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * kAuxRow);
     const u32x4 yrs = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
     int voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = 8 * sb + 2 * i + h;
-        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+        const int row = 8 * sb + 2 * i + h;                     // row of the LDS tile
+        voff[i] = (HL ? (row & 15) : row) * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
     }
     const int nb = 4 + ((sb == 0 || sb == 2) ? 1 : 0);          // DMA instructions of one batch of this wave
     int ds = strip0, dy = row0;                                 // strip / image row of the next batch
     auto issue_batch = [&](int b) {
         if (b >= nt) return;
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % kRNF) * kTileBytes + sb * 4 * 1024);
-        const int px0 = dy * W + kTilePx * ds;
+        const int px0 = dy * W + TPX * ds;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
-        if (px0 + kTilePx <= HW) {
+        if (px0 + TPX <= HW) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra_dma16(frs, st + i * 1024, voff[i], soff);
         } else {                                                 // last row of a ragged strip: clamp the source rows (their P is 0)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = 8 * sb + 2 * i + h;
-                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                const int prow_ = HL ? (row & 15) : row;
+                const int src = px0 + prow_ < HW ? prow_ : HW - 1 - px0;
                 ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
             }
         }
         ++dy;
         if (dy == H) { dy = 0; ++ds; }
         if (sb == 0) {                                           // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
+            // HL: 16 pixels, rows 16 .. 31 repeat rows 0 .. 15 (the producers' lanes r and r + 16 belong to the same pixel)
             const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % kRNF) * kAuxTile);
-            ra_dma16(ars, sa, (px0 + (lane & 31)) * kAuxRow, 0);
+            ra_dma16(ars, sa, (px0 + (lane & (TPX - 1))) * kAuxRow, 0);
         } else if (sb == 2) {                                    // Cy row of tile b + 1 (1 KiB from the start of its image row)
             const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b + 1) % kRNF) * kCyTile);
             ra_dma16_cached(yrs, sy, dy * LP * 4 + lane * 16);
@@ -540,18 +571,20 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             }
             if (q == 1) {
                 ah[1] = cat(tr(p0 + 1024), tr(p1 + 1024));
-                if constexpr (PHL) al[1] = cat(tr(p0 + kPTile + 1024), tr(p1 + kPTile + 1024));
-                af[1] = cat(tr(aa + 16 * kAuxRow), tr(aa + 20 * kAuxRow));
+                if constexpr (PHL && !HL) al[1] = cat(tr(p0 + kPTile + 1024), tr(p1 + kPTile + 1024));
+                if constexpr (!HL) af[1] = cat(tr(aa + 16 * kAuxRow), tr(aa + 20 * kAuxRow));
             }
             __builtin_amdgcn_sched_barrier(0);
+            // HL: k-step 1 holds the lo rows of the SAME pixels: P_hi f_lo only (P_lo f_lo is below fp32 resolution), no aux block
+            const bool lo_step = HL && ks == 1;                      // (compile-time after unrolling)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
-                if constexpr (PHL) o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
+                if (PHL && !lo_step) o[4 * half + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], vf[q & 1][u], o[4 * half + u], 0, 0, 0);
             }
-            if (half == 0) {
+            if (half == 0 && !lo_step) {
                 oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], af[ks], oa, 0, 0, 0);
-                if constexpr (PHL) oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], af[ks], oa, 0, 0, 0);
+                if (PHL) oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], af[ks], oa, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -1313,8 +1346,8 @@ struct RetrPlan {
     int chunks, tiles_per_chunk;
 };
 // retriever: tiles of 32 pixels inside an image row, walked strip by strip (retr_attn_kernel)
-RetrPlan plan_retr(int T, int H, int W, int chunks_req) {
-    const int tiles = ((W + svps::kTilePx - 1) / svps::kTilePx) * H;
+RetrPlan plan_retr(int T, int H, int W, int chunks_req, int tpx = svps::kTilePx) {
+    const int tiles = ((W + tpx - 1) / tpx) * H;
     int chunks = chunks_req;
     if (chunks <= 0) chunks = svps_pick_chunks(T, tiles, svps_num_cus(), 64);
     if (chunks > tiles) chunks = tiles;
@@ -1374,7 +1407,7 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         static SvpsLdsAttr attr[5];
         if (hipError_t ae = attr[slot].ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
-                           L, HW, H, W, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, mf);
+                           L, HW, H, W, p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, mf, (const __bf16*)nullptr);
         e = hipGetLastError();
     } else if (!retr_three_launch()) {
         // more than 128 slots (padded layouts of 256 rows), two passes: probabilities of all slots -> workspace, then P f
@@ -1406,11 +1439,11 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
-                           128, HW, H, W, p.tiles_per_chunk, 256, L, 0, (const float2*)st, mf);
+                           128, HW, H, W, p.tiles_per_chunk, 256, L, 0, (const float2*)st, mf, (const __bf16*)nullptr);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
-                           L - 128, HW, H, W, p.tiles_per_chunk, 256, L, 128, (const float2*)st, mf);
+                           L - 128, HW, H, W, p.tiles_per_chunk, 256, L, 128, (const float2*)st, mf, (const __bf16*)nullptr);
         e = hipGetLastError();
     }
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
@@ -1421,28 +1454,31 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
     return (int)hipGetLastError();
 }
 
-// Precision form of svps_retr_attn_fwd for L <= 128: P * rstd_v as fp16 hi + lo (retr_attn_kernel<0, false, true>). Same contract
-// and workspace.
-extern "C" int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
-                                        const void* feat, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext,
-                                        int T, int L, int H, int W, int D, int chunks, int flags, void* stream_) {
+// Precision forms of svps_retr_attn_fwd for L <= 128: P * rstd_v as fp16 hi + lo (retr_attn_kernel<0, false, true>); with feat_lo also
+// the map as fp16 hi + lo planes in 16-pixel tiles (retr_attn_kernel<0, false, true, true>, the reference-precision mode).
+namespace {
+int launch_retr_precise(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3, const void* feat,
+                        const void* feat_lo, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext, int T, int L,
+                        int H, int W, int D, int chunks, int flags, void* stream_) {
     if (!qh || !ql || !cy || !cx || !c3 || !feat || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     const int HW = H * W;
-    const RetrPlan p = plan_retr(T, H, W, chunks);
+    const bool hl = feat_lo != nullptr;
+    const RetrPlan p = plan_retr(T, H, W, chunks, hl ? 16 : svps::kTilePx);
     const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
     if (workspace_bytes < partial_bytes) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
-    auto kern = svps::retr_attn_kernel<0, false, true>;
+    auto kern = hl ? svps::retr_attn_kernel<0, false, true, true> : svps::retr_attn_kernel<0, false, true, false>;
     using Lds = svps::RetrLdsT<2>;
-    static SvpsLdsAttr attr;
-    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
+    static SvpsLdsAttr attr[2];
+    if (hipError_t ae = attr[hl ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
     hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream, static_cast<const __bf16*>(qh), static_cast<const __bf16*>(ql),
                        cy, cx, c3, static_cast<const __bf16*>(feat), static_cast<const __bf16*>(aux), partial, L, HW, H, W,
-                       p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, (flags & SVPS_FLAG_MAP_F16) ? 1 : 0);
+                       p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, (hl || (flags & SVPS_FLAG_MAP_F16)) ? 1 : 0,
+                       static_cast<const __bf16*>(feat_lo));
     hipError_t e = hipGetLastError();
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
     if (e != hipSuccess) return (int)e;
@@ -1450,6 +1486,27 @@ extern "C" int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const fl
     hipLaunchKernelGGL(svps::retr_finish_kernel, dim3(L, T), dim3(256), 0, stream, partial, out_ext, L, p.chunks);
     svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 1, stream);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
+                                        const void* feat, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext,
+                                        int T, int L, int H, int W, int D, int chunks, int flags, void* stream_) {
+    return launch_retr_precise(qh, ql, cy, cx, c3, feat, nullptr, aux, workspace, workspace_bytes, out_ext, T, L, H, W, D, chunks, flags, stream_);
+}
+
+extern "C" size_t svps_retr_attn_hl_workspace_bytes(int T, int L, int H, int W, int chunks) {
+    if (T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return 0;
+    const RetrPlan p = plan_retr(T, H, W, chunks, 16);
+    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
+}
+
+extern "C" int svps_retr_attn_hl_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
+                                     const void* feat_hi, const void* feat_lo, const void* aux, void* workspace, size_t workspace_bytes,
+                                     float* out_ext, int T, int L, int H, int W, int D, int chunks, void* stream_) {
+    if (!feat_lo) return SVPS_ERR_BAD_ARG;
+    return launch_retr_precise(qh, ql, cy, cx, c3, feat_hi, feat_lo, aux, workspace, workspace_bytes, out_ext, T, L, H, W, D, chunks,
+                               SVPS_FLAG_MAP_F16, stream_);
 }
 
 #ifdef SVPS_RETR_STAMP

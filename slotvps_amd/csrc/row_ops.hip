@@ -68,7 +68,10 @@ __global__ __launch_bounds__(256) void row_ln_kernel(const float* __restrict__ x
 // (max, exp(x - max), sum), the division as a multiplication by the reciprocal of the sum (<= 1 ulp from torch's divide). y may BE x
 // (ops.row_softmax(inplace=True)): the pointers are not declared __restrict__, and a lane only ever re-reads the element it writes.
 // Rows are 2 KB: the second and third read come from L1 / L2.
-__global__ __launch_bounds__(256) void row_softmax_kernel(const float* x, float* y, int rows, int cols) {
+// `scale` (a power of two): y = scale * softmax(x) - for a consumer that carries the probabilities as fp16 hi + lo (svps_bgemm_f16): below
+// 6.1e-5 fp16 is subnormal (absolute resolution 6e-8), and a query that receives almost no mass from any key has its whole output row
+// in that range while the LayerNorm behind it scales the row back up by up to 1 / sqrt(eps).
+__global__ __launch_bounds__(256) void row_softmax_kernel(const float* x, float* y, int rows, int cols, float scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void row_softmax_kernel(const float* x, float*
     float sum = 0.f;
     for (int c = lane; c < cols; c += 64) sum += expf(xr[c] - m);
     sum = wave_sum(sum);
-    const float inv = 1.f / sum;
+    const float inv = (1.f / sum) * scale;                   // (scale = 1: unchanged; a power of two: exact)
     for (int c = lane; c < cols; c += 64) yr[c] = expf(xr[c] - m) * inv;
 }
 
@@ -332,6 +335,13 @@ extern "C" int svps_row_ln(const float* x, const float* pre, const float* post, 
 extern "C" int svps_row_softmax(const float* x, float* y, int rows, int cols, void* stream_) {
     if (!x || !y) return SVPS_ERR_BAD_ARG;
     if (rows <= 0 || cols <= 0) return SVPS_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL(svps::row_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), x, y, rows, cols);
+    hipLaunchKernelGGL(svps::row_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), x, y, rows, cols, 1.f);
+    return (int)hipGetLastError();
+}
+
+extern "C" int svps_row_softmax_scaled(const float* x, float* y, int rows, int cols, float scale, void* stream_) {
+    if (!x || !y) return SVPS_ERR_BAD_ARG;
+    if (rows <= 0 || cols <= 0 || !(scale > 0.f)) return SVPS_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(svps::row_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), x, y, rows, cols, scale);
     return (int)hipGetLastError();
 }

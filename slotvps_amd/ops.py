@@ -265,15 +265,19 @@ def row_ln(x, w, b, eps=1e-5, pre=None, post=None, relu=False, rows_per_group=No
     return out
 
 
-def row_softmax(x, inplace=False):
-    """Softmax over the last index of a contiguous fp32 tensor (csrc/row_ops.hip), one wavefront per row."""
+def row_softmax(x, inplace=False, scale=1.0):
+    """Softmax over the last index of a contiguous fp32 tensor (csrc/row_ops.hip), one wavefront per row. scale (a power of two):
+    scale * softmax(x), for a consumer that carries the probabilities as fp16 hi + lo (bgemm(split="fp16", alpha=1 / scale))."""
     lib = _lib.load()
     _need(x, "x", torch.float32)
     cols = x.shape[-1]
     rows = x.numel() // cols
     out = x if inplace else torch.empty_like(x)
     with _on(x, out) as ctx:
-        rc = lib.svps_row_softmax(_ptr(x), _ptr(out), rows, cols, ctx.stream)
+        if scale == 1.0:
+            rc = lib.svps_row_softmax(_ptr(x), _ptr(out), rows, cols, ctx.stream)
+        else:
+            rc = lib.svps_row_softmax_scaled(_ptr(x), _ptr(out), rows, cols, float(scale), ctx.stream)
     _lib.check(rc, "svps_row_softmax")
     return out
 
@@ -717,6 +721,121 @@ def _need_any(t, name):
         raise TypeError(f"{name}: fp32 tensor expected")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: the HIP path needs a GPU tensor (no CPU fallback)")
+
+
+# ---- reference precision on the matrix cores: every 16-bit operand as fp16 hi + lo (csrc/level_fuse_hl.hip and the HL forms of
+# ---- retr_stats_t.hip, retr_attn.hip, mask_decode.hip). A level map is ONE tensor [2, T, HW, 256] fp16: plane 0 = hi, plane 1 = lo.
+def split_hl(x):
+    """fp32 tensor -> [2, *x.shape] fp16 (hi, lo) with hi + lo = x to a 22-bit mantissa (|x| < 65 504)."""
+    _need(x, "x", torch.float32)
+    hi, lo = retr_split(x.contiguous())
+    return torch.stack([hi, lo])
+
+
+def _need_hl(t, name, T=None):
+    _need(t, name, torch.float16, 4)
+    if t.shape[0] != 2 or t.shape[3] != D_MODEL or (T is not None and t.shape[1] != T):
+        raise ValueError(f"{name}: expected [2 (hi, lo), T, HW, 256] fp16, got {tuple(t.shape)}")
+
+
+def level_fuse_hl(cur, prev_hl, wc_hl, bc, H, W):
+    """K4 at the reference's precision (csrc/level_fuse_hl.hip): cur [T, 128, H, W] fp32 NCHW, prev_hl [2, T, (H/2)(W/2), 256] fp16 planes
+    of the coarser level or None (level 0), wc_hl [2, 256, 384] fp16 (split_hl of the conv weight), bc [256] fp32
+    -> the fused map as planes [2, T, H*W, 256] fp16 (hi, lo). dynamic_mask_head.py:171-188."""
+    lib = _lib.load()
+    _need(cur, "cur", torch.float32, 4)
+    T = cur.shape[0]
+    if cur.shape != (T, 128, H, W):
+        raise ValueError(f"cur {tuple(cur.shape)} != [T, 128, {H}, {W}]")
+    _need(wc_hl, "wc_hl", torch.float16, 3)
+    if wc_hl.shape != (2, 256, 384):
+        raise ValueError("wc_hl must be [2, 256, 384]")
+    _need(bc, "bc", torch.float32, 1)
+    if prev_hl is not None:
+        _need_hl(prev_hl, "prev_hl", T)
+        if prev_hl.shape[2] != (H // 2) * (W // 2) or H % 2 or W % 2:
+            raise ValueError(f"prev_hl {tuple(prev_hl.shape)} does not match an {H}x{W} level")
+    out = torch.empty((2, T, H * W, 256), dtype=torch.float16, device=cur.device)
+    with _on(cur, prev_hl, wc_hl, bc) as ctx:
+        rc = lib.svps_level_fuse_hl_fwd(_ptr(cur), _ptr(None if prev_hl is None else prev_hl[0]), _ptr(None if prev_hl is None else prev_hl[1]),
+                                        _ptr(wc_hl[0]), _ptr(wc_hl[1]), _ptr(bc), _ptr(out[0]), _ptr(out[1]), T, H, W, ctx.stream)
+    _lib.check(rc, "svps_level_fuse_hl_fwd")
+    return out
+
+
+def retr_stats_hl(feat_hl, H, W, pos_proj, rk_hi, rk_lo, rbk, eps_k, rv_hi, rv_lo, rbv, eps_v):
+    """retr_stats_tight on a map given as fp16 hi + lo planes [2, T, HW, 256]: the same aux rows [T, HW, 8]."""
+    lib = _lib.load()
+    _need_hl(feat_hl, "feat_hl")
+    _, T, HW, D = feat_hl.shape
+    if HW != H * W:
+        raise ValueError("feat rows != H*W")
+    for name, m in (("rk_hi", rk_hi), ("rk_lo", rk_lo), ("rv_hi", rv_hi), ("rv_lo", rv_lo)):
+        _need(m, name, torch.float16, 2)
+        if m.shape != (D, D):
+            raise ValueError(f"{name} must be [256, 256]")
+    _need(rbk, "rbk", torch.float32, 1)
+    _need(rbv, "rbv", torch.float32, 1)
+    ytab = xtab = None
+    if pos_proj is not None:
+        ytab, xtab = pos_proj
+        _need(ytab, "ty", torch.float32, 2)
+        _need(xtab, "tx", torch.float32, 2)
+        if ytab.shape != (H, D) or xtab.shape != (W, D):
+            raise ValueError("projected position tables do not match (H, W)")
+    aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat_hl.device)
+    with _on(feat_hl, ytab, xtab, rk_hi, rk_lo, rbk, rv_hi, rv_lo, rbv) as ctx:
+        rc = lib.svps_retr_stats_hl_fwd(_ptr(feat_hl[0]), _ptr(feat_hl[1]), _ptr(ytab), _ptr(xtab), _ptr(rk_hi), _ptr(rk_lo), _ptr(rbk),
+                                        float(eps_k), _ptr(rv_hi), _ptr(rv_lo), _ptr(rbv), float(eps_v), _ptr(aux), T, H, W, D, ctx.stream)
+    _lib.check(rc, "svps_retr_stats_hl_fwd")
+    return aux
+
+
+def retr_attn_hl(qh, ql, cy, cx, c3, feat_hl, aux, L, H, W, chunks=0):
+    """retr_attn (precision form: P * rstd_v as fp16 hi + lo) on a map given as fp16 hi + lo planes [2, T, HW, 256]; L <= 128."""
+    lib = _lib.load()
+    _need(qh, "qh", torch.float16, 3)
+    _need(ql, "ql", torch.float16, 3)
+    _need_hl(feat_hl, "feat_hl")
+    _need(aux, "aux", torch.float16, 3)
+    for name, x in (("cy", cy), ("cx", cx)):
+        _need(x, name, torch.float32, 3)
+    _need(c3, "c3", torch.float32, 2)
+    _, T, HW, D = feat_hl.shape
+    if not 1 <= L <= 128:
+        raise NotImplementedError("the reference-precision retriever covers 1 <= L <= 128 slots")
+    LP = 128
+    if (HW != H * W or qh.shape != (T, LP, D) or ql.shape != (T, LP, D) or cy.shape != (T, H, LP) or cx.shape != (T, W, LP)
+            or c3.shape != (T, LP) or aux.shape != (T, HW, 8)):
+        raise ValueError("shape mismatch")
+    ws_bytes = lib.svps_retr_attn_hl_workspace_bytes(T, L, H, W, chunks)
+    ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat_hl.device)
+    out = torch.empty((T, L, 272), dtype=torch.float32, device=feat_hl.device)
+    with _on(qh, ql, cy, cx, c3, feat_hl, aux) as ctx:
+        rc = lib.svps_retr_attn_hl_fwd(_ptr(qh), _ptr(ql), _ptr(cy), _ptr(cx), _ptr(c3), _ptr(feat_hl[0]), _ptr(feat_hl[1]), _ptr(aux),
+                                       _ptr(ws), ws_bytes, _ptr(out), T, L, H, W, D, chunks, ctx.stream)
+    _lib.check(rc, "svps_retr_attn_hl_fwd")
+    return out
+
+
+def mask_decode_hl(feat_hl, embed, bn_scale, bn_shift, fg_scale, fg_shift, want_argmax=False):
+    """K2 on a map given as fp16 hi + lo planes [2, T, HW, 256]: mask logits [T, L, HW] fp32 (+ uint8 slot argmax [T, HW])."""
+    lib = _lib.load()
+    _need_hl(feat_hl, "feat_hl")
+    _need(embed, "embed", torch.float32, 3)
+    _need(bn_scale, "bn_scale", torch.float32, 1)
+    _need(bn_shift, "bn_shift", torch.float32, 1)
+    _, T, HW, D = feat_hl.shape
+    L = embed.shape[1]
+    if embed.shape != (T, L, D) or bn_scale.numel() != D or bn_shift.numel() != D:
+        raise ValueError("shape mismatch")
+    out = torch.empty((T, L, HW), dtype=torch.float32, device=feat_hl.device)
+    amax = torch.empty((T, HW), dtype=torch.uint8, device=feat_hl.device) if want_argmax else None
+    with _on(feat_hl, embed, bn_scale, bn_shift) as ctx:
+        rc = lib.svps_mask_decode_hl_fwd(_ptr(feat_hl[0]), _ptr(feat_hl[1]), _ptr(embed), _ptr(bn_scale), _ptr(bn_shift), float(fg_scale),
+                                         float(fg_shift), _ptr(out), _ptr(amax), T, L, HW, D, ctx.stream)
+    _lib.check(rc, "svps_mask_decode_hl_fwd")
+    return (out, amax) if want_argmax else out
 
 
 # ---- exact mode: fp32 storage, fp32 arithmetic (csrc/exact_f32.hip) ---------------------------------------------

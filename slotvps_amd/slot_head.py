@@ -65,9 +65,22 @@ def fast_linear(owner, name, x, weight, bias=None, act=None, out=None, split="bf
     exact mode (owner.precision == "fp32") or shapes K8 does not cover: the GEMM library in fp32.
     act: None, "relu" or "gelu"."""
     N, K = weight.shape
-    if getattr(owner, "precision", "bf16") == "fp32" or N % 256 or K % 16 or not x.is_cuda or not owner.use_slot_gemm:
+    prec = getattr(owner, "precision", "bf16")
+    if prec == "fp32" or N % 256 or K % 16 or not x.is_cuda or not owner.use_slot_gemm:
         y = F.linear(x, weight, bias)
         y = F.relu(y) if act == "relu" else (F.gelu(y) if act == "gelu" else y)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    if prec == "fp16x2":
+        # reference precision on the matrix cores: both operands as fp16 hi + lo (22 bits; K8's F16 form, 2.8e-6 against float64 where the
+        # bf16 split measures 2.5e-5 and the library's fp32 4e-6 ... 1e-5). That form has no activation epilogue: applied behind it.
+        wp = _cached(owner, "wp_" + name + "_f16", [weight], lambda: ops.pack_b_fragments(weight, "fp16"))
+        y = ops.slot_gemm(x.contiguous(), wp, bias, ops.ACT_NONE, out if act is None else None)
+        if act is None:
+            return y
+        y = F.relu_(y) if act == "relu" else F.gelu(y)
         if out is not None:
             out.copy_(y)
             return out
@@ -84,7 +97,7 @@ def fast_linear_ln(owner, name, x, weight, bias, norm, pre=None, post=None, relu
     two-launch form; otherwise fast_linear + K5."""
     gamma, beta, eps = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else norm
     N, K = weight.shape
-    if (getattr(owner, "precision", "bf16") == "fp32" or N != 256 or K % 16 or not x.is_cuda or not owner.use_slot_gemm
+    if (getattr(owner, "precision", "bf16") in ("fp32", "fp16x2") or N != 256 or K % 16 or not x.is_cuda or not owner.use_slot_gemm
             or not getattr(owner, "fuse_ln", True)):
         y = fast_linear(owner, name, x, weight, bias)
         y = ops.row_ln(y.contiguous(), gamma, beta, eps, pre=None if pre is None else pre.contiguous().view_as(y),
@@ -112,7 +125,7 @@ def fast_ffn(owner, x, lin1, lin2, norm, act, post=None):
     """LN(x + lin2(act(lin1(x)))) (+ post): the feed-forward block of a stage (dynamic_mask_head.py:379-385, :519-525). bf16 mode:
     ONE launch (csrc/slot_ffn.hip, the hidden tensor stays on the CU), bitwise the two K8 launches it replaces; otherwise those."""
     H, K = lin1.weight.shape
-    if (getattr(owner, "precision", "bf16") == "fp32" or K != 256 or lin2.weight.shape[0] != 256 or H % 256 or not x.is_cuda
+    if (getattr(owner, "precision", "bf16") in ("fp32", "fp16x2") or K != 256 or lin2.weight.shape[0] != 256 or H % 256 or not x.is_cuda
             or not owner.use_slot_gemm or not getattr(owner, "fuse_ffn", True) or not getattr(owner, "fuse_ln", True)
             or lin1.bias is None or lin2.bias is None):
         hid = fast_linear(owner, "linear1", x, lin1.weight, lin1.bias, act=act)
@@ -275,6 +288,7 @@ class MaskDynamicConv(nn.Module):
         c = self._fused_consts()
         T, L, C = slots.shape
         H, W = hw
+        hl = feat_pm.dim() == 4                          # the map as fp16 hi + lo planes [2, T, HW, C] (precision "fp16x2")
         if self.norm_v.eps < 4e-6:
             # the kernels carry 2^7 * P * rstd_v as fp16 (csrc/common.h, kPScale): rstd_v <= 1 / sqrt(eps_v) must stay below 511
             raise ValueError(f"fused retriever: norm_v.eps = {self.norm_v.eps} < 4e-6 is outside the fp16 range of the probabilities; "
@@ -285,7 +299,13 @@ class MaskDynamicConv(nn.Module):
             self._level_stats = None
             if pending is not None and pending[0] is feat_pm:
                 stats = pending[1]
-        if self.tight_stats:
+        if hl:
+            # reference precision: factors AND map as fp16 hi + lo (K3t's HL form: three MFMAs per product)
+            if L > 128:
+                raise NotImplementedError("precision 'fp16x2' covers L <= 128 slots (the exact mode, set_precision('fp32'), has no limit)")
+            pp, rk, rbk, ek, rv, rbv, ev = self.stats_args(pos_tabs)
+            stats = ops.retr_stats_hl(feat_pm, H, W, pp, rk, c["rk_lo"], rbk, ek, rv, c["rv_lo"], rbv, ev)
+        elif self.tight_stats:
             # precision form: both statistics from factors carried as fp16 hi + lo (K3t)
             pp, rk, rbk, ek, rv, rbv, ev = self.stats_args(pos_tabs)
             stats = ops.retr_stats_tight(feat_pm, H, W, pp, rk, c["rk_lo"], rbk, ek, rv, c["rv_lo"], rbv, ev)
@@ -320,6 +340,11 @@ class MaskDynamicConv(nn.Module):
         else:
             cy = a1[:, None, :].expand(T, H, LP).contiguous()
             cx = torch.zeros((T, W, LP), dtype=torch.float32, device=slots.device)
+        if hl:
+            ext = ops.retr_attn_hl(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W)
+            # the pixel sums A_l reach |f| * (pixels a slot owns): beyond fp16's range at the fine levels, so this one product (272 -> 256 on
+            # [T L] rows) runs in the library's fp32; norm1 + ReLU on K5
+            return ops.row_ln(F.linear(ext, c["wext_lin"]), self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)
         ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W, tight=tight)
         # :456 (value projection after the sum) + :458-459 (norm1, ReLU) in one launch
         return fast_linear_ln(self, "wext", ext, c["wext_lin"], None, self.norm1, relu=True)
@@ -341,6 +366,10 @@ class MaskDynamicConv(nn.Module):
                                       self.norm_k.bias, self.norm_k.eps, wvT, self.to_v.bias, self.norm_v.weight,
                                       self.norm_v.bias, self.norm_v.eps)
             return ops.slot_attn_f32(q, k, v, self.norm1.weight, self.norm1.bias, eps=self.norm1.eps)
+        if self.precision == "fp16x2":
+            if feat_pm.dim() != 4:
+                raise ValueError("precision 'fp16x2' takes the level map as fp16 hi + lo planes [2, T, HW, C] (ops.split_hl / ops.level_fuse_hl)")
+            return self.forward_fused(slots, feat_pm, hw, pos_tabs)
         if feat_pm.dtype == torch.float16 and self.retriever != "fused":
             raise NotImplementedError("fp16 level maps (map_dtype='fp16') go with the fused retriever")
         if self.retriever == "fused":
@@ -360,6 +389,9 @@ class MaskDynamicConv(nn.Module):
     def forward(self, pro_features, features, pos, gt_non_void_mask=None):
         assert gt_non_void_mask is None
         n, c, h, w = features.shape
+        if self.precision == "fp16x2":
+            feat_pm = ops.split_hl(features.permute(0, 2, 3, 1).reshape(n, h * w, c).float().contiguous())
+            return self.forward_pm(pro_features.float(), feat_pm, (h, w), pos_tables_from_map(pos))
         store = torch.float32 if self.precision == "fp32" else (torch.float16 if getattr(self, "map_dtype", "bf16") == "fp16" else BF16)
         feat_pm = features.permute(0, 2, 3, 1).reshape(n, h * w, c).to(store).contiguous()
         return self.forward_pm(pro_features.float(), feat_pm, (h, w), pos_tables_from_map(pos))
@@ -429,8 +461,13 @@ class SlotsDynamicConv(nn.Module):
         # softmax over the QUERY axis (dim=1 of [1, Lq, Lk], :562) = last-dim softmax of the transposed logits
         if self.precision != "fp32" and self.use_slot_gemm and q.is_cuda:
             # K9 (csrc/bgemm.hip): both products on the matrix cores in split bf16; the second one reads attn_t k-major
-            attn_t = ops.row_softmax(ops.bgemm(k, q), inplace=True)            # [G, Lk, Lq]
-            out = ops.bgemm(attn_t.transpose(1, 2), v.transpose(1, 2)).view(1, -1, self.hidden_dim)
+            sp = "fp16" if self.precision == "fp16x2" else "bf16"             # operand split of K9 (fp16 hi + lo: 22 bits)
+            # fp16 split: the probabilities travel times 2^14 (<= 16 384). The softmax runs over the QUERY axis, so a query can receive
+            # almost no mass from any key - its whole output row would sit in fp16's subnormal range (absolute resolution 6e-8) while
+            # norm1 behind it scales the row back up by up to 1 / sqrt(eps) = 316 (measured: 2e-4 on a stage, against 1e-5)
+            psc = 16384.0 if sp == "fp16" else 1.0
+            attn_t = ops.row_softmax(ops.bgemm(k, q, split=sp), inplace=True, scale=psc)            # [G, Lk, Lq]
+            out = ops.bgemm(attn_t.transpose(1, 2), v.transpose(1, 2), split=sp, alpha=1.0 / psc).view(1, -1, self.hidden_dim)
         else:
             attn_t = torch.softmax(k @ q.transpose(-1, -2), dim=-1)     # [1, Lk, Lq]
             out = (attn_t.transpose(-1, -2) @ v).reshape(1, -1, self.hidden_dim)
@@ -517,9 +554,14 @@ class MaskRCNNHead(nn.Module):
         nh = mha.num_heads
         qkv = fast_linear(self, "in_proj", slots, mha.in_proj_weight, mha.in_proj_bias).view(T, L, 3, nh, C // nh)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [T, heads, L, C / heads] views
-        if self.precision == "fp32":                                        # explicit fp32 products, torch's own order (:352)
+        if self.precision in ("fp32", "fp16x2"):                            # explicit fp32 products, torch's own order (:352)
             attn = torch.softmax((q * (1.0 / math.sqrt(C // nh))) @ k.transpose(-1, -2), dim=-1)
             o = attn @ v
+            if self.precision == "fp16x2":                                  # the output projection (+ residual + norm1) on K8 / K5
+                o = o.transpose(1, 2).reshape(T, L, C)
+                if residual_norm:
+                    return fast_linear_ln(self, "out_proj", o, mha.out_proj.weight, mha.out_proj.bias, self.norm1, pre=slots)
+                return fast_linear(self, "out_proj", o, mha.out_proj.weight, mha.out_proj.bias)
         elif C // nh == 32 and L <= 256:
             # the library's own kernel for these tiny (L x L x 32 per head) problems, on the packed projection as it stands
             o = ops.slot_self_attn(qkv.view(T, L, 3 * C), nh)
@@ -554,7 +596,7 @@ class MaskRCNNHead(nn.Module):
             return self.class_logits(c), r
         n_cls, n_reg = len(self.cls_module) // 3, len(self.reg_module) // 3
         lins = [self.cls_module[3 * k] for k in range(n_cls)] + [self.reg_module[3 * k] for k in range(n_reg)]
-        if (self.precision != "fp32" and self.use_slot_gemm and obj.is_cuda and getattr(self, "fuse_ln", True)
+        if (self.precision == "bf16" and self.use_slot_gemm and obj.is_cuda and getattr(self, "fuse_ln", True)
                 and n_cls >= 1 and n_reg >= 1 and n_cls + n_reg <= 6 and -(-T * L // 64) * 2 >= _num_cus(obj.device)
                 and all(isinstance(m, nn.Linear) and m.bias is None and tuple(m.weight.shape) == (256, 256) for m in lins)):
             # both towers in ONE launch (csrc/slot_chain.hip): each tower's layers chained on the CU, both off the same input tile;
@@ -593,7 +635,8 @@ class MaskRCNNHead(nn.Module):
         if self.precision != "fp32" and self.use_slot_gemm and x[0].is_cuda:         # :398 on K9 (20 columns: not a K8 shape)
             nc_ = self.class_logits.weight.shape[0]
             cls = ops.bgemm(x[0], self.class_logits.weight, bias=self.class_logits.bias,
-                            out=None if out_cls is None else out_cls.view(1, T * L, nc_)).view(T, L, -1)
+                            out=None if out_cls is None else out_cls.view(1, T * L, nc_),
+                            split="fp16" if self.precision == "fp16x2" else "bf16").view(T, L, -1)
         else:
             cls = self.class_logits(x[0].reshape(T, L, C))
         return cls, x[1].reshape(T, L, C)
@@ -615,8 +658,10 @@ class MaskRCNNHead(nn.Module):
         assert pad_mask is None and query_pos is None and gt_non_void_mask is None
         T = len(features)
         _, c, h, w = features[0].shape
-        store = torch.float32 if self.precision == "fp32" else (torch.float16 if getattr(self, "map_dtype", "bf16") == "fp16" else BF16)
+        store = torch.float32 if self.precision in ("fp32", "fp16x2") else (torch.float16 if getattr(self, "map_dtype", "bf16") == "fp16" else BF16)
         feat_pm = torch.cat(features, 0).permute(0, 2, 3, 1).reshape(T, h * w, c).to(store).contiguous()
+        if self.precision == "fp16x2":
+            feat_pm = ops.split_hl(feat_pm)
         tabs = pos_tables_from_map(pos[0]) if pos is not None else None
         logits, emb = self.forward_pm(torch.cat(mask_query, 0).float(), feat_pm, (h, w), tabs, stage_enable)
         return [logits[t:t + 1] for t in range(T)], [emb[t:t + 1] for t in range(T)], None, None
@@ -677,9 +722,13 @@ class MultiScaleDynamicMaskHead(nn.Module):
 
     def set_precision(self, mode):
         """"bf16" (default): bf16 storage of the pixel-side tensors, matrix-core kernels. "fp32": exact mode - fp32 storage and
-        arithmetic everywhere (csrc/exact_f32.hip), the reference's own dtype (vps_temporal_slots.py:55)."""
-        if mode not in ("bf16", "fp32"):
-            raise ValueError(f"precision must be 'bf16' or 'fp32', not {mode!r}")
+        arithmetic everywhere (csrc/exact_f32.hip), the reference's own dtype (vps_temporal_slots.py:55), on the vector ALU.
+        "fp16x2": the reference's precision ON THE MATRIX CORES - every 16-bit matrix operand as fp16 hi + lo (22 bits, three MFMAs per
+        product): level maps as two fp16 planes (csrc/level_fuse_hl.hip), statistics / retriever / decode in their HL forms, the slot
+        side on K8 / K9 with fp16 hi + lo operands. Meets the exact mode's bounds against the reference's fp32 outputs at ~10x its speed
+        (tests/test_refprec_gpu.py); L <= 128, |f| < 65 504."""
+        if mode not in ("bf16", "fp32", "fp16x2"):
+            raise ValueError(f"precision must be 'bf16', 'fp32' or 'fp16x2', not {mode!r}")
         for m in self.modules():
             if hasattr(m, "precision"):
                 m.precision = mode
@@ -771,6 +820,12 @@ class MultiScaleDynamicMaskHead(nn.Module):
             conv = self.conv_trans.conv
             wT = _cached(self, "cwT", [conv.weight], lambda: conv.weight.reshape(self.dh_dim, self.trans_in_dim).t().contiguous())
             return ops.level_fuse_f32(cur.float().contiguous(), prev_pm, wT, conv.bias, hw[0], hw[1])
+        if self.precision == "fp16x2":
+            conv = self.conv_trans.conv
+            if cur.dim() != 4:
+                raise NotImplementedError("precision 'fp16x2' takes the incoming maps as [T, 128, H, W] fp32 (NCHW)")
+            w_hl = _cached(self, "cw_hl", [conv.weight], lambda: ops.split_hl(conv.weight.detach().reshape(self.dh_dim, -1).float().contiguous()))
+            return ops.level_fuse_hl(cur.float().contiguous(), prev_pm, w_hl, conv.bias, hw[0], hw[1])
         form = self._map_form(cur)
         if prev_pm is not None and form != "fp16":                       # a level follows the encoding of the level below it
             form = "bf16_in_fp16" if prev_pm.dtype == torch.float16 else "bf16"
@@ -789,7 +844,8 @@ class MultiScaleDynamicMaskHead(nn.Module):
         layout) or [T, Hi*Wi, 128] bf16 pixel-major (then hws = [(Hi, Wi)] is required); init_slots [L, 256];
         pos_tabs: per level the separable sine tables (ytab [Hi, 128], xtab [Wi, 128]) of
         ops.pos_embed_sine_tables, or None for no position embedding.
-        Returns logits [S, T, L, nc], embeds [S, T, L, 256], fused list of [T, Hi*Wi, 256] bf16."""
+        Returns logits [S, T, L, nc], embeds [S, T, L, 256], fused list of [T, Hi*Wi, 256] bf16 (fp32 in exact mode; precision "fp16x2":
+        [2, T, Hi*Wi, 256] fp16, the hi and lo planes)."""
         if not feats[0].is_cuda:
             raise RuntimeError("MultiScaleDynamicMaskHead runs on the GPU only; there is no CPU fallback")
         T = feats[0].shape[0]
@@ -818,8 +874,8 @@ class MultiScaleDynamicMaskHead(nn.Module):
             f_pm = self.fuse_level(feats[i], prev, (h, w))
             series = getattr(self, f"head_series_{i}")
             mdcs = [stage.inst_interact for stage in series]
-            if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16)
-                    and all(m.precision != "fp32" and m.retriever == "fused" and not m.tight_stats for m in mdcs)):
+            if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16) and f_pm.dim() == 3
+                    and all(m.precision == "bf16" and m.retriever == "fused" and not m.tight_stats for m in mdcs)):
                 # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats2.hip;
                 # measured 195 against 2 x 116 us at the finest level); each stage's retriever picks its rows up in forward_fused.
                 # A level with a single stage keeps K3'
@@ -879,6 +935,9 @@ def generate_final_outputs(feat_pm, slot_embed, feat_bn, fg_bn, want_argmax=Fals
     [T, L, 256] last-stage embeddings -> mask logits [T, L, HW] fp32 (+ uint8 slot argmax [T, HW])."""
     scale, shift = fold_bn_eval(feat_bn)
     fs, fb = fold_bn_eval(fg_bn)
+    if feat_pm.dim() == 4:                                   # precision "fp16x2": fp16 hi + lo planes
+        return ops.mask_decode_hl(feat_pm, slot_embed.float().contiguous(), scale, shift, float(fs.item()), float(fb.item()),
+                                  want_argmax=want_argmax)
     if feat_pm.dtype == torch.float32:                       # exact mode
         masks = ops.mask_decode_f32(feat_pm, slot_embed.float().contiguous(), scale, shift, float(fs.item()), float(fb.item()))
         return (masks, masks.argmax(dim=1).to(torch.uint8)) if want_argmax else masks
