@@ -309,6 +309,8 @@ def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, prec
         r1.head.set_map_dtype("fp16")
     elif precision == "fp16_maps_balanced":
         r1.head.set_map_dtype("fp16").set_statistics("balanced")
+    elif precision == "fp16x2":
+        r1.head.set_precision("fp16x2")
     r1.load_clip(r1.random_clip(7))
     for _ in range(2):
         r1.run()
@@ -318,8 +320,50 @@ def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, prec
         r1.run()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(frames * cpl / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
-            "clips_per_launch": cpl}
+    res = {"value": round(frames * cpl / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "clips_per_launch": cpl}
+    if precision == "fp16x2":
+        # its own roofline object: the same steps eagerly, HIP events around every launch of the library (as in the main leg)
+        from slotvps_amd import _lib, ops
+        r1.use_graph = False
+        r1.run()
+        torch.cuda.synchronize(dev)
+        kids = {"level_fuse": _lib.KERNEL_LEVEL_FUSE, "retr_stats": _lib.KERNEL_RETR_STATS, "retr_attn": _lib.KERNEL_RETR_ATTN,
+                "retr_finish": _lib.KERNEL_RETR_FINISH, "mask_decode": _lib.KERNEL_MASK_DECODE}
+        with ops.KernelTimer() as kt:
+            for _ in range(steps):
+                r1.run()
+            torch.cuda.synchronize(dev)
+            timed = {name: kt.collect(kid) for name, kid in kids.items()}
+        alg = r1.algorithmic_per_step()
+        per = {}
+        for name, (ms, n) in timed.items():
+            if n == 0:
+                continue
+            e = {"launches": n, "avg_launch_us": round(ms / n * 1e3, 2), "ms_per_step": round(ms / steps, 3)}
+            if name in alg:
+                sec = ms * 1e-3
+                e["algorithmic_bytes_per_launch"] = int(alg[name]["bytes"] * steps / n)
+                e["hbm_gbs"] = round(alg[name]["bytes"] * steps / sec / 1e9, 1)
+                e["hbm_frac"] = round(e["hbm_gbs"] / HBM_PEAK_GBS, 4)
+                e["mfma_tflops"] = round(alg[name]["flops"] * steps / sec / 1e12, 1)
+                e["mfma_frac"] = round(e["mfma_tflops"] / MFMA_PEAK_TFLOPS, 4)
+                if "executed_flops" in alg[name]:
+                    e["mfma_frac_executed"] = round(alg[name]["executed_flops"] * steps / sec / 1e12 / MFMA_PEAK_TFLOPS, 4)
+                e["bound"] = "hbm" if e["hbm_frac"] >= e["mfma_frac"] else "mfma"
+            per[name] = e
+        dom = max((k for k in per if k in alg), key=lambda k: timed[k][0])
+        d = per[dom]
+        hbm = d["bound"] == "hbm"
+        res["roofline"] = {"bound": d["bound"], "achieved": d["hbm_gbs"] if hbm else d["mfma_tflops"],
+                           "peak": HBM_PEAK_GBS if hbm else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm else "TFLOP/s",
+                           "frac": d["hbm_frac"] if hbm else d["mfma_frac"], "traffic": None, "kernel": dom,
+                           "what": "dominant kernel of the fp16x2 step by device time (HIP events on the launch stream, eager pass); algorithmic "
+                                   "bytes: the maps at 1 KiB per pixel (hi + lo planes); algorithmic flops: ONE product per multiply (the three-MFMA "
+                                   "operand splits are executed work: mfma_frac_executed)",
+                           "avg_launch_us": d["avg_launch_us"], "per_kernel": per,
+                           "slot_side_and_rest_ms_per_step": round(dt * 1e3 - sum(v["ms_per_step"] for v in per.values()), 3)}
+    return res
 
 
 def launch_ranks(a, argv):
@@ -670,6 +714,17 @@ def main():
                 line[key] = fl
             except Exception as e:
                 line[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+        if world == 1 and a.exact_leg and a.slots <= 128:
+            note("reference-precision leg (precision fp16x2: every matrix operand as fp16 hi + lo) ...")
+            try:
+                rp = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, precision="fp16x2")
+                rp["what"] = ("head.set_precision('fp16x2'): the reference's precision ON THE MATRIX CORES - level maps as fp16 hi + lo planes, three "
+                              "MFMAs per product in level fusion / statistics / retriever / decode, fp16-split slot side. Free-running against the "
+                              "reference's own fp32 outputs: mask logits 8.2e-5 / 9.2e-6 (bound 1e-4), slot argmax and panoptic ids identical on 100 % "
+                              "of the pixels (tests/test_refprec_gpu.py: the bounds of the exact mode's test); same step, fp32 logits written, hipGraph")
+                line["reference_precision"] = rp
+            except Exception as e:
+                line["reference_precision"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
         if world == 1 and a.exact_leg and a.slots <= 128:
             note("precision-form leg (bf16 storage, fp16 hi + lo statistics factors and probabilities) ...")
             try:

@@ -407,19 +407,25 @@ int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, co
  * are TWO fp16 planes [T, H*W, 256] (hi, lo): 1 KiB per pixel, the size of an fp32 map, in the operand form of the consumers.
  * Against the reference's own fp32 outputs the free-running head then sits at the reference's own reproducibility (mask logits
  * <= 1e-4, slot argmax identical wherever decidable: tests/test_refprec_gpu.py) - the bounds only the vector-ALU exact mode below met.
- *   svps_level_fuse_hl_fwd   = svps_level_fuse_fwd (dynamic_mask_head.py:171-188): cur [T, 128, H, W] fp32 NCHW; prev_hi / prev_lo the
- *                              coarser level's planes (both NULL: level 0); wc_hi / wc_lo [256, 384] fp16; out_hi / out_lo the planes
- *   svps_retr_stats_hl_fwd   = svps_retr_stats_tight_fwd (:432-433, the two LayerNorm statistics) on the planes; same aux rows
+ *   svps_level_fuse_hl_fwd   = svps_level_fuse_fwd (dynamic_mask_head.py:171-188) in the form f_i = up(f_{i-1} W_a^T) + W_b x_i + b (a 1x1
+ *                              conv commutes with bilinear interpolation; W = [W_a | W_b]): cur [T, 128, H, W] fp32 NCHW; gprev
+ *                              [T, (H/2)(W/2), 256] fp32 = f_{i-1} W_a^T (svps_slot_gemm_f16 on the coarser level's fp32 copy) or NULL
+ *                              (level 0: wb = W_1 + W_2 + W_3); wb_hi / wb_lo [256, 128] fp16; out_hi / out_lo the planes; out_f32 the
+ *                              same values as fp32 [T, H*W, 256] (the operand of the next level's coarse product) or NULL
+ *   svps_retr_stats_hl_fwd   = svps_retr_stats_tight_fwd (:432-433, the two LayerNorm statistics) on the planes, both projections from
+ *                              ONE read (slotvps_amd/csrc/retr_stats_hl.hip); same aux rows. The fp32 tables come in ACCUMULATOR order
+ *                              (column 32 B + 16 h + 4 g + j = factor row 32 B + 8 g + 4 h + j): tyk [ty_rows, 256] = Ty + r_k, txk
+ *                              [tx_rows, 256] = Tx (ty_rows = H or 1, tx_rows = W or 1: no position term), rbv [256] = r_v
  *   svps_retr_attn_hl_fwd    = svps_retr_attn_tight_fwd (:435-456) on the planes, L <= 128; tiles of 16 pixels (hi rows + lo rows of
  *                              the same pixels share one LDS tile); workspace svps_retr_attn_hl_workspace_bytes()
  *   svps_mask_decode_hl_fwd  = svps_mask_decode_fwd (vps_temporal_slots.py:144-160) on the planes: fp32 logits [T, L, HW] (required),
  *                              optional fused slot argmax [T, HW]; any HW, L <= 256
  * Same rules as everywhere: no allocation, no synchronisation, launched on `stream`, 0 or an error code.
  * ------------------------------------------------------------------------------------------- */
-int svps_level_fuse_hl_fwd(const float* cur, const void* prev_hi, const void* prev_lo, const void* wc_hi, const void* wc_lo,
-                           const float* bc, void* out_hi, void* out_lo, int T, int H, int W, void* stream);
-int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* ty, const float* tx, const void* rk_hi,
-                           const void* rk_lo, const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo,
+int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
+                           void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream);
+int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* tyk, int ty_rows, const float* txk, int tx_rows,
+                           const void* rk_hi, const void* rk_lo, float lnk_eps, const void* rv_hi, const void* rv_lo,
                            const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D, void* stream);
 size_t svps_retr_attn_hl_workspace_bytes(int T, int L, int H, int W, int chunks);
 int svps_retr_attn_hl_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,

@@ -8,37 +8,45 @@
 // but nothing is rounded to 16 bits as a VALUE. The reference runs this path in fp32 (vps_temporal_slots.py:55); the fp32 matrix
 // instructions of gfx950 run at the vector rate, so every 16-bit matrix operand is carried as FP16 hi + lo instead (hi = fp16(x),
 // lo = fp16(x - hi): 22 bits of mantissa, |x| < 65 504) and a product takes three MFMAs into one fp32 accumulator
-// (hi hi + lo hi + hi lo; the lo lo term is below fp32 resolution):
-//     * the level maps are stored as TWO fp16 planes [T, HW, 256] (hi, lo) - 1 KiB per pixel, the bytes of an fp32 map, in the form
-//       the consumers' matrix instructions take directly (retr_stats_t.hip, retr_attn.hip and mask_decode.hip have matching forms)
-//     * the incoming fp32 NCHW map, the fp32 bilinear blend of the previous level's (hi + lo) taps and the conv weight are split the same way
-//     * accumulation, bias and the blend itself (torch's upsample_bilinear2d expression) are fp32.
-// Against a float64 evaluation of the reference's formulas: <= 2e-6 of the map's scale (tests/test_refprec_gpu.py); the exact mode's
-// fp32 vector-ALU kernel (exact_f32.hip) measures the same.
+// (hi hi + lo hi + hi lo; the lo lo term is below fp32 resolution). The level maps are stored as TWO fp16 planes [T, HW, 256] (hi, lo):
+// 1 KiB per pixel, the bytes of an fp32 map, in the form the consumers' matrix instructions take directly (retr_stats_hl.hip,
+// retr_attn.hip and mask_decode.hip have matching forms).
 //
-// Mapping: 8 waves, wave w owns output channels [32w, 32w+32): its 32 x 384 weight block as hi AND lo A fragments stays in 192
-// registers. A plain kernel: per 32-pixel tile the workgroup builds the [32 px][384 ch] operand tile (hi and lo) in LDS, runs 72 MFMAs
-// per wave, splits the result and sends both out tiles through LDS so that HBM sees whole 512-byte pixel rows. No register prefetch
-// across the matrix phase (the weights leave no room for it): bound by its serial phases, ~3x the time of the 16-bit kernel for 3x
-// its matrix work and twice its output bytes.
+// A 1x1 convolution commutes with bilinear interpolation (both are linear, the taps' weights do not depend on the channel), so with
+// W = [W_a | W_b] (256 upsampled + 128 incoming channels)
+//     f_i = up( W_a f_{i-1} ) + W_b x_i + b
+// and the 256-wide part of the product runs at the COARSE resolution (a quarter of the pixels): g_{i-1} = f_{i-1} W_a^T is one launch of
+// K8 (slot_gemm.hip, fp16 hi + lo operands) on the fp32 copy this kernel writes for the levels that feed another one; what is left at
+// the fine resolution is K = 128: 24 MFMAs per wave and 32-pixel tile instead of 72, 64 weight registers instead of 192 (the first form
+// of this kernel - all of K = 384 at the fine resolution, operand tile built from eight scattered tap loads per thread with nothing
+// in flight - took 40 ms of a 160-frame step). Level 0: cat(x, x, x) W^T = x (W_1 + W_2 + W_3)^T, the sum formed in float64 on the host.
+// The result differs from the reference's order of operations by fp32 rounding only (tests/test_refprec_gpu.py: <= 1e-6 of the map's
+// scale against float64).
+//
+// Mapping: 8 waves, wave w owns output channels [32w, 32w+32) (its 32 x 128 block of W_b as hi and lo A fragments: 64 registers).
+// Per 32-pixel tile: all threads build the [32 px][128 ch] operand tile (hi, lo) in LDS from the fp32 NCHW map (loaded one tile ahead);
+// every lane requests the 4 taps x 16 channels of g it needs for ITS accumulator entries (pixel = lane & 31) before the MFMAs and
+// blends them in fp32 behind them (torch's upsample_bilinear2d expression); bias, split, out tiles through LDS so that HBM sees whole
+// 512-byte pixel rows of both planes (and of the fp32 copy).
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
 namespace svps {
 
-constexpr int kHlIn = 384;
-constexpr int kHlRowBytes = kHlIn * 2;            // 768 B per pixel row of an operand tile
+constexpr int kHlK = 128;                        // incoming channels: the contraction at the fine resolution
+constexpr int kHlRowBytes = kHlK * 2;            // 256 B per pixel row of an operand tile (16 chunks of 16 B)
 
 struct FuseHlLds {
-    static constexpr int a_hi = 0;                                  // [32][384] fp16, 16-B chunks swizzled
+    static constexpr int a_hi = 0;                                  // [32][128] fp16, 16-B chunks swizzled
     static constexpr int a_lo = kTilePx * kHlRowBytes;
     static constexpr int o_hi = 2 * kTilePx * kHlRowBytes;          // [32][256] fp16 out tiles
     static constexpr int o_lo = o_hi + kTileBytes;
-    static constexpr int total = o_lo + kTileBytes;
+    static constexpr int o_f32 = o_lo + kTileBytes;                 // [32][256] fp32 copy (rows of 1 KiB, 16-B chunks swizzled)
+    static constexpr int total = o_f32 + 2 * kTileBytes;
 };
 
-__device__ __forceinline__ int hl_a_off(int row, int chunk) {       // level_fuse.hip's operand-tile swizzle
-    return row * kHlRowBytes + (((chunk & ~15) | ((chunk ^ swz(row)) & 15)) * 16);
+__device__ __forceinline__ int hl_a_off(int row, int chunk) {       // chunk 0 .. 15
+    return row * kHlRowBytes + ((chunk ^ swz(row)) * 16);
 }
 
 // x -> (hi, lo) fp16 with hi + lo = x to 22 bits; hi saturates at +-65 504 (an overflow to inf would turn into NaN downstream)
@@ -49,16 +57,16 @@ __device__ __forceinline__ void hl_split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
-template <bool LEVEL0>
+template <bool TAPS, bool F32OUT>
 __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     const float* __restrict__ cur,            // [T, 128, H, W] fp32 (NCHW, the reference's layout)
-    const _Float16* __restrict__ prev_hi,     // [T, (H/2)*(W/2), 256] pixel-major (unused for LEVEL0)
-    const _Float16* __restrict__ prev_lo,
-    const _Float16* __restrict__ wc_hi,       // [256, 384] conv weight (row = output channel), hi and lo parts
-    const _Float16* __restrict__ wc_lo,
+    const float* __restrict__ gprev,          // TAPS: [T, (H/2)*(W/2), 256] fp32 = f_{i-1} W_a^T, pixel-major
+    const _Float16* __restrict__ wb_hi,       // [256, 128] weight of the incoming channels (level 0: W_1 + W_2 + W_3), hi and lo parts
+    const _Float16* __restrict__ wb_lo,
     const float* __restrict__ bc,             // [256]
     _Float16* __restrict__ out_hi,            // [T, H*W, 256]
     _Float16* __restrict__ out_lo,
+    float* __restrict__ out_f32,              // F32OUT: [T, H*W, 256] the same values as fp32 (operand of the next level's coarse product)
     int H, int W, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Lds = FuseHlLds;
@@ -75,98 +83,52 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     px_end = px_end < HW ? px_end : HW;
     const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
 
-    // ---- weight block of this wave: rows 32w .. 32w+31, 24 k-steps, hi and lo ---------------------------------
-    f16x8 wfh[24], wfl[24];
+    // ---- weight block of this wave: rows 32w .. 32w+31, 8 k-steps, hi and lo
+    f16x8 wfh[8], wfl[8];
     {
-        const size_t row = (size_t)(32 * w + r) * kHlIn + 8 * h;
+        const size_t row = (size_t)(32 * w + r) * kHlK + 8 * h;
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks) {
-            wfh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wc_hi + row + 16 * ks));
-            wfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wc_lo + row + 16 * ks));
+        for (int ks = 0; ks < 8; ++ks) {
+            wfh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wb_hi + row + 16 * ks));
+            wfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wb_lo + row + 16 * ks));
         }
     }
+    f32x4 bias[4];                            // register 4 g + j <-> channel 32 w + 8 g + 4 h + j
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(bc + 32 * w + 8 * g + 4 * h);
 
     char* ah = smem + Lds::a_hi;
     char* al = smem + Lds::a_lo;
-    // ---- operand tile of one 32-pixel tile (hi and lo), all 512 threads --------------------------------------
-    auto build = [&](int tile) {
-        const int px0 = px_begin + tile * kTilePx;
-        {   // (a) incoming 128-channel map -> chunks 32..47 (channels 256..383); LEVEL0 also -> 0..15, 16..31
-            //     thread = (channel, 8-pixel group): 2 x 16-B loads, 8 two-byte LDS stores per plane
-            const int ch = tid >> 2, pg = tid & 3;
-            const int pp = px0 + 8 * pg;
-            const float* src = cur + ((size_t)t * 128 + ch) * HW;
-            float v[8];
-            if (pp + 8 <= HW && (HW & 3) == 0) {
-                const f32x4 c0 = *reinterpret_cast<const f32x4*>(src + pp);
-                const f32x4 c1 = *reinterpret_cast<const f32x4*>(src + pp + 4);
+    // incoming map of one tile: thread = (channel, 8-pixel group): 2 x 16-B loads (one tile ahead), 8 two-byte LDS stores per plane
+    const int ch = tid >> 2, pg = tid & 3;
+    const float* src = cur + ((size_t)t * 128 + ch) * HW;
+    const bool aligned = (HW & 3) == 0;
+    f32x4 c0, c1;
+    auto fetch = [&](int tile) {
+        const int pp = px_begin + tile * kTilePx + 8 * pg;
+        if (pp + 8 <= HW && aligned) {
+            c0 = *reinterpret_cast<const f32x4*>(src + pp);
+            c1 = *reinterpret_cast<const f32x4*>(src + pp + 4);
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] = c0[j]; v[4 + j] = c1[j]; }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[pp + j < HW ? pp + j : HW - 1];
-            }
-            const int chunk = 32 + (ch >> 3);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = 8 * pg + j;
-                _Float16 vh, vl;
-                hl_split(v[j], vh, vl);
-                const int o = hl_a_off(row, chunk) + (ch & 7) * 2;
-                *reinterpret_cast<_Float16*>(ah + o) = vh;
-                *reinterpret_cast<_Float16*>(al + o) = vl;
-                if constexpr (LEVEL0) {
-                    const int o1 = hl_a_off(row, chunk - 32) + (ch & 7) * 2, o2 = hl_a_off(row, chunk - 16) + (ch & 7) * 2;
-                    *reinterpret_cast<_Float16*>(ah + o1) = vh;
-                    *reinterpret_cast<_Float16*>(al + o1) = vl;
-                    *reinterpret_cast<_Float16*>(ah + o2) = vh;
-                    *reinterpret_cast<_Float16*>(al + o2) = vl;
-                }
-            }
-        }
-        if constexpr (!LEVEL0) {
-            // (b) upsampled previous level -> chunks 0..31: thread = (pixel, chunks ck and ck + 16), four taps each, one chunk at a time.
-            //     F.interpolate(scale 2, bilinear, align_corners=False): source coordinate (d + 0.5) / 2 - 0.5 clamped at 0; torch's
-            //     upsample_bilinear2d expression (1-ly) ((1-lx) a + lx b) + ly ((1-lx) c + lx d) in fp32 on the exact tap values hi + lo
-            const int px = tid >> 4, ck = tid & 15;
-            int pp = px0 + px;
-            pp = pp < HW ? pp : HW - 1;
-            const int y = pp / W, x = pp - y * W;
-            const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
-            const int y0 = (int)sy, x0 = (int)sx;
-            const int y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1, x1 = x0 + 1 < Wp ? x0 + 1 : Wp - 1;
-            const float h1 = sy - (float)y0, w1 = sx - (float)x0;
-            const float h0 = 1.f - h1, w0 = 1.f - w1;
-            const size_t fb = (size_t)t * Hp * Wp * kD;
-            const size_t o00 = fb + ((size_t)y0 * Wp + x0) * kD, o01 = fb + ((size_t)y0 * Wp + x1) * kD;
-            const size_t o10 = fb + ((size_t)y1 * Wp + x0) * kD, o11 = fb + ((size_t)y1 * Wp + x1) * kD;
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {                              // (chunk u = q >> 1, half of its 8 channels): 4 channels per step -
-                const int u = q >> 1, hf = q & 1;                      // the 192 weight registers leave room for little else
-                const int co = 8 * (ck + 16 * u) + 4 * hf;
-                auto tap = [&](size_t o, f32x4& dst) {
-                    const f16x4 th = *reinterpret_cast<const f16x4*>(prev_hi + o + co);
-                    const f16x4 tl = *reinterpret_cast<const f16x4*>(prev_lo + o + co);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) dst[j] = (float)th[j] + (float)tl[j];      // exact: 22 bits
-                };
-                f32x4 a, b, cc, d;
-                tap(o00, a); tap(o01, b); tap(o10, cc); tap(o11, d);
-                f16x4 oh, ol;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = h0 * (w0 * a[j] + w1 * b[j]) + h1 * (w0 * cc[j] + w1 * d[j]);
-                    _Float16 vh, vl;
-                    hl_split(v, vh, vl);
-                    oh[j] = vh;
-                    ol[j] = vl;
-                }
-                *reinterpret_cast<f16x4*>(ah + hl_a_off(px, ck + 16 * u) + 8 * hf) = oh;
-                *reinterpret_cast<f16x4*>(al + hl_a_off(px, ck + 16 * u) + 8 * hf) = ol;
+            for (int j = 0; j < 4; ++j) {
+                c0[j] = src[pp + j < HW ? pp + j : HW - 1];
+                c1[j] = src[pp + 4 + j < HW ? pp + 4 + j : HW - 1];
             }
         }
     };
-    // out tiles -> HBM, all 512 threads: 2 x 16 KiB per tile, 2 x 2 x 16 B per thread, whole 512-byte pixel rows
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 8 * pg + j;
+            _Float16 vh, vl;
+            hl_split(j < 4 ? c0[j] : c1[j - 4], vh, vl);
+            const int o = hl_a_off(row, ch >> 3) + (ch & 7) * 2;
+            *reinterpret_cast<_Float16*>(ah + o) = vh;
+            *reinterpret_cast<_Float16*>(al + o) = vl;
+        }
+    };
+    // out tiles -> HBM, all 512 threads: whole 512-byte (fp32: 1-KiB) pixel rows
     auto store_out = [&](int tile) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -181,54 +143,101 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
                 *reinterpret_cast<u32x4*>(out_lo + o) = vl;
             }
         }
+        if constexpr (F32OUT) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int piece = u * 512 + tid;                        // [row][64 chunk positions of 16 B]
+                const int row = piece >> 6, cpos = piece & 63;
+                const int px = px_begin + tile * kTilePx + row;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + Lds::o_f32 + row * 1024 + cpos * 16);
+                if (px < px_end) *reinterpret_cast<u32x4*>(out_f32 + ((size_t)t * HW + px) * kD + ((cpos ^ (row & 15)) * 4)) = v;
+            }
+        }
     };
 
+    fetch(0);
+    commit();
     for (int it = 0; it < nt; ++it) {
-        build(it);
-        __syncthreads();                                   // operand tile `it` complete; out tiles of it-1 have been read (barrier below)
+        __syncthreads();                                   // operand tile `it` complete; out tiles of it-1 have been read
+        // ---- this lane's taps of g (its accumulator entries: pixel r, channels 32 w + 8 g + 4 h + j), requested before the MFMAs
+        f32x4 tp[4][4];                                    // [tap][g]
+        float h1 = 0.f, w1 = 0.f;
+        if constexpr (TAPS) {
+            int pp = px_begin + it * kTilePx + r;
+            pp = pp < HW ? pp : HW - 1;
+            const int y = pp / W, x = pp - y * W;
+            // F.interpolate(scale 2, bilinear, align_corners=False): source coordinate (d + 0.5) / 2 - 0.5 clamped at 0
+            const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1, x1 = x0 + 1 < Wp ? x0 + 1 : Wp - 1;
+            h1 = sy - (float)y0;
+            w1 = sx - (float)x0;
+            const float* gb = gprev + (size_t)t * Hp * Wp * kD + 32 * w + 4 * h;
+            const float* t00 = gb + ((size_t)y0 * Wp + x0) * kD;
+            const float* t01 = gb + ((size_t)y0 * Wp + x1) * kD;
+            const float* t10 = gb + ((size_t)y1 * Wp + x0) * kD;
+            const float* t11 = gb + ((size_t)y1 * Wp + x1) * kD;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                tp[0][g] = *reinterpret_cast<const f32x4*>(t00 + 8 * g);
+                tp[1][g] = *reinterpret_cast<const f32x4*>(t01 + 8 * g);
+                tp[2][g] = *reinterpret_cast<const f32x4*>(t10 + 8 * g);
+                tp[3][g] = *reinterpret_cast<const f32x4*>(t11 + 8 * g);
+            }
+        }
+        if (it + 1 < nt) fetch(it + 1);                    // the incoming map of the next tile flies under the MFMAs
         f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int ks = 0; ks < 24; ++ks) {
+            for (int j = 0; j < 4; ++j) acc[4 * g + j] = bias[g][j];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
             const f16x8 xh = *reinterpret_cast<const f16x8*>(ah + hl_a_off(r, 2 * ks + h));
             const f16x8 xl = *reinterpret_cast<const f16x8*>(al + hl_a_off(r, 2 * ks + h));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfl[ks], xh, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh[ks], xl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh[ks], xh, acc, 0, 0, 0);
         }
-        // split the result (+ bias) and write this wave's 32 channels of both out tiles: register 4 g + j <-> channel 32 w + 8 g + 4 h + j
+        // ---- + up(g): torch's upsample_bilinear2d expression (1-ly) ((1-lx) a + lx b) + ly ((1-lx) c + lx d) in fp32; split; out tiles
+        const float h0 = 1.f - h1, w0 = 1.f - w1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ch0 = 32 * w + 8 * g + 4 * h;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bc + ch0);
             f16x4 oh, ol;
+            f32x4 of;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                float v = acc[4 * g + j];
+                if constexpr (TAPS) v += h0 * (w0 * tp[0][g][j] + w1 * tp[1][g][j]) + h1 * (w0 * tp[2][g][j] + w1 * tp[3][g][j]);
                 _Float16 vh, vl;
-                hl_split(acc[4 * g + j] + b4[j], vh, vl);
+                hl_split(v, vh, vl);
                 oh[j] = vh;
                 ol[j] = vl;
+                of[j] = (float)vh + (float)vl;             // the fp32 copy holds exactly the planes' value
             }
             const int o = r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2;
             *reinterpret_cast<f16x4*>(smem + Lds::o_hi + o) = oh;
             *reinterpret_cast<f16x4*>(smem + Lds::o_lo + o) = ol;
+            if constexpr (F32OUT) *reinterpret_cast<f32x4*>(smem + Lds::o_f32 + r * 1024 + (((ch0 >> 2) ^ (r & 15)) * 16)) = of;
         }
         __syncthreads();                                   // out tiles complete; every wave is done reading operand tile `it`
+        if (it + 1 < nt) commit();                         // operand tile it+1 (its loads were issued before the MFMAs)
         store_out(it);
     }
 }
 
 }  // namespace svps
 
-// svps_level_fuse_hl_fwd (include/slotvps_hip.h): cur [T, 128, H, W] fp32 NCHW; prev_hi / prev_lo [T, (H/2)(W/2), 256] fp16 or both NULL
-// (level 0); wc_hi / wc_lo [256, 384] fp16; bc [256] fp32; out_hi / out_lo [T, H*W, 256] fp16.
-extern "C" int svps_level_fuse_hl_fwd(const float* cur, const void* prev_hi, const void* prev_lo, const void* wc_hi, const void* wc_lo,
-                                      const float* bc, void* out_hi, void* out_lo, int T, int H, int W, void* stream_) {
-    if (!cur || !wc_hi || !wc_lo || !bc || !out_hi || !out_lo || ((prev_hi == nullptr) != (prev_lo == nullptr))) return SVPS_ERR_BAD_ARG;
+// svps_level_fuse_hl_fwd (include/slotvps_hip.h): cur [T, 128, H, W] fp32 NCHW; gprev [T, (H/2)(W/2), 256] fp32 = f_{i-1} W_a^T or NULL
+// (level 0: wb = W_1 + W_2 + W_3); wb_hi / wb_lo [256, 128] fp16; bc [256] fp32; out_hi / out_lo [T, H*W, 256] fp16; out_f32 the same
+// values as fp32 [T, H*W, 256] or NULL.
+extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
+                                      void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream_) {
+    if (!cur || !wb_hi || !wb_lo || !bc || !out_hi || !out_lo) return SVPS_ERR_BAD_ARG;
     if (T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
-    if (prev_hi && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;   // x2 upsampling: even sizes
+    if (gprev && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;     // x2 upsampling: even sizes
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using H16 = _Float16;
     const int HW = H * W;
@@ -238,20 +247,18 @@ extern "C" int svps_level_fuse_hl_fwd(const float* cur, const void* prev_hi, con
     chunks = (tiles + tpc - 1) / tpc;
     constexpr int lds = svps::FuseHlLds::total;
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 0, stream);
-    hipError_t e;
-    if (prev_hi) {
-        auto kern = svps::level_fuse_hl_kernel<false>;
-        static SvpsLdsAttr attr;
-        if ((e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, cur, static_cast<const H16*>(prev_hi), static_cast<const H16*>(prev_lo),
-                           static_cast<const H16*>(wc_hi), static_cast<const H16*>(wc_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), H, W, tpc);
-    } else {
-        auto kern = svps::level_fuse_hl_kernel<true>;
-        static SvpsLdsAttr attr;
-        if ((e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, cur, (const H16*)nullptr, (const H16*)nullptr,
-                           static_cast<const H16*>(wc_hi), static_cast<const H16*>(wc_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), H, W, tpc);
-    }
+    hipError_t e = hipSuccess;
+#define SVPS_LFH(TAPS, F32)                                                                                                        \
+    do {                                                                                                                           \
+        auto kern = svps::level_fuse_hl_kernel<TAPS, F32>;                                                                         \
+        static SvpsLdsAttr attr;                                                                                                   \
+        if ((e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;                              \
+        hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, cur, gprev, static_cast<const H16*>(wb_hi),              \
+                           static_cast<const H16*>(wb_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), out_f32, H, W, tpc); \
+    } while (0)
+    if (gprev) { if (out_f32) SVPS_LFH(true, true); else SVPS_LFH(true, false); }
+    else { if (out_f32) SVPS_LFH(false, true); else SVPS_LFH(false, false); }
+#undef SVPS_LFH
     e = hipGetLastError();
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 1, stream);
     return (int)e;

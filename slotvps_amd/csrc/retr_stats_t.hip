@@ -12,10 +12,6 @@
 // once per projection (key, value: the map is read twice), one row block of the hi and lo factor resident per wave (128 registers).
 // Output: the 16-byte aux rows of K3' (same layout, consumed by retr_attn.hip unchanged); the key launch writes bytes 8 .. 11, the
 // value launch the rest.
-//
-// HL (round 4, the reference-precision mode on the matrix cores: svps_retr_stats_hl_fwd): the level map itself arrives as fp16 hi + lo
-// planes (f = hi + lo to 22 bits, written by svps_level_fuse_hl_fwd). Both planes of a tile are staged; R x = R_hi x_hi + R_lo x_hi +
-// R_hi x_lo in ONE fp32 accumulator (the lo x lo product is below fp32 resolution): three MFMAs per k-step instead of two.
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -25,18 +21,15 @@ typedef __attribute__((ext_vector_type(8))) _Float16 st_f16x8;
 typedef __attribute__((ext_vector_type(2))) uint32_t st_u32x2;
 
 constexpr int kTtRow = 256 * 2 + 16;                 // staged pixel row: 256 fp16 + pad (conflict-free 16-byte fragment reads)
-template <bool HL>
-struct StatsTLdsT {
-    static constexpr int xt = 0;                     // [2][32 px][528 B] (HL: [2][hi, lo][32 px][528 B])
-    static constexpr int x_bytes = kTilePx * kTtRow * (HL ? 2 : 1);
+struct StatsTLds {
+    static constexpr int xt = 0;                     // [2][32 px][528 B]
+    static constexpr int x_bytes = kTilePx * kTtRow;
     static constexpr int part = 2 * x_bytes;         // [2][8 waves][32 px] float: sum of squares of the wave's 32 rows
     static constexpr int total = part + 2 * 8 * 32 * 4;
 };
-using StatsTLds = StatsTLdsT<false>;
 
 struct StatsTArgs {
     const __bf16* feat;        // [T, HW, 256]
-    const __bf16* feat_lo;     // HL: [T, HW, 256] fp16, the lo plane (feat is then the fp16 hi plane)
     const float* ty;           // [H, 256] or null:  R[:, :128] pos_y[y]   (key launch only)
     const float* tx;           // [W, 256] or null:  R[:, 128:] pos_x[x]
     const _Float16* r_hi;      // [256, 256] upper triangular
@@ -50,9 +43,8 @@ struct StatsTArgs {
 };
 
 // one wave = row block RB (rows 32 RB .. 32 RB + 31) of the three factors; R is upper triangular: k-steps 2 RB .. 15 only
-template <int RB, bool HL>
+template <int RB>
 __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem, int w, int lane) {
-    using StatsTLds = StatsTLdsT<HL>;
     constexpr int KS0 = 2 * RB, NKS = 16 - KS0;
     const int r = lane & 31, h = lane >> 5;
     const int t = blockIdx.y;
@@ -72,33 +64,24 @@ __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem
     int tile1 = tile0 + a.tiles_per_wg;
     tile1 = tile1 < tiles ? tile1 : tiles;
     const __bf16* F = a.feat + (size_t)t * a.HW * 256;
-    const __bf16* FL = HL ? a.feat_lo + (size_t)t * a.HW * 256 : nullptr;
     float* part = reinterpret_cast<float*>(smem + StatsTLds::part);
     // staging: thread -> (pixel tid >> 4, 32 bytes = 16 channels); bf16 -> fp16 is exact for |f| in [6.1e-5, 65504]
     const int spx = tid >> 4, sc16 = tid & 15;
-    bf16x8 v0, v1, l0, l1;
+    bf16x8 v0, v1;
     auto fetch = [&](int tile) {
         int gp = tile * kTilePx + spx;
         gp = gp < a.HW ? gp : a.HW - 1;                              // ragged last tile / past the chunk: a valid pixel (not stored)
         v0 = *reinterpret_cast<const bf16x8*>(F + (size_t)gp * 256 + 16 * sc16);
         v1 = *reinterpret_cast<const bf16x8*>(F + (size_t)gp * 256 + 16 * sc16 + 8);
-        if constexpr (HL) {
-            l0 = *reinterpret_cast<const bf16x8*>(FL + (size_t)gp * 256 + 16 * sc16);
-            l1 = *reinterpret_cast<const bf16x8*>(FL + (size_t)gp * 256 + 16 * sc16 + 8);
-        }
     };
     auto stage = [&](int buf) {
         st_f16x8 o0, o1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { o0[j] = (_Float16)(float)v0[j]; o1[j] = (_Float16)(float)v1[j]; }
-        if (HL || a.map_f16) { o0 = __builtin_bit_cast(st_f16x8, v0); o1 = __builtin_bit_cast(st_f16x8, v1); }
+        if (a.map_f16) { o0 = __builtin_bit_cast(st_f16x8, v0); o1 = __builtin_bit_cast(st_f16x8, v1); }
         char* dst = smem + StatsTLds::xt + buf * StatsTLds::x_bytes + spx * kTtRow + 32 * sc16;
         *reinterpret_cast<st_f16x8*>(dst) = o0;
         *reinterpret_cast<st_f16x8*>(dst + 16) = o1;
-        if constexpr (HL) {
-            *reinterpret_cast<st_f16x8*>(dst + kTilePx * kTtRow) = __builtin_bit_cast(st_f16x8, l0);
-            *reinterpret_cast<st_f16x8*>(dst + kTilePx * kTtRow + 16) = __builtin_bit_cast(st_f16x8, l1);
-        }
     };
     fetch(tile0);
     stage(0);
@@ -134,10 +117,6 @@ __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem
             const st_f16x8 xf = *reinterpret_cast<const st_f16x8*>(xrow + 32 * (KS0 + i));
             ak = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[i], xf, ak, 0, 0, 0);
             ak = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[i], xf, ak, 0, 0, 0);
-            if constexpr (HL) {
-                const st_f16x8 xl = *reinterpret_cast<const st_f16x8*>(xrow + kTilePx * kTtRow + 32 * (KS0 + i));
-                ak = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[i], xl, ak, 0, 0, 0);
-            }
         }
         float sk = 0.f;
 #pragma unroll
@@ -171,31 +150,28 @@ __device__ __forceinline__ void stats_tight_role(const StatsTArgs& a, char* smem
     }
 }
 
-template <bool HL>
 __global__ __launch_bounds__(512) void retr_stats_tight_kernel(StatsTArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // waves w and w + 4 share a SIMD: row blocks (j, 7 - j) there, 18 k-steps per SIMD and tile whatever j
     switch (w) {
-        case 0: stats_tight_role<0, HL>(a, smem, w, lane); break;
-        case 1: stats_tight_role<1, HL>(a, smem, w, lane); break;
-        case 2: stats_tight_role<2, HL>(a, smem, w, lane); break;
-        case 3: stats_tight_role<3, HL>(a, smem, w, lane); break;
-        case 4: stats_tight_role<7, HL>(a, smem, w, lane); break;
-        case 5: stats_tight_role<6, HL>(a, smem, w, lane); break;
-        case 6: stats_tight_role<5, HL>(a, smem, w, lane); break;
-        default: stats_tight_role<4, HL>(a, smem, w, lane); break;
+        case 0: stats_tight_role<0>(a, smem, w, lane); break;
+        case 1: stats_tight_role<1>(a, smem, w, lane); break;
+        case 2: stats_tight_role<2>(a, smem, w, lane); break;
+        case 3: stats_tight_role<3>(a, smem, w, lane); break;
+        case 4: stats_tight_role<7>(a, smem, w, lane); break;
+        case 5: stats_tight_role<6>(a, smem, w, lane); break;
+        case 6: stats_tight_role<5>(a, smem, w, lane); break;
+        default: stats_tight_role<4>(a, smem, w, lane); break;
     }
 }
 
 }  // namespace svps
 
-namespace {
-// feat_lo == nullptr: the 16-bit map form (svps_retr_stats_tight_fwd); otherwise fp16 hi + lo planes (svps_retr_stats_hl_fwd)
-int launch_stats_tight(const void* feat, const void* feat_lo, const float* ty, const float* tx, const void* rk_hi, const void* rk_lo,
-                       const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo, const float* rbv, float lnv_eps, void* aux,
-                       int T, int H, int W, int D, int flags, void* stream_) {
+extern "C" int svps_retr_stats_tight_fwd(const void* feat, const float* ty, const float* tx, const void* rk_hi, const void* rk_lo,
+                                         const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo, const float* rbv,
+                                         float lnv_eps, void* aux, int T, int H, int W, int D, int flags, void* stream_) {
     if (!feat || !rk_hi || !rk_lo || !rbk || !rv_hi || !rv_lo || !rbv || !aux || ((ty == nullptr) != (tx == nullptr))) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
@@ -205,34 +181,13 @@ int launch_stats_tight(const void* feat, const void* feat_lo, const float* ty, c
     const int tpw = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpw - 1) / tpw;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const bool hl = feat_lo != nullptr;
-    const int mf = (hl || (flags & SVPS_FLAG_MAP_F16)) ? 1 : 0;
-    const int lds = hl ? svps::StatsTLdsT<true>::total : svps::StatsTLdsT<false>::total;
-    auto kern = hl ? svps::retr_stats_tight_kernel<true> : svps::retr_stats_tight_kernel<false>;
-    static SvpsLdsAttr attr[2];
-    if (hipError_t ae = attr[hl ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds); ae != hipSuccess) return (int)ae;
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
-    const svps::StatsTArgs ak{static_cast<const __bf16*>(feat), static_cast<const __bf16*>(feat_lo), ty, tx, static_cast<const _Float16*>(rk_hi),
-                              static_cast<const _Float16*>(rk_lo), rbk, static_cast<__bf16*>(aux), lnk_eps, HW, H, W, tpw, 0, mf};
-    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, ak);
-    const svps::StatsTArgs av{static_cast<const __bf16*>(feat), static_cast<const __bf16*>(feat_lo), nullptr, nullptr, static_cast<const _Float16*>(rv_hi),
-                              static_cast<const _Float16*>(rv_lo), rbv, static_cast<__bf16*>(aux), lnv_eps, HW, H, W, tpw, 1, mf};
-    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, av);
+    const svps::StatsTArgs ak{static_cast<const __bf16*>(feat), ty, tx, static_cast<const _Float16*>(rk_hi),
+                              static_cast<const _Float16*>(rk_lo), rbk, static_cast<__bf16*>(aux), lnk_eps, HW, H, W, tpw, 0, (flags & SVPS_FLAG_MAP_F16) ? 1 : 0};
+    hipLaunchKernelGGL(svps::retr_stats_tight_kernel, dim3(chunks, T), dim3(512), svps::StatsTLds::total, stream, ak);
+    const svps::StatsTArgs av{static_cast<const __bf16*>(feat), nullptr, nullptr, static_cast<const _Float16*>(rv_hi),
+                              static_cast<const _Float16*>(rv_lo), rbv, static_cast<__bf16*>(aux), lnv_eps, HW, H, W, tpw, 1, (flags & SVPS_FLAG_MAP_F16) ? 1 : 0};
+    hipLaunchKernelGGL(svps::retr_stats_tight_kernel, dim3(chunks, T), dim3(512), svps::StatsTLds::total, stream, av);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);
     return (int)hipGetLastError();
-}
-}  // namespace
-
-extern "C" int svps_retr_stats_tight_fwd(const void* feat, const float* ty, const float* tx, const void* rk_hi, const void* rk_lo,
-                                         const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo, const float* rbv,
-                                         float lnv_eps, void* aux, int T, int H, int W, int D, int flags, void* stream_) {
-    return launch_stats_tight(feat, nullptr, ty, tx, rk_hi, rk_lo, rbk, lnk_eps, rv_hi, rv_lo, rbv, lnv_eps, aux, T, H, W, D, flags, stream_);
-}
-
-// the statistics of the reference-precision mode: the map as fp16 hi + lo planes (svps_level_fuse_hl_fwd), both factors as hi + lo
-extern "C" int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* ty, const float* tx, const void* rk_hi,
-                                      const void* rk_lo, const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo,
-                                      const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D, void* stream_) {
-    if (!feat_lo) return SVPS_ERR_BAD_ARG;
-    return launch_stats_tight(feat_hi, feat_lo, ty, tx, rk_hi, rk_lo, rbk, lnk_eps, rv_hi, rv_lo, rbv, lnv_eps, aux, T, H, W, D, SVPS_FLAG_MAP_F16, stream_);
 }

@@ -738,33 +738,56 @@ def _need_hl(t, name, T=None):
         raise ValueError(f"{name}: expected [2 (hi, lo), T, HW, 256] fp16, got {tuple(t.shape)}")
 
 
-def level_fuse_hl(cur, prev_hl, wc_hl, bc, H, W):
-    """K4 at the reference's precision (csrc/level_fuse_hl.hip): cur [T, 128, H, W] fp32 NCHW, prev_hl [2, T, (H/2)(W/2), 256] fp16 planes
-    of the coarser level or None (level 0), wc_hl [2, 256, 384] fp16 (split_hl of the conv weight), bc [256] fp32
-    -> the fused map as planes [2, T, H*W, 256] fp16 (hi, lo). dynamic_mask_head.py:171-188."""
+def level_fuse_hl_weights(wc):
+    """conv_trans weight [256, 384] fp32 -> the operands of the reference-precision level fusion (csrc/level_fuse_hl.hip):
+    wb_hl [2, 256, 128] fp16 planes of W_b = wc[:, 256:] (incoming channels), w0_hl the same for level 0's W_1 + W_2 + W_3 (summed in
+    float64), wa_pack = pack_b_fragments(W_a = wc[:, :256], "fp16") for the coarse product g = f W_a^T on K8."""
+    w = wc.detach().double()
+    wb = w[:, 256:].float().contiguous()
+    w0 = (w[:, :128] + w[:, 128:256] + w[:, 256:]).float().contiguous()
+    return {"wb_hl": split_hl(wb), "w0_hl": split_hl(w0), "wa_pack": pack_b_fragments(w[:, :256].float().contiguous(), "fp16")}
+
+
+def level_fuse_hl(cur, prev_f32, weights, bc, H, W, want_f32=False):
+    """K4 at the reference's precision: f = up(prev W_a^T) + W_b cur + b (a 1x1 conv commutes with bilinear interpolation; the 256-wide
+    product runs at the coarse resolution on K8 with fp16 hi + lo operands). cur [T, 128, H, W] fp32 NCHW; prev_f32 [T, (H/2)(W/2), 256]
+    fp32 (the coarser level's fused map) or None (level 0: cat(x, x, x)); weights = level_fuse_hl_weights(conv weight); bc [256] fp32.
+    Returns (planes [2, T, H*W, 256] fp16 (hi, lo), the same values as fp32 [T, H*W, 256] if want_f32 else None).
+    dynamic_mask_head.py:171-188."""
     lib = _lib.load()
     _need(cur, "cur", torch.float32, 4)
     T = cur.shape[0]
     if cur.shape != (T, 128, H, W):
         raise ValueError(f"cur {tuple(cur.shape)} != [T, 128, {H}, {W}]")
-    _need(wc_hl, "wc_hl", torch.float16, 3)
-    if wc_hl.shape != (2, 256, 384):
-        raise ValueError("wc_hl must be [2, 256, 384]")
     _need(bc, "bc", torch.float32, 1)
-    if prev_hl is not None:
-        _need_hl(prev_hl, "prev_hl", T)
-        if prev_hl.shape[2] != (H // 2) * (W // 2) or H % 2 or W % 2:
-            raise ValueError(f"prev_hl {tuple(prev_hl.shape)} does not match an {H}x{W} level")
+    g = None
+    if prev_f32 is not None:
+        _need(prev_f32, "prev_f32", torch.float32, 3)
+        if prev_f32.shape != (T, (H // 2) * (W // 2), 256) or H % 2 or W % 2:
+            raise ValueError(f"prev_f32 {tuple(prev_f32.shape)} does not match an {H}x{W} level")
+        g = slot_gemm(prev_f32.view(-1, 256), weights["wa_pack"])          # [T * HWp, 256] fp32 = f_{i-1} W_a^T
+    w_hl = weights["wb_hl"] if prev_f32 is not None else weights["w0_hl"]
+    _need(w_hl, "w_hl", torch.float16, 3)
     out = torch.empty((2, T, H * W, 256), dtype=torch.float16, device=cur.device)
-    with _on(cur, prev_hl, wc_hl, bc) as ctx:
-        rc = lib.svps_level_fuse_hl_fwd(_ptr(cur), _ptr(None if prev_hl is None else prev_hl[0]), _ptr(None if prev_hl is None else prev_hl[1]),
-                                        _ptr(wc_hl[0]), _ptr(wc_hl[1]), _ptr(bc), _ptr(out[0]), _ptr(out[1]), T, H, W, ctx.stream)
+    f32 = torch.empty((T, H * W, 256), dtype=torch.float32, device=cur.device) if want_f32 else None
+    with _on(cur, g, w_hl, bc) as ctx:
+        rc = lib.svps_level_fuse_hl_fwd(_ptr(cur), _ptr(g), _ptr(w_hl[0]), _ptr(w_hl[1]), _ptr(bc), _ptr(out[0]), _ptr(out[1]), _ptr(f32),
+                                        T, H, W, ctx.stream)
     _lib.check(rc, "svps_level_fuse_hl_fwd")
-    return out
+    return out, f32
 
 
-def retr_stats_hl(feat_hl, H, W, pos_proj, rk_hi, rk_lo, rbk, eps_k, rv_hi, rv_lo, rbv, eps_v):
-    """retr_stats_tight on a map given as fp16 hi + lo planes [2, T, HW, 256]: the same aux rows [T, HW, 8]."""
+def acc_order_perm(device=None):
+    """Column permutation of the fp32 tables svps_retr_stats_hl_fwd takes: table[:, perm] puts factor row 32 B + 8 g + 4 h + j at column
+    32 B + 16 h + 4 g + j (a lane's 16 accumulator rows of a row block become 64 contiguous bytes)."""
+    b, h, g, j = torch.meshgrid(torch.arange(8), torch.arange(2), torch.arange(4), torch.arange(4), indexing="ij")
+    return (32 * b + 8 * g + 4 * h + j).reshape(-1).to(device)
+
+
+def retr_stats_hl(feat_hl, H, W, tyk, txk, rk_hi, rk_lo, eps_k, rv_hi, rv_lo, rbv, eps_v):
+    """Both LayerNorm statistics of the fused retriever from ONE read of a map given as fp16 hi + lo planes [2, T, HW, 256], both factors
+    as fp16 hi + lo (csrc/retr_stats_hl.hip): the aux rows [T, HW, 8] of retr_stats. tyk [H or 1, 256] = Ty + r_k, txk [W or 1, 256] = Tx,
+    rbv [256] = r_v: fp32, columns in accumulator order (acc_order_perm)."""
     lib = _lib.load()
     _need_hl(feat_hl, "feat_hl")
     _, T, HW, D = feat_hl.shape
@@ -774,19 +797,16 @@ def retr_stats_hl(feat_hl, H, W, pos_proj, rk_hi, rk_lo, rbk, eps_k, rv_hi, rv_l
         _need(m, name, torch.float16, 2)
         if m.shape != (D, D):
             raise ValueError(f"{name} must be [256, 256]")
-    _need(rbk, "rbk", torch.float32, 1)
+    _need(tyk, "tyk", torch.float32, 2)
+    _need(txk, "txk", torch.float32, 2)
     _need(rbv, "rbv", torch.float32, 1)
-    ytab = xtab = None
-    if pos_proj is not None:
-        ytab, xtab = pos_proj
-        _need(ytab, "ty", torch.float32, 2)
-        _need(xtab, "tx", torch.float32, 2)
-        if ytab.shape != (H, D) or xtab.shape != (W, D):
-            raise ValueError("projected position tables do not match (H, W)")
+    if tyk.shape[1] != D or txk.shape[1] != D or tyk.shape[0] not in (1, H) or txk.shape[0] not in (1, W) or rbv.numel() != D:
+        raise ValueError("tables do not match (H, W)")
     aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat_hl.device)
-    with _on(feat_hl, ytab, xtab, rk_hi, rk_lo, rbk, rv_hi, rv_lo, rbv) as ctx:
-        rc = lib.svps_retr_stats_hl_fwd(_ptr(feat_hl[0]), _ptr(feat_hl[1]), _ptr(ytab), _ptr(xtab), _ptr(rk_hi), _ptr(rk_lo), _ptr(rbk),
-                                        float(eps_k), _ptr(rv_hi), _ptr(rv_lo), _ptr(rbv), float(eps_v), _ptr(aux), T, H, W, D, ctx.stream)
+    with _on(feat_hl, tyk, txk, rk_hi, rk_lo, rv_hi, rv_lo, rbv) as ctx:
+        rc = lib.svps_retr_stats_hl_fwd(_ptr(feat_hl[0]), _ptr(feat_hl[1]), _ptr(tyk), tyk.shape[0], _ptr(txk), txk.shape[0], _ptr(rk_hi),
+                                        _ptr(rk_lo), float(eps_k), _ptr(rv_hi), _ptr(rv_lo), _ptr(rbv), float(eps_v), _ptr(aux), T, H, W, D,
+                                        ctx.stream)
     _lib.check(rc, "svps_retr_stats_hl_fwd")
     return aux
 

@@ -277,6 +277,24 @@ class MaskDynamicConv(nn.Module):
             cache[key] = (ty.float().to(ytab.device).contiguous(), tx.float().to(xtab.device).contiguous(), ytab, xtab)
         return cache[key][:2]
 
+    def stats_hl_tables(self, pos_tabs):
+        """Tables of csrc/retr_stats_hl.hip, columns in accumulator order: (Ty + r_k [H or 1, 256], Tx [W or 1, 256], r_v [256]) fp32.
+        Derived once per (weights, level geometry)."""
+        c = self._fused_consts()
+        cache = c.setdefault("hl_tables", {})
+        key = None if pos_tabs is None else (pos_tabs[0].data_ptr(), pos_tabs[1].data_ptr(), tuple(pos_tabs[0].shape), tuple(pos_tabs[1].shape))
+        if key not in cache:
+            perm = ops.acc_order_perm(c["rbk"].device)
+            if pos_tabs is None:
+                tyk = c["rbk"][perm][None].contiguous()
+                txk = torch.zeros((1, perm.numel()), dtype=torch.float32, device=perm.device)
+            else:
+                ty, tx = self.retr_pos_tables(pos_tabs)
+                tyk = (ty + c["rbk"][None])[:, perm].contiguous()
+                txk = tx[:, perm].contiguous()
+            cache[key] = (tyk, txk, c["rbv"][perm].contiguous(), pos_tabs)
+        return cache[key][:3]
+
     def stats_args(self, pos_tabs):
         """(pos_proj, rk, rbk, eps_k, rv, rbv, eps_v): this stage's arguments of ops.retr_stats / one entry of ops.retr_stats_level."""
         c = self._fused_consts()
@@ -303,8 +321,8 @@ class MaskDynamicConv(nn.Module):
             # reference precision: factors AND map as fp16 hi + lo (K3t's HL form: three MFMAs per product)
             if L > 128:
                 raise NotImplementedError("precision 'fp16x2' covers L <= 128 slots (the exact mode, set_precision('fp32'), has no limit)")
-            pp, rk, rbk, ek, rv, rbv, ev = self.stats_args(pos_tabs)
-            stats = ops.retr_stats_hl(feat_pm, H, W, pp, rk, c["rk_lo"], rbk, ek, rv, c["rv_lo"], rbv, ev)
+            tyk, txk, rbv_p = self.stats_hl_tables(pos_tabs)
+            stats = ops.retr_stats_hl(feat_pm, H, W, tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p, self.norm_v.eps)
         elif self.tight_stats:
             # precision form: both statistics from factors carried as fp16 hi + lo (K3t)
             pp, rk, rbk, ek, rv, rbv, ev = self.stats_args(pos_tabs)
@@ -812,7 +830,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
         self.map_dtype = dtype
         return self
 
-    def fuse_level(self, cur, prev_pm, hw):
+    def fuse_level(self, cur, prev_pm, hw, last=False):
         """K4 (:171-188). cur [T, 128, H, W] fp32 (the reference's layout) or [T, H*W, 128] bf16;
         prev_pm [T, (H/2)*(W/2), 256] bf16 fused map of the coarser level or None (level 0).
         Returns the fused map [T, H*W, 256] bf16 pixel-major."""
@@ -824,8 +842,15 @@ class MultiScaleDynamicMaskHead(nn.Module):
             conv = self.conv_trans.conv
             if cur.dim() != 4:
                 raise NotImplementedError("precision 'fp16x2' takes the incoming maps as [T, 128, H, W] fp32 (NCHW)")
-            w_hl = _cached(self, "cw_hl", [conv.weight], lambda: ops.split_hl(conv.weight.detach().reshape(self.dh_dim, -1).float().contiguous()))
-            return ops.level_fuse_hl(cur.float().contiguous(), prev_pm, w_hl, conv.bias, hw[0], hw[1])
+            wts = _cached(self, "cw_hl", [conv.weight], lambda: ops.level_fuse_hl_weights(conv.weight.detach().reshape(self.dh_dim, -1)))
+            prev_f32 = None
+            if prev_pm is not None:                      # the coarser level's fp32 copy (K4-HL writes it next to the planes)
+                prev_f32 = getattr(prev_pm, "_svps_f32", None)
+                if prev_f32 is None:
+                    prev_f32 = prev_pm[0].float() + prev_pm[1].float()
+            out, f32 = ops.level_fuse_hl(cur.float().contiguous(), prev_f32, wts, conv.bias, hw[0], hw[1], want_f32=not last)
+            out._svps_f32 = f32
+            return out
         form = self._map_form(cur)
         if prev_pm is not None and form != "fp16":                       # a level follows the encoding of the level below it
             form = "bf16_in_fp16" if prev_pm.dtype == torch.float16 else "bf16"
@@ -871,7 +896,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 h, w = feats[i].shape[-2:]
             else:
                 h, w = hws[i]
-            f_pm = self.fuse_level(feats[i], prev, (h, w))
+            f_pm = self.fuse_level(feats[i], prev, (h, w), last=i == self.feat_num_levels - 1)
             series = getattr(self, f"head_series_{i}")
             mdcs = [stage.inst_interact for stage in series]
             if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16) and f_pm.dim() == 3

@@ -43,19 +43,20 @@ def test_split_hl_is_22_bits(cuda):
 
 @pytest.mark.parametrize("T,H,W,lvl0", [(2, 8, 16, True), (1, 6, 10, False), (2, 34, 60, False), (3, 16, 64, False), (1, 2, 4, True)])
 def test_level_fuse_hl(cuda, T, H, W, lvl0):
-    """K4-HL against a float64 evaluation of dynamic_mask_head.py:171-188 on identical inputs (the previous level = the planes' exact sum)."""
+    """K4-HL (f = up(prev W_a^T) + W_b x + b: the coarse product on K8, the rest in csrc/level_fuse_hl.hip) against a float64 evaluation of
+    dynamic_mask_head.py:171-188 in the REFERENCE's order (conv of the concatenated, upsampled map) on identical fp32 inputs."""
     from slotvps_amd import ops
     rng = np.random.default_rng(H * W)
     cur = rng.standard_normal((T, 128, H, W)).astype(np.float32)
     prev = None if lvl0 else (3.0 * rng.standard_normal((T, (H // 2) * (W // 2), 256))).astype(np.float32)
     wc = (rng.standard_normal((256, 384)) / 20).astype(np.float32)
     bc = rng.standard_normal(256).astype(np.float32)
-    prev_hl = None if prev is None else ops.split_hl(_t(prev, cuda))
-    w_hl = ops.split_hl(_t(wc, cuda))
-    out = ops.level_fuse_hl(_t(cur, cuda), prev_hl, w_hl, _t(bc, cuda), H, W)
+    wts = ops.level_fuse_hl_weights(_t(wc, cuda))
+    out, f32 = ops.level_fuse_hl(_t(cur, cuda), None if prev is None else _t(prev, cuda), wts, _t(bc, cuda), H, W, want_f32=True)
     got = _sum_hl(out)
-    prev64 = None if prev is None else _sum_hl(prev_hl)
-    w64 = _sum_hl(w_hl)
+    assert np.array_equal(got, f32.double().cpu().numpy())      # the fp32 copy holds exactly the planes' value
+    prev64 = None if prev is None else prev.astype(np.float64)
+    w64 = wc.astype(np.float64)
     worst = 0.0
     for t in range(T):
         p = None if prev is None else np.ascontiguousarray(prev64[t].T).reshape(256, H // 2, W // 2)
