@@ -71,6 +71,12 @@ class SlotMasks:
             self._dense = self._decode(0, self.embeds.shape[0], self.embeds)
         return self._dense
 
+    def decode_clip(self, index):
+        """index [T, K] int64 (device): slot ids per frame (padded rows repeat any valid id) -> mask logits [T, K, h, w] of exactly those
+        slots, in that order, in ONE launch (the clip path of the post-process: the kept slots of every frame in score order)."""
+        emb = torch.gather(self.embeds, 1, index[:, :, None].expand(-1, -1, self.embeds.shape[2]))
+        return self._decode(0, self.embeds.shape[0], emb)
+
     def __getitem__(self, t):
         return FrameSlotMasks(self, int(t))
 
@@ -272,6 +278,7 @@ class VPS_Temporal_Slots(nn.Module):
         self._fold = None
         self.reuse_ref_features = True           # keep the previous frame's level maps
         self.decode_selected = True              # K2 decodes only the slots the post-process keeps (SlotMasks)
+        self.clip_postprocess = True             # clip_test: post-process + tracker of all frames in lock-step (_clip_results)
         self.use_graph = False                   # replay the slot head as one hipGraph per input geometry (_head_clip)
         self._head_cache = {}
         self._trunk_bf16 = False
@@ -474,10 +481,65 @@ class VPS_Temporal_Slots(nn.Module):
         Returns one result dict per frame; the tracker runs over the frames in order."""
         logits, embeds, masks, fcn = self.slot_path(imgs)
         div_mod = 100000 if self.num_classes in (23, 24) else 10000
+        firsts = [meta["iid"] % div_mod == 1 for meta in img_metas]
+        shapes = {(int(m["ori_shape"][0]), int(m["ori_shape"][1])) for m in img_metas}
+        if self.clip_postprocess and len(shapes) == 1:
+            return self._clip_results(logits, masks, embeds, fcn, shapes.pop(), firsts)
         out = []
         for t, meta in enumerate(img_metas):
-            out.append(self._frame_result(logits[t], masks[t], embeds[t], fcn[t:t + 1], meta["ori_shape"],
-                                          meta["iid"] % div_mod == 1))
+            out.append(self._frame_result(logits[t], masks[t], embeds[t], fcn[t:t + 1], meta["ori_shape"], firsts[t]))
+        return out
+
+    def _clip_results(self, logits, masks, embeds, fcn, size, firsts):
+        """_frame_result for all frames of a clip in lock-step (same decisions, same results): the post-process phases of all frames run
+        together (postprocess.forward_clip / panoptic_ids_clip: one device -> host copy per phase), the tracker's match scores come from
+        ONE copy of the embedded segment vectors of all frames (the fc stack is per row, so a memory row's embedding is the embedding of
+        the segment it was copied from) and its sequential id assignment runs on the host."""
+        H, W = size
+        T = logits.shape[0]
+        pp = self.postprocess_panoptic
+        results = pp.forward_clip(logits, masks, (H, W))
+        # ---- tracker (:345-409): embedded vectors of every frame's segments (+ of the memory a previous clip left) in one go
+        seg = [embeds[t][r.slot_index] for t, r in enumerate(results)]
+        rows = [s_.shape[0] for s_ in seg]
+        have_mem = self.prev_embedding is not None and not firsts[0]
+        raw = torch.cat(([self.prev_embedding] if have_mem else []) + seg)
+        emb_h = self.temporal_track_head._embed(raw).cpu().numpy()                                   # the only copy of the tracker
+        o = self.prev_embedding.shape[0] if have_mem else 0
+        mem_src = list(range(o))                                     # memory row -> row of `raw` it currently holds
+        dets = []
+        for t in range(T):
+            K = rows[t]
+            if firsts[t] or (t == 0 and not have_mem):
+                mem_src = list(range(o, o + K))
+                det = np.arange(K, dtype=np.int64)
+            else:
+                assert K > 0 and len(mem_src) > 0
+                prod = emb_h[o:o + K] @ emb_h[mem_src].T
+                score = torch.from_numpy(np.concatenate([np.zeros((K, 1), dtype=prod.dtype), prod], axis=1))
+                logprob = F.log_softmax(score, dim=1).numpy()
+                det, updates = greedy_track_assign(logprob, len(mem_src))
+                for p_, c_ in updates:                               # in order: a later, stronger match overwrites an earlier one
+                    if p_ == len(mem_src):
+                        mem_src.append(o + c_)
+                    else:
+                        mem_src[p_] = o + c_
+                det = det.astype(np.int64)
+            dets.append(det)
+            o += K
+        self.prev_embedding = raw[torch.as_tensor(mem_src, dtype=torch.long, device=raw.device)].clone()
+        last = results[-1]
+        self.test_track_instances = Instances((H, W), slot_index=last.slot_index, labels=torch.from_numpy(last.labels_host).to(raw.device),
+                                              output_embedding=seg[-1], obj_ids=torch.from_numpy(dets[-1]))
+        pans = pp.panoptic_ids_clip(results, self.stuff_num)
+        if fcn.shape[-2] != H or fcn.shape[-1] != W:
+            fcn = F.interpolate(fcn, size=(H, W), mode="bilinear", align_corners=False)
+        fcn_ids = fcn.argmax(dim=1)                                  # argmax of the softmax (:447)
+        out = []
+        for t, (r, (pan, cls_inds, cls_prob)) in enumerate(zip(results, pans)):
+            ins = r.labels_host > self.stuff_num - 1
+            out.append({"fcn_outputs": fcn_ids[t:t + 1, :H, :W], "panoptic_cls_inds": cls_inds, "panoptic_cls_prob": cls_prob,
+                        "panoptic_det_obj_ids": torch.from_numpy(dets[t])[torch.from_numpy(ins)], "panoptic_outputs": pan[None, :H, :W].long()})
         return out
 
     def forward_test(self, imgs, img_metas, rescale=False, ref_img=None):

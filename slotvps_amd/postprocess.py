@@ -62,17 +62,24 @@ class PostProcessPanopticInstances(nn.Module):
         return cand, counts, pairs
 
     @staticmethod
-    def _argmax(m_sorted, sel, sel_thing, kept_u8, cand, lut, size, want_ids=False, want_hist=True, want_masks=False):
+    def _argmax(m_sorted, sel, sel_thing, kept_u8, cand, lut, size, want_ids=False, want_hist=True, want_masks=False, tables=None,
+                hist=None):
+        """tables: (sel, sel_thing, lut) as uint8 DEVICE tensors already uploaded (the clip path batches its uploads); hist: a zeroed
+        [256] int32 device buffer to accumulate into (the clip path keeps one row per frame and copies them back together)."""
         lib = _lib.load()
         K, h, w = m_sorted.shape
         H, W = size
         dev = m_sorted.device
         n = len(sel)
-        t_sel = torch.tensor(sel if n else [0], dtype=torch.uint8, device=dev)
-        t_thing = torch.tensor(sel_thing if n else [0], dtype=torch.uint8, device=dev)
-        t_lut = torch.tensor(lut if n else [0], dtype=torch.uint8, device=dev)
+        if tables is None:
+            t_sel = torch.tensor(sel if n else [0], dtype=torch.uint8, device=dev)
+            t_thing = torch.tensor(sel_thing if n else [0], dtype=torch.uint8, device=dev)
+            t_lut = torch.tensor(lut if n else [0], dtype=torch.uint8, device=dev)
+        else:
+            t_sel, t_thing, t_lut = tables
         ids = torch.empty(H * W, dtype=torch.uint8, device=dev) if want_ids else None
-        hist = torch.zeros(256, dtype=torch.int32, device=dev) if want_hist else None
+        if hist is None:
+            hist = torch.zeros(256, dtype=torch.int32, device=dev) if want_hist else None
         masks = torch.empty((n, H, W), dtype=torch.float32, device=dev) if want_masks else None
         with _on(m_sorted, t_sel, t_thing, kept_u8, cand, t_lut, ids, hist, masks) as ctx:
             _lib.check(lib.svps_panoptic_argmax(_p(m_sorted), _p(t_sel), _p(t_thing), n, _p(kept_u8), _p(cand), _p(t_lut),
@@ -163,6 +170,205 @@ class PostProcessPanopticInstances(nn.Module):
             _, _, res.masks = self._argmax(m_sorted, cur, [thing[i] for i in cur], kept_u8, cand, list(range(len(cur))),
                                            size, want_hist=False, want_masks=True)
         return res
+
+    # ---- the same for ALL frames of a clip, in lock-step: one device -> host copy per PHASE instead of seven per frame ---------------
+    @staticmethod
+    def _upload(dev, arrays):
+        """Several small uint8 host arrays -> device views of ONE uploaded buffer (one H2D copy)."""
+        import numpy as np
+        lens = [max(1, len(a)) for a in arrays]
+        flat = np.zeros(sum(lens), dtype=np.uint8)
+        o = 0
+        for a, n in zip(arrays, lens):
+            flat[o:o + len(a)] = a
+            o += n
+        t = torch.from_numpy(flat).to(dev)                  # (a few hundred bytes: a pageable copy; pinning a fresh buffer costs more)
+        out, o = [], 0
+        for n in lens:
+            out.append(t[o:o + n])
+            o += n
+        return out
+
+    def _small(self, area, cur, thing):
+        if self.filter_small_option == "4":
+            return [a <= 4 for a in area]
+        if self.filter_small_option == "4_256":
+            return [a < 256 if thing[i] else a < 4 for a, i in zip(area, cur)]
+        if self.filter_small_option == "4096_256":
+            return [a < 4096 if not thing[i] else a < 256 for a, i in zip(area, cur)]
+        raise AssertionError("filter_small_option is not valid !!!!!!")
+
+    @torch.no_grad()
+    def forward_clip(self, pred_logits, pred_masks, size):
+        """forward_tensors for the T frames of a clip at once (same decisions, same kernels, same results frame by frame): pred_logits
+        [T, L, nc]; pred_masks a clip of lazy mask logits (`decode_clip(index [T, Kmax]) -> [T, Kmax, h, w]`, detector.SlotMasks) or a
+        dense [T, L, h, w] tensor; size (H, W). The frames move through the phases together - score filter, decode of the kept slots
+        (ONE K2 launch), candidates, mask_removal tables, areas, small-area loop - so the host waits for the device once per phase,
+        not seven times per frame. Returns the list of per-frame result namespaces of forward_tensors."""
+        import numpy as np
+        if not pred_masks.is_cuda:
+            raise RuntimeError("the panoptic post-process runs on the GPU only; there is no CPU fallback")
+        dev = pred_masks.device
+        T, L, nc = pred_logits.shape
+        H, W = size
+        n_px = H * W
+        scores, classes = pred_logits.float().softmax(-1).max(-1)                                   # :684
+        host = torch.stack([scores, classes.float()]).cpu().numpy()                                  # copy 1: [2, T, L]
+        fr = []
+        for t in range(T):
+            sc_l, cl_l = host[0, t], host[1, t].astype(np.int64)
+            keep = sc_l > self.threshold if nc == self.num_classes - 1 else (cl_l != nc - 1) & (sc_l > self.threshold)   # :688-691
+            idx = np.nonzero(keep)[0]
+            if idx.size == 0:
+                raise ValueError("no slot passes the score threshold (the reference's mask_removal fails here too, :652)")
+            if idx.size > 255:
+                raise NotImplementedError("more than 255 kept slots")
+            sc, cl = sc_l[idx], cl_l[idx]
+            order = sc.argsort()[::-1]                                                               # :580
+            fr.append(SimpleNamespace(sorted_idx=idx[order], sc=sc[order], cl=cl[order], K=int(idx.size),
+                                      thing=[bool(c > self.num_stuff - 1) for c in cl[order]]))      # :594
+        Kmax = max(f.K for f in fr)
+        index = np.zeros((T, Kmax), dtype=np.int64)
+        for t, f in enumerate(fr):
+            index[t, :f.K] = f.sorted_idx
+        index_d = torch.from_numpy(index).to(dev)
+        if hasattr(pred_masks, "decode_clip"):                             # the kept slots of every frame, score order, one launch
+            m_clip = pred_masks.decode_clip(index_d)
+        else:
+            m_clip = torch.gather(pred_masks.float(), 1, index_d[:, :, None, None].expand(-1, -1, *pred_masks.shape[2:]))
+        m_clip = m_clip.float().contiguous()
+        h, w = m_clip.shape[2:]
+        things = self._upload(dev, [np.asarray(f.thing, dtype=np.uint8) for f in fr])
+        lib = _lib.load()
+        cand = torch.empty((T, n_px, 2), dtype=torch.uint8, device=dev)
+        tabs = torch.zeros((T, Kmax + Kmax * Kmax), dtype=torch.int32, device=dev)                  # per frame: counts [K], pairs [K, K]
+        for t, f in enumerate(fr):
+            f.m_sorted = m_clip[t, :f.K]
+            f.cand = cand[t]
+            with _on(f.m_sorted, things[t], cand, tabs) as ctx:
+                _lib.check(lib.svps_panoptic_candidates(_p(f.m_sorted), _p(things[t]), f.K, h, w, H, W, float(self.pixel_threshold),
+                                                        _p(f.cand), _p(tabs[t]), _p(tabs[t, Kmax:]), ctx.stream), "svps_panoptic_candidates")
+        tabs_h = tabs.cpu().numpy()                                                                  # copy 2
+        # ---- mask_removal :601-640 on the tables: stuff kept first, then things by descending score --------
+        for t, f in enumerate(fr):
+            K, thing, cl = f.K, f.thing, f.cl
+            counts_h, pairs_h = tabs_h[t, :K], tabs_h[t, Kmax:Kmax + K * K].reshape(K, K)
+            kept = [not x for x in thing]
+            for i in range(K):
+                if not thing[i]:
+                    continue
+                n_i = int(counts_h[i])
+                if n_i == 0 or n_i == n_px:
+                    continue
+                overlap = sum(int(pairs_h[j, i]) for j in range(i) if thing[j] and kept[j] and cl[j] == cl[i])
+                if overlap / float(n_i) > self.fraction_threshold:
+                    continue
+                kept[i] = True
+            f.kept = kept
+            f.cur = [i for i in range(K) if not thing[i]] + [i for i in range(K) if thing[i] and kept[i]]
+            first_of_class, lut = {}, []
+            for j, i in enumerate(f.cur):                                 # get_ids_area(dedup=True) :759
+                if not thing[i]:
+                    first_of_class.setdefault(int(cl[i]), j)
+                    lut.append(first_of_class[int(cl[i])])
+                else:
+                    lut.append(j)
+            f.lut = lut
+        up = self._upload(dev, [np.asarray(x, dtype=np.uint8) for f in fr for x in (f.kept, f.cur, [f.thing[i] for i in f.cur], f.lut)])
+        for t, f in enumerate(fr):
+            f.kept_u8 = up[4 * t]
+            f.tables = (up[4 * t + 1], up[4 * t + 2], up[4 * t + 3])
+        # ---- areas, then the small-area loop :760-790: every frame that still has a small segment goes round again (together)
+        todo = list(range(T))
+        while todo:
+            hist = torch.zeros((len(todo), 256), dtype=torch.int32, device=dev)
+            for n, t in enumerate(todo):
+                f = fr[t]
+                self._argmax(f.m_sorted, f.cur, None, f.kept_u8, f.cand, None, size, tables=f.tables, hist=hist[n])
+            hist_h = hist.cpu().numpy()                                                              # copy 3 (+ one per extra round)
+            again = []
+            for n, t in enumerate(todo):
+                f = fr[t]
+                f.area = hist_h[n, :len(f.cur)].tolist()
+                f.area_lut_identity = f.lut == list(range(len(f.cur)))
+                if not f.cur:
+                    continue
+                small = self._small(f.area, f.cur, f.thing)
+                if any(small):
+                    f.cur = [i for i, s_ in zip(f.cur, small) if not s_]
+                    f.lut = list(range(len(f.cur)))
+                    again.append(t)
+            if again:
+                up = self._upload(dev, [np.asarray(x, dtype=np.uint8) for t in again
+                                        for x in (fr[t].cur, [fr[t].thing[i] for i in fr[t].cur], fr[t].lut)])
+                for n, t in enumerate(again):
+                    fr[t].tables = (up[3 * n], up[3 * n + 1], up[3 * n + 2])
+            todo = again
+        out = []
+        for t, f in enumerate(fr):
+            cur = f.cur
+            sel_d = index_d[t, :f.K][torch.as_tensor(cur, dtype=torch.long, device=dev)] if cur else index_d[t, :0]
+            out.append(SimpleNamespace(slot_index=sel_d, slot_index_host=f.sorted_idx[cur] if cur else f.sorted_idx[:0],
+                                       probs_host=f.sc[cur].copy(), labels_host=f.cl[cur].copy(), area=f.area, size=size,
+                                       _m_sorted=f.m_sorted, _cur=cur, _thing=f.thing, _kept_u8=f.kept_u8, _cand=f.cand,
+                                       _tables=f.tables, _hist_identity=f.area if f.area_lut_identity else None))
+        return out
+
+    @torch.no_grad()
+    def panoptic_ids_clip(self, results, stuff_num=None):
+        """panoptic_ids for the frames of a clip in lock-step (results of forward_clip): one copy back for the "which positions own
+        pixels" histograms of all frames, one upload of all relabel tables. Returns per frame (panoptic_output [H, W] uint8 on the
+        device, cls_inds, instance probabilities) - the last two as host tensors."""
+        import numpy as np
+        stuff_num = self.num_stuff if stuff_num is None else stuff_num
+        dev = results[0]._m_sorted.device
+        plan = []
+        for res in results:
+            cur, thing = res._cur, res._thing
+            order = [j for j, i in enumerate(cur) if not thing[i]] + [j for j, i in enumerate(cur) if thing[i]]
+            plan.append(SimpleNamespace(order=order, sel=[cur[j] for j in order], sem=[int(res.labels_host[j]) for j in order],
+                                        identity=order == list(range(len(cur)))))
+        # pass 1: which positions own pixels (torch.unique of the argmax map, :420). The area histogram of the last small-area round IS
+        # that histogram when it was taken over the same slot list in the same order with the identity table (no stuff de-duplication)
+        need = [n for n, (res, pl) in enumerate(zip(results, plan)) if not (pl.identity and res._hist_identity is not None)]
+        hist_h = None
+        if need:
+            up = self._upload(dev, [np.asarray(x, dtype=np.uint8) for n in need
+                                    for x in (plan[n].sel, [results[n]._thing[i] for i in plan[n].sel], list(range(len(plan[n].sel))))])
+            hist = torch.zeros((len(need), 256), dtype=torch.int32, device=dev)
+            for k, n in enumerate(need):
+                res = results[n]
+                self._argmax(res._m_sorted, plan[n].sel, None, res._kept_u8, res._cand, None, res.size,
+                             tables=(up[3 * k], up[3 * k + 1], up[3 * k + 2]), hist=hist[k])
+            hist_h = hist.cpu().numpy()
+        luts = []
+        for n, (res, pl) in enumerate(zip(results, plan)):
+            cur, thing = res._cur, res._thing
+            areas = hist_h[need.index(n), :len(pl.sel)].tolist() if n in need else res._hist_identity
+            present = [j for j, a in enumerate(areas) if a > 0]
+            panoptic_num = len(cur)
+            instance_num = sum(1 for i in cur if thing[i])
+            lut = [0] * max(len(pl.sel), 1)
+            count = instance_num
+            for pos in range(len(present) - 1, -1, -1):                    # :424-433
+                oid = present[pos]
+                if oid >= panoptic_num - instance_num:
+                    lut[oid] = stuff_num + count - 1
+                    count -= 1
+                else:
+                    lut[oid] = pl.sem[pos]                                 # position in unique(), not the id (:433)
+            luts.append(lut)
+        up = self._upload(dev, [np.asarray(x, dtype=np.uint8) for res, pl, lut in zip(results, plan, luts)
+                                for x in (pl.sel, [res._thing[i] for i in pl.sel], lut)])
+        out = []
+        for n, (res, pl) in enumerate(zip(results, plan)):
+            ids, _, _ = self._argmax(res._m_sorted, pl.sel, None, res._kept_u8, res._cand, None, res.size, want_ids=True, want_hist=False,
+                                     tables=(up[3 * n], up[3 * n + 1], up[3 * n + 2]))
+            ins = [j for j in range(len(res._cur)) if res._thing[res._cur[j]]]
+            cls_inds = torch.tensor([int(res.labels_host[j]) - (stuff_num - 1) for j in ins], dtype=torch.long)
+            probs = torch.from_numpy(res.probs_host[ins].copy()) if ins else torch.zeros(0)
+            out.append((ids.view(res.size[0], res.size[1]), cls_inds, probs))
+        return out
 
     def forward(self, outputs, processed_sizes, target_sizes=None, id=None):
         """Reference signature (:659): `outputs` carries pred_logits [L, nc] and pred_masks [L, h, w]."""
