@@ -17,6 +17,10 @@
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
+#ifndef SVPS_SHL_ABL
+#define SVPS_SHL_ABL 0      // timing-only ablations (wrong results): 1 no table loads, 2 no MFMAs, 4 no global tile loads, 8 no finish
+#endif
+
 namespace svps {
 
 typedef __attribute__((ext_vector_type(8))) _Float16 sh_f16x8;
@@ -138,52 +142,40 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
     auto body = [&](int tile, Pre& pn, Pre& pf) {     // pn: holds tile + 1 (staged at the end); pf: receives tile + 2
         const int cur = (tile - tile0) & 1;
         const int px0 = tile * kTilePx;
-        // key chains' start values first (older than the prefetch below: their wait does not cover it)
+        // The key chains start from Ty' + Tx' of the lane's pixel (L2-resident tables, 16 loads): requested here, consumed behind the value
+        // chain. Timing-only ablations (SVPS_SHL_ABL, finest level, T = 40: 2 790 us): without these loads 2 165, without the MFMAs 1 557,
+        // without the tile loads 2 274, without both 1 177 - the parts ADD UP (one in-order wave per SIMD: nothing overlaps), and moving the
+        // tables' use behind 54 MFMAs changed nothing (2 820): what they cost is the ISSUE of sixteen 64-sector loads, not their latency.
+        // The next step for this kernel is a column-strip tile order (Tx' constant per strip: eight of the sixteen loads disappear).
         int gp = px0 + r;
         gp = gp < a.HW ? gp : a.HW - 1;
         const int y = gp / a.W, x = gp - y * a.W;
         const float* tyr = a.tyk + (size_t)(y < a.ty_rows ? y : a.ty_rows - 1) * 256 + 16 * h;
         const float* txr = a.txk + (size_t)(x < a.tx_rows ? x : a.tx_rows - 1) * 256 + 16 * h;
-        f32x16 ka, kb;
+        f32x4 ya[4], xa[4], yb[4], xb[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 ya = *reinterpret_cast<const f32x4*>(tyr + 32 * RBA + 4 * g), xa = *reinterpret_cast<const f32x4*>(txr + 32 * RBA + 4 * g);
-            const f32x4 yb = *reinterpret_cast<const f32x4*>(tyr + 32 * RBB + 4 * g), xb = *reinterpret_cast<const f32x4*>(txr + 32 * RBB + 4 * g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ka[4 * g + j] = ya[j] + xa[j];
-                kb[4 * g + j] = yb[j] + xb[j];
-            }
+#if SVPS_SHL_ABL & 1
+            ya[g] = xa[g] = yb[g] = xb[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            (void)tyr; (void)txr;
+#else
+            ya[g] = *reinterpret_cast<const f32x4*>(tyr + 32 * RBA + 4 * g);
+            xa[g] = *reinterpret_cast<const f32x4*>(txr + 32 * RBA + 4 * g);
+            yb[g] = *reinterpret_cast<const f32x4*>(tyr + 32 * RBB + 4 * g);
+            xb[g] = *reinterpret_cast<const f32x4*>(txr + 32 * RBB + 4 * g);
+#endif
         }
-        if (tile + 2 < tile1) fetch(tile + 2, pf);
         const char* xh = smem + StatsHlLds::xt + cur * 2 * StatsHlLds::plane + r * kShRow + 16 * h;
         const char* xl = xh + StatsHlLds::plane;
-        // ---- key side. Fragments one k-step ahead of their MFMAs; the fences keep hipcc from hoisting all sixteen k-steps' reads (128
-        //      registers the weights leave no room for) to the top of the tile
         constexpr int K0 = KA < KB ? KA : KB;
-        sh_f16x8 fh[2], fl[2];
-        fh[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * K0);
-        fl[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * K0);
-#pragma unroll
-        for (int ks = K0; ks < 16; ++ks) {
-            if (ks + 1 < 16) {
-                fh[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * (ks + 1));
-                fl[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * (ks + 1));
-            }
-            if (ks >= KA) {
-                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kla[ks - KA], fh[ks & 1], ka, 0, 0, 0);
-                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kha[ks - KA], fl[ks & 1], ka, 0, 0, 0);
-                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kha[ks - KA], fh[ks & 1], ka, 0, 0, 0);
-            }
-            if (ks >= KB) {
-                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(klb[ks - KB], fh[ks & 1], kb, 0, 0, 0);
-                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(khb[ks - KB], fl[ks & 1], kb, 0, 0, 0);
-                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(khb[ks - KB], fh[ks & 1], kb, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const float sk0 = sumsq(ka) + sumsq(kb);
-        // ---- value side (the same fragments, read again: the registers hold the weights); r_v from the L1-resident table
+        // the loads of tile + 2, two at a time between the k-steps of the value chain (a 1-KiB vector-memory instruction holds its wave
+        // for ~100 cycles at issue; spread or in a row measures the same)
+        const bool more2 = tile + 2 < tile1 && !(SVPS_SHL_ABL & 4);
+        int gp2 = (tile + 2) * kTilePx + spx;
+        gp2 = gp2 < a.HW ? gp2 : a.HW - 1;
+        const size_t o2 = (size_t)gp2 * 256 + 32 * sc;
+        // ---- value side first. Fragments one k-step ahead of their MFMAs; the fences keep hipcc from hoisting all sixteen k-steps' reads
+        //      (128 registers the weights leave no room for) to the top of the tile
         f32x16 va, vb;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -195,6 +187,43 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
                 vb[4 * g + j] = rb_[j];
             }
         }
+        sh_f16x8 fh[2], fl[2];
+        fh[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * K0);
+        fl[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * K0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = K0; ks < 16; ++ks) {
+            if (ks + 1 < 16) {
+                fh[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * (ks + 1));
+                fl[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * (ks + 1));
+            }
+            if (ks >= KA && !(SVPS_SHL_ABL & 2)) {
+                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vla[ks - KA], fh[ks & 1], va, 0, 0, 0);
+                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vha[ks - KA], fl[ks & 1], va, 0, 0, 0);
+                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vha[ks - KA], fh[ks & 1], va, 0, 0, 0);
+            }
+            if (ks >= KB && !(SVPS_SHL_ABL & 2)) {
+                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlb[ks - KB], fh[ks & 1], vb, 0, 0, 0);
+                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhb[ks - KB], fl[ks & 1], vb, 0, 0, 0);
+                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhb[ks - KB], fh[ks & 1], vb, 0, 0, 0);
+            }
+            const int fi = (ks - K0 - 1) / 2;                         // loads of tile + 2: piece fi behind k-steps K0 + 1, + 3, + 5, + 7
+            if (more2 && ks > K0 && ((ks - K0 - 1) & 1) == 0 && fi < 4) {
+                pf.h[fi] = *reinterpret_cast<const u32x4*>(FH + o2 + 8 * fi);
+                pf.l[fi] = *reinterpret_cast<const u32x4*>(FL + o2 + 8 * fi);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float sv0 = sumsq(va) + sumsq(vb);
+        // ---- key side (the same fragments, read again: the registers hold the weights)
+        f32x16 ka, kb;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ka[4 * g + j] = ya[g][j] + xa[g][j];
+                kb[4 * g + j] = yb[g][j] + xb[g][j];
+            }
         fh[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * K0);
         fl[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * K0);
 #pragma unroll
@@ -203,19 +232,20 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
                 fh[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * (ks + 1));
                 fl[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * (ks + 1));
             }
-            if (ks >= KA) {
-                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vla[ks - KA], fh[ks & 1], va, 0, 0, 0);
-                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vha[ks - KA], fl[ks & 1], va, 0, 0, 0);
-                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vha[ks - KA], fh[ks & 1], va, 0, 0, 0);
+            if (ks >= KA && !(SVPS_SHL_ABL & 2)) {
+                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kla[ks - KA], fh[ks & 1], ka, 0, 0, 0);
+                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kha[ks - KA], fl[ks & 1], ka, 0, 0, 0);
+                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kha[ks - KA], fh[ks & 1], ka, 0, 0, 0);
             }
-            if (ks >= KB) {
-                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlb[ks - KB], fh[ks & 1], vb, 0, 0, 0);
-                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhb[ks - KB], fl[ks & 1], vb, 0, 0, 0);
-                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhb[ks - KB], fh[ks & 1], vb, 0, 0, 0);
+            if (ks >= KB && !(SVPS_SHL_ABL & 2)) {
+                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(klb[ks - KB], fh[ks & 1], kb, 0, 0, 0);
+                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(khb[ks - KB], fl[ks & 1], kb, 0, 0, 0);
+                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(khb[ks - KB], fh[ks & 1], kb, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        float sk = sk0, sv = sumsq(va) + sumsq(vb);
+        const float sk0 = sumsq(ka) + sumsq(kb);
+        float sk = sk0, sv = sv0;
         sk += __shfl_xor(sk, 32);
         sv += __shfl_xor(sv, 32);
         if (h == 0) {
@@ -224,7 +254,7 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
         }
         if (tile + 1 < tile1) stage(cur ^ 1, pn);
         __syncthreads();                             // sums of this tile complete; the next tile is staged
-        if (J == 0) finish(tile);
+        if (J == 0 && !(SVPS_SHL_ABL & 8)) finish(tile);
     };
     for (int tile = tile0; tile < tile1; tile += 2) {
         body(tile, p1, p0);
