@@ -689,9 +689,6 @@ def main():
                        "retriever": runner.retriever_form},
             "roofline": roof,
         }
-        if a.cpu_baseline and world == 1:
-            note("cpu_baseline leg (PyTorch CPU restatement, bounded sample) ...")
-            line["cpu_baseline"] = cpu_baseline(a)
         if world == 1 and a.latency_leg:
             del runner, gatherers
             torch.cuda.empty_cache()
@@ -789,6 +786,11 @@ def main():
                 line["whole_detector"] = whole_detector_leg(a, dev)
             except Exception as e:                       # informational leg: never costs the bench line
                 line["whole_detector"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    if rank == 0 and a.cpu_baseline and world == 1:
+        # LAST of the one-GPU legs: its 16-thread PyTorch-CPU clips leave the OpenMP pool spinning, which slows the HOST side of whatever
+        # runs next (measured: the whole-detector leg 79 ms per clip behind it, 66 ms before it)
+        note("cpu_baseline leg (PyTorch CPU restatement, bounded sample) ...")
+        line["cpu_baseline"] = cpu_baseline(a)
     if world > 1 and a.whole_detector:
         # informational: the whole detector per rank (trunk + this path + post-process + HOST tracker work), one clip at a time, all
         # ranks at once; independent per rank, then one gather of a number

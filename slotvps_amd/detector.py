@@ -62,6 +62,10 @@ class SlotMasks:
 
     def _decode(self, t0, t1, embed):
         scale, shift, fs, fb = self.fold
+        if self.fused.dim() == 4:                        # precision "fp16x2": the map as fp16 hi + lo planes [2, T, HW, 256]
+            m = ops.mask_decode_hl(self.fused[:, t0:t1].contiguous() if (t0, t1) != (0, self.fused.shape[1]) else self.fused,
+                                   embed.contiguous(), scale, shift, fs, fb)
+            return m.view(m.shape[0], m.shape[1], *self.hw)
         decode = ops.mask_decode_f32 if self.fused.dtype == torch.float32 else ops.mask_decode   # exact mode: fp32 map
         m = decode(self.fused[t0:t1], embed.contiguous(), scale, shift, fs, fb)
         return m.view(m.shape[0], m.shape[1], *self.hw)

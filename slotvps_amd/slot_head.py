@@ -709,6 +709,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
         self.map_encoding = "auto"                       # "bf16": plain bf16 tensors for the bf16 policy (see _map_form)
         if isinstance(other_config, dict) and other_config.get("map_dtype") is not None:
             self.set_map_dtype(other_config["map_dtype"])
+        self._cfg_precision = other_config.get("precision") if isinstance(other_config, dict) else None   # applied once the stages exist
         self.trans_in_dim = trans_in_dim
         self.apply_temporal_query_atten_stages = apply_temporal_query_atten_stages
         self.other_config = other_config
@@ -737,6 +738,8 @@ class MultiScaleDynamicMaskHead(nn.Module):
             self.bias_value = -math.log((1 - prior_prob) / prior_prob)
         self.precision = "bf16"
         self._reset_parameters()
+        if self._cfg_precision is not None:              # a config selects the mode with other_config=dict(precision="fp16x2")
+            self.set_precision(self._cfg_precision)
 
     def set_precision(self, mode):
         """"bf16" (default): bf16 storage of the pixel-side tensors, matrix-core kernels. "fp32": exact mode - fp32 storage and

@@ -254,3 +254,52 @@ def test_fp16x2_through_the_clip_runner(cuda):
     assert torch.isfinite(out["slot_embeds"]).all() and out["slot_argmax"].dtype == torch.uint8
     am = out["mask_logits"].argmax(dim=1)
     assert (am == out["slot_argmax"].long()).float().mean().item() >= 0.999
+
+
+def test_fp16x2_through_the_whole_detector(cuda):
+    """The detector of configs/r50_fpn_slotvps_mi355x.py with the head in the matrix-core reference-precision mode (selectable from a
+    config: dynamic_mask_head other_config=dict(precision="fp16x2")) against the same detector in the exact mode (fp32 on the vector ALU):
+    trunk, slot head, decode of the kept slots from the hi / lo planes, clip-level post-process, tracker. Both modes sit within fp32
+    rounding of the reference's arithmetic, so with the same weights and images the panoptic ids agree on (almost) every pixel."""
+    import torch
+    from util import ROOT
+    from slotvps_amd.config import Config
+    from slotvps_amd.registry import build_detector
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "r50_fpn_slotvps_mi355x.py"))
+    outs = {}
+    for mode in ("fp32", "fp16x2"):
+        torch.manual_seed(1)
+        det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(cuda).eval()
+        det.image_model.dynamic_mask_head.set_precision(mode)
+        T, H, W = 2, 256, 512
+        imgs = torch.randn(T, 3, H, W, device=cuda, generator=torch.Generator(device=cuda).manual_seed(2))
+        ncls = det.image_model.dynamic_mask_head.num_classes
+        table = torch.zeros(100, ncls, device=cuda)
+        table[torch.arange(100), torch.arange(100) % (ncls - 1)] = 12.0
+        with torch.no_grad():
+            det.image_model.fg_bn.weight.fill_(40.0)
+        base = det.head_path
+        det.head_path = lambda f, base=base, table=table: (lambda lg, em, mk: (lg + table, em, mk))(*base(f))
+        metas = [dict(iid=100001 + t, ori_shape=(H, W, 3), img_shape=(H, W, 3), filename=f"f{t}.png") for t in range(T)]
+        outs[mode] = det.clip_test(imgs, metas)
+        assert len(outs[mode]) == T and all(r["panoptic_outputs"].shape == (1, H, W) for r in outs[mode])
+    same = np.mean([(a["panoptic_outputs"] == b["panoptic_outputs"]).float().mean().item() for a, b in zip(outs["fp32"], outs["fp16x2"])])
+    print(f"\npanoptic ids of the whole detector, fp16x2 against the exact mode: equal on {100 * same:.3f} % of the pixels")
+    assert [len(r["panoptic_cls_inds"]) for r in outs["fp32"]] == [len(r["panoptic_cls_inds"]) for r in outs["fp16x2"]]
+    assert same >= 0.995
+
+
+def test_head_config_selects_the_precision():
+    from test_head_gpu import build_head as _bh          # noqa: F401  (the plain constructor path is what is checked here)
+    from slotvps_amd.slot_head import MultiScaleDynamicMaskHead
+    cfg = synth.R50_HEAD_CFG
+    head = MultiScaleDynamicMaskHead(
+        dh_dim=256, num_classes=cfg["num_classes"], dim_feedforward=cfg["dim_feedforward"], nhead=cfg["nhead"], dropout=0.0,
+        activation=cfg["activation"], dh_num_heads=7, per_dh_num_heads=list(cfg["per_dh_num_heads"]), feat_num_levels=4,
+        merge_operation="concat", trans_in_dim=cfg["trans_in_dim"], num_cls=cfg["num_cls"], num_reg=cfg["num_reg"],
+        temporal_query_attention_config=dict(d_model=256, dim_feedforward=cfg["temporal_dim_feedforward"], dropout=0.0,
+                                             activation=cfg["temporal_activation"], softmax_dim="slots", drop_path=0.),
+        apply_temporal_query_atten_stages=list(cfg["apply_temporal_query_atten_stages"]), other_config=dict(precision="fp16x2"))
+    assert head.precision == "fp16x2" and all(m.precision == "fp16x2" for m in head.modules() if hasattr(m, "precision"))
+    with pytest.raises(ValueError):
+        head.set_precision("fp8")
