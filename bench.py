@@ -582,7 +582,7 @@ def main():
             per[name] = e
         # the matrix pipe's SUSTAINED rate on this part (a stored probe result, like the PMC traffic): executed matrix work against it
         sustain = None
-        sfile = os.path.join(ROOT, "profiles", "r03", "mfma_sustain.json")
+        sfile = os.path.join(ROOT, "profiles", "r03", "mfma_sustain.json")     # (a property of the part: the round-3 probe result stands)
         if os.path.exists(sfile):
             with open(sfile) as fh:
                 sustain = json.load(fh)
@@ -593,15 +593,18 @@ def main():
         d = per[dom]
         hbm = d["bound"] == "hbm"
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
         wkey = f"{a.height}x{a.width} T={a.frames} L={a.slots} cpl={cpl}"
-        if os.path.exists(pmc):
+        for rnd in ("r04", "r03"):                       # the newest stored PMC collection whose workload matches
+            pmc = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+            if not os.path.exists(pmc):
+                continue
             with open(pmc) as fh:
                 rec = json.load(fh)
             if rec.get("workload_key") == wkey and dom in rec.get("kernels", {}):
                 traffic = int(rec["kernels"][dom]["traffic_bytes_per_launch"])
-                traffic_src = ("from the stored profile profiles/r03/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                traffic_src = (f"from the stored profile profiles/{rnd}/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                                f"separate passes, calibrated on a known-bytes copy in the same pass; bench {rec.get('bench_sha', '?')}), not measured in this run")
+                break
         # measured on-box ceilings next to the vendor peak: 1 GiB device-to-device, bytes read + written, (a) the
         # runtime's copy, (b) the library's own 16-B-per-lane streaming kernel (also the calibration kernel of the PMC passes)
         src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
