@@ -42,8 +42,11 @@ struct FuseHlLds {
     static constexpr int o_hi = 2 * kTilePx * kHlRowBytes;          // [32][256] fp16 out tiles
     static constexpr int o_lo = o_hi + kTileBytes;
     static constexpr int o_f32 = o_lo + kTileBytes;                 // [32][256] fp32 copy (rows of 1 KiB, 16-B chunks swizzled)
-    static constexpr int total = o_f32 + 2 * kTileBytes;
+    static constexpr int gtile = o_f32 + 2 * kTileBytes;            // staged taps of g: [2 source rows][18 source columns][1 KiB + 16]
+    static constexpr int kGCols = 18, kGRow = 1024 + 16;            // (padded: the lanes of a wave read different columns at the same channel)
+    static constexpr int total = gtile + 2 * kGCols * kGRow;
 };
+static_assert(FuseHlLds::total <= 160 * 1024, "LDS layout");
 
 __device__ __forceinline__ int hl_a_off(int row, int chunk) {       // chunk 0 .. 15
     return row * kHlRowBytes + ((chunk ^ swz(row)) * 16);
@@ -57,7 +60,10 @@ __device__ __forceinline__ void hl_split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
-template <bool TAPS, bool F32OUT>
+// STAGED (TAPS, W % 32 == 0: a tile is 32 pixels of ONE output row): the two source rows x <= 18 source columns of g the tile blends arrive
+// as whole 1-KiB rows (36 coalesced wave loads per tile instead of 16 loads per LANE that each touch 64 sectors - those were 46 % of
+// the kernel), one tile ahead through 20 registers, and every lane reads its four taps from LDS.
+template <bool TAPS, bool F32OUT, bool STAGED = false>
 __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     const float* __restrict__ cur,            // [T, 128, H, W] fp32 (NCHW, the reference's layout)
     const float* __restrict__ gprev,          // TAPS: [T, (H/2)*(W/2), 256] fp32 = f_{i-1} W_a^T, pixel-major
@@ -155,14 +161,60 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
         }
     };
 
+    // STAGED: wave w stages items w, w + 8, .. (< 36) of the tile's [2 rows][18 columns] of g: one 1-KiB row per wave instruction
+    f32x4 gt[5];
+    auto fetch_g = [&](int tile) {
+        const int px0 = px_begin + tile * kTilePx;         // first pixel of the tile: x0 % 32 == 0, one output row
+        const int y = px0 / W, x0 = px0 - y * W;
+        const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int y0 = (int)sy, y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1;
+        const int c_lo = x0 / 2 - 1 > 0 ? x0 / 2 - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int item = w + 8 * i;                    // 0 .. 35 (row = item / 18, column = item % 18); wave-uniform
+            if (item < 2 * Lds::kGCols) {
+                const int row = item / Lds::kGCols;
+                int col = c_lo + (item - row * Lds::kGCols);
+                col = col < Wp ? col : Wp - 1;
+                gt[i] = *reinterpret_cast<const f32x4*>(gprev + ((size_t)t * Hp * Wp + (size_t)(row ? y1 : y0) * Wp + col) * kD + 4 * lane);
+            }
+        }
+    };
+    auto commit_g = [&]() {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int item = w + 8 * i;
+            if (item < 2 * Lds::kGCols) *reinterpret_cast<f32x4*>(smem + Lds::gtile + item * Lds::kGRow + 16 * lane) = gt[i];
+        }
+    };
     fetch(0);
     commit();
+    if constexpr (STAGED) { fetch_g(0); commit_g(); }
     for (int it = 0; it < nt; ++it) {
         __syncthreads();                                   // operand tile `it` complete; out tiles of it-1 have been read
         // ---- this lane's taps of g (its accumulator entries: pixel r, channels 32 w + 8 g + 4 h + j), requested before the MFMAs
         f32x4 tp[4][4];                                    // [tap][g]
         float h1 = 0.f, w1 = 0.f;
-        if constexpr (TAPS) {
+        if constexpr (TAPS && STAGED) {
+            const int px0 = px_begin + it * kTilePx;
+            const int y = px0 / W, x = px0 - y * W + r;
+            const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int y0 = (int)sy, xs0 = (int)sx;
+            const int xs1 = xs0 + 1 < Wp ? xs0 + 1 : Wp - 1;
+            h1 = sy - (float)y0;
+            w1 = sx - (float)xs0;
+            const int c_lo = (px0 - y * W) / 2 - 1 > 0 ? (px0 - y * W) / 2 - 1 : 0;
+            const char* g0 = smem + Lds::gtile + (32 * w + 4 * h) * 4;
+            const char* a00 = g0 + (xs0 - c_lo) * Lds::kGRow, * a01 = g0 + (xs1 - c_lo) * Lds::kGRow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                tp[0][g] = *reinterpret_cast<const f32x4*>(a00 + 32 * g);
+                tp[1][g] = *reinterpret_cast<const f32x4*>(a01 + 32 * g);
+                tp[2][g] = *reinterpret_cast<const f32x4*>(a00 + Lds::kGCols * Lds::kGRow + 32 * g);
+                tp[3][g] = *reinterpret_cast<const f32x4*>(a01 + Lds::kGCols * Lds::kGRow + 32 * g);
+            }
+            if (it + 1 < nt) fetch_g(it + 1);              // the next tile's rows of g fly under the MFMAs
+        } else if constexpr (TAPS) {
             int pp = px_begin + it * kTilePx + r;
             pp = pp < HW ? pp : HW - 1;
             const int y = pp / W, x = pp - y * W;
@@ -221,8 +273,11 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             *reinterpret_cast<f16x4*>(smem + Lds::o_lo + o) = ol;
             if constexpr (F32OUT) *reinterpret_cast<f32x4*>(smem + Lds::o_f32 + r * 1024 + (((ch0 >> 2) ^ (r & 15)) * 16)) = of;
         }
-        __syncthreads();                                   // out tiles complete; every wave is done reading operand tile `it`
-        if (it + 1 < nt) commit();                         // operand tile it+1 (its loads were issued before the MFMAs)
+        __syncthreads();                                   // out tiles complete; every wave is done reading operand tile `it` (and its taps)
+        if (it + 1 < nt) {
+            commit();                                      // operand tile it+1 (its loads were issued before the MFMAs)
+            if constexpr (STAGED) commit_g();
+        }
         store_out(it);
     }
 }
@@ -250,9 +305,10 @@ extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, cons
     hipError_t e = hipSuccess;
 #define SVPS_LFH(TAPS, F32)                                                                                                        \
     do {                                                                                                                           \
-        auto kern = svps::level_fuse_hl_kernel<TAPS, F32>;                                                                         \
-        static SvpsLdsAttr attr;                                                                                                   \
-        if ((e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;                              \
+        const bool staged = TAPS && (W & 31) == 0;          /* a tile = 32 pixels of one output row: taps through LDS */           \
+        auto kern = staged ? svps::level_fuse_hl_kernel<TAPS, F32, TAPS> : svps::level_fuse_hl_kernel<TAPS, F32, false>;          \
+        static SvpsLdsAttr attr[2];                                                                                                \
+        if ((e = attr[staged ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;             \
         hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, cur, gprev, static_cast<const H16*>(wb_hi),              \
                            static_cast<const H16*>(wb_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), out_f32, H, W, tpc); \
     } while (0)

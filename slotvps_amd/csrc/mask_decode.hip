@@ -38,7 +38,7 @@ struct DecLds {
 // svps_level_fuse_hl_fwd); both planes of a tile are staged, the norm runs on hi + lo in fp32 and the logits take three MFMAs per
 // k-step: e_hi f_hi + e_lo f_hi + e_hi f_lo (e . scale as fp16 hi + lo).
 template <int NW, int NST, bool ARGMAX, typename OutT, typename MT = __bf16, bool HL = false>
-__global__ __launch_bounds__(NW * 64) void mask_decode_kernel(
+__global__ __launch_bounds__(NW * 64, (HL && NW == 4) ? 2 : 1) void mask_decode_kernel(
     const MT* __restrict__ feat,     // [T, HW, 256]
     const float* __restrict__ embed,     // [T, L, 256]
     const float* __restrict__ bn_scale,  // [256]
@@ -869,8 +869,10 @@ extern "C" int svps_mask_decode_hl_fwd(const void* feat_hi, const void* feat_lo,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using H = _Float16;
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 0, stream);
-#define SVPS_HL(W, AM) launch_decode<W, 4, AM, float, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)
-    const hipError_t e = L <= 128 ? (slot_argmax ? SVPS_HL(4, true) : SVPS_HL(4, false)) : (slot_argmax ? SVPS_HL(8, true) : SVPS_HL(8, false));
+    // L <= 128: four waves, two feature tiles per plane in flight, TWO workgroups per CU (2 x 68 KiB of LDS, 256 registers): this first-generation
+    // kernel waits for each tile (hipcc drains its builtin LDS-DMA before the next LDS read), so a second workgroup is what hides the latency
+#define SVPS_HL(W, NS, AM) launch_decode<W, NS, AM, float, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)
+    const hipError_t e = L <= 128 ? (slot_argmax ? SVPS_HL(4, 2, true) : SVPS_HL(4, 2, false)) : (slot_argmax ? SVPS_HL(8, 4, true) : SVPS_HL(8, 4, false));
 #undef SVPS_HL
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
     return (int)e;

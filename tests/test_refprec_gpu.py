@@ -41,7 +41,8 @@ def test_split_hl_is_22_bits(cuda):
     assert bool((err <= x.double().abs() * 2.0 ** -21 + 6e-8).all())
 
 
-@pytest.mark.parametrize("T,H,W,lvl0", [(2, 8, 16, True), (1, 6, 10, False), (2, 34, 60, False), (3, 16, 64, False), (1, 2, 4, True)])
+@pytest.mark.parametrize("T,H,W,lvl0", [(2, 8, 16, True), (1, 6, 10, False), (2, 34, 60, False), (3, 16, 64, False), (1, 2, 4, True),
+                                        (1, 4, 32, False), (2, 10, 96, False), (1, 64, 128, False)])     # W % 32 == 0: taps staged through LDS
 def test_level_fuse_hl(cuda, T, H, W, lvl0):
     """K4-HL (f = up(prev W_a^T) + W_b x + b: the coarse product on K8, the rest in csrc/level_fuse_hl.hip) against a float64 evaluation of
     dynamic_mask_head.py:171-188 in the REFERENCE's order (conv of the concatenated, upsampled map) on identical fp32 inputs."""

@@ -10,7 +10,7 @@ from slotvps_amd.config import Config
 from slotvps_amd.registry import build_detector
 
 dev = torch.device("cuda:0")
-cfg = Config.fromfile(os.path.join(ROOT, "configs", "r50_fpn_slotvps_mi355x.py"))
+cfg = Config.fromfile(os.path.join(ROOT, "configs", (sys.argv[1] if len(sys.argv) > 1 else "r50_fpn_slotvps_mi355x") + ".py"))
 torch.manual_seed(0)
 det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
 det.use_graph = True
@@ -47,4 +47,4 @@ with torch.no_grad():
     for _ in range(10):
         for k, v in once().items():
             acc[k] = acc.get(k, 0.0) + v
-print(json.dumps({k: round(v / 10 * 1e3, 3) for k, v in acc.items()} | {"fcn_shape": list(fcn.shape)}))
+print(json.dumps({k: round(v / 10 * 1e3, 3) for k, v in acc.items()} | {"fcn_shape": list(fcn.shape), "config": cfg.filename if hasattr(cfg, "filename") else ""}))
