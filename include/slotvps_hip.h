@@ -415,7 +415,9 @@ int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, co
  *   svps_retr_stats_hl_fwd   = svps_retr_stats_tight_fwd (:432-433, the two LayerNorm statistics) on the planes, both projections from
  *                              ONE read (slotvps_amd/csrc/retr_stats_hl.hip); same aux rows. The fp32 tables come in ACCUMULATOR order
  *                              (column 32 B + 16 h + 4 g + j = factor row 32 B + 8 g + 4 h + j): tyk [ty_rows, 256] = Ty + r_k, txk
- *                              [tx_rows, 256] = Tx (ty_rows = H or 1, tx_rows = W or 1: no position term), rbv [256] = r_v
+ *                              [tx_rows, 256] = Tx (ty_rows = H or 1, tx_rows = W or 1: no position term), rbv [256] = r_v; tx_tiled
+ *                              (W % 32 == 0): txk re-ordered to [W / 32][8 B][4 g][2 h][32 pixels][4 j], so that a wave's load for the
+ *                              32 pixels of a tile is one contiguous KiB
  *   svps_retr_attn_hl_fwd    = svps_retr_attn_tight_fwd (:435-456) on the planes, L <= 128; tiles of 16 pixels (hi rows + lo rows of
  *                              the same pixels share one LDS tile); workspace svps_retr_attn_hl_workspace_bytes()
  *   svps_mask_decode_hl_fwd  = svps_mask_decode_fwd (vps_temporal_slots.py:144-160) on the planes: fp32 logits [T, L, HW] (required),
@@ -424,7 +426,7 @@ int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, co
  * ------------------------------------------------------------------------------------------- */
 int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
                            void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream);
-int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* tyk, int ty_rows, const float* txk, int tx_rows,
+int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* tyk, int ty_rows, const float* txk, int tx_rows, int tx_tiled,
                            const void* rk_hi, const void* rk_lo, float lnk_eps, const void* rv_hi, const void* rv_lo,
                            const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D, void* stream);
 size_t svps_retr_attn_hl_workspace_bytes(int T, int L, int H, int W, int chunks);

@@ -205,14 +205,14 @@ class SlotClipRunner:
         if getattr(self.head, "precision", "bf16") == "fp16x2":
             # reference precision on the matrix cores: the maps are 1 KiB per pixel (fp16 hi + lo planes). Algorithmic flops = one product
             # per multiply; executed = the MFMAs issued (three per product in K4 / K3t / K2; K1'-HL: 4 x 32 producer + 4 x 26 consumer per
-            # 16-pixel tile). K3t reads the map once per projection (two launches per stage).
+            # 16-pixel tile). K3-HL reads both planes once per stage; K4-HL: the fine part K = 128 (the 256-wide coarse product runs on K8).
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
             return {
-                "level_fuse": {"bytes": T * sum(hw * (512 + 1024 + (256 if i else 0)) for i, hw in enumerate(px)), "flops": T * sum(px) * 2 * 384 * D,
-                               "executed_flops": T * sum(px) * 3 * 2 * 384 * D},
+                "level_fuse": {"bytes": T * sum(hw * (512 + 1024 + (256 if i else 0) + (1024 if i < len(px) - 1 else 0)) for i, hw in enumerate(px)),
+                               "flops": T * sum(px) * 2 * 384 * D, "executed_flops": T * sum(px) * 3 * 2 * 128 * D},
                 "mask_decode": {"bytes": T * px[-1] * (1024 + 4 * L + 1), "flops": T * px[-1] * 2 * L * D,
                                 "executed_flops": T * px[-1] * ((4 if L <= 128 else 8) * 48 * 32768 // 32)},
-                "retr_stats": {"bytes": T * ps * (2 * 1024 + 16), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D),
+                "retr_stats": {"bytes": T * ps * (1024 + 16), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D),
                                "executed_flops": T * ps * 3 * int(2 * 36 / 64 * 2 * D * D)},
                 "retr_attn": {"bytes": T * (ps * (1024 + 16) + stages * (L * D * 4 + L * 260 * 4) + tabs), "flops": T * ps * 4 * L * D,
                               "executed_flops": T * ps * ((4 * 32 + 4 * 26) * 32768 // 16)},

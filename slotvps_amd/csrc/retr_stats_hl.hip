@@ -7,13 +7,23 @@
 //
 // The first form of this path (retr_stats_t.hip's HL template: one launch per projection, register-staged tiles one ahead) read the
 // planes twice and had ONE tile in flight per CU: 41.6 ms of a 160-frame step, 2.7 TB/s - the latency of a tile's loads, not a resource.
-// Here: four waves of 512 registers (one per SIMD). Wave j holds row blocks j and 7 - j (R is upper triangular: 18 k-steps together) of
-// ALL FOUR factor matrices (key / value x hi / lo: 288 registers) and runs the key chain, then the value chain, on the same staged tile
-// (54 + 54 MFMAs per tile); tiles are fetched TWO ahead through registers (plain loads, compiler-counted waits) into a double-buffered
-// padded LDS tile pair. The position term of the key statistics and the constant columns r arrive as fp32 tables in ACCUMULATOR order
-// (the host permutes the 256 columns so that a lane's 16 values of a row block are 64 contiguous bytes): Ty' [H, 256] = Ty + r_k,
-// Tx' [W, 256], r_v' [256]. One barrier per tile; wave 0 finishes the previous tile from the four waves' sums and writes the whole
-// 16-byte aux rows of retr_stats.hip: {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32)}.
+// The second (four waves of 512 registers, all four factor matrices per wave, both chains in turn): 31 ms - its timing-only ablations
+// (SVPS_SHL_ABL) showed the parts of a lone in-order wave ADDING UP: matrix chain 1 160 us + position tables 620 + tile loads 515 + rest 420
+// of 2 790 at the finest level (T = 40). This form (22.7 ms): EIGHT waves, wave (projection, quarter j) holds row blocks j and 7 - j (R is
+// upper triangular: 18 k-steps together) of ITS projection's factor as hi and lo A fragments (144 registers) and runs one chain of 54
+// MFMAs per tile on the staged hi / lo planes. The key and the value wave of a quarter share a SIMD and work in PING-PONG (two barriers
+// per tile, the schedule of retr_stats.hip): while one runs its chain the other does its light work - start values, DMA requests, the
+// finish - so the matrix pipe is never shared and (s_memtime stamps, `make stampshl`, tools/shl_stamps.py) both half-periods are
+// ~2 400 cycles of chain (54 MFMAs with LDS operands: 36 cycles each + the sums of squares) beside 1 600 - 2 500 of light work.
+//   * tiles arrive by LDS-DMA (asm, two tiles ahead, ring of three, the chunk swizzle of common.h): the key waves bring the hi plane, the
+//     value waves the lo plane; no staging registers, no LDS writes. A wave's requests are older than the start-value loads of its next
+//     light phase, whose wait (vmcnt retires in order) covers them half a period before the tile is read.
+//   * the position term of the key statistics and the constant columns r arrive as fp32 tables in ACCUMULATOR order (the host permutes
+//     the 256 columns so that a lane's 16 values of a row block are contiguous; for W % 32 == 0 also TILED, so that a wave's load is one
+//     contiguous KiB): Ty' [H, 256] = Ty + r_k, Tx' [W, 256], r_v' [256]. All sixteen loads of a key wave are ONE round trip (the Ty'
+//     values land in the accumulators themselves; two fenced groups were 2 x 1 500 cycles of L2 latency on the critical path).
+//   * wave (value, 0) finishes the previous tile from the eight waves' sums and writes the whole 16-byte aux rows of retr_stats.hip:
+//     {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32)}.
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -23,15 +33,52 @@
 
 namespace svps {
 
+#ifdef SVPS_SHL_STAMP
+// diagnostic build only (tools/shl_stamps.py): s_memtime stamps of the key and the value wave of quarter 0 of one workgroup, tiles 8 .. 15
+__device__ unsigned long long shl_stamps[2][8][8];           // [key / value][tile - 8][point]
+#define SHL_STAMP(pt)                                                                                         \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && J == 0 && tile - tile0 >= 8 && tile - tile0 < 16 && lane == 0) \
+            shl_stamps[KEY ? 0 : 1][tile - tile0 - 8][pt] = __builtin_amdgcn_s_memtime();                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+#else
+#define SHL_STAMP(pt) do {} while (0)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) _Float16 sh_f16x8;
 
-constexpr int kShRow = 256 * 2 + 16;                 // staged pixel row: 256 fp16 + pad (conflict-free 16-byte fragment reads)
 struct StatsHlLds {
-    static constexpr int plane = kTilePx * kShRow;   // one plane of one tile
-    static constexpr int xt = 0;                     // [2 buffers][hi, lo][32 px][528 B]
-    static constexpr int part = 4 * plane;           // [2 buffers][key, value][4 waves][32 px] float
+    static constexpr int kSlots = 3;                 // tile ring: tile t in work, t + 1 landed, t + 2 in flight
+    static constexpr int plane = kTileBytes;         // one plane of one tile: 32 pixel rows of 512 B, 16-byte chunks swizzled (common.h)
+    static constexpr int xt = 0;                     // [3 slots][hi, lo][16 KiB]
+    static constexpr int part = kSlots * 2 * plane;  // [2 buffers][key, value][4 waves][32 px] float
     static constexpr int total = part + 2 * 2 * 4 * 32 * 4;
 };
+
+// asm LDS-DMA (invisible to hipcc's wait counting: the builtin form is drained with s_waitcnt vmcnt(0) before the next LDS read)
+__device__ __forceinline__ u32x4 shl_make_srd(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    u32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+    d[2] = __builtin_amdgcn_readfirstlane(bytes);
+    d[3] = 0x00020000u;
+    return d;
+}
+__device__ __forceinline__ void shl_dma16(u32x4 srd, uint32_t lds_addr, int voff, int soff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
+        : "memory");
+}
 
 struct StatsHlArgs {
     const _Float16* f_hi;      // [T, HW, 256]
@@ -46,64 +93,59 @@ struct StatsHlArgs {
     _Float16* aux;             // [T, HW, 8]
     float eps_k, eps_v;
     int HW, W, ty_rows, tx_rows, tiles_per_wg;
+    int tx_tiled;              // txk is in the TILED order [W / 32][8 row blocks][4 g][2 h][32 pixels][4] (W % 32 == 0): a wave's load of
+                               // (row block, g) for the 32 pixels of a tile is one contiguous KiB instead of 64 separate sectors
 };
 
 // accumulator order: column 32 RB + 16 h + 4 g + j of a table row <-> factor row 32 RB + 8 g + 4 h + j (register 4 g + j of lane half h)
-template <int J>
+// One wave = (projection KEY / value, quarter J): row blocks J and 7 - J of that projection's factor, hi and lo (144 registers).
+template <int J, bool KEY>
 __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, int lane) {
     constexpr int KA = 2 * J, NA = 16 - KA;          // row block J: k-steps KA .. 15
     constexpr int KB = 14 - 2 * J, NB = 16 - KB;     // row block 7 - J: k-steps KB .. 15
     constexpr int RBA = J, RBB = 7 - J;
+    constexpr int K0 = KA < KB ? KA : KB;
     const int r = lane & 31, h = lane >> 5;
     const int t = blockIdx.y;
-    const int tid = threadIdx.x;                     // 0 .. 255
-    sh_f16x8 kha[NA], kla[NA], khb[NB], klb[NB], vha[NA], vla[NA], vhb[NB], vlb[NB];
+    sh_f16x8 wha[NA], wla[NA], whb[NB], wlb[NB];
     {
+        const _Float16* rh = KEY ? a.rk_hi : a.rv_hi;
+        const _Float16* rl = KEY ? a.rk_lo : a.rv_lo;
         const size_t ra = (size_t)(32 * RBA + r) * 256 + 8 * h, rb = (size_t)(32 * RBB + r) * 256 + 8 * h;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            kha[i] = *reinterpret_cast<const sh_f16x8*>(a.rk_hi + ra + 16 * (KA + i));
-            kla[i] = *reinterpret_cast<const sh_f16x8*>(a.rk_lo + ra + 16 * (KA + i));
-            vha[i] = *reinterpret_cast<const sh_f16x8*>(a.rv_hi + ra + 16 * (KA + i));
-            vla[i] = *reinterpret_cast<const sh_f16x8*>(a.rv_lo + ra + 16 * (KA + i));
+            wha[i] = *reinterpret_cast<const sh_f16x8*>(rh + ra + 16 * (KA + i));
+            wla[i] = *reinterpret_cast<const sh_f16x8*>(rl + ra + 16 * (KA + i));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            khb[i] = *reinterpret_cast<const sh_f16x8*>(a.rk_hi + rb + 16 * (KB + i));
-            klb[i] = *reinterpret_cast<const sh_f16x8*>(a.rk_lo + rb + 16 * (KB + i));
-            vhb[i] = *reinterpret_cast<const sh_f16x8*>(a.rv_hi + rb + 16 * (KB + i));
-            vlb[i] = *reinterpret_cast<const sh_f16x8*>(a.rv_lo + rb + 16 * (KB + i));
+            whb[i] = *reinterpret_cast<const sh_f16x8*>(rh + rb + 16 * (KB + i));
+            wlb[i] = *reinterpret_cast<const sh_f16x8*>(rl + rb + 16 * (KB + i));
         }
     }
     const int tiles = (a.HW + kTilePx - 1) / kTilePx;
     const int tile0 = blockIdx.x * a.tiles_per_wg;
     int tile1 = tile0 + a.tiles_per_wg;
     tile1 = tile1 < tiles ? tile1 : tiles;
-    const _Float16* FH = a.f_hi + (size_t)t * a.HW * 256;
-    const _Float16* FL = a.f_lo + (size_t)t * a.HW * 256;
     float* part = reinterpret_cast<float*>(smem + StatsHlLds::part);
-    // staging: thread -> (pixel tid >> 3, 64 bytes = 32 channels) of both planes
-    const int spx = tid >> 3, sc = tid & 7;
-    struct Pre { u32x4 h[4], l[4]; };
-    auto fetch = [&](int tile, Pre& p) {
-        int gp = tile * kTilePx + spx;
-        gp = gp < a.HW ? gp : a.HW - 1;              // ragged last tile / past the chunk: a valid pixel (not stored)
-        const size_t o = (size_t)gp * 256 + 32 * sc;
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+    // staging by LDS-DMA: the key waves bring the hi plane of a tile, the value waves the lo plane - wave quarter J rows 8 J .. 8 J + 7
+    // (four 1-KiB pieces of two pixel rows); no registers, no LDS writes, requested two tiles ahead in a ring of three
+    const u32x4 srd = shl_make_srd((KEY ? a.f_hi : a.f_lo) + (size_t)t * a.HW * 256, (uint32_t)a.HW * (uint32_t)kRowBytes);
+    int voff[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            p.h[i] = *reinterpret_cast<const u32x4*>(FH + o + 8 * i);
-            p.l[i] = *reinterpret_cast<const u32x4*>(FL + o + 8 * i);
-        }
-    };
-    auto stage = [&](int buf, const Pre& p) {
-        char* dst = smem + StatsHlLds::xt + buf * 2 * StatsHlLds::plane + spx * kShRow + 64 * sc;
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * J + 2 * i + h;
+        voff[i] = row * kRowBytes + ((r ^ swz(row)) * 16);      // (rows past the end of the frame: out of range, read as zeros)
+    }
+    auto request = [&](int tile) {
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + StatsHlLds::xt + ((tile - tile0) % 3) * 2 * StatsHlLds::plane +
+                                                            (KEY ? 0 : StatsHlLds::plane) + J * 4096);
+        const int soff = __builtin_amdgcn_readfirstlane(tile * kTileBytes);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<u32x4*>(dst + 16 * i) = p.h[i];
-            *reinterpret_cast<u32x4*>(dst + StatsHlLds::plane + 16 * i) = p.l[i];
-        }
+        for (int i = 0; i < 4; ++i) shl_dma16(srd, dst + i * 1024, voff[i], soff);
     };
-    // wave 0, lanes h == 0: the tile's 32 aux rows from the four waves' sums (one 16-byte store per pixel: whole rows)
+    // wave (key, 0), lanes h == 0: the tile's 32 aux rows from the eight waves' sums (one 16-byte store per pixel: whole rows)
     auto finish = [&](int tile) {
         const int cur = (tile - tile0) & 1;
         float tk = 0.f, tv = 0.f;
@@ -126,7 +168,6 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
         const int gp = tile * kTilePx + r;
         if (h == 0 && gp < a.HW) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.aux) + ((size_t)t * a.HW + gp) * 16) = row;
     };
-    // one chain: 32 factor rows x 32 pixels, k-steps K0 .. 15, accumulator started from `c` (the constant column / position terms)
     auto sumsq = [&](const f32x16& acc) {
         float s = 0.f;
 #pragma unroll
@@ -134,142 +175,160 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
         return s;
     };
 
-    Pre p0, p1;
-    fetch(tile0, p0);
-    stage(0, p0);
-    if (tile0 + 1 < tile1) fetch(tile0 + 1, p1);
-    __syncthreads();
-    auto body = [&](int tile, Pre& pn, Pre& pf) {     // pn: holds tile + 1 (staged at the end); pf: receives tile + 2
-        const int cur = (tile - tile0) & 1;
-        const int px0 = tile * kTilePx;
-        // The key chains start from Ty' + Tx' of the lane's pixel (L2-resident tables, 16 loads): requested here, consumed behind the value
-        // chain. Timing-only ablations (SVPS_SHL_ABL, finest level, T = 40: 2 790 us): without these loads 2 165, without the MFMAs 1 557,
-        // without the tile loads 2 274, without both 1 177 - the parts ADD UP (one in-order wave per SIMD: nothing overlaps), and moving the
-        // tables' use behind 54 MFMAs changed nothing (2 820): what they cost is the ISSUE of sixteen 64-sector loads, not their latency.
-        // The next step for this kernel is a column-strip tile order (Tx' constant per strip: eight of the sixteen loads disappear).
-        int gp = px0 + r;
-        gp = gp < a.HW ? gp : a.HW - 1;
-        const int y = gp / a.W, x = gp - y * a.W;
-        const float* tyr = a.tyk + (size_t)(y < a.ty_rows ? y : a.ty_rows - 1) * 256 + 16 * h;
-        const float* txr = a.txk + (size_t)(x < a.tx_rows ? x : a.tx_rows - 1) * 256 + 16 * h;
-        f32x4 ya[4], xa[4], yb[4], xb[4];
+    // start values of the two chains of `tile`: the key waves' Ty' + Tx' rows of the lane's pixel (L2-resident tables: 16 loads whose ISSUE
+    // costs ~1 000 cycles), the value waves' constant column r_v
+    f32x16 ca, cb;
+    auto start_values = [&](int tile) {
+        if constexpr (KEY) {
+            int gp = tile * kTilePx + r;
+            gp = gp < a.HW ? gp : a.HW - 1;
+            const int y = gp / a.W, x = gp - y * a.W;
+            const float* tyr = a.tyk + (size_t)(y < a.ty_rows ? y : a.ty_rows - 1) * 256 + 16 * h;
+            // plain order: row x, columns 32 RB + 16 h + 4 g (+ j); tiled order: [x / 32][RB][g][h][x % 32][j] -> the same expression
+            // `txr + 32 * RB + 4 * g` below with strides (sb, sg) = (32, 4) resp. (1024, 256) floats
+            const int sb = a.tx_tiled ? 1024 : 32, sg = a.tx_tiled ? 256 : 4;
+            const float* txr = a.tx_tiled ? a.txk + (size_t)(x >> 5) * 8192 + (h * 32 + (x & 31)) * 4
+                                          : a.txk + (size_t)(x < a.tx_rows ? x : a.tx_rows - 1) * 256 + 16 * h;
+            // all sixteen loads in ONE round trip (two fenced groups measured 2 x 1 500 cycles of L2 latency on the critical path of the
+            // second half-period): the Ty' values land in the accumulators themselves, only the Tx' values need registers of their own
+            f32x4 xa[4], xb[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < 4; ++g) {
 #if SVPS_SHL_ABL & 1
-            ya[g] = xa[g] = yb[g] = xb[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            (void)tyr; (void)txr;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 ya = z, yb = z;
+                xa[g] = z; xb[g] = z;
+                (void)tyr; (void)txr; (void)sb; (void)sg;
 #else
-            ya[g] = *reinterpret_cast<const f32x4*>(tyr + 32 * RBA + 4 * g);
-            xa[g] = *reinterpret_cast<const f32x4*>(txr + 32 * RBA + 4 * g);
-            yb[g] = *reinterpret_cast<const f32x4*>(tyr + 32 * RBB + 4 * g);
-            xb[g] = *reinterpret_cast<const f32x4*>(txr + 32 * RBB + 4 * g);
+                const f32x4 ya = *reinterpret_cast<const f32x4*>(tyr + 32 * RBA + 4 * g), yb = *reinterpret_cast<const f32x4*>(tyr + 32 * RBB + 4 * g);
+                xa[g] = *reinterpret_cast<const f32x4*>(txr + sb * RBA + sg * g);
+                xb[g] = *reinterpret_cast<const f32x4*>(txr + sb * RBB + sg * g);
 #endif
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ca[4 * g + j] = ya[j];
+                    cb[4 * g + j] = yb[j];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ca[4 * g + j] += xa[g][j];
+                    cb[4 * g + j] += xb[g][j];
+                }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ra_ = *reinterpret_cast<const f32x4*>(a.rbv + 32 * RBA + 16 * h + 4 * g);
+                const f32x4 rb_ = *reinterpret_cast<const f32x4*>(a.rbv + 32 * RBB + 16 * h + 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ca[4 * g + j] = ra_[j];
+                    cb[4 * g + j] = rb_[j];
+                }
+            }
         }
-        const char* xh = smem + StatsHlLds::xt + cur * 2 * StatsHlLds::plane + r * kShRow + 16 * h;
-        const char* xl = xh + StatsHlLds::plane;
-        constexpr int K0 = KA < KB ? KA : KB;
-        // the loads of tile + 2, two at a time between the k-steps of the value chain (a 1-KiB vector-memory instruction holds its wave
-        // for ~100 cycles at issue; spread or in a row measures the same)
-        const bool more2 = tile + 2 < tile1 && !(SVPS_SHL_ABL & 4);
-        int gp2 = (tile + 2) * kTilePx + spx;
-        gp2 = gp2 < a.HW ? gp2 : a.HW - 1;
-        const size_t o2 = (size_t)gp2 * 256 + 32 * sc;
-        // ---- value side first. Fragments one k-step ahead of their MFMAs; the fences keep hipcc from hoisting all sixteen k-steps' reads
-        //      (128 registers the weights leave no room for) to the top of the tile
-        f32x16 va, vb;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 ra_ = *reinterpret_cast<const f32x4*>(a.rbv + 32 * RBA + 16 * h + 4 * g);
-            const f32x4 rb_ = *reinterpret_cast<const f32x4*>(a.rbv + 32 * RBB + 16 * h + 4 * g);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                va[4 * g + j] = ra_[j];
-                vb[4 * g + j] = rb_[j];
-            }
-        }
-        sh_f16x8 fh[2], fl[2];
-        fh[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * K0);
-        fl[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * K0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ks = K0; ks < 16; ++ks) {
-            if (ks + 1 < 16) {
-                fh[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * (ks + 1));
-                fl[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * (ks + 1));
-            }
-            if (ks >= KA && !(SVPS_SHL_ABL & 2)) {
-                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vla[ks - KA], fh[ks & 1], va, 0, 0, 0);
-                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vha[ks - KA], fl[ks & 1], va, 0, 0, 0);
-                va = __builtin_amdgcn_mfma_f32_32x32x16_f16(vha[ks - KA], fh[ks & 1], va, 0, 0, 0);
-            }
-            if (ks >= KB && !(SVPS_SHL_ABL & 2)) {
-                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlb[ks - KB], fh[ks & 1], vb, 0, 0, 0);
-                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhb[ks - KB], fl[ks & 1], vb, 0, 0, 0);
-                vb = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhb[ks - KB], fh[ks & 1], vb, 0, 0, 0);
-            }
-            const int fi = (ks - K0 - 1) / 2;                         // loads of tile + 2: piece fi behind k-steps K0 + 1, + 3, + 5, + 7
-            if (more2 && ks > K0 && ((ks - K0 - 1) & 1) == 0 && fi < 4) {
-                pf.h[fi] = *reinterpret_cast<const u32x4*>(FH + o2 + 8 * fi);
-                pf.l[fi] = *reinterpret_cast<const u32x4*>(FL + o2 + 8 * fi);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const float sv0 = sumsq(va) + sumsq(vb);
-        // ---- key side (the same fragments, read again: the registers hold the weights)
-        f32x16 ka, kb;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ka[4 * g + j] = ya[g][j] + xa[g][j];
-                kb[4 * g + j] = yb[g][j] + xb[g][j];
-            }
-        fh[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * K0);
-        fl[K0 & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * K0);
-#pragma unroll
-        for (int ks = K0; ks < 16; ++ks) {
-            if (ks + 1 < 16) {
-                fh[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xh + 32 * (ks + 1));
-                fl[(ks + 1) & 1] = *reinterpret_cast<const sh_f16x8*>(xl + 32 * (ks + 1));
-            }
-            if (ks >= KA && !(SVPS_SHL_ABL & 2)) {
-                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kla[ks - KA], fh[ks & 1], ka, 0, 0, 0);
-                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kha[ks - KA], fl[ks & 1], ka, 0, 0, 0);
-                ka = __builtin_amdgcn_mfma_f32_32x32x16_f16(kha[ks - KA], fh[ks & 1], ka, 0, 0, 0);
-            }
-            if (ks >= KB && !(SVPS_SHL_ABL & 2)) {
-                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(klb[ks - KB], fh[ks & 1], kb, 0, 0, 0);
-                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(khb[ks - KB], fl[ks & 1], kb, 0, 0, 0);
-                kb = __builtin_amdgcn_mfma_f32_32x32x16_f16(khb[ks - KB], fh[ks & 1], kb, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const float sk0 = sumsq(ka) + sumsq(kb);
-        float sk = sk0, sv = sv0;
-        sk += __shfl_xor(sk, 32);
-        sv += __shfl_xor(sv, 32);
-        if (h == 0) {
-            part[(cur * 2 + 0) * 128 + J * 32 + r] = sk;
-            part[(cur * 2 + 1) * 128 + J * 32 + r] = sv;
-        }
-        if (tile + 1 < tile1) stage(cur ^ 1, pn);
-        __syncthreads();                             // sums of this tile complete; the next tile is staged
-        if (J == 0 && !(SVPS_SHL_ABL & 8)) finish(tile);
     };
-    for (int tile = tile0; tile < tile1; tile += 2) {
-        body(tile, p1, p0);
-        if (tile + 1 < tile1) body(tile + 1, p0, p1);
+    // the chain of `tile` on the staged planes, then this wave's 64 rows' sum of squares per pixel
+    auto heavy = [&](int tile) {
+        const int cur = (tile - tile0) & 1;
+        // this lane's 16-byte chunk of k-step ks in pixel row r: chunk (2 ks + h) ^ swz(r) - one XOR on the lane's base address
+        const uint32_t xh = lds0 + StatsHlLds::xt + ((tile - tile0) % 3) * 2 * StatsHlLds::plane + r * kRowBytes + ((h ^ swz(r)) << 4);
+        const uint32_t xl = xh + StatsHlLds::plane;
+        auto frag = [](uint32_t base, int ks) {
+            return *reinterpret_cast<SVPS_LDS const sh_f16x8*>((uintptr_t)(base ^ ((uint32_t)ks << 5)));
+        };
+        // fragments TWO k-steps ahead of their MFMAs (a k-step of one row block is three MFMAs = 96 cycles, less than an LDS round trip under
+        // load); the fences keep hipcc from hoisting all sixteen k-steps' reads to the top of the tile
+        sh_f16x8 fh[3], fl[3];
+        fh[K0 % 3] = frag(xh, K0);
+        fl[K0 % 3] = frag(xl, K0);
+        if (K0 + 1 < 16) {
+            fh[(K0 + 1) % 3] = frag(xh, K0 + 1);
+            fl[(K0 + 1) % 3] = frag(xl, K0 + 1);
+        }
+#pragma unroll
+        for (int ks = K0; ks < 16; ++ks) {
+            if (ks + 2 < 16) {
+                fh[(ks + 2) % 3] = frag(xh, ks + 2);
+                fl[(ks + 2) % 3] = frag(xl, ks + 2);
+            }
+            if (ks >= KA && !(SVPS_SHL_ABL & 2)) {
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wla[ks - KA], fh[ks % 3], ca, 0, 0, 0);
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fl[ks % 3], ca, 0, 0, 0);
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fh[ks % 3], ca, 0, 0, 0);
+            }
+            if (ks >= KB && !(SVPS_SHL_ABL & 2)) {
+                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlb[ks - KB], fh[ks % 3], cb, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fl[ks % 3], cb, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fh[ks % 3], cb, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float ss = sumsq(ca) + sumsq(cb);
+        ss += __shfl_xor(ss, 32);
+        if (h == 0) part[(cur * 2 + (KEY ? 0 : 1)) * 128 + J * 32 + r] = ss;
+    };
+
+    // PING-PONG (two barriers per tile): in the first half-period the key waves run their chain while the value waves of the same SIMDs
+    // do their light work (start values, the DMA requests of tile + 2, the finish of tile - 1); in the second the roles swap (the key
+    // waves load the position tables of tile + 1 there). One chain at a time per SIMD: the matrix pipe is never shared.
+    // Landing of a tile: a wave's requests for tile + 2 are OLDER than the start-value loads of its next light phase, whose wait
+    // (vmcnt retires in order) therefore covers them - one half-period before the first chain reads the tile; the explicit
+    // s_waitcnt below states it.
+    request(tile0);
+    if (tile0 + 1 < tile1) request(tile0 + 1);
+    if constexpr (KEY) start_values(tile0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int tile = tile0; tile < tile1; ++tile) {
+        SHL_STAMP(0);
+        // ---- first half: key heavy, value light
+        if constexpr (KEY) {
+            heavy(tile);
+        } else {
+            start_values(tile);
+            SHL_STAMP(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of tile + 1 have landed (requested a period ago)
+            if (tile + 2 < tile1 && !(SVPS_SHL_ABL & 4)) request(tile + 2);
+            SHL_STAMP(2);
+            if (J == 0 && tile > tile0 && !(SVPS_SHL_ABL & 8)) finish(tile - 1);
+        }
+        SHL_STAMP(3);
+        __syncthreads();
+        SHL_STAMP(4);
+        // ---- second half: value heavy, key light
+        if constexpr (KEY) {
+            if (tile + 1 < tile1) start_values(tile + 1);
+            SHL_STAMP(5);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of tile + 1 have landed
+            if (tile + 2 < tile1 && !(SVPS_SHL_ABL & 4)) request(tile + 2);
+            SHL_STAMP(6);
+        } else {
+            heavy(tile);
+            SHL_STAMP(5);
+        }
+        SHL_STAMP(7);
+        __syncthreads();                             // tile + 1 is complete in LDS; the sums of `tile` are complete
     }
+    if (!KEY && J == 0 && !(SVPS_SHL_ABL & 8)) finish(tile1 - 1);
 }
 
-__global__ __launch_bounds__(256) void retr_stats_hl_kernel(StatsHlArgs a) {
+__global__ __launch_bounds__(512) void retr_stats_hl_kernel(StatsHlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
+    // waves w and w + 4 share a SIMD: the key and the value wave of one quarter - while one waits (tables, tile loads, sums) the other
+    // has MFMAs to issue
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-        case 0: stats_hl_role<0>(a, smem, lane); break;
-        case 1: stats_hl_role<1>(a, smem, lane); break;
-        case 2: stats_hl_role<2>(a, smem, lane); break;
-        default: stats_hl_role<3>(a, smem, lane); break;
+        case 0: stats_hl_role<0, true>(a, smem, lane); break;
+        case 1: stats_hl_role<1, true>(a, smem, lane); break;
+        case 2: stats_hl_role<2, true>(a, smem, lane); break;
+        case 3: stats_hl_role<3, true>(a, smem, lane); break;
+        case 4: stats_hl_role<0, false>(a, smem, lane); break;
+        case 5: stats_hl_role<1, false>(a, smem, lane); break;
+        case 6: stats_hl_role<2, false>(a, smem, lane); break;
+        default: stats_hl_role<3, false>(a, smem, lane); break;
     }
 }
 
@@ -277,13 +336,14 @@ __global__ __launch_bounds__(256) void retr_stats_hl_kernel(StatsHlArgs a) {
 
 // svps_retr_stats_hl_fwd (include/slotvps_hip.h): tyk [ty_rows, 256] = Ty + r_k, txk [tx_rows, 256] = Tx, rbv [256] - fp32, columns in
 // ACCUMULATOR order (column 32 B + 16 h + 4 g + j = factor row 32 B + 8 g + 4 h + j); ty_rows = H or 1, tx_rows = W or 1 (no position term:
-// one row each, txk zero).
-extern "C" int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* tyk, int ty_rows, const float* txk, int tx_rows,
+// one row each, txk zero). tx_tiled (W % 32 == 0): txk re-ordered to [W / 32][8 B][4 g][2 h][32 pixels][4 j].
+extern "C" int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* tyk, int ty_rows, const float* txk, int tx_rows, int tx_tiled,
                                       const void* rk_hi, const void* rk_lo, float lnk_eps, const void* rv_hi, const void* rv_lo,
                                       const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D, void* stream_) {
     if (!feat_hi || !feat_lo || !tyk || !txk || !rk_hi || !rk_lo || !rv_hi || !rv_lo || !rbv || !aux) return SVPS_ERR_BAD_ARG;
     if (D != svps::kD || T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((ty_rows != H && ty_rows != 1) || (tx_rows != W && tx_rows != 1)) return SVPS_ERR_BAD_SHAPE;
+    if (tx_tiled && (tx_rows != W || (W & 31))) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     const int HW = H * W;
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
@@ -296,9 +356,15 @@ extern "C" int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, 
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(svps::retr_stats_hl_kernel), svps::StatsHlLds::total); ae != hipSuccess) return (int)ae;
     const svps::StatsHlArgs args{static_cast<const H16*>(feat_hi), static_cast<const H16*>(feat_lo), static_cast<const H16*>(rk_hi),
                                  static_cast<const H16*>(rk_lo), static_cast<const H16*>(rv_hi), static_cast<const H16*>(rv_lo), tyk, txk, rbv,
-                                 static_cast<H16*>(aux), lnk_eps, lnv_eps, HW, W, ty_rows, tx_rows, tpw};
+                                 static_cast<H16*>(aux), lnk_eps, lnv_eps, HW, W, ty_rows, tx_rows, tpw, tx_tiled ? 1 : 0};
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
-    hipLaunchKernelGGL(svps::retr_stats_hl_kernel, dim3(chunks, T), dim3(256), svps::StatsHlLds::total, stream, args);
+    hipLaunchKernelGGL(svps::retr_stats_hl_kernel, dim3(chunks, T), dim3(512), svps::StatsHlLds::total, stream, args);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);
     return (int)hipGetLastError();
 }
+
+#ifdef SVPS_SHL_STAMP
+extern "C" int svps_shl_debug_read(unsigned long long* stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::shl_stamps), sizeof(unsigned long long) * 2 * 8 * 8);
+}
+#endif

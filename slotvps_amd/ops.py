@@ -784,7 +784,14 @@ def acc_order_perm(device=None):
     return (32 * b + 8 * g + 4 * h + j).reshape(-1).to(device)
 
 
-def retr_stats_hl(feat_hl, H, W, tyk, txk, rk_hi, rk_lo, eps_k, rv_hi, rv_lo, rbv, eps_v):
+def tile_tx_table(txk):
+    """Tx' [W, 256] (accumulator-order columns 32 B + 16 h + 4 g + j), W % 32 == 0 -> the TILED order svps_retr_stats_hl_fwd reads with
+    whole-KiB loads: [W / 32][8 B][4 g][2 h][32 pixels][4 j] (flattened back to [W, 256])."""
+    W = txk.shape[0]
+    return txk.view(W // 32, 32, 8, 2, 4, 4).permute(0, 2, 4, 3, 1, 5).contiguous().view(W, 256)
+
+
+def retr_stats_hl(feat_hl, H, W, tyk, txk, rk_hi, rk_lo, eps_k, rv_hi, rv_lo, rbv, eps_v, tx_tiled=False):
     """Both LayerNorm statistics of the fused retriever from ONE read of a map given as fp16 hi + lo planes [2, T, HW, 256], both factors
     as fp16 hi + lo (csrc/retr_stats_hl.hip): the aux rows [T, HW, 8] of retr_stats. tyk [H or 1, 256] = Ty + r_k, txk [W or 1, 256] = Tx,
     rbv [256] = r_v: fp32, columns in accumulator order (acc_order_perm)."""
@@ -804,7 +811,7 @@ def retr_stats_hl(feat_hl, H, W, tyk, txk, rk_hi, rk_lo, eps_k, rv_hi, rv_lo, rb
         raise ValueError("tables do not match (H, W)")
     aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat_hl.device)
     with _on(feat_hl, tyk, txk, rk_hi, rk_lo, rv_hi, rv_lo, rbv) as ctx:
-        rc = lib.svps_retr_stats_hl_fwd(_ptr(feat_hl[0]), _ptr(feat_hl[1]), _ptr(tyk), tyk.shape[0], _ptr(txk), txk.shape[0], _ptr(rk_hi),
+        rc = lib.svps_retr_stats_hl_fwd(_ptr(feat_hl[0]), _ptr(feat_hl[1]), _ptr(tyk), tyk.shape[0], _ptr(txk), txk.shape[0], int(bool(tx_tiled)), _ptr(rk_hi),
                                         _ptr(rk_lo), float(eps_k), _ptr(rv_hi), _ptr(rv_lo), _ptr(rbv), float(eps_v), _ptr(aux), T, H, W, D,
                                         ctx.stream)
     _lib.check(rc, "svps_retr_stats_hl_fwd")

@@ -278,8 +278,8 @@ class MaskDynamicConv(nn.Module):
         return cache[key][:2]
 
     def stats_hl_tables(self, pos_tabs):
-        """Tables of csrc/retr_stats_hl.hip, columns in accumulator order: (Ty + r_k [H or 1, 256], Tx [W or 1, 256], r_v [256]) fp32.
-        Derived once per (weights, level geometry)."""
+        """Tables of csrc/retr_stats_hl.hip, columns in accumulator order: (Ty + r_k [H or 1, 256], Tx [W or 1, 256], r_v [256]) fp32 and
+        whether Tx is in the tiled order (W % 32 == 0: ops.tile_tx_table). Derived once per (weights, level geometry)."""
         c = self._fused_consts()
         cache = c.setdefault("hl_tables", {})
         key = None if pos_tabs is None else (pos_tabs[0].data_ptr(), pos_tabs[1].data_ptr(), tuple(pos_tabs[0].shape), tuple(pos_tabs[1].shape))
@@ -292,8 +292,11 @@ class MaskDynamicConv(nn.Module):
                 ty, tx = self.retr_pos_tables(pos_tabs)
                 tyk = (ty + c["rbk"][None])[:, perm].contiguous()
                 txk = tx[:, perm].contiguous()
-            cache[key] = (tyk, txk, c["rbv"][perm].contiguous(), pos_tabs)
-        return cache[key][:3]
+            tiled = pos_tabs is not None and txk.shape[0] % 32 == 0
+            if tiled:
+                txk = ops.tile_tx_table(txk)
+            cache[key] = (tyk, txk, c["rbv"][perm].contiguous(), tiled, pos_tabs)
+        return cache[key][:4]
 
     def stats_args(self, pos_tabs):
         """(pos_proj, rk, rbk, eps_k, rv, rbv, eps_v): this stage's arguments of ops.retr_stats / one entry of ops.retr_stats_level."""
@@ -321,8 +324,9 @@ class MaskDynamicConv(nn.Module):
             # reference precision: factors AND map as fp16 hi + lo (K3t's HL form: three MFMAs per product)
             if L > 128:
                 raise NotImplementedError("precision 'fp16x2' covers L <= 128 slots (the exact mode, set_precision('fp32'), has no limit)")
-            tyk, txk, rbv_p = self.stats_hl_tables(pos_tabs)
-            stats = ops.retr_stats_hl(feat_pm, H, W, tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p, self.norm_v.eps)
+            tyk, txk, rbv_p, tiled = self.stats_hl_tables(pos_tabs)
+            stats = ops.retr_stats_hl(feat_pm, H, W, tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p, self.norm_v.eps,
+                                      tx_tiled=tiled)
         elif self.tight_stats:
             # precision form: both statistics from factors carried as fp16 hi + lo (K3t)
             pp, rk, rbk, ek, rv, rbv, ev = self.stats_args(pos_tabs)

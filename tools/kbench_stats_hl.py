@@ -17,8 +17,8 @@ g = torch.Generator(device=dev).manual_seed(0)
 f = ops.split_hl(torch.randn((a.T, a.H * a.W, 256), generator=g, device=dev))
 tabs = ops.pos_embed_sine_tables(a.H, a.W, 256, dev)
 c = m._fused_consts()
-tyk, txk, rbv = m.stats_hl_tables(tabs)
-run = lambda: ops.retr_stats_hl(f, a.H, a.W, tyk, txk, c["rk"], c["rk_lo"], 1e-5, c["rv"], c["rv_lo"], rbv, 1e-5)
+tyk, txk, rbv, tiled = m.stats_hl_tables(tabs)
+run = lambda: ops.retr_stats_hl(f, a.H, a.W, tyk, txk, c["rk"], c["rk_lo"], 1e-5, c["rv"], c["rv_lo"], rbv, 1e-5, tx_tiled=tiled)
 t0 = time.time()
 while time.time() - t0 < 0.4:
     run()
