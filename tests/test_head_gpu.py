@@ -327,6 +327,37 @@ def test_stacked_clips_equal_separate_clips(cuda):
     assert torch.equal(em2[:, :Tc], em[:, :Tc]) and torch.equal(lg2[:, :Tc], lg[:, :Tc])
 
 
+def test_init_slots_follow_their_source(cuda):
+    """the expanded init slots may only be cached for a model PARAMETER, keyed on its version. A temporary that
+    reuses the address of the previous one, and a parameter updated in place, must both be seen."""
+    import torch
+    from slotvps_amd import ops
+    params = synth.make_params(synth.head_shapes(), 5)
+    head = build_head(cuda, params)
+    T, H, W, L = 1, 32, 64, 100
+    sizes = synth.level_sizes(H, W)
+    c = synth.make_clip_features(50, T, H, W)
+    tf = [torch.from_numpy(np.stack([c[t][i] for t in range(T)])).to(cuda) for i in range(4)]
+    tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in sizes]
+    a = synth.make_slots(6, L)
+    b = synth.make_slots(7, L)
+    with torch.no_grad():
+        ref_a = head.forward_clip(tf, torch.from_numpy(a).to(cuda), tabs)[1][0].clone()
+        ref_b = head.forward_clip(tf, torch.from_numpy(b).to(cuda), tabs)[1][0].clone()
+        assert not torch.equal(ref_a, ref_b)
+        tmp = torch.from_numpy(a).to(cuda)
+        got_a = head.forward_clip(tf, tmp, tabs)[1][0].clone()
+        tmp.copy_(torch.from_numpy(b).to(cuda))                            # same address, new contents
+        got_b = head.forward_clip(tf, tmp, tabs)[1][0].clone()
+        assert torch.equal(got_a, ref_a) and torch.equal(got_b, ref_b)
+        par = torch.nn.Parameter(torch.from_numpy(a).to(cuda), requires_grad=False)
+        got_pa = head.forward_clip(tf, par, tabs)[1][0].clone()
+        got_pa2 = head.forward_clip(tf, par, tabs)[1][0].clone()           # second call: served from the cache
+        par.copy_(torch.from_numpy(b).to(cuda))                            # an optimiser step: the version moves
+        got_pb = head.forward_clip(tf, par, tabs)[1][0].clone()
+    assert torch.equal(got_pa, ref_a) and torch.equal(got_pa2, ref_a) and torch.equal(got_pb, ref_b)
+
+
 @pytest.mark.parametrize("map_dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("tag", ["T2_64x128", "T3_64x64"])
 def test_free_running_bf16_head_to_panoptic_ids(cuda, tag, map_dtype):
