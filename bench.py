@@ -37,6 +37,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from slotvps_amd.parallel import host_cores, size_host_pools  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak (same table; the 5 PF headline includes 2:1 sparsity)
@@ -83,32 +84,6 @@ def parse():
 def note(msg):
     """Progress on stderr (a silent leg of several minutes looks hung to the GPU runner)."""
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
-
-
-def host_cores():
-    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota where one is set (a box that
-    shows 128 logical CPUs but grants 16 would be timed 8x oversubscribed otherwise)."""
-    n = os.cpu_count() or 1
-    try:
-        n = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            with open(path) as fh:
-                txt = fh.read().split()
-            if path.endswith("cpu.max"):
-                quota, period = txt[0], float(txt[1])
-            else:
-                quota = txt[0]
-                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
-                    period = float(fh2.read())
-            if quota not in ("max", "-1"):
-                n = max(1, min(n, int(float(quota) / period + 0.5)))
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    return n
 
 
 def cpu_model():
@@ -244,20 +219,9 @@ def single_clip_latency(a, dev):
 
 
 def bind_rank_cpus(local_rank, world):
-    """Give rank `local_rank` of `world` its own slice of the CPUs the job may run on (affinity) and size torch's intra-op pool to
-    it. Returns what was done, for the bench line."""
-    info = {"threads": torch.get_num_threads(), "cpus": None}
-    try:
-        allowed = sorted(os.sched_getaffinity(0))
-        n = max(1, min(len(allowed), host_cores()) // max(1, world))
-        mine = allowed[local_rank * n:(local_rank + 1) * n] or allowed
-        if world > 1:
-            os.sched_setaffinity(0, mine)
-        torch.set_num_threads(max(1, len(mine) if world > 1 else torch.get_num_threads()))
-        info = {"threads": torch.get_num_threads(), "cpus": [mine[0], mine[-1]] if world > 1 else None}
-    except (AttributeError, OSError) as e:
-        info["error"] = f"{type(e).__name__}: {e}"[:80]
-    return info
+    """Give rank `local_rank` of `world` its own slice of the CPUs the job may run on (affinity) and size the host thread pools to it
+    (parallel.size_host_pools; for one rank: to the cgroup's CPU quota). Returns what was done, for the bench line."""
+    return size_host_pools(local_rank, world)
 
 
 def rank_detector_leg(a, dev, iters=3):

@@ -288,6 +288,39 @@ int svps_panoptic_argmax(const float* masks, const uint8_t* sel, const uint8_t* 
                          uint8_t* out_ids, int* hist, float* out_masks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K6c: the same post-process for the T frames of a CLIP with the decisions on the device (slotvps_amd/csrc/panoptic_clip.hip;
+ * round 4): mask_removal's keep / drop loop (vps_temporal_slots.py:601-640), the stuff de-duplication of get_ids_area (:724-757),
+ * the small-area loop (:760-790) and the relabel table of simple_test (:420-433) run in single-workgroup kernels on a per-frame state
+ * block, the pixel passes evaluate the x4 upsampling per 4 x 4 output block. Requires H == 4 h, W == 4 w.
+ *   masks [T, Ks, h, w] fp32 (frame_stride = Ks h w): logits of each frame's kept slots in descending score order;
+ *   state [T, SVPS_PPC_STATE_INTS] int32: the caller fills K, THING[K], CL[K] (class ids) per frame and zeroes the rest;
+ *   pairs [T, pair_stride] int32 zeroed (pair_stride >= max K^2); cand [T, H W, 2] uint8 scratch; out_ids [T, H W] uint8;
+ *   small_option: 0 = "4", 1 = "4_256", 2 = "4096_256" (filter_small_option, :762-776);
+ *   stages: bit 0 candidates + decisions, bit 1 `rounds` x (area pass, step), bit 2 the id pass. A frame is finished when
+ *   state[SVPS_PPC_PHASE] == 2: N surviving slots CUR[N] (indices into its K list, stuff first), AREA[N], the relabel table LUT2;
+ *   if a frame is not, call again with stages = 2 | 4 (finished frames ignore further rounds).
+ * ------------------------------------------------------------------------------------------- */
+#define SVPS_PPC_K 0
+#define SVPS_PPC_N 1
+#define SVPS_PPC_PHASE 2
+#define SVPS_PPC_ROUNDS 3
+#define SVPS_PPC_LUT_IDENT 4
+#define SVPS_PPC_THING 16
+#define SVPS_PPC_CL (SVPS_PPC_THING + 256)
+#define SVPS_PPC_COUNTS (SVPS_PPC_CL + 256)
+#define SVPS_PPC_KEPT (SVPS_PPC_COUNTS + 256)
+#define SVPS_PPC_CUR (SVPS_PPC_KEPT + 256)
+#define SVPS_PPC_LUT (SVPS_PPC_CUR + 256)
+#define SVPS_PPC_HIST (SVPS_PPC_LUT + 256)
+#define SVPS_PPC_AREA (SVPS_PPC_HIST + 256)
+#define SVPS_PPC_LUT2 (SVPS_PPC_AREA + 256)
+#define SVPS_PPC_STATE_INTS (SVPS_PPC_LUT2 + 256)
+int svps_panoptic_clip_state_ints(void);
+int svps_panoptic_clip(const float* masks, long long frame_stride, int T, int h, int w, int H, int W, int* state, int* pairs,
+                       int pair_stride, uint8_t* cand, uint8_t* out_ids, float pixel_threshold, double fraction_threshold,
+                       int small_option, int stuff_num, int rounds, int stages, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K7 deformable convolution forward, sampling half: deformable im2col of DCNv1
  * (mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:82-114, :190-241; host wrapper deform_conv_cuda.cpp:152-258).
  *   x_nhwc [N, H, W, C] fp32 pixel-major input; offset [N, dg*2*kh*kw, Ho, Wo] fp32 in the reference's layout

@@ -502,39 +502,44 @@ class VPS_Temporal_Slots(nn.Module):
         H, W = size
         T = logits.shape[0]
         pp = self.postprocess_panoptic
-        results = pp.forward_clip(logits, masks, (H, W))
-        # ---- tracker (:345-409): embedded vectors of every frame's segments (+ of the memory a previous clip left) in one go
-        seg = [embeds[t][r.slot_index] for t, r in enumerate(results)]
-        rows = [s_.shape[0] for s_ in seg]
+        # ---- tracker (:345-409): embedded vectors of the kept slots of every frame (+ of the memory a previous clip left), enqueued by the
+        # post-process BEHIND its own kernels so that they come back with its one wait
         have_mem = self.prev_embedding is not None and not firsts[0]
-        raw = torch.cat(([self.prev_embedding] if have_mem else []) + seg)
-        emb_h = self.temporal_track_head._embed(raw).cpu().numpy()                                   # the only copy of the tracker
-        o = self.prev_embedding.shape[0] if have_mem else 0
-        mem_src = list(range(o))                                     # memory row -> row of `raw` it currently holds
+        o0 = self.prev_embedding.shape[0] if have_mem else 0
+        box = {}
+
+        def side(index_d):                       # index_d [T, Kmax]: each frame's kept slots in score order (padded rows: slot 0)
+            g = torch.gather(embeds, 1, index_d[:, :, None].expand(-1, -1, embeds.shape[2])).reshape(-1, embeds.shape[2])
+            box["raw"] = torch.cat([self.prev_embedding, g]) if have_mem else g
+            box["kmax"] = index_d.shape[1]
+            return self.temporal_track_head._embed(box["raw"])
+        results = pp.forward_clip(logits, masks, (H, W), stuff_num=self.stuff_num, side=side)
+        emb_h, raw, Kmax = results.side_host, box["raw"], box["kmax"]
+        rows = [o0 + t * Kmax + np.asarray(r._sorted_pos, dtype=np.int64) for t, r in enumerate(results)]   # rows of `raw` = segments
+        mem_src = list(range(o0))                                    # memory row -> row of `raw` it currently holds
         dets = []
         for t in range(T):
-            K = rows[t]
+            K = len(rows[t])
             if firsts[t] or (t == 0 and not have_mem):
-                mem_src = list(range(o, o + K))
+                mem_src = rows[t].tolist()
                 det = np.arange(K, dtype=np.int64)
             else:
                 assert K > 0 and len(mem_src) > 0
-                prod = emb_h[o:o + K] @ emb_h[mem_src].T
+                prod = emb_h[rows[t]] @ emb_h[mem_src].T
                 score = torch.from_numpy(np.concatenate([np.zeros((K, 1), dtype=prod.dtype), prod], axis=1))
                 logprob = F.log_softmax(score, dim=1).numpy()
                 det, updates = greedy_track_assign(logprob, len(mem_src))
                 for p_, c_ in updates:                               # in order: a later, stronger match overwrites an earlier one
                     if p_ == len(mem_src):
-                        mem_src.append(o + c_)
+                        mem_src.append(int(rows[t][c_]))
                     else:
-                        mem_src[p_] = o + c_
+                        mem_src[p_] = int(rows[t][c_])
                 det = det.astype(np.int64)
             dets.append(det)
-            o += K
         self.prev_embedding = raw[torch.as_tensor(mem_src, dtype=torch.long, device=raw.device)].clone()
         last = results[-1]
         self.test_track_instances = Instances((H, W), slot_index=last.slot_index, labels=torch.from_numpy(last.labels_host).to(raw.device),
-                                              output_embedding=seg[-1], obj_ids=torch.from_numpy(dets[-1]))
+                                              output_embedding=embeds[T - 1][last.slot_index], obj_ids=torch.from_numpy(dets[-1]))
         pans = pp.panoptic_ids_clip(results, self.stuff_num)
         if fcn.shape[-2] != H or fcn.shape[-1] != W:
             fcn = F.interpolate(fcn, size=(H, W), mode="bilinear", align_corners=False)

@@ -6,6 +6,8 @@ Integer / byte work on the host; inputs are the uint8 maps the detector's GPU po
 import numpy as np
 import torch
 
+from .parallel import size_host_pools
+
 
 def _append(pano_results, result, filename):
     pano_results["all_ssegs"].append(result["fcn_outputs"].data.cpu().numpy()[0].astype(np.uint8))
@@ -34,6 +36,7 @@ def _meta_of(entry):
 def single_gpu_test(model, data_loader, show=False):
     """One detector call per frame, like the reference: `data` = dict(img=[Tensor], img_meta=[...], ref_img=[Tensor])."""
     model.eval()
+    size_host_pools()                       # host pools to the cgroup's CPU share (parallel.size_host_pools: why)
     pano_results = _empty()
     for data in data_loader:
         filename = _meta_of(data["img_meta"])["filename"].split("/")[-1]
@@ -47,6 +50,7 @@ def clip_gpu_test(model, clips):
     """Clip-batched loop: `clips` yields (imgs [T, 3, H, W], [T metas]) of consecutive frames of one video; the
     backbone runs once per frame (the reference recomputes the reference frame at every step, :245-252)."""
     model.eval()
+    size_host_pools()
     pano_results = _empty()
     for imgs, metas in clips:
         for result, meta in zip(model.clip_test(imgs, metas), metas):

@@ -12,6 +12,64 @@ import torch
 import torch.distributed as dist
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota where one is set (a box that shows 256
+    logical CPUs but grants 16 is 16 cores)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                txt = fh.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota = txt[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh2:
+                    period = float(fh2.read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+_blas_limit = None
+
+
+def size_host_pools(local_rank=0, world=1, pin=None):
+    """Size the host thread pools (torch intra-op = OpenMP, and the BLAS pool behind numpy) to this rank's share of the cores the job
+    may use, and for world > 1 pin the rank to its own slice of CPUs. Why it matters here: the per-clip host work of the detector (score
+    filter, tracker assignment) is a handful of tiny ops, but a pool sized to the 256 logical CPUs a container SEES wakes 256 spinning
+    workers for each of them; under a 16-CPU cgroup quota that exhausts the CFS budget and the whole process is throttled for the
+    rest of the 100 ms period - measured as random 10 - 80 ms stalls per clip (round 4; /sys/fs/cgroup/cpu.stat: nr_throttled).
+    Returns what was done."""
+    global _blas_limit
+    info = {"threads": torch.get_num_threads(), "cpus": None}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        n = max(1, min(len(allowed), host_cores()) // max(1, world))
+        mine = allowed[local_rank * n:(local_rank + 1) * n] or allowed
+        if world > 1 if pin is None else pin:
+            os.sched_setaffinity(0, mine)
+            info["cpus"] = [mine[0], mine[-1]]
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), n)))
+        try:
+            from threadpoolctl import threadpool_limits
+            _blas_limit = threadpool_limits(limits=max(1, min(n, 16)))        # kept alive: the limit lasts as long as the object
+        except Exception:                                                      # threadpoolctl is optional
+            pass
+        info["threads"] = torch.get_num_threads()
+        info["host_cores"] = n
+    except (AttributeError, OSError) as e:
+        info["error"] = f"{type(e).__name__}: {e}"[:80]
+    return info
+
+
 def dist_env():
     """(rank, local_rank, world_size) from the torch.distributed.run environment (defaults: single process)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),

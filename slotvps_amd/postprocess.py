@@ -8,6 +8,7 @@ kept slots), exactly as the reference's loops would decide them. Full-resolution
 materialised unless asked for (`materialize_masks`), the reference's K x 8 MB device->host copy disappears.
 """
 import ctypes
+import os
 from types import SimpleNamespace
 
 import torch
@@ -17,12 +18,24 @@ from . import _lib, ops
 
 _SOFTMAX_MASKING_CONSTANT = -99999.0
 
+# per-frame state block of svps_panoptic_clip (include/slotvps_hip.h: SVPS_PPC_*)
+PPC_K, PPC_N, PPC_PHASE, PPC_ROUNDS, PPC_LUT_IDENT = 0, 1, 2, 3, 4
+PPC_THING = 16
+PPC_CL, PPC_COUNTS, PPC_KEPT, PPC_CUR, PPC_LUT, PPC_HIST, PPC_AREA, PPC_LUT2 = (PPC_THING + 256 * i for i in range(1, 9))
+PPC_STATE_INTS = PPC_LUT2 + 256
+_SMALL_OPTION = {"4": 0, "4_256": 1, "4096_256": 2}
+
 
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
 from .ops import _on
+
+
+class _ClipResults(list):
+    """Per-frame results of forward_clip; `side_host` carries the host copy of the caller's side work."""
+    side_host = None
 
 
 class PostProcessPanopticInstances(nn.Module):
@@ -198,13 +211,69 @@ class PostProcessPanopticInstances(nn.Module):
             return [a < 4096 if not thing[i] else a < 256 for a, i in zip(area, cur)]
         raise AssertionError("filter_small_option is not valid !!!!!!")
 
+    # ---- K6c: the decisions on the device, ONE copy back per clip (csrc/panoptic_clip.hip) ---------------------------------------
+    device_decisions = True        # False: the lock-step host path below (also taken when the output is not exactly 4x the logits)
+    clip_rounds = 4                # (area pass, step) pairs enqueued speculatively; unfinished frames get more (never a wrong result)
+
+    def _clip_on_device(self, fr, m_clip, index_d, size, stuff_num, side):
+        """Frames `fr` (K, thing, cl per frame from the score filter), their kept-slot logits m_clip [T, Kmax, h, w]: candidates,
+        mask_removal, de-duplication, small-area loop, relabel table and the id maps in one enqueued sequence; `side(index_d)` may
+        enqueue more work whose result comes back with the same wait. Returns (per-frame results, side result on the host)."""
+        import numpy as np
+        lib = _lib.load()
+        assert lib.svps_panoptic_clip_state_ints() == PPC_STATE_INTS
+        dev = m_clip.device
+        T, Kmax, h, w = m_clip.shape
+        H, W = size
+        st_h = np.zeros((T, PPC_STATE_INTS), dtype=np.int32)
+        for t, f in enumerate(fr):
+            st_h[t, PPC_K] = f.K
+            st_h[t, PPC_THING:PPC_THING + f.K] = f.thing
+            st_h[t, PPC_CL:PPC_CL + f.K] = f.cl
+        state = torch.from_numpy(st_h).to(dev)
+        pairs = torch.zeros((T, Kmax * Kmax), dtype=torch.int32, device=dev)
+        cand = torch.empty((T, H * W, 2), dtype=torch.uint8, device=dev)
+        ids = torch.empty((T, H, W), dtype=torch.uint8, device=dev)
+
+        def enqueue(rounds, stages):
+            with _on(m_clip, state, pairs, cand, ids) as ctx:
+                _lib.check(lib.svps_panoptic_clip(_p(m_clip), Kmax * h * w, T, h, w, H, W, _p(state), _p(pairs), Kmax * Kmax, _p(cand),
+                                                  _p(ids), float(self.pixel_threshold), float(self.fraction_threshold),
+                                                  _SMALL_OPTION[self.filter_small_option], int(stuff_num), rounds, stages, ctx.stream),
+                           "svps_panoptic_clip")
+        enqueue(self.clip_rounds, 7)
+        side_d = side(index_d) if side is not None else None
+        st = state.cpu().numpy()                                                                     # THE copy of the clip
+        while (st[:, PPC_PHASE] != 2).any():                                # a frame with more small-area rounds than were enqueued
+            enqueue(2, 6)
+            st = state.cpu().numpy()
+        side_h = side_d.cpu().numpy() if side_d is not None else None
+        out = []
+        curs = [st[t, PPC_CUR:PPC_CUR + int(st[t, PPC_N])].tolist() for t in range(T)]
+        flat = np.concatenate([np.asarray(c, dtype=np.int64) + t * Kmax for t, c in enumerate(curs)]) if any(curs) else np.zeros(0, np.int64)
+        sel_all = index_d.reshape(-1)[torch.from_numpy(flat).to(dev)]          # the surviving slot ids of all frames: one upload, one gather
+        offs = np.cumsum([0] + [len(c) for c in curs])
+        for t, f in enumerate(fr):
+            n = int(st[t, PPC_N])
+            cur = curs[t]
+            sel_d = sel_all[offs[t]:offs[t + 1]]
+            out.append(SimpleNamespace(slot_index=sel_d, slot_index_host=f.sorted_idx[cur] if cur else f.sorted_idx[:0],
+                                       probs_host=f.sc[cur].copy(), labels_host=f.cl[cur].copy(), area=st[t, PPC_AREA:PPC_AREA + n].tolist(),
+                                       size=size, rounds=int(st[t, PPC_ROUNDS]), _m_sorted=m_clip[t, :f.K], _cur=cur, _thing=f.thing,
+                                       _kept=st[t, PPC_KEPT:PPC_KEPT + f.K].astype(np.uint8), _cand=cand[t], _ids=ids[t],
+                                       _stuff_num=int(stuff_num), _sorted_pos=cur))
+        return out, side_h
+
     @torch.no_grad()
-    def forward_clip(self, pred_logits, pred_masks, size):
-        """forward_tensors for the T frames of a clip at once (same decisions, same kernels, same results frame by frame): pred_logits
+    def forward_clip(self, pred_logits, pred_masks, size, stuff_num=None, side=None):
+        """forward_tensors for the T frames of a clip at once (same decisions, same results frame by frame): pred_logits
         [T, L, nc]; pred_masks a clip of lazy mask logits (`decode_clip(index [T, Kmax]) -> [T, Kmax, h, w]`, detector.SlotMasks) or a
         dense [T, L, h, w] tensor; size (H, W). The frames move through the phases together - score filter, decode of the kept slots
-        (ONE K2 launch), candidates, mask_removal tables, areas, small-area loop - so the host waits for the device once per phase,
-        not seven times per frame. Returns the list of per-frame result namespaces of forward_tensors."""
+        (ONE K2 launch), candidates, mask_removal tables, areas, small-area loop. With an output of exactly 4x the logits (every
+        configuration of the repository) the decisions run on the device too (`_clip_on_device`): the host waits twice per clip - for
+        the class scores and for the finished state - instead of seven times per frame; otherwise once per phase. `side(index_d)` (index
+        of the kept slots [T, Kmax]) may enqueue work of the caller whose host copy is wanted with the same wait (`.side_host` of the
+        returned list). Returns the per-frame result namespaces of forward_tensors (as a list subclass carrying `side_host`)."""
         import numpy as np
         if not pred_masks.is_cuda:
             raise RuntimeError("the panoptic post-process runs on the GPU only; there is no CPU fallback")
@@ -213,7 +282,10 @@ class PostProcessPanopticInstances(nn.Module):
         H, W = size
         n_px = H * W
         scores, classes = pred_logits.float().softmax(-1).max(-1)                                   # :684
-        host = torch.stack([scores, classes.float()]).cpu().numpy()                                  # copy 1: [2, T, L]
+        both = torch.stack([scores, classes.float()])
+        if os.environ.get("SVPS_PP_STREAM_SYNC", "1") == "1":
+            torch.cuda.current_stream(dev).synchronize()                 # wait on the stream, then copy: see _clip_on_device
+        host = both.cpu().numpy()                                                                    # copy 1: [2, T, L]
         fr = []
         for t in range(T):
             sc_l, cl_l = host[0, t], host[1, t].astype(np.int64)
@@ -238,6 +310,12 @@ class PostProcessPanopticInstances(nn.Module):
             m_clip = torch.gather(pred_masks.float(), 1, index_d[:, :, None, None].expand(-1, -1, *pred_masks.shape[2:]))
         m_clip = m_clip.float().contiguous()
         h, w = m_clip.shape[2:]
+        if self.device_decisions and H == 4 * h and W == 4 * w:
+            res, side_h = self._clip_on_device(fr, m_clip, index_d, size, self.num_stuff if stuff_num is None else stuff_num, side)
+            out = _ClipResults(res)
+            out.side_host = side_h
+            return out
+        side_d = side(index_d) if side is not None else None
         things = self._upload(dev, [np.asarray(f.thing, dtype=np.uint8) for f in fr])
         lib = _lib.load()
         cand = torch.empty((T, n_px, 2), dtype=torch.uint8, device=dev)
@@ -311,7 +389,9 @@ class PostProcessPanopticInstances(nn.Module):
             out.append(SimpleNamespace(slot_index=sel_d, slot_index_host=f.sorted_idx[cur] if cur else f.sorted_idx[:0],
                                        probs_host=f.sc[cur].copy(), labels_host=f.cl[cur].copy(), area=f.area, size=size,
                                        _m_sorted=f.m_sorted, _cur=cur, _thing=f.thing, _kept_u8=f.kept_u8, _cand=f.cand,
-                                       _tables=f.tables, _hist_identity=f.area if f.area_lut_identity else None))
+                                       _tables=f.tables, _hist_identity=f.area if f.area_lut_identity else None, _sorted_pos=cur))
+        out = _ClipResults(out)
+        out.side_host = side_d.cpu().numpy() if side_d is not None else None
         return out
 
     @torch.no_grad()
@@ -322,6 +402,16 @@ class PostProcessPanopticInstances(nn.Module):
         import numpy as np
         stuff_num = self.num_stuff if stuff_num is None else stuff_num
         dev = results[0]._m_sorted.device
+        if all(getattr(r, "_ids", None) is not None and r._stuff_num == stuff_num for r in results):      # K6c wrote them already
+            out = []
+            for res in results:
+                ins = [j for j in range(len(res._cur)) if res._thing[res._cur[j]]]
+                cls_inds = torch.tensor([int(res.labels_host[j]) - (stuff_num - 1) for j in ins], dtype=torch.long)
+                probs = torch.from_numpy(res.probs_host[ins].copy()) if ins else torch.zeros(0)
+                out.append((res._ids, cls_inds, probs))
+            return out
+        if any(getattr(r, "_ids", None) is not None for r in results):
+            raise RuntimeError("panoptic_ids_clip: stuff_num differs from the one forward_clip relabelled with; pass it to forward_clip")
         plan = []
         for res in results:
             cur, thing = res._cur, res._thing

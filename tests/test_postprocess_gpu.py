@@ -143,3 +143,91 @@ def test_postprocess_edge_cases(cuda):
     mk[8] = mk[9] = blob(3, 5, 3.0, 4.0)
     res, want = _compare_with_oracle(cuda, lg, mk, (4 * h, 4 * w))
     assert res.slot_index.tolist() == [8]                                 # slot 9 owns no pixel -> area 0 -> filtered
+
+
+def _clip_vs_frames(cuda, cases, size, rounds=None, device_decisions=True, cfg=CFG):
+    """The frames of `cases` (same L, h, w) through forward_clip / panoptic_ids_clip against forward_tensors / panoptic_ids frame by
+    frame: kept slots, labels, areas and the id maps must be identical."""
+    import torch
+    from slotvps_amd.postprocess import PostProcessPanopticInstances
+    pp = PostProcessPanopticInstances(**cfg)
+    pp.device_decisions = device_decisions
+    if rounds is not None:
+        pp.clip_rounds = rounds
+    lg = torch.from_numpy(np.stack([c[0] for c in cases])).to(cuda)
+    mk = torch.from_numpy(np.stack([c[1] for c in cases])).to(cuda)
+    res = pp.forward_clip(lg, mk, size)
+    pans = pp.panoptic_ids_clip(res)
+    ref = PostProcessPanopticInstances(**cfg)
+    for t in range(len(cases)):
+        want = ref.forward_tensors(lg[t], mk[t], size)
+        w_ids, w_cls, w_prob = ref.panoptic_ids(want)
+        np.testing.assert_array_equal(res[t].slot_index.cpu().numpy(), want.slot_index.cpu().numpy())
+        np.testing.assert_array_equal(res[t].slot_index_host, want.slot_index.cpu().numpy())
+        np.testing.assert_array_equal(res[t].labels_host, want.labels.cpu().numpy())
+        np.testing.assert_array_equal(res[t].probs_host, want.probs.cpu().numpy())
+        assert res[t].area == want.area
+        ids, cls, prob = pans[t]
+        assert torch.equal(ids.view(size[0], size[1]), w_ids)
+        np.testing.assert_array_equal(cls.numpy(), w_cls.numpy())
+        np.testing.assert_array_equal(prob.numpy(), w_prob.cpu().numpy())
+    return res
+
+
+@pytest.mark.parametrize("device_decisions", [True, False])
+def test_clip_postprocess_equals_frame_postprocess(cuda, device_decisions):
+    """K6c (decisions on the device, 4 x 4 output blocks, one copy per clip) and the lock-step host path against the per-frame path,
+    which the tests above pin to the reference's own outputs and the oracle: ragged sizes (w not a multiple of the 64-cell block),
+    20 ... 200 slots, 7 ... 39 kept."""
+    for seed in range(50, 58):
+        rng = np.random.default_rng(seed)
+        L = int(rng.choice([20, 50, 100, 200]))
+        h, w = int(rng.integers(5, 40)), int(rng.integers(5, 90))
+        T = int(rng.integers(1, 6))
+        cases = [synth.make_post_case(1000 * seed + t, L, h, w, 20, int(rng.integers(7, min(L, 40)))) for t in range(T)]
+        _clip_vs_frames(cuda, cases, (4 * h, 4 * w), device_decisions=device_decisions)
+    # the reference's own fixture inputs, as one-frame clips
+    z = np.load(os.path.join(GOLDEN, "postprocess.npz"))
+    for tag in "abc":
+        seed, L, h, w, nk = (int(x) for x in z[f"{tag}_meta"])
+        res = _clip_vs_frames(cuda, [synth.make_post_case(seed, L, h, w, 20, nk)], (4 * h, 4 * w), device_decisions=device_decisions)
+        np.testing.assert_array_equal(res[0].slot_index_host, z[f"{tag}_slot_index"])
+        np.testing.assert_array_equal(res[0].labels_host, z[f"{tag}_labels"])
+
+
+def test_clip_postprocess_more_rounds_than_enqueued(cuda):
+    """The small-area loop has a data-dependent trip count: with ONE speculative round enqueued, frames that need more must be
+    continued by the host - same results; and at the full size (1024 x 2048 from 256 x 512)."""
+    cases = [synth.make_post_case(77 + t, 100, 20, 36, 20, 30) for t in range(4)]
+    res = _clip_vs_frames(cuda, cases, (80, 144), rounds=1)
+    assert max(r.rounds for r in res) >= 1                      # at least one frame went round the small-area loop
+    cases = [synth.make_post_case(21 + t, 100, 256, 512, 20, 30) for t in range(2)]
+    _clip_vs_frames(cuda, cases, (1024, 2048))
+
+
+def test_clip_postprocess_edge_cases(cuda):
+    """Stuff only with duplicated classes (de-duplication table, then the identity pass), things only with twins, nothing kept by the
+    score filter (must raise like the per-frame path)."""
+    import torch
+    from slotvps_amd.postprocess import PostProcessPanopticInstances
+    L, h, w = 12, 8, 16
+    base = np.full((L, 20), -4.0, np.float32)
+    base[:, 19] = 6.0
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    blob = lambda cy, cx, s, amp: (amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s)) - 1.0).astype(np.float32)
+    masks = np.full((L, h, w), -3.0, np.float32)
+    pp = PostProcessPanopticInstances(**CFG)
+    with pytest.raises(ValueError):
+        pp.forward_clip(torch.from_numpy(base[None]).to(cuda), torch.from_numpy(masks[None]).to(cuda), (4 * h, 4 * w))
+    lg, mk = base.copy(), masks.copy()
+    for s, c in [(0, 3), (1, 3), (2, 7)]:
+        lg[s] = -4.0
+        lg[s, c] = 8.0
+    mk[0], mk[1] = blob(2, 3, 4.0, 6.0), blob(6, 12, 4.0, 6.0)
+    lg2, mk2 = base.copy(), masks.copy()
+    for s, c in [(0, 12), (1, 12), (2, 15), (3, 4)]:
+        lg2[s] = -4.0
+        lg2[s, c] = 8.0 - 0.1 * s
+    mk2[0], mk2[1], mk2[2], mk2[3] = blob(3, 4, 2.0, 8.0), blob(3, 4, 2.0, 7.5), blob(5, 11, 1.5, 8.0), blob(4, 8, 6.0, 3.0)
+    for dd in (True, False):
+        _clip_vs_frames(cuda, [(lg, mk), (lg2, mk2), (lg, mk)], (4 * h, 4 * w), device_decisions=dd)

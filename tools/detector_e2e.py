@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from slotvps_amd.config import Config
 from slotvps_amd.registry import build_detector
+from slotvps_amd.parallel import size_host_pools
+if os.environ.get('SVPS_SIZE_POOLS', '1') == '1':
+    size_host_pools()
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default=os.path.join(ROOT, "configs", "r50_fpn_slotvps_mi355x.py"))

@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from slotvps_amd.config import Config
 from slotvps_amd.registry import build_detector
+from slotvps_amd.parallel import size_host_pools
+if os.environ.get('SVPS_SIZE_POOLS', '1') == '1':
+    size_host_pools()
 
 dev = torch.device("cuda:0")
 cfg = Config.fromfile(os.path.join(ROOT, "configs", (sys.argv[1] if len(sys.argv) > 1 else "r50_fpn_slotvps_mi355x") + ".py"))
