@@ -314,8 +314,17 @@ int svps_panoptic_argmax(const float* masks, const uint8_t* sel, const uint8_t* 
 #define SVPS_PPC_HIST (SVPS_PPC_LUT + 256)
 #define SVPS_PPC_AREA (SVPS_PPC_HIST + 256)
 #define SVPS_PPC_LUT2 (SVPS_PPC_AREA + 256)
-#define SVPS_PPC_STATE_INTS (SVPS_PPC_LUT2 + 256)
+#define SVPS_PPC_SLOT (SVPS_PPC_LUT2 + 256)
+#define SVPS_PPC_SCORE (SVPS_PPC_SLOT + 256)
+#define SVPS_PPC_STATE_INTS (SVPS_PPC_SCORE + 256)
 int svps_panoptic_clip_state_ints(void);
+/* The score filter (:684-691) and the descending-score order (:580) of every frame on the device, so that nothing of the clip's
+ * post-process waits for the host: scores / classes [T, L] = softmax(class logits).max(-1) (fp32 / int64), L <= 255; nc = number of
+ * class logits. Fills K, SLOT[K] (kept slot ids, best score first), SCORE[K] (float bits), CL[K], THING[K] of the zeroed state and
+ * index [T, L] int64 (the same ids padded with 0: the gather index of the decode). Equal scores among the kept slots of a frame
+ * have no defined order in the reference (np.argsort's unstable default); here: descending slot id, numpy's scalar path. */
+int svps_panoptic_clip_select(const float* scores, const long long* classes, int T, int L, int nc, int num_classes, int num_stuff,
+                              float threshold, long long* index, int* state, void* stream);
 int svps_panoptic_clip(const float* masks, long long frame_stride, int T, int h, int w, int H, int W, int* state, int* pairs,
                        int pair_stride, uint8_t* cand, uint8_t* out_ids, float pixel_threshold, double fraction_threshold,
                        int small_option, int stuff_num, int rounds, int stages, void* stream);

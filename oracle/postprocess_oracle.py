@@ -73,7 +73,9 @@ def mask_removal(cls_prob, mask_logits, cls_idx, pixel_threshold=0.4, fraction_t
     im_shape = mask_logits.shape[1:]
     mask_image = np.zeros((int(np.max(cls_idx)) + 1,) + im_shape, dtype=np.float32)
     panoptic_image = np.zeros(im_shape, dtype=np.float32)
-    order = np.argsort(cls_prob)[::-1]
+    # the reference: np.argsort(cls_prob)[::-1] (:580) - an unstable sort, whose order among EQUAL scores differs between numpy's AVX-512
+    # and scalar builds; pinned here (and in the product) to the scalar path's: ties in descending slot order
+    order = np.argsort(cls_prob, kind="stable")[::-1]
     cls_prob, cls_idx = cls_prob[order], cls_idx[order]
     mask_prob, mask_copy = mask_prob[order], mask_logits[order]
     keep_prob, keep_idx, keep_mask, keep_inds = [], [], [], []

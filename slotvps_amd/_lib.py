@@ -53,6 +53,7 @@ SIGNATURES = {
     "svps_panoptic_candidates": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "svps_panoptic_argmax": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "svps_panoptic_clip_state_ints": (_i, []),
+    "svps_panoptic_clip_select": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "svps_panoptic_clip": (_i, [_vp, _c.c_longlong, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _c.c_double, _i, _i, _i, _i, _vp]),
     "svps_deform_im2col": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "svps_deform_im2col_bf16": (_i, [_vp, _vp, _vp] + [_i] * 15 + [_vp]),

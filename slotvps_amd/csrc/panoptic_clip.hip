@@ -94,6 +94,47 @@ __device__ __forceinline__ void up16(const float* __restrict__ m, const Cell& ce
     }
 }
 
+// ---- the score filter :684-691 and the descending-score order :580 of every frame. scores / classes [T, L] = softmax(logits).max(-1)
+// (computed by the caller); writes K, the kept slots in score order (A_SLOT, and `index` [T, L] int64 for the decode, padded with slot 0),
+// their scores, classes and thing flags. Equal scores among kept slots have no defined order in the reference (np.argsort's default
+// sort is unstable: its AVX-512 and scalar builds order ties differently); every path of this library takes the order of numpy's
+// scalar path, `argsort(kind="stable")[::-1]`: ties in DESCENDING slot order. grid T, 256 threads, L <= 255.
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ scores, const long long* __restrict__ classes, int L,
+                                                     int drop_last_class, int nc, int num_stuff, float thr, long long* __restrict__ index,
+                                                     int* __restrict__ state) {
+    __shared__ float s_sc[256];
+    __shared__ int s_keep[256], s_k;
+    const int tid = threadIdx.x, t = blockIdx.x;
+    int* st = state + (size_t)t * ST;
+    float sc = 0.f;
+    long long cl = 0;
+    bool keep = false;
+    if (tid < L) {
+        sc = scores[(size_t)t * L + tid];
+        cl = classes[(size_t)t * L + tid];
+        keep = sc > thr && (!drop_last_class || cl != nc - 1);
+    }
+    s_sc[tid] = sc;
+    s_keep[tid] = keep;
+    if (tid == 0) s_k = 0;
+    __syncthreads();
+    int rank = 0;
+    if (keep)
+        for (int j = 0; j < L; ++j)
+            if (s_keep[j] && j != tid) rank += s_sc[j] > sc || (s_sc[j] == sc && j > tid);
+    if (keep) atomicAdd(&s_k, 1);
+    if (tid < L) index[(size_t)t * L + tid] = 0;
+    __syncthreads();
+    if (keep) {
+        index[(size_t)t * L + rank] = tid;
+        st[SVPS_PPC_SLOT + rank] = tid;
+        st[SVPS_PPC_SCORE + rank] = __float_as_int(sc);
+        st[SVPS_PPC_CL + rank] = (int)cl;
+        st[SVPS_PPC_THING + rank] = cl > num_stuff - 1;                 // :594
+    }
+    if (tid == 0) st[SVPS_PPC_K] = s_k;
+}
+
 // ---- candidates of every frame (pp_candidates_kernel per 4 x 4 block). grid (ceil(w / 64), ceil(h / 4), T), 256 threads = 64 x 4 cells
 __global__ __launch_bounds__(256) void candidates_kernel(Args a) {
     __shared__ int lcount[256];
@@ -418,6 +459,16 @@ __global__ __launch_bounds__(256) void step_kernel(Args a) {
 }  // namespace svps
 
 extern "C" int svps_panoptic_clip_state_ints(void) { return SVPS_PPC_STATE_INTS; }
+
+extern "C" int svps_panoptic_clip_select(const float* scores, const long long* classes, int T, int L, int nc, int num_classes,
+                                         int num_stuff, float threshold, long long* index, int* state, void* stream_) {
+    if (!scores || !classes || !index || !state) return SVPS_ERR_BAD_ARG;
+    if (T <= 0 || L <= 0 || L > 255 || nc <= 0) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(svps::ppc::select_kernel, dim3(T), dim3(256), 0, stream, scores, classes, L, nc == num_classes - 1 ? 0 : 1, nc,
+                       num_stuff, threshold, index, state);
+    return (int)hipGetLastError();
+}
 
 extern "C" int svps_panoptic_clip(const float* masks, long long frame_stride, int T, int h, int w, int H, int W, int* state,
                                   int* pairs, int pair_stride, uint8_t* cand, uint8_t* out_ids, float pixel_threshold,

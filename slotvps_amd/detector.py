@@ -515,6 +515,7 @@ class VPS_Temporal_Slots(nn.Module):
             return self.temporal_track_head._embed(box["raw"])
         results = pp.forward_clip(logits, masks, (H, W), stuff_num=self.stuff_num, side=side)
         emb_h, raw, Kmax = results.side_host, box["raw"], box["kmax"]
+        assert Kmax == results[0]._row_stride
         rows = [o0 + t * Kmax + np.asarray(r._sorted_pos, dtype=np.int64) for t, r in enumerate(results)]   # rows of `raw` = segments
         mem_src = list(range(o0))                                    # memory row -> row of `raw` it currently holds
         dets = []

@@ -8,7 +8,6 @@ kept slots), exactly as the reference's loops would decide them. Full-resolution
 materialised unless asked for (`materialize_masks`), the reference's K x 8 MB device->host copy disappears.
 """
 import ctypes
-import os
 from types import SimpleNamespace
 
 import torch
@@ -21,8 +20,8 @@ _SOFTMAX_MASKING_CONSTANT = -99999.0
 # per-frame state block of svps_panoptic_clip (include/slotvps_hip.h: SVPS_PPC_*)
 PPC_K, PPC_N, PPC_PHASE, PPC_ROUNDS, PPC_LUT_IDENT = 0, 1, 2, 3, 4
 PPC_THING = 16
-PPC_CL, PPC_COUNTS, PPC_KEPT, PPC_CUR, PPC_LUT, PPC_HIST, PPC_AREA, PPC_LUT2 = (PPC_THING + 256 * i for i in range(1, 9))
-PPC_STATE_INTS = PPC_LUT2 + 256
+PPC_CL, PPC_COUNTS, PPC_KEPT, PPC_CUR, PPC_LUT, PPC_HIST, PPC_AREA, PPC_LUT2, PPC_SLOT, PPC_SCORE = (PPC_THING + 256 * i for i in range(1, 11))
+PPC_STATE_INTS = PPC_SCORE + 256
 _SMALL_OPTION = {"4": 0, "4_256": 1, "4096_256": 2}
 
 
@@ -122,7 +121,7 @@ class PostProcessPanopticInstances(nn.Module):
             raise NotImplementedError("more than 255 kept slots")
         sc = scores[idx].cpu().numpy()
         cl = classes[idx].cpu().numpy()
-        order = sc.argsort()[::-1]                                                                   # :580
+        order = sc.argsort(kind="stable")[::-1]               # :580; equal scores: see svps_panoptic_clip_select (include/slotvps_hip.h)
         sorted_idx = idx[torch.from_numpy(order.copy()).to(dev)]
         sc, cl = sc[order], cl[order]
         K = len(sc)
@@ -215,54 +214,67 @@ class PostProcessPanopticInstances(nn.Module):
     device_decisions = True        # False: the lock-step host path below (also taken when the output is not exactly 4x the logits)
     clip_rounds = 4                # (area pass, step) pairs enqueued speculatively; unfinished frames get more (never a wrong result)
 
-    def _clip_on_device(self, fr, m_clip, index_d, size, stuff_num, side):
-        """Frames `fr` (K, thing, cl per frame from the score filter), their kept-slot logits m_clip [T, Kmax, h, w]: candidates,
-        mask_removal, de-duplication, small-area loop, relabel table and the id maps in one enqueued sequence; `side(index_d)` may
-        enqueue more work whose result comes back with the same wait. Returns (per-frame results, side result on the host)."""
+    def _clip_on_device(self, scores, classes, nc, pred_masks, size, stuff_num, side):
+        """The whole post-process of a clip enqueued without waiting for anything: score filter + order (svps_panoptic_clip_select),
+        decode of the slots in that order (K2), candidates, mask_removal, de-duplication, small-area loop, relabel table and the id
+        maps (svps_panoptic_clip); `side(index_d)` may enqueue more work whose result comes back with the same wait. Returns the
+        per-frame results (a list carrying `side_host`)."""
         import numpy as np
         lib = _lib.load()
         assert lib.svps_panoptic_clip_state_ints() == PPC_STATE_INTS
-        dev = m_clip.device
-        T, Kmax, h, w = m_clip.shape
+        dev = scores.device
+        T, L = scores.shape
         H, W = size
-        st_h = np.zeros((T, PPC_STATE_INTS), dtype=np.int32)
-        for t, f in enumerate(fr):
-            st_h[t, PPC_K] = f.K
-            st_h[t, PPC_THING:PPC_THING + f.K] = f.thing
-            st_h[t, PPC_CL:PPC_CL + f.K] = f.cl
-        state = torch.from_numpy(st_h).to(dev)
-        pairs = torch.zeros((T, Kmax * Kmax), dtype=torch.int32, device=dev)
+        h, w = H // 4, W // 4
+        scores, classes = scores.contiguous(), classes.contiguous()
+        state = torch.zeros((T, PPC_STATE_INTS), dtype=torch.int32, device=dev)
+        index_d = torch.empty((T, L), dtype=torch.int64, device=dev)
+        with _on(scores, classes, index_d, state) as ctx:
+            _lib.check(lib.svps_panoptic_clip_select(_p(scores), _p(classes), T, L, nc, self.num_classes, self.num_stuff,
+                                                     float(self.threshold), _p(index_d), _p(state), ctx.stream), "svps_panoptic_clip_select")
+        if hasattr(pred_masks, "decode_clip"):                             # every frame's slots in score order (rows past K: slot 0)
+            m_clip = pred_masks.decode_clip(index_d)
+        else:
+            m_clip = torch.gather(pred_masks.float(), 1, index_d[:, :, None, None].expand(-1, -1, *pred_masks.shape[2:]))
+        m_clip = m_clip.float().contiguous()
+        pairs = torch.zeros((T, L * L), dtype=torch.int32, device=dev)
         cand = torch.empty((T, H * W, 2), dtype=torch.uint8, device=dev)
         ids = torch.empty((T, H, W), dtype=torch.uint8, device=dev)
 
         def enqueue(rounds, stages):
             with _on(m_clip, state, pairs, cand, ids) as ctx:
-                _lib.check(lib.svps_panoptic_clip(_p(m_clip), Kmax * h * w, T, h, w, H, W, _p(state), _p(pairs), Kmax * Kmax, _p(cand),
+                _lib.check(lib.svps_panoptic_clip(_p(m_clip), L * h * w, T, h, w, H, W, _p(state), _p(pairs), L * L, _p(cand),
                                                   _p(ids), float(self.pixel_threshold), float(self.fraction_threshold),
                                                   _SMALL_OPTION[self.filter_small_option], int(stuff_num), rounds, stages, ctx.stream),
                            "svps_panoptic_clip")
         enqueue(self.clip_rounds, 7)
         side_d = side(index_d) if side is not None else None
-        st = state.cpu().numpy()                                                                     # THE copy of the clip
+        st = state.cpu().numpy()                                                                     # THE wait of the clip
+        if (st[:, PPC_K] == 0).any():
+            raise ValueError("no slot passes the score threshold (the reference's mask_removal fails here too, :652)")
         while (st[:, PPC_PHASE] != 2).any():                                # a frame with more small-area rounds than were enqueued
             enqueue(2, 6)
             st = state.cpu().numpy()
         side_h = side_d.cpu().numpy() if side_d is not None else None
-        out = []
         curs = [st[t, PPC_CUR:PPC_CUR + int(st[t, PPC_N])].tolist() for t in range(T)]
-        flat = np.concatenate([np.asarray(c, dtype=np.int64) + t * Kmax for t, c in enumerate(curs)]) if any(curs) else np.zeros(0, np.int64)
+        flat = np.concatenate([np.asarray(c, dtype=np.int64) + t * L for t, c in enumerate(curs)]) if any(curs) else np.zeros(0, np.int64)
         sel_all = index_d.reshape(-1)[torch.from_numpy(flat).to(dev)]          # the surviving slot ids of all frames: one upload, one gather
         offs = np.cumsum([0] + [len(c) for c in curs])
-        for t, f in enumerate(fr):
-            n = int(st[t, PPC_N])
-            cur = curs[t]
-            sel_d = sel_all[offs[t]:offs[t + 1]]
-            out.append(SimpleNamespace(slot_index=sel_d, slot_index_host=f.sorted_idx[cur] if cur else f.sorted_idx[:0],
-                                       probs_host=f.sc[cur].copy(), labels_host=f.cl[cur].copy(), area=st[t, PPC_AREA:PPC_AREA + n].tolist(),
-                                       size=size, rounds=int(st[t, PPC_ROUNDS]), _m_sorted=m_clip[t, :f.K], _cur=cur, _thing=f.thing,
-                                       _kept=st[t, PPC_KEPT:PPC_KEPT + f.K].astype(np.uint8), _cand=cand[t], _ids=ids[t],
-                                       _stuff_num=int(stuff_num), _sorted_pos=cur))
-        return out, side_h
+        out = []
+        for t in range(T):
+            K, cur = int(st[t, PPC_K]), curs[t]
+            sorted_idx = st[t, PPC_SLOT:PPC_SLOT + K].astype(np.int64)
+            sc = st[t, PPC_SCORE:PPC_SCORE + K].copy().view(np.float32)
+            cl = st[t, PPC_CL:PPC_CL + K].astype(np.int64)
+            thing = [bool(x) for x in st[t, PPC_THING:PPC_THING + K]]
+            out.append(SimpleNamespace(slot_index=sel_all[offs[t]:offs[t + 1]], slot_index_host=sorted_idx[cur] if cur else sorted_idx[:0],
+                                       probs_host=sc[cur].copy(), labels_host=cl[cur].copy(), area=st[t, PPC_AREA:PPC_AREA + len(cur)].tolist(),
+                                       size=size, rounds=int(st[t, PPC_ROUNDS]), _m_sorted=m_clip[t, :K], _cur=cur, _thing=thing,
+                                       _kept=st[t, PPC_KEPT:PPC_KEPT + K].astype(np.uint8), _cand=cand[t], _ids=ids[t],
+                                       _stuff_num=int(stuff_num), _sorted_pos=cur, _row_stride=L))
+        out = _ClipResults(out)
+        out.side_host = side_h
+        return out
 
     @torch.no_grad()
     def forward_clip(self, pred_logits, pred_masks, size, stuff_num=None, side=None):
@@ -282,9 +294,10 @@ class PostProcessPanopticInstances(nn.Module):
         H, W = size
         n_px = H * W
         scores, classes = pred_logits.float().softmax(-1).max(-1)                                   # :684
+        hw = tuple(pred_masks.shape[-2:])
+        if self.device_decisions and H == 4 * hw[0] and W == 4 * hw[1] and L <= 255:
+            return self._clip_on_device(scores, classes, nc, pred_masks, size, self.num_stuff if stuff_num is None else stuff_num, side)
         both = torch.stack([scores, classes.float()])
-        if os.environ.get("SVPS_PP_STREAM_SYNC", "1") == "1":
-            torch.cuda.current_stream(dev).synchronize()                 # wait on the stream, then copy: see _clip_on_device
         host = both.cpu().numpy()                                                                    # copy 1: [2, T, L]
         fr = []
         for t in range(T):
@@ -296,7 +309,7 @@ class PostProcessPanopticInstances(nn.Module):
             if idx.size > 255:
                 raise NotImplementedError("more than 255 kept slots")
             sc, cl = sc_l[idx], cl_l[idx]
-            order = sc.argsort()[::-1]                                                               # :580
+            order = sc.argsort(kind="stable")[::-1]                                                  # :580 (ties: as above)
             fr.append(SimpleNamespace(sorted_idx=idx[order], sc=sc[order], cl=cl[order], K=int(idx.size),
                                       thing=[bool(c > self.num_stuff - 1) for c in cl[order]]))      # :594
         Kmax = max(f.K for f in fr)
@@ -310,11 +323,6 @@ class PostProcessPanopticInstances(nn.Module):
             m_clip = torch.gather(pred_masks.float(), 1, index_d[:, :, None, None].expand(-1, -1, *pred_masks.shape[2:]))
         m_clip = m_clip.float().contiguous()
         h, w = m_clip.shape[2:]
-        if self.device_decisions and H == 4 * h and W == 4 * w:
-            res, side_h = self._clip_on_device(fr, m_clip, index_d, size, self.num_stuff if stuff_num is None else stuff_num, side)
-            out = _ClipResults(res)
-            out.side_host = side_h
-            return out
         side_d = side(index_d) if side is not None else None
         things = self._upload(dev, [np.asarray(f.thing, dtype=np.uint8) for f in fr])
         lib = _lib.load()
@@ -389,7 +397,8 @@ class PostProcessPanopticInstances(nn.Module):
             out.append(SimpleNamespace(slot_index=sel_d, slot_index_host=f.sorted_idx[cur] if cur else f.sorted_idx[:0],
                                        probs_host=f.sc[cur].copy(), labels_host=f.cl[cur].copy(), area=f.area, size=size,
                                        _m_sorted=f.m_sorted, _cur=cur, _thing=f.thing, _kept_u8=f.kept_u8, _cand=f.cand,
-                                       _tables=f.tables, _hist_identity=f.area if f.area_lut_identity else None, _sorted_pos=cur))
+                                       _tables=f.tables, _hist_identity=f.area if f.area_lut_identity else None, _sorted_pos=cur,
+                                       _row_stride=Kmax))
         out = _ClipResults(out)
         out.side_host = side_d.cpu().numpy() if side_d is not None else None
         return out

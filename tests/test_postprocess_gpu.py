@@ -231,3 +231,15 @@ def test_clip_postprocess_edge_cases(cuda):
     mk2[0], mk2[1], mk2[2], mk2[3] = blob(3, 4, 2.0, 8.0), blob(3, 4, 2.0, 7.5), blob(5, 11, 1.5, 8.0), blob(4, 8, 6.0, 3.0)
     for dd in (True, False):
         _clip_vs_frames(cuda, [(lg, mk), (lg2, mk2), (lg, mk)], (4 * h, 4 * w), device_decisions=dd)
+
+
+def test_clip_postprocess_equal_scores(cuda):
+    """Two kept slots with bit-identical class logits have equal scores; the reference's order among them is an accident of numpy's
+    unstable argsort (AVX-512 and scalar builds differ). Every path here - per frame, clip on the host, clip on the device, and the
+    oracle - takes the scalar path's order (ties in descending slot order): they must agree."""
+    lg, mk = synth.make_post_case(91, 50, 12, 20, 20, 12)
+    order = np.argsort(-lg.max(-1))
+    lg[order[3]] = lg[order[2]]                                  # a tie among the kept slots
+    for dd in (True, False):
+        _clip_vs_frames(cuda, [(lg, mk), synth.make_post_case(92, 50, 12, 20, 20, 9)], (48, 80), device_decisions=dd)
+    _compare_with_oracle(cuda, lg, mk, (48, 80))
