@@ -74,6 +74,12 @@ def parse():
                     help="1 (default): K2 writes the fp32 mask logits of all slots [T, L, HW] - the tensor generate_final_outputs returns "
                          "(vps_temporal_slots.py:144-160) - next to the fused per-pixel slot argmax; 0: argmax-only mode (the step's result is "
                          "the per-pixel slot assignment + class logits; carried by the default line as the `argmax_only` leg)")
+    ap.add_argument("--input-form", choices=["tower16", "nchw_f32"], default="tower16",
+                    help="what the step starts from. tower16 (default, round 4): the semantic tower's own output as 16-bit pixel-major rows "
+                         "[T, Hi*Wi, 128] - what its last GroupNorm + ReLU kernel writes - with conv_trans (a linear 1x1 conv, "
+                         "vps_capsule.py:76-79) folded into K4's weights (K4 reads 256 instead of 512 B per pixel); nchw_f32: the "
+                         "reference's tensors behind conv_trans, [T, 128, Hi, Wi] fp32 (carried by the default line as the "
+                         "`reference_input_tensors` leg)")
     ap.add_argument("--exact-leg", type=int, default=1, help="0 to skip the exact-mode (fp32) leg")
     ap.add_argument("--viper-leg", type=int, default=1, help="0 to skip the informational VIPER (1088x1920 T=10 200 slots) leg")
     ap.add_argument("--whole-detector", type=int, default=1,
@@ -205,7 +211,7 @@ def single_clip_latency(a, dev):
     from slotvps_amd.clip import SlotClipRunner
     from slotvps_amd import synth
     r1 = SlotClipRunner(dev, a.frames, a.height, a.width, L=a.slots, param_seed=0, cfg=dict(synth.R50_HEAD_CFG, num_classes=a.num_classes),
-                        split_p=not a.fast_p, use_graph=True, n_slots=1, clips_per_launch=1)
+                        split_p=not a.fast_p, use_graph=True, n_slots=1, clips_per_launch=1, input_form=a.input_form)
     r1.head.set_retriever(a.retriever)
     r1.load_clip(r1.random_clip(99))
     for _ in range(3):
@@ -257,13 +263,15 @@ def rank_detector_leg(a, dev, iters=3):
         return -1.0
 
 
-def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, precision="bf16", decode_logits=None):
+def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, precision="bf16", decode_logits=None, input_form=None):
     """frames/s of the same graph-replayed step on another configuration (informational legs of the default line)."""
     from slotvps_amd.clip import SlotClipRunner
     from slotvps_amd import synth
     r1 = SlotClipRunner(dev, frames, height, width, L=slots, param_seed=0, cfg=dict(synth.R50_HEAD_CFG, num_classes=num_classes),
                         use_graph=True, n_slots=1, clips_per_launch=cpl,
-                        decode_logits=bool(a.decode_logits) if decode_logits is None else decode_logits)
+                        decode_logits=bool(a.decode_logits) if decode_logits is None else decode_logits,
+                        # (the fp32 / fp16x2 forms of K4 take the reference's fp32 tensors: conv_trans stays in front of them)
+                        input_form="nchw_f32" if precision in ("fp32", "fp16x2") else (input_form or a.input_form))
     r1.head.set_retriever(a.retriever)
     if precision == "fp32":
         r1.head.set_precision("fp32")
@@ -428,7 +436,8 @@ def main():
     from slotvps_amd import synth
     head_cfg = dict(synth.R50_HEAD_CFG, num_classes=a.num_classes)
     runner = SlotClipRunner(dev, T, a.height, a.width, L=a.slots, param_seed=0, cfg=head_cfg, split_p=not a.fast_p,
-                            use_graph=not a.no_graph, n_slots=n_pool, clips_per_launch=cpl, decode_logits=bool(a.decode_logits))
+                            use_graph=not a.no_graph, n_slots=n_pool, clips_per_launch=cpl, decode_logits=bool(a.decode_logits),
+                            input_form=a.input_form)
     runner.head.set_retriever(a.retriever)
     runner.head.set_map_dtype(a.map_dtype)
     HWf = runner.sizes[-1][0] * runner.sizes[-1][1]
@@ -601,7 +610,7 @@ def main():
             e1.record()
             torch.cuda.synchronize(dev)
             return 10 * units * 1024 * (ri + ro) / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        mix_k4, mix_rd, mix_wr = mix_rate(5, 4), mix_rate(1, 0), mix_rate(0, 1)
+        mix_k4, mix_rd, mix_wr, mix_k4_rows = mix_rate(5, 4), mix_rate(1, 0), mix_rate(0, 1), mix_rate(3, 4)
         del src, dst
         roof = {"bound": d["bound"], "achieved": d["hbm_gbs"] if hbm else d["mfma_tflops"],
                 "peak": HBM_PEAK_GBS if hbm else MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm else "TFLOP/s",
@@ -612,10 +621,12 @@ def main():
                 "algorithmic_flops_per_launch_avg": d["algorithmic_flops_per_launch"],
                 "retriever_form": runner.retriever_form,
                 "copy_kernel_ceiling": {"gbps": round(copy_gbs, 1), "own_streaming_kernel_gbps": round(probe_gbs, 1),
-                                        "mix_5_read_4_write_gbps": round(mix_k4, 1), "read_only_gbps": round(mix_rd, 1),
+                                        "mix_5_read_4_write_gbps": round(mix_k4, 1), "mix_3_read_4_write_gbps": round(mix_k4_rows, 1),
+                                        "read_only_gbps": round(mix_rd, 1),
                                         "write_only_gbps": round(mix_wr, 1),
                                         "what": "1 GiB device-to-device, bytes read + written: torch copy / the library's 16-B-per-lane streaming kernel; "
-                                                "svps_probe_mix: level_fuse's 640 B in : 512 B out mix without its arithmetic, and the one-way streams"},
+                                                "svps_probe_mix: level_fuse's 640 B in : 512 B out mix (fp32 NCHW incoming map) and its 384 : 512 mix (the tower's 16-bit rows, "
+                                                "input_form tower16) without its arithmetic, and the one-way streams"},
                 "per_kernel": per}
         if sustain is not None:
             roof["matrix_pipe_sustained"] = {"tflops": sustain["register_operands"]["tflops"],
@@ -643,8 +654,10 @@ def main():
                                    f"decode with fused per-pixel slot argmax ({'argmax-only: the [T, L, HW] fp32 logits are not written' if not a.decode_logits else 'fp32 logits of all slots written'}), "
                                    f"{a.height}x{a.width} T={T} clips, {a.slots} slots, "
                                    f"{cpl} independent clips stacked per launch x {cif} in flight per step, "
-                                   f"synthetic FPN features resident in HBM",
-                       "decode_logits": bool(a.decode_logits),
+                                   + ("synthetic outputs of the semantic tower (16-bit pixel-major rows, as its last GroupNorm + ReLU kernel writes them) "
+                                      "resident in HBM, conv_trans folded into the level fusion's weights" if a.input_form == "tower16" else
+                                      "synthetic level maps behind conv_trans (fp32 NCHW, the reference's tensors) resident in HBM"),
+                       "decode_logits": bool(a.decode_logits), "input_form": a.input_form,
                        "clip_frames": T, "slots": a.slots, "levels": [list(s) for s in runner.sizes],
                        "parallelism": f"clip-parallel x{world}", "world_size": world,
                        "backend": (torch.distributed.get_backend() + " (RCCL)") if world > 1 else "none",
@@ -675,6 +688,18 @@ def main():
                 fl["what"] = ("the same step with the fp32 mask logits of all slots written (generate_final_outputs' full output), hipGraph" if other else
                               "the same step with K2 in argmax-only mode: per-pixel slot assignment (uint8) + class logits, the [T, L, HW] fp32 logits "
                               "are not written (round 3's headline workload; NOT what generate_final_outputs returns), hipGraph")
+                line[key] = fl
+            except Exception as e:
+                line[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+        if world == 1 and a.exact_leg:
+            other_form = "nchw_f32" if a.input_form == "tower16" else "tower16"
+            key = "reference_input_tensors" if other_form == "nchw_f32" else "tower_rows_folded_conv_trans"
+            try:
+                fl = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, input_form=other_form)
+                fl["what"] = ("the same step starting from the reference's own tensors - [T, 128, Hi, Wi] fp32 level maps behind conv_trans "
+                              "(vps_capsule.py:76-79; rounds 1 - 3's headline input): K4 reads 512 instead of 256 B per pixel; hipGraph"
+                              if other_form == "nchw_f32" else
+                              "the same step starting from the semantic tower's 16-bit pixel-major rows, conv_trans folded into K4's weights; hipGraph")
                 line[key] = fl
             except Exception as e:
                 line[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
@@ -778,7 +803,7 @@ def main():
         # the driver's record of a round keeps `config` and `roofline` in full but only the NAMES of other keys: every informational
         # leg's figure is repeated here as a flat number (frames/s unless the key says otherwise)
         legs = {}
-        for key in ("argmax_only", "with_fp32_mask_logits", "reference_precision", "precision_form", "balanced_form", "fp16_level_maps",
+        for key in ("argmax_only", "with_fp32_mask_logits", "reference_input_tensors", "tower_rows_folded_conv_trans", "reference_precision", "precision_form", "balanced_form", "fp16_level_maps",
                     "fp16_level_maps_balanced", "exact_mode", "whole_detector", "whole_detector_per_rank"):
             if isinstance(line.get(key), dict) and line[key].get("value") is not None:
                 legs[key + "_frames_per_s"] = line[key]["value"]

@@ -137,11 +137,12 @@ int svps_kv_project_fwd(const void* feat, const float* pos_y, const float* pos_x
  *     level i > 0:  f_i = conv_trans( cat( interpolate(f_{i-1}, x2, bilinear, align_corners=False), x_i ) )
  *     level 0   :   f_0 = conv_trans( cat( x_0, x_0, x_0 ) )               (prev == NULL)
  *   cur   the incoming 128-channel map: [T, 128, H, W] fp32 NCHW (cur_flags & 1, the reference's
- *         layout) or [T, H*W, 128] bf16 pixel-major
+ *         layout) or [T, H*W, 128] 16-bit pixel-major in the element type of the conv's operands: bf16, or fp16 with
+ *         cur_flags == 2 (round 4: the semantic tower hands its own output over, conv_trans folded into wc / bc by the caller)
  *   prev  [T, (H/2)*(W/2), 256] bf16 pixel-major fused map of the previous (coarser) level, or NULL
  *   wc    [256, 384] bf16 conv_trans weight (row = output channel), bc [256] fp32 bias
  *   out   [T, H*W, 256] bf16 pixel-major
- *   cur_flags & 2: prev, wc and out are FP16 (needs the fp32 NCHW `cur`): the conv and the bilinear blend run on fp16 operands - the
+ *   cur_flags & 2: prev, wc and out are FP16: the conv and the bilinear blend run on fp16 operands - the
  *         same bytes with three more mantissa bits; every consumer of the map then takes SVPS_FLAG_MAP_F16.
  *   cur_flags & 4 (together with & 2): the bf16 storage POLICY in the fp16 ENCODING - wc is bf16, the conv runs on bf16 operands exactly as
  *         in the bf16 form, every value of `out` is rounded to bf16 first and stored as the fp16 number it equals (prev likewise holds bf16
@@ -193,6 +194,11 @@ int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const v
 size_t svps_group_norm_relu_workspace_bytes(int N, int HW, int C);
 int svps_group_norm_relu_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y,
                              float* y_nchw, void* workspace, size_t workspace_bytes, int N, int HW, int C, void* stream);
+/* The same with a third optional result: y16 [N, HW, C] 16-bit pixel-major - bf16, or fp16 (saturating) with y16_is_fp16 - the
+ * form in which the tower's LAST layer hands its output to svps_level_fuse_fwd (16-bit pixel-major `cur`; the linear 1x1 conv_trans
+ * between them, mmdet/models/detectors/vps_capsule.py:76-79, folded into K4's weights by the caller); y, y_nchw, y16: any subset. */
+int svps_group_norm_relu16_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y, float* y_nchw,
+                               void* y16, int y16_is_fp16, void* workspace, size_t workspace_bytes, int N, int HW, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Slot-side helpers (slotvps_amd/csrc/row_ops.hip), rows of D = 256 fp32 values.

@@ -47,6 +47,7 @@ SIGNATURES = {
     "svps_row_softmax_scaled": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "svps_group_norm_relu_workspace_bytes": (_sz, [_i, _i, _i]),
     "svps_group_norm_relu_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "svps_group_norm_relu16_fwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
     "svps_retr_query_prep": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_retr_split": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "svps_slot_self_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -161,6 +161,10 @@ class UPSNetFPN(nn.Module):
                 m.conv_offset.bias.data.zero_()
 
     fuse_norm = True        # pixel-major tower: K7' -> GroupNorm + ReLU (csrc/gn_relu.hip) without layout copies between the layers
+    emit_pm16 = None        # torch.bfloat16 / torch.float16: the last layer also writes its output as 16-bit pixel-major rows, kept in
+    #                         `last_pm16` (per returned level, coarse -> fine; None where the fused tower did not run): what K4 reads
+    #                         when the detector folds conv_trans into K4's weights (VPS_Temporal_Slots.fold_trans)
+    last_pm16 = None
 
     def _tower(self, x):
         """The shared tower on one level. Where every layer runs K7' (fp32-class, C % 64 == 0, 128 / 256 output channels) the
@@ -181,7 +185,7 @@ class UPSNetFPN(nn.Module):
                              and dc.conv.stride == (1, 1) and dc.conv.padding == (1, 1) and dc.conv.dilation == (1, 1)
                              and gn.num_channels % 4 == 0 and 256 % (gn.num_channels // 4) == 0)
         if not ok:
-            return self.deform_convs[0](x)
+            return self.deform_convs[0](x), None
         N, _, H, W = x.shape
         cur_nchw = x.contiguous()
         cur_pm = x.permute(0, 2, 3, 1).contiguous()                       # [N, H, W, C]
@@ -190,14 +194,21 @@ class UPSNetFPN(nn.Module):
             O = dc.conv.weight.shape[0]
             off = dc.conv_offset(cur_nchw)                                # framework 3 x 3 convolution (NCHW in, [N, 18, H, W] out)
             y = deform_conv_fused_pm(cur_pm, off, dc.conv._weight_pack(), O, 1, 1, 1)          # [N, HW, O]
+            if i + 3 >= len(seq) and self.emit_pm16 is not None:          # last layer: NCHW for the semantic logits, 16-bit rows for K4
+                _, y_nchw, y16 = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=True,
+                                                        want_16=self.emit_pm16, want_pm=False)
+                return y_nchw.view(N, O, H, W), y16
             y_pm, y_nchw = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=True)
             cur_pm, cur_nchw = y_pm.view(N, H, W, O), y_nchw.view(N, O, H, W)
-        return cur_nchw
+        return cur_nchw, None
 
     def forward(self, inputs):
         assert len(inputs) == self.num_levels
-        px = [self._tower(inputs[i]) for i in range(self.num_levels)]
-        feat_before = [px[3], px[2], px[1], px[0]] if self.return_feat_levels == 4 else [px[2], px[1], px[0]]
+        both = [self._tower(inputs[i]) for i in range(self.num_levels)]
+        px = [b[0] for b in both]
+        order = [3, 2, 1, 0] if self.return_feat_levels == 4 else [2, 1, 0]
+        feat_before = [px[i] for i in order]
+        self.last_pm16 = [both[i][1] for i in order] if all(both[i][1] is not None for i in order) else None
         ups = [px[0]] + [F.interpolate(px[i], None, 2 ** i, mode="bilinear", align_corners=False) for i in (1, 2, 3)]
         fcn_score = self.conv_pred(torch.cat(ups, dim=1))
         return self.upsample(fcn_score), fcn_score, feat_before

@@ -31,7 +31,7 @@ class SlotClipRunner:
     hipGraph of one clip step. All tensors live on `device`."""
 
     def __init__(self, device, T, H, W, L=100, param_seed=0, cfg=None, split_p=True, use_graph=True, n_slots=1,
-                 clips_per_launch=1, decode_logits=True):
+                 clips_per_launch=1, decode_logits=True, input_form="nchw_f32"):
         if torch.device(device).type != "cuda":
             raise RuntimeError("SlotClipRunner runs on the GPU only; there is no CPU fallback")
         self.device = torch.device(device)
@@ -65,14 +65,36 @@ class SlotClipRunner:
         # n_slots independent input buffer sets, each with its own captured graph: the producer of the
         # FPN maps writes clip i straight into slot i % n_slots, so no staging copy sits in the step
         self.n_slots = n_slots
-        self.slots_feats = [[torch.zeros((T, 128, h, w), device=self.device) for (h, w) in self.sizes]
-                            for _ in range(n_slots)]
-        self.static_feats = self.slots_feats[0]
+        # input_form: "nchw_f32" - the reference's tensors, [T, 128, Hi, Wi] fp32 behind conv_trans (vps_capsule.py:76-79); "tower16" -
+        # the semantic tower's OWN output as 16-bit pixel-major rows [T, Hi*Wi, 128] (what its last GroupNorm + ReLU kernel writes,
+        # csrc/gn_relu.hip) with conv_trans, a linear 1x1 conv, folded into K4's weights: K4 reads 256 instead of 512 B per pixel
+        if input_form not in ("nchw_f32", "tower16"):
+            raise ValueError(f"input_form {input_form!r}")
+        self.input_form = input_form
+        self.pre_linear = None
+        if input_form == "tower16":
+            g = torch.Generator().manual_seed(param_seed + 2)
+            c = self.cfg["trans_in_dim"] - self.cfg["dh_dim"]
+            self.pre_linear = (nn.Parameter((torch.randn(c, c, 1, 1, generator=g) * (2.0 / c) ** 0.5).to(self.device), requires_grad=False),
+                               nn.Parameter((torch.randn(c, generator=g) * 0.1 - 0.45).to(self.device), requires_grad=False))
+        self._alloc_inputs()
         self.use_graph = use_graph
         self.graphs = [None] * n_slots
         self.validation_reports = []                      # graph validations that failed and were repeated (run())
         self.outs = [None] * n_slots
         self.out = None
+
+    def _input_dtype(self):
+        if self.input_form == "nchw_f32":
+            return torch.float32
+        return torch.float16 if self.head._map_form() == "fp16" else torch.bfloat16
+
+    def _alloc_inputs(self):
+        dt = self._input_dtype()
+        shape = (lambda h, w: (self.T, 128, h, w)) if self.input_form == "nchw_f32" else (lambda h, w: (self.T, h * w, 128))
+        self.slots_feats = [[torch.zeros(shape(h, w), dtype=dt, device=self.device) for (h, w) in self.sizes] for _ in range(self.n_slots)]
+        self.static_feats = self.slots_feats[0]
+        self.graphs = [None] * self.n_slots
 
     def refold(self):
         """Fold the eval BatchNorms into the scalars / vectors K2 takes (host floats: no sync per step)."""
@@ -82,8 +104,8 @@ class SlotClipRunner:
             self.fg_scale, self.fg_shift = float(fs.item()), float(fb.item())
 
     def _step(self, slot=0):
-        logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs,
-                                                       clip_frames=self.clip_frames)
+        logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs, hws=self.sizes,
+                                                       clip_frames=self.clip_frames, pre_linear=self.pre_linear)
         if fused[-1].dim() == 4:                             # precision "fp16x2": the map as fp16 hi + lo planes; the logits are always written
             masks, amax = ops.mask_decode_hl(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift, self.fg_scale, self.fg_shift,
                                              want_argmax=True)
@@ -103,6 +125,8 @@ class SlotClipRunner:
         return out
 
     def load_clip(self, feats, slot=0):
+        if self.slots_feats[slot][0].dtype != self._input_dtype():         # the head's map dtype was switched: the rows follow it
+            self._alloc_inputs()
         for dst, src in zip(self.slots_feats[slot], feats):
             dst.copy_(src)
 
@@ -168,6 +192,8 @@ class SlotClipRunner:
 
     def random_clip(self, seed):
         g = torch.Generator(device=self.device).manual_seed(seed)
+        if self.input_form == "tower16":                                   # behind a ReLU: non-negative rows
+            return [torch.randn((self.T, h * w, 128), generator=g, device=self.device).relu_().to(self._input_dtype()) for (h, w) in self.sizes]
         return [torch.randn((self.T, 128, h, w), generator=g, device=self.device) for (h, w) in self.sizes]
 
     # ---- algorithmic accounting ------------------------------------------------
@@ -196,7 +222,8 @@ class SlotClipRunner:
                             flops: 4 * L * D (logits + attn.v; the hi / lo splits are not algorithmic)
           kv_project (K3)   bytes: 512 in + 1024 out; flops 4 * D^2
           slot_attn  (K1)   bytes: 1024 in (+ q, out per frame-stage); flops 4 * L * D
-          level_fuse (K4)   bytes: 512 (fp32 NCHW map) in + 512 out (+ 128 of the 4x smaller previous level); flops 2 * 384 * D
+          level_fuse (K4)   bytes: 512 (fp32 NCHW map; 256 for the tower's 16-bit rows, input_form "tower16") in + 512 out (+ 128 of the 4x
+                            smaller previous level); flops 2 * 384 * D
           mask_decode (K2)  bytes: 512 in + 4 L + 1 out (finest level only); flops 2 * L * D"""
         D, L, T = self.cfg["dh_dim"], self.L, self.T
         px = [h * w for (h, w) in self.sizes]
@@ -218,7 +245,8 @@ class SlotClipRunner:
                               "executed_flops": T * ps * ((4 * 32 + 4 * 26) * 32768 // 16)},
             }
         out = {
-            "level_fuse": {"bytes": T * sum(hw * (1024 + (128 if i else 0)) for i, hw in enumerate(px)), "flops": T * sum(px) * 2 * 384 * D},
+            "level_fuse": {"bytes": T * sum(hw * ((768 if self.input_form == "tower16" else 1024) + (128 if i else 0)) for i, hw in enumerate(px)),
+                           "flops": T * sum(px) * 2 * 384 * D},
             # executed: 32 MFMA 32x32x16 per 32-pixel tile and wave (e as bf16 hi + lo), 4 waves (8 for more than 128 slots)
             "mask_decode": {"bytes": T * px[-1] * (512 + (4 * L if self.decode_logits else 0) + 1), "flops": T * px[-1] * 2 * L * D,
                             "executed_flops": T * px[-1] * ((4 if L <= 128 else 8) * 32 * 32768 // 32)},

@@ -86,8 +86,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // tile = 32 consecutive pixels x C channels; LDS [32][C + 1] floats for the NCHW copy
+// y16 (nullable): the same values as 16-bit pixel-major rows - bf16 (f16 == 0) or fp16 (saturating at +-65 504) - the form in which
+// the tower's LAST layer hands its output to K4 (conv_trans folded into K4's weights); y (nullable) the fp32 rows the next K7' reads
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float2* __restrict__ ab, float* __restrict__ y,
-                                                       float* __restrict__ y_nchw, int HW, int C, int tiles_per_wg) {
+                                                       float* __restrict__ y_nchw, void* __restrict__ y16, int f16, int HW, int C,
+                                                       int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const int n = blockIdx.y, tid = threadIdx.x;
     const int cols = C >> 2, rows = 256 / cols;
@@ -117,7 +120,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                     f32x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = fmaxf(fmaf(a4[j], v[j], b4[j]), 0.f);
-                    *reinterpret_cast<f32x4*>(y + off) = o;
+                    if (y) *reinterpret_cast<f32x4*>(y + off) = o;
+                    if (y16) {
+                        uint2 pk;
+                        if (f16) {
+                            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                            h4 q;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) q[j] = (_Float16)fminf(o[j], 65504.f);
+                            pk = __builtin_bit_cast(uint2, q);
+                        } else {
+                            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+                            b4 q;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) q[j] = (__bf16)o[j];
+                            pk = __builtin_bit_cast(uint2, q);
+                        }
+                        *reinterpret_cast<uint2*>(static_cast<char*>(y16) + off * 2) = pk;
+                    }
                     if (y_nchw) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) tile[q * ldc + 4 * cc + j] = o[j];
@@ -156,7 +176,14 @@ extern "C" size_t svps_group_norm_relu_workspace_bytes(int N, int HW, int C) {
 
 extern "C" int svps_group_norm_relu_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y,
                                         float* y_nchw, void* workspace, size_t workspace_bytes, int N, int HW, int C, void* stream_) {
-    if (!x || !gamma || !beta || !y || !workspace) return SVPS_ERR_BAD_ARG;
+    if (!y) return SVPS_ERR_BAD_ARG;
+    return svps_group_norm_relu16_fwd(x, gamma, beta, groups, eps, y, y_nchw, nullptr, 0, workspace, workspace_bytes, N, HW, C, stream_);
+}
+
+extern "C" int svps_group_norm_relu16_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y,
+                                          float* y_nchw, void* y16, int y16_is_fp16, void* workspace, size_t workspace_bytes, int N,
+                                          int HW, int C, void* stream_) {
+    if (!x || !gamma || !beta || !workspace || (!y && !y_nchw && !y16)) return SVPS_ERR_BAD_ARG;
     if (N <= 0 || HW <= 0 || C <= 0 || (C & 3) || C > 1024 || groups <= 0 || groups > 256 || C % groups) return SVPS_ERR_BAD_SHAPE;
     if (256 % (C >> 2)) return SVPS_ERR_BAD_SHAPE;                           // float4 columns of a pixel row must divide the workgroup
     if (workspace_bytes < svps_group_norm_relu_workspace_bytes(N, HW, C)) return SVPS_ERR_WORKSPACE;
@@ -175,6 +202,7 @@ extern "C" int svps_group_norm_relu_fwd(const float* x, const float* gamma, cons
     static SvpsLdsAttr attr;
     if (lds > 48 * 1024)
         if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(svps::gn_apply_kernel), (int)lds); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(svps::gn_apply_kernel, dim3(wgs, N), dim3(256), lds, stream, x, (const float2*)ab, y, y_nchw, HW, C, tpw);
+    hipLaunchKernelGGL(svps::gn_apply_kernel, dim3(wgs, N), dim3(256), lds, stream, x, (const float2*)ab, y, y_nchw, y16, y16_is_fp16, HW,
+                       C, tpw);
     return (int)hipGetLastError();
 }

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the maps and of the conv operands (common.h)
     typedef MT mx4 __attribute__((ext_vector_type(4)));
-    static_assert(NCHW_F32 || __is_same(MT, __bf16), "a pixel-major 16-bit incoming map is bf16");
+    // a pixel-major 16-bit incoming map has the element type of the conv's operands in level_fuse_kernel_v4: MT, but bf16 in the BP
+    // form (here re-encoded on the way into the operand tile, like the weights)
     using Lds = FuseLds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -153,6 +154,13 @@ __global__ __launch_bounds__(512) void level_fuse_kernel(
             int pp = px0 + px;
             pp = pp < HW ? pp : HW - 1;
             p.cb = *reinterpret_cast<const u32x4*>(static_cast<const MT*>(cur_) + ((size_t)t * HW + pp) * 128 + 8 * ck);
+            if constexpr (BP) {
+                const bf16x8 xb = __builtin_bit_cast(bf16x8, p.cb);
+                mx8 xm;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xm[j] = to_map<MT, false>((float)xb[j]);
+                p.cb = __builtin_bit_cast(u32x4, xm);
+            }
         }
         if constexpr (!LEVEL0) {
             const int px = tid >> 4, ck = tid & 15;                    // chunks ck and ck + 16
@@ -660,7 +668,7 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     typedef OT ox8 __attribute__((ext_vector_type(8)));
     typedef OT ox4 __attribute__((ext_vector_type(4)));
     const OT* wc = static_cast<const OT*>(wc_);
-    static_assert(NCHW_F32 || __is_same(MT, __bf16), "a pixel-major 16-bit incoming map is bf16");
+    // (a pixel-major 16-bit incoming map is copied into the operand tile as it is: its element type is OT)
     using Lds = Fuse4Lds;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1098,7 +1106,6 @@ extern "C" int svps_level_fuse_fwd(const void* cur, int cur_flags, const void* p
     if (!cur || !wc || !bc || !out) return SVPS_ERR_BAD_ARG;
     const bool cur_is_nchw_f32 = cur_flags & 1;
     const bool maps_f16 = cur_flags & 2;                       // prev, wc and out are fp16 (three more mantissa bits in the same bytes)
-    if (maps_f16 && !cur_is_nchw_f32) return SVPS_ERR_BAD_ARG;    // a 16-bit pixel-major incoming map is bf16
     if (T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;   // 32-bit buffer offsets inside a frame
     if (prev && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;   // x2 upsampling: even sizes
@@ -1110,14 +1117,22 @@ extern "C" int svps_level_fuse_fwd(const void* cur, int cur_flags, const void* p
     const bool fast = prev && (W & 31) == 0 && (size_t)H * W * 512 < 0x7fffffffu && !legacy;
     static const bool v2 = getenv("SVPS_K4_V2") != nullptr;          // comparison runs: the eight-wave form of round 2
     const bool bf16_values = cur_flags & 4;                    // fp16 encoding, bf16 rounding points (the bf16 storage policy; see to_map)
-    if (maps_f16 && bf16_values)
+    if (maps_f16 && bf16_values && cur_is_nchw_f32)
         e = fast ? launch_fuse_v4<_Float16, true, true>(cur, prev, wc, bc, out, T, H, W, stream)
             : prev ? launch_fuse<_Float16, true, false, true>(cur, prev, wc, bc, out, T, H, W, stream)
                    : launch_fuse<_Float16, true, true, true>(cur, prev, wc, bc, out, T, H, W, stream);
-    else if (maps_f16)
+    else if (maps_f16 && bf16_values)                          // pixel-major incoming map: bf16 (the conv's operand type in this form)
+        e = fast ? launch_fuse_v4<_Float16, false, true>(cur, prev, wc, bc, out, T, H, W, stream)
+            : prev ? launch_fuse<_Float16, false, false, true>(cur, prev, wc, bc, out, T, H, W, stream)
+                   : launch_fuse<_Float16, false, true, true>(cur, prev, wc, bc, out, T, H, W, stream);
+    else if (maps_f16 && cur_is_nchw_f32)
         e = fast ? launch_fuse_v4<_Float16, true>(cur, prev, wc, bc, out, T, H, W, stream)
             : prev ? launch_fuse<_Float16, true, false>(cur, prev, wc, bc, out, T, H, W, stream)
                    : launch_fuse<_Float16, true, true>(cur, prev, wc, bc, out, T, H, W, stream);
+    else if (maps_f16)                                         // pixel-major incoming map: fp16
+        e = fast ? launch_fuse_v4<_Float16, false>(cur, prev, wc, bc, out, T, H, W, stream)
+            : prev ? launch_fuse<_Float16, false, false>(cur, prev, wc, bc, out, T, H, W, stream)
+                   : launch_fuse<_Float16, false, true>(cur, prev, wc, bc, out, T, H, W, stream);
     else if (fast && !v2)
         e = cur_is_nchw_f32 ? launch_fuse_v4<__bf16, true>(cur, prev, wc, bc, out, T, H, W, stream)
                             : launch_fuse_v4<__bf16, false>(cur, prev, wc, bc, out, T, H, W, stream);

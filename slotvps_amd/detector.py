@@ -36,6 +36,23 @@ class _AttrDict(dict):
     __getattr__ = dict.get
 
 
+class LevelMaps(list):
+    """The level maps the trunk hands to the slot head, coarse -> fine. `hws` their sizes; `folded`: the maps are the semantic tower's OWN
+    output as 16-bit pixel-major rows [T, Hi*Wi, 128] and conv_trans (vps_capsule.py:76-79, a linear 1x1 conv) is still to be
+    applied - the head folds it into K4's weights; otherwise [T, 128, Hi, Wi] fp32 maps behind conv_trans, the reference's tensors."""
+    hws = None
+    folded = False
+
+    @staticmethod
+    def cat(a, b):
+        """Frames of `a` followed by the frames of `b` (same geometry, same form)."""
+        out = LevelMaps(torch.cat([x, y], 0) for x, y in zip(a, b))
+        out.hws = getattr(a, "hws", None) or [tuple(x.shape[-2:]) for x in a]
+        out.folded = bool(getattr(a, "folded", False))
+        assert out.folded == bool(getattr(b, "folded", False))
+        return out
+
+
 class SlotMasks:
     """Mask logits of a clip, decoded on demand (K2). The reference materialises `pred_masks` for all L slots
     ([L, h, w] fp32 per frame, vps_temporal_slots.py:297-308) and its post-process then keeps the few slots whose class
@@ -284,6 +301,10 @@ class VPS_Temporal_Slots(nn.Module):
         self.decode_selected = True              # K2 decodes only the slots the post-process keeps (SlotMasks)
         self.clip_postprocess = True             # clip_test: post-process + tracker of all frames in lock-step (_clip_results)
         self.use_graph = False                   # replay the slot head as one hipGraph per input geometry (_head_clip)
+        # conv_trans folded into K4's weights (round 4): the semantic tower's last GroupNorm + ReLU writes its output as 16-bit
+        # pixel-major rows and K4 reads THOSE (256 instead of 512 B per pixel, no framework conv, no layout copy in between). Applies in
+        # the 16-bit precision of the head with the pixel-major tower (fp32 trunk); otherwise the reference's tensors as before
+        self.fold_trans = True
         self._head_cache = {}
         self._trunk_bf16 = False
         self._ref_cache = None
@@ -331,13 +352,26 @@ class VPS_Temporal_Slots(nn.Module):
         im = self.image_model
         # trunk_bf16: PyTorch autocast (bf16 convolutions / GEMMs, fp32 normalisation layers) around the PyTorch part;
         # off by default: the reference's trunk is fp32
+        head = im.dynamic_mask_head
+        pf = im.panopticFPN
+        want16 = None
+        if self.fold_trans and head.precision == "bf16" and hasattr(pf, "emit_pm16"):
+            want16 = torch.float16 if head._map_form() == "fp16" else torch.bfloat16
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.trunk_bf16):
             x = im.backbone(imgs)
             if im.with_neck:
                 x = im.neck(x)
+            if hasattr(pf, "emit_pm16"):
+                pf.emit_pm16 = want16
             fcn_output, _, fcn_feature = self.extract_semantic_feats(x)
-            feats = self.semantic_trans_ins(fcn_feature)
-        return [f.float().contiguous() for f in feats], fcn_output.float()
+            pm16 = pf.last_pm16 if want16 is not None else None
+            if pm16 is None:
+                feats = LevelMaps(f.float().contiguous() for f in self.semantic_trans_ins(fcn_feature))
+            else:
+                feats = LevelMaps(pm16)
+                feats.folded = True
+            feats.hws = [tuple(f.shape[-2:]) for f in fcn_feature]
+        return feats, fcn_output.float()
 
     def _head_clip(self, feats):
         """The slot head on one clip's level maps; with `use_graph` the whole head (about 200 launches) is captured once per
@@ -347,16 +381,20 @@ class VPS_Temporal_Slots(nn.Module):
         # The captured graph bakes in pointers to weight-DERIVED tensors (packed K8 weights, QR factors, position tables) and the
         # kernel choices of the current modes: key it on the identity + version of every head parameter and on the mode switches,
         # so load_state_dict / in-place edits / set_precision / set_retriever / set_slot_gemm / the ops-level forms re-capture.
-        wkey = tuple((p_.data_ptr(), p_._version) for p_ in head.parameters()) + (im.init_mask_query.weight.data_ptr(), im.init_mask_query.weight._version)
+        hws = getattr(feats, "hws", None) or [tuple(f.shape[-2:]) for f in feats]
+        folded = bool(getattr(feats, "folded", False))
+        pre = (im.conv_trans.conv.weight, im.conv_trans.conv.bias) if folded else None
+        wkey = tuple((p_.data_ptr(), p_._version) for p_ in head.parameters()) + (im.init_mask_query.weight.data_ptr(), im.init_mask_query.weight._version) \
+            + (tuple((p_.data_ptr(), p_._version) for p_ in pre if p_ is not None) if folded else ())
         modes = tuple(sorted({(type(m).__name__, getattr(m, "precision", None), getattr(m, "retriever", None), getattr(m, "use_slot_gemm", None), getattr(m, "tight_stats", None), getattr(m, "precise_query_p", None), getattr(m, "query_side", None), getattr(m, "map_dtype", None), getattr(m, "map_encoding", None), getattr(m, "range_check", None))
                               for m in head.modules() if hasattr(m, "precision")})) + (ops.RETR_STATS_FORM,)
-        key = tuple(tuple(f.shape) for f in feats) + (str(feats[0].device), hash(wkey), modes)
+        key = tuple(tuple(f.shape) for f in feats) + (str(feats[0].device), str(feats[0].dtype), folded, tuple(hws), hash(wkey), modes)
         ent = self._head_cache.get(key)
         if ent is None:
             D = im.init_mask_query.weight.shape[1]
-            ent = {"pos": [ops.pos_embed_sine_tables(f.shape[-2], f.shape[-1], D, f.device) for f in feats], "graph": None}
+            ent = {"pos": [ops.pos_embed_sine_tables(h_, w_, D, feats[0].device) for (h_, w_) in hws], "graph": None}
             self._head_cache = {key: ent}                    # one geometry at a time
-        run = lambda fs: im.dynamic_mask_head.forward_clip(fs, im.init_mask_query.weight, ent["pos"])
+        run = lambda fs: im.dynamic_mask_head.forward_clip(fs, im.init_mask_query.weight, ent["pos"], hws=hws, pre_linear=pre)
         if not self.use_graph:
             return run(feats)
         if ent["graph"] is None:
@@ -401,7 +439,8 @@ class VPS_Temporal_Slots(nn.Module):
         Mask logits: `SlotMasks` (decoded per frame for the slots the post-process keeps) or, with dense=True /
         self.decode_selected = False, the reference's [T, L, H/4, W/4] tensor of all slots."""
         logits, embeds, fused = self._head_clip(feats)
-        masks = SlotMasks(fused[-1], embeds[-1].contiguous(), self._decode_fold(), tuple(feats[-1].shape[-2:]))
+        hw = feats.hws[-1] if getattr(feats, "hws", None) else tuple(feats[-1].shape[-2:])
+        masks = SlotMasks(fused[-1], embeds[-1].contiguous(), self._decode_fold(), tuple(hw))
         if dense is None:
             dense = not self.decode_selected
         return logits[-1], embeds[-1], masks.dense() if dense else masks
@@ -476,7 +515,7 @@ class VPS_Temporal_Slots(nn.Module):
         else:
             ref_feats, _ = self.trunk(ref_img)
         self._ref_cache = (img.clone(), cur_feats)
-        logits, embeds, masks = self.head_path([torch.cat([r, c], 0) for r, c in zip(ref_feats, cur_feats)])
+        logits, embeds, masks = self.head_path(LevelMaps.cat(ref_feats, cur_feats))
         return self._frame_result(logits[1], masks[1], embeds[1], fcn, meta["ori_shape"], self.fid == 1)
 
     @torch.no_grad()

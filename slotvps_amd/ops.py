@@ -195,10 +195,10 @@ def kv_project(feat, H, W, pos_tabs, wk, bk, lnk_w, lnk_b, lnk_eps, wv, bv, lnv_
 
 def level_fuse(cur, prev, wc, bc, H, W, bf16_values=False):
     """K4: fused level map [T, H*W, 256] bf16 = conv1x1(cat(bilinear_x2(prev), cur)) (+ level-0 form when
-    prev is None). cur: [T, 128, H, W] fp32 (NCHW, the reference's layout) or [T, H*W, 128] bf16;
-    prev: [T, (H/2)*(W/2), 256] bf16; wc [256, 384] bf16; bc [256] fp32.
+    prev is None). cur: [T, 128, H, W] fp32 (NCHW, the reference's layout) or [T, H*W, 128] 16-bit pixel-major in the element type of
+    the conv's operands (= wc's dtype); prev: [T, (H/2)*(W/2), 256] bf16; wc [256, 384] bf16; bc [256] fp32.
     (MultiScaleDynamicMaskHead.forward lines 171-188 of the reference's dynamic_mask_head.py.)
-    wc (and prev) fp16: the fp16 form - operands, previous level and result fp16 (cur must be the fp32 NCHW map).
+    wc (and prev) fp16: the fp16 form - operands, previous level and result fp16.
     bf16_values (fp16 form only): every rounding point rounds to bf16 and the value is stored in the fp16 encoding - the bf16 storage
     policy, bit for bit above fp16's subnormal range, in the encoding the consumers' matrix instructions take directly."""
     lib = _lib.load()
@@ -211,15 +211,13 @@ def level_fuse(cur, prev, wc, bc, H, W, bf16_values=False):
             raise ValueError(f"cur {tuple(cur.shape)} != [T, 128, {H}, {W}]")
         nchw = 1
     else:
-        _need(cur, "cur", torch.bfloat16, 3)
+        _need(cur, "cur", wc.dtype, 3)
         T = cur.shape[0]
         if cur.shape != (T, H * W, 128):
             raise ValueError(f"cur {tuple(cur.shape)} != [T, {H * W}, 128]")
         nchw = 0
     # bf16_values: bf16 weights, fp16-ENCODED previous level and result (bf16 values); otherwise the maps have the weight's type
     mdt = torch.float16 if (wc.dtype == torch.float16 or bf16_values) else torch.bfloat16
-    if mdt == torch.float16 and not nchw:
-        raise ValueError("level_fuse: the fp16 form takes the fp32 NCHW incoming map")
     _need(wc, "wc", torch.bfloat16 if bf16_values else mdt, 2)
     _need(bc, "bc", torch.float32, 1)
     if wc.shape != (256, 384):
@@ -282,10 +280,11 @@ def row_softmax(x, inplace=False, scale=1.0):
     return out
 
 
-def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False):
+def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False, want_16=None, want_pm=True):
     """relu(GroupNorm(groups)(x)) for pixel-major fp32 activations x [N, HW, C] (csrc/gn_relu.hip) -> (y [N, HW, C], y_nchw [N, C, HW]
     or None): the normalisation of the semantic tower in the layout of the deformable-convolution kernel, optionally also in the
-    layout the framework's convolutions take."""
+    layout the framework's convolutions take. want_16 = torch.bfloat16 / torch.float16: a third result, the same values as 16-bit
+    pixel-major rows (what K4 takes as its incoming map); want_pm = False drops the fp32 rows (the tower's last layer)."""
     lib = _lib.load()
     _need(x, "x", torch.float32, 3)
     N, HW, C = x.shape
@@ -293,14 +292,19 @@ def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False):
     _need(beta, "beta", torch.float32, 1)
     if gamma.numel() != C or beta.numel() != C:
         raise ValueError("group_norm_relu_pm: affine parameters do not match C")
-    y = torch.empty_like(x)
+    if want_16 not in (None, torch.bfloat16, torch.float16):
+        raise ValueError("group_norm_relu_pm: want_16 is torch.bfloat16, torch.float16 or None")
+    y = torch.empty_like(x) if want_pm else None
     yn = torch.empty((N, C, HW), dtype=torch.float32, device=x.device) if want_nchw else None
+    y16 = torch.empty((N, HW, C), dtype=want_16, device=x.device) if want_16 is not None else None
     ws_bytes = lib.svps_group_norm_relu_workspace_bytes(N, HW, C)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
-    with _on(x, gamma, beta, y, yn, ws) as ctx:
-        rc = lib.svps_group_norm_relu_fwd(_ptr(x), _ptr(gamma), _ptr(beta), int(groups), float(eps), _ptr(y), _ptr(yn), _ptr(ws),
-                                          ws_bytes, N, HW, C, ctx.stream)
-    _lib.check(rc, "svps_group_norm_relu_fwd")
+    with _on(x, gamma, beta, y, yn, y16, ws) as ctx:
+        rc = lib.svps_group_norm_relu16_fwd(_ptr(x), _ptr(gamma), _ptr(beta), int(groups), float(eps), _ptr(y), _ptr(yn), _ptr(y16),
+                                            int(want_16 == torch.float16), _ptr(ws), ws_bytes, N, HW, C, ctx.stream)
+    _lib.check(rc, "svps_group_norm_relu16_fwd")
+    if want_16 is not None:
+        return y, yn, y16
     return y, yn
 
 

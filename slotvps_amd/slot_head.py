@@ -805,23 +805,45 @@ class MultiScaleDynamicMaskHead(nn.Module):
         if getattr(self, "map_dtype", "bf16") == "fp16":
             return "fp16"
         mdcs = [m for m in self.modules() if hasattr(m, "retriever")]
-        if (self.map_encoding == "bf16" or (cur is not None and (cur.dim() != 4 or cur.dtype == BF16))
-                or any(m.retriever != "fused" or m.range_check or m.norm_v.eps < 4e-6 for m in mdcs)):
+        if self.map_encoding == "bf16" or any(m.retriever != "fused" or m.range_check or m.norm_v.eps < 4e-6 for m in mdcs):
             return "bf16"
         return "bf16_in_fp16"
 
-    def _conv_weights(self, form=None):
+    def _conv_weights(self, form=None, pre=None, level0=False):
+        """K4's weight [256, 384] and bias in the operand type of `form`. pre = (W_t [128, 128], b_t [128] or None): a linear 1x1 map
+        x = W_t y + b_t in front of the head (the detector's conv_trans, vps_capsule.py:76-79) FOLDED into them, so that K4 reads y
+        itself: the x columns become W_x W_t (composed in float64), the bias b + W_x b_t. The shared conv then has two forms: a level
+        with a previous map multiplies x by columns 256 .. 383 only, level 0 (cat(x, x, x), :171-176) by all three blocks."""
         conv = self.conv_trans.conv
         form = form or self._map_form()
-        key = (conv.weight._version, conv.weight.data_ptr(), form)
-        if getattr(self, "_cw_key", None) != key:
+        key = (conv.weight._version, conv.weight.data_ptr(), form, bool(level0)) + \
+            (() if pre is None else tuple((t.data_ptr(), t._version) for t in pre if t is not None))
+        cache = self.__dict__.setdefault("_cw_cache", {})
+        ent = cache.get(key)
+        if ent is None:
             w = conv.weight.detach().reshape(self.dh_dim, self.trans_in_dim)
-            if form == "fp16":
-                self._cw = w.to(torch.float16).contiguous()
-            else:                                                             # (bf16 weights in the bf16-in-fp16 form as well)
-                self._cw = w.to(BF16).contiguous()
-            self._cw_key = key
-        return self._cw, conv.bias
+            b = conv.bias
+            if pre is not None:
+                wt = pre[0].detach().reshape(pre[0].shape[0], -1).double()
+                if wt.shape[0] != self.trans_in_dim - self.dh_dim:
+                    raise ValueError(f"pre_linear maps to {wt.shape[0]} channels, K4's incoming map has {self.trans_in_dim - self.dh_dim}")
+                if wt.shape[1] != wt.shape[0]:
+                    raise NotImplementedError("pre_linear must keep the channel count (K4 reads a 128-channel incoming map)")
+                wd = w.double()
+                n = wt.shape[0]
+                blocks = range(0, self.trans_in_dim, n) if level0 else [self.dh_dim]
+                wx_sum = sum(wd[:, o:o + n] for o in blocks)
+                wd = wd.clone()
+                for o in blocks:
+                    wd[:, o:o + n] = wd[:, o:o + n] @ wt
+                w = wd.float()
+                if pre[1] is not None:
+                    b = (conv.bias.detach().double() + wx_sum @ pre[1].detach().double()).float()
+            ent = (w.to(torch.float16 if form == "fp16" else BF16).contiguous(), b)     # (bf16 weights in the bf16-in-fp16 form as well)
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = ent
+        return ent
 
     def set_map_dtype(self, dtype):
         """bf16 mode: storage of the fused level maps (and operand type of the level-fusion conv). "bf16" (default, BASELINE's
@@ -837,10 +859,12 @@ class MultiScaleDynamicMaskHead(nn.Module):
         self.map_dtype = dtype
         return self
 
-    def fuse_level(self, cur, prev_pm, hw, last=False):
-        """K4 (:171-188). cur [T, 128, H, W] fp32 (the reference's layout) or [T, H*W, 128] bf16;
-        prev_pm [T, (H/2)*(W/2), 256] bf16 fused map of the coarser level or None (level 0).
-        Returns the fused map [T, H*W, 256] bf16 pixel-major."""
+    def fuse_level(self, cur, prev_pm, hw, last=False, pre=None):
+        """K4 (:171-188). cur [T, 128, H, W] fp32 (the reference's layout) or [T, H*W, 128] 16-bit pixel-major (bf16; fp16 with
+        map_dtype "fp16"); prev_pm [T, (H/2)*(W/2), 256] fused map of the coarser level or None (level 0); pre: see _conv_weights.
+        Returns the fused map [T, H*W, 256] pixel-major."""
+        if pre is not None and self.precision != "bf16":
+            raise NotImplementedError("a folded pre_linear needs the 16-bit level fusion (precision 'bf16')")
         if self.precision == "fp32":
             conv = self.conv_trans.conv
             wT = _cached(self, "cwT", [conv.weight], lambda: conv.weight.reshape(self.dh_dim, self.trans_in_dim).t().contiguous())
@@ -861,19 +885,21 @@ class MultiScaleDynamicMaskHead(nn.Module):
         form = self._map_form(cur)
         if prev_pm is not None and form != "fp16":                       # a level follows the encoding of the level below it
             form = "bf16_in_fp16" if prev_pm.dtype == torch.float16 else "bf16"
-        wc, bc = self._conv_weights(form)
-        if cur.dtype not in (torch.float32, BF16) or (form != "bf16" and cur.dtype != torch.float32):
-            cur = cur.float()
-        if form != "bf16" and cur.dim() != 4:
-            raise NotImplementedError("map_dtype='fp16' takes the incoming maps as [T, 128, H, W] (NCHW)")
+        wc, bc = self._conv_weights(form, pre, level0=prev_pm is None)
+        if cur.dim() == 4:
+            cur = cur.float()                                              # NCHW: the reference's fp32 map
+        elif cur.dtype != wc.dtype:
+            cur = cur.to(wc.dtype)                                         # pixel-major rows: the conv's operand type
         return ops.level_fuse(cur.contiguous(), prev_pm, wc, bc, hw[0], hw[1], bf16_values=form == "bf16_in_fp16")
 
-    def forward_clip(self, feats, init_slots, pos_tabs, hws=None, clip_frames=None):
+    def forward_clip(self, feats, init_slots, pos_tabs, hws=None, clip_frames=None, pre_linear=None):
         """Batched clip entry. clip_frames: frames per clip when several clips of equal length are stacked along T
         (T % clip_frames == 0): every kernel then covers all of them in one launch and the temporal slot attention
         stays inside each clip. None = one clip of T frames (the reference's call).
         feats: list over the 4 levels (coarse -> fine) of [T, 128, Hi, Wi] fp32 (NCHW, the reference's
-        layout) or [T, Hi*Wi, 128] bf16 pixel-major (then hws = [(Hi, Wi)] is required); init_slots [L, 256];
+        layout) or [T, Hi*Wi, 128] 16-bit pixel-major (then hws = [(Hi, Wi)] is required); pre_linear = (W_t, b_t): a linear 1x1 map
+        in front of the head folded into K4's weights (_conv_weights: the detector's conv_trans - the feats are then ITS input, the
+        semantic tower's own output); init_slots [L, 256];
         pos_tabs: per level the separable sine tables (ytab [Hi, 128], xtab [Wi, 128]) of
         ops.pos_embed_sine_tables, or None for no position embedding.
         Returns logits [S, T, L, nc], embeds [S, T, L, 256], fused list of [T, Hi*Wi, 256] bf16 (fp32 in exact mode; precision "fp16x2":
@@ -903,7 +929,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 h, w = feats[i].shape[-2:]
             else:
                 h, w = hws[i]
-            f_pm = self.fuse_level(feats[i], prev, (h, w), last=i == self.feat_num_levels - 1)
+            f_pm = self.fuse_level(feats[i], prev, (h, w), last=i == self.feat_num_levels - 1, pre=pre_linear)
             series = getattr(self, f"head_series_{i}")
             mdcs = [stage.inst_interact for stage in series]
             if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16) and f_pm.dim() == 3

@@ -294,9 +294,20 @@ def test_pixel_major_tower_equals_module_sequence(cuda):
     x = torch.randn(2, 256, 24, 40, device=cuda)
     with torch.no_grad():
         tower.fuse_norm = True
-        a = tower._tower(x)
+        a, none16 = tower._tower(x)
         tower.fuse_norm = False
-        b = tower._tower(x)
+        b, _ = tower._tower(x)
+        tower.fuse_norm = True
+        outs = {}
+        for dt in (torch.bfloat16, torch.float16):                 # the last layer's 16-bit pixel-major rows (what K4 reads when
+            tower.emit_pm16 = dt                                   # conv_trans is folded): the same values, rounded once
+            outs[dt] = tower._tower(x)
+        tower.emit_pm16 = None
     torch.cuda.synchronize()
+    assert none16 is None
     assert a.shape == b.shape == (2, 128, 24, 40)
     assert float((a - b).abs().max()) < 2e-4 * max(1.0, float(b.abs().max()))
+    for dt, (nchw, y16) in outs.items():
+        assert float((nchw - a).abs().max()) < 1e-4 * max(1.0, float(a.abs().max()))   # (the offset convs are not run-to-run identical)
+        assert y16.dtype == dt and y16.shape == (2, 24 * 40, 128)
+        assert torch.equal(y16, nchw.permute(0, 2, 3, 1).reshape(2, -1, 128).to(dt))   # the same values of the same run, rounded once

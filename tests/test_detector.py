@@ -289,8 +289,10 @@ def test_baseline_config0_512x1024_first_frame():
     with pytest.raises(ValueError, match="no slot passes the score threshold"):
         det(img=[img], img_meta=[[meta]], return_loss=False, rescale=True, ref_img=[img])
     feats, fcn = det.trunk(img)
-    assert [tuple(f.shape[-2:]) for f in feats] == [(16, 32), (32, 64), (64, 128), (128, 256)] and fcn.shape == (1, 19, H, W)
-    logits, embeds, masks = det.head_path([torch.cat([f, f], 0) for f in feats], dense=True)   # the reference's all-slot form
+    assert feats.hws == [(16, 32), (32, 64), (64, 128), (128, 256)] and fcn.shape == (1, 19, H, W)
+    assert feats.folded and all(f.shape == (1, h * w, 128) and f.dtype == torch.bfloat16 for f, (h, w) in zip(feats, feats.hws))
+    from slotvps_amd.detector import LevelMaps
+    logits, embeds, masks = det.head_path(LevelMaps.cat(feats, feats), dense=True)             # the reference's all-slot form
     assert logits.shape == (2, 100, 20) and masks.shape == (2, 100, 128, 256) and torch.isfinite(masks).all()
     assert torch.equal(logits[0], logits[1]) and torch.equal(masks[0], masks[1])      # identical frames, per-frame kernels
     with torch.no_grad():                                      # slot l prefers class l % 19, strongly
@@ -313,6 +315,7 @@ def test_trunk_bf16_autocast_option():
     """Optional bf16 autocast of the PyTorch trunk: same shapes / dtypes, level maps close to the fp32 trunk."""
     dev = torch.device("cuda:0")
     det = _make_detector(dev)
+    det.fold_trans = False                                     # the reference's tensors behind conv_trans in both runs
     imgs = torch.randn(2, 3, 128, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
     f32, s32 = det.trunk(imgs)
     det.trunk_bf16 = True
@@ -406,3 +409,38 @@ def test_fp16_level_maps_through_the_whole_detector():
     same = np.mean([(a["panoptic_outputs"] == b["panoptic_outputs"]).float().mean().item() for a, b in zip(outs["bf16"], outs["fp16"])])
     print(f"\npanoptic ids equal between bf16 and fp16 level maps on {100 * same:.2f} % of the pixels")
     assert same >= 0.6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("map_dtype", ["bf16", "fp16"])
+def test_conv_trans_folded_into_level_fusion(map_dtype):
+    """conv_trans (a linear 1x1 conv, vps_capsule.py:76-79) folded into K4's weights - the tower's last GroupNorm +
+    ReLU hands K4 its own output as 16-bit pixel-major rows. Against the reference's order of operations (conv_trans in fp32 by the
+    framework, then K4 on the fp32 NCHW map) the fused maps agree to the rounding of the 16-bit operands, and the semantic logits are
+    the same tensor."""
+    dev = torch.device("cuda:0")
+    det = _make_detector(dev)
+    head = det.image_model.dynamic_mask_head
+    head.set_map_dtype(map_dtype)
+    with torch.no_grad():
+        ct = det.image_model.conv_trans.conv
+        ct.weight.normal_(0, 0.12)
+        ct.bias.normal_(0, 0.3)
+    imgs = torch.randn(2, 3, 128, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    det.fold_trans = True
+    fa, sa = det.trunk(imgs)
+    la, ea, fused_a = det._head_clip(fa)
+    fused_a = [f.float().clone() for f in fused_a]
+    det.fold_trans = False
+    fb, sb = det.trunk(imgs)
+    lb, eb, fused_b = det._head_clip(fb)
+    assert fa.folded and not fb.folded and fa.hws == fb.hws
+    assert fa[0].dtype == (torch.float16 if map_dtype == "fp16" else torch.bfloat16) and fb[0].dtype == torch.float32
+    assert (sa - sb).abs().max().item() <= 1e-4 * sb.abs().max().item()      # (the framework's convolutions are not run-to-run identical)
+    ulp = 2.0 ** -7 if map_dtype == "bf16" else 2.0 ** -10
+    for a, b in zip(fused_a, fused_b):
+        b = b.float()
+        scale = b.abs().max().item()
+        # different rounding points (y rounded instead of W_t y + b_t, composed weights rounded once): a few operand ulps of the map's scale
+        assert (a - b).abs().max().item() <= 3 * ulp * scale, ((a - b).abs().max().item(), scale)
+        assert (a - b).abs().mean().item() <= 0.3 * ulp * scale

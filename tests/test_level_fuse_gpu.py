@@ -175,3 +175,31 @@ def test_level_fuse_fp16_maps_saturate(cuda):
     assert torch.isfinite(out).all() and float(out.max()) == 65504.0 and float(out.min()) == -65504.0
     out0 = ops.level_fuse(cur, None, wc, torch.zeros(256, device=cuda), H, W).float()           # level-0 form (first kernel)
     assert torch.isfinite(out0).all() and float(out0.abs().max()) == 65504.0
+
+
+@pytest.mark.parametrize("T,H,W,level0", [(2, 8, 16, True), (2, 16, 32, False), (2, 68, 120, False), (9, 32, 64, False), (3, 64, 128, False)])
+@pytest.mark.parametrize("form", ["fp16", "bf16_in_fp16"])
+def test_level_fuse_pixel_major_rows_in_the_fp16_forms(cuda, T, H, W, level0, form):
+    """Round 4: the incoming map as 16-bit pixel-major rows (what the semantic tower's last kernel writes) in the fp16-encoded forms -
+    fp16 rows for fp16 maps, bf16 rows for the bf16 policy in the fp16 encoding. The rows hold exactly the values the fp32 NCHW path
+    would round its input to, so both paths must give the SAME bits (fast path, generic kernel and level 0)."""
+    import torch
+    from slotvps_amd import ops
+    seed = 31 * H + W + T
+    rng = np.random.default_rng(seed)
+    params = synth.make_params({"conv_trans.conv.weight": (256, 384, 1, 1), "conv_trans.conv.bias": (256,)}, seed)
+    twc = torch.from_numpy(params["conv_trans.conv.weight"].reshape(256, 384)).to(cuda)
+    tbc = torch.from_numpy(params["conv_trans.conv.bias"]).to(cuda)
+    cur = torch.from_numpy(np.stack([synth.smooth_features(rng, 128, H, W) for _ in range(T)])).to(cuda)
+    rows_dt = torch.float16 if form == "fp16" else torch.bfloat16
+    rows = cur.reshape(T, 128, H * W).transpose(1, 2).to(rows_dt).contiguous()                 # [T, HW, 128]
+    nchw = rows.float().transpose(1, 2).reshape(T, 128, H, W).contiguous()                     # the same values as the reference's layout
+    prev = None
+    if not level0:
+        prev = torch.from_numpy(np.stack([synth.smooth_features(rng, 256, H // 2, W // 2).reshape(256, -1).T * 1.5 for _ in range(T)])).to(cuda)
+        prev = prev.to(torch.float16).contiguous() if form == "fp16" else prev.to(torch.bfloat16).float().to(torch.float16).contiguous()
+    wc = twc.to(torch.float16).contiguous() if form == "fp16" else twc.to(torch.bfloat16).contiguous()
+    a = ops.level_fuse(nchw, prev, wc, tbc, H, W, bf16_values=form == "bf16_in_fp16")
+    b = ops.level_fuse(rows, prev, wc, tbc, H, W, bf16_values=form == "bf16_in_fp16")
+    torch.cuda.synchronize()
+    assert a.dtype == b.dtype == torch.float16 and torch.equal(a, b)
