@@ -88,7 +88,7 @@ extern "C" int svps_probe_mix(const void* src, void* dst, size_t units, int ri, 
     const svps::u32x4* s = static_cast<const svps::u32x4*>(src);
     svps::u32x4* d = static_cast<svps::u32x4*>(dst);
 #define SVPS_MIX(RI, RO) if (ri == RI && ro == RO) { hipLaunchKernelGGL((svps::probe_mix_kernel<RI, RO>), grid, block, 0, stream, s, d, units); return (int)hipGetLastError(); }
-    SVPS_MIX(5, 4) SVPS_MIX(1, 1) SVPS_MIX(1, 0) SVPS_MIX(0, 1) SVPS_MIX(4, 1) SVPS_MIX(2, 1)
+    SVPS_MIX(5, 4) SVPS_MIX(3, 4) SVPS_MIX(1, 1) SVPS_MIX(1, 0) SVPS_MIX(0, 1) SVPS_MIX(4, 1) SVPS_MIX(2, 1)
 #undef SVPS_MIX
     return SVPS_ERR_BAD_SHAPE;
 }
