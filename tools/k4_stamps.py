@@ -13,6 +13,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--T", type=int, default=40)
 ap.add_argument("--H", type=int, default=256)
 ap.add_argument("--W", type=int, default=512)
+ap.add_argument("--rows", type=int, default=0, help="1: the default step's form since round 4 - the incoming map as bf16 pixel-major rows, "
+                                                     "the bf16 storage policy in the fp16 encoding (bf16_values)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
@@ -20,11 +22,23 @@ cur = torch.randn((a.T, 128, a.H, a.W), generator=g, device=dev)
 prev = torch.randn((a.T, a.H * a.W // 4, 256), generator=g, device=dev).to(torch.bfloat16)
 wc = (torch.randn((256, 384), generator=g, device=dev) * 0.05).to(torch.bfloat16)
 bc = torch.zeros(256, device=dev)
+kw = {}
+if a.rows:
+    cur = cur.reshape(a.T, 128, -1).transpose(1, 2).to(torch.bfloat16).contiguous()
+    prev = prev.float().to(torch.float16)
+    kw = dict(bf16_values=True)
 t0 = time.time()
 while time.time() - t0 < 1.5:
     for _ in range(5):
-        ops.level_fuse(cur, prev, wc, bc, a.H, a.W)
+        ops.level_fuse(cur, prev, wc, bc, a.H, a.W, **kw)
     torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    ops.level_fuse(cur, prev, wc, bc, a.H, a.W, **kw)
+e1.record()
+torch.cuda.synchronize()
+print(f"(stamped build) {e0.elapsed_time(e1) * 100:.1f} us per launch, T = {a.T}, rows = {a.rows}")
 lib = _lib.load()
 st = np.zeros((2, 8, 8), dtype=np.uint64)
 lib.svps_k4_debug_read.argtypes = [ctypes.c_void_p]
