@@ -988,38 +988,66 @@ __global__ __launch_bounds__(512) void level_fuse_kernel_v4(
     };
 
     constexpr int kCur = NCHW_F32 ? 4 : 2;                           // map loads per helper thread and tile
-    CurRegs cx, cy;
-    // prologue: tiles 0 and 1 requested, everything landed (once per workgroup)
+#ifndef SVPS_K4_AHEAD
+#define SVPS_K4_AHEAD 1
+#endif
+    // the incoming map is loaded kAhead tiles ahead of its use, through kAhead + 1 register sets. Round 4 (the map as 16-bit rows): the
+    // stamps show the helpers waiting 560 - 1 400 cycles per tile for loads issued a whole iteration earlier (under the kernel's own
+    // store traffic a load takes 3 500 - 4 400 cycles), but two tiles ahead (-DSVPS_K4_AHEAD=2, parity-green) measures the same on one
+    // box in both input forms (1 216 - 1 221 against 1 223 - 1 228 us, T = 40, rows; 1 311 - 1 320 against 1 305 - 1 309 NCHW): the wait
+    // moves, the memory system's rate for this access mix does not. One ahead stays the shipped schedule
+    constexpr int kAhead = (SVPS_K4_AHEAD);
+    static_assert(kAhead == 1 || kAhead == 2, "map prefetch depth");
+    CurRegs cx, cy, cz;
+    int ld_strip = tile_begin / H, ld_y = tile_begin - (tile_begin / H) * H;   // the map loads' own walk over the tiles (column strips)
+    auto load_next = [&](int tile, CurRegs& cr) {
+        load_cur(tile, ld_y * W + ld_strip * kTilePx, cr);
+        if (tile < nt) {
+            ++ld_y;
+            if (ld_y == H) { ld_y = 0; ++ld_strip; }
+        }
+    };
+    // prologue: tiles 0 and 1 requested (kAhead == 2: the map of tile 2 as well), everything landed (once per workgroup)
     const Req r0 = stage_requests(0);
-    load_cur(0, r0.px0, cx);
+    load_next(0, cx);
     Req r_next = stage_requests(1);                                  // tile it+1: staging buffer of its taps, first pixel, vertical weight
-    load_cur(1, r_next.px0, cy);
+    load_next(1, cy);
+    if constexpr (kAhead == 2) load_next(2, cz);
     wait_vm<0>();
     __syncthreads();                                                 // P: every helper's tap pieces of tiles 0 and 1 visible
     build(0, cx, r0.buf, r0.wy);
-    // iteration it: requests of tile it+2 (its buffers were consumed by build(it) before B(it)), operand tile it+1 from the registers
-    // loaded one iteration ago; issue order taps DMA, map loads
+    // iteration it: tap requests of tile it+2 (its buffers were consumed by build(it) before B(it)), map loads of tile it+1+kAhead,
+    // operand tile it+1 from the registers loaded kAhead iterations ago; issue order taps DMA, map loads
     auto iter = [&](int it, CurRegs& use, CurRegs& load) {
         K4_STAMP(1, 0);
         __syncthreads();                                             // B(it): operand tile it complete; out tile it-1 complete; taps of tile it+1 visible
         K4_STAMP(1, 1);
         const Req r_new = stage_requests(it + 2);                    // (a fresh group's buffer was last read by build(it) before B(it))
         K4_STAMP(1, 2);
-        load_cur(it + 2, r_new.px0, load);
+        load_next(it + 1 + kAhead, load);
         K4_STAMP(1, 3);
         K4_STAMP(1, 4);
-        // the map loads of tile it+1 (issued one iteration ago) landed. Younger, in issue order: this iteration's tap requests and map loads
-        wait_vm_dyn(last_dma + kCur);
+        // the map loads of tile it+1 landed. Younger, in issue order: (kAhead == 2: the map loads of tile it+2, one iteration old,) this
+        // iteration's tap requests and map loads
+        wait_vm_dyn((kAhead - 1) * kCur + last_dma + kCur);
         K4_STAMP(1, 5);
         if (it + 1 < nt) build(it + 1, use, r_next.buf, r_next.wy);
         K4_STAMP(1, 6);
         r_next = r_new;
-        wait_vm_dyn(kCur);                                           // the tap requests of tile it+2 landed (younger: its map loads)
+        wait_vm_dyn(kCur);                                           // the tap requests of tile it+2 landed (younger: this iteration's map loads)
         K4_STAMP(1, 7);
     };
-    for (int it = 0; it < nt; it += 2) {
-        iter(it, cy, cx);
-        if (it + 1 < nt) iter(it + 1, cx, cy);
+    if constexpr (kAhead == 1) {
+        for (int it = 0; it < nt; it += 2) {
+            iter(it, cy, cx);
+            if (it + 1 < nt) iter(it + 1, cx, cy);
+        }
+    } else {                                                         // tile t lives in set t % 3: iteration it builds from set (it+1) % 3, loads into it % 3
+        for (int it = 0; it < nt; it += 3) {
+            iter(it, cy, cx);
+            if (it + 1 < nt) iter(it + 1, cz, cy);
+            if (it + 2 < nt) iter(it + 2, cx, cz);
+        }
     }
     __syncthreads();                                                 // F
 }
