@@ -109,6 +109,10 @@ def load():
         raise SlotVPSLibraryError(
             f"{LIB_PATH} not found: build it with `make -C slotvps_amd/csrc` or "
             "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+    # PyTorch-ROCm first: the library's libamdhip64 dependency must resolve to the HIP runtime torch has loaded. Loaded before torch, it
+    # binds /opt/rocm's copy, torch then brings its own, and the second ROCr instance of the process finds no device (hipError 100 at
+    # the first kernel: seen with `python __graft_entry__.py smoke`, where build() loaded the library before anything imported torch)
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64 missing
