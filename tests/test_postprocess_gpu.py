@@ -243,3 +243,11 @@ def test_clip_postprocess_equal_scores(cuda):
     for dd in (True, False):
         _clip_vs_frames(cuda, [(lg, mk), synth.make_post_case(92, 50, 12, 20, 20, 9)], (48, 80), device_decisions=dd)
     _compare_with_oracle(cuda, lg, mk, (48, 80))
+
+
+def test_clip_postprocess_many_kept_slots(cuda):
+    """More kept slots than the decision kernel holds pair counts for in LDS (K > 120: the pair table is read from global memory) - the
+    VIPER geometry's worst case (200 slots)."""
+    cases = [synth.make_post_case(300 + t, 200, 17, 30, 20, nk) for t, nk in enumerate((150, 199, 121))]
+    res = _clip_vs_frames(cuda, cases, (68, 120))
+    assert max(len(r._thing) for r in res) > 120
