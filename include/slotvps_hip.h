@@ -231,6 +231,11 @@ int svps_slot_gemm(const float* x, const void* wpack, const float* bias, float* 
  * the query side of the fused retriever, MaskDynamicConv.forward's to_q (dynamic_mask_head.py:431) and the folded key projection.
  * wpack: fp16 fragments (pack_b_fragments(weight, split="fp16")). No activation. */
 int svps_slot_gemm_f16(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, void* stream);
+/* The fp16-split form with the epilogues of the bf16-split form (round 4; the slot side of precision "fp16x2"): act 0 none, 1 ReLU, 2
+ * GELU (erf) as in svps_slot_gemm; the LayerNorm step of svps_slot_gemm_ln (N = 256; same arguments). */
+int svps_slot_gemm_f16_act(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, int act, void* stream);
+int svps_slot_gemm_ln_f16(const float* x, const void* wpack, const float* bias, const float* pre, const float* post, const float* gamma,
+                          const float* beta, float eps, int relu, float* y, int M, int K, void* stream);
 /* the same product for N = 256 with the step that follows most dense layers of the slot update fused into the launch
  * (dynamic_mask_head.py:356-358, :374-376, :384-385, :394-397, :458-459, :515-525):
  *     y = LN(x W^T + bias [+ pre]) * gamma + beta  (+ReLU if relu)  (+ post)

@@ -83,6 +83,8 @@ SIGNATURES = {
     "svps_deform_conv_fused_fwd": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "svps_slot_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_slot_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "svps_slot_gemm_f16_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "svps_slot_gemm_ln_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
     "svps_prof_mark": (None, [_i, _i, _vp]),

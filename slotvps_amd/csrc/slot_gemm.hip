@@ -353,6 +353,46 @@ extern "C" int svps_slot_gemm_f16(const float* x, const void* wpack, const float
     return (int)hipGetLastError();
 }
 
+// the fp16-split form with the activation / LayerNorm epilogues of the bf16-split form (round 4: the slot side of precision "fp16x2"
+// ran its activations and LayerNorms as separate launches)
+extern "C" int svps_slot_gemm_f16_act(const float* x, const void* wpack, const float* bias, float* y, int M, int K, int N, int act,
+                                      void* stream_) {
+    if (!x || !wpack || !y) return SVPS_ERR_BAD_ARG;
+    if (M <= 0 || K <= 0 || (K & 15) || N <= 0 || (N % svps::kGmCols) || act < 0 || act > 2) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const __bf16* wp = static_cast<const __bf16*>(wpack);
+    const int wg64 = ((M + 63) / 64) * (N / svps::kGmCols);
+    const bool small = wg64 < 2 * svps_num_cus();
+    const int rows = small ? 32 : 64;
+    const dim3 grid((M + rows - 1) / rows, N / svps::kGmCols);
+#define SVPS_GEMM(A, R, P) hipLaunchKernelGGL((svps::slot_gemm_kernel<A, R, P, false, true>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N)
+    if (small) {
+        if (act == 0) SVPS_GEMM(0, 1, true); else if (act == 1) SVPS_GEMM(1, 1, true); else SVPS_GEMM(2, 1, true);
+    } else {
+        if (act == 0) SVPS_GEMM(0, 2, false); else if (act == 1) SVPS_GEMM(1, 2, false); else SVPS_GEMM(2, 2, false);
+    }
+#undef SVPS_GEMM
+    return (int)hipGetLastError();
+}
+
+extern "C" int svps_slot_gemm_ln_f16(const float* x, const void* wpack, const float* bias, const float* pre, const float* post,
+                                     const float* gamma, const float* beta, float eps, int relu, float* y, int M, int K,
+                                     void* stream_) {
+    if (!x || !wpack || !y || !gamma || !beta) return SVPS_ERR_BAD_ARG;
+    if (M <= 0 || K <= 0 || (K & 15)) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const __bf16* wp = static_cast<const __bf16*>(wpack);
+    const int N = svps::kGmCols;
+    const svps::GemmLn ln{pre, post, gamma, beta, eps, relu};
+    const int wg64 = (M + 63) / 64;
+    const bool small = wg64 < 2 * svps_num_cus();
+    const int rows = small ? 32 : 64;
+    const dim3 grid((M + rows - 1) / rows, 1);
+    if (small) hipLaunchKernelGGL((svps::slot_gemm_kernel<0, 1, true, true, true>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N, ln);
+    else hipLaunchKernelGGL((svps::slot_gemm_kernel<0, 2, false, true, true>), grid, dim3(512), 0, stream, x, wp, bias, y, M, K, N, ln);
+    return (int)hipGetLastError();
+}
+
 extern "C" int svps_slot_gemm_ln(const float* x, const void* wpack, const float* bias, const float* pre, const float* post,
                                  const float* gamma, const float* beta, float eps, int relu, float* y, int M, int K,
                                  void* stream_) {

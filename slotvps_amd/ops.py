@@ -531,13 +531,11 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 def slot_gemm(x, wpack, bias=None, act=ACT_NONE, out=None):
     """K8: y = act(x @ W^T + bias) for x [..., K] fp32 and wpack = pack_b_fragments(W [N, K]); N % 256 == 0, K % 16 == 0.
     Split-bf16 matrix-core products with fp32 accumulation (fp32-class; see csrc/slot_gemm.hip). A weight packed with split="fp16"
-    runs the fp16 hi + lo form (no activation; operands within the fp16 range)."""
+    runs the fp16 hi + lo form (operands within the fp16 range)."""
     lib = _lib.load()
     _need(x, "x", torch.float32)
     f16 = wpack.dtype == torch.float16
     _need(wpack, "wpack", torch.float16 if f16 else torch.bfloat16, 5)
-    if f16 and act != ACT_NONE:
-        raise ValueError("slot_gemm: the fp16-split form has no activation")
     K = x.shape[-1]
     M = x.numel() // K
     N = wpack.shape[0] * 32
@@ -550,7 +548,9 @@ def slot_gemm(x, wpack, bias=None, act=ACT_NONE, out=None):
     elif out.shape != x.shape[:-1] + (N,) or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("slot_gemm: out must be a contiguous fp32 tensor of shape x.shape[:-1] + (N,)")
     with _on(x, wpack, bias, out) as ctx:
-        if f16:
+        if f16 and act != ACT_NONE:
+            _lib.check(lib.svps_slot_gemm_f16_act(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), M, K, N, int(act), ctx.stream), "svps_slot_gemm_f16_act")
+        elif f16:
             _lib.check(lib.svps_slot_gemm_f16(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), M, K, N, ctx.stream), "svps_slot_gemm_f16")
         else:
             _lib.check(lib.svps_slot_gemm(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(out), M, K, N, int(act), ctx.stream), "svps_slot_gemm")
@@ -559,10 +559,11 @@ def slot_gemm(x, wpack, bias=None, act=ACT_NONE, out=None):
 
 def slot_gemm_ln(x, wpack, bias, gamma, beta, eps=1e-5, pre=None, post=None, relu=False, out=None):
     """K8 with the LayerNorm step fused into the launch: y = LN(x @ W^T + bias [+ pre]) * gamma + beta (+ReLU) (+post) for
-    N = 256; bitwise the result of slot_gemm followed by row_ln."""
+    N = 256; bitwise the result of slot_gemm followed by row_ln. A weight packed with split="fp16": the fp16 hi + lo form."""
     lib = _lib.load()
     _need(x, "x", torch.float32)
-    _need(wpack, "wpack", torch.bfloat16, 5)
+    f16 = wpack.dtype == torch.float16
+    _need(wpack, "wpack", torch.float16 if f16 else torch.bfloat16, 5)
     K = x.shape[-1]
     M = x.numel() // K
     if wpack.shape[0] * 32 != D_MODEL or wpack.shape[1] * 16 != K:
@@ -582,9 +583,10 @@ def slot_gemm_ln(x, wpack, bias, gamma, beta, eps=1e-5, pre=None, post=None, rel
     elif out.shape != shape or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("slot_gemm_ln: out must be a contiguous fp32 tensor of shape x.shape[:-1] + (256,)")
     with _on(x, wpack, bias, pre, post, gamma, beta, out) as ctx:
-        rc = lib.svps_slot_gemm_ln(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(pre), _ptr(post), _ptr(gamma), _ptr(beta), float(eps),
-                                   int(bool(relu)), _ptr(out), M, K, ctx.stream)
-    _lib.check(rc, "svps_slot_gemm_ln")
+        fn = lib.svps_slot_gemm_ln_f16 if f16 else lib.svps_slot_gemm_ln
+        rc = fn(_ptr(x), _ptr(wpack), _ptr(bias), _ptr(pre), _ptr(post), _ptr(gamma), _ptr(beta), float(eps),
+                int(bool(relu)), _ptr(out), M, K, ctx.stream)
+    _lib.check(rc, "svps_slot_gemm_ln_f16" if f16 else "svps_slot_gemm_ln")
     return out
 
 

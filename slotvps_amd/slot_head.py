@@ -75,16 +75,10 @@ def fast_linear(owner, name, x, weight, bias=None, act=None, out=None, split="bf
         return y
     if prec == "fp16x2":
         # reference precision on the matrix cores: both operands as fp16 hi + lo (22 bits; K8's F16 form, 2.8e-6 against float64 where the
-        # bf16 split measures 2.5e-5 and the library's fp32 4e-6 ... 1e-5). That form has no activation epilogue: applied behind it.
+        # bf16 split measures 2.5e-5 and the library's fp32 4e-6 ... 1e-5), the activation in the kernel's epilogue
         wp = _cached(owner, "wp_" + name + "_f16", [weight], lambda: ops.pack_b_fragments(weight, "fp16"))
-        y = ops.slot_gemm(x.contiguous(), wp, bias, ops.ACT_NONE, out if act is None else None)
-        if act is None:
-            return y
-        y = F.relu_(y) if act == "relu" else F.gelu(y)
-        if out is not None:
-            out.copy_(y)
-            return out
-        return y
+        code = {None: ops.ACT_NONE, "relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act]
+        return ops.slot_gemm(x.contiguous(), wp, bias, code, out)
     # split="fp16": operands as fp16 hi + lo (22 bits) instead of bf16 hi + lo (16): the query side of the fused retriever
     wp = _cached(owner, "wp_" + name + ("_f16" if split == "fp16" else ""), [weight], lambda: ops.pack_b_fragments(weight, split))
     code = {None: ops.ACT_NONE, "relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act]
@@ -97,7 +91,12 @@ def fast_linear_ln(owner, name, x, weight, bias, norm, pre=None, post=None, relu
     two-launch form; otherwise fast_linear + K5."""
     gamma, beta, eps = (norm.weight, norm.bias, norm.eps) if isinstance(norm, nn.LayerNorm) else norm
     N, K = weight.shape
-    if (getattr(owner, "precision", "bf16") in ("fp32", "fp16x2") or N != 256 or K % 16 or not x.is_cuda or not owner.use_slot_gemm
+    prec = getattr(owner, "precision", "bf16")
+    if prec == "fp16x2" and N == 256 and K % 16 == 0 and x.is_cuda and owner.use_slot_gemm and getattr(owner, "fuse_ln", True):
+        wp = _cached(owner, "wp_" + name + "_f16", [weight], lambda: ops.pack_b_fragments(weight, "fp16"))   # K8's fp16-split form + LN epilogue
+        return ops.slot_gemm_ln(x.contiguous(), wp, bias, gamma, beta, eps, pre=None if pre is None else pre.contiguous(),
+                                post=None if post is None else post.contiguous(), relu=relu, out=out)
+    if (prec in ("fp32", "fp16x2") or N != 256 or K % 16 or not x.is_cuda or not owner.use_slot_gemm
             or not getattr(owner, "fuse_ln", True)):
         y = fast_linear(owner, name, x, weight, bias)
         y = ops.row_ln(y.contiguous(), gamma, beta, eps, pre=None if pre is None else pre.contiguous().view_as(y),
