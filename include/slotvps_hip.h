@@ -250,6 +250,9 @@ int svps_slot_gemm_ln(const float* x, const void* wpack, const float* bias, cons
  * arithmetic is svps_slot_gemm (act) followed by svps_slot_gemm_ln operation for operation - bitwise the same result. */
 int svps_slot_ffn(const float* x, const void* w1pack, const float* b1, const void* w2pack, const float* b2, const float* pre,
                   const float* post, const float* gamma, const float* beta, float eps, int act, float* y, int M, int H, void* stream);
+/* The same block in the fp16-split form (precision "fp16x2"): weights packed with split "fp16", activations split into fp16 hi + lo. */
+int svps_slot_ffn_f16(const float* x, const void* w1pack, const float* b1, const void* w2pack, const float* b2, const float* pre,
+                      const float* post, const float* gamma, const float* beta, float eps, int act, float* y, int M, int H, void* stream);
 
 /* A chain of up to 6 layers  y_l = LN(src_l W_l^T + b_l [+ pre_l]) * gamma_l + beta_l (+ReLU if relu_l) (+ post_l)  on the same
  * [M, 256] rows in ONE launch (slotvps_amd/csrc/slot_chain.hip): the class / embedding towers (dynamic_mask_head.py:394-397), the

@@ -57,8 +57,16 @@ __device__ __forceinline__ float ffn_wave_sum(float x) {
 }
 
 
-template <int ACT>   // 1 ReLU, 2 GELU (erf)
+// ST: the 16-bit type both operands are split into: __bf16 (hi + lo: 16 bits of mantissa) or _Float16 (22 bits; |x| < 65 504: precision
+// "fp16x2", round 4) - three MFMAs per product either way
+template <int ACT, typename ST = __bf16>   // ACT: 1 ReLU, 2 GELU (erf)
 __global__ __launch_bounds__(512) void slot_ffn_kernel(FfnArgs a) {
+    typedef ST stx8 __attribute__((ext_vector_type(8)));
+    typedef ST stx4 __attribute__((ext_vector_type(4)));
+    auto mfma_st = [](stx8 x_, stx8 w_, f32x16 c_) {
+        if constexpr (__is_same(ST, _Float16)) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x_, w_, c_, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x_, w_, c_, 0, 0, 0);
+    };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,15 +90,15 @@ __global__ __launch_bounds__(512) void slot_ffn_kernel(FfnArgs a) {
         const char* ah = tile + r * kFfRow + 32 * ks0 + 16 * h;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bf16x8 wh = __builtin_bit_cast(bf16x8, wb[2 * u]);
-            const bf16x8 wl = __builtin_bit_cast(bf16x8, wb[2 * u + 1]);
+            const stx8 wh = __builtin_bit_cast(stx8, wb[2 * u]);
+            const stx8 wl = __builtin_bit_cast(stx8, wb[2 * u + 1]);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(ah + 32 * b * kFfRow + 32 * u);
-                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(ah + 32 * b * kFfRow + 32 * u + FfnLds::half);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[b], 0, 0, 0);
+                const stx8 xh = *reinterpret_cast<const stx8*>(ah + 32 * b * kFfRow + 32 * u);
+                const stx8 xl = *reinterpret_cast<const stx8*>(ah + 32 * b * kFfRow + 32 * u + FfnLds::half);
+                acc[b] = mfma_st(xh, wh, acc[b]);
+                acc[b] = mfma_st(xl, wh, acc[b]);
+                acc[b] = mfma_st(xh, wl, acc[b]);
             }
         }
     };
@@ -110,14 +118,14 @@ __global__ __launch_bounds__(512) void slot_ffn_kernel(FfnArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int q = tid + 512 * i, row = q >> 6, kg = (q & 63) * 4;
-            bf16x4 vh, vl;
+            stx4 vh, vl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                vh[e] = (__bf16)av[i][e];
-                vl[e] = (__bf16)(av[i][e] - (float)vh[e]);
+                vh[e] = (ST)av[i][e];
+                vl[e] = (ST)(av[i][e] - (float)vh[e]);
             }
-            *reinterpret_cast<bf16x4*>(smem + FfnLds::xt + row * kFfRow + kg * 2) = vh;
-            *reinterpret_cast<bf16x4*>(smem + FfnLds::xt + FfnLds::half + row * kFfRow + kg * 2) = vl;
+            *reinterpret_cast<stx4*>(smem + FfnLds::xt + row * kFfRow + kg * 2) = vh;
+            *reinterpret_cast<stx4*>(smem + FfnLds::xt + FfnLds::half + row * kFfRow + kg * 2) = vl;
         }
     }
     __syncthreads();
@@ -141,8 +149,8 @@ __global__ __launch_bounds__(512) void slot_ffn_kernel(FfnArgs a) {
                 v[e] = acc1[b][i + e] + bv;
                 if constexpr (ACT == 1) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 if constexpr (ACT == 2) v[e] = svps_gelu_erf(v[e]);
-                const __bf16 hi = (__bf16)v[e];
-                const __bf16 lo = (__bf16)(v[e] - (float)hi);
+                const ST hi = (ST)v[e];
+                const ST lo = (ST)(v[e] - (float)hi);
                 hb[e] = __builtin_bit_cast(unsigned short, hi);
                 lb[e] = __builtin_bit_cast(unsigned short, lo);
                 acc1[b][i + e] = 0.f;
@@ -265,6 +273,28 @@ __global__ __launch_bounds__(512) void slot_ffn_kernel(FfnArgs a) {
 }
 
 }  // namespace svps
+
+namespace {
+template <int ACT, typename ST>
+int launch_ffn(const svps::FfnArgs& a, hipStream_t stream) {
+    static SvpsLdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(svps::slot_ffn_kernel<ACT, ST>), svps::FfnLds::total); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((svps::slot_ffn_kernel<ACT, ST>), dim3((a.M + svps::kFfRows - 1) / svps::kFfRows), dim3(512), svps::FfnLds::total, stream, a);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+// the same block with both weights packed as fp16 hi + lo (ops.pack_b_fragments(..., "fp16")) and the activations split likewise
+extern "C" int svps_slot_ffn_f16(const float* x, const void* w1pack, const float* b1, const void* w2pack, const float* b2,
+                                 const float* pre, const float* post, const float* gamma, const float* beta, float eps, int act,
+                                 float* y, int M, int H, void* stream_) {
+    if (!x || !w1pack || !w2pack || !gamma || !beta || !y) return SVPS_ERR_BAD_ARG;
+    if (M <= 0 || H <= 0 || (H & 255) || (act != 1 && act != 2)) return SVPS_ERR_BAD_SHAPE;
+    const svps::FfnArgs a{x, static_cast<const __bf16*>(w1pack), b1, static_cast<const __bf16*>(w2pack), b2, pre, post, gamma, beta,
+                          y, eps, M, H};
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return act == 1 ? launch_ffn<1, _Float16>(a, stream) : launch_ffn<2, _Float16>(a, stream);
+}
 
 extern "C" int svps_slot_ffn(const float* x, const void* w1pack, const float* b1, const void* w2pack, const float* b2,
                              const float* pre, const float* post, const float* gamma, const float* beta, float eps, int act,

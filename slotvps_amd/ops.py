@@ -596,8 +596,9 @@ def slot_ffn(x, w1pack, b1, w2pack, b2, gamma, beta, eps=1e-5, act=ACT_RELU, pre
     Bitwise slot_gemm(act) followed by slot_gemm_ln; the [M, H] hidden tensor is never written."""
     lib = _lib.load()
     _need(x, "x", torch.float32)
-    _need(w1pack, "w1pack", torch.bfloat16, 5)
-    _need(w2pack, "w2pack", torch.bfloat16, 5)
+    f16 = w1pack.dtype == torch.float16                  # both weights packed with split="fp16": the fp16 hi + lo form
+    _need(w1pack, "w1pack", torch.float16 if f16 else torch.bfloat16, 5)
+    _need(w2pack, "w2pack", torch.float16 if f16 else torch.bfloat16, 5)
     if x.shape[-1] != D_MODEL:
         raise ValueError("slot_ffn works on rows of 256 values")
     M = x.numel() // D_MODEL
@@ -621,9 +622,10 @@ def slot_ffn(x, w1pack, b1, w2pack, b2, gamma, beta, eps=1e-5, act=ACT_RELU, pre
     elif out.shape != x.shape or not out.is_contiguous() or out.dtype != torch.float32:
         raise ValueError("slot_ffn: out must be a contiguous fp32 tensor of x's shape")
     with _on(x, w1pack, b1, w2pack, b2, pre, post, gamma, beta, out) as ctx:
-        rc = lib.svps_slot_ffn(_ptr(x), _ptr(w1pack), _ptr(b1), _ptr(w2pack), _ptr(b2), _ptr(pre), _ptr(post), _ptr(gamma),
-                               _ptr(beta), float(eps), int(act), _ptr(out), M, H, ctx.stream)
-    _lib.check(rc, "svps_slot_ffn")
+        fn = lib.svps_slot_ffn_f16 if f16 else lib.svps_slot_ffn
+        rc = fn(_ptr(x), _ptr(w1pack), _ptr(b1), _ptr(w2pack), _ptr(b2), _ptr(pre), _ptr(post), _ptr(gamma),
+                _ptr(beta), float(eps), int(act), _ptr(out), M, H, ctx.stream)
+    _lib.check(rc, "svps_slot_ffn_f16" if f16 else "svps_slot_ffn")
     return out
 
 

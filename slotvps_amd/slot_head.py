@@ -124,7 +124,8 @@ def fast_ffn(owner, x, lin1, lin2, norm, act, post=None):
     """LN(x + lin2(act(lin1(x)))) (+ post): the feed-forward block of a stage (dynamic_mask_head.py:379-385, :519-525). bf16 mode:
     ONE launch (csrc/slot_ffn.hip, the hidden tensor stays on the CU), bitwise the two K8 launches it replaces; otherwise those."""
     H, K = lin1.weight.shape
-    if (getattr(owner, "precision", "bf16") in ("fp32", "fp16x2") or K != 256 or lin2.weight.shape[0] != 256 or H % 256 or not x.is_cuda
+    split = "fp16" if getattr(owner, "precision", "bf16") == "fp16x2" else "bf16"
+    if (getattr(owner, "precision", "bf16") == "fp32" or K != 256 or lin2.weight.shape[0] != 256 or H % 256 or not x.is_cuda
             or not owner.use_slot_gemm or not getattr(owner, "fuse_ffn", True) or not getattr(owner, "fuse_ln", True)
             or lin1.bias is None or lin2.bias is None):
         hid = fast_linear(owner, "linear1", x, lin1.weight, lin1.bias, act=act)
@@ -135,8 +136,9 @@ def fast_ffn(owner, x, lin1, lin2, norm, act, post=None):
         # covers at least half the chip (measured: 16 000 rows 124 vs 179 us, 8 000 rows 97 vs 102, 500 rows 94 vs 47)
         hid = fast_linear(owner, "linear1", x, lin1.weight, lin1.bias, act=act)
         return fast_linear_ln(owner, "linear2", hid, lin2.weight, lin2.bias, norm, pre=x, post=post)
-    w1 = _cached(owner, "wp_linear1", [lin1.weight], lambda: ops.pack_b_fragments(lin1.weight))
-    w2 = _cached(owner, "wp_linear2", [lin2.weight], lambda: ops.pack_b_fragments(lin2.weight))
+    sfx = "_f16" if split == "fp16" else ""
+    w1 = _cached(owner, "wp_linear1" + sfx, [lin1.weight], lambda: ops.pack_b_fragments(lin1.weight, split))
+    w2 = _cached(owner, "wp_linear2" + sfx, [lin2.weight], lambda: ops.pack_b_fragments(lin2.weight, split))
     xc = x.contiguous()
     return ops.slot_ffn(xc, w1, lin1.bias, w2, lin2.bias, norm.weight, norm.bias, norm.eps,
                         act={"relu": ops.ACT_RELU, "gelu": ops.ACT_GELU}[act], pre=xc,

@@ -131,10 +131,52 @@ def test_slot_gemm_fp16_split_is_fp32_class(cuda, M, K, N):
     e16, ebf = np.abs(got16.cpu().numpy() - ref).max(), np.abs(gotbf.cpu().numpy() - ref).max()
     print(f"\nK8 M={M} K={K} N={N}: fp16 split {e16:.2e}, bf16 split {ebf:.2e} (outputs of order 1)")
     assert e16 <= 5e-6 and e16 < 0.3 * ebf                       # measured 2.8e-6 against 2.5e-5: what is left is the fp32 accumulation
-    with pytest.raises(ValueError):
-        ops.slot_gemm(tx, ops.pack_b_fragments(torch.from_numpy(w).to(cuda), split="fp16"), tb, ops.ACT_RELU)
+    # round 4: the fp16-split form has the epilogues of the bf16-split form - activation, LayerNorm, the one-launch FFN (precision "fp16x2")
+    wp16 = ops.pack_b_fragments(torch.from_numpy(w).to(cuda), split="fp16")
+    assert torch.equal(ops.slot_gemm(tx, wp16, tb, ops.ACT_RELU), torch.relu(got16))
+    gl = ops.slot_gemm(tx, wp16, tb, ops.ACT_GELU).cpu().numpy()
+    from scipy.special import erf
+    assert np.abs(gl - 0.5 * ref * (1.0 + erf(ref / np.sqrt(2.0)))).max() <= 8e-6
+    if N == 256:
+        gamma = torch.from_numpy(rng.uniform(0.5, 1.5, 256).astype(np.float32)).to(cuda)
+        beta = torch.from_numpy((0.1 * rng.standard_normal(256)).astype(np.float32)).to(cuda)
+        pre = torch.from_numpy(rng.standard_normal((M, 256)).astype(np.float32)).to(cuda)
+        fused = ops.slot_gemm_ln(tx, wp16, tb, gamma, beta, 1e-5, pre=pre, relu=True)
+        two = ops.row_ln(got16, gamma, beta, 1e-5, pre=pre, relu=True)
+        assert torch.equal(fused, two)                                # bitwise the two-launch form, as for the bf16 split
     with pytest.raises(ValueError):
         ops.pack_b_fragments(torch.full((256, 256), 7e4, device=cuda), split="fp16")
+
+
+@pytest.mark.parametrize("M,H,act", [(16000, 2048, "gelu"), (500, 1024, "relu"), (70, 512, "gelu")])
+def test_slot_ffn_fp16_split_is_bitwise_the_two_launches(cuda, M, H, act):
+    """The one-launch feed-forward block in the fp16-split form (svps_slot_ffn_f16, precision "fp16x2") == svps_slot_gemm_f16_act
+    followed by svps_slot_gemm_ln_f16 (bit for bit with ReLU; with GELU a few fp32 ulps on ~1.5 % of the outputs, measured 3.6e-7: the
+    two kernels do not round every fp16 lo part of the small GELU values alike); and fp32-class against float64."""
+    import torch
+    from scipy.special import erf
+    from slotvps_amd import ops
+    rng = np.random.default_rng(M + H)
+    x = rng.standard_normal((M, 256)).astype(np.float32)
+    w1 = (rng.standard_normal((H, 256)) / 16).astype(np.float32)
+    w2 = (rng.standard_normal((256, H)) / np.sqrt(H)).astype(np.float32)
+    b1, b2 = (0.1 * rng.standard_normal(H)).astype(np.float32), (0.1 * rng.standard_normal(256)).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, 256).astype(np.float32), (0.1 * rng.standard_normal(256)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    tx = t(x)
+    p1, p2 = ops.pack_b_fragments(t(w1), split="fp16"), ops.pack_b_fragments(t(w2), split="fp16")
+    code = ops.ACT_GELU if act == "gelu" else ops.ACT_RELU
+    one = ops.slot_ffn(tx, p1, t(b1), p2, t(b2), t(gamma), t(beta), 1e-5, act=code, pre=tx)
+    hid = ops.slot_gemm(tx, p1, t(b1), code)
+    two = ops.slot_gemm_ln(hid, p2, t(b2), t(gamma), t(beta), 1e-5, pre=tx)
+    assert torch.equal(one, two) if act == "relu" else (one - two).abs().max().item() <= 1.5e-6
+    h64 = x.astype(np.float64) @ w1.astype(np.float64).T + b1
+    h64 = 0.5 * h64 * (1.0 + erf(h64 / np.sqrt(2.0))) if act == "gelu" else np.maximum(h64, 0.0)
+    y = x + h64 @ w2.astype(np.float64).T + b2
+    y = (y - y.mean(-1, keepdims=True)) / np.sqrt(y.var(-1, keepdims=True) + 1e-5) * gamma + beta
+    err = np.abs(one.cpu().numpy() - y).max()
+    print(f"\nFFN fp16 split M={M} H={H} {act}: {err:.2e} against float64")
+    assert err <= 1.5e-5
 
 
 @pytest.mark.parametrize("M,K,pre,post,relu,bias", [(16000, 256, True, False, False, True), (500, 2048, True, True, False, True),
