@@ -713,7 +713,7 @@ def main():
                 rp = side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, a.clips_per_launch, 3, precision="fp16x2")
                 rp["what"] = ("head.set_precision('fp16x2'): the reference's precision ON THE MATRIX CORES - level maps as fp16 hi + lo planes, three "
                               "MFMAs per product in level fusion / statistics / retriever / decode, fp16-split slot side. Free-running against the "
-                              "reference's own fp32 outputs: mask logits 8.2e-5 / 9.2e-6 (bound 1e-4), slot argmax and panoptic ids identical on 100 % "
+                              "reference's own fp32 outputs: mask logits 6.8e-5 / 8.3e-6 (bound 1e-4), slot argmax and panoptic ids identical on 100 % "
                               "of the pixels (tests/test_refprec_gpu.py: the bounds of the exact mode's test); same step, fp32 logits written, hipGraph")
                 line["reference_precision"] = rp
             except Exception as e:
