@@ -182,6 +182,12 @@ int svps_row_softmax_scaled(const float* x, float* y, int rows, int cols, float 
  * ------------------------------------------------------------------------------------------- */
 int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, int N, int C, int H,
                                int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho, int Wo, void* stream);
+/* The same with the per-channel sums and sums of squares of the result for the GroupNorm behind the layer (round 4: the statistics pass
+ * re-read the whole result): gn_partial [N, chunks, 2, O] fp32, chunks = svps_deform_conv_fused_stats_chunks(O, Ho, Wo) per frame,
+ * written deterministically (one lane per entry); hand it to svps_group_norm_relu_stats_fwd. NULL: no statistics. */
+int svps_deform_conv_fused_stats_chunks(int O, int Ho, int Wo);
+int svps_deform_conv_fused_stats_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, float* gn_partial, int N, int C,
+                                     int H, int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm + ReLU on pixel-major fp32 activations (slotvps_amd/csrc/gn_relu.hip): the normalisation between the deformable
@@ -199,6 +205,14 @@ int svps_group_norm_relu_fwd(const float* x, const float* gamma, const float* be
  * between them, mmdet/models/detectors/vps_capsule.py:76-79, folded into K4's weights by the caller); y, y_nchw, y16: any subset. */
 int svps_group_norm_relu16_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y, float* y_nchw,
                                void* y16, int y16_is_fp16, void* workspace, size_t workspace_bytes, int N, int HW, int C, void* stream);
+/* ... with the statistics supplied by the producer of x (partial [N, chunks, 2, C] as svps_deform_conv_fused_stats_fwd writes them;
+ * NULL: computed here) - the pass over x for the moments disappears. Same workspace size. */
+int svps_group_norm_relu_stats_fwd(const float* x, const float* partial, int chunks, const float* gamma, const float* beta, int groups,
+                                   float eps, float* y, float* y_nchw, void* y16, int y16_is_fp16, void* workspace, size_t workspace_bytes,
+                                   int N, int HW, int C, void* stream);
+/* [N, C, HW] fp32 (NCHW) -> [N, HW, C] fp32 pixel-major: the layout copy in front of the semantic tower's first layer (C % 4 == 0,
+ * 256 % (C / 4) == 0). */
+int svps_nchw_to_pixel_major(const float* x, float* y, int N, int C, int HW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Slot-side helpers (slotvps_amd/csrc/row_ops.hip), rows of D = 256 fp32 values.

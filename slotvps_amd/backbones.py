@@ -188,17 +188,19 @@ class UPSNetFPN(nn.Module):
             return self.deform_convs[0](x), None
         N, _, H, W = x.shape
         cur_nchw = x.contiguous()
-        cur_pm = x.permute(0, 2, 3, 1).contiguous()                       # [N, H, W, C]
+        cur_pm = ops.nchw_to_pixel_major(cur_nchw) if (x.shape[1] % 4 == 0 and 256 % (x.shape[1] // 4) == 0) \
+            else x.permute(0, 2, 3, 1).contiguous()                       # [N, H, W, C]
         for i in range(0, len(seq), 3):
             dc, gn = seq[i], seq[i + 1]
             O = dc.conv.weight.shape[0]
             off = dc.conv_offset(cur_nchw)                                # framework 3 x 3 convolution (NCHW in, [N, 18, H, W] out)
-            y = deform_conv_fused_pm(cur_pm, off, dc.conv._weight_pack(), O, 1, 1, 1)          # [N, HW, O]
+            # [N, HW, O] + the GroupNorm's per-channel sums from the kernel's epilogue (no moments pass over y)
+            y, st = deform_conv_fused_pm(cur_pm, off, dc.conv._weight_pack(), O, 1, 1, 1, gn_stats=True)
             if i + 3 >= len(seq) and self.emit_pm16 is not None:          # last layer: NCHW for the semantic logits, 16-bit rows for K4
                 _, y_nchw, y16 = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=True,
-                                                        want_16=self.emit_pm16, want_pm=False)
+                                                        want_16=self.emit_pm16, want_pm=False, stats=st)
                 return y_nchw.view(N, O, H, W), y16
-            y_pm, y_nchw = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=True)
+            y_pm, y_nchw = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=True, stats=st)
             cur_pm, cur_nchw = y_pm.view(N, H, W, O), y_nchw.view(N, O, H, W)
         return cur_nchw, None
 

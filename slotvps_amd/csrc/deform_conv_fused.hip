@@ -42,7 +42,8 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
                                                                 const float* __restrict__ offset,   // [N, 18, Ho, Wo]
                                                                 const __bf16* __restrict__ wpack,   // [OB, KS, 2, 64, 8]
                                                                 float* __restrict__ out,            // [N, Ho*Wo, 32 OB]
-                                                                int C, int H, int W, int Ho, int Wo, int pad, int stride, int dil) {
+                                                                int C, int H, int W, int Ho, int Wo, int pad, int stride, int dil,
+                                                                float* __restrict__ gn_part = nullptr) {   // [N, chunks, 2, 32 OB] or null
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Lds = DcLds;
     constexpr int NB = 32 / OB;            // pixel blocks per wave: 4 or ... (OB = 8 -> 4, OB = 4 -> 2)
@@ -176,6 +177,37 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
         __syncthreads();
     }
 
+    // ---- per-channel sums and sums of squares of this workgroup's pixels for the GroupNorm behind the layer (round 4: its statistics
+    // pass re-read the whole result): every wave reduces its pixel blocks over the 32 lanes that hold the same channels and writes ONE
+    // partial row per (tile, pixel half) - chunks = tiles (O = 256) or 2 tiles (O = 128) per frame, each (chunk, channel) written by
+    // exactly one lane: deterministic, combined in float64 by gn_finalize_kernel
+    if (gn_part) {
+        float s1[16], s2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll
+        for (int b = 0; b < NPB; ++b) {
+            if (p0 + 32 * (pb0 + b) + r < HWo) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s1[i] += acc[b][i]; s2[i] += acc[b][i] * acc[b][i]; }
+            }
+        }
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s1[i] += __shfl_xor(s1[i], m); s2[i] += __shfl_xor(s2[i], m); }
+        }
+        if (r == 0) {
+            const int chunks = (OB == 8) ? gridDim.x : 2 * gridDim.x;
+            const int chunk = (OB == 8) ? blockIdx.x : 2 * blockIdx.x + (w >> 2);
+            float* base = gn_part + (((size_t)n * chunks + chunk) * 2) * (32 * OB) + 32 * ob + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(base + 8 * g) = f32x4{s1[4 * g], s1[4 * g + 1], s1[4 * g + 2], s1[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(base + 32 * OB + 8 * g) = f32x4{s2[4 * g], s2[4 * g + 1], s2[4 * g + 2], s2[4 * g + 3]};
+            }
+        }
+    }
     // ---- out[n, p, o]: lane (pixel r of block b, h) holds output channels 32 ob + 8 g + 4 h + i ----
     float* on = out + (size_t)n * HWo * (32 * OB);
 #pragma unroll
@@ -196,6 +228,18 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
 extern "C" int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, int N, int C,
                                           int H, int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho, int Wo,
                                           void* stream_) {
+    return svps_deform_conv_fused_stats_fwd(x_nhwc, offset, wpack, out, nullptr, N, C, H, W, O, kh, kw, pad, stride, dil, Ho, Wo, stream_);
+}
+
+extern "C" int svps_deform_conv_fused_stats_chunks(int O, int Ho, int Wo) {
+    if ((O != 128 && O != 256) || Ho <= 0 || Wo <= 0) return 0;
+    const int tiles = (Ho * Wo + svps::kDcPx - 1) / svps::kDcPx;
+    return O == 256 ? tiles : 2 * tiles;
+}
+
+extern "C" int svps_deform_conv_fused_stats_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, float* gn_partial,
+                                                int N, int C, int H, int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho,
+                                                int Wo, void* stream_) {
     if (!x_nhwc || !offset || !wpack || !out) return SVPS_ERR_BAD_ARG;
     if (N <= 0 || H <= 0 || W <= 0 || kh != 3 || kw != 3 || C <= 0 || (C % svps::kDcCh) || (O != 128 && O != 256) || stride <= 0 ||
         dil <= 0 || pad < 0)
@@ -210,13 +254,13 @@ extern "C" int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offs
         static SvpsLdsAttr attr;
         if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DcLds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(kern, dim3(tiles, N), dim3(512), svps::DcLds::total, stream, x_nhwc, offset, static_cast<const __bf16*>(wpack),
-                           out, C, H, W, Ho, Wo, pad, stride, dil);
+                           out, C, H, W, Ho, Wo, pad, stride, dil, gn_partial);
     } else {
         auto kern = svps::deform_conv_fused_kernel<4>;
         static SvpsLdsAttr attr;
         if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DcLds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(kern, dim3(tiles, N), dim3(512), svps::DcLds::total, stream, x_nhwc, offset, static_cast<const __bf16*>(wpack),
-                           out, C, H, W, Ho, Wo, pad, stride, dil);
+                           out, C, H, W, Ho, Wo, pad, stride, dil, gn_partial);
     }
     svps_prof_mark(SVPS_KERNEL_DEFORM_CONV, 1, stream);
     return (int)hipGetLastError();

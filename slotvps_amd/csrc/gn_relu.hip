@@ -85,6 +85,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// partial rows of a producer kernel ([N, chunks_in, 2, C]: one per 128- or 64-pixel tile, thousands per frame) -> [N, R, 2, C]: workgroup
+// (r, n) sums its slice of the rows in float64 (gn_finalize_kernel is one workgroup per frame: it would walk them serially)
+__global__ __launch_bounds__(256) void gn_reduce_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int chunks_in, int R) {
+    const int n = blockIdx.y, r = blockIdx.x;
+    const int per = (chunks_in + R - 1) / R;
+    const int k0 = r * per;
+    int k1 = k0 + per;
+    k1 = k1 < chunks_in ? k1 : chunks_in;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        double a = 0.0;
+        for (int k = k0; k < k1; ++k) a += (double)in[(((size_t)n * chunks_in + k) * 2) * C + c];
+        out[(((size_t)n * R + r) * 2) * C + c] = (float)a;
+    }
+}
+
 // tile = 32 consecutive pixels x C channels; LDS [32][C + 1] floats for the NCHW copy
 // y16 (nullable): the same values as 16-bit pixel-major rows - bf16 (f16 == 0) or fp16 (saturating at +-65 504) - the form in which
 // the tower's LAST layer hands its output to K4 (conv_trans folded into K4's weights); y (nullable) the fp32 rows the next K7' reads
@@ -166,7 +181,65 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
+// [N, C, HW] fp32 (NCHW) -> [N, HW, C] fp32 pixel-major: the layout copy in front of the tower's first K7' (the framework's
+// permute + contiguous ran at a third of the copy rate). 32-pixel tiles through LDS, 128-byte reads per channel row, whole pixel rows out
+__global__ __launch_bounds__(256) void nchw_to_pm_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int ldc = C + 1;
+    const int tiles = (HW + 31) >> 5;
+    const int t0 = blockIdx.x * tiles_per_wg;
+    int t1 = t0 + tiles_per_wg;
+    t1 = t1 < tiles ? t1 : tiles;
+    const int cols = C >> 2, rows = 256 / cols;
+    const int pr = tid / cols, cc = tid - pr * cols;
+    for (int t = t0; t < t1; ++t) {
+        const int p0 = t << 5;
+        for (int e = tid; e < C * 8; e += 256) {
+            const int c = e >> 3, q4 = (e & 7) * 4;
+            const int p = p0 + q4;
+            const float* src = x + ((size_t)n * C + c) * HW + p;
+            if (p + 3 < HW && ((HW & 3) == 0)) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tile[(q4 + j) * ldc + c] = v[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tile[(q4 + j) * ldc + c] = p + j < HW ? src[j] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (pr < rows) {
+            for (int q = pr; q < 32; q += rows) {
+                const int p = p0 + q;
+                if (p < HW) {
+                    const f32x4 o = {tile[q * ldc + 4 * cc], tile[q * ldc + 4 * cc + 1], tile[q * ldc + 4 * cc + 2], tile[q * ldc + 4 * cc + 3]};
+                    *reinterpret_cast<f32x4*>(y + ((size_t)n * HW + p) * C + 4 * cc) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace svps
+
+extern "C" int svps_nchw_to_pixel_major(const float* x, float* y, int N, int C, int HW, void* stream_) {
+    if (!x || !y) return SVPS_ERR_BAD_ARG;
+    if (N <= 0 || HW <= 0 || C <= 0 || (C & 3) || C > 1024 || (256 % (C >> 2))) return SVPS_ERR_BAD_SHAPE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int tiles = (HW + 31) / 32;
+    int wgs = (2048 + N - 1) / N;
+    wgs = wgs < tiles ? wgs : tiles;
+    const int tpw = (tiles + wgs - 1) / wgs;
+    wgs = (tiles + tpw - 1) / tpw;
+    const size_t lds = (size_t)32 * (C + 1) * sizeof(float);
+    static SvpsLdsAttr attr;
+    if (lds > 48 * 1024)
+        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(svps::nchw_to_pm_kernel), (int)lds); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(svps::nchw_to_pm_kernel, dim3(wgs, N), dim3(256), lds, stream, x, y, HW, C, tpw);
+    return (int)hipGetLastError();
+}
 
 extern "C" size_t svps_group_norm_relu_workspace_bytes(int N, int HW, int C) {
     if (N <= 0 || HW <= 0 || C <= 0) return 0;
@@ -183,15 +256,27 @@ extern "C" int svps_group_norm_relu_fwd(const float* x, const float* gamma, cons
 extern "C" int svps_group_norm_relu16_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y,
                                           float* y_nchw, void* y16, int y16_is_fp16, void* workspace, size_t workspace_bytes, int N,
                                           int HW, int C, void* stream_) {
+    return svps_group_norm_relu_stats_fwd(x, nullptr, 0, gamma, beta, groups, eps, y, y_nchw, y16, y16_is_fp16, workspace, workspace_bytes,
+                                          N, HW, C, stream_);
+}
+
+// partial != null: the per-channel sums come from the producer of x (svps_deform_conv_fused_stats_fwd: [N, chunks, 2, C]); the
+// statistics pass over x is skipped and `workspace` only holds the per-channel scale / shift (N C float2)
+extern "C" int svps_group_norm_relu_stats_fwd(const float* x, const float* partial_in, int chunks_in, const float* gamma, const float* beta,
+                                              int groups, float eps, float* y, float* y_nchw, void* y16, int y16_is_fp16, void* workspace,
+                                              size_t workspace_bytes, int N, int HW, int C, void* stream_) {
     if (!x || !gamma || !beta || !workspace || (!y && !y_nchw && !y16)) return SVPS_ERR_BAD_ARG;
+    if (partial_in && chunks_in <= 0) return SVPS_ERR_BAD_SHAPE;
     if (N <= 0 || HW <= 0 || C <= 0 || (C & 3) || C > 1024 || groups <= 0 || groups > 256 || C % groups) return SVPS_ERR_BAD_SHAPE;
     if (256 % (C >> 2)) return SVPS_ERR_BAD_SHAPE;                           // float4 columns of a pixel row must divide the workgroup
     if (workspace_bytes < svps_group_norm_relu_workspace_bytes(N, HW, C)) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int chunks = (HW + 2047) / 2048;
-    float* partial = static_cast<float*>(workspace);
-    float2* ab = reinterpret_cast<float2*>(partial + (size_t)N * chunks * 2 * C);
-    hipLaunchKernelGGL(svps::gn_stats_kernel, dim3(chunks, N), dim3(256), 0, stream, x, partial, HW, C, 2048);
+    float* own = static_cast<float*>(workspace);
+    float2* ab = reinterpret_cast<float2*>(own + (size_t)N * chunks * 2 * C);
+    const float* partial = own;
+    if (!partial_in) hipLaunchKernelGGL(svps::gn_stats_kernel, dim3(chunks, N), dim3(256), 0, stream, x, own, HW, C, 2048);
+    else hipLaunchKernelGGL(svps::gn_reduce_kernel, dim3(chunks, N), dim3(256), 0, stream, partial_in, own, C, chunks_in, chunks);
     hipLaunchKernelGGL(svps::gn_finalize_kernel, dim3(N), dim3(256), 0, stream, partial, gamma, beta, ab, HW, C, groups, chunks, eps);
     const int tiles = (HW + 31) / 32;
     int wgs = (2048 + N - 1) / N;                                           // ~2048 workgroups per launch

@@ -35,8 +35,10 @@ def fused_applicable(x, weight, stride, padding, dilation, groups, deformable_gr
             and _pair(dilation)[0] == _pair(dilation)[1] and x.shape[2] * x.shape[3] * C < 2 ** 31)
 
 
-def deform_conv_fused_pm(x_nhwc, offset, wpack, O, stride=1, padding=0, dilation=1):
-    """K7' on pixel-major tensors: x_nhwc [N, H, W, C] fp32 contiguous, offset [N, 18, Ho, Wo] fp32 -> [N, Ho*Wo, O] fp32."""
+def deform_conv_fused_pm(x_nhwc, offset, wpack, O, stride=1, padding=0, dilation=1, gn_stats=False):
+    """K7' on pixel-major tensors: x_nhwc [N, H, W, C] fp32 contiguous, offset [N, 18, Ho, Wo] fp32 -> [N, Ho*Wo, O] fp32.
+    gn_stats: also return (partial [N, chunks, 2, O], chunks) - the per-channel sums and sums of squares of the result, written by the
+    kernel's epilogue, for ops.group_norm_relu_pm(stats=...)."""
     if not x_nhwc.is_cuda:
         raise RuntimeError("deform_conv runs on the GPU only; there is no CPU fallback")
     lib = _lib.load()
@@ -48,11 +50,14 @@ def deform_conv_fused_pm(x_nhwc, offset, wpack, O, stride=1, padding=0, dilation
     if offset.shape != (N, 18, Ho, Wo) or not x_nhwc.is_contiguous() or x_nhwc.dtype != torch.float32:
         raise ValueError("deform_conv_fused_pm: x [N, H, W, C] fp32 contiguous and offset [N, 18, Ho, Wo] expected")
     out = torch.empty((N, Ho * Wo, O), dtype=torch.float32, device=x_nhwc.device)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    with ops._on(x_nhwc, offset, wpack, out) as ctx:
-        rc = lib.svps_deform_conv_fused_fwd(p(x_nhwc), p(offset), p(wpack), p(out), N, C, H, W, O, 3, 3, p_, s, d, Ho, Wo, ctx.stream)
-    _lib.check(rc, "svps_deform_conv_fused_fwd")
-    return out
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    chunks = lib.svps_deform_conv_fused_stats_chunks(O, Ho, Wo) if gn_stats else 0
+    part = torch.empty((N, chunks, 2, O), dtype=torch.float32, device=x_nhwc.device) if gn_stats else None
+    with ops._on(x_nhwc, offset, wpack, out, part) as ctx:
+        rc = lib.svps_deform_conv_fused_stats_fwd(p(x_nhwc), p(offset), p(wpack), p(out), p(part), N, C, H, W, O, 3, 3, p_, s, d, Ho, Wo,
+                                                  ctx.stream)
+    _lib.check(rc, "svps_deform_conv_fused_stats_fwd")
+    return (out, (part, chunks)) if gn_stats else out
 
 
 def deform_conv_fused(x, offset, wpack, O, stride=1, padding=0, dilation=1):

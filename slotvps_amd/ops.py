@@ -280,11 +280,25 @@ def row_softmax(x, inplace=False, scale=1.0):
     return out
 
 
-def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False, want_16=None, want_pm=True):
+def nchw_to_pixel_major(x):
+    """[N, C, H, W] fp32 contiguous -> [N, H, W, C] fp32 (csrc/gn_relu.hip: 32-pixel tiles through LDS; the framework's permute +
+    contiguous runs at a third of the copy rate)."""
+    lib = _lib.load()
+    _need(x, "x", torch.float32, 4)
+    N, C, H, W = x.shape
+    y = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    with _on(x, y) as ctx:
+        _lib.check(lib.svps_nchw_to_pixel_major(_ptr(x), _ptr(y), N, C, H * W, ctx.stream), "svps_nchw_to_pixel_major")
+    return y
+
+
+def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False, want_16=None, want_pm=True, stats=None):
     """relu(GroupNorm(groups)(x)) for pixel-major fp32 activations x [N, HW, C] (csrc/gn_relu.hip) -> (y [N, HW, C], y_nchw [N, C, HW]
     or None): the normalisation of the semantic tower in the layout of the deformable-convolution kernel, optionally also in the
     layout the framework's convolutions take. want_16 = torch.bfloat16 / torch.float16: a third result, the same values as 16-bit
-    pixel-major rows (what K4 takes as its incoming map); want_pm = False drops the fp32 rows (the tower's last layer)."""
+    pixel-major rows (what K4 takes as its incoming map); want_pm = False drops the fp32 rows (the tower's last layer).
+    stats = (partial [N, chunks, 2, C], chunks): per-channel sums from the kernel that produced x (dcn.deform_conv_fused_pm(...,
+    gn_stats=True)) - the moments pass over x is skipped."""
     lib = _lib.load()
     _need(x, "x", torch.float32, 3)
     N, HW, C = x.shape
@@ -300,9 +314,12 @@ def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False, wan
     ws_bytes = lib.svps_group_norm_relu_workspace_bytes(N, HW, C)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
     with _on(x, gamma, beta, y, yn, y16, ws) as ctx:
-        rc = lib.svps_group_norm_relu16_fwd(_ptr(x), _ptr(gamma), _ptr(beta), int(groups), float(eps), _ptr(y), _ptr(yn), _ptr(y16),
-                                            int(want_16 == torch.float16), _ptr(ws), ws_bytes, N, HW, C, ctx.stream)
-    _lib.check(rc, "svps_group_norm_relu16_fwd")
+        part, chunks = (stats[0], int(stats[1])) if stats is not None else (None, 0)
+        if part is not None and (part.dtype != torch.float32 or not part.is_contiguous() or part.numel() != N * chunks * 2 * C):
+            raise ValueError("group_norm_relu_pm: stats must be ([N, chunks, 2, C] fp32 contiguous, chunks)")
+        rc = lib.svps_group_norm_relu_stats_fwd(_ptr(x), _ptr(part), chunks, _ptr(gamma), _ptr(beta), int(groups), float(eps), _ptr(y),
+                                                _ptr(yn), _ptr(y16), int(want_16 == torch.float16), _ptr(ws), ws_bytes, N, HW, C, ctx.stream)
+    _lib.check(rc, "svps_group_norm_relu_stats_fwd")
     if want_16 is not None:
         return y, yn, y16
     return y, yn

@@ -311,3 +311,32 @@ def test_pixel_major_tower_equals_module_sequence(cuda):
         assert float((nchw - a).abs().max()) < 1e-4 * max(1.0, float(a.abs().max()))   # (the offset convs are not run-to-run identical)
         assert y16.dtype == dt and y16.shape == (2, 24 * 40, 128)
         assert torch.equal(y16, nchw.permute(0, 2, 3, 1).reshape(2, -1, 128).to(dt))   # the same values of the same run, rounded once
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W,O", [(2, 256, 24, 40, 256), (1, 128, 17, 23, 128), (3, 64, 8, 16, 128)])
+def test_fused_kernel_group_norm_statistics(cuda, N, C, H, W, O):
+    """K7' with the GroupNorm statistics in its epilogue (svps_deform_conv_fused_stats_fwd): the same output bits, the per-channel
+    partial sums add up to the sums of the result (ragged last tile: HW not a multiple of 128), and GroupNorm + ReLU from those
+    statistics equals GroupNorm + ReLU with its own moments pass to fp32 rounding; nchw_to_pixel_major == permute + contiguous."""
+    import torch
+    from slotvps_amd import ops
+    from slotvps_amd.dcn import deform_conv_fused_pm, pack_weight_fragments
+    g = torch.Generator(device=cuda).manual_seed(N + C + H)
+    x = torch.randn((N, C, H, W), generator=g, device=cuda)
+    xp = ops.nchw_to_pixel_major(x)
+    assert torch.equal(xp, x.permute(0, 2, 3, 1).contiguous())
+    off = 0.7 * torch.randn((N, 18, H, W), generator=g, device=cuda)
+    wgt = torch.randn((O, C, 3, 3), generator=g, device=cuda) / (3 * C ** 0.5)
+    wp = pack_weight_fragments(wgt)
+    a = deform_conv_fused_pm(xp, off, wp, O, 1, 1, 1)
+    b, (part, chunks) = deform_conv_fused_pm(xp, off, wp, O, 1, 1, 1, gn_stats=True)
+    assert torch.equal(a, b) and part.shape == (N, chunks, 2, O)
+    s1, s2 = part[:, :, 0].double().sum(1), part[:, :, 1].double().sum(1)
+    assert (s1 - a.double().sum(1)).abs().max().item() <= 1e-4 * a.abs().sum(1).max().item()
+    assert (s2 - (a.double() ** 2).sum(1)).abs().max().item() <= 1e-5 * (a.double() ** 2).sum(1).max().item()
+    gamma = torch.rand((O,), generator=g, device=cuda) + 0.5
+    beta = 0.2 * torch.randn((O,), generator=g, device=cuda)
+    y0, n0 = ops.group_norm_relu_pm(a, gamma, beta, 32, 1e-5, want_nchw=True)
+    y1, n1 = ops.group_norm_relu_pm(a, gamma, beta, 32, 1e-5, want_nchw=True, stats=(part, chunks))
+    assert (y0 - y1).abs().max().item() <= 2e-6 * max(1.0, y0.abs().max().item()) and (n0 - n1).abs().max().item() <= 2e-6 * max(1.0, y0.abs().max().item())
