@@ -363,3 +363,35 @@ def test_fp16x2_kernels_at_the_full_size_against_the_exact_mode(cuda):
     assert er <= 1e-4                   # measured 1.5e-5 (both sit within ~5e-5 of float64 at small sizes)
     assert e2 <= 2e-6 and same == 1.0   # measured 3.3e-7
     assert ((s0 - HW).abs() / HW).max().item() <= 2e-6 and ((s1 - tau.sum(1)).abs() / tau.sum(1)).max().item() <= 2e-6
+
+
+def test_fp16x2_full_size_clip_against_the_exact_mode(cuda):
+    """One 1024 x 2048 T = 2 clip through the whole hot path (four level fusions, seven stages, decode), free-running, in the
+    matrix-core mode and in the exact mode (fp32 vector ALU) on the same synthetic inputs and weights: the two independent
+    implementations agree to fp32-class on the first stage (4e-5) and then drift apart by the head's own amplification (x250 over
+    the seven stages on these random N(0, 1) maps: the reference's result moves the same way under a change of summation order,
+    DESIGN.md section 4) - embeddings 1.2e-2 and mask logits 1.2e-3 at the end, with the slot argmax identical on every pixel whose
+    margin exceeds that drift (99.89 % of all pixels). Recorded as a measurement; the bounds are this behaviour with a margin."""
+    import torch
+    from slotvps_amd.clip import SlotClipRunner
+    outs = {}
+    for prec in ("fp32", "fp16x2"):
+        r = SlotClipRunner(cuda, T=2, H=1024, W=2048, L=100, param_seed=0, use_graph=False)
+        r.head.set_precision(prec)
+        r.load_clip(r.random_clip(7))
+        o = r.run()
+        torch.cuda.synchronize()
+        outs[prec] = {k: v.float().clone() for k, v in o.items() if k in ("class_logits", "slot_embeds", "mask_logits")}
+        outs[prec]["argmax"] = o["mask_logits"].argmax(dim=1)
+        del r, o
+        torch.cuda.empty_cache()
+    a, b = outs["fp32"], outs["fp16x2"]
+    emb = [(a["slot_embeds"][s] - b["slot_embeds"][s]).abs().max().item() for s in range(a["slot_embeds"].shape[0])]
+    dm = (a["mask_logits"] - b["mask_logits"]).abs().max().item()
+    srt = a["mask_logits"].sort(dim=1).values
+    decided = (srt[:, -1] - srt[:, -2]) > 2 * dm
+    same = (a["argmax"] == b["argmax"]).double().mean().item()
+    same_dec = (a["argmax"] == b["argmax"])[decided].double().mean().item()
+    print(f"\nfull-size clip, fp16x2 vs exact mode, free-running: slot embeddings per stage " + " ".join(f"{e:.1e}" for e in emb) +
+          f"; mask logits {dm:.2e}; slot argmax equal on {100 * same:.4f} % of the pixels ({100 * same_dec:.4f} % of the {100 * decided.double().mean().item():.1f} % decidable)")
+    assert emb[0] <= 2e-4 and emb[-1] <= 5e-2 and dm <= 5e-3 and same_dec == 1.0 and same >= 0.995
