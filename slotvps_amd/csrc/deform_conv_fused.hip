@@ -143,10 +143,14 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
         const char* bl = bh + kDcPx * kDcRow;
         // weights of the chunk's four k-steps (hi, lo): k-step index of chunk ch = ch * 4 + u  (k = tap * C + c)
         bf16x8 ah[4], al[4];
+#ifndef SVPS_K7_ABL
+#define SVPS_K7_ABL 0          // timing-only ablations (wrong results; separate library): 1 weights of chunk 0 every time (L2-resident), 2 no gather
+#endif
+        const int chw = (SVPS_K7_ABL & 1) ? 0 : ch;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            ah[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ch * 4 + u) * 2) * 64]);
-            al[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ch * 4 + u) * 2 + 1) * 64]);
+            ah[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((chw * 4 + u) * 2) * 64]);
+            al[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((chw * 4 + u) * 2 + 1) * 64]);
         }
 #pragma unroll
         for (int b = 0; b < NPB; ++b) {
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
         // spills); with this order the result is bitwise reproducible and equal to the column-buffer path to 8e-6, at the
         // same speed. tests/test_deform_conv.py asserts both.
         if (ch + 1 < nch) {
-            gather(ch + 1);
+            if (!(SVPS_K7_ABL & 2)) gather(ch + 1);
             blend_store((ch + 1) & 1);
         }
         __syncthreads();
