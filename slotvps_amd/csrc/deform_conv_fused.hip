@@ -47,7 +47,14 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Lds = DcLds;
     constexpr int NB = 32 / OB;            // pixel blocks per wave: 4 or ... (OB = 8 -> 4, OB = 4 -> 2)
-    constexpr int NPB = (OB == 8) ? 4 : 2;
+#ifndef SVPS_K7_O128_FOUR_WAVES
+#define SVPS_K7_O128_FOUR_WAVES 1
+#endif
+    // O = 128, round 4: waves 0 .. 3 own one output block each for ALL four pixel blocks and waves 4 .. 7 only gather / blend (before:
+    // wave w and w + 4 shared an output block for two pixel blocks each and both streamed its weight fragments from L2 - twice the
+    // weight traffic of the O = 256 form per output; tools/kbench_k7.py)
+    constexpr bool kFourMma = OB == 4 && SVPS_K7_O128_FOUR_WAVES;
+    constexpr int NPB = (OB == 8 || kFourMma) ? 4 : 2;
     static_assert(OB == 8 || OB == 4, "O = 256 or 128");
     (void)NB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -57,7 +64,8 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
     const int HWo = Ho * Wo;
     const int p0 = blockIdx.x * kDcPx;
     const int ob = (OB == 8) ? w : (w & 3);
-    const int pb0 = (OB == 8) ? 0 : 2 * (w >> 2);
+    const int pb0 = (OB == 8 || kFourMma) ? 0 : 2 * (w >> 2);
+    const bool mma_wave = !kFourMma || w < 4;
     const int KS = 9 * C / 16;
     const int cchunks = C / kDcCh, nch = 9 * cchunks;
     const float* xn = x + (size_t)n * H * W * C;
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
 #define SVPS_K7_ABL 0          // timing-only ablations (wrong results; separate library): 1 weights of chunk 0 every time (L2-resident), 2 no gather
 #endif
         const int chw = (SVPS_K7_ABL & 1) ? 0 : ch;
+        if (mma_wave) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             ah[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((chw * 4 + u) * 2) * 64]);
@@ -168,6 +177,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], sl[u], acc[b], 0, 0, 0);
             }
         }
+        }
         // The gather of the next chunk is issued AFTER this chunk's MFMAs (they run on while it waits for memory; the partner
         // wave of the SIMD fills the gaps). Issued before them - 80 registers of loaded samples live across the MFMA
         // section - the hipcc build of this kernel returned different, wrong tiles from run to run on gfx950 (every load was
@@ -185,7 +195,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
     // pass re-read the whole result): every wave reduces its pixel blocks over the 32 lanes that hold the same channels and writes ONE
     // partial row per (tile, pixel half) - chunks = tiles (O = 256) or 2 tiles (O = 128) per frame, each (chunk, channel) written by
     // exactly one lane: deterministic, combined in float64 by gn_finalize_kernel
-    if (gn_part) {
+    if (gn_part && mma_wave) {
         float s1[16], s2[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
             for (int i = 0; i < 16; ++i) { s1[i] += __shfl_xor(s1[i], m); s2[i] += __shfl_xor(s2[i], m); }
         }
         if (r == 0) {
-            const int chunks = (OB == 8) ? gridDim.x : 2 * gridDim.x;
-            const int chunk = (OB == 8) ? blockIdx.x : 2 * blockIdx.x + (w >> 2);
+            const int chunks = (OB == 8 || kFourMma) ? gridDim.x : 2 * gridDim.x;
+            const int chunk = (OB == 8 || kFourMma) ? blockIdx.x : 2 * blockIdx.x + (w >> 2);
             float* base = gn_part + (((size_t)n * chunks + chunk) * 2) * (32 * OB) + 32 * ob + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
     }
     // ---- out[n, p, o]: lane (pixel r of block b, h) holds output channels 32 ob + 8 g + 4 h + i ----
     float* on = out + (size_t)n * HWo * (32 * OB);
+    if (!mma_wave) return;
 #pragma unroll
     for (int b = 0; b < NPB; ++b) {
         const int p = p0 + 32 * (pb0 + b) + r;
@@ -238,7 +249,7 @@ extern "C" int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offs
 extern "C" int svps_deform_conv_fused_stats_chunks(int O, int Ho, int Wo) {
     if ((O != 128 && O != 256) || Ho <= 0 || Wo <= 0) return 0;
     const int tiles = (Ho * Wo + svps::kDcPx - 1) / svps::kDcPx;
-    return O == 256 ? tiles : 2 * tiles;
+    return (O == 256 || SVPS_K7_O128_FOUR_WAVES) ? tiles : 2 * tiles;
 }
 
 extern "C" int svps_deform_conv_fused_stats_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, float* gn_partial,
