@@ -213,6 +213,11 @@ int svps_group_norm_relu_stats_fwd(const float* x, const float* partial, int chu
 /* [N, C, HW] fp32 (NCHW) -> [N, HW, C] fp32 pixel-major: the layout copy in front of the semantic tower's first layer (C % 4 == 0,
  * 256 % (C / 4) == 0). */
 int svps_nchw_to_pixel_major(const float* x, float* y, int N, int C, int HW, void* stream);
+/* The prediction layer of the semantic head in one kernel (mmdet/models/panoptic/upsnetFPN.py, forward):
+ * out [N, K, H, W] = conv1x1( cat( p0, up2(p1), up4(p2), up8(p3) ) ) + bias, p_i [N, C, H >> i, W >> i] fp32 NCHW, bilinear
+ * upsampling with align_corners = False (torch's arithmetic), weight [K, 4 C] (K <= 32), H % 8 == W % 8 == 0. */
+int svps_semantic_pred_fwd(const float* p0, const float* p1, const float* p2, const float* p3, const float* weight, const float* bias,
+                           float* out, int N, int C, int K, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Slot-side helpers (slotvps_amd/csrc/row_ops.hip), rows of D = 256 fp32 values.

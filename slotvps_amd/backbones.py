@@ -160,6 +160,7 @@ class UPSNetFPN(nn.Module):
                 m.conv_offset.weight.data.zero_()
                 m.conv_offset.bias.data.zero_()
 
+    fuse_pred = True        # the prediction layer (three upsamplings + concat + 1x1 conv) as one kernel (csrc/semantic_pred.hip)
     fuse_norm = True        # pixel-major tower: K7' -> GroupNorm + ReLU (csrc/gn_relu.hip) without layout copies between the layers
     emit_pm16 = None        # torch.bfloat16 / torch.float16: the last layer also writes its output as 16-bit pixel-major rows, kept in
     #                         `last_pm16` (per returned level, coarse -> fine; None where the fused tower did not run): what K4 reads
@@ -211,6 +212,13 @@ class UPSNetFPN(nn.Module):
         order = [3, 2, 1, 0] if self.return_feat_levels == 4 else [2, 1, 0]
         feat_before = [px[i] for i in order]
         self.last_pm16 = [both[i][1] for i in order] if all(both[i][1] is not None for i in order) else None
-        ups = [px[0]] + [F.interpolate(px[i], None, 2 ** i, mode="bilinear", align_corners=False) for i in (1, 2, 3)]
-        fcn_score = self.conv_pred(torch.cat(ups, dim=1))
+        conv = self.conv_pred.conv
+        if (self.fuse_pred and self.num_levels == 4 and px[0].is_cuda and px[0].dtype == torch.float32 and not torch.is_autocast_enabled()
+                and conv.weight.shape[0] <= 32 and px[0].shape[-2] % 8 == 0 and px[0].shape[-1] % 8 == 0
+                and all(px[i].shape[-2:] == (px[0].shape[-2] >> i, px[0].shape[-1] >> i) and px[i].is_contiguous() for i in range(4))):
+            from . import ops
+            fcn_score = ops.semantic_pred(px, conv.weight, conv.bias)      # upsampling x 3 + concat + 1x1 conv in one kernel
+        else:
+            ups = [px[0]] + [F.interpolate(px[i], None, 2 ** i, mode="bilinear", align_corners=False) for i in (1, 2, 3)]
+            fcn_score = self.conv_pred(torch.cat(ups, dim=1))
         return self.upsample(fcn_score), fcn_score, feat_before

@@ -292,6 +292,29 @@ def nchw_to_pixel_major(x):
     return y
 
 
+def semantic_pred(levels, weight, bias):
+    """fcn_score = conv1x1(cat(p0, up2(p1), up4(p2), up8(p3))) in one kernel (csrc/semantic_pred.hip): levels = four fp32 NCHW maps
+    [N, C, H >> i, W >> i], finest first; weight [K, 4 C, 1, 1] or [K, 4 C]; bias [K] or None -> [N, K, H, W] fp32."""
+    lib = _lib.load()
+    if len(levels) != 4:
+        raise ValueError("semantic_pred takes four pyramid levels")
+    N, C, H, W = levels[0].shape
+    for i, p in enumerate(levels):
+        _need(p, f"levels[{i}]", torch.float32, 4)
+        if p.shape != (N, C, H >> i, W >> i):
+            raise ValueError(f"levels[{i}] {tuple(p.shape)} != [{N}, {C}, {H >> i}, {W >> i}]")
+    w = weight.detach().reshape(weight.shape[0], -1)
+    _need(w, "weight", torch.float32, 2)
+    K = w.shape[0]
+    if w.shape[1] != 4 * C or K > 32 or H % 8 or W % 8:
+        raise ValueError("semantic_pred: weight [K <= 32, 4 C] and H, W multiples of 8 expected")
+    out = torch.empty((N, K, H, W), dtype=torch.float32, device=levels[0].device)
+    with _on(*levels, w, bias, out) as ctx:
+        _lib.check(lib.svps_semantic_pred_fwd(_ptr(levels[0]), _ptr(levels[1]), _ptr(levels[2]), _ptr(levels[3]), _ptr(w), _ptr(bias), _ptr(out),
+                                              N, C, K, H, W, ctx.stream), "svps_semantic_pred_fwd")
+    return out
+
+
 def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False, want_16=None, want_pm=True, stats=None):
     """relu(GroupNorm(groups)(x)) for pixel-major fp32 activations x [N, HW, C] (csrc/gn_relu.hip) -> (y [N, HW, C], y_nchw [N, C, HW]
     or None): the normalisation of the semantic tower in the layout of the deformable-convolution kernel, optionally also in the

@@ -340,3 +340,28 @@ def test_fused_kernel_group_norm_statistics(cuda, N, C, H, W, O):
     y0, n0 = ops.group_norm_relu_pm(a, gamma, beta, 32, 1e-5, want_nchw=True)
     y1, n1 = ops.group_norm_relu_pm(a, gamma, beta, 32, 1e-5, want_nchw=True, stats=(part, chunks))
     assert (y0 - y1).abs().max().item() <= 2e-6 * max(1.0, y0.abs().max().item()) and (n0 - n1).abs().max().item() <= 2e-6 * max(1.0, y0.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 128, 19, 32, 64), (1, 64, 24, 16, 40), (1, 128, 19, 256, 512)])
+def test_semantic_prediction_layer_in_one_kernel(cuda, N, C, K, H, W):
+    """csrc/semantic_pred.hip against the framework's three bilinear upsamplings + concatenation + 1x1 convolution
+    (upsnetFPN.py forward) on the same inputs: the class scores to fp32 rounding of a 4 C-term sum, their argmax on all but a handful
+    of pixels (near-ties; the framework's convolution has its own summation order too)."""
+    import torch
+    import torch.nn.functional as F
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(N + C + H)
+    px = [torch.randn((N, C, H >> i, W >> i), generator=g, device=cuda) for i in range(4)]
+    wgt = torch.randn((K, 4 * C, 1, 1), generator=g, device=cuda) / (4 * C) ** 0.5
+    bias = 0.1 * torch.randn((K,), generator=g, device=cuda)
+    got = ops.semantic_pred(px, wgt, bias)
+    ups = [px[0]] + [F.interpolate(px[i], None, 2 ** i, mode="bilinear", align_corners=False) for i in (1, 2, 3)]
+    cat = torch.cat(ups, dim=1)
+    want = F.conv2d(cat, wgt, bias)
+    ref64 = F.conv2d(cat.double(), wgt.double(), bias.double())
+    e_got, e_fw = (got.double() - ref64).abs().max().item(), (want.double() - ref64).abs().max().item()
+    same = (got.argmax(1) == want.argmax(1)).double().mean().item()
+    print(f"\nsemantic_pred N={N} C={C} K={K} {H}x{W}: {e_got:.2e} against float64 (the framework's convolution: {e_fw:.2e}), argmax equal on {100 * same:.4f} %")
+    assert e_got <= 5e-6 and e_got <= 4 * e_fw + 1e-6 and same >= 0.9999
+    assert torch.equal(got, ops.semantic_pred(px, wgt, bias))
