@@ -160,6 +160,8 @@ class UPSNetFPN(nn.Module):
                 m.conv_offset.weight.data.zero_()
                 m.conv_offset.bias.data.zero_()
 
+    fuse_offset = False     # True: the offset convolutions of the tower on its pixel-major rows (csrc/offset_conv.hip) - measured 3.6 ms
+    #                         against the framework's 3.0 per clip, so off by default
     fuse_pred = True        # the prediction layer (three upsamplings + concat + 1x1 conv) as one kernel (csrc/semantic_pred.hip)
     fuse_norm = True        # pixel-major tower: K7' -> GroupNorm + ReLU (csrc/gn_relu.hip) without layout copies between the layers
     emit_pm16 = None        # torch.bfloat16 / torch.float16: the last layer also writes its output as 16-bit pixel-major rows, kept in
@@ -194,15 +196,26 @@ class UPSNetFPN(nn.Module):
         for i in range(0, len(seq), 3):
             dc, gn = seq[i], seq[i + 1]
             O = dc.conv.weight.shape[0]
-            off = dc.conv_offset(cur_nchw)                                # framework 3 x 3 convolution (NCHW in, [N, 18, H, W] out)
+            co = dc.conv_offset
+            if self.fuse_offset and co.weight.shape[0] <= 32 and co.weight.shape[1] % 16 == 0:
+                # the offset convolution on the pixel-major rows themselves (csrc/offset_conv.hip): no NCHW copy of the layer's input
+                if getattr(co, "_svps_pack_key", None) != (co.weight.data_ptr(), co.weight._version):
+                    co._svps_pack, co._svps_pack_key = ops.pack_conv3x3_small(co.weight), (co.weight.data_ptr(), co.weight._version)
+                off = ops.conv3x3_pm_small(cur_pm, co._svps_pack, co.bias, co.weight.shape[0])
+            else:
+                if cur_nchw is None:
+                    cur_nchw = cur_pm.permute(0, 3, 1, 2).contiguous()
+                off = co(cur_nchw)                                        # framework 3 x 3 convolution (NCHW in, [N, 18, H, W] out)
             # [N, HW, O] + the GroupNorm's per-channel sums from the kernel's epilogue (no moments pass over y)
             y, st = deform_conv_fused_pm(cur_pm, off, dc.conv._weight_pack(), O, 1, 1, 1, gn_stats=True)
             if i + 3 >= len(seq) and self.emit_pm16 is not None:          # last layer: NCHW for the semantic logits, 16-bit rows for K4
                 _, y_nchw, y16 = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=True,
                                                         want_16=self.emit_pm16, want_pm=False, stats=st)
                 return y_nchw.view(N, O, H, W), y16
-            y_pm, y_nchw = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=True, stats=st)
-            cur_pm, cur_nchw = y_pm.view(N, H, W, O), y_nchw.view(N, O, H, W)
+            last = i + 3 >= len(seq)
+            need_nchw = last or not self.fuse_offset                      # the NCHW copy only fed the framework's offset convolution
+            y_pm, y_nchw = ops.group_norm_relu_pm(y, gn.weight, gn.bias, gn.num_groups, gn.eps, want_nchw=need_nchw, stats=st)
+            cur_pm, cur_nchw = y_pm.view(N, H, W, O), (y_nchw.view(N, O, H, W) if y_nchw is not None else None)
         return cur_nchw, None
 
     def forward(self, inputs):

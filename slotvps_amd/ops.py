@@ -292,6 +292,32 @@ def nchw_to_pixel_major(x):
     return y
 
 
+def pack_conv3x3_small(weight):
+    """nn.Conv2d weight [O <= 32, C, 3, 3] -> the packed [32, 9 C] matrix of svps_conv3x3_pm_small_fwd (k = tap C + c, rows >= O zero)."""
+    O, C, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or O > 32 or C % 16:
+        raise ValueError("pack_conv3x3_small: [O <= 32, C % 16 == 0, 3, 3] expected")
+    m = torch.zeros((32, 9 * C), dtype=torch.float32, device=weight.device)
+    m[:O] = weight.detach().float().permute(0, 2, 3, 1).reshape(O, 9 * C)          # (o, ty, tx, c)
+    return pack_b_fragments(m)
+
+
+def conv3x3_pm_small(x_nhwc, wpack, bias, O):
+    """3 x 3 convolution (stride 1, padding 1) with few output channels on pixel-major activations (csrc/offset_conv.hip): x_nhwc
+    [N, H, W, C] fp32 -> [N, O, H, W] fp32; wpack = pack_conv3x3_small(weight). The offset convolution of DeformConvWithOffset."""
+    lib = _lib.load()
+    _need(x_nhwc, "x_nhwc", torch.float32, 4)
+    N, H, W, C = x_nhwc.shape
+    _need(wpack, "wpack", torch.bfloat16, 5)
+    if wpack.shape[0] != 1 or wpack.shape[1] * 16 != 9 * C:
+        raise ValueError("conv3x3_pm_small: packed weight does not match C")
+    out = torch.empty((N, O, H, W), dtype=torch.float32, device=x_nhwc.device)
+    with _on(x_nhwc, wpack, bias, out) as ctx:
+        _lib.check(lib.svps_conv3x3_pm_small_fwd(_ptr(x_nhwc), _ptr(wpack), _ptr(bias), _ptr(out), N, C, H, W, O, ctx.stream),
+                   "svps_conv3x3_pm_small_fwd")
+    return out
+
+
 def semantic_pred(levels, weight, bias):
     """fcn_score = conv1x1(cat(p0, up2(p1), up4(p2), up8(p3))) in one kernel (csrc/semantic_pred.hip): levels = four fp32 NCHW maps
     [N, C, H >> i, W >> i], finest first; weight [K, 4 C, 1, 1] or [K, 4 C]; bias [K] or None -> [N, K, H, W] fp32."""

@@ -365,3 +365,24 @@ def test_semantic_prediction_layer_in_one_kernel(cuda, N, C, K, H, W):
     print(f"\nsemantic_pred N={N} C={C} K={K} {H}x{W}: {e_got:.2e} against float64 (the framework's convolution: {e_fw:.2e}), argmax equal on {100 * same:.4f} %")
     assert e_got <= 5e-6 and e_got <= 4 * e_fw + 1e-6 and same >= 0.9999
     assert torch.equal(got, ops.semantic_pred(px, wgt, bias))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,W", [(2, 256, 24, 40), (1, 128, 17, 23), (1, 64, 5, 7), (1, 256, 64, 128)])
+def test_offset_convolution_on_pixel_major_rows(cuda, N, C, H, W):
+    """csrc/offset_conv.hip (the conv_offset of DeformConvWithOffset on the tower's pixel-major activations, split-bf16 on the matrix
+    cores) against a float64 convolution: fp32-class, like the framework's fp32 convolution; ragged sizes and the zero padding."""
+    import torch
+    import torch.nn.functional as F
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(N + C + H)
+    x = torch.randn((N, C, H, W), generator=g, device=cuda)
+    wgt = torch.randn((18, C, 3, 3), generator=g, device=cuda) / (3 * C ** 0.5)
+    bias = 0.5 * torch.randn((18,), generator=g, device=cuda)
+    got = ops.conv3x3_pm_small(x.permute(0, 2, 3, 1).contiguous(), ops.pack_conv3x3_small(wgt), bias, 18)
+    ref = F.conv2d(x.double(), wgt.double(), bias.double(), padding=1)
+    fw = F.conv2d(x, wgt, bias, padding=1)
+    e_got, e_fw = (got.double() - ref).abs().max().item(), (fw.double() - ref).abs().max().item()
+    print(f"\noffset conv N={N} C={C} {H}x{W}: {e_got:.2e} against float64 (the framework's fp32 convolution {e_fw:.2e})")
+    assert got.shape == (N, 18, H, W) and e_got <= 4e-5          # split-bf16: 16 bits of mantissa over 9 C terms (K7' itself: 2.2e-5)
+    assert torch.equal(got, ops.conv3x3_pm_small(x.permute(0, 2, 3, 1).contiguous(), ops.pack_conv3x3_small(wgt), bias, 18))
