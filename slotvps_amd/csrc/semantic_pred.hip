@@ -31,18 +31,20 @@ struct SpArgs {
     int C, K, H, W;
 };
 
-template <int KU>                 // class scores kept per thread: 20 (Cityscapes' 19) or 32
-__global__ __launch_bounds__(256) void semantic_pred_kernel(SpArgs a) {
+// workgroup = 256 x 4 pixels (1 024 threads sharing one weight tile in LDS: with 256-thread workgroups the 40 - 64 KB tile capped the CU at
+// two to four workgroups - two waves per SIMD, a latency-bound kernel: 5.1 ms for VIPER's ten frames and 23 classes)
+template <int KU>                 // class scores kept per thread: 20 (Cityscapes' 19), 24 (VIPER's 23) or 32
+__global__ __launch_bounds__(1024) void semantic_pred_kernel(SpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wl[];          // [4 C][KU]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.y * 256 + threadIdx.x;
     const int C4 = 4 * a.C;
-    for (int e = tid; e < C4 * KU; e += 256) {
+    for (int e = tid; e < C4 * KU; e += 1024) {
         const int ch = e / KU, k = e - ch * KU;
         wl[e] = k < a.K ? a.w[(size_t)k * C4 + ch] : 0.f;
     }
     __syncthreads();
-    const int x = blockIdx.x * 256 + tid, y = blockIdx.y, n = blockIdx.z;
-    if (x >= a.W) return;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, n = blockIdx.z;
+    if (x >= a.W || y >= a.H) return;
     float acc[KU];
 #pragma unroll
     for (int k = 0; k < KU; ++k) acc[k] = 0.f;
@@ -89,22 +91,27 @@ extern "C" int svps_semantic_pred_fwd(const float* p0, const float* p1, const fl
                                       const float* bias, float* out, int N, int C, int K, int H, int W, void* stream_) {
     if (!p0 || !p1 || !p2 || !p3 || !weight || !out) return SVPS_ERR_BAD_ARG;
     if (N <= 0 || C <= 0 || K <= 0 || K > svps::kSpK || H <= 0 || W <= 0 || (H & 7) || (W & 7)) return SVPS_ERR_BAD_SHAPE;
-    const int ku = K <= 20 ? 20 : svps::kSpK;
+    const int ku = K <= 20 ? 20 : (K <= 24 ? 24 : svps::kSpK);
     const size_t lds = (size_t)4 * C * ku * sizeof(float);
     if (lds > 160 * 1024) return SVPS_ERR_BAD_SHAPE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     svps::SpArgs a{{p0, p1, p2, p3}, weight, bias, out, C, K, H, W};
-    const dim3 grid((W + 255) / 256, H, N);
+    const dim3 grid((W + 255) / 256, (H + 3) / 4, N);
     if (ku == 20) {
         static SvpsLdsAttr attr;
         if (lds > 48 * 1024)
             if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(svps::semantic_pred_kernel<20>), (int)lds); e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(svps::semantic_pred_kernel<20>, grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL(svps::semantic_pred_kernel<20>, grid, dim3(256, 4), lds, stream, a);
+    } else if (ku == 24) {                                    // VIPER's 23 classes
+        static SvpsLdsAttr attr;
+        if (lds > 48 * 1024)
+            if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(svps::semantic_pred_kernel<24>), (int)lds); e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(svps::semantic_pred_kernel<24>, grid, dim3(256, 4), lds, stream, a);
     } else {
         static SvpsLdsAttr attr;
         if (lds > 48 * 1024)
             if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(svps::semantic_pred_kernel<32>), (int)lds); e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(svps::semantic_pred_kernel<32>, grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL(svps::semantic_pred_kernel<32>, grid, dim3(256, 4), lds, stream, a);
     }
     return (int)hipGetLastError();
 }

@@ -343,7 +343,7 @@ def test_fused_kernel_group_norm_statistics(cuda, N, C, H, W, O):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,C,K,H,W", [(2, 128, 19, 32, 64), (1, 64, 24, 16, 40), (1, 128, 19, 256, 512)])
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 128, 19, 32, 64), (1, 64, 24, 16, 40), (1, 128, 30, 24, 40), (1, 128, 19, 256, 512)])
 def test_semantic_prediction_layer_in_one_kernel(cuda, N, C, K, H, W):
     """csrc/semantic_pred.hip against the framework's three bilinear upsamplings + concatenation + 1x1 convolution
     (upsnetFPN.py forward) on the same inputs: the class scores to fp32 rounding of a 4 C-term sum, their argmax on all but a handful
