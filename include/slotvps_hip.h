@@ -221,7 +221,7 @@ int svps_semantic_pred_fwd(const float* p0, const float* p1, const float* p2, co
 /* The offset-producing convolution of DeformConvWithOffset (mmdet/ops/dcn/deform_conv.py: conv_offset - 3 x 3, stride 1, padding 1,
  * C -> O <= 32 channels) on pixel-major activations: x_nhwc [N, H, W, C] fp32, wpack = the [32, 9 C] matrix (row o < O: w[o, c, tap] at
  * k = tap C + c; rows >= O zero) in B-fragment order with bf16 hi + lo halves (ops.pack_b_fragments), bias [O] or NULL ->
- * out [N, O, H, W] fp32 (the layout svps_deform_conv_fused_fwd reads its offsets in). C % 16 == 0. fp32-class. */
+ * out [N, O, H, W] fp32 (the layout svps_deform_conv_fused_fwd reads its offsets in). C % 32 == 0. fp32-class. */
 int svps_conv3x3_pm_small_fwd(const float* x_nhwc, const void* wpack, const float* bias, float* out, int N, int C, int H, int W, int O,
                               void* stream);
 

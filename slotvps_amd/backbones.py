@@ -160,8 +160,8 @@ class UPSNetFPN(nn.Module):
                 m.conv_offset.weight.data.zero_()
                 m.conv_offset.bias.data.zero_()
 
-    fuse_offset = False     # True: the offset convolutions of the tower on its pixel-major rows (csrc/offset_conv.hip) - measured 3.6 ms
-    #                         against the framework's 3.0 per clip, so off by default
+    fuse_offset = True      # the offset convolutions of the tower on its pixel-major rows (csrc/offset_conv.hip: LDS halo tiles, 1.8 ms against the
+    #                         framework's 3.0 per clip) - and no NCHW copy of the intermediate layers any more
     fuse_pred = True        # the prediction layer (three upsamplings + concat + 1x1 conv) as one kernel (csrc/semantic_pred.hip)
     fuse_norm = True        # pixel-major tower: K7' -> GroupNorm + ReLU (csrc/gn_relu.hip) without layout copies between the layers
     emit_pm16 = None        # torch.bfloat16 / torch.float16: the last layer also writes its output as 16-bit pixel-major rows, kept in
@@ -197,7 +197,7 @@ class UPSNetFPN(nn.Module):
             dc, gn = seq[i], seq[i + 1]
             O = dc.conv.weight.shape[0]
             co = dc.conv_offset
-            if self.fuse_offset and co.weight.shape[0] <= 32 and co.weight.shape[1] % 16 == 0:
+            if self.fuse_offset and co.weight.shape[0] <= 32 and co.weight.shape[1] % 32 == 0:
                 # the offset convolution on the pixel-major rows themselves (csrc/offset_conv.hip): no NCHW copy of the layer's input
                 if getattr(co, "_svps_pack_key", None) != (co.weight.data_ptr(), co.weight._version):
                     co._svps_pack, co._svps_pack_key = ops.pack_conv3x3_small(co.weight), (co.weight.data_ptr(), co.weight._version)

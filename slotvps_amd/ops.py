@@ -295,8 +295,8 @@ def nchw_to_pixel_major(x):
 def pack_conv3x3_small(weight):
     """nn.Conv2d weight [O <= 32, C, 3, 3] -> the packed [32, 9 C] matrix of svps_conv3x3_pm_small_fwd (k = tap C + c, rows >= O zero)."""
     O, C, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or O > 32 or C % 16:
-        raise ValueError("pack_conv3x3_small: [O <= 32, C % 16 == 0, 3, 3] expected")
+    if (kh, kw) != (3, 3) or O > 32 or C % 32:
+        raise ValueError("pack_conv3x3_small: [O <= 32, C % 32 == 0, 3, 3] expected")
     m = torch.zeros((32, 9 * C), dtype=torch.float32, device=weight.device)
     m[:O] = weight.detach().float().permute(0, 2, 3, 1).reshape(O, 9 * C)          # (o, ty, tx, c)
     return pack_b_fragments(m)
