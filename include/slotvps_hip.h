@@ -183,9 +183,9 @@ int svps_row_softmax_scaled(const float* x, float* y, int rows, int cols, float 
 int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, int N, int C, int H,
                                int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho, int Wo, void* stream);
 /* The same with the per-channel sums and sums of squares of the result for the GroupNorm behind the layer (round 4: the statistics pass
- * re-read the whole result): gn_partial [N, chunks, 2, O] fp32, chunks = svps_deform_conv_fused_stats_chunks(O, Ho, Wo) per frame,
+ * re-read the whole result): gn_partial [N, chunks, 2, O] fp32, chunks = svps_deform_conv_fused_stats_chunks(N, O, Ho, Wo) per frame (the launch picks its tile shape from N, O, Ho Wo),
  * written deterministically (one lane per entry); hand it to svps_group_norm_relu_stats_fwd. NULL: no statistics. */
-int svps_deform_conv_fused_stats_chunks(int O, int Ho, int Wo);
+int svps_deform_conv_fused_stats_chunks(int N, int O, int Ho, int Wo);
 int svps_deform_conv_fused_stats_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, float* gn_partial, int N, int C,
                                      int H, int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho, int Wo, void* stream);
 

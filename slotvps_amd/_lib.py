@@ -52,7 +52,7 @@ SIGNATURES = {
     "svps_nchw_to_pixel_major": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "svps_semantic_pred_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "svps_conv3x3_pm_small_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "svps_deform_conv_fused_stats_chunks": (_i, [_i, _i, _i]),
+    "svps_deform_conv_fused_stats_chunks": (_i, [_i, _i, _i, _i]),
     "svps_deform_conv_fused_stats_fwd": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "svps_retr_query_prep": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_retr_split": (_i, [_vp, _vp, _vp, _sz, _vp]),

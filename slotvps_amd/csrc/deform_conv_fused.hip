@@ -26,18 +26,30 @@
 
 namespace svps {
 
-constexpr int kDcPx = 128;                 // output pixels per workgroup
-constexpr int kDcCh = 64;                  // channels per chunk (4 k-steps)
-constexpr int kDcRow = kDcCh * 2 + 16;     // bytes per pixel row of a sample tile (padded: conflict-free 16-byte fragment reads)
-
-struct DcLds {
-    static constexpr int coords = 0;                                   // [9][128] x {int idx[4]; float w[4]}
-    static constexpr int bufs = 9 * kDcPx * 32;                        // [2][hi | lo][128 px][kDcRow]
-    static constexpr int buf_bytes = 2 * kDcPx * kDcRow;
-    static constexpr int total = bufs + 2 * buf_bytes;
+// Two tile shapes (round 4), chosen per launch (svps_deform_conv_fused_stats_fwd): 128 output pixels per workgroup in chunks of 64 channels
+// (4 k-steps), or 256 pixels in chunks of 32 channels (2 k-steps) - the same LDS budget and the same MFMAs / gathers per chunk, but every
+// weight fragment streamed from L2 feeds twice the pixels at twice the barriers per MAC. Measured (tools/kbench_k7.py, T = 5):
+// O = 128 at 256 x 512: 2 425 against 2 630 us; O = 256 at 256 x 512: 3 486 against 3 350; 64 x 128 (320 against 160 workgroups on 256
+// CUs): 244 against 352; 32 x 64 (80 against 40 workgroups): 134 against 233.
+template <bool T256>
+struct DcTile {
+    static constexpr int px = T256 ? 256 : 128;        // output pixels per workgroup
+    static constexpr int ch = T256 ? 32 : 64;          // channels per chunk
+    static constexpr int ks = ch / 16;                 // k-steps per chunk
+    static constexpr int gr = ch / 4;                  // 4-channel groups per pixel and chunk
+    static constexpr int row = ch * 2 + 16;            // bytes per pixel row of a sample tile (padded: conflict-free 16-byte fragment reads)
 };
 
-template <int OB>                          // output channel blocks: 8 (O = 256) or 4 (O = 128)
+template <bool T256>
+struct DcLds {
+    static constexpr int coords = 0;                                   // [9][px] x {int idx[4]; float w[4]}
+    static constexpr int bufs = 9 * DcTile<T256>::px * 32;             // [2][hi | lo][px][row]
+    static constexpr int buf_bytes = 2 * DcTile<T256>::px * DcTile<T256>::row;
+    static constexpr int total = bufs + 2 * buf_bytes;
+};
+static_assert(DcLds<true>::total <= 160 * 1024 && DcLds<false>::total <= 160 * 1024, "LDS budget");
+
+template <int OB, bool T256>               // output channel blocks: 8 (O = 256) or 4 (O = 128); tile shape
 __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __restrict__ x,        // [N, H, W, C]
                                                                 const float* __restrict__ offset,   // [N, 18, Ho, Wo]
                                                                 const __bf16* __restrict__ wpack,   // [OB, KS, 2, 64, 8]
@@ -45,7 +57,8 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
                                                                 int C, int H, int W, int Ho, int Wo, int pad, int stride, int dil,
                                                                 float* __restrict__ gn_part = nullptr) {   // [N, chunks, 2, 32 OB] or null
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Lds = DcLds;
+    using Lds = DcLds<T256>;
+    constexpr int kDcPx = DcTile<T256>::px, kDcCh = DcTile<T256>::ch, kDcKs = DcTile<T256>::ks, kDcGr = DcTile<T256>::gr, kDcRow = DcTile<T256>::row;
     constexpr int NB = 32 / OB;            // pixel blocks per wave: 4 or ... (OB = 8 -> 4, OB = 4 -> 2)
 #ifndef SVPS_K7_O128_FOUR_WAVES
 #define SVPS_K7_O128_FOUR_WAVES 1
@@ -54,7 +67,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
     // wave w and w + 4 shared an output block for two pixel blocks each and both streamed its weight fragments from L2 - twice the
     // weight traffic of the O = 256 form per output; tools/kbench_k7.py)
     constexpr bool kFourMma = OB == 4 && SVPS_K7_O128_FOUR_WAVES;
-    constexpr int NPB = (OB == 8 || kFourMma) ? 4 : 2;
+    constexpr int NPB = (OB == 8 || kFourMma) ? kDcPx / 32 : kDcPx / 64;
     static_assert(OB == 8 || OB == 4, "O = 256 or 128");
     (void)NB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
     const int HWo = Ho * Wo;
     const int p0 = blockIdx.x * kDcPx;
     const int ob = (OB == 8) ? w : (w & 3);
-    const int pb0 = (OB == 8 || kFourMma) ? 0 : 2 * (w >> 2);
+    const int pb0 = (OB == 8 || kFourMma) ? 0 : (kDcPx / 64) * (w >> 2);
     const bool mma_wave = !kFourMma || w < 4;
     const int KS = 9 * C / 16;
     const int cchunks = C / kDcCh, nch = 9 * cchunks;
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
         const int t = ch / cchunks, c0 = (ch - t * cchunks) * kDcCh;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int q = tid + 512 * i, px = q >> 4, cg = (q & 15) * 4;
+            const int q = tid + 512 * i, px = q / kDcGr, cg = (q % kDcGr) * 4;
             const int* ci = reinterpret_cast<const int*>(smem + Lds::coords + (t * kDcPx + px) * 32);
             const u32x4 id = *reinterpret_cast<const u32x4*>(ci);
             gw[i] = *reinterpret_cast<const f32x4*>(ci + 4);
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
         char* bh = smem + Lds::bufs + buf * Lds::buf_bytes;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int q = tid + 512 * i, px = q >> 4, cg = (q & 15) * 4;
+            const int q = tid + 512 * i, px = q / kDcGr, cg = (q % kDcGr) * 4;
             bf16x4 vh, vl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -150,28 +163,28 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
         const char* bh = smem + Lds::bufs + (ch & 1) * Lds::buf_bytes;
         const char* bl = bh + kDcPx * kDcRow;
         // weights of the chunk's four k-steps (hi, lo): k-step index of chunk ch = ch * 4 + u  (k = tap * C + c)
-        bf16x8 ah[4], al[4];
+        bf16x8 ah[kDcKs], al[kDcKs];
 #ifndef SVPS_K7_ABL
 #define SVPS_K7_ABL 0          // timing-only ablations (wrong results; separate library): 1 weights of chunk 0 every time (L2-resident), 2 no gather
 #endif
         const int chw = (SVPS_K7_ABL & 1) ? 0 : ch;
         if (mma_wave) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            ah[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((chw * 4 + u) * 2) * 64]);
-            al[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((chw * 4 + u) * 2 + 1) * 64]);
+        for (int u = 0; u < kDcKs; ++u) {
+            ah[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((chw * kDcKs + u) * 2) * 64]);
+            al[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((chw * kDcKs + u) * 2 + 1) * 64]);
         }
 #pragma unroll
         for (int b = 0; b < NPB; ++b) {
             const int prow = (32 * (pb0 + b) + r) * kDcRow + 16 * h;
-            bf16x8 sh[4], sl[4];
+            bf16x8 sh[kDcKs], sl[kDcKs];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kDcKs; ++u) {
                 sh[u] = *reinterpret_cast<const bf16x8*>(bh + prow + 32 * u);
                 sl[u] = *reinterpret_cast<const bf16x8*>(bl + prow + 32 * u);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kDcKs; ++u) {
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], sh[u], acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], sh[u], acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], sl[u], acc[b], 0, 0, 0);
@@ -246,9 +259,39 @@ extern "C" int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offs
     return svps_deform_conv_fused_stats_fwd(x_nhwc, offset, wpack, out, nullptr, N, C, H, W, O, kh, kw, pad, stride, dil, Ho, Wo, stream_);
 }
 
-extern "C" int svps_deform_conv_fused_stats_chunks(int O, int Ho, int Wo) {
-    if ((O != 128 && O != 256) || Ho <= 0 || Wo <= 0) return 0;
-    const int tiles = (Ho * Wo + svps::kDcPx - 1) / svps::kDcPx;
+namespace {
+// tile shape of a launch (see DcTile): deterministic in (N, O, Ho Wo) - the GroupNorm partial rows are laid out per tile. Rule from the
+// measurements of tools/kbench_k7.py (SVPS_K7_TILE=128 / 256 overrides it for such runs)
+bool dc_tile256(int N, int O, int HWo) {
+    static const int forced = [] { const char* e = getenv("SVPS_K7_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 128) return false;
+    if (forced == 256) return true;
+    const long wg128 = (long)((HWo + 127) / 128) * N;
+    const int cus = svps_num_cus();
+    (void)O;
+    return wg128 > cus;     // more than one round of 128-pixel workgroups: the 256-pixel tile wins or ties on every shape of the two towers measured
+                            // (T = 5 at 1024 x 2048: 10.10 -> 9.68 ms over the twelve launches; VIPER T = 10: 20.5 -> 18.4); below that it halves the parallelism
+}
+
+template <int OB, bool T256>
+int dc_launch(const float* x, const float* offset, const void* wpack, float* out, float* gn_partial, int N, int C, int H, int W, int Ho, int Wo,
+              int pad, int stride, int dil, hipStream_t stream) {
+    using T = svps::DcTile<T256>;
+    if (C % T::ch) return SVPS_ERR_BAD_SHAPE;
+    auto kern = svps::deform_conv_fused_kernel<OB, T256>;
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DcLds<T256>::total); ae != hipSuccess) return (int)ae;
+    const int tiles = (Ho * Wo + T::px - 1) / T::px;
+    hipLaunchKernelGGL(kern, dim3(tiles, N), dim3(512), svps::DcLds<T256>::total, stream, x, offset, static_cast<const __bf16*>(wpack), out, C, H, W,
+                       Ho, Wo, pad, stride, dil, gn_partial);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int svps_deform_conv_fused_stats_chunks(int N, int O, int Ho, int Wo) {
+    if ((O != 128 && O != 256) || Ho <= 0 || Wo <= 0 || N <= 0) return 0;
+    const int px = dc_tile256(N, O, Ho * Wo) ? 256 : 128;
+    const int tiles = (Ho * Wo + px - 1) / px;
     return (O == 256 || SVPS_K7_O128_FOUR_WAVES) ? tiles : 2 * tiles;
 }
 
@@ -256,27 +299,19 @@ extern "C" int svps_deform_conv_fused_stats_fwd(const float* x_nhwc, const float
                                                 int N, int C, int H, int W, int O, int kh, int kw, int pad, int stride, int dil, int Ho,
                                                 int Wo, void* stream_) {
     if (!x_nhwc || !offset || !wpack || !out) return SVPS_ERR_BAD_ARG;
-    if (N <= 0 || H <= 0 || W <= 0 || kh != 3 || kw != 3 || C <= 0 || (C % svps::kDcCh) || (O != 128 && O != 256) || stride <= 0 ||
+    if (N <= 0 || H <= 0 || W <= 0 || kh != 3 || kw != 3 || C <= 0 || (C % 64) || (O != 128 && O != 256) || stride <= 0 ||
         dil <= 0 || pad < 0)
         return SVPS_ERR_BAD_SHAPE;
     if (Ho != (H + 2 * pad - (dil * 2 + 1)) / stride + 1 || Wo != (W + 2 * pad - (dil * 2 + 1)) / stride + 1) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W * C >= ((size_t)1 << 31)) return SVPS_ERR_BAD_SHAPE;          // 32-bit pixel indices inside a frame
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int tiles = (Ho * Wo + svps::kDcPx - 1) / svps::kDcPx;
+    const bool t256 = dc_tile256(N, O, Ho * Wo);
     svps_prof_mark(SVPS_KERNEL_DEFORM_CONV, 0, stream);
-    if (O == 256) {
-        auto kern = svps::deform_conv_fused_kernel<8>;
-        static SvpsLdsAttr attr;
-        if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DcLds::total); ae != hipSuccess) return (int)ae;
-        hipLaunchKernelGGL(kern, dim3(tiles, N), dim3(512), svps::DcLds::total, stream, x_nhwc, offset, static_cast<const __bf16*>(wpack),
-                           out, C, H, W, Ho, Wo, pad, stride, dil, gn_partial);
-    } else {
-        auto kern = svps::deform_conv_fused_kernel<4>;
-        static SvpsLdsAttr attr;
-        if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DcLds::total); ae != hipSuccess) return (int)ae;
-        hipLaunchKernelGGL(kern, dim3(tiles, N), dim3(512), svps::DcLds::total, stream, x_nhwc, offset, static_cast<const __bf16*>(wpack),
-                           out, C, H, W, Ho, Wo, pad, stride, dil, gn_partial);
-    }
+    int rc;
+    if (O == 256) rc = t256 ? dc_launch<8, true>(x_nhwc, offset, wpack, out, gn_partial, N, C, H, W, Ho, Wo, pad, stride, dil, stream)
+                            : dc_launch<8, false>(x_nhwc, offset, wpack, out, gn_partial, N, C, H, W, Ho, Wo, pad, stride, dil, stream);
+    else rc = t256 ? dc_launch<4, true>(x_nhwc, offset, wpack, out, gn_partial, N, C, H, W, Ho, Wo, pad, stride, dil, stream)
+                   : dc_launch<4, false>(x_nhwc, offset, wpack, out, gn_partial, N, C, H, W, Ho, Wo, pad, stride, dil, stream);
     svps_prof_mark(SVPS_KERNEL_DEFORM_CONV, 1, stream);
-    return (int)hipGetLastError();
+    return rc;
 }

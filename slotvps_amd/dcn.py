@@ -51,7 +51,7 @@ def deform_conv_fused_pm(x_nhwc, offset, wpack, O, stride=1, padding=0, dilation
         raise ValueError("deform_conv_fused_pm: x [N, H, W, C] fp32 contiguous and offset [N, 18, Ho, Wo] expected")
     out = torch.empty((N, Ho * Wo, O), dtype=torch.float32, device=x_nhwc.device)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
-    chunks = lib.svps_deform_conv_fused_stats_chunks(O, Ho, Wo) if gn_stats else 0
+    chunks = lib.svps_deform_conv_fused_stats_chunks(N, O, Ho, Wo) if gn_stats else 0
     part = torch.empty((N, chunks, 2, O), dtype=torch.float32, device=x_nhwc.device) if gn_stats else None
     with ops._on(x_nhwc, offset, wpack, out, part) as ctx:
         rc = lib.svps_deform_conv_fused_stats_fwd(p(x_nhwc), p(offset), p(wpack), p(out), p(part), N, C, H, W, O, 3, 3, p_, s, d, Ho, Wo,
