@@ -76,11 +76,12 @@ def dist_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, single_rank_group=False):
     """Initialise torch.distributed when launched with WORLD_SIZE > 1. backend: 'nccl' (= RCCL on ROCm)
-    on GPUs, 'gloo' on CPU. Returns (rank, local_rank, world)."""
+    on GPUs, 'gloo' on CPU. single_rank_group: create the process group for a world of one as well (the collectives then run
+    through the backend with one member: how the RCCL path is exercised on a one-GPU box). Returns (rank, local_rank, world)."""
     rank, local_rank, world = dist_env()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -172,17 +173,19 @@ class ClipResultGatherer:
     over that peer's direct xGMI link); the caller goes on with the next clip and a staging set is only waited for when
     it comes round again. `drain` waits for everything in flight. No collective touches the data path of the kernels.
 
-    Single process (world 1): the staging copy is the whole operation."""
+    No process group (a plain single process): the staging copy is the whole operation. With a process group the gathers are
+    issued whatever its size (a group of one still goes through the backend)."""
 
     def __init__(self, template, depth=2):
-        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.collective = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.collective else 1
+        self.rank = dist.get_rank() if self.collective else 0
         self.names = sorted(template)
         self.depth = max(1, depth)
         self.device = next(iter(template.values())).device
         self.stage = [{k: torch.empty_like(template[k]) for k in self.names} for _ in range(self.depth)]
         self.recv = None
-        if self.world > 1 and self.rank == 0:
+        if self.collective and self.rank == 0:
             self.recv = [{k: [torch.empty_like(template[k]) for _ in range(self.world)] for k in self.names}
                          for _ in range(self.depth)]
         self.pending = [[] for _ in range(self.depth)]
@@ -204,7 +207,7 @@ class ClipResultGatherer:
         st = self.stage[d]
         for k in self.names:
             st[k].copy_(tensors[k], non_blocking=True)
-        if self.world == 1:
+        if not self.collective:
             return d
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
@@ -226,6 +229,6 @@ class ClipResultGatherer:
 
     def last(self, d):
         """Rank 0, after the staging set `d` has been waited for: name -> list over ranks of the gathered tensors."""
-        if self.world == 1:
+        if not self.collective:
             return {k: [self.stage[d][k]] for k in self.names}
         return self.recv[d] if self.rank == 0 else None

@@ -746,6 +746,27 @@ class MultiScaleDynamicMaskHead(nn.Module):
         if self._cfg_precision is not None:              # a config selects the mode with other_config=dict(precision="fp16x2")
             self.set_precision(self._cfg_precision)
 
+    # name -> (precision, map storage, statistics form, retriever form)
+    MODES = {
+        "bf16": ("bf16", "bf16", "fast", "fused"),
+        "fp16": ("bf16", "fp16", "fast", "fused"),
+        "fp16x2": ("fp16x2", "bf16", "fast", "fused"),
+        "fp32": ("fp32", "bf16", "fast", "fused"),
+        "bf16_kv": ("bf16", "bf16", "fast", "kv"),
+        "bf16_balanced": ("bf16", "bf16", "balanced", "fused"),
+        "bf16_tight": ("bf16", "bf16", "tight", "fused"),
+        "fp16_balanced": ("bf16", "fp16", "balanced", "fused"),
+        "fp16_tight": ("bf16", "fp16", "tight", "fused"),
+    }
+
+    def set_mode(self, name):
+        if name not in self.MODES:
+            raise ValueError(f"mode must be one of {sorted(self.MODES)}, not {name!r}")
+        prec, maps, stats, retr = self.MODES[name]
+        self.set_precision(prec).set_map_dtype(maps).set_statistics(stats).set_retriever(retr)
+        self.mode = name
+        return self
+
     def set_precision(self, mode):
         """"bf16" (default): bf16 storage of the pixel-side tensors, matrix-core kernels. "fp32": exact mode - fp32 storage and
         arithmetic everywhere (csrc/exact_f32.hip), the reference's own dtype (vps_temporal_slots.py:55), on the vector ALU.

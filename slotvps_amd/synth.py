@@ -228,3 +228,25 @@ def make_decode_case(seed, L=100, h=12, w=20, D=256):
                 feat_bn=(f32(rng.uniform(0.5, 1.5, D)), f32(0.1 * rng.standard_normal(D)), f32(0.2 * rng.standard_normal(D)),
                          f32(rng.uniform(0.5, 2.0, D))),
                 fg_bn=(f32([0.1]), f32([0.03]), f32([0.2]), f32([1.7])))
+
+
+def temper_queries(params, tau):
+    """Scale the query LayerNorm (inst_interact.norm_q.{weight,bias}) of every slot<->pixel retriever by `tau` (in place).
+    make_params gives LayerNorm gains U(0.5, 1.5) on 256-wide rows, i.e. UNSCALED logits q.k (dynamic_mask_head.py:435) with
+    sigma ~ 16: each of the seven stages then amplifies a perturbation of its incoming slots 2 - 4 x, and the reference's OWN
+    fp32 result sits 5e-4 ... 1.5e-3 (mask logits) from its float64 evaluation - no implementation can be held to 1e-4 free-running
+    on such weights, the reference under another summation order included. tau = 0.25 (logit sigma ~ 4) keeps the chain near
+    contractive (reference fp32 vs float64: ~2e-5): the regime in which the north star's free-running tolerance is decidable.
+    The full-size fixture (tests/golden/make_golden_full.py) holds both regimes and records the reference's own floor for each."""
+    for k in params:
+        if "inst_interact.norm_q." in k and "temporal_query_head" not in k:
+            params[k] = (params[k] * np.float32(tau)).astype(np.float32)
+    return params
+
+
+def make_feat_bn(seed, D=256):
+    """Eval-mode BatchNorm parameters of the decode (feat_bn [4, D]: weight, bias, running_mean, running_var; fg_bn [4])."""
+    rng = np.random.default_rng(seed)
+    bn = np.stack([rng.uniform(0.5, 1.5, D), 0.1 * rng.standard_normal(D), 0.2 * rng.standard_normal(D),
+                   rng.uniform(0.5, 2.0, D)]).astype(np.float32)
+    return bn, np.array([0.1, 0.03, 0.2, 1.7], dtype=np.float32)

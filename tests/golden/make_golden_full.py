@@ -1,0 +1,137 @@
+"""Full-size golden fixture (tests/golden/head_full.npz): the REFERENCE's own MultiScaleDynamicMaskHead
+(mmdet/models/detectors/dynamic_mask_head.py:138-228) + the six lines of generate_final_outputs (vps_temporal_slots.py:144-160)
+run at BASELINE.json's sizes in the build container, stored compactly.
+
+Cases (weights / inputs / slots regenerated from the seeds by slotvps_amd.synth; nothing of the reference is stored but outputs):
+  T5_1024x2048_L100        config 2 (1024 x 2048, T = 5, 100 slots, 20 classes); query LayerNorms tempered x0.25 (synth.temper_queries):
+                           the regime in which the reference's fp32 result is reproducible to ~2e-5, so that the north star's
+                           free-running tolerance (1e-4 on the mask logits, identical slot argmax) is decidable
+  T2_1024x2048_L100_sharp  the same head with the untempered synth weights every other fixture uses (logit sigma ~ 16): the chain amplifies
+                           2 - 4 x per stage and the reference's own fp32 result sits ~1e-3 from its float64 evaluation - the per-stage
+                           (teacher-forced) errors are the meaningful numbers here, the free-running ones are bounded by that floor
+  T2_1088x1920_L200        config 5's geometry (VIPER 1080 x 1920 padded, 200 slots, 24 classes, level sizes 34x60 ... 272x480), tempered
+
+Per case: per-stage slot embeddings [T, 7, L, 256] and class logits [T, 7, L, nc]; of the decode of EVERY frame (its own last-stage
+embeddings, its own finest fused map): the uint8 per-pixel slot argmax [T, HW], the top-2 margin as fp16 [T, HW], a strided sample of
+the fp32 mask logits [T, L, H/sy, W/sx]; strided samples of the fused maps (finest level of the last frame, coarsest level of frame 0);
+and `floor`: the distance of the reference's fp32 run from the SAME modules run in float64 on the same inputs (per-stage embeddings,
+mask logits, fraction of pixels with the same argmax) - the reference's own reproducibility at this size.
+
+Runs only here (needs /root/reference); ~3 minutes, ~25 GB. Usage: python tests/golden/make_golden_full.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from slotvps_amd import synth  # noqa: E402
+import make_golden as mg  # noqa: E402
+
+D = 256
+CASES = {   # tag: (T, H, W, L, num_classes, seed, tau, (sy, sx) mask sample strides)
+    "T5_1024x2048_L100": (5, 1024, 2048, 100, 20, 501, 0.25, (8, 16)),
+    "T2_1024x2048_L100_sharp": (2, 1024, 2048, 100, 20, 502, 1.0, (8, 16)),
+    "T2_1088x1920_L200": (2, 1088, 1920, 200, 24, 503, 0.25, (8, 16)),
+}
+FUSED3_STRIDE, FUSED0_STRIDE = 16, 4
+
+
+def build_head(dmh, nc):
+    cfg = synth.R50_HEAD_CFG
+    return dmh.MultiScaleDynamicMaskHead(
+        dh_dim=D, num_classes=nc, dim_feedforward=cfg["dim_feedforward"], nhead=cfg["nhead"],
+        dropout=0.0, activation=cfg["activation"], dh_num_heads=7, per_dh_num_heads=list(cfg["per_dh_num_heads"]),
+        feat_num_levels=4, merge_operation="concat", trans_in_dim=cfg["trans_in_dim"], return_intermediate=True,
+        use_focal=True, prior_prob=0.01, num_cls=cfg["num_cls"], num_reg=cfg["num_reg"], drop_path=0.,
+        temporal_query_attention_config=dict(d_model=D, dim_feedforward=cfg["temporal_dim_feedforward"], dropout=0.0,
+                                             activation=cfg["temporal_activation"], softmax_dim="slots", drop_path=0.),
+        apply_temporal_query_atten_stages=list(cfg["apply_temporal_query_atten_stages"])).eval()
+
+
+def run(dmh, pos_mod, NestedTensor, case, dt):
+    T, H, W, L, nc, seed, tau, _ = case
+    head = build_head(dmh, nc)
+    params = synth.temper_queries(synth.make_params(synth.head_shapes(dict(synth.R50_HEAD_CFG, num_classes=nc)), seed), tau)
+    mg.load_state(head, params)
+    head = head.to(dt)
+    sizes = synth.level_sizes(H, W)
+    feats = synth.make_clip_features(seed + 1, T, H, W)
+    slots = synth.make_slots(seed + 2, L)
+    pos = [pos_mod(NestedTensor(torch.zeros(1, 128, h, w), torch.zeros(1, h, w, dtype=torch.bool))).to(dt) for (h, w) in sizes]
+    features = [[torch.from_numpy(f[None]).to(dt) for f in feats[t]] for t in range(T)]
+    del feats
+    init = [torch.from_numpy(slots.copy()).to(dt) for _ in range(T)]
+    logits, embeds, fused = head(features=features, init_masks=init, pad_mask=None, pos=[pos for _ in range(T)], query_pos=None)
+    del features
+    bn, fg = synth.make_feat_bn(seed + 3)
+    feat_bn, fg_bn = nn.BatchNorm2d(D).eval(), nn.BatchNorm2d(1).eval()
+    feat_bn.weight.data, feat_bn.bias.data = torch.from_numpy(bn[0]), torch.from_numpy(bn[1])
+    feat_bn.running_mean.data, feat_bn.running_var.data = torch.from_numpy(bn[2]), torch.from_numpy(bn[3])
+    fg_bn.weight.data.fill_(float(fg[0])); fg_bn.bias.data.fill_(float(fg[1]))
+    fg_bn.running_mean.data.fill_(float(fg[2])); fg_bn.running_var.data.fill_(float(fg[3]))
+    feat_bn, fg_bn = feat_bn.to(dt), fg_bn.to(dt)
+    masks = []
+    for t in range(T):
+        g = torch.nn.functional.normalize(feat_bn(fused[t][3]), p=2, dim=1)          # vps_temporal_slots.py:146-147
+        m = torch.einsum("nchw,nlc->nlhw", g, embeds[t][-1])                          # :149
+        m = fg_bn(m.permute(1, 0, 2, 3)).permute(1, 0, 2, 3)                          # :153-154
+        masks.append(m[0])                                                            # [L, h, w]
+    E = torch.stack([e[:, 0] for e in embeds])                                        # [T, 7, L, 256]
+    C = torch.stack([c[:, 0] for c in logits])                                        # [T, 7, L, nc]
+    return E, C, torch.stack(masks), fused
+
+
+def main():
+    torch.set_grad_enabled(False)
+    dmh, pe, NestedTensor = mg.load_reference("/root/reference")
+    pos_mod = pe.PositionEmbeddingSine(128, normalize=True)
+    out = {}
+    for tag, case in CASES.items():
+        T, H, W, L, nc, seed, tau, (sy, sx) = case
+        t0 = time.time()
+        E, C, M, fused = run(dmh, pos_mod, NestedTensor, case, torch.float32)
+        h3, w3 = M.shape[-2:]
+        srt = M.topk(2, dim=1)
+        out[f"{tag}_meta"] = np.array([T, H, W, L, nc, seed, sy, sx, FUSED3_STRIDE, FUSED0_STRIDE], dtype=np.int64)
+        out[f"{tag}_tau"] = np.float32(tau)
+        out[f"{tag}_embeds"] = E.numpy().astype(np.float32)
+        out[f"{tag}_logits"] = C.numpy().astype(np.float32)
+        out[f"{tag}_argmax"] = srt.indices[:, 0].reshape(T, -1).numpy().astype(np.uint8)
+        out[f"{tag}_margin"] = (srt.values[:, 0] - srt.values[:, 1]).reshape(T, -1).numpy().astype(np.float16)
+        out[f"{tag}_mask_sample"] = M[:, :, ::sy, ::sx].contiguous().numpy().astype(np.float32)
+        out[f"{tag}_mask_absmax"] = np.float32(M.abs().max().item())
+        f3 = fused[T - 1][3][0]                                                        # [256, h, w]
+        out[f"{tag}_fused3_sample"] = f3[:, ::FUSED3_STRIDE, ::FUSED3_STRIDE].permute(1, 2, 0).contiguous().numpy().astype(np.float32)
+        f0 = fused[0][0][0]
+        out[f"{tag}_fused0_sample"] = f0[:, ::FUSED0_STRIDE, ::FUSED0_STRIDE].permute(1, 2, 0).contiguous().numpy().astype(np.float32)
+        out[f"{tag}_fused3_absmax"] = np.float32(f3.abs().max().item())
+        t1 = time.time()
+        am32 = srt.indices[:, 0].clone()
+        del fused, srt
+        E64, C64, M64, fused64 = run(dmh, pos_mod, NestedTensor, case, torch.float64)
+        del fused64
+        fl_e = [(E.double()[:, s] - E64[:, s]).abs().max().item() for s in range(7)]
+        fl_c = [(C.double()[:, s] - C64[:, s]).abs().max().item() for s in range(7)]
+        fl_m = (M.double() - M64).abs().max().item()
+        same = (am32 == M64.argmax(dim=1)).double().mean().item()
+        out[f"{tag}_floor_embeds"] = np.array(fl_e, dtype=np.float64)
+        out[f"{tag}_floor_logits"] = np.array(fl_c, dtype=np.float64)
+        out[f"{tag}_floor_mask"] = np.float64(fl_m)
+        out[f"{tag}_floor_argmax_same"] = np.float64(same)
+        print(f"{tag}: fp32 {t1 - t0:.0f} s, float64 {time.time() - t1:.0f} s; the reference's fp32 run vs float64: embeddings per stage "
+              + " ".join(f"{x:.1e}" for x in fl_e) + f"; mask logits {fl_m:.2e} (|m| <= {M.abs().max().item():.2f}); argmax equal on "
+              f"{100 * same:.4f} %; slots owning pixels: {am32.unique().numel()} of {L}", flush=True)
+        del E, C, M, E64, C64, M64
+    path = os.path.join(mg.GOLDEN, "head_full.npz")
+    np.savez_compressed(path, **out)
+    print(os.path.basename(path), os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

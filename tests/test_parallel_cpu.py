@@ -174,3 +174,28 @@ def test_bench_launcher_starts_the_ranks_itself():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "refusing" in r.stderr
+
+
+def _one_rank_worker(port, q):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from slotvps_amd import parallel
+    parallel.init_distributed(backend="gloo", single_rank_group=True)
+    tmpl = parallel.clip_result_template(2, 8, 16, torch.device("cpu"))
+    gat = parallel.ClipResultGatherer(tmpl, depth=2)
+    assert gat.collective and gat.world == 1
+    for i in range(3):
+        d = gat.submit({k: torch.full_like(v, i + 1) for k, v in tmpl.items()})
+    gat.drain()
+    q.put((d, int(gat.last(d)["fcn_outputs"][0][0, 0, 0]), parallel.max_over_ranks(2.5, torch.device("cpu"))))
+    torch.distributed.destroy_process_group()
+
+
+def test_group_of_one_goes_through_the_backend():
+    """A process group of ONE rank still issues the gathers (the CPU rehearsal of tests/test_parallel_gpu.py::test_one_rank_nccl_group)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=120)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and out == (0, 3, 2.5)
