@@ -450,14 +450,6 @@ int svps_probe_mix(const void* src, void* dst, size_t units, int ri, int ro, voi
 int svps_retr_stats_fwd(const void* feat, const float* ty, const float* tx, const void* rk, const float* rbk,
                         float lnk_eps, const void* rv, const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D,
                         int flags, void* stream);
-/* svps_retr_stats_tight_fwd: the same statistics with BOTH factors as FP16 hi + lo (hi + lo = R to 22 bits;
- * slotvps_amd/csrc/retr_stats_t.hip): rstd_k (in front of logits of magnitude up to ~80, dynamic_mask_head.py:431-435) and rstd_v to
- * ~2e-7 relative instead of ~3e-5 / ~5e-5 - the statistics of the fused retriever's precision mode
- * (MaskDynamicConv.tight), a plain kernel launched once per projection. Same aux rows; tiles need not lie inside an image row.
- * ty / tx both NULL: no position term. */
-int svps_retr_stats_tight_fwd(const void* feat, const float* ty, const float* tx, const void* rk_hi, const void* rk_lo,
-                              const float* rbk, float lnk_eps, const void* rv_hi, const void* rv_lo, const float* rbv,
-                              float lnv_eps, void* aux, int T, int H, int W, int D, int flags, void* stream);
 /* svps_retr_stats_level_fwd: the statistics of ALL retriever stages of one pyramid level (n_stages = 1 or 2; the stages of a level
  * read the same fused map, MultiScaleDynamicMaskHead.forward :190-215) in ONE read of the map (slotvps_amd/csrc/retr_stats2.hip:
  * eight waves, stage s on waves 4 s .. 4 s + 3, factors in AGPRs). Arguments as svps_retr_stats_fwd, as HOST arrays of n_stages device
@@ -472,16 +464,9 @@ int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const fl
                        const void* feat, const void* aux, void* workspace,
                        size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,
                        int flags, void* stream);
-/* svps_retr_attn_tight_fwd: the precision form for L <= 128 (P * rstd_v carried as fp16 hi + lo: the consumers' matrix work
- * twice; with svps_retr_stats_tight_fwd the fused retriever agrees with a float64 evaluation of dynamic_mask_head.py:423-461 to the
- * 1e-4 class instead of 1e-3). Same contract and workspace as svps_retr_attn_fwd. */
-int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
-                       const void* feat, const void* aux, void* workspace,
-                       size_t workspace_bytes, float* out_ext, int T, int L, int H, int W, int D, int chunks,
-                       int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Reference precision ON THE MATRIX CORES (round 4; head.set_precision("fp16x2")): the reference runs this path in fp32
+ * Reference precision ON THE MATRIX CORES (round 4; head.set_mode("fp16x2")): the reference runs this path in fp32
  * (fp16_enabled = False, mmdet/models/detectors/vps_temporal_slots.py:55). gfx950's fp32 matrix instructions run at the vector
  * rate, so these entry points carry every 16-bit matrix operand as FP16 hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 bits of
  * mantissa, |x| < 65 504) and spend three MFMAs per product (hi hi + lo hi + hi lo) into one fp32 accumulator. The fused level maps
@@ -493,13 +478,13 @@ int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, co
  *                              [T, (H/2)(W/2), 256] fp32 = f_{i-1} W_a^T (svps_slot_gemm_f16 on the coarser level's fp32 copy) or NULL
  *                              (level 0: wb = W_1 + W_2 + W_3); wb_hi / wb_lo [256, 128] fp16; out_hi / out_lo the planes; out_f32 the
  *                              same values as fp32 [T, H*W, 256] (the operand of the next level's coarse product) or NULL
- *   svps_retr_stats_hl_fwd   = svps_retr_stats_tight_fwd (:432-433, the two LayerNorm statistics) on the planes, both projections from
+ *   svps_retr_stats_hl_fwd   = svps_retr_stats_fwd (:432-433, the two LayerNorm statistics) with hi + lo factors on the planes, both projections from
  *                              ONE read (slotvps_amd/csrc/retr_stats_hl.hip); same aux rows. The fp32 tables come in ACCUMULATOR order
  *                              (column 32 B + 16 h + 4 g + j = factor row 32 B + 8 g + 4 h + j): tyk [ty_rows, 256] = Ty + r_k, txk
  *                              [tx_rows, 256] = Tx (ty_rows = H or 1, tx_rows = W or 1: no position term), rbv [256] = r_v; tx_tiled
  *                              (W % 32 == 0): txk re-ordered to [W / 32][8 B][4 g][2 h][32 pixels][4 j], so that a wave's load for the
  *                              32 pixels of a tile is one contiguous KiB
- *   svps_retr_attn_hl_fwd    = svps_retr_attn_tight_fwd (:435-456) on the planes, L <= 128; tiles of 16 pixels (hi rows + lo rows of
+ *   svps_retr_attn_hl_fwd    = svps_retr_attn_fwd (:435-456) with hi + lo probabilities on the planes; tiles of 16 pixels (hi rows + lo rows of
  *                              the same pixels share one LDS tile); workspace svps_retr_attn_hl_workspace_bytes()
  *   svps_mask_decode_hl_fwd  = svps_mask_decode_fwd (vps_temporal_slots.py:144-160) on the planes: fp32 logits [T, L, HW] (required),
  *                              optional fused slot argmax [T, HW]; any HW, L <= 256

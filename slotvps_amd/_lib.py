@@ -72,10 +72,8 @@ SIGNATURES = {
     "svps_bgemm_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "svps_retr_stats_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "svps_retr_stats_level_fwd": (_i, [_vp, _i] + [_vp] * 9 + [_i, _i, _i, _i, _i, _vp]),
-    "svps_retr_stats_tight_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "svps_retr_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "svps_retr_attn_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "svps_retr_attn_tight_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_level_fuse_hl_fwd": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),   # cur, gprev, wb_hi, wb_lo, bc, out_hi, out_lo, out_f32
     "svps_retr_stats_hl_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "svps_retr_attn_hl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -111,7 +111,7 @@ class SlotClipRunner:
                                              want_argmax=True)
             if not self.decode_logits:
                 masks = None
-        elif fused[-1].dtype == torch.float32:               # exact mode (head.set_precision("fp32")): fp32 map, fp32 decode kernel
+        elif fused[-1].dtype == torch.float32:               # exact mode (head.set_mode("fp32")): fp32 map, fp32 decode kernel
             masks = ops.mask_decode_f32(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift, self.fg_scale, self.fg_shift)
             amax = masks.argmax(dim=1).to(torch.uint8)
             if not self.decode_logits:
@@ -231,7 +231,7 @@ class SlotClipRunner:
         stages = sum(n for _, n in self.k1_launch_shapes())
         if getattr(self.head, "precision", "bf16") == "fp16x2":
             # reference precision on the matrix cores: the maps are 1 KiB per pixel (fp16 hi + lo planes). Algorithmic flops = one product
-            # per multiply; executed = the MFMAs issued (three per product in K4 / K3t / K2; K1'-HL: 4 x 32 producer + 4 x 26 consumer per
+            # per multiply; executed = the MFMAs issued (three per product in K4 / K3-HL / K2; K1'-HL: 4 x 32 producer + 4 x 26 consumer per
             # 16-pixel tile). K3-HL reads both planes once per stage; K4-HL: the fine part K = 128 (the 256-wide coarse product runs on K8).
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
             return {

@@ -1489,12 +1489,6 @@ int launch_retr_precise(const void* qh, const void* ql, const float* cy, const f
 }
 }  // namespace
 
-extern "C" int svps_retr_attn_tight_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
-                                        const void* feat, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext,
-                                        int T, int L, int H, int W, int D, int chunks, int flags, void* stream_) {
-    return launch_retr_precise(qh, ql, cy, cx, c3, feat, nullptr, aux, workspace, workspace_bytes, out_ext, T, L, H, W, D, chunks, flags, stream_);
-}
-
 extern "C" size_t svps_retr_attn_hl_workspace_bytes(int T, int L, int H, int W, int chunks) {
     if (T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return 0;
     const RetrPlan p = plan_retr(T, H, W, chunks, 16);

@@ -5,7 +5,7 @@
 // (retr_stats.hip). In the reference-precision mode (precision "fp16x2") the map is f = hi + lo (two fp16 planes, level_fuse_hl.hip) and
 // both factors are R = hi + lo: R x = R_hi x_hi + R_lo x_hi + R_hi x_lo, three MFMAs per k-step into one fp32 accumulator.
 //
-// The first form of this path (retr_stats_t.hip's HL template: one launch per projection, register-staged tiles one ahead) read the
+// The first form of this path (one launch per projection, register-staged tiles one ahead) read the
 // planes twice and had ONE tile in flight per CU: 41.6 ms of a 160-frame step, 2.7 TB/s - the latency of a tile's loads, not a resource.
 // The second (four waves of 512 registers, all four factor matrices per wave, both chains in turn): 31 ms - its timing-only ablations
 // (SVPS_SHL_ABL) showed the parts of a lone in-order wave ADDING UP: matrix chain 1 160 us + position tables 620 + tile loads 515 + rest 420

@@ -380,14 +380,14 @@ class VPS_Temporal_Slots(nn.Module):
         head = im.dynamic_mask_head
         # The captured graph bakes in pointers to weight-DERIVED tensors (packed K8 weights, QR factors, position tables) and the
         # kernel choices of the current modes: key it on the identity + version of every head parameter and on the mode switches,
-        # so load_state_dict / in-place edits / set_precision / set_retriever / set_slot_gemm / the ops-level forms re-capture.
+        # so load_state_dict / in-place edits / set_mode / set_slot_gemm / the statistics form re-capture.
         hws = getattr(feats, "hws", None) or [tuple(f.shape[-2:]) for f in feats]
         folded = bool(getattr(feats, "folded", False))
         pre = (im.conv_trans.conv.weight, im.conv_trans.conv.bias) if folded else None
         wkey = tuple((p_.data_ptr(), p_._version) for p_ in head.parameters()) + (im.init_mask_query.weight.data_ptr(), im.init_mask_query.weight._version) \
             + (tuple((p_.data_ptr(), p_._version) for p_ in pre if p_ is not None) if folded else ())
-        modes = tuple(sorted({(type(m).__name__, getattr(m, "precision", None), getattr(m, "retriever", None), getattr(m, "use_slot_gemm", None), getattr(m, "tight_stats", None), getattr(m, "precise_query_p", None), getattr(m, "query_side", None), getattr(m, "map_dtype", None), getattr(m, "map_encoding", None), getattr(m, "range_check", None))
-                              for m in head.modules() if hasattr(m, "precision")})) + (ops.RETR_STATS_FORM,)
+        modes = (head.mode, head.stats_form, head.map_encoding) + tuple(sorted({(type(m).__name__, getattr(m, "use_slot_gemm", None), getattr(m, "query_side", None), getattr(m, "range_check", None))
+                                                                                 for m in head.modules() if hasattr(m, "precision")}))
         key = tuple(tuple(f.shape) for f in feats) + (str(feats[0].device), str(feats[0].dtype), folded, tuple(hws), hash(wkey), modes)
         ent = self._head_cache.get(key)
         if ent is None:

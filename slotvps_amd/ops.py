@@ -407,37 +407,6 @@ def retr_stats(feat, H, W, pos_proj, rk, rbk, eps_k, rv, rbv, eps_v):
     return aux
 
 
-def retr_stats_tight(feat, H, W, pos_proj, rk_hi, rk_lo, rbk, eps_k, rv_hi, rv_lo, rbv, eps_v):
-    """K3t (csrc/retr_stats_t.hip): retr_stats with both factors as fp16 hi + lo (hi + lo = R to 22 bits): rstd_k, rstd_v to ~2e-7
-    relative instead of ~3e-5 / ~5e-5 - the statistics of the fused retriever's precision mode. Same aux rows."""
-    lib = _lib.load()
-    mflag = _map_flag(feat)
-    T, HW, D = feat.shape
-    if HW != H * W:
-        raise ValueError("feat rows != H*W")
-    for name, m in (("rk_hi", rk_hi), ("rk_lo", rk_lo), ("rv_hi", rv_hi), ("rv_lo", rv_lo)):
-        _need(m, name, torch.float16, 2)
-        if m.shape != (D, D):
-            raise ValueError(f"{name} must be [256, 256]")
-    _need(rbk, "rbk", torch.float32, 1)
-    _need(rbv, "rbv", torch.float32, 1)
-    ytab = xtab = None
-    if pos_proj is not None:
-        ytab, xtab = pos_proj
-        _need(ytab, "ty", torch.float32, 2)
-        _need(xtab, "tx", torch.float32, 2)
-        if ytab.shape != (H, D) or xtab.shape != (W, D):
-            raise ValueError("projected position tables do not match (H, W)")
-    aux = torch.empty((T, HW, 8), dtype=torch.float16, device=feat.device)
-    with _on(feat, ytab, xtab, rk_hi, rk_lo, rbk, rv_hi, rv_lo, rbv) as ctx:
-        rc = lib.svps_retr_stats_tight_fwd(_ptr(feat), _ptr(ytab), _ptr(xtab), _ptr(rk_hi), _ptr(rk_lo), _ptr(rbk), float(eps_k),
-                                           _ptr(rv_hi), _ptr(rv_lo), _ptr(rbv), float(eps_v), _ptr(aux), T, H, W, D, mflag, ctx.stream)
-    _lib.check(rc, "svps_retr_stats_tight_fwd")
-    return aux
-
-
-RETR_STATS_FORM = "level"  # "level": csrc/retr_stats2.hip, every stage of a pyramid level in one read of the map; "stage": csrc/retr_stats.hip per stage
-
 _ZERO_TABLES = {}
 
 
@@ -496,7 +465,7 @@ def retr_slot_pad(L):
     return 128 if L <= 128 else 256
 
 
-def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0, tight=False):
+def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0):
     """K1': out_ext [T, L, 272] fp32 = {sum_p P rstd_v f_p, sum_p P rstd_v, sum_p P, 0...} with P the softmax over slots of
     rstd_k (Q''.f + cy + cx) + c3 (rstd_k, rstd_v: from the aux rows of retr_stats). qh / ql [T, LP, 256] fp16 (retr_split), cy [T, H, LP], cx [T, W, LP], c3 [T, LP] fp32 with the slot axis
     padded to LP = 128 (L <= 128) or 256 (L <= 256: two passes - probabilities of all slots through the workspace, then P f)."""
@@ -515,9 +484,7 @@ def retr_attn(qh, ql, cy, cx, c3, feat, aux, L, H, W, chunks=0, tight=False):
     if (HW != H * W or qh.shape != (T, LP, D) or ql.shape != (T, LP, D) or cy.shape != (T, H, LP) or cx.shape != (T, W, LP)
             or c3.shape != (T, LP) or aux.shape != (T, HW, 8)):
         raise ValueError("shape mismatch")
-    if tight and L > 128:
-        raise NotImplementedError("the precision form of the fused retriever (P * rstd_v as fp16 hi + lo) covers L <= 128")
-    fwd, name = ((lib.svps_retr_attn_tight_fwd, "svps_retr_attn_tight_fwd") if tight else (lib.svps_retr_attn_fwd, "svps_retr_attn_fwd"))
+    fwd, name = lib.svps_retr_attn_fwd, "svps_retr_attn_fwd"
     ws_bytes = lib.svps_retr_attn_workspace_bytes(T, L, H, W, chunks)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=feat.device)
     out = torch.empty((T, L, 272), dtype=torch.float32, device=feat.device)
@@ -798,7 +765,7 @@ def _need_any(t, name):
 
 
 # ---- reference precision on the matrix cores: every 16-bit operand as fp16 hi + lo (csrc/level_fuse_hl.hip and the HL forms of
-# ---- retr_stats_t.hip, retr_attn.hip, mask_decode.hip). A level map is ONE tensor [2, T, HW, 256] fp16: plane 0 = hi, plane 1 = lo.
+# ---- retr_stats_hl.hip, retr_attn.hip, mask_decode.hip). A level map is ONE tensor [2, T, HW, 256] fp16: plane 0 = hi, plane 1 = lo.
 def split_hl(x):
     """fp32 tensor -> [2, *x.shape] fp16 (hi, lo) with hi + lo = x to a 22-bit mantissa (|x| < 65 504)."""
     _need(x, "x", torch.float32)

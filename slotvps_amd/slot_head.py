@@ -16,7 +16,7 @@ There is no CPU path: modules raise if their tensors are not on a GPU.
 Storage policy (what is rounded to bf16 in HBM): the fused level map f, the projection operand f+pos,
 the projection weights, and the post-LayerNorm q / k / v. Slot-side tensors stay fp32.
 
-Exact mode (`head.set_precision("fp32")`): the reference runs this path in fp32 (vps_temporal_slots.py:55); in this
+Exact mode (`head.set_mode("fp32")`): the reference runs this path in fp32 (vps_temporal_slots.py:55); in this
 mode nothing is stored below fp32 and the pixel side runs on the fp32 kernels of csrc/exact_f32.hip (level fusion,
 projections + LayerNorm, retriever, decode), the slot-side self-attention on explicit fp32 matrix products. One to two
 orders of magnitude slower; it exists so that the head can be compared free-running with the reference's own outputs.
@@ -203,14 +203,6 @@ class MaskDynamicConv(nn.Module):
         # arithmetic, no fp16 staging - for a map that exceeds the range, with a one-time warning. Off by default: maps behind
         # the level-fusion conv of batch-normalised features are O(1) ... O(100).
         self.range_check = False
-        # precision form of the fused retriever (bf16 mode, L <= 128; head.set_statistics("tight")): both QR factors of the statistics
-        # as fp16 hi + lo (csrc/retr_stats_t.hip) and P * rstd_v as fp16 hi + lo (retr_attn_kernel<.., PHL>): the error against float64
-        # drops from the 1e-3 class to the 1e-4 class; the statistics cost ~2x, the retriever ~1.2x
-        self.tight_stats = False
-        # the cheap part of the precision form on its own (head.set_statistics("balanced")): P * rstd_v as fp16 hi + lo with the
-        # default statistics kernels (K3' / K3''): what is left is the fp16 rounding of the QR factors (rstd_v 7e-5, rstd_k 5e-5
-        # relative) - 1e-4 ... 2.5e-4 against float64 for 7 % of the step
-        self.precise_query_p = False
         # operands of the query-side products (to_q, the key fold, the position terms): "fp16" hi + lo (default), "bf16" hi + lo, "fp32" library
         self.query_side = "fp16"
 
@@ -243,7 +235,7 @@ class MaskDynamicConv(nn.Module):
                 # position tables of retr_pos_tables()
                 out["r" + name] = torch.triu(r[:, :256]).to(dev).to(torch.float16).contiguous()
                 out["rb" + name] = r[:, 256].float().to(dev).contiguous()
-                # precision mode (csrc/retr_stats_t.hip): R = hi + lo, two fp16 matrices
+                # reference precision (csrc/retr_stats_hl.hip): R = hi + lo, two fp16 matrices
                 out["r" + name + "_lo"] = (torch.triu(r[:, :256]) - out["r" + name].double().cpu()).to(dev).to(torch.float16).contiguous()
                 if name == "k":
                     out["rk64"] = torch.triu(r[:, :256])
@@ -314,7 +306,7 @@ class MaskDynamicConv(nn.Module):
         if self.norm_v.eps < 4e-6:
             # the kernels carry 2^7 * P * rstd_v as fp16 (csrc/common.h, kPScale): rstd_v <= 1 / sqrt(eps_v) must stay below 511
             raise ValueError(f"fused retriever: norm_v.eps = {self.norm_v.eps} < 4e-6 is outside the fp16 range of the probabilities; "
-                             "use set_retriever('kv') or set_precision('fp32')")
+                             "use set_mode('bf16_kv') or set_mode('fp32')")
         if stats is None:
             # statistics already computed for this map by the level pass (MultiScaleDynamicMaskHead.forward_clip)?
             pending = getattr(self, "_level_stats", None)
@@ -322,16 +314,12 @@ class MaskDynamicConv(nn.Module):
             if pending is not None and pending[0] is feat_pm:
                 stats = pending[1]
         if hl:
-            # reference precision: factors AND map as fp16 hi + lo (K3t's HL form: three MFMAs per product)
+            # reference precision: factors AND map as fp16 hi + lo (K3-HL: three MFMAs per product)
             if L > 128:
-                raise NotImplementedError("precision 'fp16x2' covers L <= 128 slots (the exact mode, set_precision('fp32'), has no limit)")
+                raise NotImplementedError("precision 'fp16x2' covers L <= 128 slots (the exact mode, set_mode('fp32'), has no limit)")
             tyk, txk, rbv_p, tiled = self.stats_hl_tables(pos_tabs)
             stats = ops.retr_stats_hl(feat_pm, H, W, tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p, self.norm_v.eps,
                                       tx_tiled=tiled)
-        elif self.tight_stats:
-            # precision form: both statistics from factors carried as fp16 hi + lo (K3t)
-            pp, rk, rbk, ek, rv, rbv, ev = self.stats_args(pos_tabs)
-            stats = ops.retr_stats_tight(feat_pm, H, W, pp, rk, c["rk_lo"], rbk, ek, rv, c["rv_lo"], rbv, ev)
         elif stats is None:
             stats = ops.retr_stats(feat_pm, H, W, *self.stats_args(pos_tabs))
         LP = ops.retr_slot_pad(L)
@@ -340,7 +328,6 @@ class MaskDynamicConv(nn.Module):
         # (16 bits, ~1e-5 relative on Q'') cost ~5e-4 on the slot update. query_side = "fp16" (default): the same K8 / K9 launches
         # with fp16 hi + lo operands (22 bits; LayerNorm outputs, O(0.1) weights and sine tables are well inside fp16's range);
         # "bf16": round 2's operands; "fp32": the GEMM library.
-        tight = self.tight_stats or self.precise_query_p
         qs = self.query_side if self.use_slot_gemm else "fp32"
         if qs == "fp32":
             xq = F.linear(slots, self.to_q.weight, self.to_q.bias)
@@ -368,7 +355,7 @@ class MaskDynamicConv(nn.Module):
             # the pixel sums A_l reach |f| * (pixels a slot owns): beyond fp16's range at the fine levels, so this one product (272 -> 256 on
             # [T L] rows) runs in the library's fp32; norm1 + ReLU on K5
             return ops.row_ln(F.linear(ext, c["wext_lin"]), self.norm1.weight, self.norm1.bias, self.norm1.eps, relu=True)
-        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W, tight=tight)
+        ext = ops.retr_attn(qh, ql, cy, cx, c3, feat_pm, stats, L, H, W)
         # :456 (value projection after the sum) + :458-459 (norm1, ReLU) in one launch
         return fast_linear_ln(self, "wext", ext, c["wext_lin"], None, self.norm1, relu=True)
 
@@ -709,12 +696,11 @@ class MultiScaleDynamicMaskHead(nn.Module):
             raise NotImplementedError("the released configs use merge_operation='concat'")
         self.per_dh_num_heads = list(per_dh_num_heads)
         self.dh_dim = dh_dim
-        # storage of the fused level maps: "bf16" or "fp16" (set_map_dtype); a config selects it with other_config=dict(map_dtype="fp16")
+        # a config selects the mode (MODES below) with other_config=dict(mode="fp16x2"); applied once the stages exist
         self.map_dtype = "bf16"
         self.map_encoding = "auto"                       # "bf16": plain bf16 tensors for the bf16 policy (see _map_form)
-        if isinstance(other_config, dict) and other_config.get("map_dtype") is not None:
-            self.set_map_dtype(other_config["map_dtype"])
-        self._cfg_precision = other_config.get("precision") if isinstance(other_config, dict) else None   # applied once the stages exist
+        self.stats_form = "level"                        # "level": K3'' - both stages of a pyramid level from one read of the map; "stage": K3' per stage
+        self._cfg_mode = other_config.get("mode") if isinstance(other_config, dict) else None
         self.trans_in_dim = trans_in_dim
         self.apply_temporal_query_atten_stages = apply_temporal_query_atten_stages
         self.other_config = other_config
@@ -742,72 +728,52 @@ class MultiScaleDynamicMaskHead(nn.Module):
             self.prior_prob = prior_prob
             self.bias_value = -math.log((1 - prior_prob) / prior_prob)
         self.precision = "bf16"
+        self.mode = "bf16"
         self._reset_parameters()
-        if self._cfg_precision is not None:              # a config selects the mode with other_config=dict(precision="fp16x2")
-            self.set_precision(self._cfg_precision)
+        if self._cfg_mode is not None:
+            self.set_mode(self._cfg_mode)
 
-    # name -> (precision, map storage, statistics form, retriever form)
+    # THE mode surface of the head: name -> (precision, storage of the level maps, retriever form). What each costs and how far it sits
+    # from the reference's own fp32 outputs at BASELINE's sizes: tests/test_full_size_gpu.py, bench.py (config.mode_*), README.
+    #   "fp16x2"  the reference's precision ON THE MATRIX CORES: every 16-bit matrix operand as fp16 hi + lo (22 bits, three MFMAs per
+    #             product), level maps as two fp16 planes (csrc/level_fuse_hl.hip), statistics / retriever / decode in their HL forms, slot
+    #             side on K8 / K9 with fp16 hi + lo operands. Meets the north star's tolerance (1e-4 on the mask logits, identical slot argmax
+    #             wherever decidable) free-running at full size - the mode bench.py's `value` is quoted on. |f| < 65 504, L <= 256.
+    #   "fp32"    exact mode: fp32 storage and fp32 vector-ALU arithmetic everywhere (csrc/exact_f32.hip), the reference's own dtype
+    #             (vps_temporal_slots.py:55); meets the tolerance as well, ~14x slower than fp16x2.
+    #   "bf16"    BASELINE.json's storage policy: bf16 level maps (stored in the fp16 encoding where every consumer takes it), statistics-
+    #             fused retriever K3'' + K1' with single fp16 operands. 2.5x the speed of fp16x2; the storage rounding of the maps alone moves
+    #             the mask logits by ~1e-3, i.e. it does NOT meet the tolerance.
+    #   "fp16"    the same kernels with fp16 level maps (same bytes, three more mantissa bits): ~1.5e-4 from the map rounding alone.
+    #   "bf16_kv" round 1's form through bf16 k / v tensors (csrc/kv_project.hip + csrc/slot_attn.hip): the fallback for maps outside
+    #             fp16's range (MaskDynamicConv.range_check) and the only form without fp16 staging.
     MODES = {
-        "bf16": ("bf16", "bf16", "fast", "fused"),
-        "fp16": ("bf16", "fp16", "fast", "fused"),
-        "fp16x2": ("fp16x2", "bf16", "fast", "fused"),
-        "fp32": ("fp32", "bf16", "fast", "fused"),
-        "bf16_kv": ("bf16", "bf16", "fast", "kv"),
-        "bf16_balanced": ("bf16", "bf16", "balanced", "fused"),
-        "bf16_tight": ("bf16", "bf16", "tight", "fused"),
-        "fp16_balanced": ("bf16", "fp16", "balanced", "fused"),
-        "fp16_tight": ("bf16", "fp16", "tight", "fused"),
+        "fp16x2": ("fp16x2", "bf16", "fused"),
+        "fp32": ("fp32", "bf16", "fused"),
+        "bf16": ("bf16", "bf16", "fused"),
+        "fp16": ("bf16", "fp16", "fused"),
+        "bf16_kv": ("bf16", "bf16", "kv"),
     }
 
     def set_mode(self, name):
         if name not in self.MODES:
             raise ValueError(f"mode must be one of {sorted(self.MODES)}, not {name!r}")
-        prec, maps, stats, retr = self.MODES[name]
-        self.set_precision(prec).set_map_dtype(maps).set_statistics(stats).set_retriever(retr)
+        prec, maps, retr = self.MODES[name]
+        for m in self.modules():
+            if hasattr(m, "precision"):
+                m.precision = prec
+                m.map_dtype = maps                       # the stages' reference-signature entry points store their maps the same way
+            if hasattr(m, "retriever"):
+                m.retriever = retr
+        self.map_dtype = maps
         self.mode = name
         return self
 
-    def set_precision(self, mode):
-        """"bf16" (default): bf16 storage of the pixel-side tensors, matrix-core kernels. "fp32": exact mode - fp32 storage and
-        arithmetic everywhere (csrc/exact_f32.hip), the reference's own dtype (vps_temporal_slots.py:55), on the vector ALU.
-        "fp16x2": the reference's precision ON THE MATRIX CORES - every 16-bit matrix operand as fp16 hi + lo (22 bits, three MFMAs per
-        product): level maps as two fp16 planes (csrc/level_fuse_hl.hip), statistics / retriever / decode in their HL forms, the slot
-        side on K8 / K9 with fp16 hi + lo operands. Meets the exact mode's bounds against the reference's fp32 outputs at ~10x its speed
-        (tests/test_refprec_gpu.py); L <= 128, |f| < 65 504."""
-        if mode not in ("bf16", "fp32", "fp16x2"):
-            raise ValueError(f"precision must be 'bf16', 'fp32' or 'fp16x2', not {mode!r}")
-        for m in self.modules():
-            if hasattr(m, "precision"):
-                m.precision = mode
-        return self
-
     def set_slot_gemm(self, on):
-        """bf16 mode: K8 (split-bf16 matrix-core GEMM, default) or the GEMM library in fp32 for the dense slot-side layers."""
+        """Debug switch: K8 (split matrix-core GEMM, default) or the GEMM library in fp32 for the dense slot-side layers."""
         for m in self.modules():
             if hasattr(m, "use_slot_gemm"):
                 m.use_slot_gemm = bool(on)
-        return self
-
-    def set_statistics(self, mode):
-        """bf16 mode, fused retriever. "fast" (default): K3' / K3'' statistics from fp16 QR factors, P * rstd_v as one fp16 (1e-3 class
-        against float64). "balanced": the same statistics, P * rstd_v as fp16 hi + lo (1e-4 ... 2.5e-4). "tight": K3t statistics from
-        fp16 hi + lo factors on top of that (3e-5 ... 8e-5: a float32 evaluation of the reference's formulas measures 4e-5). The query
-        side runs on K8 / K9 with fp16 hi + lo operands in every form (MaskDynamicConv.query_side)."""
-        if mode not in ("fast", "balanced", "tight"):
-            raise ValueError(f"statistics must be 'fast', 'balanced' or 'tight', not {mode!r}")
-        for m in self.modules():
-            if hasattr(m, "tight_stats"):
-                m.tight_stats = mode == "tight"
-                m.precise_query_p = mode == "balanced"
-        return self
-
-    def set_retriever(self, form):
-        """bf16 mode only: "fused" (K3' + K1', default) or "kv" (K3 + K1 through bf16 k / v tensors)."""
-        if form not in ("fused", "kv"):
-            raise ValueError(f"retriever must be 'fused' or 'kv', not {form!r}")
-        for m in self.modules():
-            if hasattr(m, "retriever"):
-                m.retriever = form
         return self
 
     def _reset_parameters(self):
@@ -866,20 +832,6 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 cache.clear()
             cache[key] = ent
         return ent
-
-    def set_map_dtype(self, dtype):
-        """bf16 mode: storage of the fused level maps (and operand type of the level-fusion conv). "bf16" (default, BASELINE's
-        storage) or "fp16": the same 16 bits with three more of mantissa - K4 runs its conv and its bilinear blend on fp16 operands,
-        the statistics / retriever kernels skip their bf16 -> fp16 pass, K2 runs fp16 MFMAs. The maps then sit 8x closer to the
-        reference's fp32 maps (what limits the distance of the whole head from the reference's own outputs); |f| must stay below
-        65 504 (as for the fused retriever). Fused retriever only (the kv form takes bf16 maps)."""
-        if dtype not in ("bf16", "fp16"):
-            raise ValueError(f"map_dtype must be 'bf16' or 'fp16', not {dtype!r}")
-        for m in self.modules():                         # the stages' reference-signature entry points store their maps the same way
-            if hasattr(m, "precision"):
-                m.map_dtype = dtype
-        self.map_dtype = dtype
-        return self
 
     def fuse_level(self, cur, prev_pm, hw, last=False, pre=None):
         """K4 (:171-188). cur [T, 128, H, W] fp32 (the reference's layout) or [T, H*W, 128] 16-bit pixel-major (bf16; fp16 with
@@ -954,8 +906,8 @@ class MultiScaleDynamicMaskHead(nn.Module):
             f_pm = self.fuse_level(feats[i], prev, (h, w), last=i == self.feat_num_levels - 1, pre=pre_linear)
             series = getattr(self, f"head_series_{i}")
             mdcs = [stage.inst_interact for stage in series]
-            if (ops.RETR_STATS_FORM == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16) and f_pm.dim() == 3
-                    and all(m.precision == "bf16" and m.retriever == "fused" and not m.tight_stats for m in mdcs)):
+            if (self.stats_form == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16) and f_pm.dim() == 3
+                    and all(m.precision == "bf16" and m.retriever == "fused" for m in mdcs)):
                 # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats2.hip;
                 # measured 195 against 2 x 116 us at the finest level); each stage's retriever picks its rows up in forward_fused.
                 # A level with a single stage keeps K3'

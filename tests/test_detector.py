@@ -264,13 +264,13 @@ def test_head_graph_follows_weight_and_mode_changes():
         second = a[1].clone()
         a, b = both()
         assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[1], second)
-        saved = ops.RETR_STATS_FORM
+        saved = im.dynamic_mask_head.stats_form
         try:
-            ops.RETR_STATS_FORM = "stage"                                       # an ops-level mode switch re-captures as well
+            im.dynamic_mask_head.stats_form = "stage"                           # a switch of the statistics form re-captures as well
             a, b = both()
             assert all(torch.equal(x, y) for x, y in zip(a, b))
         finally:
-            ops.RETR_STATS_FORM = saved
+            im.dynamic_mask_head.stats_form = saved
 
 
 @pytest.mark.gpu
@@ -381,7 +381,7 @@ def test_viper_config_clip_runs_through_the_whole_detector():
 
 @pytest.mark.gpu
 def test_fp16_level_maps_through_the_whole_detector():
-    """`other_config=dict(map_dtype="fp16")` on the head (or head.set_map_dtype): trunk + fp16 level maps + selected-slot decode +
+    """`other_config=dict(mode="fp16")` on the head (or head.set_mode): trunk + fp16 level maps + selected-slot decode +
     post-process + tracker run as with bf16 maps. The two storages agree on most pixels of the panoptic output (measured 75 %: a
     random-initialised head is chaotic - its free-running slot argmax agrees with the reference's on 87 - 91 % of the pixels with bf16
     maps and on 97 - 98 % with fp16 maps, tests/test_head_gpu.py - and one segment more or less renumbers the instance ids)."""
@@ -393,7 +393,7 @@ def test_fp16_level_maps_through_the_whole_detector():
     for md in ("bf16", "fp16"):
         torch.manual_seed(1)
         det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
-        det.image_model.dynamic_mask_head.set_map_dtype(md)
+        det.image_model.dynamic_mask_head.set_mode(md)
         T, H, W = 2, 256, 512
         imgs = torch.randn(T, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
         ncls = det.image_model.dynamic_mask_head.num_classes
@@ -421,7 +421,7 @@ def test_conv_trans_folded_into_level_fusion(map_dtype):
     dev = torch.device("cuda:0")
     det = _make_detector(dev)
     head = det.image_model.dynamic_mask_head
-    head.set_map_dtype(map_dtype)
+    head.set_mode(map_dtype)
     with torch.no_grad():
         ct = det.image_model.conv_trans.conv
         ct.weight.normal_(0, 0.12)

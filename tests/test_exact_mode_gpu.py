@@ -101,7 +101,7 @@ def test_exact_head_free_running_vs_reference_fp32(cuda, tag):
     feats = synth.make_clip_features(seed + 1, T, H, W)
     slots = synth.make_slots(seed + 2, L)
     sizes = synth.level_sizes(H, W)
-    head = build_head(cuda, params).set_precision("fp32")
+    head = build_head(cuda, params).set_mode("fp32")
     with torch.no_grad():
         tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
         pos_tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in sizes]

@@ -42,7 +42,7 @@ def build_head(cuda, params):
     return head.to(cuda).eval()
 
 
-@pytest.mark.parametrize("form", ["fused", "kv", "balanced"])
+@pytest.mark.parametrize("form", ["fused", "kv"])
 @pytest.mark.parametrize("tag", ["T2_64x128", "T3_64x64"])
 def test_head_matches_oracle_and_reference(cuda, tag, form):
     import torch
@@ -54,16 +54,9 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     feats = synth.make_clip_features(seed + 1, T, H, W)
     slots = synth.make_slots(seed + 2, L)
     sizes = synth.level_sizes(H, W)
-    balanced = form == "balanced"                   # the fused retriever with hi + lo probabilities
-    if balanced:
-        form = "fused"
-    head = build_head(cuda, params).set_retriever(form)
-    if balanced:
-        head.set_statistics("balanced")
+    head = build_head(cuda, params).set_mode("bf16" if form == "fused" else "bf16_kv")
     if os.environ.get("SVPS_TEST_SLOT_GEMM") == "0":          # experiment switches: the slot side's dense layers in library fp32,
         head.set_slot_gemm(False)
-    if os.environ.get("SVPS_TEST_STATS"):                     # another statistics mode
-        head.set_statistics(os.environ["SVPS_TEST_STATS"])
     if os.environ.get("SVPS_TEST_BGEMM") == "torch":          # K9 replaced by float64 matmuls (which layer limits a stage's parity?)
         def _bg(a_, b_, bias=None, alpha=1.0, out=None):
             a3 = a_ if a_.dim() == 3 else a_.unsqueeze(0)
@@ -123,9 +116,8 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     # elements seen through one sharp softmax (measured <= 9e-3). fused form: nothing is rounded as a tensor; what is left
     # are the 16-bit splits of Q'' and P and the fp16 statistics (measured <= 2e-3).
     # Since the probabilities travel as 2^7 * P * rstd_v (csrc/common.h: slots that own almost no pixel no longer fall into fp16's
-    # subnormal range) the whole stage measures 2.2e-4 ... 9.6e-4 in the default form (1.2e-3 before, growing with the level) and
-    # 4e-5 ... 2.7e-4 in the balanced form (probability split and query-side products out of the budget; 1.2e-3 before).
-    bound = (5e-4 if balanced else 2e-3) if form == "fused" else 2e-2
+    # subnormal range) the whole stage measures 2.2e-4 ... 9.6e-4 in the default form (1.2e-3 before, growing with the level).
+    bound = 2e-3 if form == "fused" else 2e-2
     assert max(stage_err) <= bound and max(logit_err) <= bound, (stage_err, logit_err)
     assert free[0] <= 5e-3 and free_mean <= 5e-2
 
@@ -202,7 +194,7 @@ def test_reference_signature_roundtrip(cuda, map_dtype):
     import torch
     from slotvps_amd.position_encoding import PositionEmbeddingSine, nested_tensor_from_tensor_list
     params = synth.make_params(synth.head_shapes(), 7)
-    head = build_head(cuda, params).set_map_dtype(map_dtype)
+    head = build_head(cuda, params).set_mode(map_dtype)
     T, H, W, L = 2, 64, 64, 100
     feats = synth.make_clip_features(8, T, H, W)
     pe = PositionEmbeddingSine(128, normalize=True)
@@ -383,7 +375,7 @@ def test_free_running_bf16_head_to_panoptic_ids(cuda, tag, map_dtype):
     slots = synth.make_slots(seed + 2, L)
     sizes = synth.level_sizes(H, W)
     h, w = sizes[-1]
-    head = build_head(cuda, params).set_map_dtype(map_dtype)       # 16-bit storage of the level maps: bf16 (default) or fp16
+    head = build_head(cuda, params).set_mode(map_dtype)       # 16-bit storage of the level maps: bf16 (default) or fp16
     wb, bb, mu, var = z[f"{tag}_bn"]
     fg = z[f"{tag}_fg"]
     feat_bn = torch.nn.BatchNorm2d(256).to(cuda).eval()
@@ -429,7 +421,7 @@ def test_free_running_bf16_head_to_panoptic_ids(cuda, tag, map_dtype):
 
 @pytest.mark.parametrize("tag", ["T2_64x128", "T3_64x64"])
 def test_fp16_level_maps_against_the_reference(cuda, tag):
-    """head.set_map_dtype("fp16"): the fused level maps (and the operands of the level-fusion conv) as fp16 instead of bf16 - the same
+    """head.set_mode("fp16"): the fused level maps (and the operands of the level-fusion conv) as fp16 instead of bf16 - the same
     bytes, three more mantissa bits. What limits the distance of the bf16 path from the REFERENCE's own fp32 outputs is the rounding
     of those maps (one bf16 ulp at magnitude 8 is 3e-2); measured here for both storages on the reference fixture: the finest fused
     map, every stage teacher-forced on the reference's embeddings, the mask logits decoded from the reference's embeddings, and the
@@ -454,10 +446,8 @@ def test_fp16_level_maps_against_the_reference(cuda, tag):
         fg_bn.weight.fill_(float(fg[0])); fg_bn.bias.fill_(float(fg[1]))
         fg_bn.running_mean.fill_(float(fg[2])); fg_bn.running_var.fill_(float(fg[3]))
     res = {}
-    for md in ("bf16", "fp16", "fp16+balanced"):
-        head = build_head(cuda, params).set_retriever("fused").set_map_dtype(md.split("+")[0])
-        if md.endswith("balanced"):
-            head.set_statistics("balanced")
+    for md in ("bf16", "fp16"):
+        head = build_head(cuda, params).set_mode(md)
         with torch.no_grad():
             tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
             pos_tabs = [ops.pos_embed_sine_tables(h, w_, 256, cuda) for (h, w_) in sizes]
@@ -486,38 +476,35 @@ def test_fp16_level_maps_against_the_reference(cuda, tag):
               + f"; mask logits {res[md]['mask']:.2e}, slot argmax equal {100 * res[md]['same']:.2f} % (free-running head {100 * res[md]['free']:.2f} %)")
     b16, f16 = res["bf16"], res["fp16"]
     assert f16["map"] <= 0.25 * b16["map"] and f16["tf"] <= 0.4 * b16["tf"] and f16["mask"] <= 0.3 * b16["mask"], (b16, f16)
-    # ABSOLUTE bounds (measured on MI355X: T2_64x128 1.03e-4 / 100 % / 96.9 %, T3_64x64 7.7e-5 / 100 % / 98.4 %, the same
-    # with the balanced retriever): with fp16 level maps the mask logits decoded from the reference's embeddings sit AT the north star's
+    # ABSOLUTE bounds (measured on MI355X: T2_64x128 1.03e-4 / 100 % / 96.9 %, T3_64x64 7.7e-5 / 100 % / 98.4 %): with fp16 level maps the mask logits decoded from the reference's embeddings sit AT the north star's
     # 1e-4 (one fp16 rounding of the map, 3.4e-3 at |f| < 8, through the normalised dot product) and their slot argmax is the reference's on
     # every pixel; the free-running head stays at 97 - 98 %: 16-bit maps cannot do better, the form that meets 1e-4 / 100 % free-running is
     # precision "fp16x2" (tests/test_refprec_gpu.py)
-    for md in ("fp16", "fp16+balanced"):
+    for md in ("fp16",):
         assert res[md]["mask"] <= 1.2e-4 and res[md]["same"] == 1.0 and res[md]["free"] >= 0.96, (md, res[md])
     assert res["fp16"]["map"] <= 4e-3 and res["fp16"]["tf"] <= 1.2e-2
 
 
 def test_map_dtype_switch_is_checked(cuda):
-    """set_map_dtype accepts "bf16" / "fp16" only; fp16 level maps go with the fused retriever (the kv form's K3 takes bf16 operands)."""
+    """set_mode accepts the names of MultiScaleDynamicMaskHead.MODES only; the bf16 policy's two encodings of the level maps agree."""
     import torch
     from slotvps_amd import ops
     params = synth.make_params(synth.head_shapes(), 7)
     head = build_head(cuda, params)
     with pytest.raises(ValueError):
-        head.set_map_dtype("fp8")
-    head.set_map_dtype("fp16").set_retriever("kv")
+        head.set_mode("fp8")
+    head.set_mode("fp16")
+    assert head.mode == "fp16" and all(m.map_dtype == "fp16" for m in head.modules() if hasattr(m, "precision"))
     T, H, W, L = 1, 64, 64, 100
     feats = synth.make_clip_features(8, T, H, W)
     tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
     tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in synth.level_sizes(H, W)]
-    with pytest.raises(NotImplementedError), torch.no_grad():
-        head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
-    head.set_retriever("fused")
     with torch.no_grad():
         logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
     assert all(f.dtype == torch.float16 for f in fused) and torch.isfinite(embeds).all()
     # the bf16 policy: bf16 VALUES; in the fp16 encoding by default (no conversion pass in the consumers), as bf16 tensors on request -
     # the same values and the same result
-    head.set_map_dtype("bf16")
+    head.set_mode("bf16")
     with torch.no_grad():
         lg_c, em_c, fused_c = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), tabs)
         head.map_encoding = "bf16"
@@ -544,7 +531,7 @@ def test_clip_runner_from_the_tower_rows(cuda, map_dtype):
     ra = SlotClipRunner(cuda, input_form="tower16", **kw)
     rb = SlotClipRunner(cuda, input_form="nchw_f32", **kw)
     for r in (ra, rb):
-        r.head.set_map_dtype(map_dtype)
+        r.head.set_mode(map_dtype)
     rows = ra.random_clip(5)
     ra.load_clip(rows)
     wt, bt = ra.pre_linear

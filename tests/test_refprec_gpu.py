@@ -1,4 +1,4 @@
-"""Reference precision ON THE MATRIX CORES (head.set_precision("fp16x2"), round 4) against the REFERENCE'S OWN fp32 outputs.
+"""Reference precision ON THE MATRIX CORES (head.set_mode("fp16x2"), round 4) against the REFERENCE'S OWN fp32 outputs.
 
 The reference runs the slot head in fp32 (vps_temporal_slots.py:55). The exact mode (csrc/exact_f32.hip, fp32 on the vector ALU) meets
 the north star's bounds - mask logits within 1e-4, per-pixel slot argmax identical wherever decidable - at 142 frames/s. This mode
@@ -165,7 +165,7 @@ def test_fp16x2_head_free_running_vs_reference_fp32(cuda, tag):
     from slotvps_amd import ops
     from slotvps_amd.slot_head import generate_final_outputs
     z, (T, H, W, L), params, feats, slots, sizes, feat_bn, fg_bn = _fixture(tag, cuda)
-    head = build_head(cuda, params).set_precision("fp16x2")
+    head = build_head(cuda, params).set_mode("fp16x2")
     with torch.no_grad():
         tf = [torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda) for i in range(4)]
         pos_tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in sizes]
@@ -214,7 +214,7 @@ def test_fp16x2_free_running_head_to_panoptic_ids(cuda, tag):
     from slotvps_amd.postprocess import PostProcessPanopticInstances
     z, (T, H, W, L), params, feats, slots, sizes, feat_bn, fg_bn = _fixture(tag, cuda)
     h, w = sizes[-1]
-    head = build_head(cuda, params).set_precision("fp16x2")
+    head = build_head(cuda, params).set_mode("fp16x2")
     gain = 400.0
     bias = np.zeros((L, 20), dtype=np.float32)
     bias[np.arange(L), np.arange(L) % 19] = 12.0
@@ -247,7 +247,7 @@ def test_fp16x2_through_the_clip_runner(cuda):
     import torch
     from slotvps_amd.clip import SlotClipRunner
     r = SlotClipRunner(cuda, T=2, H=64, W=128, L=100, param_seed=3, use_graph=True, clips_per_launch=2)
-    r.head.set_precision("fp16x2")
+    r.head.set_mode("fp16x2")
     r.load_clip(r.random_clip(5))
     out = r.run()                                   # captures + validates the graph against the eager step (raises on a mismatch)
     torch.cuda.synchronize()
@@ -259,7 +259,7 @@ def test_fp16x2_through_the_clip_runner(cuda):
 
 def test_fp16x2_through_the_whole_detector(cuda):
     """The detector of configs/r50_fpn_slotvps_mi355x.py with the head in the matrix-core reference-precision mode (selectable from a
-    config: dynamic_mask_head other_config=dict(precision="fp16x2")) against the same detector in the exact mode (fp32 on the vector ALU):
+    config: dynamic_mask_head other_config=dict(mode="fp16x2")) against the same detector in the exact mode (fp32 on the vector ALU):
     trunk, slot head, decode of the kept slots from the hi / lo planes, clip-level post-process, tracker. Both modes sit within fp32
     rounding of the reference's arithmetic, so with the same weights and images the panoptic ids agree on (almost) every pixel."""
     import torch
@@ -271,7 +271,7 @@ def test_fp16x2_through_the_whole_detector(cuda):
     for mode in ("fp32", "fp16x2"):
         torch.manual_seed(1)
         det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(cuda).eval()
-        det.image_model.dynamic_mask_head.set_precision(mode)
+        det.image_model.dynamic_mask_head.set_mode(mode)
         T, H, W = 2, 256, 512
         imgs = torch.randn(T, 3, H, W, device=cuda, generator=torch.Generator(device=cuda).manual_seed(2))
         ncls = det.image_model.dynamic_mask_head.num_classes
@@ -300,10 +300,10 @@ def test_head_config_selects_the_precision():
         merge_operation="concat", trans_in_dim=cfg["trans_in_dim"], num_cls=cfg["num_cls"], num_reg=cfg["num_reg"],
         temporal_query_attention_config=dict(d_model=256, dim_feedforward=cfg["temporal_dim_feedforward"], dropout=0.0,
                                              activation=cfg["temporal_activation"], softmax_dim="slots", drop_path=0.),
-        apply_temporal_query_atten_stages=list(cfg["apply_temporal_query_atten_stages"]), other_config=dict(precision="fp16x2"))
+        apply_temporal_query_atten_stages=list(cfg["apply_temporal_query_atten_stages"]), other_config=dict(mode="fp16x2"))
     assert head.precision == "fp16x2" and all(m.precision == "fp16x2" for m in head.modules() if hasattr(m, "precision"))
     with pytest.raises(ValueError):
-        head.set_precision("fp8")
+        head.set_mode("fp8")
 
 
 def test_fp16x2_kernels_at_the_full_size_against_the_exact_mode(cuda):
@@ -377,7 +377,7 @@ def test_fp16x2_full_size_clip_against_the_exact_mode(cuda):
     outs = {}
     for prec in ("fp32", "fp16x2"):
         r = SlotClipRunner(cuda, T=2, H=1024, W=2048, L=100, param_seed=0, use_graph=False)
-        r.head.set_precision(prec)
+        r.head.set_mode(prec)
         r.load_clip(r.random_clip(7))
         o = r.run()
         torch.cuda.synchronize()

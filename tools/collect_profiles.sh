@@ -8,7 +8,7 @@ PARTS=${PARTS:-"1 2 3 4 7 8 9 5 6"}
 O=$R/gpurun_out/$V
 mkdir -p $O
 cd $R
-LEGS="--cpu-baseline 0 --whole-detector 0 --latency-leg 0 --exact-leg 0 --viper-leg 0"
+LEGS="--cpu-baseline 0 --whole-detector 0 --latency-leg 0 --exact-leg 0 --viper-leg 0 --parity-leg 0"
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 has 1 && { echo "[1] bench"; timeout -k 10 700 python3 bench.py > $O/bench_$V.json 2> $O/bench_$V.err || echo "bench rc $?"; }
 cd /tmp && export TMPDIR=/tmp

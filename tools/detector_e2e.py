@@ -17,14 +17,14 @@ ap.add_argument("--frames", type=int, default=0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--profile-tower", type=int, default=0)
-ap.add_argument("--map-dtype", default="bf16", help="storage of the fused level maps: bf16 or fp16 (head.set_map_dtype)")
+ap.add_argument("--map-dtype", default="bf16", help="head mode (MultiScaleDynamicMaskHead.MODES): bf16, fp16, fp16x2, fp32")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = Config.fromfile(a.config)
 torch.manual_seed(0)
 det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
 det.use_graph = bool(a.graph)
-det.image_model.dynamic_mask_head.set_map_dtype(a.map_dtype)
+det.image_model.dynamic_mask_head.set_mode(a.map_dtype)
 T = a.frames or cfg.clip["frames"]
 H, W = cfg.clip["height"], cfg.clip["width"]
 L = det.image_model.init_mask_query.weight.shape[0]

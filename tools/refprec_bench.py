@@ -24,5 +24,5 @@ sys.argv = [sys.argv[0]]
 a = bench.parse()
 a.height, a.width, a.frames, a.slots = x.height, x.width, x.frames, x.slots
 dev = torch.device("cuda:0")
-res = bench.side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, x.clips_per_launch, x.steps, precision=x.precision)
+res = bench.side_leg(a, dev, a.frames, a.height, a.width, a.slots, a.num_classes, x.clips_per_launch, x.steps, mode=x.precision, with_roofline=True)
 print(json.dumps(res), flush=True)

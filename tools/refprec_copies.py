@@ -9,7 +9,7 @@ from slotvps_amd.clip import SlotClipRunner
 
 dev = torch.device("cuda:0")
 r = SlotClipRunner(dev, 5, 1024, 2048, L=100, use_graph=False, clips_per_launch=int(os.environ.get("CPL", "4")))
-r.head.set_precision(os.environ.get("PRECISION", "fp16x2"))
+r.head.set_mode(os.environ.get("PRECISION", "fp16x2"))
 r.load_clip(r.random_clip(1))
 for _ in range(2):
     r.run()

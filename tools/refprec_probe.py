@@ -31,7 +31,7 @@ for tag in ("T2_64x128", "T3_64x64"):
     sizes = synth.level_sizes(H, W)
     for mode in a.modes:
         prec, _, var = mode.partition(":")
-        head = build_head(dev, params).set_precision(prec)
+        head = build_head(dev, params).set_mode(prec)
         if var == "libgemm":
             head.set_slot_gemm(False)
         saved_bgemm = ops.bgemm
