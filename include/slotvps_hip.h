@@ -484,7 +484,9 @@ int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const fl
  *                              [tx_rows, 256] = Tx (ty_rows = H or 1, tx_rows = W or 1: no position term), rbv [256] = r_v; tx_tiled
  *                              (W % 32 == 0): txk re-ordered to [W / 32][8 B][4 g][2 h][32 pixels][4 j], so that a wave's load for the
  *                              32 pixels of a tile is one contiguous KiB
- *   svps_retr_attn_hl_fwd    = svps_retr_attn_fwd (:435-456) with hi + lo probabilities on the planes; tiles of 16 pixels (hi rows + lo rows of
+ *   svps_retr_attn_hl_fwd    = svps_retr_attn_fwd (:435-456) with hi + lo probabilities on the planes, 1 <= L <= 256 (more than 128 slots: the
+ *                              per-pixel softmax statistics over all slots first, 8 B per pixel in the workspace, then the retriever once per
+ *                              half of the slots); tiles of 16 pixels (hi rows + lo rows of
  *                              the same pixels share one LDS tile); workspace svps_retr_attn_hl_workspace_bytes()
  *   svps_mask_decode_hl_fwd  = svps_mask_decode_fwd (vps_temporal_slots.py:144-160) on the planes: fp32 logits [T, L, HW] (required),
  *                              optional fused slot argmax [T, HW]; any HW, L <= 256

@@ -253,10 +253,9 @@ class SlotClipRunner:
         }
         if self.retriever_form == "fused":
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
-            # K3' reads the map (512 B / pixel) and writes one 16-byte aux row (both statistics) per stage; K3'' (ops.RETR_STATS_FORM
+            # K3' reads the map (512 B / pixel) and writes one 16-byte aux row (both statistics) per stage; K3'' (head.stats_form
             # "level", the default) reads the map once per LEVEL and writes the rows of all its stages
-            from . import ops as _ops
-            if _ops.RETR_STATS_FORM == "level":
+            if self.head.stats_form == "level":
                 sbytes = T * sum(hw * (512 + 16 * n) if n == 2 else n * hw * (512 + 16) for hw, n in self.k1_launch_shapes())
             else:
                 sbytes = T * ps * (512 + 16)

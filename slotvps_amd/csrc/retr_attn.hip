@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off,
     const float2* __restrict__ ext_stats, int map_f16,          // map_f16: the map is fp16 already (no conversion in LDS)
     const __bf16* __restrict__ feat_lo) {                       // HL: the lo plane [T, HW, 256] fp16 (feat is the hi plane)
-    static_assert(!HL || (PHL && !EXT), "the hi + lo map form goes with hi + lo probabilities, L <= 128");
+    static_assert(!HL || PHL, "the hi + lo map form goes with hi + lo probabilities");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = RetrLdsT<PHL ? 2 : 1>;
     constexpr int A = kRPrefetch;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         f32x2 ext_n = {0.f, 0.f};                                   // EXT: statistics of this lane's pixel, requested one tile ahead
         auto request_ext = [&](int strip, int row) {
             if constexpr (EXT) {
-                int px = row * W + kTilePx * strip + r;
+                int px = row * W + TPX * strip + rp;
                 px = px < HW ? px : HW - 1;
                 ext_n = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(exr, px * 8, 0, 0));
             }
@@ -658,21 +658,29 @@ struct LStatsLds {
     static constexpr int total = stats + 2 * 8 * 32 * 8;
 };
 
+// HL (round 5, reference precision for more than 128 slots): the map as fp16 hi + lo planes in the 16-pixel tile of retr_attn_kernel<.., HL>
+// (tile rows 0 .. 15 = hi rows, staged by waves 0 .. 3 from `feat`; rows 16 .. 31 = lo rows of the same pixels, waves 4 .. 7 from `feat_lo`):
+// the chain yields [Q''.f_hi | Q''.f_lo] in the two column halves, folded with one v_permlane16_swap + add per register (Cy + Cx start in
+// the hi half only); wave w combines pixels 2w, 2w + 1.
+template <bool HL>
 __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
     const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,  // [T, 256, 256]
     const float* __restrict__ cy, const float* __restrict__ cx,        // [T, H, 256], [T, W, 256]
     const float* __restrict__ c3g,                                     // [T, 256]
     const __bf16* __restrict__ feat, const __bf16* __restrict__ aux,   // aux: the 16-byte rows of retr_stats.hip (rstd_k = bytes 8 .. 11)
     float2* __restrict__ out,                                          // [T, HW]
-    int L, int HW, int H, int W, int tiles_per_chunk, int map_f16) {
+    int L, int HW, int H, int W, int tiles_per_chunk, int map_f16,
+    const __bf16* __restrict__ feat_lo) {                              // HL: the lo plane (feat is the hi plane)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     using Lds = LStatsLds;
     constexpr int NF = Lds::kNF, A = Lds::kA, LP = 256;
+    constexpr int TPX = HL ? 16 : kTilePx;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
+    const int rp = HL ? (r & 15) : r;                                  // this lane's pixel inside the tile
     const int t = blockIdx.y, c = blockIdx.x;
-    const int tiles = ((W + kTilePx - 1) / kTilePx) * H;
+    const int tiles = ((W + TPX - 1) / TPX) * H;
     const int tid0 = c * tiles_per_chunk;
     int nt = tiles - tid0;
     nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;
@@ -703,7 +711,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
 
     const u32x4 cys = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
     const u32x4 cxs = ra_make_srd(cx + (size_t)t * W * LP, (uint32_t)(W * LP) * 4u);
-    const u32x4 frs = ra_make_srd(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 frs = ra_make_srd((HL && w >= 4 ? feat_lo : feat) + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
     const u32x4 krs = ra_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * kAuxRow);
     const u32x4 ors = ra_make_srd(out + (size_t)t * HW, (uint32_t)HW * 8u);
     auto ld16 = [](u32x4 srd, int off) {                            // asm + its own wait (no compiler-visible load in the loop)
@@ -713,42 +721,47 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
     };
     f32x4 cxv[4];
     auto load_cx = [&](int strip) {
-        int xx = kTilePx * strip + r;
+        int xx = TPX * strip + rp;
         xx = xx < W ? xx : W - 1;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) cxv[g] = ld16(cxs, (xx * LP + slot0 + 8 * g) * 4);
+        for (int g = 0; g < 4; ++g) {
+            cxv[g] = ld16(cxs, (xx * LP + slot0 + 8 * g) * 4);
+            if (HL && (r & 16)) cxv[g] = f32x4{0.f, 0.f, 0.f, 0.f};   // the lo half of the accumulator starts from zero
+        }
     };
+    const float cy_on = (HL && (r & 16)) ? 0.f : 1.f;
     load_cx(strip0);
 
     // ---- staging: rows 4w .. 4w+3 of every tile (two pieces); wave 7: the Cy row; wave 6: rstd_k of the 32 pixels
     int voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = 4 * w + 2 * i + h;
-        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+        const int row = 4 * w + 2 * i + h;                           // row of the LDS tile (HL: rows 16 .. 31 = lo rows of pixels 0 .. 15)
+        voff[i] = (HL ? (row & 15) : row) * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
     }
     const int nb = 2 + (w >= 6 ? 1 : 0);                            // DMA instructions of one batch of this wave
     int ds = strip0, dy = row0;
     auto stage = [&](int tile) {
         if (tile >= nt) return;
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NF) * kTileBytes + w * 2048);
-        const int px0 = dy * W + kTilePx * ds;
+        const int px0 = dy * W + TPX * ds;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
-        if (px0 + kTilePx <= HW) {
+        if (px0 + TPX <= HW) {
             ra_dma16(frs, st, voff[0], soff);
             ra_dma16(frs, st + 1024, voff[1], soff);
         } else {                                                     // last row of a ragged strip: clamp the source rows (not stored)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 4 * w + 2 * i + h;
-                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                const int prow_ = HL ? (row & 15) : row;
+                const int src = px0 + prow_ < HW ? prow_ : HW - 1 - px0;
                 ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
             }
         }
         if (w == 7) {
             ra_dma16_cached(cys, __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + (tile % NF) * 1024), dy * LP * 4 + lane * 16);
         } else if (w == 6) {                                         // 4 B per lane: pixels px0 + (lane & 31), clamped into the frame
-            int px = px0 + (lane & 31);
+            int px = px0 + (lane & (TPX - 1));
             px = px < HW ? px : HW - 1;
             uint32_t keep;
             const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::kring + (tile % NF) * 256);
@@ -766,7 +779,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
         if (dy == H) { dy = 0; ++ds; }
     };
     auto convert = [&](int tile) {
-        if (tile >= nt || map_f16) return;
+        if (tile >= nt || map_f16 || HL) return;
         const uint32_t st = lds0 + Lds::ring + (tile % NF) * kTileBytes + w * 2048 + lane * 16;
         u32x4 w_[2];
 #pragma unroll
@@ -795,9 +808,9 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
         float den = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 8; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
-        const int xx = kTilePx * fs + r;
+        const int xx = TPX * fs + rp;
         const int pxs = fy * W + xx;
-        const bool mine = have && h == 0 && (r >> 2) == w && xx < W;
+        const bool mine = have && h == 0 && (HL ? (r < 16 && (r >> 1) == w) : (r >> 2) == w) && xx < W;
         const f32x2 val = {mall, 1.f / den};
         const int so = mine ? pxs * 8 : 0x7ffffff0;                  // out of range -> dropped by the hardware range check
         asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(val), "v"(so), "s"(ors) : "memory");
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
             for (int g = 0; g < 4; ++g) {
                 const f32x4 cyv = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j] + cxv[g][j];
+                for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j] * cy_on + cxv[g][j];
             }
         }
         const float rk = *reinterpret_cast<const float*>(smem + Lds::kring + (it % NF) * 256 + r * 4) * kLog2e;
@@ -857,6 +870,13 @@ __global__ __launch_bounds__(512) void retr_logit_stats_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
         stage(it + A + 1);
+        if constexpr (HL) {                                          // fold [Q''.f_hi + Cy + Cx | Q''.f_lo]: both halves then hold the full sum
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[i]), __float_as_uint(s[i]), false, false);
+                s[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+        }
         float mloc = kNegBig;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -1430,12 +1450,12 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
         float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);
         const RetrPlan pl = plan_retr(T, H, W, 0);
         static SvpsLdsAttr attr_s, attr_e;
-        if (hipError_t ae = attr_s.ensure(reinterpret_cast<const void*>(svps::retr_logit_stats_kernel), svps::LStatsLds::total); ae != hipSuccess) return (int)ae;
+        if (hipError_t ae = attr_s.ensure(reinterpret_cast<const void*>(svps::retr_logit_stats_kernel<false>), svps::LStatsLds::total); ae != hipSuccess) return (int)ae;
         auto kern = svps::retr_attn_kernel<0, true>;
         if (hipError_t ae = attr_e.ensure(reinterpret_cast<const void*>(kern), svps::RetrLds::total); ae != hipSuccess) return (int)ae;
-        hipLaunchKernelGGL(svps::retr_logit_stats_kernel, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream,
+        hipLaunchKernelGGL(svps::retr_logit_stats_kernel<false>, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream,
                            static_cast<const _Float16*>(qh), static_cast<const _Float16*>(ql), cy, cx, c3, f_, a_, st, L, HW, H, W,
-                           pl.tiles_per_chunk, mf);
+                           pl.tiles_per_chunk, mf, (const __bf16*)nullptr);
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), svps::RetrLds::total, stream, qh_, ql_, cy, cx, c3, f_, a_, partial,
@@ -1454,32 +1474,59 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
     return (int)hipGetLastError();
 }
 
-// Precision forms of svps_retr_attn_fwd for L <= 128: P * rstd_v as fp16 hi + lo (retr_attn_kernel<0, false, true>); with feat_lo also
-// the map as fp16 hi + lo planes in 16-pixel tiles (retr_attn_kernel<0, false, true, true>, the reference-precision mode).
+// Reference-precision form of svps_retr_attn_fwd: P * rstd_v as fp16 hi + lo, the map as fp16 hi + lo planes in 16-pixel tiles
+// (retr_attn_kernel<0, false, true, true>). More than 128 slots (round 5): the softmax statistics over all 256 slot rows first
+// (retr_logit_stats_kernel<true>: 8 B per pixel into the workspace), then the retriever once per half of the slots with those statistics
+// (retr_attn_kernel<0, true, true, true>) - every logit is computed twice, nothing of size [L, HW] passes through HBM.
 namespace {
-int launch_retr_precise(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3, const void* feat,
-                        const void* feat_lo, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext, int T, int L,
-                        int H, int W, int D, int chunks, int flags, void* stream_) {
-    if (!qh || !ql || !cy || !cx || !c3 || !feat || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
-    if (D != svps::kD || T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
+int launch_retr_hl(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3, const void* feat,
+                   const void* feat_lo, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext, int T, int L,
+                   int H, int W, int D, int chunks, void* stream_) {
+    if (!qh || !ql || !cy || !cx || !c3 || !feat || !feat_lo || !aux || !workspace || !out_ext) return SVPS_ERR_BAD_ARG;
+    if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     const int HW = H * W;
-    const bool hl = feat_lo != nullptr;
-    const RetrPlan p = plan_retr(T, H, W, chunks, hl ? 16 : svps::kTilePx);
+    const RetrPlan p = plan_retr(T, H, W, chunks, 16);
     const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
-    if (workspace_bytes < partial_bytes) return SVPS_ERR_WORKSPACE;
+    const size_t stats_bytes = L > 128 ? (size_t)T * HW * sizeof(float2) : 0;
+    if (workspace_bytes < partial_bytes + stats_bytes) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
-    auto kern = hl ? svps::retr_attn_kernel<0, false, true, true> : svps::retr_attn_kernel<0, false, true, false>;
     using Lds = svps::RetrLdsT<2>;
-    static SvpsLdsAttr attr[2];
-    if (hipError_t ae = attr[hl ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
+    const __bf16* qh_ = static_cast<const __bf16*>(qh);
+    const __bf16* ql_ = static_cast<const __bf16*>(ql);
+    const __bf16* fh_ = static_cast<const __bf16*>(feat);
+    const __bf16* fl_ = static_cast<const __bf16*>(feat_lo);
+    const __bf16* a_ = static_cast<const __bf16*>(aux);
+    hipError_t e;
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
-    hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream, static_cast<const __bf16*>(qh), static_cast<const __bf16*>(ql),
-                       cy, cx, c3, static_cast<const __bf16*>(feat), static_cast<const __bf16*>(aux), partial, L, HW, H, W,
-                       p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, (hl || (flags & SVPS_FLAG_MAP_F16)) ? 1 : 0,
-                       static_cast<const __bf16*>(feat_lo));
-    hipError_t e = hipGetLastError();
+    if (L <= 128) {
+        auto kern = svps::retr_attn_kernel<0, false, true, true>;
+        static SvpsLdsAttr attr;
+        if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream, qh_, ql_, cy, cx, c3, fh_, a_, partial, L, HW, H, W,
+                           p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, 1, fl_);
+        e = hipGetLastError();
+    } else {
+        float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);     // partial_bytes is a multiple of 16
+        const RetrPlan pl = plan_retr(T, H, W, 0, 16);
+        auto kstat = svps::retr_logit_stats_kernel<true>;
+        auto kern = svps::retr_attn_kernel<0, true, true, true>;
+        static SvpsLdsAttr attr_s, attr_e;
+        if (hipError_t ae = attr_s.ensure(reinterpret_cast<const void*>(kstat), svps::LStatsLds::total); ae != hipSuccess) return (int)ae;
+        if (hipError_t ae = attr_e.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(kstat, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream, static_cast<const _Float16*>(qh),
+                           static_cast<const _Float16*>(ql), cy, cx, c3, fh_, a_, st, L, HW, H, W, pl.tiles_per_chunk, 1, fl_);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream, qh_, ql_, cy, cx, c3, fh_, a_, partial, 128, HW, H, W,
+                           p.tiles_per_chunk, 256, L, 0, (const float2*)st, 1, fl_);
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream, qh_, ql_, cy, cx, c3, fh_, a_, partial, L - 128, HW, H, W,
+                           p.tiles_per_chunk, 256, L, 128, (const float2*)st, 1, fl_);
+        e = hipGetLastError();
+    }
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 1, stream);
     if (e != hipSuccess) return (int)e;
     svps_prof_mark(SVPS_KERNEL_RETR_FINISH, 0, stream);
@@ -1490,17 +1537,15 @@ int launch_retr_precise(const void* qh, const void* ql, const float* cy, const f
 }  // namespace
 
 extern "C" size_t svps_retr_attn_hl_workspace_bytes(int T, int L, int H, int W, int chunks) {
-    if (T <= 0 || L <= 0 || L > 128 || H <= 0 || W <= 0) return 0;
+    if (T <= 0 || L <= 0 || L > 256 || H <= 0 || W <= 0) return 0;
     const RetrPlan p = plan_retr(T, H, W, chunks, 16);
-    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
+    return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float) + (L > 128 ? (size_t)T * H * W * sizeof(float2) : 0);
 }
 
 extern "C" int svps_retr_attn_hl_fwd(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3,
                                      const void* feat_hi, const void* feat_lo, const void* aux, void* workspace, size_t workspace_bytes,
                                      float* out_ext, int T, int L, int H, int W, int D, int chunks, void* stream_) {
-    if (!feat_lo) return SVPS_ERR_BAD_ARG;
-    return launch_retr_precise(qh, ql, cy, cx, c3, feat_hi, feat_lo, aux, workspace, workspace_bytes, out_ext, T, L, H, W, D, chunks,
-                               SVPS_FLAG_MAP_F16, stream_);
+    return launch_retr_hl(qh, ql, cy, cx, c3, feat_hi, feat_lo, aux, workspace, workspace_bytes, out_ext, T, L, H, W, D, chunks, stream_);
 }
 
 #ifdef SVPS_RETR_STAMP

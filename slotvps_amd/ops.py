@@ -860,7 +860,8 @@ def retr_stats_hl(feat_hl, H, W, tyk, txk, rk_hi, rk_lo, eps_k, rv_hi, rv_lo, rb
 
 
 def retr_attn_hl(qh, ql, cy, cx, c3, feat_hl, aux, L, H, W, chunks=0):
-    """retr_attn (precision form: P * rstd_v as fp16 hi + lo) on a map given as fp16 hi + lo planes [2, T, HW, 256]; L <= 128."""
+    """retr_attn with P * rstd_v as fp16 hi + lo on a map given as fp16 hi + lo planes [2, T, HW, 256]; slot axis of qh / ql / cy / cx / c3
+    padded to LP = 128 (L <= 128) or 256 (L <= 256: softmax statistics over all slots first, then the retriever once per half of the slots)."""
     lib = _lib.load()
     _need(qh, "qh", torch.float16, 3)
     _need(ql, "ql", torch.float16, 3)
@@ -870,9 +871,9 @@ def retr_attn_hl(qh, ql, cy, cx, c3, feat_hl, aux, L, H, W, chunks=0):
         _need(x, name, torch.float32, 3)
     _need(c3, "c3", torch.float32, 2)
     _, T, HW, D = feat_hl.shape
-    if not 1 <= L <= 128:
-        raise NotImplementedError("the reference-precision retriever covers 1 <= L <= 128 slots")
-    LP = 128
+    if not 1 <= L <= 256:
+        raise ValueError("the reference-precision retriever covers 1 <= L <= 256 slots")
+    LP = retr_slot_pad(L)
     if (HW != H * W or qh.shape != (T, LP, D) or ql.shape != (T, LP, D) or cy.shape != (T, H, LP) or cx.shape != (T, W, LP)
             or c3.shape != (T, LP) or aux.shape != (T, HW, 8)):
         raise ValueError("shape mismatch")

@@ -315,8 +315,6 @@ class MaskDynamicConv(nn.Module):
                 stats = pending[1]
         if hl:
             # reference precision: factors AND map as fp16 hi + lo (K3-HL: three MFMAs per product)
-            if L > 128:
-                raise NotImplementedError("precision 'fp16x2' covers L <= 128 slots (the exact mode, set_mode('fp32'), has no limit)")
             tyk, txk, rbv_p, tiled = self.stats_hl_tables(pos_tabs)
             stats = ops.retr_stats_hl(feat_pm, H, W, tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p, self.norm_v.eps,
                                       tx_tiled=tiled)
