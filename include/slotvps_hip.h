@@ -473,11 +473,13 @@ int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const fl
  * are TWO fp16 planes [T, H*W, 256] (hi, lo): 1 KiB per pixel, the size of an fp32 map, in the operand form of the consumers.
  * Against the reference's own fp32 outputs the free-running head then sits at the reference's own reproducibility (mask logits
  * <= 1e-4, slot argmax identical wherever decidable: tests/test_refprec_gpu.py) - the bounds only the vector-ALU exact mode below met.
- *   svps_level_fuse_hl_fwd   = svps_level_fuse_fwd (dynamic_mask_head.py:171-188) in the form f_i = up(f_{i-1} W_a^T) + W_b x_i + b (a 1x1
- *                              conv commutes with bilinear interpolation; W = [W_a | W_b]): cur [T, 128, H, W] fp32 NCHW; gprev
- *                              [T, (H/2)(W/2), 256] fp32 = f_{i-1} W_a^T (svps_slot_gemm_f16 on the coarser level's fp32 copy) or NULL
- *                              (level 0: wb = W_1 + W_2 + W_3); wb_hi / wb_lo [256, 128] fp16; out_hi / out_lo the planes; out_f32 the
- *                              same values as fp32 [T, H*W, 256] (the operand of the next level's coarse product) or NULL
+ *   svps_level_fuse_hl_fwd   = svps_level_fuse_fwd (dynamic_mask_head.py:171-188). A 1x1 conv commutes with bilinear interpolation; with
+ *                              W = [W_a | W_b] and G^(m)_i = f_i (W_a^m)^T the level recursion is
+ *                                  G^(m)_i = up( G^(m+1)_{i-1} ) + (W_a^m W_b) x_i + W_a^m b      (level 0: W_a^m (W_1 + W_2 + W_3) x_0)
+ *                              - ONE call computes out = up(gprev) + wb cur + bc: cur [T, 128, H, W] fp32 NCHW; gprev [T, (H/2)(W/2), 256]
+ *                              fp32 or NULL (no upsampled term); wb_hi / wb_lo [256, 128] fp16 (the host composes W_a^m W_b in float64);
+ *                              out_hi / out_lo the planes (both or neither: m = 0), out_f32 the same values as fp32 [T, H*W, 256] or NULL
+ *                              (m >= 1: the operand of the finer levels); at least one output. Level i of n is n - i calls.
  *   svps_retr_stats_hl_fwd   = svps_retr_stats_fwd (:432-433, the two LayerNorm statistics) with hi + lo factors on the planes, both projections from
  *                              ONE read (slotvps_amd/csrc/retr_stats_hl.hip); same aux rows. The fp32 tables come in ACCUMULATOR order
  *                              (column 32 B + 16 h + 4 g + j = factor row 32 B + 8 g + 4 h + j): tyk [ty_rows, 256] = Ty + r_k, txk

@@ -232,11 +232,15 @@ class SlotClipRunner:
         if getattr(self.head, "precision", "bf16") == "fp16x2":
             # reference precision on the matrix cores: the maps are 1 KiB per pixel (fp16 hi + lo planes). Algorithmic flops = one product
             # per multiply; executed = the MFMAs issued (three per product in K4 / K3-HL / K2; K1'-HL: 4 x 32 producer + 4 x 26 consumer per
-            # 16-pixel tile). K3-HL reads both planes once per stage; K4-HL: the fine part K = 128 (the 256-wide coarse product runs on K8).
+            # 16-pixel tile). K3-HL reads both planes once per stage; K4-HL: K = 128 products only (composed weights).
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
             return {
-                "level_fuse": {"bytes": T * sum(hw * (512 + 1024 + (256 if i else 0) + (1024 if i < len(px) - 1 else 0)) for i, hw in enumerate(px)),
-                               "flops": T * sum(px) * 2 * 384 * D, "executed_flops": T * sum(px) * 3 * 2 * 128 * D},
+                # K4-HL: per pixel 512 B of the incoming fp32 map in, the two planes (1 KiB) out, the 4x smaller level below (its fp32 G, 1 KiB
+                # per coarse pixel) in - the function's own I/O in this storage; the G^(m) outputs a level writes for its finer levels (fp32,
+                # n - 1 - i launches of the same K = 128 kernel, csrc/level_fuse_hl.hip) are executed work, not algorithmic bytes
+                "level_fuse": {"bytes": T * sum(hw * (512 + 1024 + (256 if i else 0)) for i, hw in enumerate(px)),
+                               "flops": T * sum(px) * 2 * 384 * D,
+                               "executed_flops": T * sum(hw * (len(px) - i) for i, hw in enumerate(px)) * 3 * 2 * 128 * D},
                 "mask_decode": {"bytes": T * px[-1] * (1024 + 4 * L + 1), "flops": T * px[-1] * 2 * L * D,
                                 "executed_flops": T * px[-1] * ((4 if L <= 128 else 8) * 48 * 32768 // 32)},
                 "retr_stats": {"bytes": T * ps * (1024 + 16), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D),

@@ -63,7 +63,9 @@ __device__ __forceinline__ void hl_split(float x, _Float16& hi, _Float16& lo) {
 // STAGED (TAPS, W % 32 == 0: a tile is 32 pixels of ONE output row): the two source rows x <= 18 source columns of g the tile blends arrive
 // as whole 1-KiB rows (36 coalesced wave loads per tile instead of 16 loads per LANE that each touch 64 sectors - those were 46 % of
 // the kernel), one tile ahead through 20 registers, and every lane reads its four taps from LDS.
-template <bool TAPS, bool F32OUT, bool STAGED = false>
+// PLANES = false (round 5): only the fp32 result is written - the launches that produce G^(m) = f W_a^m^T for the finer levels (see
+// svps_level_fuse_hl_fwd below); the fp32 value is then the unsplit sum itself.
+template <bool TAPS, bool F32OUT, bool STAGED = false, bool PLANES = true>
 __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     const float* __restrict__ cur,            // [T, 128, H, W] fp32 (NCHW, the reference's layout)
     const float* __restrict__ gprev,          // TAPS: [T, (H/2)*(W/2), 256] fp32 = f_{i-1} W_a^T, pixel-major
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     // out tiles -> HBM, all 512 threads: whole 512-byte (fp32: 1-KiB) pixel rows
     auto store_out = [&](int tile) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < (PLANES ? 2 : 0); ++u) {
             const int piece = u * 512 + tid;                            // [row][chunk position]
             const int row = piece >> 5, cpos = piece & 31;
             const int px = px_begin + tile * kTilePx + row;
@@ -262,15 +264,21 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             for (int j = 0; j < 4; ++j) {
                 float v = acc[4 * g + j];
                 if constexpr (TAPS) v += h0 * (w0 * tp[0][g][j] + w1 * tp[1][g][j]) + h1 * (w0 * tp[2][g][j] + w1 * tp[3][g][j]);
-                _Float16 vh, vl;
-                hl_split(v, vh, vl);
-                oh[j] = vh;
-                ol[j] = vl;
-                of[j] = (float)vh + (float)vl;             // the fp32 copy holds exactly the planes' value
+                if constexpr (PLANES) {
+                    _Float16 vh, vl;
+                    hl_split(v, vh, vl);
+                    oh[j] = vh;
+                    ol[j] = vl;
+                    of[j] = (float)vh + (float)vl;         // the fp32 copy holds exactly the planes' value
+                } else {
+                    of[j] = v;
+                }
             }
             const int o = r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2;
-            *reinterpret_cast<f16x4*>(smem + Lds::o_hi + o) = oh;
-            *reinterpret_cast<f16x4*>(smem + Lds::o_lo + o) = ol;
+            if constexpr (PLANES) {
+                *reinterpret_cast<f16x4*>(smem + Lds::o_hi + o) = oh;
+                *reinterpret_cast<f16x4*>(smem + Lds::o_lo + o) = ol;
+            }
             if constexpr (F32OUT) *reinterpret_cast<f32x4*>(smem + Lds::o_f32 + r * 1024 + (((ch0 >> 2) ^ (r & 15)) * 16)) = of;
         }
         __syncthreads();                                   // out tiles complete; every wave is done reading operand tile `it` (and its taps)
@@ -284,12 +292,16 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
 
 }  // namespace svps
 
-// svps_level_fuse_hl_fwd (include/slotvps_hip.h): cur [T, 128, H, W] fp32 NCHW; gprev [T, (H/2)(W/2), 256] fp32 = f_{i-1} W_a^T or NULL
-// (level 0: wb = W_1 + W_2 + W_3); wb_hi / wb_lo [256, 128] fp16; bc [256] fp32; out_hi / out_lo [T, H*W, 256] fp16; out_f32 the same
-// values as fp32 [T, H*W, 256] or NULL.
+// svps_level_fuse_hl_fwd (include/slotvps_hip.h): out = up(gprev) + wb cur + bc. cur [T, 128, H, W] fp32 NCHW; gprev [T, (H/2)(W/2), 256]
+// fp32 or NULL (no upsampled term); wb_hi / wb_lo [256, 128] fp16; bc [256] fp32; out_hi / out_lo [T, H*W, 256] fp16 planes (both or
+// neither); out_f32 the same values as fp32 [T, H*W, 256] or NULL (at least one output).
+// The level recursion without any 256-wide product (round 5): with G^(m)_i = f_i (W_a^m)^T,
+//     G^(m)_i = up( G^(m+1)_{i-1} ) + (W_a^m W_b) x_i + W_a^m b          (level 0: W_a^m (W_1 + W_2 + W_3) x_0 + W_a^m b)
+// - the 1x1 conv commutes with the interpolation at EVERY level, so the host composes W_a^m W_b in float64 once per weight version and
+// level i is 4 - i launches of this kernel (m = 0: the planes of f_i; m >= 1: fp32 only), each a K = 128 product at level i's resolution.
 extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
                                       void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream_) {
-    if (!cur || !wb_hi || !wb_lo || !bc || !out_hi || !out_lo) return SVPS_ERR_BAD_ARG;
+    if (!cur || !wb_hi || !wb_lo || !bc || (!out_hi != !out_lo) || (!out_hi && !out_f32)) return SVPS_ERR_BAD_ARG;
     if (T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     if (gprev && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;     // x2 upsampling: even sizes
@@ -303,17 +315,18 @@ extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, cons
     constexpr int lds = svps::FuseHlLds::total;
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 0, stream);
     hipError_t e = hipSuccess;
-#define SVPS_LFH(TAPS, F32)                                                                                                        \
+#define SVPS_LFH(TAPS, F32, PL)                                                                                                    \
     do {                                                                                                                           \
         const bool staged = TAPS && (W & 31) == 0;          /* a tile = 32 pixels of one output row: taps through LDS */           \
-        auto kern = staged ? svps::level_fuse_hl_kernel<TAPS, F32, TAPS> : svps::level_fuse_hl_kernel<TAPS, F32, false>;          \
+        auto kern = staged ? svps::level_fuse_hl_kernel<TAPS, F32, TAPS, PL> : svps::level_fuse_hl_kernel<TAPS, F32, false, PL>;  \
         static SvpsLdsAttr attr[2];                                                                                                \
         if ((e = attr[staged ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;             \
         hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, cur, gprev, static_cast<const H16*>(wb_hi),              \
                            static_cast<const H16*>(wb_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), out_f32, H, W, tpc); \
     } while (0)
-    if (gprev) { if (out_f32) SVPS_LFH(true, true); else SVPS_LFH(true, false); }
-    else { if (out_f32) SVPS_LFH(false, true); else SVPS_LFH(false, false); }
+    if (!out_hi) { if (gprev) SVPS_LFH(true, true, false); else SVPS_LFH(false, true, false); }
+    else if (gprev) { if (out_f32) SVPS_LFH(true, true, true); else SVPS_LFH(true, false, true); }
+    else { if (out_f32) SVPS_LFH(false, true, true); else SVPS_LFH(false, false, true); }
 #undef SVPS_LFH
     e = hipGetLastError();
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 1, stream);

@@ -789,6 +789,49 @@ def level_fuse_hl_weights(wc):
     return {"wb_hl": split_hl(wb), "w0_hl": split_hl(w0), "wa_pack": pack_b_fragments(w[:, :256].float().contiguous(), "fp16")}
 
 
+def level_fuse_hl_composed(wc, bc, n_levels=4):
+    """Operands of the level recursion WITHOUT any 256-wide product (csrc/level_fuse_hl.hip, round 5): with W = [W_a | W_b] and
+    G^(m)_i = f_i (W_a^m)^T, G^(m)_i = up(G^(m+1)_{i-1}) + (W_a^m W_b) x_i + W_a^m b (level 0: W_a^m (W_1 + W_2 + W_3) x_0). Composed in
+    float64: {"w": [m] -> [2, 256, 128] fp16 planes of W_a^m W_b, "w0": the same for level 0, "b": [m] -> [256] fp32 = W_a^m b}, m < n_levels."""
+    w = wc.detach().double().reshape(256, 384)
+    b = bc.detach().double()
+    wa, wb = w[:, :256], w[:, 256:]
+    w0 = w[:, :128] + w[:, 128:256] + w[:, 256:]
+    out = {"w": [], "w0": [], "b": []}
+    p = torch.eye(256, dtype=torch.float64, device=w.device)
+    for m in range(n_levels):
+        out["w"].append(split_hl((p @ wb).float().contiguous()))
+        out["w0"].append(split_hl((p @ w0).float().contiguous()))
+        out["b"].append((p @ b).float().contiguous())
+        p = wa @ p
+    return out
+
+
+def level_fuse_hl_g(cur, gprev, w_hl, bias, H, W, planes=True, f32=False):
+    """One launch of K4-HL: out = up(gprev) + w cur + bias. cur [T, 128, H, W] fp32 NCHW; gprev [T, (H/2)(W/2), 256] fp32 or None; w_hl
+    [2, 256, 128] fp16 planes; bias [256] fp32. Returns (planes [2, T, H*W, 256] fp16 or None, fp32 [T, H*W, 256] or None)."""
+    lib = _lib.load()
+    _need(cur, "cur", torch.float32, 4)
+    T = cur.shape[0]
+    if cur.shape != (T, 128, H, W):
+        raise ValueError(f"cur {tuple(cur.shape)} != [T, 128, {H}, {W}]")
+    _need(bias, "bias", torch.float32, 1)
+    _need(w_hl, "w_hl", torch.float16, 3)
+    if gprev is not None:
+        _need(gprev, "gprev", torch.float32, 3)
+        if gprev.shape != (T, (H // 2) * (W // 2), 256) or H % 2 or W % 2:
+            raise ValueError(f"gprev {tuple(gprev.shape)} does not match an {H}x{W} level")
+    if not (planes or f32):
+        raise ValueError("nothing to write")
+    out = torch.empty((2, T, H * W, 256), dtype=torch.float16, device=cur.device) if planes else None
+    o32 = torch.empty((T, H * W, 256), dtype=torch.float32, device=cur.device) if f32 else None
+    with _on(cur, gprev, w_hl, bias) as ctx:
+        rc = lib.svps_level_fuse_hl_fwd(_ptr(cur), _ptr(gprev), _ptr(w_hl[0]), _ptr(w_hl[1]), _ptr(bias), _ptr(out[0]) if planes else None,
+                                        _ptr(out[1]) if planes else None, _ptr(o32), T, H, W, ctx.stream)
+    _lib.check(rc, "svps_level_fuse_hl_fwd")
+    return out, o32
+
+
 def level_fuse_hl(cur, prev_f32, weights, bc, H, W, want_f32=False):
     """K4 at the reference's precision: f = up(prev W_a^T) + W_b cur + b (a 1x1 conv commutes with bilinear interpolation; the 256-wide
     product runs at the coarse resolution on K8 with fp16 hi + lo operands). cur [T, 128, H, W] fp32 NCHW; prev_f32 [T, (H/2)(W/2), 256]

@@ -845,14 +845,29 @@ class MultiScaleDynamicMaskHead(nn.Module):
             conv = self.conv_trans.conv
             if cur.dim() != 4:
                 raise NotImplementedError("precision 'fp16x2' takes the incoming maps as [T, 128, H, W] fp32 (NCHW)")
-            wts = _cached(self, "cw_hl", [conv.weight], lambda: ops.level_fuse_hl_weights(conv.weight.detach().reshape(self.dh_dim, -1)))
-            prev_f32 = None
-            if prev_pm is not None:                      # the coarser level's fp32 copy (K4-HL writes it next to the planes)
-                prev_f32 = getattr(prev_pm, "_svps_f32", None)
-                if prev_f32 is None:
-                    prev_f32 = prev_pm[0].float() + prev_pm[1].float()
-            out, f32 = ops.level_fuse_hl(cur.float().contiguous(), prev_f32, wts, conv.bias, hw[0], hw[1], want_f32=not last)
-            out._svps_f32 = f32
+            # the level recursion without any 256-wide product (csrc/level_fuse_hl.hip): G^(m)_i = f_i (W_a^m)^T = up(G^(m+1)_{i-1}) +
+            # (W_a^m W_b) x_i + W_a^m b. `level` counts from the coarsest; level i produces the orders m = 0 .. (levels_left) its finer
+            # levels will ask for: m = 0 the planes of f_i, m >= 1 fp32 only
+            cw = _cached(self, "cw_hl_composed", [conv.weight, conv.bias],
+                         lambda: ops.level_fuse_hl_composed(conv.weight, conv.bias, self.feat_num_levels))
+            if prev_pm is None:
+                level, gp = 0, {}
+            else:
+                level, gp = prev_pm._svps_level + 1, prev_pm._svps_g
+            orders = 1 if last else max(1, self.feat_num_levels - level)
+            cur32 = cur.float().contiguous()
+            out, g = None, {}
+            for m in range(orders):
+                if prev_pm is not None and (m + 1) not in gp:
+                    raise RuntimeError(f"level {level} needs G^({m + 1}) of the level below (was that level fused with last=True?)")
+                w_hl = cw["w0"][m] if prev_pm is None else cw["w"][m]
+                planes, f32 = ops.level_fuse_hl_g(cur32, None if prev_pm is None else gp[m + 1], w_hl, cw["b"][m], hw[0], hw[1],
+                                                  planes=m == 0, f32=m > 0)
+                if m == 0:
+                    out = planes
+                else:
+                    g[m] = f32
+            out._svps_level, out._svps_g = level, g
             return out
         form = self._map_form(cur)
         if prev_pm is not None and form != "fp16":                       # a level follows the encoding of the level below it

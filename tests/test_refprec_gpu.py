@@ -397,3 +397,32 @@ def test_fp16x2_full_size_clip_against_the_exact_mode(cuda):
     print(f"\nfull-size clip, fp16x2 vs exact mode, free-running: slot embeddings per stage " + " ".join(f"{e:.1e}" for e in emb) +
           f"; mask logits {dm:.2e}; slot argmax equal on {100 * same:.4f} % of the pixels ({100 * same_dec:.4f} % of the {100 * decided.double().mean().item():.1f} % decidable)")
     assert emb[0] <= 2e-4 and emb[-1] <= 5e-2 and dm <= 5e-3 and same_dec == 1.0 and same >= 0.995
+
+
+@pytest.mark.parametrize("T,H,W", [(2, 64, 128), (1, 32, 96), (1, 32, 40)])
+def test_level_recursion_without_wide_products(cuda, T, H, W):
+    """The four-level recursion of the fp16x2 head (slot_head.fuse_level: G^(m)_i = up(G^(m+1)_{i-1}) + (W_a^m W_b) x_i + W_a^m b with the
+    weights composed in float64, csrc/level_fuse_hl.hip - no 256-wide product at any resolution) against a float64 evaluation of
+    dynamic_mask_head.py:171-188 in the REFERENCE's order (upsample the previous fused map, concatenate, 1x1 conv) on identical inputs:
+    every level's planes within 5e-6 of the map's scale; staged (W % 32 == 0 at the fine levels) and per-lane tap paths."""
+    import torch
+    params = synth.make_params(synth.head_shapes(), 21)
+    head = build_head(cuda, params).set_mode("fp16x2")
+    feats = synth.make_clip_features(22, T, H, W)
+    sizes = synth.level_sizes(H, W)
+    wc = params["conv_trans.conv.weight"].reshape(256, 384).astype(np.float64)
+    bc = params["conv_trans.conv.bias"].astype(np.float64)
+    prev, prev64, worst = None, [None] * T, 0.0
+    with torch.no_grad():
+        for i, (h, w) in enumerate(sizes):
+            cur = torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda)
+            f = head.fuse_level(cur, prev, (h, w), last=i == 3)
+            got = _sum_hl(f)
+            assert sorted(f._svps_g) == list(range(1, 4 - i))          # the orders the finer levels will ask for
+            for t in range(T):
+                ref = orc.fuse_level(feats[t][i].astype(np.float64), prev64[t], wc, bc)
+                worst = max(worst, float(np.abs(got[t] - ref).max() / max(1.0, np.abs(ref).max())))
+                prev64[t] = np.ascontiguousarray(ref.T).reshape(256, h, w)
+            prev = f
+    print(f"\nlevel recursion T={T} {H}x{W}: {worst:.2e} of the maps' scale over the four levels")
+    assert worst <= 5e-6
