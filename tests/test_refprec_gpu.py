@@ -399,7 +399,7 @@ def test_fp16x2_full_size_clip_against_the_exact_mode(cuda):
     assert emb[0] <= 2e-4 and emb[-1] <= 5e-2 and dm <= 5e-3 and same_dec == 1.0 and same >= 0.995
 
 
-@pytest.mark.parametrize("T,H,W", [(2, 64, 128), (1, 32, 96), (1, 32, 40)])
+@pytest.mark.parametrize("T,H,W", [(2, 64, 128), (1, 32, 96), (1, 64, 256)])
 def test_level_recursion_without_wide_products(cuda, T, H, W):
     """The four-level recursion of the fp16x2 head (slot_head.fuse_level: G^(m)_i = up(G^(m+1)_{i-1}) + (W_a^m W_b) x_i + W_a^m b with the
     weights composed in float64, csrc/level_fuse_hl.hip - no 256-wide product at any resolution) against a float64 evaluation of
