@@ -17,6 +17,8 @@
 // tiles by LDS-DMA into a 4-stage ring, wave w owns slots [32w, 32w+32), pixel = lane), so the
 // logits leave the accumulators as 128-B pixel-contiguous row segments of the [T, L, HW] output.
 #include <cstdlib>
+#include <stdlib.h>
+
 #include <type_traits>
 #include "common.h"
 #include "../../include/slotvps_hip.h"
@@ -306,11 +308,19 @@ __device__ unsigned long long k2_stamps[4][8][8];            // [wave][iteration
 // LOGITS = false: argmax-only mode (out == NULL) - the [T, L, HW] logits are neither transposed nor stored: per pixel 512 B in and
 // 1 B out instead of 512 + 4 L + 1 (a consumer that only needs the per-pixel slot id, e.g. the clip driver's assignment map)
 // ABL (timing-only builds, -DSVPS_K2_ABLATE + tools/ablate_k2.sh): 1 no MFMAs, 2 no fragment reads either, 4 no argmax epilogue, 8 no DMA
-template <bool ARGMAX, int NW = 4, bool LOGITS = true, int ABL = 0, int NSTG = 0, typename MT = __bf16>
+// HL (round 5, the reference-precision mode; NW = 4, MT = fp16): the map arrives as fp16 hi + lo planes. As in retr_attn_kernel<.., HL> a tile
+// is SIXTEEN pixels - LDS rows 0 .. 15 their hi rows (staged by waves 0, 1 from `feat`), rows 16 .. 31 their lo rows (waves 2, 3 from
+// `feat_lo`) - so ring, swizzle, fragment addresses, barrier schedule and vmcnt arithmetic are those of the 32-pixel form. The chain
+// (e as fp16 hi + lo) yields [e.f_hi | e.f_lo] in the two column halves of the accumulator, folded with one v_permlane16_swap + add per
+// register; the norm runs on hi + lo in fp32 (16 threads per pixel); the logits leave as two 16-byte stores per lane and tile (4 lanes =
+// one 64-byte row segment of a slot; consecutive tiles fill the other half of the 128-byte line).
+template <bool ARGMAX, int NW = 4, bool LOGITS = true, int ABL = 0, int NSTG = 0, typename MT = __bf16, bool HL = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v2(
     const MT* __restrict__ feat, const float* __restrict__ embed, const float* __restrict__ bn_scale,
     const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
-    uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk) {
+    uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk, const MT* __restrict__ feat_lo = nullptr) {
+    static_assert(!HL || (NW == 4 && !(ABL & 32)), "the hi + lo form: four waves, the skewed loop");
+    constexpr int TPX = HL ? 16 : kTilePx;                        // pixels per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef MT mx8 __attribute__((ext_vector_type(8)));         // MT: element type of the fused map, bf16 or fp16 (common.h)
     using Lds = Dec2Lds<NW, LOGITS, NSTG>;
@@ -326,10 +336,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
     int r = r_, h = h_;
     const int t = blockIdx.y, c = blockIdx.x;
 
-    const int px_begin = c * tiles_per_chunk * kTilePx;
-    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    const int px_begin = c * tiles_per_chunk * TPX;
+    int px_end = px_begin + tiles_per_chunk * TPX;
     px_end = px_end < HW ? px_end : HW;
-    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+    const int nt = (px_end - px_begin + TPX - 1) / TPX;
 
     float* aff = reinterpret_cast<float*>(smem + Lds::affine);
     float* inv_norm = reinterpret_cast<float*>(smem + Lds::norm);
@@ -376,9 +386,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
     wait_vm<0>();
     __syncthreads();
     const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
-    const u32x4 frs = make_srd_d(feat + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 frs = make_srd_d((HL && w >= 2 ? feat_lo : feat) + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
     const u32x4 ors = make_srd_d(LOGITS ? out + (size_t)t * L * HW : nullptr, LOGITS ? (uint32_t)L * (uint32_t)HW * 4u : 0u);
-    constexpr int kMS = LOGITS ? 4 : 0;                          // mask stores per wave and tile
+    constexpr int kMS = LOGITS ? (HL ? 2 : 4) : 0;               // mask stores per wave and tile
     const u32x4 ars = make_srd_d(ARGMAX ? slot_argmax + (size_t)t * HW : nullptr, ARGMAX ? (uint32_t)HW : 0u);
     auto stage = [&](int tile) {          // exactly PC DMA instructions per wave, or none
         if (tile >= nt || (ABL & 8)) return;
@@ -389,13 +399,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
 #pragma unroll
             for (int i = 0; i < PC; ++i) {
                 const int row = 2 * PC * w + 2 * i + hh;
-                voff[i] = row * kRowBytes + ((rr ^ swz(row)) * 16);
+                voff[i] = (HL ? (row & 15) : row) * kRowBytes + ((rr ^ swz(row)) * 16);
             }
         }
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * kTileBytes + w * PC * 1024);
-        const int px0 = px_begin + tile * kTilePx;
+        const int px0 = px_begin + tile * TPX;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
-        if (px0 + kTilePx <= HW) {
+        if (px0 + TPX <= HW) {
             if constexpr (PC == 4) {
                 dma16x4_d(frs, st, voff[0], voff[1] - 1024, voff[2] - 2048, voff[3] - 3072, soff);
             } else {
@@ -406,7 +416,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
 #pragma unroll
             for (int i = 0; i < PC; ++i) {
                 const int row = 2 * PC * w + 2 * i + h;
-                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                const int prow = HL ? (row & 15) : row;
+                const int src = px0 + prow < HW ? prow : HW - 1 - px0;
                 dma16_d(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
             }
         }
@@ -422,8 +433,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                 const int sl = __float_as_int(cnd.y);
                 if (cnd.x > b || (cnd.x == b && sl < bs)) { b = cnd.x; bs = sl; }
             }
-            const int px = px_begin + tile * kTilePx + r;
-            store1_d(bs, ars, px < px_end ? px : 0x7ffffff0);
+            const int px = px_begin + tile * TPX + r;
+            store1_d(bs, ars, (px < px_end && r < TPX) ? px : 0x7ffffff0);
         } else {
             store1_d(0, ars, 0x7ffffff0);                // same instruction for every lane; dropped by the range check
         }
@@ -585,17 +596,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         // the per-pixel norm is not needed to order the slots - the argmax is taken over sgn(fg_scale) * (s + c). It equals the
         // full mode's argmax except where two slots' logits round to the SAME fp32 value (the full mode then reports the lower
         // slot, this mode the larger s + c): pixels without a decision at fp32 resolution.
-        if constexpr (LOGITS && CH) {   // ||scale * f + shift||^2 per pixel: 2 NW threads per pixel, 16 / NW chunks each
-            constexpr int TPP = 2 * NW;
+        if constexpr (LOGITS && CH) {   // ||scale * f + shift||^2 per pixel: 2 NW threads per pixel, 16 / NW chunks each (HL: 16 threads, 2 chunks)
+            constexpr int TPP = HL ? 16 : 2 * NW;
             const int npx = tid_o / TPP, nsub = tid_o % TPP;
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < 32 / TPP; ++i) {
                 const int chunk = nsub + TPP * i;
                 const mx8 x = *reinterpret_cast<const mx8*>(ft + npx * kRowBytes + ((chunk ^ swz(npx)) * 16));
+                mx8 xl = x;
+                if constexpr (HL) xl = *reinterpret_cast<const mx8*>(ft + (npx + 16) * kRowBytes + ((chunk ^ swz(npx + 16)) * 16));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float g = (float)x[j] * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
+                    const float xv = HL ? (float)x[j] + (float)xl[j] : (float)x[j];
+                    const float g = xv * aff[8 * chunk + j] + aff[kD + 8 * chunk + j];
                     ss += g * g;
                 }
                 __builtin_amdgcn_sched_barrier(0);       // one chunk at a time: the affine rows are not worth 64 VGPRs
@@ -624,7 +638,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         float inr = 1.f;
         f32x4 c4[2];                                     // e . shift of slots sl .. sl + 3, one group ahead
         if constexpr (EP) {
-            if constexpr (LOGITS) inr = inv_norm[((it - 1) & 1) * kTilePx + r];
+            if constexpr (LOGITS) inr = inv_norm[((it - 1) & 1) * kTilePx + (HL ? (r & 15) : r)];
             c4[0] = *reinterpret_cast<const f32x4*>(cs + 32 * w + acc_row(0, h));
         }
         f32x16 s;
@@ -663,8 +677,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                             const int sl = __float_as_int(cnd[ww].y);
                             if (cnd[ww].x > b || (cnd[ww].x == b && sl < bs)) { b = cnd[ww].x; bs = sl; }
                         }
-                        const int px = px_begin + (it - 2) * kTilePx + r;
-                        const bool ok = w == 0 && h == 0 && it >= 2 && px < px_end;
+                        const int px = px_begin + (it - 2) * TPX + r;
+                        const bool ok = w == 0 && h == 0 && it >= 2 && px < px_end && r < TPX;
                         store1_d(bs, ars, ok ? px : 0x7ffffff0);
                     }
                 }
@@ -672,7 +686,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                     const int i = 4 * grp + u;
                     const int sl = acc_row(i, h);        // slot inside this wave's block of 32
                     const float m = LOGITS ? (sp[i] + c4[grp & 1][u]) * inr * fg_scale + fg_shift : (sp[i] + c4[grp & 1][u]) * ksgn;
-                    if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + r * 4) = m;
+                    if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + (HL ? (r & 15) : r) * 4) = m;   // (HL: lanes r and r + 16 hold the same pixel)
                     if constexpr (ARGMAX) {
                         if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
                     }
@@ -698,10 +712,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                 if (h == 0) am[((it - 1) & 1) * NW * kTilePx + w * kTilePx + r] = make_float2(best, __int_as_float(best_slot));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-local transpose: own writes done, no barrier needed
-            const int px0 = px_begin + (it - 1) * kTilePx;
+            const int px0 = px_begin + (it - 1) * TPX;
 #pragma unroll
             for (int u = 0; u < kMS; ++u) {
-                const int sl = 8 * u + (lane_o >> 3), cc = lane_o & 7;
+                const int sl = HL ? 16 * u + (lane_o >> 2) : 8 * u + (lane_o >> 3), cc = HL ? (lane_o & 3) : (lane_o & 7);
                 const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * Lds::kORow + cc * 16);
                 const int slot = 32 * w + sl, px = px0 + 4 * cc;
                 const bool ok = slot < L && px < px_end;
@@ -710,6 +724,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
             }
         }
         K2_STAMP(6);
+        if constexpr (CH && HL) {
+            // columns r < 16: e . f_hi of pixel r; columns r >= 16: e . f_lo of pixel r - 16. Fold: afterwards both halves hold the full sum
+            // (v_permlane16_swap with the same value in both operands returns [row0, row0, row2, row2] and [row1, row1, row3, row3])
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[i]), __float_as_uint(s[i]), false, false);
+                s[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+        }
         if constexpr (CH) sp = s;
 #ifdef SVPS_K2_STAMP
         asm volatile("" : "+v"(sp));
@@ -754,20 +777,22 @@ hipError_t launch_decode(const void* feat, const float* embed, const float* bn_s
     return hipGetLastError();
 }
 
-template <bool ARGMAX, int NW, bool LOGITS = true, int ABL = 0, int NSTG = 0, typename MT = __bf16>
+template <bool ARGMAX, int NW, bool LOGITS = true, int ABL = 0, int NSTG = 0, typename MT = __bf16, bool HL = false>
 hipError_t launch_decode_v2(const void* feat, const float* embed, const float* bn_scale, const float* bn_shift,
                             float fg_scale, float fg_shift, void* out, uint8_t* slot_argmax, int T, int L, int HW,
-                            hipStream_t stream) {
-    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW, LOGITS, ABL, NSTG, MT>;
+                            hipStream_t stream, const void* feat_lo = nullptr) {
+    auto kern = svps::mask_decode_kernel_v2<ARGMAX, NW, LOGITS, ABL, NSTG, MT, HL>;
     using Lds = svps::Dec2Lds<NW, LOGITS, NSTG>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
-    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;      // NW = 4: two co-resident workgroups per CU (2 x 68 KiB LDS); 8: one
+    constexpr int tpx = HL ? 16 : svps::kTilePx;                     // HL: a tile is sixteen pixels (hi rows + lo rows)
+    const int tiles = (HW + tpx - 1) / tpx;                          // NW = 4: two co-resident workgroups per CU (2 x 68 KiB LDS); 8: one
     int chunks = svps_pick_chunks(T, tiles, (NW == 4 ? 2 : 1) * dec_num_cus());
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(64 * NW), Lds::total, stream, static_cast<const MT*>(feat),
-                       embed, bn_scale, bn_shift, fg_scale, fg_shift, static_cast<float*>(out), slot_argmax, L, HW, tpc);
+                       embed, bn_scale, bn_shift, fg_scale, fg_shift, static_cast<float*>(out), slot_argmax, L, HW, tpc,
+                       static_cast<const MT*>(feat_lo));
     return hipGetLastError();
 }
 
@@ -872,7 +897,15 @@ extern "C" int svps_mask_decode_hl_fwd(const void* feat_hi, const void* feat_lo,
     // L <= 128: four waves, two feature tiles per plane in flight, TWO workgroups per CU (2 x 68 KiB of LDS, 256 registers): this first-generation
     // kernel waits for each tile (hipcc drains its builtin LDS-DMA before the next LDS read), so a second workgroup is what hides the latency
 #define SVPS_HL(W, NS, AM) launch_decode<W, NS, AM, float, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)
-    const hipError_t e = L <= 128 ? (slot_argmax ? SVPS_HL(4, 2, true) : SVPS_HL(4, 2, false)) : (slot_argmax ? SVPS_HL(8, 4, true) : SVPS_HL(8, 4, false));
+    hipError_t e;
+    static const bool old_form = getenv("SVPS_K2_HL_V1") != nullptr;         // comparison runs only (tools/kbench3.py)
+    if (L <= 128 && (HW & 3) == 0 && !old_form) {
+        // round 5: the skewed fast path on 16-pixel hi / lo tiles (mask_decode_kernel_v2<.., HL>)
+        e = slot_argmax ? launch_decode_v2<true, 4, true, 0, 0, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)
+                        : launch_decode_v2<false, 4, true, 0, 0, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo);
+    } else {
+        e = L <= 128 ? (slot_argmax ? SVPS_HL(4, 2, true) : SVPS_HL(4, 2, false)) : (slot_argmax ? SVPS_HL(8, 4, true) : SVPS_HL(8, 4, false));
+    }
 #undef SVPS_HL
     svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
     return (int)e;
