@@ -222,6 +222,14 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         }
         const int slot0 = 32 * sb + 4 * h;                          // accumulator register 4 g + j <-> slot row slot0 + 8 g + j
         const int key = (r >> 1) & 3;
+        // HL (round 5): after the chain lane r < 16 holds [Q''.f_hi + Cy + Cx] and lane r + 16 [Q''.f_lo] of the SAME pixel for all 16 slot
+        // registers. The fold EXCHANGES register halves instead of duplicating sums (v_permlane16_swap(s[i], s[i + 8])): lane r < 16 ends up
+        // with the full logits of registers 0 .. 7 (slot groups g = 0, 1), lane r + 16 with those of registers 8 .. 15 (g = 2, 3) - the
+        // softmax head and the finish then run on EIGHT registers per lane instead of sixteen duplicated ones (the producers are the
+        // critical path of this form: dropping consumer MFMAs changed nothing, halving this vector work does).
+        constexpr int NG = HL ? 2 : 4;                              // slot groups of four per lane behind the chain
+        constexpr int NE = 4 * NG;
+        const int gsel = HL ? 2 * ((r >> 4) & 1) : 0;               // first slot group of this lane: g = gsel + g'
         const uint32_t lane_row = lds0 + Lds::fring + r * kRowBytes + ((h ^ swz(r)) << 4);
         // tables through buffer descriptors (scalar registers) + 32-bit lane offsets: no 64-bit pointers in vector registers
         auto uniform_rsrc = [](const void* p, int bytes) {          // every word provably wave-uniform: no waterfall loops
@@ -323,7 +331,8 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 if (!live_p) fac = 0.f;                             // pixels past the right edge of the map
             };
             char* prow = smem + Lds::pring + ((it - 1) & 1) * kPBuf + sb * 2048 + r * 64 + 8 * h;
-            auto p2_store = [&](int g) {                            // four slots of P(it-1) = e * fac, fp16
+            char* prowh = smem + Lds::pring + ((it - 1) & 1) * kPBuf + sb * 2048 + (r & 15) * 64 + 8 * h;   // HL: row of this lane's pixel
+            auto p2_store = [&](int g) {                            // four slots of P(it-1) = e * fac, fp16 (HL: g = 0, 1 of this lane's groups)
                 f16x4 ph;
                 if constexpr (PHL) {
                     f16x4 pl;
@@ -334,6 +343,16 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                                                              // product and lo from the exact product minus its own hi: v_fma_mixlo_f16)
                         ph[j] = (_Float16)x;
                         pl[j] = (_Float16)(x - (float)ph[j]);
+                    }
+                    if constexpr (HL) {
+                        // this lane's slot group gsel + g of pixel r & 15 goes to BOTH rows of that pixel (rows 16 .. 31 of the P tile repeat
+                        // rows 0 .. 15: the A operand of the consumers' lo k-step); rows r and r + 16 share the swizzle key
+                        char* pr = prowh + (((gsel + g) ^ key) * 16);
+                        *reinterpret_cast<f16x4*>(pr) = ph;
+                        *reinterpret_cast<f16x4*>(pr + 1024) = ph;
+                        *reinterpret_cast<f16x4*>(pr + kPTile) = pl;
+                        *reinterpret_cast<f16x4*>(pr + kPTile + 1024) = pl;
+                        return;
                     }
                     *reinterpret_cast<f16x4*>(prow + kPTile + ((g ^ key) * 16)) = pl;
                 } else {
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                         for (int u = 0; u < 4; ++u) kf[(grp + 1) & 1][u] = frag(tb, 2 * (grp + 1) + kOrd[u]);
                     } else {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) c3v[g] = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
+                        for (int g = 0; g < NG; ++g) c3v[g] = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * (gsel + g));
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -367,8 +386,13 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                     }
                     if constexpr (P2) {
                         if (grp == 0) p2_factor();
-                        if (grp == 1) { p2_store(0); p2_store(1); }
-                        if (grp == 2) { p2_store(2); p2_store(3); }
+                        if constexpr (HL) {
+                            if (grp == 1) p2_store(0);
+                            if (grp == 2) p2_store(1);
+                        } else {
+                            if (grp == 1) { p2_store(0); p2_store(1); }
+                            if (grp == 2) { p2_store(2); p2_store(3); }
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {                   // one MFMA, then its share of the other work
@@ -385,17 +409,18 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             } else if constexpr (P2) {
                 p2_factor();
 #pragma unroll
-                for (int g = 0; g < 4; ++g) p2_store(g);
+                for (int g = 0; g < NG; ++g) p2_store(g);
             }
             RETR_STAMP(0, 2);
             if constexpr (!CHAIN) return;
             if constexpr (HL) {
-                // columns r < 16: Q''.f_hi + Cy + Cx of pixel r; columns r >= 16: Q''.f_lo of pixel r - 16. Fold the halves: afterwards
-                // both hold the full sum (v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of
-                // its second: with the same value in both, the two results are [row0, row0, row2, row2] and [row1, row1, row3, row3])
+                // columns r < 16: Q''.f_hi + Cy + Cx of pixel r; columns r >= 16: Q''.f_lo of pixel r - 16. v_permlane16_swap exchanges the
+                // odd 16-lane rows of its first operand with the even rows of its second: swap(s[i], s[i + 8]) returns
+                // [s_i.row0, s_{i+8}.row0, s_i.row2, s_{i+8}.row2] and [s_i.row1, s_{i+8}.row1, s_i.row3, s_{i+8}.row3], whose sum is the
+                // full logit of register i in the even rows (lanes r < 16) and of register i + 8 in the odd rows (lanes r >= 16)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[i]), __float_as_uint(s[i]), false, false);
+                for (int i = 0; i < 8; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[i]), __float_as_uint(s[i + 8]), false, false);
                     s[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
                 }
             }
@@ -408,12 +433,16 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             const bool more = it + 1 < nt;
             float mloc = kNegBig;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     s[4 * g + j] = fmaf(rk_c, s[4 * g + j], c3v[g][j]);
                     if constexpr (!EXT) mloc = fmaxf(mloc, s[4 * g + j]);
                 }
+            }
+            if constexpr (HL && !EXT) {                             // the two lanes of a pixel hold different slot groups: combine them
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(mloc), __float_as_uint(mloc), false, false);
+                mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
             // Cy row of tile it+1 (staged with batch `it`): requested now, added to Cx after the exponentials
             f32x4 cyv[4];
@@ -426,14 +455,19 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             if (more) request_ext(ts, ty);
             RETR_STAMP(0, 6);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] -= mloc;
+            for (int i = 0; i < NE; ++i) s[i] -= mloc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+            for (int i = 0; i < NE; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
             if constexpr (!EXT) {
                 float sl[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) sl[i] = (s[i] + s[4 + i]) + (s[8 + i] + s[12 + i]);
-                const float sloc = ra_half_swap_sum((sl[0] + sl[1]) + (sl[2] + sl[3]));
+                for (int i = 0; i < 4; ++i) sl[i] = HL ? s[i] + s[4 + i] : (s[i] + s[4 + i]) + (s[8 + i] + s[12 + i]);
+                float sloc = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+                if constexpr (HL) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(sloc), __float_as_uint(sloc), false, false);
+                    sloc = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                }
+                sloc = ra_half_swap_sum(sloc);
                 if (h == 0) stats[(it & 1) * 128 + sb * 32 + r] = make_float2(mloc, sloc);
             }
             e = s;
