@@ -7,7 +7,7 @@ program itself after `--`, no launcher in between):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_fetch -o f --output-format csv -- \
         python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-baseline 0 --whole-detector 0 --latency-leg 0 --no-graph
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/pmc_write -o w --output-format csv -- (same command)
-    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02/pmc_traffic.json "<workload key>"
+    python3 tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r05/pmc_traffic.json "<workload key>" <mode>
 
 Units and corrections. The counters come in KiB (value * 1024 B). The microarchitecture guide states that on gfx950
 FETCH_SIZE tallies the 128-byte requests of wide coalesced streams at 64 B (so it reads half the bytes) and that WRITE_SIZE is
@@ -23,7 +23,7 @@ import os
 import sys
 
 # kernel-name fragment in the trace -> the name bench.py uses in `roofline.per_kernel`
-KERNELS = {"retr_attn_kernel": "retr_attn", "retr_stats_kernel": "retr_stats", "retr_stats2_kernel": "retr_stats", "retr_logit_stats": "retr_logit_stats", "retr_probs_kernel": "retr_probs", "retr_pv_kernel": "retr_pv",
+KERNELS = {"retr_attn_kernel": "retr_attn", "retr_stats_kernel": "retr_stats", "retr_stats_hl_kernel": "retr_stats", "retr_stats2_kernel": "retr_stats", "retr_logit_stats": "retr_logit_stats", "retr_probs_kernel": "retr_probs", "retr_pv_kernel": "retr_pv",
            "retr_finish": "retr_finish", "slot_attn_partial": "slot_attn", "slot_attn_finish": "slot_attn_finish",
            "kv_project": "kv_project", "level_fuse": "level_fuse", "mask_decode": "mask_decode", "row_ln": "row_ln",
            "slot_self_attn": "slot_self_attn"}
@@ -79,6 +79,7 @@ def main():
            "kernels": kernels}
     if len(sys.argv) > 4:
         rec["workload_key"] = sys.argv[4]
+    rec["mode"] = sys.argv[5] if len(sys.argv) > 5 else "bf16"          # head mode of the profiled step (bench.py --mode)
     os.makedirs(os.path.dirname(dst), exist_ok=True)
     with open(dst, "w") as fh:
         json.dump(rec, fh, indent=1)
