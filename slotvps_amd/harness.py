@@ -6,7 +6,7 @@ Integer / byte work on the host; inputs are the uint8 maps the detector's GPU po
 import numpy as np
 import torch
 
-from .parallel import size_host_pools
+from .parallel import host_pools
 
 
 def _append(pano_results, result, filename):
@@ -33,28 +33,32 @@ def _meta_of(entry):
     return meta
 
 
-def single_gpu_test(model, data_loader, show=False):
-    """One detector call per frame, like the reference: `data` = dict(img=[Tensor], img_meta=[...], ref_img=[Tensor])."""
+def single_gpu_test(model, data_loader, show=False, size_pools=True):
+    """One detector call per frame, like the reference: `data` = dict(img=[Tensor], img_meta=[...], ref_img=[Tensor]).
+    size_pools: host thread pools sized to the cgroup's CPU share for the duration of the loop (parallel.host_pools: why), the caller's
+    settings restored afterwards."""
+    import contextlib
     model.eval()
-    size_host_pools()                       # host pools to the cgroup's CPU share (parallel.size_host_pools: why)
     pano_results = _empty()
-    for data in data_loader:
-        filename = _meta_of(data["img_meta"])["filename"].split("/")[-1]
-        with torch.no_grad():
-            result = model(return_loss=False, rescale=not show, **data)
-        _append(pano_results, result, filename)
+    with (host_pools() if size_pools else contextlib.nullcontext()):
+        for data in data_loader:
+            filename = _meta_of(data["img_meta"])["filename"].split("/")[-1]
+            with torch.no_grad():
+                result = model(return_loss=False, rescale=not show, **data)
+            _append(pano_results, result, filename)
     return pano_results
 
 
-def clip_gpu_test(model, clips):
+def clip_gpu_test(model, clips, size_pools=True):
     """Clip-batched loop: `clips` yields (imgs [T, 3, H, W], [T metas]) of consecutive frames of one video; the
     backbone runs once per frame (the reference recomputes the reference frame at every step, :245-252)."""
+    import contextlib
     model.eval()
-    size_host_pools()
     pano_results = _empty()
-    for imgs, metas in clips:
-        for result, meta in zip(model.clip_test(imgs, metas), metas):
-            _append(pano_results, result, meta["filename"].split("/")[-1])
+    with (host_pools() if size_pools else contextlib.nullcontext()):
+        for imgs, metas in clips:
+            for result, meta in zip(model.clip_test(imgs, metas), metas):
+                _append(pano_results, result, meta["filename"].split("/")[-1])
     return pano_results
 
 

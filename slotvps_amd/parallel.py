@@ -38,18 +38,56 @@ def host_cores():
     return n
 
 
+class host_pools:
+    """Context manager: size the host thread pools (torch intra-op = OpenMP, and the BLAS pool behind numpy) to this rank's share of the
+    cores the job may use for the duration of a loop, and put the caller's settings back afterwards (an embedding application keeps its
+    own pools). Why it matters here: the per-clip host work of the detector (score filter, tracker assignment) is a handful of tiny ops,
+    but a pool sized to the 256 logical CPUs a container SEES wakes 256 spinning workers for each of them; under a 16-CPU cgroup quota
+    that exhausts the CFS budget and the whole process is throttled for the rest of the 100 ms period - measured as random 10 - 80 ms
+    stalls per clip (round 4; /sys/fs/cgroup/cpu.stat: nr_throttled). `info` says what was done."""
+
+    def __init__(self, local_rank=0, world=1, pin=None):
+        self.args = (local_rank, world, pin)
+        self.info = None
+
+    def __enter__(self):
+        self._threads = torch.get_num_threads()
+        try:
+            self._affinity = os.sched_getaffinity(0)
+        except (AttributeError, OSError):
+            self._affinity = None
+        self.info, self._blas = _size_host_pools(*self.args)
+        return self
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self._threads)
+        if self._blas is not None:
+            try:
+                self._blas.restore_original_limits()
+            except Exception:
+                pass
+        if self._affinity is not None and self.info.get("cpus") is not None:
+            try:
+                os.sched_setaffinity(0, self._affinity)
+            except OSError:
+                pass
+        return False
+
+
 _blas_limit = None
 
 
 def size_host_pools(local_rank=0, world=1, pin=None):
-    """Size the host thread pools (torch intra-op = OpenMP, and the BLAS pool behind numpy) to this rank's share of the cores the job
-    may use, and for world > 1 pin the rank to its own slice of CPUs. Why it matters here: the per-clip host work of the detector (score
-    filter, tracker assignment) is a handful of tiny ops, but a pool sized to the 256 logical CPUs a container SEES wakes 256 spinning
-    workers for each of them; under a 16-CPU cgroup quota that exhausts the CFS budget and the whole process is throttled for the
-    rest of the 100 ms period - measured as random 10 - 80 ms stalls per clip (round 4; /sys/fs/cgroup/cpu.stat: nr_throttled).
-    Returns what was done."""
+    """The same sizing for the REST OF THE PROCESS (a rank of bench.py: nothing else lives in it). Library entry points use the
+    `host_pools` context manager instead, which restores the caller's settings. Returns what was done."""
     global _blas_limit
+    info, _blas_limit = _size_host_pools(local_rank, world, pin)       # kept alive: the BLAS limit lasts as long as the object
+    return info
+
+
+def _size_host_pools(local_rank=0, world=1, pin=None):
     info = {"threads": torch.get_num_threads(), "cpus": None}
+    blas = None
     try:
         allowed = sorted(os.sched_getaffinity(0))
         n = max(1, min(len(allowed), host_cores()) // max(1, world))
@@ -60,14 +98,14 @@ def size_host_pools(local_rank=0, world=1, pin=None):
         torch.set_num_threads(max(1, min(torch.get_num_threads(), n)))
         try:
             from threadpoolctl import threadpool_limits
-            _blas_limit = threadpool_limits(limits=max(1, min(n, 16)))        # kept alive: the limit lasts as long as the object
+            blas = threadpool_limits(limits=max(1, min(n, 16)))
         except Exception:                                                      # threadpoolctl is optional
             pass
         info["threads"] = torch.get_num_threads()
         info["host_cores"] = n
     except (AttributeError, OSError) as e:
         info["error"] = f"{type(e).__name__}: {e}"[:80]
-    return info
+    return info, blas
 
 
 def dist_env():

@@ -802,7 +802,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
         with a previous map multiplies x by columns 256 .. 383 only, level 0 (cat(x, x, x), :171-176) by all three blocks."""
         conv = self.conv_trans.conv
         form = form or self._map_form()
-        key = (conv.weight._version, conv.weight.data_ptr(), form, bool(level0)) + \
+        key = (conv.weight._version, conv.weight.data_ptr(), conv.bias._version, conv.bias.data_ptr(), form, bool(level0)) + \
             (() if pre is None else tuple((t.data_ptr(), t._version) for t in pre if t is not None))
         cache = self.__dict__.setdefault("_cw_cache", {})
         ent = cache.get(key)
@@ -826,8 +826,8 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 if pre[1] is not None:
                     b = (conv.bias.detach().double() + wx_sum @ pre[1].detach().double()).float()
             ent = (w.to(torch.float16 if form == "fp16" else BF16).contiguous(), b)     # (bf16 weights in the bf16-in-fp16 form as well)
-            if len(cache) > 8:
-                cache.clear()
+            while len(cache) >= 8:                       # evict the OLDEST entry only (dict order = insertion order): the tensors of the
+                cache.pop(next(iter(cache)))             # newer entries may be baked into a live hipGraph of a clip runner
             cache[key] = ent
         return ent
 

@@ -55,3 +55,14 @@ def test_single_gpu_test_result_layout():
     assert r["all_ssegs"][1].dtype == np.uint8 and r["all_ssegs"][1].shape == (4, 6) and r["all_ssegs"][2][0, 0] == 3
     assert r["all_panos"][0][0, 0] == (301 % 256)                        # the harness casts to uint8 (tools/test_vpq.py:44-46)
     assert r["all_pano_obj_ids"][2].tolist() == [0, 3] and r["all_pano_cls_inds"][0].tolist() == [1, 2]
+
+
+def test_host_pools_restore_the_callers_settings():
+    """parallel.host_pools (used by single_gpu_test / clip_gpu_test) sizes the host thread pools for the duration of the loop only."""
+    import torch
+    from slotvps_amd import parallel
+    before = torch.get_num_threads()
+    torch.set_num_threads(max(1, before))
+    with parallel.host_pools() as hp:
+        assert hp.info is not None and hp.info["threads"] <= max(1, before)
+    assert torch.get_num_threads() == before
