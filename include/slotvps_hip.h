@@ -364,6 +364,8 @@ int svps_panoptic_clip_state_ints(void);
  * have no defined order in the reference (np.argsort's unstable default); here: descending slot id, numpy's scalar path. */
 int svps_panoptic_clip_select(const float* scores, const long long* classes, int T, int L, int nc, int num_classes, int num_stuff,
                               float threshold, long long* index, int* state, void* stream);
+/* frame_stride / (h * w) = slot rows per frame of `masks`: a frame whose K exceeds it is skipped (the caller decoded only the first rows
+ * of the score order, sees K after its wait and runs the clip again with all rows). */
 int svps_panoptic_clip(const float* masks, long long frame_stride, int T, int h, int w, int H, int W, int* state, int* pairs,
                        int pair_stride, uint8_t* cand, uint8_t* out_ids, float pixel_threshold, double fraction_threshold,
                        int small_option, int stuff_num, int rounds, int stages, void* stream);

@@ -40,6 +40,9 @@ struct Args {
     float thr;
     double frac;
     int small_option, stuff_num;
+    int rows;                  // frame_stride / (h * w): slot rows a frame of `masks` holds. A frame whose K exceeds it (the caller decoded only the
+                               // first `rows` slots of the score order) is SKIPPED by the kernels that read masks - its state is then meaningless
+                               // and the caller, who sees K > rows after its one wait, runs the clip again with all rows
 };
 
 __device__ __forceinline__ void axis_taps(int dst, int n_out, int n_in, int& i0, int& i1, float& l0, float& l1) {
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(256) void candidates_kernel(Args a) {
     const int tid = threadIdx.x, t = blockIdx.z;
     int* st = a.state + (size_t)t * ST;
     const int K = st[SVPS_PPC_K];
+    if (K > a.rows) return;                      // (uniform per workgroup; see Args::rows)
     lcount[tid] = 0;
     s_thing[tid] = tid < K ? (uint8_t)st[SVPS_PPC_THING + tid] : 0;
     __syncthreads();
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(Args a) {
     const int phase = st[SVPS_PPC_PHASE];
     if (IDS ? phase != 2 : phase >= 2) return;
     const int n = st[SVPS_PPC_N], K = st[SVPS_PPC_K];
+    if (K > a.rows) return;
     lhist[tid] = 0;
     if (tid < n) {
         const int k = st[SVPS_PPC_CUR + tid];
@@ -481,7 +486,7 @@ extern "C" int svps_panoptic_clip(const float* masks, long long frame_stride, in
         return SVPS_ERR_BAD_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Args a{masks, frame_stride, T, h, w, H, W, state, pairs, pair_stride, cand, out_ids, pixel_threshold, fraction_threshold,
-           small_option, stuff_num};
+           small_option, stuff_num, (int)(frame_stride / ((long long)h * w))};
     const dim3 grid((w + 63) / 64, (h + 3) / 4, T);
     svps_prof_mark(SVPS_KERNEL_PANOPTIC_POST, 0, stream);
     if (stages & 1) {

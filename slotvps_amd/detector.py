@@ -58,8 +58,9 @@ class SlotMasks:
     ([L, h, w] fp32 per frame, vps_temporal_slots.py:297-308) and its post-process then keeps the few slots whose class
     score passes the threshold (:685-691, computed from the [L, nc] class logits alone). Here the decode of a frame runs
     AFTER that selection, on the kept slots only, in the order the post-process wants them: K2 then writes 4 K HW bytes
-    per frame instead of 4 L HW, and nobody gathers rows out of a [L, HW] tensor. `dense()` is the reference's all-slot
-    form (same kernel, bit-identical rows)."""
+    per frame instead of 4 L HW (per-frame path), and nobody gathers rows out of a [L, HW] tensor. The clip path decides on the device
+    without waiting for the host, so it decodes the first `PostProcessPanopticInstances.clip_decode_cap` slots of every frame's score
+    order (64; all L again if a frame keeps more). `dense()` is the reference's all-slot form (same kernel, bit-identical rows)."""
 
     def __init__(self, fused, embeds, fold, hw):
         self.fused, self.embeds, self.fold, self.hw = fused, embeds, fold, hw     # [T, HW, 256], [T, L, 256]

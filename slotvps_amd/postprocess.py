@@ -214,10 +214,15 @@ class PostProcessPanopticInstances(nn.Module):
     device_decisions = True        # False: the lock-step host path below (also taken when the output is not exactly 4x the logits)
     clip_rounds = 4                # (area pass, step) pairs enqueued speculatively; unfinished frames get more (never a wrong result)
 
-    def _clip_on_device(self, scores, classes, nc, pred_masks, size, stuff_num, side):
+    # rows of every frame that are decoded (and handed to `side`) BEFORE the host knows how many slots pass the score filter: the first
+    # `clip_decode_cap` slots of the score order. A frame that keeps more (the released configs keep ~30 of 100 - 200) makes the clip run
+    # again with all L rows - never a wrong result. None: always all L rows (K2 then writes 4 L h w bytes per frame: ~1 GB per VIPER clip)
+    clip_decode_cap = 64
+
+    def _clip_on_device(self, scores, classes, nc, pred_masks, size, stuff_num, side, cap=None):
         """The whole post-process of a clip enqueued without waiting for anything: score filter + order (svps_panoptic_clip_select),
-        decode of the slots in that order (K2), candidates, mask_removal, de-duplication, small-area loop, relabel table and the id
-        maps (svps_panoptic_clip); `side(index_d)` may enqueue more work whose result comes back with the same wait. Returns the
+        decode of the first `cap` slots in that order (K2), candidates, mask_removal, de-duplication, small-area loop, relabel table and the
+        id maps (svps_panoptic_clip); `side(index_d)` may enqueue more work whose result comes back with the same wait. Returns the
         per-frame results (a list carrying `side_host`)."""
         import numpy as np
         lib = _lib.load()
@@ -226,13 +231,16 @@ class PostProcessPanopticInstances(nn.Module):
         T, L = scores.shape
         H, W = size
         h, w = H // 4, W // 4
+        if cap is None:
+            cap = L if self.clip_decode_cap is None else min(L, int(self.clip_decode_cap))
         scores, classes = scores.contiguous(), classes.contiguous()
         state = torch.zeros((T, PPC_STATE_INTS), dtype=torch.int32, device=dev)
-        index_d = torch.empty((T, L), dtype=torch.int64, device=dev)
-        with _on(scores, classes, index_d, state) as ctx:
+        index_full = torch.empty((T, L), dtype=torch.int64, device=dev)
+        with _on(scores, classes, index_full, state) as ctx:
             _lib.check(lib.svps_panoptic_clip_select(_p(scores), _p(classes), T, L, nc, self.num_classes, self.num_stuff,
-                                                     float(self.threshold), _p(index_d), _p(state), ctx.stream), "svps_panoptic_clip_select")
-        if hasattr(pred_masks, "decode_clip"):                             # every frame's slots in score order (rows past K: slot 0)
+                                                     float(self.threshold), _p(index_full), _p(state), ctx.stream), "svps_panoptic_clip_select")
+        index_d = index_full[:, :cap].contiguous() if cap < L else index_full
+        if hasattr(pred_masks, "decode_clip"):                             # every frame's first `cap` slots in score order (rows past K: slot 0)
             m_clip = pred_masks.decode_clip(index_d)
         else:
             m_clip = torch.gather(pred_masks.float(), 1, index_d[:, :, None, None].expand(-1, -1, *pred_masks.shape[2:]))
@@ -243,7 +251,7 @@ class PostProcessPanopticInstances(nn.Module):
 
         def enqueue(rounds, stages):
             with _on(m_clip, state, pairs, cand, ids) as ctx:
-                _lib.check(lib.svps_panoptic_clip(_p(m_clip), L * h * w, T, h, w, H, W, _p(state), _p(pairs), L * L, _p(cand),
+                _lib.check(lib.svps_panoptic_clip(_p(m_clip), cap * h * w, T, h, w, H, W, _p(state), _p(pairs), L * L, _p(cand),
                                                   _p(ids), float(self.pixel_threshold), float(self.fraction_threshold),
                                                   _SMALL_OPTION[self.filter_small_option], int(stuff_num), rounds, stages, ctx.stream),
                            "svps_panoptic_clip")
@@ -252,13 +260,16 @@ class PostProcessPanopticInstances(nn.Module):
         st = state.cpu().numpy()                                                                     # THE wait of the clip
         if (st[:, PPC_K] == 0).any():
             raise ValueError("no slot passes the score threshold (the reference's mask_removal fails here too, :652)")
+        if (st[:, PPC_K] > cap).any():
+            # a frame keeps more slots than were decoded: the kernels skipped it (svps_panoptic_clip: Args::rows); everything again with all rows
+            return self._clip_on_device(scores, classes, nc, pred_masks, size, stuff_num, side, cap=L)
         while (st[:, PPC_PHASE] != 2).any():                                # a frame with more small-area rounds than were enqueued
             enqueue(2, 6)
             st = state.cpu().numpy()
         side_h = side_d.cpu().numpy() if side_d is not None else None
         curs = [st[t, PPC_CUR:PPC_CUR + int(st[t, PPC_N])].tolist() for t in range(T)]
         flat = np.concatenate([np.asarray(c, dtype=np.int64) + t * L for t, c in enumerate(curs)]) if any(curs) else np.zeros(0, np.int64)
-        sel_all = index_d.reshape(-1)[torch.from_numpy(flat).to(dev)]          # the surviving slot ids of all frames: one upload, one gather
+        sel_all = index_full.reshape(-1)[torch.from_numpy(flat).to(dev)]       # the surviving slot ids of all frames: one upload, one gather
         offs = np.cumsum([0] + [len(c) for c in curs])
         out = []
         for t in range(T):
@@ -271,7 +282,7 @@ class PostProcessPanopticInstances(nn.Module):
                                        probs_host=sc[cur].copy(), labels_host=cl[cur].copy(), area=st[t, PPC_AREA:PPC_AREA + len(cur)].tolist(),
                                        size=size, rounds=int(st[t, PPC_ROUNDS]), _m_sorted=m_clip[t, :K], _cur=cur, _thing=thing,
                                        _kept=st[t, PPC_KEPT:PPC_KEPT + K].astype(np.uint8), _cand=cand[t], _ids=ids[t],
-                                       _stuff_num=int(stuff_num), _sorted_pos=cur, _row_stride=L))
+                                       _stuff_num=int(stuff_num), _sorted_pos=cur, _row_stride=cap))
         out = _ClipResults(out)
         out.side_host = side_h
         return out

@@ -251,3 +251,27 @@ def test_clip_postprocess_many_kept_slots(cuda):
     cases = [synth.make_post_case(300 + t, 200, 17, 30, 20, nk) for t, nk in enumerate((150, 199, 121))]
     res = _clip_vs_frames(cuda, cases, (68, 120))
     assert max(len(r._thing) for r in res) > 120
+
+
+@pytest.mark.parametrize("overflow_frame", [0, 2])
+def test_clip_postprocess_decode_cap(cuda, overflow_frame):
+    """The clip path decodes the first `clip_decode_cap` slots of every frame's score order before the host knows K. A frame that keeps
+    more (here: the first / the LAST frame of the clip, whose missing rows would lie past the end of the decoded buffer) is skipped by the
+    kernels and the clip runs again with all rows: same results as without a cap; frames within the cap never take the second pass."""
+    from slotvps_amd.postprocess import PostProcessPanopticInstances
+    nk = [9, 9, 9]
+    nk[overflow_frame] = 30
+    cases = [synth.make_post_case(400 + t, 100, 12, 24, 20, k) for t, k in enumerate(nk)]
+    saved = PostProcessPanopticInstances.clip_decode_cap
+    try:
+        PostProcessPanopticInstances.clip_decode_cap = 16          # 30 kept > 16: the rerun path
+        res = _clip_vs_frames(cuda, cases, (48, 96))
+        assert res[0]._row_stride == 100
+        PostProcessPanopticInstances.clip_decode_cap = 32          # all frames within the cap: one pass on 32 rows
+        res = _clip_vs_frames(cuda, cases, (48, 96))
+        assert res[0]._row_stride == 32
+        PostProcessPanopticInstances.clip_decode_cap = None        # no cap: all L rows
+        res = _clip_vs_frames(cuda, cases, (48, 96))
+        assert res[0]._row_stride == 100
+    finally:
+        PostProcessPanopticInstances.clip_decode_cap = saved
