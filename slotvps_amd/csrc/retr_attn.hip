@@ -1536,7 +1536,16 @@ int launch_retr_hl(const void* qh, const void* ql, const float* cy, const float*
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
     if (L <= 128) {
         auto kern = svps::retr_attn_kernel<0, false, true, true>;
-        static SvpsLdsAttr attr;
+        int slot = 0;
+#ifdef SVPS_RETR_ABLATE
+        // diagnostic build only (tools/ablate.sh builds it as a separate library): timing-only variants that return wrong results
+        static const int ablate = [] { const char* a = getenv("SVPS_RETR_ABLATE"); return a ? atoi(a) : 0; }();
+        if (ablate == 1) { kern = svps::retr_attn_kernel<1, false, true, true>; slot = 1; }
+        else if (ablate == 2) { kern = svps::retr_attn_kernel<2, false, true, true>; slot = 2; }
+        else if (ablate == 4) { kern = svps::retr_attn_kernel<4, false, true, true>; slot = 3; }
+#endif
+        static SvpsLdsAttr attrs[4];
+        SvpsLdsAttr& attr = attrs[slot];
         if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
         hipLaunchKernelGGL(kern, dim3(p.chunks, T), dim3(512), Lds::total, stream, qh_, ql_, cy, cx, c3, fh_, a_, partial, L, HW, H, W,
                            p.tiles_per_chunk, 128, L, 0, (const float2*)nullptr, 1, fl_);
