@@ -28,6 +28,8 @@
 // every lane requests the 4 taps x 16 channels of g it needs for ITS accumulator entries (pixel = lane & 31) before the MFMAs and
 // blends them in fp32 behind them (torch's upsample_bilinear2d expression); bias, split, out tiles through LDS so that HBM sees whole
 // 512-byte pixel rows of both planes (and of the fp32 copy).
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -111,26 +113,30 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     const int ch = tid >> 2, pg = tid & 3;
     const float* src = cur + ((size_t)t * 128 + ch) * HW;
     const bool aligned = (HW & 3) == 0;
-    f32x4 c0, c1;
-    auto fetch = [&](int tile) {
+    // TWO register sets (round 5): the incoming map (and the rows of g) are requested TWO tiles ahead - HBM latency under load is longer
+    // than one tile period of this lock-step workgroup (one tile ahead left every commit waiting for its loads)
+    f32x4 c0[2], c1[2];
+    auto fetch = [&](int tile, auto par) {
+        constexpr int P = decltype(par)::value;
         const int pp = px_begin + tile * kTilePx + 8 * pg;
         if (pp + 8 <= HW && aligned) {
-            c0 = *reinterpret_cast<const f32x4*>(src + pp);
-            c1 = *reinterpret_cast<const f32x4*>(src + pp + 4);
+            c0[P] = *reinterpret_cast<const f32x4*>(src + pp);
+            c1[P] = *reinterpret_cast<const f32x4*>(src + pp + 4);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                c0[j] = src[pp + j < HW ? pp + j : HW - 1];
-                c1[j] = src[pp + 4 + j < HW ? pp + 4 + j : HW - 1];
+                c0[P][j] = src[pp + j < HW ? pp + j : HW - 1];
+                c1[P][j] = src[pp + 4 + j < HW ? pp + 4 + j : HW - 1];
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](auto par) {
+        constexpr int P = decltype(par)::value;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = 8 * pg + j;
             _Float16 vh, vl;
-            hl_split(j < 4 ? c0[j] : c1[j - 4], vh, vl);
+            hl_split(j < 4 ? c0[P][j] : c1[P][j - 4], vh, vl);
             const int o = hl_a_off(row, ch >> 3) + (ch & 7) * 2;
             *reinterpret_cast<_Float16*>(ah + o) = vh;
             *reinterpret_cast<_Float16*>(al + o) = vl;
@@ -164,8 +170,9 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     };
 
     // STAGED: wave w stages items w, w + 8, .. (< 36) of the tile's [2 rows][18 columns] of g: one 1-KiB row per wave instruction
-    f32x4 gt[5];
-    auto fetch_g = [&](int tile) {
+    f32x4 gt[2][5];
+    auto fetch_g = [&](int tile, auto par) {
+        constexpr int P = decltype(par)::value;
         const int px0 = px_begin + tile * kTilePx;         // first pixel of the tile: x0 % 32 == 0, one output row
         const int y = px0 / W, x0 = px0 - y * W;
         const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
@@ -178,25 +185,45 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
                 const int row = item / Lds::kGCols;
                 int col = c_lo + (item - row * Lds::kGCols);
                 col = col < Wp ? col : Wp - 1;
-                gt[i] = *reinterpret_cast<const f32x4*>(gprev + ((size_t)t * Hp * Wp + (size_t)(row ? y1 : y0) * Wp + col) * kD + 4 * lane);
+                gt[P][i] = *reinterpret_cast<const f32x4*>(gprev + ((size_t)t * Hp * Wp + (size_t)(row ? y1 : y0) * Wp + col) * kD + 4 * lane);
             }
         }
     };
-    auto commit_g = [&]() {
+    auto commit_g = [&](auto par) {
+        constexpr int P = decltype(par)::value;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int item = w + 8 * i;
-            if (item < 2 * Lds::kGCols) *reinterpret_cast<f32x4*>(smem + Lds::gtile + item * Lds::kGRow + 16 * lane) = gt[i];
+            if (item < 2 * Lds::kGCols) *reinterpret_cast<f32x4*>(smem + Lds::gtile + item * Lds::kGRow + 16 * lane) = gt[P][i];
         }
     };
-    fetch(0);
-    commit();
-    if constexpr (STAGED) { fetch_g(0); commit_g(); }
-    for (int it = 0; it < nt; ++it) {
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    fetch(0, I0{});
+    if constexpr (STAGED) fetch_g(0, I0{});
+    if (nt > 1) {
+        fetch(1, I1{});
+        if constexpr (STAGED) fetch_g(1, I1{});
+    }
+    commit(I0{});
+    if constexpr (STAGED) commit_g(I0{});
+    // One tile. Invariant at the top: LDS holds the operand tile (and the rows of g) of tile `it`; register set P ^ 1 holds tile it + 1
+    // (requested one whole iteration ago); set P is free and takes tile it + 2.
+    auto body = [&](int it, auto par) {
+        constexpr int P = decltype(par)::value;
+        using IP = std::integral_constant<int, P>;
+        using IQ = std::integral_constant<int, P ^ 1>;
         __syncthreads();                                   // operand tile `it` complete; out tiles of it-1 have been read
-        // ---- this lane's taps of g (its accumulator entries: pixel r, channels 32 w + 8 g + 4 h + j), requested before the MFMAs
+        if (it + 2 < nt) {
+            fetch(it + 2, IP{});
+            if constexpr (STAGED) fetch_g(it + 2, IP{});
+        }
+        // ---- per-lane taps of g (non-staged form: this lane's accumulator entries - pixel r, channels 32 w + 8 g + 4 h + j - requested
+        // before the MFMAs)
         f32x4 tp[4][4];                                    // [tap][g]
         float h1 = 0.f, w1 = 0.f;
+        const char* a00 = nullptr;
+        const char* a01 = nullptr;
         if constexpr (TAPS && STAGED) {
             const int px0 = px_begin + it * kTilePx;
             const int y = px0 / W, x = px0 - y * W + r;
@@ -207,15 +234,8 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             w1 = sx - (float)xs0;
             const int c_lo = (px0 - y * W) / 2 - 1 > 0 ? (px0 - y * W) / 2 - 1 : 0;
             const char* g0 = smem + Lds::gtile + (32 * w + 4 * h) * 4;
-            const char* a00 = g0 + (xs0 - c_lo) * Lds::kGRow, * a01 = g0 + (xs1 - c_lo) * Lds::kGRow;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                tp[0][g] = *reinterpret_cast<const f32x4*>(a00 + 32 * g);
-                tp[1][g] = *reinterpret_cast<const f32x4*>(a01 + 32 * g);
-                tp[2][g] = *reinterpret_cast<const f32x4*>(a00 + Lds::kGCols * Lds::kGRow + 32 * g);
-                tp[3][g] = *reinterpret_cast<const f32x4*>(a01 + Lds::kGCols * Lds::kGRow + 32 * g);
-            }
-            if (it + 1 < nt) fetch_g(it + 1);              // the next tile's rows of g fly under the MFMAs
+            a00 = g0 + (xs0 - c_lo) * Lds::kGRow;
+            a01 = g0 + (xs1 - c_lo) * Lds::kGRow;          // (the taps themselves are read from LDS group by group behind the MFMAs)
         } else if constexpr (TAPS) {
             int pp = px_begin + it * kTilePx + r;
             pp = pp < HW ? pp : HW - 1;
@@ -239,7 +259,6 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
                 tp[3][g] = *reinterpret_cast<const f32x4*>(t11 + 8 * g);
             }
         }
-        if (it + 1 < nt) fetch(it + 1);                    // the incoming map of the next tile flies under the MFMAs
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -258,6 +277,12 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ch0 = 32 * w + 8 * g + 4 * h;
+            if constexpr (TAPS && STAGED) {
+                tp[0][g] = *reinterpret_cast<const f32x4*>(a00 + 32 * g);
+                tp[1][g] = *reinterpret_cast<const f32x4*>(a01 + 32 * g);
+                tp[2][g] = *reinterpret_cast<const f32x4*>(a00 + Lds::kGCols * Lds::kGRow + 32 * g);
+                tp[3][g] = *reinterpret_cast<const f32x4*>(a01 + Lds::kGCols * Lds::kGRow + 32 * g);
+            }
             f16x4 oh, ol;
             f32x4 of;
 #pragma unroll
@@ -283,10 +308,14 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
         }
         __syncthreads();                                   // out tiles complete; every wave is done reading operand tile `it` (and its taps)
         if (it + 1 < nt) {
-            commit();                                      // operand tile it+1 (its loads were issued before the MFMAs)
-            if constexpr (STAGED) commit_g();
+            commit(IQ{});                                  // operand tile it + 1: its loads were issued a whole iteration ago
+            if constexpr (STAGED) commit_g(IQ{});
         }
         store_out(it);
+    };
+    for (int it = 0; it < nt; it += 2) {
+        body(it, I0{});
+        if (it + 1 < nt) body(it + 1, I1{});
     }
 }
 
