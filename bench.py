@@ -5,27 +5,33 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W          (the driver's form: this process is one rank)
 
-One "step" = one pass of the hot path over one batch of synthetic clips per rank: `--clips-per-launch`
-(default 32) independent T=5 clips of 1024x2048 stacked along the frame axis -> four levels of 128-channel
-FPN feature maps (32x64 ... 256x512, resident in HBM) -> the 7-stage multi-scale slot head (K4, K3, K1
-once per level / stage for all frames of the batch; temporal slot attention stays inside each clip) ->
-slot->mask decode of all frames (K2). Weights: the R50-FPN Slot-VPS head architecture with seeded synthetic values
-(no checkpoints exist, README.md:25 of the reference). Clips are independent, so ranks share nothing
-(weak scaling); after every step the results of its clips (uint8 slot-argmax maps + class logits of every frame) are
-gathered to rank 0 over RCCL on a side stream, overlapped with the next step, inside the timed region.
+One "step" = one pass of the hot path over one batch of synthetic clips per rank: `--clips-per-launch` (default 32) independent T = 5
+clips of 1024x2048 stacked along the frame axis -> four levels of 128-channel FPN feature maps (32x64 ... 256x512, resident in HBM) ->
+the 7-stage multi-scale slot head (level fusion, LayerNorm statistics, slot <-> pixel retriever once per level / stage for all frames of
+the batch; temporal slot attention stays inside each clip) -> slot -> mask decode of all frames. Weights: the R50-FPN Slot-VPS head
+architecture with seeded synthetic values (no checkpoints exist, README.md:25 of the reference). Clips are independent, so ranks share
+nothing (weak scaling); after every step the results of its clips (uint8 slot-argmax maps + class logits of every frame) are gathered to
+rank 0 over RCCL on a side stream, overlapped with the next step, inside the timed region.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions):
-  value            frames/s, whole job            = n_gpus * steps * T / max-over-ranks wall time
-  roofline         the DOMINANT kernel of the step by device time (HIP events recorded on the launch stream around every
-                   launch of the library, in a second, eager pass over the same steps): its algorithmic bytes against the
-                   8 TB/s HBM3E peak and its algorithmic matrix flops against the 2.5 PFLOP/s dense bf16 peak; `bound` is the
-                   larger of the two fractions. `per_kernel` carries the same for every kernel, `retriever_pair` for
-                   K3' + K1' together (accounting: SlotClipRunner.algorithmic_per_step)
-  cpu_baseline     the PyTorch-CPU restatement of the same head + decode (oracle/torch_cpu_head.py, pinned through the
-                   NumPy oracle against the reference's own modules) on the host cores: T = 5 clips, fp32, all cores
-                   (median) and 8 threads, bounded sample
-  whole_detector   informational (N=1 only, outside the timed region, never part of `value`): one clip through the whole
-                   detector - PyTorch-ROCm ResNet-50 + FPN + semantic tower, this path, GPU post-process, tracker
+FROZEN definition of `value` (round 5): head mode `fp16x2` - the fastest mode whose results meet the north star's tolerance against the
+reference's own outputs at this size (mask logits 1e-4, slot argmax identical wherever decidable) -, input = the reference head's own
+tensors ([T, 128, Hi, Wi] fp32 behind conv_trans), fp32 mask logits of all slots written. Round 4's headline (mode bf16, tower rows) is
+`config.value_prev_definition`.
+
+Prints ONE JSON line on rank 0:
+  value            frames/s, whole job            = n_gpus * steps * T * clips per step / max-over-ranks wall time
+  config           the workload + EVERY leg as a flat scalar (the driver's record keeps scalars): mode_<m>_fps for the modes fp16x2 / bf16 /
+                   fp16 / fp32, mode_<m>_mask_logit_err_vs_ref / _argmax_equal_pct / _meets_contract = the whole hot path of every mode
+                   free-running against the REFERENCE's own outputs at 1024x2048 T = 5 (tests/golden/head_full.npz, measured by this run:
+                   tools/fullsize_parity.py), fastest_mode_meeting_contract, k_<kernel>_{ms_per_step, hbm_frac, mfma_frac, mfma_frac_executed}
+  roofline         the DOMINANT kernel of the step by device time (HIP events recorded on the launch stream around every launch of the
+                   library, in a second, eager pass over the same steps): its algorithmic bytes against the 8 TB/s HBM3E peak and its
+                   algorithmic matrix flops against the 2.5 PFLOP/s dense peak; `bound` is the larger of the two fractions; `per_kernel`
+                   carries the same for every kernel (accounting: SlotClipRunner.algorithmic_per_step); `traffic`: PMC bytes per launch from
+                   the stored profile of the same workload and mode (profiles/rNN/pmc_traffic.json)
+  cpu_baseline     the PyTorch-CPU restatement of the same head + decode (oracle/torch_cpu_head.py, pinned through the NumPy oracle against
+                   the reference's own modules) on the host cores: T = 5 clips, fp32, all cores (median) and 8 threads, bounded sample
+  modes / parity / other_configs / whole_detector    the same legs in full (informational, N = 1 only, outside the timed region)
 """
 import argparse
 import json
