@@ -250,3 +250,17 @@ def make_feat_bn(seed, D=256):
     bn = np.stack([rng.uniform(0.5, 1.5, D), 0.1 * rng.standard_normal(D), 0.2 * rng.standard_normal(D),
                    rng.uniform(0.5, 2.0, D)]).astype(np.float32)
     return bn, np.array([0.1, 0.03, 0.2, 1.7], dtype=np.float32)
+
+
+FULL_SIZE_MASK_GAIN = 400.0        # the decode's fg_bn keeps the synthetic mask logits within +-0.33: scaled so that the post-process sees decisive masks
+
+
+def full_size_class_bias(L, nc):
+    """[L, nc] bias added to the last stage's class logits in the full-size integer-target test: every third slot becomes a confident
+    segment of class (slot % (nc - 1)) - stuff and things, duplicated stuff classes included -, every other slot a confident "no object"."""
+    b = np.zeros((L, nc), dtype=np.float32)
+    b[:, nc - 1] = 12.0
+    for l in range(0, L, 3):
+        b[l, nc - 1] = 0.0
+        b[l, l % (nc - 1)] = 12.0
+    return b

@@ -17,7 +17,13 @@ the fp32 mask logits [T, L, H/sy, W/sx]; strided samples of the fused maps (fine
 and `floor`: the distance of the reference's fp32 run from the SAME modules run in float64 on the same inputs (per-stage embeddings,
 mask logits, fraction of pixels with the same argmax) - the reference's own reproducibility at this size.
 
-Runs only here (needs /root/reference); ~3 minutes, ~25 GB. Usage: python tests/golden/make_golden_full.py
+Integer target at full size (case T5_1024x2048_L100, frames 0 and T - 1): the REFERENCE's own PostProcessPanopticInstances
+(vps_temporal_slots.py:528-807, imported as in make_golden_post.py) on the reference head's last-stage class logits (+ a fixed bias table
+that makes every third slot a confident segment: synth.full_size_class_bias) and its full-resolution-input mask logits (x synth.FULL_SIZE_MASK_GAIN),
+output size 1024 x 2048, followed by the relabel of simple_test :411-435 (oracle/postprocess_oracle.panoptic_relabel, itself pinned by
+tests/golden/simple_test.npz): the uint8 panoptic id map of the frame, the kept slots and their labels.
+
+Runs only here (needs /root/reference); ~5 minutes, ~25 GB. Usage: python tests/golden/make_golden_full.py
 """
 import os
 import sys
@@ -87,6 +93,16 @@ def run(dmh, pos_mod, NestedTensor, case, dt):
     return E, C, torch.stack(masks), fused
 
 
+def reference_postprocess():
+    import make_golden_post as mgp
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    vts, Instances = mgp.load_reference()
+    pp = vts.PostProcessPanopticInstances(is_thing_map={i: i > 10 for i in range(20)}, threshold=0.85, fraction_threshold=0.03,
+                                          pixel_threshold=0.4, apply_mask_removal=True, apply_mask_removal_only_ins=True,
+                                          use_mask_low_constant=False)
+    return pp, Instances
+
+
 def main():
     torch.set_grad_enabled(False)
     dmh, pe, NestedTensor = mg.load_reference("/root/reference")
@@ -111,6 +127,25 @@ def main():
         f0 = fused[0][0][0]
         out[f"{tag}_fused0_sample"] = f0[:, ::FUSED0_STRIDE, ::FUSED0_STRIDE].permute(1, 2, 0).contiguous().numpy().astype(np.float32)
         out[f"{tag}_fused3_absmax"] = np.float32(f3.abs().max().item())
+        if tag == "T5_1024x2048_L100":
+            # ---- the integer target: the reference's post-process + relabel on its own head outputs, frames 0 and T - 1
+            from oracle import postprocess_oracle as po
+            pp, Instances = reference_postprocess()
+            bias = torch.from_numpy(synth.full_size_class_bias(L, nc))
+            for t in (0, T - 1):
+                tp = time.time()
+                inst = Instances((1, 1))
+                inst.pred_logits = C[t, 6] + bias
+                inst.pred_masks = (synth.FULL_SIZE_MASK_GAIN * M[t]).contiguous()
+                inst.slot_index = torch.arange(L)
+                res = pp(inst, [(H, W)], id=0)
+                ids, cls_inds, _ = po.panoptic_relabel(res.masks.numpy(), res.labels.numpy())
+                out[f"{tag}_pan_ids_{t}"] = np.asarray(ids).astype(np.uint8)
+                out[f"{tag}_pan_slot_index_{t}"] = res.slot_index.numpy().astype(np.int64)
+                out[f"{tag}_pan_labels_{t}"] = res.labels.numpy().astype(np.int64)
+                print(f"  frame {t}: reference post-process at {H}x{W}: {len(res.labels)} segments kept, {len(np.unique(ids))} ids in the map, "
+                      f"{time.time() - tp:.0f} s", flush=True)
+                del res, inst
         t1 = time.time()
         am32 = srt.indices[:, 0].clone()
         del fused, srt

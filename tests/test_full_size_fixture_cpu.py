@@ -23,6 +23,11 @@ def test_fixture_records_the_reference_floor():
         assert z[f"{tag}_embeds"].shape == (T, 7, L, 256) and z[f"{tag}_logits"].shape == (T, 7, L, nc)
         assert z[f"{tag}_argmax"].shape == (T, (H // 4) * (W // 4)) and z[f"{tag}_argmax"].max() < L
         assert z[f"{tag}_margin"].dtype == np.float16 and (z[f"{tag}_margin"] >= 0).all()
+    # the integer target: panoptic id maps of the reference's own post-process at 1024 x 2048 (frames 0 and T - 1 of the T5 case)
+    for t in (0, 4):
+        ids = z[f"T5_1024x2048_L100_pan_ids_{t}"]
+        assert ids.shape == (1024, 2048) and ids.dtype == np.uint8 and len(np.unique(ids)) >= 10
+        assert len(z[f"T5_1024x2048_L100_pan_labels_{t}"]) == len(z[f"T5_1024x2048_L100_pan_slot_index_{t}"]) >= 10
 
 
 @pytest.mark.parametrize("tag", list(fsp.CASES))

@@ -81,3 +81,22 @@ def test_full_size_clip_against_the_reference(cuda, tag, mode):
     if mode in ("fp16x2", "fp32"):
         # decode alone (the reference's own last-stage embeddings on this mode's finest map): fp32 summation order
         assert row["mask_err_tf"] <= 2e-6
+
+
+@pytest.mark.parametrize("mode,bound", [("fp16x2", 0.9995), ("fp32", 0.9995), ("fp16", 0.97), ("bf16", 0.85)])
+def test_full_size_panoptic_ids_against_the_reference(cuda, mode, bound):
+    """The INTEGER target at BASELINE's size: free-running head -> decode (K2) -> post-process on the device (K6) -> relabel against the
+    panoptic id maps the REFERENCE's own PostProcessPanopticInstances (vps_temporal_slots.py:528-807) + the relabel of simple_test
+    (:411-435) produced from the reference head's own outputs at 1024 x 2048 (frames 0 and T - 1 of the T5 case; 25 segments: stuff with
+    duplicated classes and things). The modes that meet the float tolerance must keep the same slots with the same labels and agree on
+    (almost) every pixel - a pixel can differ only where two scaled mask logits lie within the modes' 1e-5-class error of each other;
+    the 16-bit modes are held to their measured agreement."""
+    case = _case("T5_1024x2048_L100")
+    rows = fsp.panoptic_rows(cuda, case, mode)
+    assert len(rows) == 2
+    for r in rows:
+        print(f"\n[{mode}] frame {r['frame']}: panoptic ids equal on {100 * r['ids_equal']:.4f} % of the 1024 x 2048 pixels; kept slots equal "
+              f"{r['slots_equal']}, labels equal {r['labels_equal']} ({r['segments']} segments)")
+        assert r["ids_equal"] >= bound, r
+        if mode in ("fp16x2", "fp32"):
+            assert r["slots_equal"] and r["labels_equal"], r

@@ -138,6 +138,46 @@ def run_mode(dev, case, mode, teacher_forced=True):
     return row
 
 
+POST_CFG = dict(is_thing_map={i: i > 10 for i in range(20)}, threshold=0.85, fraction_threshold=0.03, pixel_threshold=0.4,
+                apply_mask_removal=True, apply_mask_removal_only_ins=True, use_mask_low_constant=False)
+
+
+def panoptic_rows(dev, case, mode):
+    """The INTEGER target at full size: free-running head in `mode` -> decode -> panoptic post-process (K6) -> relabel, against the id maps
+    the REFERENCE's own PostProcessPanopticInstances + the relabel of simple_test produced from the reference head's outputs at
+    1024 x 2048 (fixture keys pan_ids_<t>: frames 0 and T - 1; class bias / mask gain: synth.full_size_class_bias, FULL_SIZE_MASK_GAIN).
+    Returns per frame: fraction of pixels with the reference's panoptic id, kept slots equal, labels equal."""
+    import torch
+    from slotvps_amd import ops
+    from slotvps_amd.slot_head import generate_final_outputs
+    from slotvps_amd.postprocess import PostProcessPanopticInstances
+    T, L, H, W, sizes, ref = case["T"], case["L"], case["H"], case["W"], case["sizes"], case["ref"]
+    h3, w3 = sizes[3]
+    head = build_head(dev, case, mode)
+    feat_bn, fg_bn = _bns(dev, case)
+    bias = torch.from_numpy(synth.full_size_class_bias(L, case["nc"])).to(dev)
+    rows = []
+    with torch.no_grad():
+        tf = [torch.from_numpy(f).to(dev) for f in case["feats"]]
+        pos_tabs = [ops.pos_embed_sine_tables(h, w, 256, dev) for (h, w) in sizes]
+        logits, embeds, fused = head.forward_clip(tf, torch.from_numpy(case["slots"]).to(dev), pos_tabs)
+        masks = generate_final_outputs(fused[3], embeds[6].contiguous(), feat_bn, fg_bn)
+        pp = PostProcessPanopticInstances(**POST_CFG)
+        for t in sorted(int(k.split("_")[-1]) for k in ref if k.startswith("pan_ids_")):
+            res = pp.forward_tensors(logits[6, t] + bias, (synth.FULL_SIZE_MASK_GAIN * masks[t]).view(L, h3, w3).contiguous(), (H, W))
+            ids, cls_inds, _ = pp.panoptic_ids(res)
+            torch.cuda.synchronize()
+            ids = ids.cpu().numpy().reshape(H, W).astype(np.int64)
+            want = ref[f"pan_ids_{t}"].astype(np.int64)
+            rows.append(dict(mode=mode, frame=t, ids_equal=float((ids == want).mean()),
+                             slots_equal=bool(np.array_equal(res.slot_index.cpu().numpy(), ref[f"pan_slot_index_{t}"])),
+                             labels_equal=bool(np.array_equal(res.labels.cpu().numpy(), ref[f"pan_labels_{t}"])),
+                             segments=int(len(ref[f"pan_labels_{t}"]))))
+    del head, fused, masks, tf
+    torch.cuda.empty_cache()
+    return rows
+
+
 def fmt(row):
     e = lambda xs: " ".join(f"{x:.1e}" for x in xs)
     s = (f"[{row['case']} / {row['mode']}] mask logits {row['mask_err']:.2e} free-running ({row['mask_err_tf']:.2e} with the reference's last embeddings; "
