@@ -748,6 +748,12 @@ def main():
                     cfgd[f"mode_{mode}_argmax_equal_pct"] = round(100 * row["argmax_equal"], 4)
                     cfgd[f"mode_{mode}_argmax_equal_where_decidable_pct"] = round(100 * row["argmax_equal_decidable"], 4)
                     cfgd[f"mode_{mode}_meets_contract"] = bool(row["meets"])
+                    # the INTEGER target: head -> decode -> post-process (K6) -> relabel against the id maps of the reference's own
+                    # post-process at 1024 x 2048 (frames 0 and T - 1)
+                    prow = fsp.panoptic_rows(dev, case, mode)
+                    line["parity"].setdefault("panoptic_rows", {})[mode] = prow
+                    cfgd[f"mode_{mode}_panoptic_ids_equal_pct"] = round(100 * min(r["ids_equal"] for r in prow), 4)
+                    cfgd[f"mode_{mode}_panoptic_segments_equal"] = bool(all(r["slots_equal"] and r["labels_equal"] for r in prow))
                 cfgd["ref_own_fp32_vs_float64_mask_logit_err"] = float(f"{line['parity']['rows'][a.mode]['ref_floor_mask']:.3g}") if a.mode in line["parity"]["rows"] else None
                 cfgd["headline_mode_meets_contract"] = bool(line["parity"]["rows"].get(a.mode, {}).get("meets", False))
                 ok_modes = [m for m in line["parity"]["rows"] if line["parity"]["rows"][m]["meets"] and cfgd.get(f"mode_{m}_fps") is not None]
