@@ -21,6 +21,10 @@
 // O = 128: wave w owns channel block w & 3 for pixel blocks 2(w>>2), 2(w>>2)+1. Per chunk and wave 48 (24) MFMA, then the
 // gather of chunk i+1 (16 x 16-byte loads per thread), its blend + hi/lo split + LDS write; one workgroup barrier per chunk;
 // weights stream from L2 in fragment order (1 KiB per wave instruction).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
@@ -251,6 +255,266 @@ __global__ __launch_bounds__(512) void deform_conv_fused_kernel(const float* __r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K7'' (round 5) - the same function with the input staged through LDS: the form above gathers 4 corners x 9 taps = 36 rows of 4 C
+// bytes per output pixel from L2 (24 GB for the 256 -> 128 layer of the semantic tower at 256 x 512, T = 5: L2-bandwidth-bound,
+// 2.4 ms). Here a workgroup owns an 8 x 16 block of output pixels; per 32-channel chunk the (8 + 7) x (16 + 7) input pixels its samples
+// can touch when |offset| <= 2 (one tap to each side, two pixels of offset, the bilinear neighbour) are loaded ONCE into LDS
+// (requested under the previous chunk's last taps into six registers) and the nine taps of the chunk gather their corners from there:
+// 1.6 instead of 36 pixel rows per output pixel and chunk from L2. A SAMPLE with a corner outside the staged region (a larger offset)
+// is gathered from global memory as before - decided per sample in the coordinate pass, so the result never depends on it. Loop order:
+// channel chunk outer, tap inner (the accumulation order differs from the form above by fp32 rounding only); 3 x 3, stride 1, pad 1,
+// dilation 1 (the layers of the semantic tower), C % 32 == 0.
+struct DhLds {
+    static constexpr int TH = 8, TW = 16, PX = 128, CH = 32, KS = 2, GR = 8;
+    static constexpr int ROW = CH * 2 + 16;                       // bytes per pixel row of a sample tile (padded)
+    static constexpr int D = 2;                                   // |offset| covered by the staged region
+    static constexpr int RH = TH + 2 + 2 * D + 1, RW = TW + 2 + 2 * D + 1;   // 15 x 23 input pixels
+    static constexpr int RS = CH * 4 + 16;                        // bytes per staged pixel (fp32, padded)
+    static constexpr int RITEMS = RH * RW * 8;                    // 16-byte pieces of a staged region
+    static constexpr int RPT = (RITEMS + 511) / 512;              // ... per thread: 6
+    static constexpr int coords = 0;                              // [9][PX] x {int idx[4]; float w[4]}
+    static constexpr int bufs = 9 * PX * 32;                      // [2][hi | lo][PX][ROW]
+    static constexpr int buf_bytes = 2 * PX * ROW;
+    static constexpr int region = bufs + 2 * buf_bytes;
+    static constexpr int total = region + RH * RW * RS;
+};
+static_assert(DhLds::total <= 160 * 1024, "LDS budget");
+
+template <int OB>                          // output channel blocks: 8 (O = 256) or 4 (O = 128: waves 0 .. 3 multiply, 4 .. 7 only gather)
+__global__ __launch_bounds__(512) void deform_conv_halo_kernel(const float* __restrict__ x,        // [N, H, W, C]
+                                                               const float* __restrict__ offset,   // [N, 18, H, W]
+                                                               const __bf16* __restrict__ wpack,   // [OB, KS, 2, 64, 8]
+                                                               float* __restrict__ out,            // [N, H*W, 32 OB]
+                                                               int C, int H, int W, int tiles_x,
+                                                               float* __restrict__ gn_part) {      // [N, tiles, 2, 32 OB] or null
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = DhLds;
+    constexpr int PX = Lds::PX, CH = Lds::CH, KS = Lds::KS, GR = Lds::GR, ROW = Lds::ROW, RW = Lds::RW, RH = Lds::RH, RS = Lds::RS;
+    constexpr int NPB = PX / 32;
+    static_assert(OB == 8 || OB == 4, "O = 256 or 128");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y;
+    const int HW = H * W;
+    const int tyb = blockIdx.x / tiles_x, txb = blockIdx.x - tyb * tiles_x;
+    const int y0 = tyb * Lds::TH, x0 = txb * Lds::TW;
+    const int ry0 = y0 - 1 - Lds::D, rx0 = x0 - 1 - Lds::D;
+    const int ob = (OB == 8) ? w : (w & 3);
+    const bool mma_wave = OB == 8 || w < 4;
+    const int KSall = 9 * C / 16;
+    const int cchunks = C / CH, nch = 9 * cchunks;
+    const float* xn = x + (size_t)n * HW * C;
+
+    // ---- sampling coordinates of the tile: 9 taps x 128 pixels -> 4 corner addresses + 4 weights (0 where invalid). A sample whose four
+    // corners lie inside the staged region gets their byte offsets into it (>= 0); any other sample (|offset| > 2) the pixel indices of the
+    // frame encoded as -(index + 1) and is gathered from global memory - per SAMPLE, so one far sample costs one far gather, not the tile
+    for (int e = tid; e < 9 * PX; e += 512) {
+        const int t = e / PX, px = e - t * PX;
+        int ho = y0 + (px >> 4), wo = x0 + (px & 15);
+        ho = ho < H ? ho : H - 1;
+        wo = wo < W ? wo : W - 1;
+        const float* off = offset + ((size_t)n * 18 + 2 * t) * HW + (size_t)ho * W + wo;
+        const int i = t / 3, j = t - 3 * i;
+        const float hf = (float)(ho - 1 + i) + off[0];
+        const float wf = (float)(wo - 1 + j) + off[HW];
+        int idx[4] = {0, 0, 0, 0};
+        float wt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (hf > -1.f && wf > -1.f && hf < (float)H && wf < (float)W) {
+            const int hl = (int)floorf(hf), wl = (int)floorf(wf);
+            const int hh = hl + 1, wh = wl + 1;
+            const float lh = hf - (float)hl, lw = wf - (float)wl;
+            const float uh = 1.f - lh, uw = 1.f - lw;
+            const int hlc = hl < 0 ? 0 : hl, wlc = wl < 0 ? 0 : wl;
+            const int hhc = hh > H - 1 ? H - 1 : hh, whc = wh > W - 1 ? W - 1 : wh;
+            wt[0] = (hl >= 0 && wl >= 0) ? uh * uw : 0.f;
+            wt[1] = (hl >= 0 && wh <= W - 1) ? uh * lw : 0.f;
+            wt[2] = (hh <= H - 1 && wl >= 0) ? lh * uw : 0.f;
+            wt[3] = (hh <= H - 1 && wh <= W - 1) ? lh * lw : 0.f;
+            const int a = hlc - ry0, b = hhc - ry0, c = wlc - rx0, d = whc - rx0;
+            if (a >= 0 && b < RH && c >= 0 && d < RW && a < RH && b >= 0 && c < RW && d >= 0) {
+                idx[0] = (a * RW + c) * RS; idx[1] = (a * RW + d) * RS; idx[2] = (b * RW + c) * RS; idx[3] = (b * RW + d) * RS;
+            } else {
+                idx[0] = -(hlc * W + wlc) - 1; idx[1] = -(hlc * W + whc) - 1; idx[2] = -(hhc * W + wlc) - 1; idx[3] = -(hhc * W + whc) - 1;
+            }
+        }
+        int* ci = reinterpret_cast<int*>(smem + Lds::coords + e * 32);
+        ci[0] = idx[0]; ci[1] = idx[1]; ci[2] = idx[2]; ci[3] = idx[3];
+        float* cw = reinterpret_cast<float*>(ci + 4);
+        cw[0] = wt[0]; cw[1] = wt[1]; cw[2] = wt[2]; cw[3] = wt[3];
+    }
+    __syncthreads();
+
+    // ---- staged region of one 32-channel chunk: RH x RW pixels x 128 B, thread -> 16-byte pieces tid + 512 i ----
+    f32x4 rg[Lds::RPT];
+    auto region_fetch = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < Lds::RPT; ++i) {
+            const int j = tid + 512 * i, rp = j >> 3, l8 = j & 7;
+            const int ry = rp / RW, rx = rp - ry * RW;
+            const int y = ry0 + ry, xx = rx0 + rx;
+            rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < Lds::RITEMS && y >= 0 && y < H && xx >= 0 && xx < W)
+                rg[i] = *reinterpret_cast<const f32x4*>(xn + ((size_t)y * W + xx) * C + cc * CH + 4 * l8);
+        }
+    };
+    auto region_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < Lds::RPT; ++i) {
+            const int j = tid + 512 * i, rp = j >> 3, l8 = j & 7;
+            if (j < Lds::RITEMS) *reinterpret_cast<f32x4*>(smem + Lds::region + rp * RS + 16 * l8) = rg[i];
+        }
+    };
+
+    // ---- gather / blend: thread -> items q = tid + 512 i (i < 2): pixel q >> 3, channel group (q & 7) * 4 of the chunk ----
+    f32x4 gv[2][4];                       // [item][corner]
+    f32x4 gw[2];                          // corner weights of the item's (tap, pixel)
+    auto gather = [&](int t, int cc) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 512 * i, px = q / GR, cg = (q % GR) * 4;
+            const int* ci = reinterpret_cast<const int*>(smem + Lds::coords + (t * PX + px) * 32);
+            const u32x4 id = *reinterpret_cast<const u32x4*>(ci);
+            gw[i] = *reinterpret_cast<const f32x4*>(ci + 4);
+            if ((int)id[0] < 0) {                          // a far sample: its corners from global memory
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[i][k] = *reinterpret_cast<const f32x4*>(xn + (size_t)(-(int)id[k] - 1) * C + cc * CH + cg);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gv[i][k] = *reinterpret_cast<const f32x4*>(smem + Lds::region + id[k] + cg * 4);
+            }
+        }
+    };
+    auto blend_store = [&](int buf) {
+        char* bh = smem + Lds::bufs + buf * Lds::buf_bytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = tid + 512 * i, px = q / GR, cg = (q % GR) * 4;
+            bf16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // the reference's expression: w1 v1 + w2 v2 + w3 v3 + w4 v4 (:112)
+                const float v = gw[i][0] * gv[i][0][e] + gw[i][1] * gv[i][1][e] + gw[i][2] * gv[i][2][e] + gw[i][3] * gv[i][3][e];
+                vh[e] = (__bf16)v;
+                vl[e] = (__bf16)(v - (float)vh[e]);
+            }
+            *reinterpret_cast<bf16x4*>(bh + px * ROW + cg * 2) = vh;
+            *reinterpret_cast<bf16x4*>(bh + PX * ROW + px * ROW + cg * 2) = vl;
+        }
+    };
+
+    f32x16 acc[NPB];
+#pragma unroll
+    for (int b = 0; b < NPB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+
+    region_fetch(0);
+    region_commit();
+    __syncthreads();
+    gather(0, 0);
+    blend_store(0);
+    __syncthreads();
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpack) + ((size_t)ob * KSall * 2) * 64 + lane;   // fragment (ks, part): + (ks * 2 + part) * 64
+    int t = 0, cc = 0;                                         // chunk ch = (channel chunk cc, tap t): cc outer, t inner
+    for (int ch = 0; ch < nch; ++ch) {
+        const char* bh = smem + Lds::bufs + (ch & 1) * Lds::buf_bytes;
+        const char* bl = bh + PX * ROW;
+        if (mma_wave) {
+            // k-steps of (tap t, channels 32 cc ..): k = tap * C + c
+            const int ks0 = (t * C + cc * CH) / 16;
+            bf16x8 ah[KS], al[KS];
+#pragma unroll
+            for (int u = 0; u < KS; ++u) {
+                ah[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ks0 + u) * 2) * 64]);
+                al[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ks0 + u) * 2 + 1) * 64]);
+            }
+#pragma unroll
+            for (int b = 0; b < NPB; ++b) {
+                const int prow = (32 * b + r) * ROW + 16 * h;
+                bf16x8 sh[KS], sl[KS];
+#pragma unroll
+                for (int u = 0; u < KS; ++u) {
+                    sh[u] = *reinterpret_cast<const bf16x8*>(bh + prow + 32 * u);
+                    sl[u] = *reinterpret_cast<const bf16x8*>(bl + prow + 32 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < KS; ++u) {
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], sh[u], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[u], sh[u], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[u], sl[u], acc[b], 0, 0, 0);
+                }
+            }
+        }
+        // next chunk (issued AFTER this chunk's MFMAs, as in the form above)
+        int tn = t + 1, ccn = cc;
+        if (tn == 9) { tn = 0; ++ccn; }
+        if (ch + 1 < nch) {
+            if (t == 4 && cc + 1 < cchunks) region_fetch(cc + 1);            // lands under the taps 5 .. 8 of this channel chunk
+            if (t == 8) {
+                // the gathers of this channel chunk are all done (the last one ran in the previous iteration, before its barrier)
+                region_commit();
+                __syncthreads();
+            }
+            gather(tn, ccn);
+            blend_store((ch + 1) & 1);
+        }
+        t = tn;
+        cc = ccn;
+        __syncthreads();
+    }
+
+    // ---- GroupNorm partial sums (see the form above): one partial row per tile and multiplying wave ----
+    if (!mma_wave) return;
+    bool valid[NPB];
+    int pidx[NPB];
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+        const int pxl = 32 * b + r;
+        const int ho = y0 + (pxl >> 4), wo = x0 + (pxl & 15);
+        valid[b] = ho < H && wo < W;
+        pidx[b] = ho * W + wo;
+    }
+    if (gn_part) {
+        float s1[16], s2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll
+        for (int b = 0; b < NPB; ++b) {
+            if (valid[b]) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s1[i] += acc[b][i]; s2[i] += acc[b][i] * acc[b][i]; }
+            }
+        }
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s1[i] += __shfl_xor(s1[i], m); s2[i] += __shfl_xor(s2[i], m); }
+        }
+        if (r == 0) {
+            float* base = gn_part + (((size_t)n * gridDim.x + blockIdx.x) * 2) * (32 * OB) + 32 * ob + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(base + 8 * g) = f32x4{s1[4 * g], s1[4 * g + 1], s1[4 * g + 2], s1[4 * g + 3]};
+                *reinterpret_cast<f32x4*>(base + 32 * OB + 8 * g) = f32x4{s2[4 * g], s2[4 * g + 1], s2[4 * g + 2], s2[4 * g + 3]};
+            }
+        }
+    }
+    float* on = out + (size_t)n * HW * (32 * OB);
+#pragma unroll
+    for (int b = 0; b < NPB; ++b) {
+        if (valid[b]) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[b][4 * g], acc[b][4 * g + 1], acc[b][4 * g + 2], acc[b][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(on + (size_t)pidx[b] * (32 * OB) + 32 * ob + 8 * g + 4 * h) = v;
+            }
+        }
+    }
+}
+
 }  // namespace svps
 
 extern "C" int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offset, const void* wpack, float* out, int N, int C,
@@ -260,6 +524,11 @@ extern "C" int svps_deform_conv_fused_fwd(const float* x_nhwc, const float* offs
 }
 
 namespace {
+// K7'' (the staged form) for the layers it covers: 3 x 3, stride 1, pad 1, dilation 1 (Ho = H, Wo = W); SVPS_K7_HALO=0 keeps the form above
+bool dc_use_halo(int C, int H, int W, int Ho, int Wo, int pad, int stride, int dil) {
+    static const bool off = [] { const char* e = getenv("SVPS_K7_HALO"); return e && atoi(e) == 0; }();
+    return !off && pad == 1 && stride == 1 && dil == 1 && Ho == H && Wo == W && (C % svps::DhLds::CH) == 0;
+}
 // tile shape of a launch (see DcTile): deterministic in (N, O, Ho Wo) - the GroupNorm partial rows are laid out per tile. Rule from the
 // measurements of tools/kbench_k7.py (SVPS_K7_TILE=128 / 256 overrides it for such runs)
 bool dc_tile256(int N, int O, int HWo) {
@@ -290,6 +559,8 @@ int dc_launch(const float* x, const float* offset, const void* wpack, float* out
 
 extern "C" int svps_deform_conv_fused_stats_chunks(int N, int O, int Ho, int Wo) {
     if ((O != 128 && O != 256) || Ho <= 0 || Wo <= 0 || N <= 0) return 0;
+    // (the statistics entry point is only used by the semantic tower: 3 x 3, stride 1, pad 1 -> the staged form's 8 x 16 tiles)
+    if (dc_use_halo(svps::DhLds::CH, Ho, Wo, Ho, Wo, 1, 1, 1)) return ((Ho + svps::DhLds::TH - 1) / svps::DhLds::TH) * ((Wo + svps::DhLds::TW - 1) / svps::DhLds::TW);
     const int px = dc_tile256(N, O, Ho * Wo) ? 256 : 128;
     const int tiles = (Ho * Wo + px - 1) / px;
     return (O == 256 || SVPS_K7_O128_FOUR_WAVES) ? tiles : 2 * tiles;
@@ -306,8 +577,31 @@ extern "C" int svps_deform_conv_fused_stats_fwd(const float* x_nhwc, const float
     if ((size_t)H * W * C >= ((size_t)1 << 31)) return SVPS_ERR_BAD_SHAPE;          // 32-bit pixel indices inside a frame
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const bool t256 = dc_tile256(N, O, Ho * Wo);
+    // the partial rows of the statistics are laid out per tile of the form svps_deform_conv_fused_stats_chunks() assumed: the staged
+    // form's for a 3 x 3 / stride 1 / pad 1 / dilation 1 layer (the semantic tower's; the only caller with statistics)
+    if (gn_partial && dc_use_halo(svps::DhLds::CH, Ho, Wo, Ho, Wo, 1, 1, 1) && !dc_use_halo(C, H, W, Ho, Wo, pad, stride, dil)) return SVPS_ERR_BAD_SHAPE;
     svps_prof_mark(SVPS_KERNEL_DEFORM_CONV, 0, stream);
     int rc;
+    if (dc_use_halo(C, H, W, Ho, Wo, pad, stride, dil)) {
+        const int tx = (W + svps::DhLds::TW - 1) / svps::DhLds::TW, ty = (H + svps::DhLds::TH - 1) / svps::DhLds::TH;
+        hipError_t ae;
+        if (O == 256) {
+            auto kern = svps::deform_conv_halo_kernel<8>;
+            static SvpsLdsAttr attr;
+            if ((ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DhLds::total)) != hipSuccess) return (int)ae;
+            hipLaunchKernelGGL(kern, dim3(tx * ty, N), dim3(512), svps::DhLds::total, stream, x_nhwc, offset, static_cast<const __bf16*>(wpack), out,
+                               C, H, W, tx, gn_partial);
+        } else {
+            auto kern = svps::deform_conv_halo_kernel<4>;
+            static SvpsLdsAttr attr;
+            if ((ae = attr.ensure(reinterpret_cast<const void*>(kern), svps::DhLds::total)) != hipSuccess) return (int)ae;
+            hipLaunchKernelGGL(kern, dim3(tx * ty, N), dim3(512), svps::DhLds::total, stream, x_nhwc, offset, static_cast<const __bf16*>(wpack), out,
+                               C, H, W, tx, gn_partial);
+        }
+        rc = (int)hipGetLastError();
+        svps_prof_mark(SVPS_KERNEL_DEFORM_CONV, 1, stream);
+        return rc;
+    }
     if (O == 256) rc = t256 ? dc_launch<8, true>(x_nhwc, offset, wpack, out, gn_partial, N, C, H, W, Ho, Wo, pad, stride, dil, stream)
                             : dc_launch<8, false>(x_nhwc, offset, wpack, out, gn_partial, N, C, H, W, Ho, Wo, pad, stride, dil, stream);
     else rc = t256 ? dc_launch<4, true>(x_nhwc, offset, wpack, out, gn_partial, N, C, H, W, Ho, Wo, pad, stride, dil, stream)

@@ -119,7 +119,10 @@ def test_hip_deform_conv_matches_oracle(cuda, N, C, O, H, W, dg):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C,O,H,W,scale", [(2, 256, 256, 16, 32, 2.5), (1, 256, 128, 33, 20, 2.5), (2, 128, 128, 9, 7, 6.0),
-                                             (1, 64, 128, 40, 40, 0.0)])
+                                             (1, 64, 128, 40, 40, 0.0),
+                                             # K7'' (the staged form): offsets inside the staged region (|offset| <= 2) on most / some / all tiles,
+                                             # sizes that are no multiple of the 8 x 16 tile
+                                             (2, 256, 128, 24, 40, 0.5), (1, 128, 128, 33, 20, 0.7), (1, 64, 128, 17, 50, 1.0), (1, 128, 256, 8, 16, 0.3)])
 def test_fused_deform_conv_without_column_buffer_matches_oracle(cuda, N, C, O, H, W, scale):
     """K7' (csrc/deform_conv_fused.hip): one kernel, no column buffer, split-bf16 products with fp32 accumulation, against
     the float64 oracle on the same fp32 input: fp32-class tolerance (the im2col + fp32 GEMM path holds 2e-5). Offsets reach

@@ -17,7 +17,7 @@ ap.add_argument("--frames", type=int, default=0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--profile-tower", type=int, default=0)
-ap.add_argument("--map-dtype", default="bf16", help="head mode (MultiScaleDynamicMaskHead.MODES): bf16, fp16, fp16x2, fp32")
+ap.add_argument("--mode", "--map-dtype", dest="map_dtype", default="bf16", help="head mode (MultiScaleDynamicMaskHead.MODES): bf16, fp16, fp16x2, fp32")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = Config.fromfile(a.config)
