@@ -368,40 +368,60 @@ __global__ __launch_bounds__(512) void deform_conv_halo_kernel(const float* __re
         }
     };
 
-    // ---- gather / blend: thread -> items q = tid + 512 i (i < 2): pixel q >> 3, channel group (q & 7) * 4 of the chunk ----
-    f32x4 gv[2][4];                       // [item][corner]
-    f32x4 gw[2];                          // corner weights of the item's (tap, pixel)
+    // ---- gather / blend: 1024 items per chunk (pixel q >> 3, channel group (q & 7) * 4). O = 256: every thread two (q = tid + 512 i).
+    // O = 128: the four multiplying waves carry the chunk's 24 MFMAs and the requests of the next chunk's weight fragments, so their threads
+    // take ONE item (q = tid) and the threads of waves 4 .. 7 THREE (q = tid + 256 i): measured at 256 x 512, 256 -> 128: equal shares
+    // 1 917 us, one item on the multiplying waves 1 790, none the same within the box-to-box noise. The gather / blend is VALU-bound
+    // (~150 vector instructions per item): packed fp32 math below
+#ifndef SVPS_K7_MMA_ITEMS
+#define SVPS_K7_MMA_ITEMS 1            // O = 128: items per thread of the multiplying waves (0 or 1; the other waves take the rest)
+#endif
+    constexpr int NI = OB == 8 ? 2 : 4 - SVPS_K7_MMA_ITEMS;
+    const int ni = OB == 8 ? 2 : (mma_wave ? SVPS_K7_MMA_ITEMS : 4 - SVPS_K7_MMA_ITEMS);
+    auto item = [&](int i) { return OB == 8 ? tid + 512 * i : (mma_wave ? tid : (SVPS_K7_MMA_ITEMS ? tid : tid - 256) + 256 * i); };
+    f32x4 gv[NI][4];                      // [item][corner]
+    f32x4 gw[NI];                         // corner weights of the item's (tap, pixel)
     auto gather = [&](int t, int cc) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + 512 * i, px = q / GR, cg = (q % GR) * 4;
-            const int* ci = reinterpret_cast<const int*>(smem + Lds::coords + (t * PX + px) * 32);
-            const u32x4 id = *reinterpret_cast<const u32x4*>(ci);
-            gw[i] = *reinterpret_cast<const f32x4*>(ci + 4);
-            if ((int)id[0] < 0) {                          // a far sample: its corners from global memory
+        for (int i = 0; i < NI; ++i) {
+            if (i < ni) {
+                const int q = item(i), px = q / GR, cg = (q % GR) * 4;
+                const int* ci = reinterpret_cast<const int*>(smem + Lds::coords + (t * PX + px) * 32);
+                const u32x4 id = *reinterpret_cast<const u32x4*>(ci);
+                gw[i] = *reinterpret_cast<const f32x4*>(ci + 4);
+                if ((int)id[0] < 0) {                      // a far sample: its corners from global memory
 #pragma unroll
-                for (int k = 0; k < 4; ++k) gv[i][k] = *reinterpret_cast<const f32x4*>(xn + (size_t)(-(int)id[k] - 1) * C + cc * CH + cg);
-            } else {
+                    for (int k = 0; k < 4; ++k) gv[i][k] = *reinterpret_cast<const f32x4*>(xn + (size_t)(-(int)id[k] - 1) * C + cc * CH + cg);
+                } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) gv[i][k] = *reinterpret_cast<const f32x4*>(smem + Lds::region + id[k] + cg * 4);
+                    for (int k = 0; k < 4; ++k) gv[i][k] = *reinterpret_cast<const f32x4*>(smem + Lds::region + id[k] + cg * 4);
+                }
             }
         }
     };
     auto blend_store = [&](int buf) {
         char* bh = smem + Lds::bufs + buf * Lds::buf_bytes;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = tid + 512 * i, px = q / GR, cg = (q % GR) * 4;
-            bf16x4 vh, vl;
+        for (int i = 0; i < NI; ++i) {
+            if (i < ni) {
+                const int q = item(i), px = q / GR, cg = (q % GR) * 4;
+                // the reference's expression: w1 v1 + w2 v2 + w3 v3 + w4 v4 (:112), two channels per packed instruction (v_pk_mul / v_pk_fma_f32;
+                // these waves' vector work is what bounds the kernel, and nothing of it sits behind an MFMA of its own wave)
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                bf16x2_t vh[2], vl[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // the reference's expression: w1 v1 + w2 v2 + w3 v3 + w4 v4 (:112)
-                const float v = gw[i][0] * gv[i][0][e] + gw[i][1] * gv[i][1][e] + gw[i][2] * gv[i][2][e] + gw[i][3] * gv[i][3][e];
-                vh[e] = (__bf16)v;
-                vl[e] = (__bf16)(v - (float)vh[e]);
+                for (int e = 0; e < 2; ++e) {
+                    const f32x2_t c0 = {gv[i][0][2 * e], gv[i][0][2 * e + 1]}, c1 = {gv[i][1][2 * e], gv[i][1][2 * e + 1]};
+                    const f32x2_t c2 = {gv[i][2][2 * e], gv[i][2][2 * e + 1]}, c3 = {gv[i][3][2 * e], gv[i][3][2 * e + 1]};
+                    const f32x2_t w0 = {gw[i][0], gw[i][0]}, w1 = {gw[i][1], gw[i][1]}, w2 = {gw[i][2], gw[i][2]}, w3 = {gw[i][3], gw[i][3]};
+                    const f32x2_t v = __builtin_elementwise_fma(w3, c3, __builtin_elementwise_fma(w2, c2, __builtin_elementwise_fma(w1, c1, w0 * c0)));
+                    vh[e] = __builtin_convertvector(v, bf16x2_t);
+                    vl[e] = __builtin_convertvector(v - __builtin_convertvector(vh[e], f32x2_t), bf16x2_t);
+                }
+                *reinterpret_cast<bf16x4*>(bh + px * ROW + cg * 2) = __builtin_shufflevector(vh[0], vh[1], 0, 1, 2, 3);
+                *reinterpret_cast<bf16x4*>(bh + PX * ROW + px * ROW + cg * 2) = __builtin_shufflevector(vl[0], vl[1], 0, 1, 2, 3);
             }
-            *reinterpret_cast<bf16x4*>(bh + px * ROW + cg * 2) = vh;
-            *reinterpret_cast<bf16x4*>(bh + PX * ROW + px * ROW + cg * 2) = vl;
         }
     };
 
@@ -419,18 +439,26 @@ __global__ __launch_bounds__(512) void deform_conv_halo_kernel(const float* __re
     __syncthreads();
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(wpack) + ((size_t)ob * KSall * 2) * 64 + lane;   // fragment (ks, part): + (ks * 2 + part) * 64
     int t = 0, cc = 0;                                         // chunk ch = (channel chunk cc, tap t): cc outer, t inner
+    // weight fragments of a chunk: k-steps of (tap t, channels 32 cc ..), k = tap * C + c; requested ONE CHUNK AHEAD (they come from L2: used
+    // in the chunk they were requested in, their latency sat at the head of every chunk's MFMA section)
+    bf16x8 ahn[KS], aln[KS];
+    auto weights = [&](int t_, int cc_) {
+        const int ks0 = (t_ * C + cc_ * CH) / 16;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            ahn[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ks0 + u) * 2) * 64]);
+            aln[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ks0 + u) * 2 + 1) * 64]);
+        }
+    };
+    if (mma_wave) weights(0, 0);
     for (int ch = 0; ch < nch; ++ch) {
         const char* bh = smem + Lds::bufs + (ch & 1) * Lds::buf_bytes;
         const char* bl = bh + PX * ROW;
         if (mma_wave) {
-            // k-steps of (tap t, channels 32 cc ..): k = tap * C + c
-            const int ks0 = (t * C + cc * CH) / 16;
             bf16x8 ah[KS], al[KS];
 #pragma unroll
-            for (int u = 0; u < KS; ++u) {
-                ah[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ks0 + u) * 2) * 64]);
-                al[u] = __builtin_bit_cast(bf16x8, wsrc[(size_t)((ks0 + u) * 2 + 1) * 64]);
-            }
+            for (int u = 0; u < KS; ++u) { ah[u] = ahn[u]; al[u] = aln[u]; }
+            if (ch + 1 < nch) weights(t == 8 ? 0 : t + 1, t == 8 ? cc + 1 : cc);
 #pragma unroll
             for (int b = 0; b < NPB; ++b) {
                 const int prow = (32 * b + r) * ROW + 16 * h;
