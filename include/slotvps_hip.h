@@ -242,6 +242,8 @@ int svps_retr_query_prep(const float* x, const float* lnq_w, const float* lnq_b,
                          void* stream);
 int svps_retr_split(const float* q2, void* hi, void* lo, size_t n, void* stream);
 int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream);
+/* the same with fp16 hi + lo operands (22 bits of mantissa instead of 16: the slot side of the reference-precision mode, round 5) */
+int svps_slot_self_attn_f16(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8 dense layers of the slot update (slotvps_amd/csrc/slot_gemm.hip): y = act(x W^T + bias), the nn.Linear layers of

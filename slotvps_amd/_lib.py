@@ -57,6 +57,7 @@ SIGNATURES = {
     "svps_retr_query_prep": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_retr_split": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "svps_slot_self_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "svps_slot_self_attn_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_panoptic_candidates": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "svps_panoptic_argmax": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "svps_panoptic_clip_state_ints": (_i, []),

@@ -151,19 +151,29 @@ __global__ __launch_bounds__(256) void retr_split_kernel(const float* __restrict
 // x 8 heads (tools/self_attn_probe.py): 15 us, against 30 us for the framework's fused attention kernel, 112 us for
 // matmul + softmax + matmul through the GEMM library and 81 us for a one-thread-per-query fp32 vector-ALU kernel (the first
 // version of this function); 2.2e-5 from the fp32 result on O(1) outputs.
-typedef __attribute__((ext_vector_type(8))) __bf16 ra_bf16x8;
+// ST = the 16-bit type of the operand split: __bf16 (hi + lo = 16 bits of mantissa; the 16-bit modes) or _Float16 (22 bits: the slot side of
+// mode "fp16x2", round 5 - q / sqrt(32), k, v are O(1 ... 10) and the probabilities <= 1: inside fp16's range; a probability below
+// fp16's normal range keeps an ABSOLUTE resolution of 6e-8, and nothing behind this kernel rescales a row)
 typedef __attribute__((ext_vector_type(16))) float ra_f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 ra_b8;
+typedef __attribute__((ext_vector_type(8))) _Float16 ra_h8;
+__device__ __forceinline__ ra_f32x16 mfma16(ra_b8 a, ra_b8 b, ra_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ ra_f32x16 mfma16(ra_h8 a, ra_h8 b, ra_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-__device__ __forceinline__ void split8(const float* v, ra_bf16x8& hi, ra_bf16x8& lo) {
+template <typename ST>
+__device__ __forceinline__ void split8(const float* v, __attribute__((ext_vector_type(8))) ST& hi, __attribute__((ext_vector_type(8))) ST& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        hi[j] = (__bf16)v[j];
-        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+        float x = v[j];
+        asm volatile("" : "+v"(x));              // ONE fp32 value for both halves (see retr_attn.hip, p2_store)
+        hi[j] = (ST)x;
+        lo[j] = (ST)(x - (float)hi[j]);
     }
 }
 
-template <int NW>
+template <int NW, typename ST = __bf16>
 __global__ __launch_bounds__(NW * 64) void slot_self_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int L, int nh, float scale_log2e) {
+    typedef __attribute__((ext_vector_type(8))) ST ra_bf16x8;        // (8 x the split type)
     constexpr int HD = 32, LKP = 32 * NW;                             // padded key count
     constexpr int kVtRow = LKP * 2 + 16;                              // bytes per dim row of V^T (padded: conflict-free 16-byte reads)
     __shared__ __attribute__((aligned(16))) char vt[2 * HD * kVtRow]; // [hi | lo][dim][key] bf16
@@ -179,9 +189,11 @@ __global__ __launch_bounds__(NW * 64) void slot_self_attn_kernel(const float* __
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const __bf16 hi = (__bf16)vv[e];
-            *reinterpret_cast<__bf16*>(vt + (4 * d4 + e) * kVtRow + key * 2) = hi;
-            *reinterpret_cast<__bf16*>(vt + HD * kVtRow + (4 * d4 + e) * kVtRow + key * 2) = (__bf16)(vv[e] - (float)hi);
+            float xv = vv[e];
+            asm volatile("" : "+v"(xv));
+            const ST hi = (ST)xv;
+            *reinterpret_cast<ST*>(vt + (4 * d4 + e) * kVtRow + key * 2) = hi;
+            *reinterpret_cast<ST*>(vt + HD * kVtRow + (4 * d4 + e) * kVtRow + key * 2) = (ST)(xv - (float)hi);
         }
     }
     // ---- this wave's queries as B fragments (hi / lo), pre-scaled
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(NW * 64) void slot_self_attn_kernel(const float* __
                 v[0] = a.x * scale_log2e; v[1] = a.y * scale_log2e; v[2] = a.z * scale_log2e; v[3] = a.w * scale_log2e;
                 v[4] = b.x * scale_log2e; v[5] = b.y * scale_log2e; v[6] = b.z * scale_log2e; v[7] = b.w * scale_log2e;
             }
-            split8(v, qh[ks], ql[ks]);
+            split8<ST>(v, qh[ks], ql[ks]);
         }
     }
     // ---- S^T blocks: keys x queries
@@ -216,10 +228,10 @@ __global__ __launch_bounds__(NW * 64) void slot_self_attn_kernel(const float* __
                 v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
             }
             ra_bf16x8 kh, kl;
-            split8(v, kh, kl);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], acc[nb], 0, 0, 0);
+            split8<ST>(v, kh, kl);
+            acc[nb] = mfma16(kh, qh[ks], acc[nb]);
+            acc[nb] = mfma16(kl, qh[ks], acc[nb]);
+            acc[nb] = mfma16(kh, ql[ks], acc[nb]);
         }
     }
     // ---- softmax over keys (rows), per query (lane column): rows of register i: 32 nb + (i & 3) + 8 (i >> 2) + 4 h
@@ -268,13 +280,13 @@ __global__ __launch_bounds__(NW * 64) void slot_self_attn_kernel(const float* __
                 p[4 + e] = __uint_as_float(sw[1]);
             }
             ra_bf16x8 ph, pl;
-            split8(p, ph, pl);
+            split8<ST>(p, ph, pl);
             const char* va = vt + r * kVtRow + (32 * nb + 16 * ks2 + 8 * h) * 2;
             const ra_bf16x8 vh = *reinterpret_cast<const ra_bf16x8*>(va);
             const ra_bf16x8 vl = *reinterpret_cast<const ra_bf16x8*>(va + HD * kVtRow);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, o, 0, 0, 0);
+            o = mfma16(vh, ph, o);
+            o = mfma16(vl, ph, o);
+            o = mfma16(vh, pl, o);
         }
     // ---- O[query][dim] = O^T / den: lane (query r, h) holds dims 8 g + 4 h + e
     const int qi = 32 * w + r;
@@ -309,16 +321,27 @@ extern "C" int svps_retr_split(const float* q2, void* hi, void* lo, size_t n, vo
     return (int)hipGetLastError();
 }
 
-extern "C" int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream_) {
+namespace {
+template <typename ST>
+int launch_self_attn(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream_) {
     if (!qkv || !out) return SVPS_ERR_BAD_ARG;
     if (T <= 0 || L <= 0 || L > 256 || nheads <= 0 || head_dim != 32) return SVPS_ERR_BAD_SHAPE;
     const float sl2 = 1.4426950408889634f / sqrtf((float)head_dim);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (L <= 128)
-        hipLaunchKernelGGL(svps::slot_self_attn_kernel<4>, dim3(nheads, T), dim3(256), 0, stream, qkv, out, L, nheads, sl2);
+        hipLaunchKernelGGL((svps::slot_self_attn_kernel<4, ST>), dim3(nheads, T), dim3(256), 0, stream, qkv, out, L, nheads, sl2);
     else
-        hipLaunchKernelGGL(svps::slot_self_attn_kernel<8>, dim3(nheads, T), dim3(512), 0, stream, qkv, out, L, nheads, sl2);
+        hipLaunchKernelGGL((svps::slot_self_attn_kernel<8, ST>), dim3(nheads, T), dim3(512), 0, stream, qkv, out, L, nheads, sl2);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int svps_slot_self_attn(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream_) {
+    return launch_self_attn<__bf16>(qkv, out, T, L, nheads, head_dim, stream_);
+}
+// the same with fp16 hi + lo operands (22 bits): the slot side of mode "fp16x2"
+extern "C" int svps_slot_self_attn_f16(const float* qkv, float* out, int T, int L, int nheads, int head_dim, void* stream_) {
+    return launch_self_attn<_Float16>(qkv, out, T, L, nheads, head_dim, stream_);
 }
 
 extern "C" int svps_row_ln(const float* x, const float* pre, const float* post, const float* w, const float* b,

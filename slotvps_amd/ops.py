@@ -524,9 +524,10 @@ def retr_split(q2):
     return hi, lo
 
 
-def slot_self_attn(qkv, nheads):
+def slot_self_attn(qkv, nheads, split="bf16"):
     """qkv [T, L, 3 * C] fp32 (packed in_proj output: q | k | v, each nheads x 32) -> [T, L, C] = softmax(q k^T / sqrt(32)) v
-    per frame and head (nn.MultiheadAttention between its two projections, dynamic_mask_head.py:346-355)."""
+    per frame and head (nn.MultiheadAttention between its two projections, dynamic_mask_head.py:346-355). split: operand split of the
+    matrix products, "bf16" (hi + lo = 16 bits) or "fp16" (22 bits: mode fp16x2)."""
     lib = _lib.load()
     _need(qkv, "qkv", torch.float32, 3)
     T, L, C3 = qkv.shape
@@ -535,7 +536,8 @@ def slot_self_attn(qkv, nheads):
         raise ValueError("slot_self_attn: head_dim must be 32")
     out = torch.empty((T, L, C), dtype=torch.float32, device=qkv.device)
     with _on(qkv) as ctx:
-        _lib.check(lib.svps_slot_self_attn(_ptr(qkv), _ptr(out), T, L, nheads, 32, ctx.stream), "svps_slot_self_attn")
+        fn = lib.svps_slot_self_attn_f16 if split == "fp16" else lib.svps_slot_self_attn
+        _lib.check(fn(_ptr(qkv), _ptr(out), T, L, nheads, 32, ctx.stream), "svps_slot_self_attn")
     return out
 
 

@@ -562,6 +562,12 @@ class MaskRCNNHead(nn.Module):
         nh = mha.num_heads
         qkv = fast_linear(self, "in_proj", slots, mha.in_proj_weight, mha.in_proj_bias).view(T, L, 3, nh, C // nh)
         q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [T, heads, L, C / heads] views
+        if self.precision == "fp16x2" and C // nh == 32 and L <= 256 and self.use_slot_gemm:
+            # the library's attention kernel with fp16 hi + lo operands (22 bits; round 5: three GEMM-library launches + softmax before)
+            o = ops.slot_self_attn(qkv.view(T, L, 3 * C), nh, split="fp16")
+            if residual_norm:
+                return fast_linear_ln(self, "out_proj", o, mha.out_proj.weight, mha.out_proj.bias, self.norm1, pre=slots)
+            return fast_linear(self, "out_proj", o, mha.out_proj.weight, mha.out_proj.bias)
         if self.precision in ("fp32", "fp16x2"):                            # explicit fp32 products, torch's own order (:352)
             attn = torch.softmax((q * (1.0 / math.sqrt(C // nh))) @ k.transpose(-1, -2), dim=-1)
             o = attn @ v

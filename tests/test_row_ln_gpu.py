@@ -59,9 +59,21 @@ def test_slot_self_attention_kernel_matches_oracle_mha(cuda, T, L):
     qkv = torch.nn.functional.linear(tx, g("in_proj_weight"), g("in_proj_bias"))
     o = ops.slot_self_attn(qkv.contiguous(), 8)
     got = torch.nn.functional.linear(o, g("out_proj.weight"), g("out_proj.bias")).cpu().numpy()
+    o16 = ops.slot_self_attn(qkv.contiguous(), 8, split="fp16")       # fp16 hi + lo operands: the slot side of mode fp16x2
+    got16 = torch.nn.functional.linear(o16.double(), g("out_proj.weight").double(), g("out_proj.bias").double()).cpu().numpy()
+    qkv64 = (x.astype(np.float64) @ P["in_proj_weight"].astype(np.float64).T + P["in_proj_bias"].astype(np.float64))
     for t in range(T):
         ref = orc.multihead_self_attention(x[t].astype(np.float64), P, "", 8, np.float64)
         assert np.abs(got[t] - ref).max() <= 5e-5          # split-bf16 products with fp32 accumulation: fp32-class
+        # the kernel alone in the fp16 split against float64 on the SAME fp32 qkv (the projections in float64): the operand split's 22 bits
+        q_, k_, v_ = (qkv[t].double().cpu().numpy()[:, i * 256:(i + 1) * 256].reshape(L, 8, 32).transpose(1, 0, 2) for i in range(3))
+        a_ = q_ @ k_.transpose(0, 2, 1) / np.sqrt(32.0)
+        a_ = np.exp(a_ - a_.max(-1, keepdims=True))
+        o_ = ((a_ / a_.sum(-1, keepdims=True)) @ v_).transpose(1, 0, 2).reshape(L, 256)
+        e16 = float(np.abs(o16[t].double().cpu().numpy() - o_).max())
+        assert e16 <= 3e-6, e16                              # (the bf16 split on the same inputs: ~2e-5)
+        assert np.abs(got16[t] - ref).max() <= 2e-5
+    del qkv64
 
 
 def test_retr_query_prep_and_split(cuda):
