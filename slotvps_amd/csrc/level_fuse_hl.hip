@@ -26,7 +26,7 @@
 // Mapping: 8 waves, wave w owns output channels [32w, 32w+32) (its 32 x 128 block of W_b as hi and lo A fragments: 64 registers).
 // Per 32-pixel tile: all threads build the [32 px][128 ch] operand tile (hi, lo) in LDS from the fp32 NCHW map (loaded one tile ahead);
 // every lane requests the 4 taps x 16 channels of g it needs for ITS accumulator entries (pixel = lane & 31) before the MFMAs and
-// blends them in fp32 behind them (torch's upsample_bilinear2d expression); bias, split, out tiles through LDS so that HBM sees whole
+// blends them in fp32 behind them (four tap weights per lane and tile); bias, split, out tiles through LDS so that HBM sees whole
 // 512-byte pixel rows of both planes (and of the fp32 copy).
 #include <type_traits>
 
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
 
     char* ah = smem + Lds::a_hi;
     char* al = smem + Lds::a_lo;
-    // incoming map of one tile: thread = (channel, 8-pixel group): 2 x 16-B loads (one tile ahead), 8 two-byte LDS stores per plane
-    const int ch = tid >> 2, pg = tid & 3;
+    // incoming map of one tile: thread = (channel PAIR, 4-pixel group): 2 x 16-B loads (two tiles ahead), 4 four-byte LDS stores per plane
+    // (round 5; before: one channel x 8 pixels per thread and 8 TWO-byte stores per plane - twice the LDS instructions and address arithmetic)
+    const int ch = 2 * (tid >> 3), pg = tid & 7;
     const float* src = cur + ((size_t)t * 128 + ch) * HW;
     const bool aligned = (HW & 3) == 0;
     // TWO register sets (round 5): the incoming map (and the rows of g) are requested TWO tiles ahead - HBM latency under load is longer
@@ -118,28 +119,32 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     f32x4 c0[2], c1[2];
     auto fetch = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
-        const int pp = px_begin + tile * kTilePx + 8 * pg;
-        if (pp + 8 <= HW && aligned) {
+        const int pp = px_begin + tile * kTilePx + 4 * pg;                 // c0: channel ch, c1: channel ch + 1, pixels pp .. pp + 3
+        if (pp + 4 <= HW && aligned) {
             c0[P] = *reinterpret_cast<const f32x4*>(src + pp);
-            c1[P] = *reinterpret_cast<const f32x4*>(src + pp + 4);
+            c1[P] = *reinterpret_cast<const f32x4*>(src + HW + pp);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 c0[P][j] = src[pp + j < HW ? pp + j : HW - 1];
-                c1[P][j] = src[pp + 4 + j < HW ? pp + 4 + j : HW - 1];
+                c1[P][j] = src[HW + (pp + j < HW ? pp + j : HW - 1)];
             }
         }
     };
     auto commit = [&](auto par) {
         constexpr int P = decltype(par)::value;
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int row = 8 * pg + j;
-            _Float16 vh, vl;
-            hl_split(j < 4 ? c0[P][j] : c1[P][j - 4], vh, vl);
-            const int o = hl_a_off(row, ch >> 3) + (ch & 7) * 2;
-            *reinterpret_cast<_Float16*>(ah + o) = vh;
-            *reinterpret_cast<_Float16*>(al + o) = vl;
+        for (int j = 0; j < 4; ++j) {
+            const int row = 4 * pg + j;
+            f16x2_t vh, vl;
+            _Float16 h0_, l0_, h1_, l1_;
+            hl_split(c0[P][j], h0_, l0_);
+            hl_split(c1[P][j], h1_, l1_);
+            vh[0] = h0_; vh[1] = h1_; vl[0] = l0_; vl[1] = l1_;
+            const int o = hl_a_off(row, ch >> 3) + (ch & 7) * 2;             // (ch even: a 4-byte slot)
+            *reinterpret_cast<f16x2_t*>(ah + o) = vh;
+            *reinterpret_cast<f16x2_t*>(al + o) = vl;
         }
     };
     // out tiles -> HBM, all 512 threads: whole 512-byte (fp32: 1-KiB) pixel rows
@@ -272,8 +277,11 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh[ks], xl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh[ks], xh, acc, 0, 0, 0);
         }
-        // ---- + up(g): torch's upsample_bilinear2d expression (1-ly) ((1-lx) a + lx b) + ly ((1-lx) c + lx d) in fp32; split; out tiles
+        // ---- + up(g) in fp32: w00 a + w01 b + w10 c + w11 d with the four tap weights formed once per lane and tile (round 5: four
+        // instead of seven vector instructions per element; torch's upsample_bilinear2d groups the same sum as (1-ly) ((1-lx) a + lx b) +
+        // ly ((1-lx) c + lx d) - an fp32 rounding of difference, inside the 5e-6 bound against float64 of tests/test_refprec_gpu.py); split; out tiles
         const float h0 = 1.f - h1, w0 = 1.f - w1;
+        const float w00 = h0 * w0, w01 = h0 * w1, w10 = h1 * w0, w11 = h1 * w1;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ch0 = 32 * w + 8 * g + 4 * h;
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = acc[4 * g + j];
-                if constexpr (TAPS) v += h0 * (w0 * tp[0][g][j] + w1 * tp[1][g][j]) + h1 * (w0 * tp[2][g][j] + w1 * tp[3][g][j]);
+                if constexpr (TAPS) v = fmaf(w11, tp[3][g][j], fmaf(w10, tp[2][g][j], fmaf(w01, tp[1][g][j], fmaf(w00, tp[0][g][j], v))));
                 if constexpr (PLANES) {
                     _Float16 vh, vl;
                     hl_split(v, vh, vl);
