@@ -637,9 +637,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         }
         float inr = 1.f;
         f32x4 c4[2];                                     // e . shift of slots sl .. sl + 3, one group ahead
+        // HL: after the fold by register exchange (end of the previous iteration) lane r < 16 holds the sums of accumulator registers 0 .. 7
+        // and lane r + 16 those of registers 8 .. 15 of the SAME pixel: eight epilogue elements per lane (slot groups 2 hi16, 2 hi16 + 1)
+        const int hi16 = HL ? ((r >> 4) & 1) : 0;
+        constexpr int kEG = HL ? 2 : 4;                  // epilogue groups of four elements per lane
         if constexpr (EP) {
             if constexpr (LOGITS) inr = inv_norm[((it - 1) & 1) * kTilePx + (HL ? (r & 15) : r)];
-            c4[0] = *reinterpret_cast<const f32x4*>(cs + 32 * w + acc_row(0, h));
+            c4[0] = *reinterpret_cast<const f32x4*>(cs + 32 * w + acc_row(0, h) + 16 * hi16);
         }
         f32x16 s;
 #pragma unroll
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                 }
             }
             if constexpr (EP) {
-                if (grp < 3) c4[(grp + 1) & 1] = *reinterpret_cast<const f32x4*>(cs + 32 * w + acc_row(4 * (grp + 1), h));
+                if (grp + 1 < kEG) c4[(grp + 1) & 1] = *reinterpret_cast<const f32x4*>(cs + 32 * w + acc_row(4 * (grp + 1), h) + 16 * hi16);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -683,12 +687,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                     }
                 }
                 if constexpr (EP) {
-                    const int i = 4 * grp + u;
-                    const int sl = acc_row(i, h);        // slot inside this wave's block of 32
-                    const float m = LOGITS ? (sp[i] + c4[grp & 1][u]) * inr * fg_scale + fg_shift : (sp[i] + c4[grp & 1][u]) * ksgn;
-                    if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + (HL ? (r & 15) : r) * 4) = m;   // (HL: lanes r and r + 16 hold the same pixel)
-                    if constexpr (ARGMAX) {
-                        if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
+                    if (grp < kEG) {
+                        const int i = 4 * grp + u;
+                        const int sl = acc_row(i, h) + 16 * hi16;   // slot inside this wave's block of 32
+                        const float m = LOGITS ? (sp[i] + c4[grp & 1][u]) * inr * fg_scale + fg_shift : (sp[i] + c4[grp & 1][u]) * ksgn;
+                        if constexpr (LOGITS) *reinterpret_cast<float*>(ot + sl * Lds::kORow + (HL ? (r & 15) : r) * 4) = m;
+                        if constexpr (ARGMAX) {
+                            if (32 * w + sl < L && m > best) { best = m; best_slot = 32 * w + sl; }   // slots ascend with i within a lane
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -697,6 +703,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         K2_STAMP(5);
         if constexpr (EP) {
             if constexpr (ARGMAX) {
+                if constexpr (HL) {                      // the two lanes of a pixel hold different slots: combine them first (ties: lower slot)
+                    const auto qb = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                    const auto qs = __builtin_amdgcn_permlane16_swap((uint32_t)best_slot, (uint32_t)best_slot, false, false);
+                    const float b0 = __uint_as_float(qb[0]), b1 = __uint_as_float(qb[1]);
+                    const int s0 = (int)qs[0], s1 = (int)qs[1];
+                    const bool take1 = b1 > b0 || (b1 == b0 && s1 < s0);
+                    best = take1 ? b1 : b0;
+                    best_slot = take1 ? s1 : s0;
+                }
                 // v_permlane32_swap: [0] = the value of lane r, [1] = of lane r + 32, in both lanes (no address register, no LDS trip)
                 const auto pb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
                 const auto ps = __builtin_amdgcn_permlane32_swap((uint32_t)best_slot, (uint32_t)best_slot, false, false);
@@ -725,11 +740,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
         }
         K2_STAMP(6);
         if constexpr (CH && HL) {
-            // columns r < 16: e . f_hi of pixel r; columns r >= 16: e . f_lo of pixel r - 16. Fold: afterwards both halves hold the full sum
-            // (v_permlane16_swap with the same value in both operands returns [row0, row0, row2, row2] and [row1, row1, row3, row3])
+            // columns r < 16: e . f_hi of pixel r; columns r >= 16: e . f_lo of pixel r - 16. Fold by EXCHANGING register halves (as in
+            // retr_attn_kernel<.., HL>): v_permlane16_swap(s[i], s[i + 8]) returns [s_i.row0, s_{i+8}.row0, ..] and [s_i.row1, s_{i+8}.row1, ..],
+            // whose sum is the full value of register i in lanes r < 16 and of register i + 8 in lanes r >= 16: eight epilogue elements per lane
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[i]), __float_as_uint(s[i]), false, false);
+            for (int i = 0; i < 8; ++i) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(s[i]), __float_as_uint(s[i + 8]), false, false);
                 s[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
             }
         }
