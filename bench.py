@@ -296,7 +296,6 @@ def side_leg(a, dev, frames, height, width, slots, num_classes, cpl, steps, mode
     if with_roofline:
         from slotvps_amd import _lib, ops
         r1.use_graph = False
-        r1.head.two_streams = False                       # (per-kernel durations on one stream: see the main leg)
         r1.run()
         torch.cuda.synchronize(dev)
         kids = {"level_fuse": _lib.KERNEL_LEVEL_FUSE, "retr_stats": _lib.KERNEL_RETR_STATS, "retr_attn": _lib.KERNEL_RETR_ATTN,
@@ -519,11 +518,6 @@ def main():
     if rank == 0:
         eager = runner.use_graph
         runner.use_graph = False
-        # per-kernel durations are measured with every launch on ONE stream (head.two_streams off): in the timed step the map side (K4,
-        # statistics) runs ahead on a side stream and overlaps the slot chain's small launches - an event pair around a kernel that shares
-        # the chip measures the sharing, not the kernel
-        two_saved = getattr(runner.head, "two_streams", False)
-        runner.head.two_streams = False
         for i in range(2):
             step(i, False)
         torch.cuda.synchronize(dev)
@@ -536,7 +530,6 @@ def main():
             torch.cuda.synchronize(dev)
             timed = {name: kt.collect(kid) for name, kid in kids.items()}
         runner.use_graph = eager
-        runner.head.two_streams = two_saved
         alg = runner.algorithmic_per_step()
         nsteps = a.steps * cif
         per = {}
@@ -678,7 +671,6 @@ def main():
                        "gather_ok": gather_ok, "gathered_payloads": rank_sums, "host_cpu_binding_rank0": binding,
                        "gather": f"per step, {gatherers[0].bytes_per_submit} B per rank to rank 0, async on a side stream (RCCL)" if world > 1 else "none (one rank)",
                        "hipgraph": not a.no_graph, "graph_validation_repeats": len(runner.validation_reports),
-                       "two_streams": bool(two_saved) if roof is not None else None,
                        "clips_in_flight": cif, "clips_per_launch": cpl,
                        "retriever": runner.retriever_form},
             "roofline": roof,

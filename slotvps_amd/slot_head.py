@@ -21,7 +21,6 @@ mode nothing is stored below fp32 and the pixel side runs on the fp32 kernels of
 projections + LayerNorm, retriever, decode), the slot-side self-attention on explicit fp32 matrix products. One to two
 orders of magnitude slower; it exists so that the head can be compared free-running with the reference's own outputs.
 """
-import contextlib
 import copy
 import math
 
@@ -297,18 +296,6 @@ class MaskDynamicConv(nn.Module):
         c = self._fused_consts()
         return (self.retr_pos_tables(pos_tabs), c["rk"], c["rbk"], self.norm_k.eps, c["rv"], c["rbv"], self.norm_v.eps)
 
-    def compute_stats(self, feat_pm, hw, pos_tabs):
-        """The aux rows (both LayerNorm statistics per pixel) of this stage for a fused map: K3' (16-bit maps) or K3-HL (hi + lo planes).
-        They depend on the map and the weights only - not on the slots - so the head computes them ahead on its side stream."""
-        c = self._fused_consts()
-        H, W = hw
-        if feat_pm.dim() == 4:
-            # reference precision: factors AND map as fp16 hi + lo (K3-HL: three MFMAs per product)
-            tyk, txk, rbv_p, tiled = self.stats_hl_tables(pos_tabs)
-            return ops.retr_stats_hl(feat_pm, H, W, tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p, self.norm_v.eps,
-                                     tx_tiled=tiled)
-        return ops.retr_stats(feat_pm, H, W, *self.stats_args(pos_tabs))
-
     def forward_fused(self, slots, feat_pm, hw, pos_tabs, stats=None):
         """K3' + K1' (csrc/retr_stats.hip, csrc/retr_attn.hip): slots [T, L, C] fp32, feat_pm [T, H*W, C] bf16.
         `stats` = the aux rows of ops.retr_stats if already computed for this (map, stage)."""
@@ -326,8 +313,13 @@ class MaskDynamicConv(nn.Module):
             self._level_stats = None
             if pending is not None and pending[0] is feat_pm:
                 stats = pending[1]
-        if stats is None:
-            stats = self.compute_stats(feat_pm, hw, pos_tabs)
+        if hl:
+            # reference precision: factors AND map as fp16 hi + lo (K3-HL: three MFMAs per product)
+            tyk, txk, rbv_p, tiled = self.stats_hl_tables(pos_tabs)
+            stats = ops.retr_stats_hl(feat_pm, H, W, tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p, self.norm_v.eps,
+                                      tx_tiled=tiled)
+        elif stats is None:
+            stats = ops.retr_stats(feat_pm, H, W, *self.stats_args(pos_tabs))
         LP = ops.retr_slot_pad(L)
         # :431 q = norm_q(to_q(slots)); g = q * gamma_k (zero rows up to LP), c3 = q . beta_k, a1 = g . b~_k: one launch
         # The query side ends up inside logits that are sums of 256 terms of magnitude ~5 cancelling to <= 80: bf16 hi + lo operands
@@ -712,7 +704,6 @@ class MultiScaleDynamicMaskHead(nn.Module):
         self.map_dtype = "bf16"
         self.map_encoding = "auto"                       # "bf16": plain bf16 tensors for the bf16 policy (see _map_form)
         self.stats_form = "level"                        # "level": K3'' - both stages of a pyramid level from one read of the map; "stage": K3' per stage
-        self.two_streams = True                          # forward_clip: the map side (K4, statistics) ahead on a side stream (see there)
         self._cfg_mode = other_config.get("mode") if isinstance(other_config, dict) else None
         self.trans_in_dim = trans_in_dim
         self.apply_temporal_query_atten_stages = apply_temporal_query_atten_stages
@@ -924,71 +915,35 @@ class MultiScaleDynamicMaskHead(nn.Module):
         out_logits = torch.empty((n_stages, T, init_slots.shape[0], self.num_classes), dtype=torch.float32, device=slots.device) if direct else None
         out_embeds = torch.empty((n_stages, T, init_slots.shape[0], self.dh_dim), dtype=torch.float32, device=slots.device) if direct else None
         all_logits, all_embeds, fused = [], [], []
-        tabs_of = lambda i: None if pos_tabs is None else pos_tabs[i]
-        sizes = [tuple(feats[i].shape[-2:]) if feats[i].dim() == 4 else tuple(hws[i]) for i in range(self.feat_num_levels)]
-        # ---- the map side: level fusions (K4) and the LayerNorm statistics of every stage (K3) depend on the incoming maps and the weights
-        # only, not on the slots. Two streams (round 5): the map side runs AHEAD on a side stream, the slot chain (retriever K1' + slot update
-        # per stage, then the caller's decode) on the caller's stream behind one event per stage - the map side's big kernels fill the chip
-        # while the slot side's small launches and the coarse levels' short kernels leave most of it idle. Everything the side stream
-        # allocates stays referenced until the streams have joined (no block of it can be handed out again before its consumers ran).
-        fused_retr = self.precision != "fp32" and all(st.inst_interact.retriever == "fused" for i in range(self.feat_num_levels)
-                                                       for st in getattr(self, f"head_series_{i}"))
-        two = bool(getattr(self, "two_streams", True)) and fused_retr and feats[0].is_cuda
-        main = torch.cuda.current_stream(feats[0].device)
-        side = None
-        if two:
-            side = self.__dict__.get("_side_stream")
-            if side is None or side.device != feats[0].device:
-                side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=feats[0].device)
-            side.wait_stream(main)
-        keep, ready = [], []                             # tensors of the side stream; per stage (event, aux rows or None)
-        with torch.cuda.stream(side) if two else contextlib.nullcontext():
-            prev = None
-            for i in range(self.feat_num_levels):
-                h, w = sizes[i]
-                f_pm = self.fuse_level(feats[i], prev, (h, w), last=i == self.feat_num_levels - 1, pre=pre_linear)
-                series = getattr(self, f"head_series_{i}")
-                mdcs = [stage.inst_interact for stage in series]
-                aux_l = [None] * len(series)
-                if fused_retr:
-                    if (self.stats_form == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16) and f_pm.dim() == 3
-                            and all(m.precision == "bf16" for m in mdcs)):
-                        # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats2.hip;
-                        # measured 195 against 2 x 116 us at the finest level). A level with a single stage keeps K3'
-                        aux_l = list(ops.retr_stats_level(f_pm, h, w, [m.stats_args(tabs_of(i)) for m in mdcs]))
-                    elif two:
-                        aux_l = [m.compute_stats(f_pm, (h, w), tabs_of(i)) for m in mdcs]
-                ev = None
-                if two:
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                keep.append((f_pm, aux_l))
-                for a_ in aux_l:
-                    ready.append((ev, a_))
-                prev = f_pm
-                fused.append(f_pm)
-        # ---- the slot chain
+        prev = None
         stage_idx = 0
         for i in range(self.feat_num_levels):
-            h, w = sizes[i]
-            f_pm = fused[i]
-            for stage in getattr(self, f"head_series_{i}"):
-                ev, aux = ready[stage_idx]
-                if ev is not None:
-                    main.wait_event(ev)
-                if aux is not None:
-                    stage.inst_interact._level_stats = (f_pm, aux)
+            if feats[i].dim() == 4:
+                h, w = feats[i].shape[-2:]
+            else:
+                h, w = hws[i]
+            f_pm = self.fuse_level(feats[i], prev, (h, w), last=i == self.feat_num_levels - 1, pre=pre_linear)
+            series = getattr(self, f"head_series_{i}")
+            mdcs = [stage.inst_interact for stage in series]
+            if (self.stats_form == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16) and f_pm.dim() == 3
+                    and all(m.precision == "bf16" and m.retriever == "fused" for m in mdcs)):
+                # K3'': the LayerNorm statistics of both stages of this level from ONE read of the fused map (csrc/retr_stats2.hip;
+                # measured 195 against 2 x 116 us at the finest level); each stage's retriever picks its rows up in forward_fused.
+                # A level with a single stage keeps K3'
+                tabs_i = None if pos_tabs is None else pos_tabs[i]
+                for m, aux in zip(mdcs, ops.retr_stats_level(f_pm, h, w, [m.stats_args(tabs_i) for m in mdcs])):
+                    m._level_stats = (f_pm, aux)
+            for stage in series:
                 enable = stage_idx in self.apply_temporal_query_atten_stages
-                logits, slots = stage.forward_pm(slots, f_pm, (h, w), tabs_of(i), enable, clips,
+                logits, slots = stage.forward_pm(slots, f_pm, (h, w), None if pos_tabs is None else pos_tabs[i], enable, clips,
                                                  out_cls=out_logits[stage_idx] if direct else None,
                                                  out_emb=out_embeds[stage_idx] if direct else None)
                 slots = slots.detach()
                 all_logits.append(logits)
                 all_embeds.append(slots)
                 stage_idx += 1
-        if two:
-            main.wait_stream(side)                       # (every event above already orders the work; this joins the capture / the allocator's view)
-        del keep, ready
+            prev = f_pm
+            fused.append(f_pm)
         if direct and all(t.data_ptr() == out_logits[j].data_ptr() for j, t in enumerate(all_logits)) \
                 and all(t.data_ptr() == out_embeds[j].data_ptr() for j, t in enumerate(all_embeds)):
             return out_logits, out_embeds, fused
