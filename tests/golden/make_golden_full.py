@@ -10,6 +10,7 @@ Cases (weights / inputs / slots regenerated from the seeds by slotvps_amd.synth;
                            2 - 4 x per stage and the reference's own fp32 result sits ~1e-3 from its float64 evaluation - the per-stage
                            (teacher-forced) errors are the meaningful numbers here, the free-running ones are bounded by that floor
   T2_1088x1920_L200        config 5's geometry (VIPER 1080 x 1920 padded, 200 slots, 24 classes, level sizes 34x60 ... 272x480), tempered
+  T2_1024x2048_L100_swin   config 4's head (Swin-L config: ReLU in the stage feed-forward block, GELU in the temporal head), tempered
 
 Per case: per-stage slot embeddings [T, 7, L, 256] and class logits [T, 7, L, nc]; of the decode of EVERY frame (its own last-stage
 embeddings, its own finest fused map): the uint8 per-pixel slot argmax [T, HW], the top-2 margin as fp16 [T, HW], a strided sample of
@@ -44,12 +45,15 @@ CASES = {   # tag: (T, H, W, L, num_classes, seed, tau, (sy, sx) mask sample str
     "T5_1024x2048_L100": (5, 1024, 2048, 100, 20, 501, 0.25, (8, 16)),
     "T2_1024x2048_L100_sharp": (2, 1024, 2048, 100, 20, 502, 1.0, (8, 16)),
     "T2_1088x1920_L200": (2, 1088, 1920, 200, 24, 503, 0.25, (8, 16)),
+    "T2_1024x2048_L100_swin": (2, 1024, 2048, 100, 20, 504, 0.25, (8, 16)),
 }
+# head-config overrides per case (the Swin-L config's head: ReLU in the stage FFN, GELU in the temporal head - swinL_fpn_slotvps.py:41)
+CFG_OVERRIDES = {"T2_1024x2048_L100_swin": dict(activation="relu", temporal_activation="gelu")}
 FUSED3_STRIDE, FUSED0_STRIDE = 16, 4
 
 
-def build_head(dmh, nc):
-    cfg = synth.R50_HEAD_CFG
+def build_head(dmh, nc, over=None):
+    cfg = dict(synth.R50_HEAD_CFG, **(over or {}))
     return dmh.MultiScaleDynamicMaskHead(
         dh_dim=D, num_classes=nc, dim_feedforward=cfg["dim_feedforward"], nhead=cfg["nhead"],
         dropout=0.0, activation=cfg["activation"], dh_num_heads=7, per_dh_num_heads=list(cfg["per_dh_num_heads"]),
@@ -60,9 +64,9 @@ def build_head(dmh, nc):
         apply_temporal_query_atten_stages=list(cfg["apply_temporal_query_atten_stages"])).eval()
 
 
-def run(dmh, pos_mod, NestedTensor, case, dt):
+def run(dmh, pos_mod, NestedTensor, case, dt, over=None):
     T, H, W, L, nc, seed, tau, _ = case
-    head = build_head(dmh, nc)
+    head = build_head(dmh, nc, over)
     params = synth.temper_queries(synth.make_params(synth.head_shapes(dict(synth.R50_HEAD_CFG, num_classes=nc)), seed), tau)
     mg.load_state(head, params)
     head = head.to(dt)
@@ -111,7 +115,9 @@ def main():
     for tag, case in CASES.items():
         T, H, W, L, nc, seed, tau, (sy, sx) = case
         t0 = time.time()
-        E, C, M, fused = run(dmh, pos_mod, NestedTensor, case, torch.float32)
+        over = CFG_OVERRIDES.get(tag)
+        E, C, M, fused = run(dmh, pos_mod, NestedTensor, case, torch.float32, over)
+        out[f"{tag}_cfg"] = np.array(repr(sorted((over or {}).items())))
         h3, w3 = M.shape[-2:]
         srt = M.topk(2, dim=1)
         out[f"{tag}_meta"] = np.array([T, H, W, L, nc, seed, sy, sx, FUSED3_STRIDE, FUSED0_STRIDE], dtype=np.int64)
@@ -149,7 +155,7 @@ def main():
         t1 = time.time()
         am32 = srt.indices[:, 0].clone()
         del fused, srt
-        E64, C64, M64, fused64 = run(dmh, pos_mod, NestedTensor, case, torch.float64)
+        E64, C64, M64, fused64 = run(dmh, pos_mod, NestedTensor, case, torch.float64, over)
         del fused64
         fl_e = [(E.double()[:, s] - E64[:, s]).abs().max().item() for s in range(7)]
         fl_c = [(C.double()[:, s] - C64[:, s]).abs().max().item() for s in range(7)]

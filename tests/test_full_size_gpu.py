@@ -1,6 +1,6 @@
 """Parity at BASELINE.json's sizes against the REFERENCE ITSELF (tests/golden/head_full.npz: outputs of the imported
 MultiScaleDynamicMaskHead, dynamic_mask_head.py:138-228, and of generate_final_outputs, vps_temporal_slots.py:144-160, at
-1024 x 2048 T = 5 / 100 slots and at the VIPER geometry 1088 x 1920 / 200 slots; tests/golden/make_golden_full.py).
+1024 x 2048 T = 5 / 100 slots, at the VIPER geometry 1088 x 1920 / 200 slots and with the Swin-L config's head; tests/golden/make_golden_full.py).
 
 Every mode of the head (MultiScaleDynamicMaskHead.MODES) runs the whole hot path - four level fusions, seven stages, decode of every
 frame - free-running and teacher-forced per stage (stage s fed the reference's stage s - 1 embeddings) through the C ABI; the numbers
@@ -55,6 +55,11 @@ BOUNDS = {
     ("fp32", "T2_1088x1920_L200"): dict(mask=1e-4, tf=1e-4, eq=0.9995, contract=True),
     ("fp16", "T2_1088x1920_L200"): dict(mask=4e-3, tf=8e-3, eq=0.99, contract=False),
     ("bf16", "T2_1088x1920_L200"): dict(mask=3e-2, tf=6e-2, eq=0.93, contract=False),
+    # the Swin-L config's head (ReLU feed-forward block, GELU temporal head; BASELINE config 4)
+    ("fp16x2", "T2_1024x2048_L100_swin"): dict(mask=1e-4, tf=1e-4, eq=0.9995, contract=True),
+    ("fp32", "T2_1024x2048_L100_swin"): dict(mask=1e-4, tf=1e-4, eq=0.9995, contract=True),
+    ("fp16", "T2_1024x2048_L100_swin"): dict(mask=4e-3, tf=8e-3, eq=0.99, contract=False),
+    ("bf16", "T2_1024x2048_L100_swin"): dict(mask=3e-2, tf=6e-2, eq=0.93, contract=False),
 }
 
 

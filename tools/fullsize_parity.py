@@ -20,7 +20,7 @@ if ROOT not in sys.path:
 from slotvps_amd import synth  # noqa: E402
 
 FIXTURE = os.path.join(ROOT, "tests", "golden", "head_full.npz")
-CASES = ("T5_1024x2048_L100", "T2_1024x2048_L100_sharp", "T2_1088x1920_L200")
+CASES = ("T5_1024x2048_L100", "T2_1024x2048_L100_sharp", "T2_1088x1920_L200", "T2_1024x2048_L100_swin")
 # the north star's contract: 1e-4 on the float mask logits, the integer slot argmax identical wherever the reference's own top-2 margin
 # exceeds DECIDABLE_FACTOR x the measured mask-logit error (below that a pixel's argmax is not determined by values known to +-error)
 TOL_MASK = 1e-4
@@ -31,7 +31,9 @@ def load_case(tag, fixture=FIXTURE):
     z = np.load(fixture)
     T, H, W, L, nc, seed, sy, sx, s3, s0 = (int(x) for x in z[f"{tag}_meta"])
     tau = float(z[f"{tag}_tau"])
-    cfg = dict(synth.R50_HEAD_CFG, num_classes=nc)
+    import ast
+    over = dict(ast.literal_eval(str(z[f"{tag}_cfg"]))) if f"{tag}_cfg" in z.files else {}      # head-config overrides of the case (Swin-L head)
+    cfg = dict(synth.R50_HEAD_CFG, num_classes=nc, **over)
     params = synth.temper_queries(synth.make_params(synth.head_shapes(cfg), seed), tau)
     feats = synth.make_clip_features(seed + 1, T, H, W)
     feats = [np.stack([feats[t][i] for t in range(T)]) for i in range(4)]          # per level [T, 128, h, w]
