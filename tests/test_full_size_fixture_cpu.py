@@ -34,7 +34,7 @@ def test_fixture_records_the_reference_floor():
 def test_oracle_coarse_levels_against_the_full_size_fixture(tag):
     case = fsp.load_case(tag)
     ref = case["ref"]
-    cfg = dict(per_level_stages=(1, 2))
+    cfg = dict(per_level_stages=(1, 2), activation=case["cfg"]["activation"], temporal_activation=case["cfg"]["temporal_activation"])
     feats = [[case["feats"][i][0] for i in range(2)]]                       # frame 0, levels 0 and 1
     pos = [orc.pos_embed_sine(h, w) for (h, w) in case["sizes"][:2]]
     logits, embeds, fused = orc.head_forward(feats, case["slots"], pos, case["params"], cfg=cfg, dt=np.float64)
