@@ -61,6 +61,11 @@ struct StatsHlLds {
     static constexpr int xt = 0;                     // [3 slots][hi, lo][16 KiB]
     static constexpr int part = kSlots * 2 * plane;  // [2 buffers][key, value][4 waves][32 px] float
     static constexpr int total = part + 2 * 2 * 4 * 32 * 4;
+    // TILED tables only (round 5): the start values come through LDS as well, so that no wave waits on an L2 round trip
+    static constexpr int tabx = total;               // [4 key waves][2 row blocks][4 g][1 KiB: lane's 16 bytes]  Tx' of the NEXT tile
+    static constexpr int taby = tabx + 4 * 8192;     // [4 key waves][1 KiB: 16 chunks (block, h, g), repeated]     Ty' of the next tile's row
+    static constexpr int rbv = taby + 4 * 1024;      // [256] r_v' (constant)
+    static constexpr int total_tables = rbv + 1024;
 };
 
 // asm LDS-DMA (invisible to hipcc's wait counting: the builtin form is drained with s_waitcnt vmcnt(0) before the next LDS read)
@@ -105,7 +110,7 @@ struct StatsHlArgs {
 
 // accumulator order: column 32 RB + 16 h + 4 g + j of a table row <-> factor row 32 RB + 8 g + 4 h + j (register 4 g + j of lane half h)
 // One wave = (projection KEY / value, quarter J): row blocks J and 7 - J of that projection's factor, hi and lo (144 registers).
-template <int J, bool KEY>
+template <int J, bool KEY, bool TLDS>
 __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, int lane) {
     constexpr int KA = 2 * J, NA = 16 - KA;          // row block J: k-steps KA .. 15
     constexpr int KB = 14 - 2 * J, NB = 16 - KB;     // row block 7 - J: k-steps KB .. 15
@@ -273,9 +278,64 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (!TLDS) {
+            float ss = sumsq(ca) + sumsq(cb);
+            ss += __shfl_xor(ss, 32);
+            if (h == 0) part[(cur * 2 + (KEY ? 0 : 1)) * 128 + J * 32 + r] = ss;
+        }
+    };
+    // (TLDS) the sums of squares of `tile`'s finished chains - in the wave's LIGHT half-period, under the other wave's chain
+    auto sums = [&](int tile) {
+        const int cur = (tile - tile0) & 1;
         float ss = sumsq(ca) + sumsq(cb);
         ss += __shfl_xor(ss, 32);
         if (h == 0) part[(cur * 2 + (KEY ? 0 : 1)) * 128 + J * 32 + r] = ss;
+    };
+    // (TLDS) the tables of a tile by LDS-DMA into this key wave's own 9 KiB: eight 1-KiB pieces of the tiled Tx' (row block, g: exactly
+    // the lanes' 16 bytes in lane order) and the sixteen 16-byte chunks (block, h, g) of the row's Ty'. No registers, no wait: they are
+    // requested one period before start_values_lds reads them back (same wave: vmcnt alone orders it).
+    const u32x4 srd_tx = shl_make_srd(a.txk, (uint32_t)a.tx_rows * 1024u);
+    const u32x4 srd_ty = shl_make_srd(a.tyk, (uint32_t)a.ty_rows * 1024u);
+    const int vty = (((lane & 8) ? RBB : RBA) * 32 + (lane & 7) * 4) * 4;
+    auto request_tables = [&](int tile) {
+        const int gp0 = tile * kTilePx;
+        const int y = gp0 / a.W, xt = (gp0 - y * a.W) >> 5;
+        const uint32_t dx = __builtin_amdgcn_readfirstlane(lds0 + StatsHlLds::tabx + J * 8192);
+        const int sx = __builtin_amdgcn_readfirstlane(xt * 32768);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            shl_dma16(srd_tx, dx + g * 1024, lane * 16, sx + (RBA * 4 + g) * 1024);
+            shl_dma16(srd_tx, dx + (4 + g) * 1024, lane * 16, sx + (RBB * 4 + g) * 1024);
+        }
+        const int sy = __builtin_amdgcn_readfirstlane((y < a.ty_rows ? y : a.ty_rows - 1) * 1024);
+        shl_dma16(srd_ty, __builtin_amdgcn_readfirstlane(lds0 + StatsHlLds::taby + J * 1024), vty, sy);
+    };
+    auto start_values_lds = [&]() {
+        if constexpr (KEY) {
+            const char* bx = smem + StatsHlLds::tabx + J * 8192 + lane * 16;
+            const char* by = smem + StatsHlLds::taby + J * 1024 + h * 64;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 xa = *reinterpret_cast<const f32x4*>(bx + g * 1024), xb = *reinterpret_cast<const f32x4*>(bx + (4 + g) * 1024);
+                const f32x4 ya = *reinterpret_cast<const f32x4*>(by + g * 16), yb = *reinterpret_cast<const f32x4*>(by + 128 + g * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ca[4 * g + j] = ya[j] + xa[j];
+                    cb[4 * g + j] = yb[j] + xb[j];
+                }
+            }
+        } else {
+            const char* bv = smem + StatsHlLds::rbv + h * 64;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ra_ = *reinterpret_cast<const f32x4*>(bv + RBA * 128 + g * 16), rb_ = *reinterpret_cast<const f32x4*>(bv + RBB * 128 + g * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ca[4 * g + j] = ra_[j];
+                    cb[4 * g + j] = rb_[j];
+                }
+            }
+        }
     };
 
     // PING-PONG (two barriers per tile): in the first half-period the key waves run their chain while the value waves of the same SIMDs
@@ -284,6 +344,66 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
     // Landing of a tile: a wave's requests for tile + 2 are OLDER than the start-value loads of its next light phase, whose wait
     // (vmcnt retires in order) therefore covers them - one half-period before the first chain reads the tile; the explicit
     // s_waitcnt below states it.
+    if constexpr (TLDS) {
+        // Round 5 (tiled tables): the start values through LDS too (requested a period ahead), and each wave's sums of squares moved
+        // into ITS LIGHT half - a half-period is then the bare chain (54 MFMAs) beside ~1 000 cycles of light work.
+        //   half A of tile: key chain(tile)   | value: sums(tile - 1), constants, landing wait, request(tile + 2), finish(tile - 2)
+        //   half B of tile: value chain(tile) | key:   sums(tile), landing wait, start values of tile + 1 from LDS, requests of tile + 2
+        request(tile0);
+        if (tile0 + 1 < tile1) request(tile0 + 1);
+        if constexpr (KEY) request_tables(tile0);
+        if (threadIdx.x < 256) reinterpret_cast<float*>(smem + StatsHlLds::rbv)[threadIdx.x] = a.rbv[threadIdx.x];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (KEY) {
+            start_values_lds();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (tile0 + 1 < tile1) request_tables(tile0 + 1);
+        }
+        for (int tile = tile0; tile < tile1; ++tile) {
+            SHL_STAMP(0);
+            if constexpr (KEY) {
+                heavy(tile);
+            } else {
+                if (tile > tile0) sums(tile - 1);
+                start_values_lds();
+                SHL_STAMP(1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile + 1 have landed (requested a period ago)
+                if (tile + 2 < tile1 && !(SVPS_SHL_ABL & 4)) request(tile + 2);
+                SHL_STAMP(2);
+                if (J == 0 && tile >= tile0 + 2 && !(SVPS_SHL_ABL & 8)) finish(tile - 2);
+            }
+            SHL_STAMP(3);
+            __syncthreads();
+            SHL_STAMP(4);
+            if constexpr (KEY) {
+                sums(tile);
+                SHL_STAMP(5);
+                if (tile + 1 < tile1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tables and this wave's pieces of tile + 1 have landed
+                    start_values_lds();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and are in registers before the next requests overwrite them
+                    if (tile + 2 < tile1) {
+                        request_tables(tile + 2);
+                        if (!(SVPS_SHL_ABL & 4)) request(tile + 2);
+                    }
+                }
+                SHL_STAMP(6);
+            } else {
+                heavy(tile);
+                SHL_STAMP(5);
+            }
+            SHL_STAMP(7);
+            __syncthreads();
+        }
+        if constexpr (!KEY) {
+            sums(tile1 - 1);
+            if (J == 0 && tile1 - tile0 >= 2 && !(SVPS_SHL_ABL & 8)) finish(tile1 - 2);
+        }
+        __syncthreads();
+        if (!KEY && J == 0 && !(SVPS_SHL_ABL & 8)) finish(tile1 - 1);
+        return;
+    }
     request(tile0);
     if (tile0 + 1 < tile1) request(tile0 + 1);
     if constexpr (KEY) start_values(tile0);
@@ -322,20 +442,21 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
     if (!KEY && J == 0 && !(SVPS_SHL_ABL & 8)) finish(tile1 - 1);
 }
 
+template <bool TLDS>
 __global__ __launch_bounds__(512) void retr_stats_hl_kernel(StatsHlArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     // waves w and w + 4 share a SIMD: the key and the value wave of one quarter - while one waits (tables, tile loads, sums) the other
     // has MFMAs to issue
     switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-        case 0: stats_hl_role<0, true>(a, smem, lane); break;
-        case 1: stats_hl_role<1, true>(a, smem, lane); break;
-        case 2: stats_hl_role<2, true>(a, smem, lane); break;
-        case 3: stats_hl_role<3, true>(a, smem, lane); break;
-        case 4: stats_hl_role<0, false>(a, smem, lane); break;
-        case 5: stats_hl_role<1, false>(a, smem, lane); break;
-        case 6: stats_hl_role<2, false>(a, smem, lane); break;
-        default: stats_hl_role<3, false>(a, smem, lane); break;
+        case 0: stats_hl_role<0, true, TLDS>(a, smem, lane); break;
+        case 1: stats_hl_role<1, true, TLDS>(a, smem, lane); break;
+        case 2: stats_hl_role<2, true, TLDS>(a, smem, lane); break;
+        case 3: stats_hl_role<3, true, TLDS>(a, smem, lane); break;
+        case 4: stats_hl_role<0, false, TLDS>(a, smem, lane); break;
+        case 5: stats_hl_role<1, false, TLDS>(a, smem, lane); break;
+        case 6: stats_hl_role<2, false, TLDS>(a, smem, lane); break;
+        default: stats_hl_role<3, false, TLDS>(a, smem, lane); break;
     }
 }
 
@@ -359,13 +480,21 @@ extern "C" int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, 
     chunks = (tiles + tpw - 1) / tpw;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     using H16 = _Float16;
-    static SvpsLdsAttr attr;
-    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(svps::retr_stats_hl_kernel), svps::StatsHlLds::total); ae != hipSuccess) return (int)ae;
+    static const bool no_tlds = [] { const char* e = getenv("SVPS_SHL_TLDS"); return e && e[0] == '0'; }();
+    const bool tlds = tx_tiled && ty_rows == H && !no_tlds;
+    static SvpsLdsAttr attr, attr_t;
+    if (hipError_t ae = tlds ? attr_t.ensure(reinterpret_cast<const void*>(svps::retr_stats_hl_kernel<true>), svps::StatsHlLds::total_tables)
+                             : attr.ensure(reinterpret_cast<const void*>(svps::retr_stats_hl_kernel<false>), svps::StatsHlLds::total);
+        ae != hipSuccess)
+        return (int)ae;
     const svps::StatsHlArgs args{static_cast<const H16*>(feat_hi), static_cast<const H16*>(feat_lo), static_cast<const H16*>(rk_hi),
                                  static_cast<const H16*>(rk_lo), static_cast<const H16*>(rv_hi), static_cast<const H16*>(rv_lo), tyk, txk, rbv,
                                  static_cast<H16*>(aux), lnk_eps, lnv_eps, HW, W, ty_rows, tx_rows, tpw, tx_tiled ? 1 : 0};
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 0, stream);
-    hipLaunchKernelGGL(svps::retr_stats_hl_kernel, dim3(chunks, T), dim3(512), svps::StatsHlLds::total, stream, args);
+    if (tlds)
+        hipLaunchKernelGGL(svps::retr_stats_hl_kernel<true>, dim3(chunks, T), dim3(512), svps::StatsHlLds::total_tables, stream, args);
+    else
+        hipLaunchKernelGGL(svps::retr_stats_hl_kernel<false>, dim3(chunks, T), dim3(512), svps::StatsHlLds::total, stream, args);
     svps_prof_mark(SVPS_KERNEL_RETR_STATS, 1, stream);
     return (int)hipGetLastError();
 }
