@@ -33,8 +33,12 @@
                             // parity goes from the reference's own reproducibility (mask logits 8.7e-6, stages <= 2.7e-5) to 2.9e-5 / 4.9e-5 (sharp
                             // case 3.3e-4 -> 8.1e-4): inside the tolerance, not adopted - the mode's point is to be indistinguishable from the reference
 #endif
+#ifndef SVPS_SHL_PRIO
+#define SVPS_SHL_PRIO 1     // tiled-tables form: 1 = s_setprio 1 around each chain, 2 = static s_setprio 1 for the value waves (the younger half), 0 none
+#endif
 #ifndef SVPS_SHL_ABL
-#define SVPS_SHL_ABL 0      // timing-only ablations (wrong results): 1 no table loads, 2 no MFMAs, 4 no global tile loads, 8 no finish
+#define SVPS_SHL_ABL 0      // timing-only ablations (wrong results): 1 no table loads, 2 no MFMAs, 4 no global tile loads, 8 no finish,
+                            // (tiled tables) 16 no start values in the loop, 32 no sums of squares, 64 no table requests in the loop
 #endif
 
 namespace svps {
@@ -135,6 +139,10 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
         }
     }
     const int tiles = (a.HW + kTilePx - 1) / kTilePx;
+    // (TLDS) a workgroup walks its tiles COLUMN-major - sequence number s -> image row s % H, 32-pixel column s / H - so that the Tx'
+    // values of its tiles change once per H tiles instead of every tile (a tile is 16 contiguous KiB either way)
+    const int rows = a.HW / a.W, wt = a.W >> 5;
+    auto where = [&](int s) { return TLDS ? (s % rows) * wt + s / rows : s; };
     const int tile0 = blockIdx.x * a.tiles_per_wg;
     int tile1 = tile0 + a.tiles_per_wg;
     tile1 = tile1 < tiles ? tile1 : tiles;
@@ -152,7 +160,7 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
     auto request = [&](int tile) {
         const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + StatsHlLds::xt + ((tile - tile0) % 3) * 2 * StatsHlLds::plane +
                                                             (KEY ? 0 : StatsHlLds::plane) + J * 4096);
-        const int soff = __builtin_amdgcn_readfirstlane(tile * kTileBytes);
+        const int soff = __builtin_amdgcn_readfirstlane(where(tile) * kTileBytes);
 #pragma unroll
         for (int i = 0; i < 4; ++i) shl_dma16(srd, dst + i * 1024, voff[i], soff);
     };
@@ -176,7 +184,7 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
         row[1] = (uint32_t)__builtin_bit_cast(uint16_t, sl);
         row[2] = __float_as_uint(rk);
         row[3] = __float_as_uint(rv);
-        const int gp = tile * kTilePx + r;
+        const int gp = where(tile) * kTilePx + r;
         if (h == 0 && gp < a.HW) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.aux) + ((size_t)t * a.HW + gp) * 16) = row;
     };
     auto sumsq = [&](const f32x16& acc) {
@@ -259,6 +267,7 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
             fh[(K0 + 1) % 3] = frag(xh, K0 + 1);
             fl[(K0 + 1) % 3] = frag(xl, K0 + 1);
         }
+        if (TLDS && SVPS_SHL_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = K0; ks < 16; ++ks) {
             if (ks + 2 < 16) {
@@ -278,6 +287,7 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (TLDS && SVPS_SHL_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if constexpr (!TLDS) {
             float ss = sumsq(ca) + sumsq(cb);
             ss += __shfl_xor(ss, 32);
@@ -298,14 +308,15 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
     const u32x4 srd_ty = shl_make_srd(a.tyk, (uint32_t)a.ty_rows * 1024u);
     const int vty = (((lane & 8) ? RBB : RBA) * 32 + (lane & 7) * 4) * 4;
     auto request_tables = [&](int tile) {
-        const int gp0 = tile * kTilePx;
-        const int y = gp0 / a.W, xt = (gp0 - y * a.W) >> 5;
-        const uint32_t dx = __builtin_amdgcn_readfirstlane(lds0 + StatsHlLds::tabx + J * 8192);
-        const int sx = __builtin_amdgcn_readfirstlane(xt * 32768);
+        const int xt = tile / rows, y = tile - xt * rows;
+        if (tile == tile0 || y == 0) {               // a new 32-pixel column: its Tx' (otherwise the ones in LDS stay)
+            const uint32_t dx = __builtin_amdgcn_readfirstlane(lds0 + StatsHlLds::tabx + J * 8192);
+            const int sx = __builtin_amdgcn_readfirstlane(xt * 32768);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            shl_dma16(srd_tx, dx + g * 1024, lane * 16, sx + (RBA * 4 + g) * 1024);
-            shl_dma16(srd_tx, dx + (4 + g) * 1024, lane * 16, sx + (RBB * 4 + g) * 1024);
+            for (int g = 0; g < 4; ++g) {
+                shl_dma16(srd_tx, dx + g * 1024, lane * 16, sx + (RBA * 4 + g) * 1024);
+                shl_dma16(srd_tx, dx + (4 + g) * 1024, lane * 16, sx + (RBB * 4 + g) * 1024);
+            }
         }
         const int sy = __builtin_amdgcn_readfirstlane((y < a.ty_rows ? y : a.ty_rows - 1) * 1024);
         shl_dma16(srd_ty, __builtin_amdgcn_readfirstlane(lds0 + StatsHlLds::taby + J * 1024), vty, sy);
@@ -360,16 +371,24 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (tile0 + 1 < tile1) request_tables(tile0 + 1);
         }
+        if (!KEY && SVPS_SHL_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         for (int tile = tile0; tile < tile1; ++tile) {
             SHL_STAMP(0);
             if constexpr (KEY) {
                 heavy(tile);
             } else {
-                if (tile > tile0) sums(tile - 1);
-                start_values_lds();
+                // tile + 2 is requested at the TOP of the light half, before the landing wait of tile + 1 (its ring slot was last read
+                // by the chains of tile - 1): two tiles in flight per CU. With the request after the wait (one tile in flight) the
+                // loads took longer than a period to land and both light halves ended in ~1 100 cycles of vmcnt wait.
+                const bool ahead = tile + 2 < tile1 && !(SVPS_SHL_ABL & 4);
+                if (ahead) request(tile + 2);
+                if (tile > tile0 && !(SVPS_SHL_ABL & 32)) sums(tile - 1);
+                if (!(SVPS_SHL_ABL & 16)) start_values_lds();
                 SHL_STAMP(1);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile + 1 have landed (requested a period ago)
-                if (tile + 2 < tile1 && !(SVPS_SHL_ABL & 4)) request(tile + 2);
+                // this wave's pieces of tile + 1 (requested a period ago) have landed; the four requests above stay in flight
+                // (before the finish: its store counts in vmcnt as well)
+                if (ahead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 SHL_STAMP(2);
                 if (J == 0 && tile >= tile0 + 2 && !(SVPS_SHL_ABL & 8)) finish(tile - 2);
             }
@@ -377,16 +396,17 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
             __syncthreads();
             SHL_STAMP(4);
             if constexpr (KEY) {
-                sums(tile);
+                const bool ahead = tile + 2 < tile1 && !(SVPS_SHL_ABL & 4);
+                if (ahead) request(tile + 2);
+                if (!(SVPS_SHL_ABL & 32)) sums(tile);
                 SHL_STAMP(5);
                 if (tile + 1 < tile1) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tables and this wave's pieces of tile + 1 have landed
-                    start_values_lds();
+                    // the tables of tile + 1 and (older) this wave's pieces of tile + 1 have landed
+                    if (ahead) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!(SVPS_SHL_ABL & 16)) start_values_lds();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and are in registers before the next requests overwrite them
-                    if (tile + 2 < tile1) {
-                        request_tables(tile + 2);
-                        if (!(SVPS_SHL_ABL & 4)) request(tile + 2);
-                    }
+                    if (tile + 2 < tile1 && !(SVPS_SHL_ABL & 64)) request_tables(tile + 2);
                 }
                 SHL_STAMP(6);
             } else {
