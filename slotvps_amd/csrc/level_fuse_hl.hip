@@ -35,6 +35,20 @@
 
 namespace svps {
 
+#ifdef SVPS_K4HL_STAMP
+// diagnostic build only (tools/k4hl_stamps.py): s_memtime stamps of waves 0 and 4 of one workgroup, tiles 8 .. 15
+__device__ unsigned long long k4hl_stamps[2][8][8];          // [wave 0 / 4][tile - 8][point]
+#define K4HL_STAMP(pt)                                                                                              \
+    do {                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && (w & 3) == 0 && it >= 8 && it < 16 && lane == 0)                  \
+            k4hl_stamps[w >> 2][it - 8][pt] = __builtin_amdgcn_s_memtime();                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    } while (0)
+#else
+#define K4HL_STAMP(pt) do {} while (0)
+#endif
+
 constexpr int kHlK = 128;                        // incoming channels: the contraction at the fine resolution
 constexpr int kHlRowBytes = kHlK * 2;            // 256 B per pixel row of an operand tile (16 chunks of 16 B)
 
@@ -44,9 +58,10 @@ struct FuseHlLds {
     static constexpr int o_hi = 2 * kTilePx * kHlRowBytes;          // [32][256] fp16 out tiles
     static constexpr int o_lo = o_hi + kTileBytes;
     static constexpr int o_f32 = o_lo + kTileBytes;                 // [32][256] fp32 copy (rows of 1 KiB, 16-B chunks swizzled)
-    static constexpr int gtile = o_f32 + 2 * kTileBytes;            // staged taps of g: [2 source rows][18 source columns][1 KiB + 16]
+    static constexpr int gtile = o_f32 + 2 * kTileBytes;            // staged taps of g: [3 source rows (row % 3)][18 source columns][1 KiB + 16]
     static constexpr int kGCols = 18, kGRow = 1024 + 16;            // (padded: the lanes of a wave read different columns at the same channel)
-    static constexpr int total = gtile + 2 * kGCols * kGRow;
+    static constexpr int kGRows = 3;                                // a ring: walking down a column strip, two output rows share their source rows
+    static constexpr int total = gtile + kGRows * kGCols * kGRow;
 };
 static_assert(FuseHlLds::total <= 160 * 1024, "LDS layout");
 
@@ -62,9 +77,25 @@ __device__ __forceinline__ void hl_split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
+// The same for a PAIR of values (round 5): on gfx950 the vector forms compile to packed instructions - v_cvt_pk_f16_f32, v_pk_add_f32 (and
+// v_pk_fma_f32 for the blend below) - two values per issue slot; this kernel is bound by vector issue (12 VALU per MFMA before).
+typedef __attribute__((ext_vector_type(2))) float hl_f32x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 hl_f16x2;
+__device__ __forceinline__ void hl_split2(hl_f32x2 x, hl_f16x2& hi, hl_f16x2& lo) {
+    x[0] = __builtin_amdgcn_fmed3f(x[0], -65504.f, 65504.f);
+    x[1] = __builtin_amdgcn_fmed3f(x[1], -65504.f, 65504.f);
+    asm volatile("" : "+v"(x));          // ONE fp32 pair for both halves (see hl_split)
+    hi = __builtin_convertvector(x, hl_f16x2);
+    lo = __builtin_convertvector(x - __builtin_convertvector(hi, hl_f32x2), hl_f16x2);
+}
+
 // STAGED (TAPS, W % 32 == 0: a tile is 32 pixels of ONE output row): the two source rows x <= 18 source columns of g the tile blends arrive
-// as whole 1-KiB rows (36 coalesced wave loads per tile instead of 16 loads per LANE that each touch 64 sectors - those were 46 % of
-// the kernel), one tile ahead through 20 registers, and every lane reads its four taps from LDS.
+// as whole 1-KiB rows (coalesced wave loads instead of 16 loads per LANE that each touch 64 sectors - those were 46 % of the kernel),
+// two tiles ahead through 20 registers, and every lane reads its four taps from LDS. A workgroup walks DOWN a 32-pixel column strip
+// (round 5; tile sequence number s -> strip s / H, output row s % H): two consecutive output rows blend the same two source rows and
+// the next pair needs ONE new row, so the rows live in a ring of three and a tile stages 18 rows of 1 KiB every other tile instead of
+// 36 every tile (s_memtime stamps, tools/k4hl_stamps.py: issuing those loads behind the previous tile's stores was 1 000 - 3 000 of
+// a tile's 7 500 cycles, and the younger waves held everyone at the second barrier).
 // PLANES = false (round 5): only the fp32 result is written - the launches that produce G^(m) = f W_a^m^T for the finer levels (see
 // svps_level_fuse_hl_fwd below); the fp32 value is then the unsplit sum itself.
 template <bool TAPS, bool F32OUT, bool STAGED = false, bool PLANES = true>
@@ -88,10 +119,24 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     const int HW = H * W;
     const int Hp = H >> 1, Wp = W >> 1;
 
-    const int px_begin = c * tiles_per_chunk * kTilePx;
+    const int px_begin = c * tiles_per_chunk * kTilePx;            // row-major forms: the chunk is a run of pixels
     int px_end = px_begin + tiles_per_chunk * kTilePx;
     px_end = px_end < HW ? px_end : HW;
-    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+    int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+    const int s_begin = c * tiles_per_chunk;                       // STAGED: a run of tile sequence numbers (column strips, all tiles full)
+    if constexpr (STAGED) {
+        px_end = HW;
+        const int left = H * (W >> 5) - s_begin;
+        nt = left < tiles_per_chunk ? left : tiles_per_chunk;
+    }
+    auto tile_px0 = [&](int tile) {                                // first pixel of the workgroup's tile number `tile`
+        if constexpr (STAGED) {
+            const int sq = s_begin + tile, strip = sq / H;
+            return (sq - strip * H) * W + 32 * strip;
+        } else {
+            return px_begin + tile * kTilePx;
+        }
+    };
 
     // ---- weight block of this wave: rows 32w .. 32w+31, 8 k-steps, hi and lo
     f16x8 wfh[8], wfl[8];
@@ -119,7 +164,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     f32x4 c0[2], c1[2];
     auto fetch = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
-        const int pp = px_begin + tile * kTilePx + 4 * pg;                 // c0: channel ch, c1: channel ch + 1, pixels pp .. pp + 3
+        const int pp = tile_px0(tile) + 4 * pg;                            // c0: channel ch, c1: channel ch + 1, pixels pp .. pp + 3
         if (pp + 4 <= HW && aligned) {
             c0[P] = *reinterpret_cast<const f32x4*>(src + pp);
             c1[P] = *reinterpret_cast<const f32x4*>(src + HW + pp);
@@ -133,27 +178,24 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     };
     auto commit = [&](auto par) {
         constexpr int P = decltype(par)::value;
-        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 4 * pg + j;
-            f16x2_t vh, vl;
-            _Float16 h0_, l0_, h1_, l1_;
-            hl_split(c0[P][j], h0_, l0_);
-            hl_split(c1[P][j], h1_, l1_);
-            vh[0] = h0_; vh[1] = h1_; vl[0] = l0_; vl[1] = l1_;
+            hl_f16x2 vh, vl;                                                 // (channel ch, channel ch + 1) of pixel row `row`
+            hl_split2(hl_f32x2{c0[P][j], c1[P][j]}, vh, vl);
             const int o = hl_a_off(row, ch >> 3) + (ch & 7) * 2;             // (ch even: a 4-byte slot)
-            *reinterpret_cast<f16x2_t*>(ah + o) = vh;
-            *reinterpret_cast<f16x2_t*>(al + o) = vl;
+            *reinterpret_cast<hl_f16x2*>(ah + o) = vh;
+            *reinterpret_cast<hl_f16x2*>(al + o) = vl;
         }
     };
     // out tiles -> HBM, all 512 threads: whole 512-byte (fp32: 1-KiB) pixel rows
     auto store_out = [&](int tile) {
+        const int tpx0 = tile_px0(tile);
 #pragma unroll
         for (int u = 0; u < (PLANES ? 2 : 0); ++u) {
             const int piece = u * 512 + tid;                            // [row][chunk position]
             const int row = piece >> 5, cpos = piece & 31;
-            const int px = px_begin + tile * kTilePx + row;
+            const int px = tpx0 + row;
             const u32x4 vh = *reinterpret_cast<const u32x4*>(smem + Lds::o_hi + row * kRowBytes + cpos * 16);
             const u32x4 vl = *reinterpret_cast<const u32x4*>(smem + Lds::o_lo + row * kRowBytes + cpos * 16);
             if (px < px_end) {
@@ -167,39 +209,55 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             for (int u = 0; u < 4; ++u) {
                 const int piece = u * 512 + tid;                        // [row][64 chunk positions of 16 B]
                 const int row = piece >> 6, cpos = piece & 63;
-                const int px = px_begin + tile * kTilePx + row;
+                const int px = tpx0 + row;
                 const u32x4 v = *reinterpret_cast<const u32x4*>(smem + Lds::o_f32 + row * 1024 + cpos * 16);
                 if (px < px_end) *reinterpret_cast<u32x4*>(out_f32 + ((size_t)t * HW + px) * kD + ((cpos ^ (row & 15)) * 4)) = v;
             }
         }
     };
 
-    // STAGED: wave w stages items w, w + 8, .. (< 36) of the tile's [2 rows][18 columns] of g: one 1-KiB row per wave instruction
+    // STAGED: which source rows of g tile number `tile` has to bring - both (the first tile of the workgroup or of a strip: 36 items =
+    // [row][18 columns]), the lower one only (18 items) or none (the rows of the tile above are its rows); wave w stages items w, w + 8, ..
+    // One 1-KiB row of g per wave instruction.
+    struct GNeed { int n, y0, y1, c_lo; };
+    auto g_need = [&](int tile) {
+        const int sq = s_begin + tile, strip = sq / H, y = sq - strip * H;
+        const int y0 = (int)fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1;
+        const int py0 = (int)fmaxf((y - 0.5f) * 0.5f - 0.5f, 0.f), py1 = py0 + 1 < Hp ? py0 + 1 : Hp - 1;      // rows of output row y - 1
+        GNeed nd;
+        nd.n = (tile == 0 || y == 0) ? 2 * Lds::kGCols : (y1 != py1 ? Lds::kGCols : 0);
+        nd.y0 = y0;
+        nd.y1 = y1;
+        nd.c_lo = 16 * strip - 1 > 0 ? 16 * strip - 1 : 0;
+        return nd;
+    };
     f32x4 gt[2][5];
     auto fetch_g = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
-        const int px0 = px_begin + tile * kTilePx;         // first pixel of the tile: x0 % 32 == 0, one output row
-        const int y = px0 / W, x0 = px0 - y * W;
-        const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f);
-        const int y0 = (int)sy, y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1;
-        const int c_lo = x0 / 2 - 1 > 0 ? x0 / 2 - 1 : 0;
+        const GNeed nd = g_need(tile);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int item = w + 8 * i;                    // 0 .. 35 (row = item / 18, column = item % 18); wave-uniform
-            if (item < 2 * Lds::kGCols) {
-                const int row = item / Lds::kGCols;
-                int col = c_lo + (item - row * Lds::kGCols);
+            const int item = w + 8 * i;                    // wave-uniform
+            if (item < nd.n) {
+                const int upper = nd.n > Lds::kGCols ? (item < Lds::kGCols ? 1 : 0) : 0;      // 36 items: the first 18 are row y0
+                int col = nd.c_lo + (item < Lds::kGCols ? item : item - Lds::kGCols);
                 col = col < Wp ? col : Wp - 1;
-                gt[P][i] = *reinterpret_cast<const f32x4*>(gprev + ((size_t)t * Hp * Wp + (size_t)(row ? y1 : y0) * Wp + col) * kD + 4 * lane);
+                gt[P][i] = *reinterpret_cast<const f32x4*>(gprev + ((size_t)t * Hp * Wp + (size_t)(upper ? nd.y0 : nd.y1) * Wp + col) * kD + 4 * lane);
             }
         }
     };
-    auto commit_g = [&](auto par) {
+    auto commit_g = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
+        const GNeed nd = g_need(tile);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int item = w + 8 * i;
-            if (item < 2 * Lds::kGCols) *reinterpret_cast<f32x4*>(smem + Lds::gtile + item * Lds::kGRow + 16 * lane) = gt[P][i];
+            if (item < nd.n) {
+                const int upper = nd.n > Lds::kGCols ? (item < Lds::kGCols ? 1 : 0) : 0;
+                const int ci = item < Lds::kGCols ? item : item - Lds::kGCols;
+                const int slot = (upper ? nd.y0 : nd.y1) % Lds::kGRows;
+                *reinterpret_cast<f32x4*>(smem + Lds::gtile + (slot * Lds::kGCols + ci) * Lds::kGRow + 16 * lane) = gt[P][i];
+            }
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -211,38 +269,53 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
         if constexpr (STAGED) fetch_g(1, I1{});
     }
     commit(I0{});
-    if constexpr (STAGED) commit_g(I0{});
+    if constexpr (STAGED) commit_g(0, I0{});
+    // STAGED: the two source rows of this lane's taps blended HORIZONTALLY (16 channels each), kept across tiles: the next output row of the
+    // strip usually blends the same two source rows with other vertical weights - every other tile reads no taps at all (the tap reads
+    // were 128 KiB of LDS traffic per tile, as much as the operand fragments)
+    f32x4 hb[2][4];
+    int hb_y0 = -1, hb_y1 = -1;
     // One tile. Invariant at the top: LDS holds the operand tile (and the rows of g) of tile `it`; register set P ^ 1 holds tile it + 1
     // (requested one whole iteration ago); set P is free and takes tile it + 2.
     auto body = [&](int it, auto par) {
         constexpr int P = decltype(par)::value;
         using IP = std::integral_constant<int, P>;
         using IQ = std::integral_constant<int, P ^ 1>;
+        K4HL_STAMP(0);
         __syncthreads();                                   // operand tile `it` complete; out tiles of it-1 have been read
+        K4HL_STAMP(1);
         if (it + 2 < nt) {
             fetch(it + 2, IP{});
             if constexpr (STAGED) fetch_g(it + 2, IP{});
         }
+        K4HL_STAMP(2);
         // ---- per-lane taps of g (non-staged form: this lane's accumulator entries - pixel r, channels 32 w + 8 g + 4 h + j - requested
         // before the MFMAs)
         f32x4 tp[4][4];                                    // [tap][g]
         float h1 = 0.f, w1 = 0.f;
         const char* a00 = nullptr;
         const char* a01 = nullptr;
+        int grow1 = 0;
+        bool fresh = true;
         if constexpr (TAPS && STAGED) {
-            const int px0 = px_begin + it * kTilePx;
+            const int px0 = tile_px0(it);
             const int y = px0 / W, x = px0 - y * W + r;
             const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
             const int y0 = (int)sy, xs0 = (int)sx;
+            const int y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1;
             const int xs1 = xs0 + 1 < Wp ? xs0 + 1 : Wp - 1;
             h1 = sy - (float)y0;
             w1 = sx - (float)xs0;
             const int c_lo = (px0 - y * W) / 2 - 1 > 0 ? (px0 - y * W) / 2 - 1 : 0;
-            const char* g0 = smem + Lds::gtile + (32 * w + 4 * h) * 4;
+            const char* g0 = smem + Lds::gtile + (y0 % Lds::kGRows) * Lds::kGCols * Lds::kGRow + (32 * w + 4 * h) * 4;
             a00 = g0 + (xs0 - c_lo) * Lds::kGRow;
             a01 = g0 + (xs1 - c_lo) * Lds::kGRow;          // (the taps themselves are read from LDS group by group behind the MFMAs)
+            grow1 = ((y1 % Lds::kGRows) - (y0 % Lds::kGRows)) * Lds::kGCols * Lds::kGRow;        // from the upper to the lower source row
+            fresh = it == 0 || y == 0 || y0 != hb_y0 || y1 != hb_y1;
+            hb_y0 = y0;
+            hb_y1 = y1;
         } else if constexpr (TAPS) {
-            int pp = px_begin + it * kTilePx + r;
+            int pp = tile_px0(it) + r;
             pp = pp < HW ? pp : HW - 1;
             const int y = pp / W, x = pp - y * W;
             // F.interpolate(scale 2, bilinear, align_corners=False): source coordinate (d + 0.5) / 2 - 0.5 clamped at 0
@@ -277,34 +350,58 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh[ks], xl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh[ks], xh, acc, 0, 0, 0);
         }
+        K4HL_STAMP(3);
         // ---- + up(g) in fp32: w00 a + w01 b + w10 c + w11 d with the four tap weights formed once per lane and tile (round 5: four
         // instead of seven vector instructions per element; torch's upsample_bilinear2d groups the same sum as (1-ly) ((1-lx) a + lx b) +
         // ly ((1-lx) c + lx d) - an fp32 rounding of difference, inside the 5e-6 bound against float64 of tests/test_refprec_gpu.py); split; out tiles
         const float h0 = 1.f - h1, w0 = 1.f - w1;
         const float w00 = h0 * w0, w01 = h0 * w1, w10 = h1 * w0, w11 = h1 * w1;
+        if constexpr (TAPS && STAGED) {
+            if (fresh) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(a00 + 32 * g), tb = *reinterpret_cast<const f32x4*>(a01 + 32 * g);
+                    const f32x4 tc = *reinterpret_cast<const f32x4*>(a00 + grow1 + 32 * g), td = *reinterpret_cast<const f32x4*>(a01 + grow1 + 32 * g);
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const hl_f32x2 u = hl_f32x2{w0, w0} * hl_f32x2{ta[j], ta[j + 1]}, l = hl_f32x2{w0, w0} * hl_f32x2{tc[j], tc[j + 1]};
+                        const hl_f32x2 u2 = __builtin_elementwise_fma(hl_f32x2{w1, w1}, hl_f32x2{tb[j], tb[j + 1]}, u);
+                        const hl_f32x2 l2 = __builtin_elementwise_fma(hl_f32x2{w1, w1}, hl_f32x2{td[j], td[j + 1]}, l);
+                        hb[0][g][j] = u2[0]; hb[0][g][j + 1] = u2[1];
+                        hb[1][g][j] = l2[0]; hb[1][g][j + 1] = l2[1];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ch0 = 32 * w + 8 * g + 4 * h;
-            if constexpr (TAPS && STAGED) {
-                tp[0][g] = *reinterpret_cast<const f32x4*>(a00 + 32 * g);
-                tp[1][g] = *reinterpret_cast<const f32x4*>(a01 + 32 * g);
-                tp[2][g] = *reinterpret_cast<const f32x4*>(a00 + Lds::kGCols * Lds::kGRow + 32 * g);
-                tp[3][g] = *reinterpret_cast<const f32x4*>(a01 + Lds::kGCols * Lds::kGRow + 32 * g);
-            }
             f16x4 oh, ol;
             f32x4 of;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = acc[4 * g + j];
-                if constexpr (TAPS) v = fmaf(w11, tp[3][g][j], fmaf(w10, tp[2][g][j], fmaf(w01, tp[1][g][j], fmaf(w00, tp[0][g][j], v))));
+            for (int j = 0; j < 4; j += 2) {                // two channels at a time: packed fp32 / conversion instructions
+                hl_f32x2 v = {acc[4 * g + j], acc[4 * g + j + 1]};
+                if constexpr (TAPS && STAGED) {
+                    // torch's grouping: (1 - ly) ((1 - lx) a + lx b) + ly ((1 - lx) c + lx d)
+                    v = __builtin_elementwise_fma(hl_f32x2{h0, h0}, hl_f32x2{hb[0][g][j], hb[0][g][j + 1]}, v);
+                    v = __builtin_elementwise_fma(hl_f32x2{h1, h1}, hl_f32x2{hb[1][g][j], hb[1][g][j + 1]}, v);
+                } else if constexpr (TAPS) {
+                    v = __builtin_elementwise_fma(hl_f32x2{w00, w00}, hl_f32x2{tp[0][g][j], tp[0][g][j + 1]}, v);
+                    v = __builtin_elementwise_fma(hl_f32x2{w01, w01}, hl_f32x2{tp[1][g][j], tp[1][g][j + 1]}, v);
+                    v = __builtin_elementwise_fma(hl_f32x2{w10, w10}, hl_f32x2{tp[2][g][j], tp[2][g][j + 1]}, v);
+                    v = __builtin_elementwise_fma(hl_f32x2{w11, w11}, hl_f32x2{tp[3][g][j], tp[3][g][j + 1]}, v);
+                }
                 if constexpr (PLANES) {
-                    _Float16 vh, vl;
-                    hl_split(v, vh, vl);
-                    oh[j] = vh;
-                    ol[j] = vl;
-                    of[j] = (float)vh + (float)vl;         // the fp32 copy holds exactly the planes' value
+                    hl_f16x2 vh, vl;
+                    hl_split2(v, vh, vl);
+                    oh[j] = vh[0]; oh[j + 1] = vh[1];
+                    ol[j] = vl[0]; ol[j + 1] = vl[1];
+                    const hl_f32x2 back = __builtin_convertvector(vh, hl_f32x2) + __builtin_convertvector(vl, hl_f32x2);
+                    of[j] = back[0];                       // the fp32 copy holds exactly the planes' value
+                    of[j + 1] = back[1];
                 } else {
-                    of[j] = v;
+                    of[j] = v[0];
+                    of[j + 1] = v[1];
                 }
             }
             const int o = r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2;
@@ -314,12 +411,16 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             }
             if constexpr (F32OUT) *reinterpret_cast<f32x4*>(smem + Lds::o_f32 + r * 1024 + (((ch0 >> 2) ^ (r & 15)) * 16)) = of;
         }
+        K4HL_STAMP(4);
         __syncthreads();                                   // out tiles complete; every wave is done reading operand tile `it` (and its taps)
+        K4HL_STAMP(5);
         if (it + 1 < nt) {
             commit(IQ{});                                  // operand tile it + 1: its loads were issued a whole iteration ago
-            if constexpr (STAGED) commit_g(IQ{});
+            if constexpr (STAGED) commit_g(it + 1, IQ{});
         }
+        K4HL_STAMP(6);
         store_out(it);
+        K4HL_STAMP(7);
     };
     for (int it = 0; it < nt; it += 2) {
         body(it, I0{});
@@ -336,6 +437,12 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
 //     G^(m)_i = up( G^(m+1)_{i-1} ) + (W_a^m W_b) x_i + W_a^m b          (level 0: W_a^m (W_1 + W_2 + W_3) x_0 + W_a^m b)
 // - the 1x1 conv commutes with the interpolation at EVERY level, so the host composes W_a^m W_b in float64 once per weight version and
 // level i is 4 - i launches of this kernel (m = 0: the planes of f_i; m >= 1: fp32 only), each a K = 128 product at level i's resolution.
+#ifdef SVPS_K4HL_STAMP
+extern "C" int svps_k4hl_debug_read(unsigned long long* stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::k4hl_stamps), sizeof(unsigned long long) * 2 * 8 * 8);
+}
+#endif
+
 extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
                                       void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream_) {
     if (!cur || !wb_hi || !wb_lo || !bc || (!out_hi != !out_lo) || (!out_hi && !out_f32)) return SVPS_ERR_BAD_ARG;

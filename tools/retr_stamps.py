@@ -14,6 +14,7 @@ ap.add_argument("--W", type=int, default=512)
 ap.add_argument("--L", type=int, default=100)
 ap.add_argument("--warm-s", type=float, default=2.0)
 ap.add_argument("--map-dtype", default="fp16", help="fp16 (as on the default path: no conversion pass) or bf16")
+ap.add_argument("--hl", type=int, default=0, help="1: the fp16x2 form (hi / lo planes, K3-HL + K1'-HL)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -23,9 +24,12 @@ feat = torch.randn((a.T, HW, 256), device=dev).to(torch.float16 if a.map_dtype =
 slots = torch.randn((a.T, a.L, 256), device=dev)
 tabs = ops.pos_embed_sine_tables(a.H, a.W, 256, dev)
 c = m._fused_consts()
+if a.hl:
+    m.precision = "fp16x2"
+    planes = ops.split_hl(2.0 * torch.randn((a.T, HW, 256), device=dev))
 with torch.no_grad():
-    st = ops.retr_stats(feat, a.H, a.W, m.retr_pos_tables(tabs), c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
-    fn = lambda: m.forward_fused(slots, feat, (a.H, a.W), tabs, stats=st)
+    st = None if a.hl else ops.retr_stats(feat, a.H, a.W, m.retr_pos_tables(tabs), c["rk"], c["rbk"], 1e-5, c["rv"], c["rbv"], 1e-5)
+    fn = (lambda: m.forward_pm(slots, planes, (a.H, a.W), tabs)) if a.hl else (lambda: m.forward_fused(slots, feat, (a.H, a.W), tabs, stats=st))
     t0 = time.time()
     while time.time() - t0 < a.warm_s:                       # >= 2 s of back-to-back launches on random data
         for _ in range(20):
