@@ -28,8 +28,6 @@
 // every lane requests the 4 taps x 16 channels of g it needs for ITS accumulator entries (pixel = lane & 31) before the MFMAs and
 // blends them in fp32 behind them (four tap weights per lane and tile); bias, split, out tiles through LDS so that HBM sees whole
 // 512-byte pixel rows of both planes (and of the fp32 copy).
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "common.h"
@@ -38,34 +36,18 @@
 namespace svps {
 
 #ifdef SVPS_K4HL_STAMP
-// diagnostic build only (tools/k4hl_stamps.py): s_memtime stamps of the eight waves of one workgroup, tiles 8 .. 15
-__device__ unsigned long long k4hl_stamps[8][8][12];          // [wave][tile - 8][point]
+// diagnostic build only (tools/k4hl_stamps.py): s_memtime stamps of waves 0 and 4 of one workgroup, tiles 8 .. 15
+__device__ unsigned long long k4hl_stamps[2][8][8];          // [wave 0 / 4][tile - 8][point]
 #define K4HL_STAMP(pt)                                                                                              \
     do {                                                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
-        if (blockIdx.x == 3 && blockIdx.y == 2 && it >= 8 && it < 16 && lane == 0)                                  \
-            k4hl_stamps[w][it - 8][pt] = __builtin_amdgcn_s_memtime();                                               \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && (w & 3) == 0 && it >= 8 && it < 16 && lane == 0)                  \
+            k4hl_stamps[w >> 2][it - 8][pt] = __builtin_amdgcn_s_memtime();                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     } while (0)
 #else
 #define K4HL_STAMP(pt) do {} while (0)
 #endif
-
-#ifndef SVPS_K4HL_ABL
-#define SVPS_K4HL_ABL 0             // timing-only ablations of the ping-pong form (wrong results): 1 no plane stores
-#endif
-#ifndef SVPS_K4HL_RAWBAR
-#define SVPS_K4HL_RAWBAR 1
-#endif
-// __syncthreads() drains vmcnt as well: every barrier then waits for the stores (and the requests for later tiles) the wave has just
-// issued - a full HBM round trip per half-period in the stamps. The kernels here only share LDS: lgkmcnt(0) + s_barrier.
-__device__ __forceinline__ void hl_barrier() {
-#if SVPS_K4HL_RAWBAR
-    wg_barrier();
-#else
-    __syncthreads();
-#endif
-}
 
 constexpr int kHlK = 128;                        // incoming channels: the contraction at the fine resolution
 constexpr int kHlRowBytes = kHlK * 2;            // 256 B per pixel row of an operand tile (16 chunks of 16 B)
@@ -116,6 +98,15 @@ __device__ __forceinline__ void hl_split2(hl_f32x2 x, hl_f16x2& hi, hl_f16x2& lo
 // a tile's 7 500 cycles, and the younger waves held everyone at the second barrier).
 // PLANES = false (round 5): only the fp32 result is written - the launches that produce G^(m) = f W_a^m^T for the finer levels (see
 // svps_level_fuse_hl_fwd below); the fp32 value is then the unsplit sum itself.
+// (strip, row) of a tile sequence number of the column-strip walk, advanced one tile at a time: every consumer of a tile's position
+// (requests, commits, taps, stores) keeps its own cursor instead of dividing the sequence number by H - this kernel is bound by the
+// instructions it issues, not by memory (timing-only ablation of round 5: 72 % of its time remains with NO global traffic at all)
+struct HlCursor {
+    int strip, y;
+    __device__ __forceinline__ void next(int H) { if (++y == H) { y = 0; ++strip; } }
+    __device__ __forceinline__ int px0(int W) const { return y * W + 32 * strip; }
+};
+
 template <bool TAPS, bool F32OUT, bool STAGED = false, bool PLANES = true>
 __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     const float* __restrict__ cur,            // [T, 128, H, W] fp32 (NCHW, the reference's layout)
@@ -147,15 +138,22 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
         const int left = H * (W >> 5) - s_begin;
         nt = left < tiles_per_chunk ? left : tiles_per_chunk;
     }
-    auto tile_px0 = [&](int tile) {                                // first pixel of the workgroup's tile number `tile`
+    HlCursor c_first = {0, 0};                                     // the workgroup's first tile
+    if constexpr (STAGED) {
+        c_first.strip = s_begin / H;
+        c_first.y = s_begin - c_first.strip * H;
+    }
+    // first pixel of the tile a consumer's cursor points at; the cursor moves on (row-major forms: from the tile number)
+    auto take_px0 = [&](HlCursor& cu, int tile) {
         if constexpr (STAGED) {
-            const int sq = s_begin + tile, strip = sq / H;
-            return (sq - strip * H) * W + 32 * strip;
+            const int p = cu.px0(W);
+            cu.next(H);
+            return p;
         } else {
             return px_begin + tile * kTilePx;
         }
     };
-
+    HlCursor cu_fetch = c_first, cu_store = c_first, cu_taps = c_first, cu_gf = c_first, cu_gc = c_first;
     // ---- weight block of this wave: rows 32w .. 32w+31, 8 k-steps, hi and lo
     f16x8 wfh[8], wfl[8];
     {
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     f32x4 c0[2], c1[2];
     auto fetch = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
-        const int pp = tile_px0(tile) + 4 * pg;                            // c0: channel ch, c1: channel ch + 1, pixels pp .. pp + 3
+        const int pp = take_px0(cu_fetch, tile) + 4 * pg;                  // c0: channel ch, c1: channel ch + 1, pixels pp .. pp + 3
         if (pp + 4 <= HW && aligned) {
             c0[P] = *reinterpret_cast<const f32x4*>(src + pp);
             c1[P] = *reinterpret_cast<const f32x4*>(src + HW + pp);
@@ -208,7 +206,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     };
     // out tiles -> HBM, all 512 threads: whole 512-byte (fp32: 1-KiB) pixel rows
     auto store_out = [&](int tile) {
-        const int tpx0 = tile_px0(tile);
+        const int tpx0 = take_px0(cu_store, tile);
 #pragma unroll
         for (int u = 0; u < (PLANES ? 2 : 0); ++u) {
             const int piece = u * 512 + tid;                            // [row][chunk position]
@@ -238,10 +236,11 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     // [row][18 columns]), the lower one only (18 items) or none (the rows of the tile above are its rows); wave w stages items w, w + 8, ..
     // One 1-KiB row of g per wave instruction.
     struct GNeed { int n, y0, y1, c_lo; };
-    auto g_need = [&](int tile) {
-        const int sq = s_begin + tile, strip = sq / H, y = sq - strip * H;
-        const int y0 = (int)fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1;
-        const int py0 = (int)fmaxf((y - 0.5f) * 0.5f - 0.5f, 0.f), py1 = py0 + 1 < Hp ? py0 + 1 : Hp - 1;      // rows of output row y - 1
+    auto g_need = [&](HlCursor& cu, int tile) {
+        const int strip = cu.strip, y = cu.y;
+        cu.next(H);
+        const int y0 = (y > 0 ? y - 1 : 0) >> 1, y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1;       // = floor(max((y + 0.5) / 2 - 0.5, 0)) and the row below
+        const int py0 = (y > 1 ? y - 2 : 0) >> 1, py1 = py0 + 1 < Hp ? py0 + 1 : Hp - 1;    // rows of output row y - 1
         GNeed nd;
         nd.n = (tile == 0 || y == 0) ? 2 * Lds::kGCols : (y1 != py1 ? Lds::kGCols : 0);
         nd.y0 = y0;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     f32x4 gt[2][5];
     auto fetch_g = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
-        const GNeed nd = g_need(tile);
+        const GNeed nd = g_need(cu_gf, tile);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int item = w + 8 * i;                    // wave-uniform
@@ -266,7 +265,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     };
     auto commit_g = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
-        const GNeed nd = g_need(tile);
+        const GNeed nd = g_need(cu_gc, tile);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int item = w + 8 * i;
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
         using IP = std::integral_constant<int, P>;
         using IQ = std::integral_constant<int, P ^ 1>;
         K4HL_STAMP(0);
-        hl_barrier();                                   // operand tile `it` complete; out tiles of it-1 have been read
+        __syncthreads();                                   // operand tile `it` complete; out tiles of it-1 have been read
         K4HL_STAMP(1);
         if (it + 2 < nt) {
             fetch(it + 2, IP{});
@@ -316,15 +315,15 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
         int grow1 = 0;
         bool fresh = true;
         if constexpr (TAPS && STAGED) {
-            const int px0 = tile_px0(it);
-            const int y = px0 / W, x = px0 - y * W + r;
+            const int y = cu_taps.y, x0t = 32 * cu_taps.strip, x = x0t + r;
+            cu_taps.next(H);
             const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
             const int y0 = (int)sy, xs0 = (int)sx;
             const int y1 = y0 + 1 < Hp ? y0 + 1 : Hp - 1;
             const int xs1 = xs0 + 1 < Wp ? xs0 + 1 : Wp - 1;
             h1 = sy - (float)y0;
             w1 = sx - (float)xs0;
-            const int c_lo = (px0 - y * W) / 2 - 1 > 0 ? (px0 - y * W) / 2 - 1 : 0;
+            const int c_lo = x0t / 2 - 1 > 0 ? x0t / 2 - 1 : 0;
             const char* g0 = smem + Lds::gtile + (y0 % Lds::kGRows) * Lds::kGCols * Lds::kGRow + (32 * w + 4 * h) * 4;
             a00 = g0 + (xs0 - c_lo) * Lds::kGRow;
             a01 = g0 + (xs1 - c_lo) * Lds::kGRow;          // (the taps themselves are read from LDS group by group behind the MFMAs)
@@ -333,7 +332,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             hb_y0 = y0;
             hb_y1 = y1;
         } else if constexpr (TAPS) {
-            int pp = tile_px0(it) + r;
+            int pp = px_begin + it * kTilePx + r;
             pp = pp < HW ? pp : HW - 1;
             const int y = pp / W, x = pp - y * W;
             // F.interpolate(scale 2, bilinear, align_corners=False): source coordinate (d + 0.5) / 2 - 0.5 clamped at 0
@@ -430,7 +429,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             if constexpr (F32OUT) *reinterpret_cast<f32x4*>(smem + Lds::o_f32 + r * 1024 + (((ch0 >> 2) ^ (r & 15)) * 16)) = of;
         }
         K4HL_STAMP(4);
-        hl_barrier();                                   // out tiles complete; every wave is done reading operand tile `it` (and its taps)
+        __syncthreads();                                   // out tiles complete; every wave is done reading operand tile `it` (and its taps)
         K4HL_STAMP(5);
         if (it + 1 < nt) {
             commit(IQ{});                                  // operand tile it + 1: its loads were issued a whole iteration ago
@@ -446,359 +445,6 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// PING-PONG form (round 5) of the staged-taps kernel, for launches that write EITHER the planes OR the fp32 result (all launches of the
-// level recursion): the lock-step form above spends a tile as  [loads issued | MFMA chain | blend + split]  barrier  [operand commit |
-// out stores]  with all eight waves in the same phase - the matrix pipe and the vector units idle through the memory phase, the memory
-// pipes through the other (s_memtime stamps: ~3 200 + ~2 000 cycles of a 5 300-cycle tile at the finest level; HBM floor ~4 100).
-// Here waves 0-3 (group X, output channels 0 .. 127) and waves 4-7 (group Y, channels 128 .. 255) - one of each per SIMD - work in
-// opposite phases, half-period h:
-//     X:  h = 2k    P1(k): chain on a(k), blend, split, its channels of the out tile        h = 2k + 1  M_X(k): commit a(k+1), request a(k+2),
-//                                                                                                       store its half of out(k)
-//     Y:  h = 2k+1  P1(k)                                                                    h = 2k + 2  M_Y(k): commit the g rows of tile k+2,
-//                                                                                                       request those of k+3, store its half of out(k)
-// One workgroup barrier per half-period. The operand tile is double-buffered (X reads a(k) one half-period before Y); the out tile is
-// not (the groups own disjoint chunk ranges of every row: the XOR swizzles keep a group's channels inside its half). The source rows of
-// g live in FOUR slots handed out by a running counter (live at any time: the two rows of the tile being blended + at most two new
-// ones), tracked by the same little state machine in both groups. ONE register set per group: a request is issued right after the
-// commit that frees the registers and has a whole period (~4 000 cycles) to land.
-struct FusePpLds {
-    static constexpr int a = 0;                                     // [2][hi 8 KiB | lo 8 KiB]
-    static constexpr int out = 2 * 2 * kTilePx * kHlRowBytes;       // planes: o_hi 16 KiB + o_lo 16 KiB; fp32: 32 KiB
-    static constexpr int gring = out + 2 * kTileBytes;
-    static constexpr int kGCols = 18, kGRow = 1024 + 16, kGSlots = 4;
-    static constexpr int stage = gring + kGSlots * kGCols * kGRow;  // [4 X waves][4 pieces][1 KiB] the incoming fp32 tile as its threads requested it
-    static constexpr int total = stage + 4 * 4 * 1024;
-};
-static_assert(FusePpLds::total <= 160 * 1024, "LDS layout");
-
-// asm LDS-DMA (invisible to hipcc's wait counting - with register loads it put s_waitcnt vmcnt(0) in front of the barrier that follows
-// the requests: every half-period then ended in a full HBM round trip, s_memtime stamps). nt: the incoming map is read once.
-__device__ __forceinline__ u32x4 hl_make_srd(const void* base, uint32_t bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(base);
-    u32x4 d;
-    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
-    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
-    d[2] = __builtin_amdgcn_readfirstlane(bytes);
-    d[3] = 0x00020000u;
-    return d;
-}
-template <bool NT>
-__device__ __forceinline__ void hl_dma16(u32x4 srd, uint32_t lds_addr, int voff, int soff) {
-    uint32_t keep;
-    if constexpr (NT)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff) : "memory");
-}
-
-struct HlRows { int r0, r1, s0, s1, ctr; };                         // source rows of the last planned tile and their slots (wave-uniform)
-struct HlPlan { int y0, y1, s0, s1; bool new0, new1, fresh; };
-// source rows of output row y (F.interpolate scale 2, align_corners = False: floor(max((y + 0.5) / 2 - 0.5, 0)) = max(y - 1, 0) >> 1)
-__device__ __forceinline__ HlPlan hl_plan(HlRows& st, int y, int Hp, bool reset) {
-    HlPlan p;
-    p.y0 = (y > 0 ? y - 1 : 0) >> 1;
-    p.y1 = p.y0 + 1 < Hp ? p.y0 + 1 : Hp - 1;
-    if (reset) {                                                    // first tile of the workgroup or of a column strip: nothing is there
-        p.new0 = true;
-        p.new1 = p.y1 != p.y0;
-        p.s0 = st.ctr & 3;
-        p.s1 = p.new1 ? (st.ctr + 1) & 3 : p.s0;
-        p.fresh = true;
-    } else {                                                        // walking down: y0 is one of the previous tile's rows
-        p.new0 = false;
-        p.s0 = p.y0 == st.r0 ? st.s0 : st.s1;
-        if (p.y1 == p.y0) { p.new1 = false; p.s1 = p.s0; }
-        else if (p.y1 == st.r1) { p.new1 = false; p.s1 = st.s1; }
-        else { p.new1 = true; p.s1 = st.ctr & 3; }
-        p.fresh = p.y0 != st.r0 || p.y1 != st.r1;
-    }
-    st.r0 = p.y0; st.r1 = p.y1; st.s0 = p.s0; st.s1 = p.s1;
-    st.ctr += (p.new0 ? 1 : 0) + (p.new1 ? 1 : 0);
-    return p;
-}
-struct HlCursor {                                                   // (strip, row) of a tile sequence number, advanced one tile at a time
-    int strip, y;
-    __device__ __forceinline__ void next(int H) { if (++y == H) { y = 0; ++strip; } }
-    __device__ __forceinline__ int px0(int W) const { return y * W + 32 * strip; }
-};
-
-template <bool PLANES>
-__global__ __launch_bounds__(512) void level_fuse_hl_pp_kernel(
-    const float* __restrict__ cur, const float* __restrict__ gprev, const _Float16* __restrict__ wb_hi, const _Float16* __restrict__ wb_lo,
-    const float* __restrict__ bc, _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo, float* __restrict__ out_f32,
-    int H, int W, int tiles_per_chunk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Lds = FusePpLds;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = w >> 2, wq = w & 3, gt_id = tid & 255;          // group, wave and thread inside the group
-    const int r = lane & 31, h = lane >> 5;
-    const int t = blockIdx.y, c = blockIdx.x;
-    const int HW = H * W, Hp = H >> 1, Wp = W >> 1;
-    const int s_begin = c * tiles_per_chunk;
-    const int left = H * (W >> 5) - s_begin;
-    const int nt = left < tiles_per_chunk ? left : tiles_per_chunk;
-    HlCursor c0_;                                                   // the workgroup's first tile
-    c0_.strip = s_begin / H;
-    c0_.y = s_begin - c0_.strip * H;
-
-    f16x8 wfh[8], wfl[8];
-    {
-        const size_t row = (size_t)(32 * w + r) * kHlK + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            wfh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wb_hi + row + 16 * ks));
-            wfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(wb_lo + row + 16 * ks));
-        }
-    }
-    f32x4 bias[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bias[g] = *reinterpret_cast<const f32x4*>(bc + 32 * w + 8 * g + 4 * h);
-
-    // ---- P1: one tile on this wave's 32 output channels
-    f32x4 hb[2][4];                                                 // this lane's two source rows blended horizontally (see the form above)
-    HlRows bst = {-1, -1, 0, 0, 0};                                 // blend-side row state
-    HlCursor bc_ = c0_;
-    auto p1 = [&](int k) {
-        const char* ah = smem + Lds::a + (k & 1) * 2 * kTilePx * kHlRowBytes;
-        const char* al = ah + kTilePx * kHlRowBytes;
-        const bool reset = k == 0 || bc_.y == 0;
-        const HlPlan pl = hl_plan(bst, bc_.y, Hp, reset);
-        const int y = bc_.y, x = 32 * bc_.strip + r;
-        bc_.next(H);
-        const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
-        const int xs0 = (int)sx;
-        const int xs1 = xs0 + 1 < Wp ? xs0 + 1 : Wp - 1;
-        const float h1 = sy - (float)pl.y0, w1 = sx - (float)xs0;
-        const int c_lo = (x - r) / 2 - 1 > 0 ? (x - r) / 2 - 1 : 0;
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[4 * g + j] = bias[g][j];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const f16x8 xh = *reinterpret_cast<const f16x8*>(ah + hl_a_off(r, 2 * ks + h));
-            const f16x8 xl = *reinterpret_cast<const f16x8*>(al + hl_a_off(r, 2 * ks + h));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfl[ks], xh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh[ks], xl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfh[ks], xh, acc, 0, 0, 0);
-        }
-        const float h0 = 1.f - h1, w0 = 1.f - w1;
-        if (pl.fresh) {
-            const char* g0 = smem + Lds::gring + (32 * w + 4 * h) * 4;
-            const char* a00 = g0 + (pl.s0 * Lds::kGCols + (xs0 - c_lo)) * Lds::kGRow;
-            const char* a01 = g0 + (pl.s0 * Lds::kGCols + (xs1 - c_lo)) * Lds::kGRow;
-            const int grow1 = (pl.s1 - pl.s0) * Lds::kGCols * Lds::kGRow;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 ta = *reinterpret_cast<const f32x4*>(a00 + 32 * g), tb = *reinterpret_cast<const f32x4*>(a01 + 32 * g);
-                const f32x4 tc = *reinterpret_cast<const f32x4*>(a00 + grow1 + 32 * g), td = *reinterpret_cast<const f32x4*>(a01 + grow1 + 32 * g);
-#pragma unroll
-                for (int j = 0; j < 4; j += 2) {
-                    const hl_f32x2 u = hl_f32x2{w0, w0} * hl_f32x2{ta[j], ta[j + 1]}, l = hl_f32x2{w0, w0} * hl_f32x2{tc[j], tc[j + 1]};
-                    const hl_f32x2 u2 = __builtin_elementwise_fma(hl_f32x2{w1, w1}, hl_f32x2{tb[j], tb[j + 1]}, u);
-                    const hl_f32x2 l2 = __builtin_elementwise_fma(hl_f32x2{w1, w1}, hl_f32x2{td[j], td[j + 1]}, l);
-                    hb[0][g][j] = u2[0]; hb[0][g][j + 1] = u2[1];
-                    hb[1][g][j] = l2[0]; hb[1][g][j + 1] = l2[1];
-                }
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ch0 = 32 * w + 8 * g + 4 * h;
-            f16x4 oh, ol;
-            f32x4 of;
-#pragma unroll
-            for (int j = 0; j < 4; j += 2) {
-                hl_f32x2 v = {acc[4 * g + j], acc[4 * g + j + 1]};
-                v = __builtin_elementwise_fma(hl_f32x2{h0, h0}, hl_f32x2{hb[0][g][j], hb[0][g][j + 1]}, v);
-                v = __builtin_elementwise_fma(hl_f32x2{h1, h1}, hl_f32x2{hb[1][g][j], hb[1][g][j + 1]}, v);
-                if constexpr (PLANES) {
-                    hl_f16x2 vh, vl;
-                    hl_split2(v, vh, vl);
-                    oh[j] = vh[0]; oh[j + 1] = vh[1];
-                    ol[j] = vl[0]; ol[j + 1] = vl[1];
-                } else {
-                    of[j] = v[0];
-                    of[j + 1] = v[1];
-                }
-            }
-            if constexpr (PLANES) {
-                const int o = r * kRowBytes + (((ch0 >> 3) ^ swz(r)) * 16) + (ch0 & 7) * 2;
-                *reinterpret_cast<f16x4*>(smem + Lds::out + o) = oh;
-                *reinterpret_cast<f16x4*>(smem + Lds::out + kTileBytes + o) = ol;
-            } else {
-                *reinterpret_cast<f32x4*>(smem + Lds::out + r * 1024 + (((ch0 >> 2) ^ (r & 15)) * 16)) = of;
-            }
-        }
-    };
-    // ---- this group's half of the out tile -> HBM: whole half rows (256 B of a plane, 512 B of the fp32 result)
-    HlCursor sc_ = c0_;
-    auto store_half = [&]() {
-        const int tpx0 = sc_.px0(W);
-        sc_.next(H);
-        if constexpr (PLANES) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int piece = u * 256 + gt_id;                      // [32 rows][16 chunk positions of this group's half]
-                const int row = piece >> 4, cpos = 16 * grp + (piece & 15);
-                const u32x4 vh = *reinterpret_cast<const u32x4*>(smem + Lds::out + row * kRowBytes + cpos * 16);
-                const u32x4 vl = *reinterpret_cast<const u32x4*>(smem + Lds::out + kTileBytes + row * kRowBytes + cpos * 16);
-                const size_t o = ((size_t)t * HW + tpx0 + row) * kD + ((cpos ^ swz(row)) * 8);
-                if (!(SVPS_K4HL_ABL & 1) || vh[0] == 0x12345u) {
-                    *reinterpret_cast<u32x4*>(out_hi + o) = vh;
-                    *reinterpret_cast<u32x4*>(out_lo + o) = vl;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int piece = u * 256 + gt_id;                      // [32 rows][32 chunk positions of this group's half]
-                const int row = piece >> 5, cpos = 32 * grp + (piece & 31);
-                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + Lds::out + row * 1024 + cpos * 16);
-                *reinterpret_cast<u32x4*>(out_f32 + ((size_t)t * HW + tpx0 + row) * kD + ((cpos ^ (row & 15)) * 4)) = v;
-            }
-        }
-    };
-
-    if (grp == 0) {
-        // ================================ group X: operand tiles ==================================
-        // thread = (channel pairs cp and cp + 32, 4-pixel group): 4 x 16 B per tile, requested by LDS-DMA into the wave's own staging KiBs
-        // (a lane reads back exactly what it requested: no barrier, vmcnt alone), 8 four-byte LDS stores per plane
-        const int ch = 2 * (gt_id >> 3), pg = gt_id & 7;
-        const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
-        const u32x4 srd = hl_make_srd(cur + (size_t)t * 128 * HW, (uint32_t)(128u * (uint32_t)HW * 4u));
-        const uint32_t stg = __builtin_amdgcn_readfirstlane(lds0 + Lds::stage + wq * 4096);
-        int voff[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) voff[i][j] = ((ch + 64 * i + j) * HW + 4 * pg) * 4;
-        HlCursor fc_ = c0_;
-        auto fetch = [&]() {
-            const int soff = __builtin_amdgcn_readfirstlane(fc_.px0(W) * 4);
-            fc_.next(H);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) hl_dma16<true>(srd, stg + (2 * i + j) * 1024, voff[i][j], soff);
-        };
-        auto commit = [&](int k) {
-            char* ah = smem + Lds::a + (k & 1) * 2 * kTilePx * kHlRowBytes;
-            char* al = ah + kTilePx * kHlRowBytes;
-            const char* sp = smem + Lds::stage + wq * 4096 + lane * 16;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const f32x4 ca = *reinterpret_cast<const f32x4*>(sp + (2 * i) * 1024), cb = *reinterpret_cast<const f32x4*>(sp + (2 * i + 1) * 1024);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = 4 * pg + j, chi = ch + 64 * i;
-                    hl_f16x2 vh, vl;
-                    hl_split2(hl_f32x2{ca[j], cb[j]}, vh, vl);
-                    const int o = hl_a_off(row, chi >> 3) + (chi & 7) * 2;
-                    *reinterpret_cast<hl_f16x2*>(ah + o) = vh;
-                    *reinterpret_cast<hl_f16x2*>(al + o) = vl;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staging KiBs are in registers before the next request overwrites them
-        };
-        fetch();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        commit(0);
-        if (nt > 1) fetch();
-        hl_barrier();
-        for (int hp = 0; hp <= 2 * nt; ++hp) {
-            const int k = hp >> 1, it = k;
-            (void)it;
-            if (!(hp & 1)) {
-                K4HL_STAMP(0);
-                if (k < nt) p1(k);
-                K4HL_STAMP(1);
-            } else {
-                K4HL_STAMP(3);
-                if (k + 1 < nt) {
-                    // the requests of a(k + 1) are older than the four stores that followed them a period ago (k = 0: nothing followed)
-                    if (k == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    commit(k + 1);
-                }
-                K4HL_STAMP(4);
-                if (k + 2 < nt) fetch();
-                K4HL_STAMP(5);
-                store_half();
-                K4HL_STAMP(6);
-            }
-            hl_barrier();
-            if (!(hp & 1)) K4HL_STAMP(2);
-            else K4HL_STAMP(7);
-        }
-    } else {
-        // ================================ group Y: the rows of g ===================================
-        // wave wq brings items wq, wq + 4, .. (< 18) of a row by LDS-DMA straight into the row's slot: one 1-KiB row of g per instruction
-        const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
-        const u32x4 srd = hl_make_srd(gprev + (size_t)t * Hp * Wp * kD, (uint32_t)Hp * (uint32_t)Wp * 1024u);
-        HlRows cst = {-1, -1, 0, 0, 0};                             // request-side row state (runs ahead of the blend side)
-        HlCursor gc_ = c0_;                                         // tile whose rows are requested next
-        auto request_row = [&](int row, int c_lo, int slot) {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int item = wq + 4 * i;
-                if (item < Lds::kGCols) {
-                    int col = c_lo + item;
-                    col = col < Wp ? col : Wp - 1;
-                    hl_dma16<false>(srd, __builtin_amdgcn_readfirstlane(lds0 + Lds::gring + (slot * Lds::kGCols + item) * Lds::kGRow), lane * 16,
-                                    __builtin_amdgcn_readfirstlane((row * Wp + col) * 1024));
-                }
-            }
-        };
-        // the new rows of the next tile (none, the lower one, or - first tile of the workgroup or of a strip - both)
-        auto fetch_g = [&](int k) {
-            const bool reset = k == 0 || gc_.y == 0;
-            const HlPlan gp = hl_plan(cst, gc_.y, Hp, reset);
-            const int c_lo = 16 * gc_.strip - 1 > 0 ? 16 * gc_.strip - 1 : 0;
-            gc_.next(H);
-            if (gp.new0) request_row(gp.y0, c_lo, gp.s0);
-            if (gp.new1) request_row(gp.y1, c_lo, gp.s1);
-        };
-        fetch_g(0);
-        if (nt > 1) fetch_g(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        hl_barrier();
-        for (int hp = 0; hp <= 2 * nt; ++hp) {
-            if (hp & 1) {
-                const int it = hp >> 1;
-                (void)it;
-                K4HL_STAMP(0);
-                p1(hp >> 1);
-                K4HL_STAMP(1);
-                hl_barrier();
-                K4HL_STAMP(2);
-            } else {
-                const int k = (hp >> 1) - 1, it = k;                // M_Y(k): request the rows of tile k + 3, store out(k)
-                (void)it;
-                K4HL_STAMP(3);
-                // the rows requested a period ago (tile k + 2: blended by X in the next half-period but one) have landed; the stores that
-                // followed them may still be in flight
-                if (k >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                K4HL_STAMP(4);
-                if (k + 3 < nt) fetch_g(k + 3);
-                K4HL_STAMP(5);
-                if (k >= 0) store_half();
-                K4HL_STAMP(6);
-                hl_barrier();
-                K4HL_STAMP(7);
-            }
-        }
-    }
-}
-
 }  // namespace svps
 
 // svps_level_fuse_hl_fwd (include/slotvps_hip.h): out = up(gprev) + wb cur + bc. cur [T, 128, H, W] fp32 NCHW; gprev [T, (H/2)(W/2), 256]
@@ -810,7 +456,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_pp_kernel(
 // level i is 4 - i launches of this kernel (m = 0: the planes of f_i; m >= 1: fp32 only), each a K = 128 product at level i's resolution.
 #ifdef SVPS_K4HL_STAMP
 extern "C" int svps_k4hl_debug_read(unsigned long long* stamps) {
-    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::k4hl_stamps), sizeof(unsigned long long) * 8 * 8 * 12);
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::k4hl_stamps), sizeof(unsigned long long) * 2 * 8 * 8);
 }
 #endif
 
@@ -839,21 +485,6 @@ extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, cons
         hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, cur, gprev, static_cast<const H16*>(wb_hi),              \
                            static_cast<const H16*>(wb_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), out_f32, H, W, tpc); \
     } while (0)
-    static const bool no_pp = [] { const char* e_ = getenv("SVPS_K4HL_PP"); return e_ && e_[0] == '0'; }();
-    if (gprev && (W & 31) == 0 && (!out_hi != !out_f32) && !no_pp) {
-        // the ping-pong form: staged taps, planes OR fp32 (every launch of the level recursion)
-        constexpr int lds_pp = svps::FusePpLds::total;
-        static SvpsLdsAttr attr_pp[2];
-        if (out_hi) {
-            if ((e = attr_pp[0].ensure(reinterpret_cast<const void*>(svps::level_fuse_hl_pp_kernel<true>), lds_pp)) != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(svps::level_fuse_hl_pp_kernel<true>, dim3(chunks, T), dim3(512), lds_pp, stream, cur, gprev, static_cast<const H16*>(wb_hi),
-                               static_cast<const H16*>(wb_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), out_f32, H, W, tpc);
-        } else {
-            if ((e = attr_pp[1].ensure(reinterpret_cast<const void*>(svps::level_fuse_hl_pp_kernel<false>), lds_pp)) != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(svps::level_fuse_hl_pp_kernel<false>, dim3(chunks, T), dim3(512), lds_pp, stream, cur, gprev, static_cast<const H16*>(wb_hi),
-                               static_cast<const H16*>(wb_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), out_f32, H, W, tpc);
-        }
-    } else
     if (!out_hi) { if (gprev) SVPS_LFH(true, true, false); else SVPS_LFH(false, true, false); }
     else if (gprev) { if (out_f32) SVPS_LFH(true, true, true); else SVPS_LFH(true, false, true); }
     else { if (out_f32) SVPS_LFH(false, true, true); else SVPS_LFH(false, false, true); }

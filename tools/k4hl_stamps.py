@@ -1,8 +1,7 @@
 """(GPU box) In-kernel timeline of the reference-precision level fusion (csrc/level_fuse_hl.hip) from s_memtime stamps, and its launch time.
 Build: make -C slotvps_amd/csrc stampk4hl; run with SLOTVPS_LIB=slotvps_amd/libslotvps_hip_stampk4hl.so (timing alone: any library).
 Points of a tile (waves 0 and 4): 0 top, 1 past barrier 1, 2 loads of tile + 2 issued, 3 MFMA chain done, 4 blend + split + out tiles written,
-5 past barrier 2, 6 operand tile of tile + 1 committed, 7 out tiles stored. Ping-pong form (waves 0 = group X, 4 = group Y), relative to the
-earliest stamp of tile k: 0 P1 begins, 1 P1 done, 2 past its barrier; 3 memory phase begins, 4 commit done, 5 requests issued, 6 half stored, 7 past barrier.
+5 past barrier 2, 6 operand tile of tile + 1 committed, 7 out tiles stored.
     python tools/k4hl_stamps.py [--T 40] [--H 256] [--W 512] [--planes 1] [--f32 0] [--taps 1]"""
 import argparse, ctypes, os, sys
 import numpy as np
@@ -39,17 +38,12 @@ byts = px * (512 + (256 if a.taps else 0) + 1024 * (a.planes + a.f32))
 print(f"level_fuse_hl taps={a.taps} planes={a.planes} f32={a.f32}: {us:9.1f} us  {byts / us / 1e3:7.0f} GB/s algorithmic", flush=True)
 lib = _lib.load()
 if hasattr(lib, "svps_k4hl_debug_read"):
-    buf = (ctypes.c_ulonglong * 768)()
+    buf = (ctypes.c_ulonglong * 128)()
     lib.svps_k4hl_debug_read.restype = ctypes.c_int
     assert lib.svps_k4hl_debug_read(buf) == 0
-    st = np.array(list(buf), dtype=np.int64).reshape(8, 8, 12)
-    t0 = st[:, 2][st[:, 2] > 0].min()
-    print("all waves, tile 10, cycles since the earliest stamp of the tile:")
-    for wv in range(8):
-        print(f"  wave {wv}: " + " ".join(f"p{k}={int(st[wv, 2, k] - t0):6d}" for k in range(12)))
-    for role, name in ((0, "wave 0"), (4, "wave 4")):
+    st = np.array(list(buf), dtype=np.int64).reshape(2, 8, 8)
+    for role, name in ((0, "wave 0"), (1, "wave 4")):
         for it in range(1, 7):
-            base = st[role, it][st[role, it] > 0].min()
-            d = st[role, it] - base
-            nxt = st[role, it + 1][st[role, it + 1] > 0].min() - base
+            d = st[role, it] - st[role, it, 0]
+            nxt = st[role, it + 1, 0] - st[role, it, 0]
             print(f"{name} tile {it + 8}: " + " ".join(f"p{k}={int(d[k]):6d}" for k in range(8)) + f"  | next top {int(nxt)}")
