@@ -42,7 +42,8 @@ def test_split_hl_is_22_bits(cuda):
 
 
 @pytest.mark.parametrize("T,H,W,lvl0", [(2, 8, 16, True), (1, 6, 10, False), (2, 34, 60, False), (3, 16, 64, False), (1, 2, 4, True),
-                                        (1, 4, 32, False), (2, 10, 96, False), (1, 64, 128, False)])     # W % 32 == 0: taps staged through LDS
+                                        (1, 4, 32, False), (2, 10, 96, False), (1, 64, 128, False),      # W % 32 == 0: taps staged through LDS
+                                        (1, 20, 1024, False)])    # 640 tiles: workgroups of three tiles that cross column strips (ring of source rows)
 def test_level_fuse_hl(cuda, T, H, W, lvl0):
     """K4-HL (f = up(prev W_a^T) + W_b x + b: the coarse product on K8, the rest in csrc/level_fuse_hl.hip) against a float64 evaluation of
     dynamic_mask_head.py:171-188 in the REFERENCE's order (conv of the concatenated, upsampled map) on identical fp32 inputs."""
@@ -91,7 +92,8 @@ def _module(cuda, seed):
 
 @pytest.mark.parametrize("T,H,W,L,pos", [(2, 8, 32, 100, True), (1, 16, 64, 128, True), (1, 5, 20, 37, True), (2, 34, 60, 100, True),
                                          (1, 3, 64, 1, False), (1, 40, 16, 100, True), (3, 9, 40, 100, True), (1, 7, 7, 64, True),
-                                         (2, 34, 60, 200, True), (1, 8, 32, 129, True), (1, 5, 20, 256, True), (1, 16, 64, 200, False)])
+                                         (2, 34, 60, 200, True), (1, 8, 32, 129, True), (1, 5, 20, 256, True), (1, 16, 64, 200, False),
+                                         (1, 20, 512, 100, True)])      # 320 tiles of 32 pixels on 256 CUs: workgroups of two tiles that cross column strips (K3-HL)
 def test_retriever_hl_vs_float64_oracle(cuda, T, H, W, L, pos):
     """MaskDynamicConv.forward (:423-461) in the fp16x2 form - statistics with hi + lo factors and map (K3t-HL), the retriever on 16-pixel
     hi / lo tiles with hi + lo probabilities (K1'-HL), fp16-split query side - against the float64 oracle on the SAME map (the exact sum of
