@@ -24,6 +24,18 @@
 //     values land in the accumulators themselves; two fenced groups were 2 x 1 500 cycles of L2 latency on the critical path).
 //   * wave (value, 0) finishes the previous tile from the eight waves' sums and writes the whole 16-byte aux rows of retr_stats.hip:
 //     {1, hi sigma_v, lo sigma_v, 0 (fp16), rstd_k, rstd_v (fp32)}.
+// Round 5 - the TILED-TABLES form (template parameter TLDS; W % 32 == 0 with position tables: every level of the product configurations),
+// from the stamps and timing-only ablations of that schedule (22.1 -> 18.4 ms per step):
+//   * the start values come through LDS as well: a key wave requests its own 8 KiB of Tx' (once per 32-pixel COLUMN: a workgroup walks its
+//     tiles column-major, sequence number s -> row s % H, column s / H) and the 16 chunks of the row's Ty' by LDS-DMA one period ahead and
+//     reads back what it requested (no barrier, vmcnt alone); r_v' sits in LDS. No wave waits on an L2 round trip, no staging registers.
+//   * each wave's sums of squares moved into ITS light half (the accumulators are free until the next start values arrive from LDS), so
+//     a half-period is the bare chain; the finish of a tile follows two half-periods later.
+//   * tile + 2 is requested at the TOP of the light half, BEFORE the landing wait of tile + 1 (s_waitcnt vmcnt(4): the four new requests
+//     stay in flight): two tiles in flight per CU - with one, the loads took longer than a period to land.
+//   * s_setprio 1 around a chain: the value waves are the younger half of the workgroup and lose issue arbitration to the key waves'
+//     light work (their chain took 2 150 cycles beside the key waves' 1 910; static priority for the younger half was zero-sum).
+// The other form (!TLDS: no position tables, or W % 32 != 0) keeps the schedule described above.
 #include "common.h"
 #include "../../include/slotvps_hip.h"
 
