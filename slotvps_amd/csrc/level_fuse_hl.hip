@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
             return px_begin + tile * kTilePx;
         }
     };
-    HlCursor cu_fetch = c_first, cu_store = c_first, cu_taps = c_first, cu_gf = c_first, cu_gc = c_first;
+    HlCursor cu_fetch = c_first, cu_store = c_first, cu_taps = c_first, cu_gf = c_first;
     // ---- weight block of this wave: rows 32w .. 32w+31, 8 k-steps, hi and lo
     f16x8 wfh[8], wfl[8];
     {
@@ -178,8 +178,29 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     // TWO register sets (round 5): the incoming map (and the rows of g) are requested TWO tiles ahead - HBM latency under load is longer
     // than one tile period of this lock-step workgroup (one tile ahead left every commit waiting for its loads)
     f32x4 c0[2], c1[2];
+    // STAGED (W % 32 == 0: every tile full, 16-byte aligned): all global traffic through buffer descriptors - a lane's offsets inside a
+    // frame are constants, a tile adds ONE scalar offset (round 5: the 64-bit address arithmetic per load / store was a fifth of the
+    // vector instructions of a tile, and this kernel is bound by the instructions it issues)
+    auto frame_rsrc = [](const void* p_, uint32_t bytes) {
+        const uint64_t a = reinterpret_cast<uint64_t>(p_);
+        const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs_cur = frame_rsrc(cur + (size_t)t * 128 * HW, (uint32_t)HW * 512u);
+    const __amdgpu_buffer_rsrc_t rs_g = frame_rsrc(STAGED ? gprev + (size_t)t * Hp * Wp * kD : cur, STAGED ? (uint32_t)(Hp * Wp) * 1024u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_hi = frame_rsrc(PLANES ? (const void*)(out_hi + (size_t)t * HW * kD) : (const void*)cur, PLANES ? (uint32_t)HW * 512u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_lo = frame_rsrc(PLANES ? (const void*)(out_lo + (size_t)t * HW * kD) : (const void*)cur, PLANES ? (uint32_t)HW * 512u : 0u);
+    const __amdgpu_buffer_rsrc_t rs_f32 = frame_rsrc(F32OUT ? (const void*)(out_f32 + (size_t)t * HW * kD) : (const void*)cur, F32OUT ? (uint32_t)HW * 1024u : 0u);
+    const int vo_c0 = (ch * HW + 4 * pg) * 4, vo_c1 = vo_c0 + HW * 4;
     auto fetch = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
+        if constexpr (STAGED) {
+            const int soff = take_px0(cu_fetch, tile) * 4;
+            c0[P] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, vo_c0, soff, 0));
+            c1[P] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, vo_c1, soff, 0));
+            return;
+        }
         const int pp = take_px0(cu_fetch, tile) + 4 * pg;                  // c0: channel ch, c1: channel ch + 1, pixels pp .. pp + 3
         if (pp + 4 <= HW && aligned) {
             c0[P] = *reinterpret_cast<const f32x4*>(src + pp);
@@ -207,6 +228,28 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     // out tiles -> HBM, all 512 threads: whole 512-byte (fp32: 1-KiB) pixel rows
     auto store_out = [&](int tile) {
         const int tpx0 = take_px0(cu_store, tile);
+        if constexpr (STAGED) {
+#pragma unroll
+            for (int u = 0; u < (PLANES ? 2 : 0); ++u) {
+                const int piece = u * 512 + tid;
+                const int row = piece >> 5, cpos = piece & 31;
+                const u32x4 vh = *reinterpret_cast<const u32x4*>(smem + Lds::o_hi + row * kRowBytes + cpos * 16);
+                const u32x4 vl = *reinterpret_cast<const u32x4*>(smem + Lds::o_lo + row * kRowBytes + cpos * 16);
+                const int vo = row * kRowBytes + ((cpos ^ swz(row)) * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(vh, rs_hi, vo, tpx0 * kRowBytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(vl, rs_lo, vo, tpx0 * kRowBytes, 0);
+            }
+            if constexpr (F32OUT) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int piece = u * 512 + tid;
+                    const int row = piece >> 6, cpos = piece & 63;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + Lds::o_f32 + row * 1024 + cpos * 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_f32, row * 1024 + ((cpos ^ (row & 15)) * 16), tpx0 * 1024, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < (PLANES ? 2 : 0); ++u) {
             const int piece = u * 512 + tid;                            // [row][chunk position]
@@ -249,9 +292,11 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
         return nd;
     };
     f32x4 gt[2][5];
+    GNeed ndv[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};                   // what register set P holds (planned once, at the request)
     auto fetch_g = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
         const GNeed nd = g_need(cu_gf, tile);
+        ndv[P] = nd;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int item = w + 8 * i;                    // wave-uniform
@@ -259,13 +304,13 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
                 const int upper = nd.n > Lds::kGCols ? (item < Lds::kGCols ? 1 : 0) : 0;      // 36 items: the first 18 are row y0
                 int col = nd.c_lo + (item < Lds::kGCols ? item : item - Lds::kGCols);
                 col = col < Wp ? col : Wp - 1;
-                gt[P][i] = *reinterpret_cast<const f32x4*>(gprev + ((size_t)t * Hp * Wp + (size_t)(upper ? nd.y0 : nd.y1) * Wp + col) * kD + 4 * lane);
+                gt[P][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, lane * 16, ((upper ? nd.y0 : nd.y1) * Wp + col) * 1024, 0));
             }
         }
     };
     auto commit_g = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
-        const GNeed nd = g_need(cu_gc, tile);
+        const GNeed nd = ndv[P];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int item = w + 8 * i;
@@ -478,7 +523,7 @@ extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, cons
     hipError_t e = hipSuccess;
 #define SVPS_LFH(TAPS, F32, PL)                                                                                                    \
     do {                                                                                                                           \
-        const bool staged = TAPS && (W & 31) == 0;          /* a tile = 32 pixels of one output row: taps through LDS */           \
+        const bool staged = TAPS && (W & 31) == 0 && HW < (1 << 22);   /* a tile = 32 pixels of one output row; 32-bit frame offsets */ \
         auto kern = staged ? svps::level_fuse_hl_kernel<TAPS, F32, TAPS, PL> : svps::level_fuse_hl_kernel<TAPS, F32, false, PL>;  \
         static SvpsLdsAttr attr[2];                                                                                                \
         if ((e = attr[staged ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;             \
