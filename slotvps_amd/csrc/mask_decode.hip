@@ -307,7 +307,9 @@ __device__ unsigned long long k2_stamps[4][8][8];            // [wave][iteration
 // NW waves = 32 NW slots: 4 (L <= 128: two workgroups per CU) or 8 (L <= 256: one workgroup of 512 threads per CU)
 // LOGITS = false: argmax-only mode (out == NULL) - the [T, L, HW] logits are neither transposed nor stored: per pixel 512 B in and
 // 1 B out instead of 512 + 4 L + 1 (a consumer that only needs the per-pixel slot id, e.g. the clip driver's assignment map)
-// ABL (timing-only builds, -DSVPS_K2_ABLATE + tools/ablate_k2.sh): 1 no MFMAs, 2 no fragment reads either, 4 no argmax epilogue, 8 no DMA
+// ABL (timing-only builds, -DSVPS_K2_ABLATE + tools/ablate_k2.sh; the HL form: tools/kbench_k2hl.py with SVPS_K2_ABLATE): 1 no MFMAs, 2 no
+// fragment reads either, 4 no epilogue (the chain is then dead code as well: = 6), 8 no DMA, 64 no logit stores (round 5, HL at T = 40: base 2 120 us,
+// 64: 2 119 - the stores are free -, 2: 1 776, 6: 840, 14: 514)
 // HL (round 5, the reference-precision mode; NW = 4, MT = fp16): the map arrives as fp16 hi + lo planes. As in retr_attn_kernel<.., HL> a tile
 // is SIXTEEN pixels - LDS rows 0 .. 15 their hi rows (staged by waves 0, 1 from `feat`), rows 16 .. 31 their lo rows (waves 2, 3 from
 // `feat_lo`) - so ring, swizzle, fragment addresses, barrier schedule and vmcnt arithmetic are those of the 32-pixel form. The chain
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
                 const int sl = 8 * u + (lane_o >> 3), cc = lane_o & 7;
                 const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * Lds::kORow + cc * 16);
                 const int slot = 32 * w + sl, px = px0 + 4 * cc;
-                const bool ok = slot < L && px < px_end;
+                const bool ok = slot < L && px < px_end && !(ABL & 64);       // ABL 64 (timing only): no logit stores
                 store16_d(val, ors, ok ? (slot * HW + px) * 4 : 0x7ffffff0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -915,6 +917,21 @@ extern "C" int svps_mask_decode_hl_fwd(const void* feat_hi, const void* feat_lo,
 #define SVPS_HL(W, NS, AM) launch_decode<W, NS, AM, float, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)
     hipError_t e;
     static const bool old_form = getenv("SVPS_K2_HL_V1") != nullptr;         // comparison runs only (tools/kbench3.py)
+#ifdef SVPS_K2_ABLATE
+    if (const char* ae = getenv("SVPS_K2_ABLATE"); ae && L <= 128 && (HW & 3) == 0 && slot_argmax) {      // timing-only (tools/kbench_k2hl.py)
+#define SVPS_K2A(N) case N: ea = launch_decode_v2<true, 4, true, N, 0, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo); break;
+        hipError_t ea = hipErrorUnknown;
+        switch (atoi(ae)) {
+            SVPS_K2A(1) SVPS_K2A(2) SVPS_K2A(4) SVPS_K2A(5) SVPS_K2A(6) SVPS_K2A(8) SVPS_K2A(14) SVPS_K2A(64) SVPS_K2A(65) SVPS_K2A(72)
+            default: break;
+        }
+#undef SVPS_K2A
+        if (ea != hipErrorUnknown) {
+            svps_prof_mark(SVPS_KERNEL_MASK_DECODE, 1, stream);
+            return (int)ea;
+        }
+    }
+#endif
     if (L <= 128 && (HW & 3) == 0 && !old_form) {
         // round 5: the skewed fast path on 16-pixel hi / lo tiles (mask_decode_kernel_v2<.., HL>)
         e = slot_argmax ? launch_decode_v2<true, 4, true, 0, 0, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)

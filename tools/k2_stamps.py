@@ -14,16 +14,22 @@ ap.add_argument("--T", type=int, default=40)
 ap.add_argument("--H", type=int, default=256)
 ap.add_argument("--W", type=int, default=512)
 ap.add_argument("--logits", action="store_true")
+ap.add_argument("--hl", action="store_true", help="the fp16x2 form (hi / lo planes, logits + argmax)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 f = torch.randn((a.T, a.H * a.W, 256), generator=g, device=dev).to(torch.bfloat16)
 e = torch.relu(torch.randn((a.T, 100, 256), generator=g, device=dev))
 one, zero = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+if a.hl:
+    planes = ops.split_hl(2.0 * torch.randn((a.T, a.H * a.W, 256), generator=g, device=dev))
+    run = lambda: ops.mask_decode_hl(planes, e, one, zero, 0.1, 0.0, want_argmax=True)
+else:
+    run = lambda: ops.mask_decode(f, e, one, zero, 0.1, 0.0, want_argmax=True, want_logits=a.logits)
 t0 = time.time()
 while time.time() - t0 < 1.5:
     for _ in range(5):
-        ops.mask_decode(f, e, one, zero, 0.1, 0.0, want_argmax=True, want_logits=a.logits)
+        run()
     torch.cuda.synchronize()
 lib = _lib.load()
 st = np.zeros((4, 8, 8), dtype=np.uint64)
