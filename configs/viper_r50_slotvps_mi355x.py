@@ -26,7 +26,10 @@ model = dict(
         apply_mask_removal=True, apply_mask_removal_only_ins=True, use_mask_low_constant=False, num_classes=24),
     simple_track_head=dict(num_fcs_query=2, in_channels_query=256, query_matched_weight=1.0),
     other_config=dict(proposal_num=200, has_no_obj=True, pos_config=dict(position_embedding="sine", hidden_dim=256),
-                      test_forward_ref_img=True, test_only_save_main_results=True),
+                      test_forward_ref_img=True, test_only_save_main_results=True,
+                      # MI355X build only: precision mode of the slot head (MultiScaleDynamicMaskHead.MODES); "fp16x2" = the default, the
+                      # mode that meets the reference's outputs to 1e-4; "bf16" / "fp16" are opt-in 16-bit storage policies
+                      mode="fp16x2"),
 )
 train_cfg = None
 test_cfg = dict(loss_pano_weight=None, class_mapping={i: 12 + i for i in range(1, 11)})

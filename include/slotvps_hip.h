@@ -39,7 +39,7 @@ extern "C" {
 #define SVPS_FLAG_OUT_BF16 1 /* write mask logits as bf16 instead of fp32 */
 #define SVPS_FLAG_MAP_F16 2  /* the fused map `feat` is fp16, not bf16 (MultiScaleDynamicMaskHead.map_dtype = "fp16") */
 
-/* kernel ids for the profiling hooks */
+/* kernel ids of the launch hook (svps_set_launch_hook) */
 #define SVPS_KERNEL_SLOT_ATTN 0
 #define SVPS_KERNEL_SLOT_ATTN_FINISH 1
 #define SVPS_KERNEL_MASK_DECODE 2
@@ -200,8 +200,9 @@ int svps_deform_conv_fused_stats_fwd(const float* x_nhwc, const float* offset, c
 size_t svps_group_norm_relu_workspace_bytes(int N, int HW, int C);
 int svps_group_norm_relu_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y,
                              float* y_nchw, void* workspace, size_t workspace_bytes, int N, int HW, int C, void* stream);
-/* The same with a third optional result: y16 [N, HW, C] 16-bit pixel-major - bf16, or fp16 (saturating) with y16_is_fp16 - the
- * form in which the tower's LAST layer hands its output to svps_level_fuse_fwd (16-bit pixel-major `cur`; the linear 1x1 conv_trans
+/* The same with a third optional result: y16 [N, HW, C] 16-bit pixel-major - bf16 (y16_is_fp16 = 0), fp16 (1, saturating) or TWO fp16
+ * planes hi + lo [2, N, HW, C] (2: hi = fp16(x), lo = fp16(x - hi), what svps_level_fuse_hl_pm_fwd takes) - the form in which the tower's
+ * LAST layer hands its output to svps_level_fuse_fwd / svps_level_fuse_hl_pm_fwd (16-bit pixel-major `cur`; the linear 1x1 conv_trans
  * between them, mmdet/models/detectors/vps_capsule.py:76-79, folded into K4's weights by the caller); y, y_nchw, y16: any subset. */
 int svps_group_norm_relu16_fwd(const float* x, const float* gamma, const float* beta, int groups, float eps, float* y, float* y_nchw,
                                void* y16, int y16_is_fp16, void* workspace, size_t workspace_bytes, int N, int HW, int C, void* stream);
@@ -390,32 +391,15 @@ int svps_deform_im2col_bf16(const void* x_nhwc, const float* offset, void* cols,
                             int deformable_groups, int Ho, int Wo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Profiling hooks: when enabled every kernel launch of this library is bracketed by HIP events on
- * the launch stream. svps_prof_collect synchronises those events (host-blocking) and returns the
- * summed device time of one kernel id. Used by bench.py for the roofline line.
+ * Launch hook (round 6): the one trace point of the product library. Every entry point that launches one of the kernels named by
+ * SVPS_KERNEL_* calls svps_prof_mark(id, 0, stream) before and svps_prof_mark(id, 1, stream) behind its launches; with no hook
+ * installed (the default) that is one relaxed load and a branch. A profiler installs a callback with svps_set_launch_hook - the
+ * diagnostics library (include/slotvps_hip_diag.h, libslotvps_hip_diag.so: HIP events on the launch stream, bench.py's roofline leg)
+ * is one; the event bookkeeping, the hardware probes and the ablation / stamp builds are NOT part of this library.
  * ------------------------------------------------------------------------------------------- */
-void svps_prof_enable(int on);
-void svps_prof_reset(void);
+typedef void (*svps_launch_hook_t)(int kernel_id, int is_end, void* stream);
+void svps_set_launch_hook(svps_launch_hook_t hook);   /* NULL removes it */
 void svps_prof_mark(int kernel_id, int is_end, void* stream);
-int svps_prof_collect(int kernel_id, double* total_ms, int* launches);
-
-/* ---------------------------------------------------------------------------------------------
- * Hardware-semantics probes (diagnostics, used by tests/test_probes_gpu.py): they pin the
- * instruction behaviour the kernels rely on - MFMA 32x32x16 bf16 operand/result lane maps, the
- * ds_read_b64_tr_b16 transposed read, and the swizzled LDS-DMA tile image.
- *   probe_mfma: a [32,16] bf16, b [16,32] bf16 (row-major) -> c [32,32] fp32 = a @ b
- *   probe_tile: x [32, 256] bf16 -> rows [32,256] (through read_row_frag) and
- *               cols [32,256] (through read_col_frag), both must reproduce x
- * ------------------------------------------------------------------------------------------- */
-int svps_probe_mfma(const void* a, const void* b, float* c, void* stream);
-int svps_probe_tile(const void* x, void* rows, void* cols, void* stream);
-/* svps_probe_copy: dst[0:bytes] = src[0:bytes] with 16 B per lane streaming loads / stores (bytes a multiple of 16): the
- * known-bytes kernel the HBM counters are calibrated on and the hand-written copy ceiling of bench.py */
-int svps_probe_copy(const void* src, void* dst, size_t bytes, void* stream);
-/* svps_probe_mix: mixed-traffic streaming probe - per unit ri KiB are read from src and ro KiB written to dst (src >= units * ri
- * KiB, dst >= units * ro KiB, at least 1 KiB), every byte once: the read : write mix of a kernel without its arithmetic, to state
- * the box's ceiling for that mix (K4: 5 : 4). (ri, ro) in {(5,4), (1,1), (1,0), (0,1), (4,1), (2,1)}. */
-int svps_probe_mix(const void* src, void* dst, size_t units, int ri, int ro, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Statistics-fused retriever (K3' + K1'): MaskDynamicConv.forward (dynamic_mask_head.py:423-461) without k / v tensors.
@@ -500,6 +484,11 @@ int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const fl
  * ------------------------------------------------------------------------------------------- */
 int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
                            void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream);
+/* The same function with the incoming map as fp16 hi + lo PIXEL-MAJOR planes cur_hi / cur_lo [T, H*W, 128] (round 6: the semantic
+ * tower's own output rows as svps_group_norm_relu_stats_fwd(.., y16_is_fp16 = 2) writes them, with the linear conv_trans
+ * (vps_capsule.py:76-79) composed into wb / bc by the caller) - no NCHW detour, no split in the kernel: the operand tile is the rows. */
+int svps_level_fuse_hl_pm_fwd(const void* cur_hi, const void* cur_lo, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
+                              void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream);
 int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* tyk, int ty_rows, const float* txk, int tx_rows, int tx_tiled,
                            const void* rk_hi, const void* rk_lo, float lnk_eps, const void* rv_hi, const void* rv_lo,
                            const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D, void* stream);

@@ -8,6 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SLOTVPS_LIB") or os.path.join(_HERE, "libslotvps_hip.so")   # env: A/B builds
+# diagnostics (include/slotvps_hip_diag.h): HIP-event timing behind the product's launch hook, hardware / streaming probes. Loaded on
+# demand by bench.py's roofline leg, tests/test_probes_gpu.py and tools/ (load_diag); nothing in this package needs it to run
+DIAG_LIB_PATH = os.environ.get("SLOTVPS_DIAG_LIB") or os.path.join(_HERE, "libslotvps_hip_diag.so")
 
 ERR_NAMES = {-1: "SVPS_ERR_BAD_ARG", -2: "SVPS_ERR_BAD_SHAPE", -3: "SVPS_ERR_WORKSPACE"}
 
@@ -76,6 +79,7 @@ SIGNATURES = {
     "svps_retr_attn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "svps_retr_attn_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_level_fuse_hl_fwd": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),   # cur, gprev, wb_hi, wb_lo, bc, out_hi, out_lo, out_f32
+    "svps_level_fuse_hl_pm_fwd": (_i, [_vp] * 9 + [_i, _i, _i, _vp]),   # cur_hi, cur_lo, gprev, wb_hi, wb_lo, bc, out_hi, out_lo, out_f32
     "svps_retr_stats_hl_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "svps_retr_attn_hl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "svps_retr_attn_hl_fwd": (_i, [_vp] * 9 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -91,17 +95,25 @@ SIGNATURES = {
     "svps_slot_gemm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "svps_slot_gemm_f16_act": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "svps_slot_gemm_ln_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _vp]),
+    "svps_set_launch_hook": (None, [_vp]),
+    "svps_prof_mark": (None, [_i, _i, _vp]),
+}
+
+# name -> (restype, argtypes); must list every symbol of include/slotvps_hip_diag.h
+DIAG_SIGNATURES = {
+    "svps_diag_launch_hook": (None, [_i, _i, _vp]),
     "svps_prof_enable": (None, [_i]),
     "svps_prof_reset": (None, []),
-    "svps_prof_mark": (None, [_i, _i, _vp]),
     "svps_prof_collect": (_i, [_i, _c.POINTER(_c.c_double), _c.POINTER(_i)]),
     "svps_probe_mfma": (_i, [_vp, _vp, _vp, _vp]),
     "svps_probe_tile": (_i, [_vp, _vp, _vp, _vp]),
     "svps_probe_copy": (_i, [_vp, _vp, _sz, _vp]),
     "svps_probe_mix": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
+    "svps_probe_mfma_feed": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 _lib = None
+_diag = None
 
 
 class SlotVPSLibraryError(RuntimeError):
@@ -137,6 +149,32 @@ def load():
         raise SlotVPSLibraryError(f"ABI version {ver} != 1")
     _lib = lib
     return lib
+
+
+def load_diag():
+    """Load the diagnostics library once (include/slotvps_hip_diag.h) and install its HIP-event recorder as the product's launch hook
+    (svps_set_launch_hook): recording itself stays off until svps_prof_enable(1) (ops.KernelTimer). Raises if it is absent - a
+    measurement must not silently measure nothing."""
+    global _diag
+    if _diag is not None:
+        return _diag
+    lib = load()
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise SlotVPSLibraryError(f"{DIAG_LIB_PATH} not found: build it with `make -C slotvps_amd/csrc`")
+    try:
+        diag = ctypes.CDLL(DIAG_LIB_PATH)
+    except OSError as e:
+        raise SlotVPSLibraryError(f"cannot load {DIAG_LIB_PATH}: {e}") from e
+    for name, (res, args) in DIAG_SIGNATURES.items():
+        try:
+            fn = getattr(diag, name)
+        except AttributeError as e:
+            raise SlotVPSLibraryError(f"{DIAG_LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    lib.svps_set_launch_hook(ctypes.cast(diag.svps_diag_launch_hook, ctypes.c_void_p))
+    _diag = diag
+    return diag
 
 
 def check(code, what):

@@ -164,7 +164,7 @@ class UPSNetFPN(nn.Module):
     #                         framework's 3.0 per clip) - and no NCHW copy of the intermediate layers any more
     fuse_pred = True        # the prediction layer (three upsamplings + concat + 1x1 conv) as one kernel (csrc/semantic_pred.hip)
     fuse_norm = True        # pixel-major tower: K7' -> GroupNorm + ReLU (csrc/gn_relu.hip) without layout copies between the layers
-    emit_pm16 = None        # torch.bfloat16 / torch.float16: the last layer also writes its output as 16-bit pixel-major rows, kept in
+    emit_pm16 = None        # torch.bfloat16 / torch.float16 / "hl" (two fp16 planes hi + lo): the last layer also writes its output as 16-bit pixel-major rows, kept in
     #                         `last_pm16` (per returned level, coarse -> fine; None where the fused tower did not run): what K4 reads
     #                         when the detector folds conv_trans into K4's weights (VPS_Temporal_Slots.fold_trans)
     last_pm16 = None

@@ -84,14 +84,23 @@ class SlotClipRunner:
         self.outs = [None] * n_slots
         self.out = None
 
+    def _planes_in(self):
+        """input_form "tower16" in head mode fp16x2: the tower's rows as two fp16 planes hi + lo [2, T, HW, 128] (gn_relu.hip, round 6)."""
+        return self.input_form == "tower16" and self.head.precision == "fp16x2"
+
     def _input_dtype(self):
         if self.input_form == "nchw_f32":
             return torch.float32
+        if self._planes_in():
+            return torch.float16
         return torch.float16 if self.head._map_form() == "fp16" else torch.bfloat16
 
     def _alloc_inputs(self):
         dt = self._input_dtype()
         shape = (lambda h, w: (self.T, 128, h, w)) if self.input_form == "nchw_f32" else (lambda h, w: (self.T, h * w, 128))
+        if self._planes_in():
+            shape = lambda h, w: (2, self.T, h * w, 128)
+        self._alloc_key = (dt, self._planes_in())
         self.slots_feats = [[torch.zeros(shape(h, w), dtype=dt, device=self.device) for (h, w) in self.sizes] for _ in range(self.n_slots)]
         self.static_feats = self.slots_feats[0]
         self.graphs = [None] * self.n_slots
@@ -125,7 +134,7 @@ class SlotClipRunner:
         return out
 
     def load_clip(self, feats, slot=0):
-        if self.slots_feats[slot][0].dtype != self._input_dtype():         # the head's map dtype was switched: the rows follow it
+        if getattr(self, "_alloc_key", None) != (self._input_dtype(), self._planes_in()):   # the head's mode was switched: the rows follow it
             self._alloc_inputs()
         for dst, src in zip(self.slots_feats[slot], feats):
             dst.copy_(src)
@@ -192,6 +201,8 @@ class SlotClipRunner:
 
     def random_clip(self, seed):
         g = torch.Generator(device=self.device).manual_seed(seed)
+        if self._planes_in():
+            return [ops.split_hl(torch.randn((self.T, h * w, 128), generator=g, device=self.device).relu_()) for (h, w) in self.sizes]
         if self.input_form == "tower16":                                   # behind a ReLU: non-negative rows
             return [torch.randn((self.T, h * w, 128), generator=g, device=self.device).relu_().to(self._input_dtype()) for (h, w) in self.sizes]
         return [torch.randn((self.T, 128, h, w), generator=g, device=self.device) for (h, w) in self.sizes]

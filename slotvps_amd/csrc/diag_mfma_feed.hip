@@ -2,6 +2,7 @@
 // from LDS / registers, with vector fillers between the MFMAs, beside a second wave on the SIMD? tools/mfma_feed_probe.py.
 #include "common.h"
 #include "../../include/slotvps_hip.h"
+#include "../../include/slotvps_hip_diag.h"
 
 namespace svps {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;

@@ -2,6 +2,7 @@
 // production kernels use, so a wrong lane map shows up as a wrong matrix instead of a wrong mask.
 #include "common.h"
 #include "../../include/slotvps_hip.h"
+#include "../../include/slotvps_hip_diag.h"
 
 namespace svps {
 

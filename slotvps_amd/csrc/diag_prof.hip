@@ -1,11 +1,12 @@
-// Optional per-kernel device timing with HIP events on the launch stream (bench.py's roofline
-// line). Disabled by default: svps_prof_mark is then a single predictable branch.
+// DIAGNOSTICS library (libslotvps_hip_diag.so, include/slotvps_hip_diag.h): per-kernel device timing with HIP events on the launch
+// stream (bench.py's roofline leg). svps_diag_launch_hook is installed into the product library with svps_set_launch_hook.
 #include <hip/hip_runtime.h>
 
 #include <mutex>
 #include <vector>
 
 #include "../../include/slotvps_hip.h"
+#include "../../include/slotvps_hip_diag.h"
 
 namespace {
 
@@ -39,8 +40,6 @@ Prof& prof() {
 
 }  // namespace
 
-extern "C" int svps_abi_version(void) { return SVPS_ABI_VERSION; }
-
 extern "C" void svps_prof_enable(int on) { prof().on = on != 0; }
 
 extern "C" void svps_prof_reset(void) {
@@ -55,7 +54,7 @@ extern "C" void svps_prof_reset(void) {
     }
 }
 
-extern "C" void svps_prof_mark(int kernel_id, int is_end, void* stream) {
+extern "C" void svps_diag_launch_hook(int kernel_id, int is_end, void* stream) {
     Prof& p = prof();
     if (!p.on) return;
     if (kernel_id < 0 || kernel_id >= SVPS_KERNEL_COUNT) return;

@@ -101,8 +101,9 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const float* __restrict_
 }
 
 // tile = 32 consecutive pixels x C channels; LDS [32][C + 1] floats for the NCHW copy
-// y16 (nullable): the same values as 16-bit pixel-major rows - bf16 (f16 == 0) or fp16 (saturating at +-65 504) - the form in which
-// the tower's LAST layer hands its output to K4 (conv_trans folded into K4's weights); y (nullable) the fp32 rows the next K7' reads
+// y16 (nullable): the same values as 16-bit pixel-major rows - bf16 (f16 == 0), fp16 (f16 == 1, saturating at +-65 504) or TWO fp16 planes
+// hi + lo (f16 == 2: [2, N, HW, C], hi = fp16(x), lo = fp16(x - hi), the operand form of level_fuse_hl.hip: 22 bits of the fp32 value) - the
+// form in which the tower's LAST layer hands its output to K4 (conv_trans folded into K4's weights); y (nullable) the fp32 rows the next K7' reads
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float2* __restrict__ ab, float* __restrict__ y,
                                                        float* __restrict__ y_nchw, void* __restrict__ y16, int f16, int HW, int C,
                                                        int tiles_per_wg) {
@@ -138,7 +139,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                     if (y) *reinterpret_cast<f32x4*>(y + off) = o;
                     if (y16) {
                         uint2 pk;
-                        if (f16) {
+                        if (f16 == 2) {
+                            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                            h4 qh, ql;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float v = fminf(o[j], 65504.f);              // (o >= 0 behind the ReLU)
+                                asm volatile("" : "+v"(v));                  // ONE fp32 value for both halves (level_fuse_hl.hip, hl_split)
+                                qh[j] = (_Float16)v;
+                                ql[j] = (_Float16)(v - (float)qh[j]);
+                            }
+                            pk = __builtin_bit_cast(uint2, qh);
+                            *reinterpret_cast<uint2*>(static_cast<char*>(y16) + ((size_t)gridDim.y * HW * C + off) * 2) = __builtin_bit_cast(uint2, ql);
+                        } else if (f16) {
                             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                             h4 q;
 #pragma unroll

@@ -107,9 +107,12 @@ struct HlCursor {
     __device__ __forceinline__ int px0(int W) const { return y * W + 32 * strip; }
 };
 
-template <bool TAPS, bool F32OUT, bool STAGED = false, bool PLANES = true>
+// PMIN (round 6): the incoming map arrives as fp16 hi + lo PIXEL-MAJOR planes [T, HW, 128] (cur_ = hi, cur_lo_ = lo: the semantic tower's
+// own rows, gn_relu.hip) - a thread moves one 16-byte chunk of each plane straight into the operand tile: no transposition, no split.
+template <bool TAPS, bool F32OUT, bool STAGED = false, bool PLANES = true, bool PMIN = false>
 __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
-    const float* __restrict__ cur,            // [T, 128, H, W] fp32 (NCHW, the reference's layout)
+    const void* __restrict__ cur_,            // [T, 128, H, W] fp32 (NCHW, the reference's layout); PMIN: [T, HW, 128] fp16, the hi plane
+    const void* __restrict__ cur_lo_,         // PMIN: the lo plane
     const float* __restrict__ gprev,          // TAPS: [T, (H/2)*(W/2), 256] fp32 = f_{i-1} W_a^T, pixel-major
     const _Float16* __restrict__ wb_hi,       // [256, 128] weight of the incoming channels (level 0: W_1 + W_2 + W_3), hi and lo parts
     const _Float16* __restrict__ wb_lo,
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     int H, int W, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Lds = FuseHlLds;
+    const float* cur = static_cast<const float*>(cur_);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,7 +191,10 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
         return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t rs_cur = frame_rsrc(cur + (size_t)t * 128 * HW, (uint32_t)HW * 512u);
+    const __amdgpu_buffer_rsrc_t rs_cur = PMIN ? frame_rsrc(static_cast<const _Float16*>(cur_) + (size_t)t * HW * kHlK, (uint32_t)HW * 256u)
+                                               : frame_rsrc(cur + (size_t)t * 128 * HW, (uint32_t)HW * 512u);
+    const __amdgpu_buffer_rsrc_t rs_cur_lo = PMIN ? frame_rsrc(static_cast<const _Float16*>(cur_lo_) + (size_t)t * HW * kHlK, (uint32_t)HW * 256u) : rs_cur;
+    const int prow = tid >> 4, pchunk = tid & 15;                 // PMIN: this thread's (pixel row, 16-byte chunk) of the operand tile
     const __amdgpu_buffer_rsrc_t rs_g = frame_rsrc(STAGED ? gprev + (size_t)t * Hp * Wp * kD : cur, STAGED ? (uint32_t)(Hp * Wp) * 1024u : 0u);
     const __amdgpu_buffer_rsrc_t rs_hi = frame_rsrc(PLANES ? (const void*)(out_hi + (size_t)t * HW * kD) : (const void*)cur, PLANES ? (uint32_t)HW * 512u : 0u);
     const __amdgpu_buffer_rsrc_t rs_lo = frame_rsrc(PLANES ? (const void*)(out_lo + (size_t)t * HW * kD) : (const void*)cur, PLANES ? (uint32_t)HW * 512u : 0u);
@@ -195,6 +202,21 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     const int vo_c0 = (ch * HW + 4 * pg) * 4, vo_c1 = vo_c0 + HW * 4;
     auto fetch = [&](int tile, auto par) {
         constexpr int P = decltype(par)::value;
+        if constexpr (PMIN) {
+            const int tpx0 = take_px0(cu_fetch, tile);
+            if constexpr (STAGED) {
+                const int vo = prow * kHlRowBytes + pchunk * 16;
+                c0[P] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, vo, tpx0 * kHlRowBytes, 0));
+                c1[P] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur_lo, vo, tpx0 * kHlRowBytes, 0));
+            } else {
+                int px = tpx0 + prow;
+                px = px < HW ? px : HW - 1;
+                const size_t o = ((size_t)t * HW + px) * kHlK + 8 * pchunk;
+                c0[P] = *reinterpret_cast<const f32x4*>(static_cast<const _Float16*>(cur_) + o);
+                c1[P] = *reinterpret_cast<const f32x4*>(static_cast<const _Float16*>(cur_lo_) + o);
+            }
+            return;
+        }
         if constexpr (STAGED) {
             const int soff = take_px0(cu_fetch, tile) * 4;
             c0[P] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, vo_c0, soff, 0));
@@ -215,6 +237,11 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     };
     auto commit = [&](auto par) {
         constexpr int P = decltype(par)::value;
+        if constexpr (PMIN) {
+            *reinterpret_cast<f32x4*>(ah + hl_a_off(prow, pchunk)) = c0[P];
+            *reinterpret_cast<f32x4*>(al + hl_a_off(prow, pchunk)) = c1[P];
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 4 * pg + j;
@@ -505,9 +532,9 @@ extern "C" int svps_k4hl_debug_read(unsigned long long* stamps) {
 }
 #endif
 
-extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
-                                      void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream_) {
-    if (!cur || !wb_hi || !wb_lo || !bc || (!out_hi != !out_lo) || (!out_hi && !out_f32)) return SVPS_ERR_BAD_ARG;
+static int svps_level_fuse_hl_launch(const void* cur, const void* cur_lo, bool pm, const float* gprev, const void* wb_hi, const void* wb_lo,
+                                     const float* bc, void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream_) {
+    if (!cur || (pm && !cur_lo) || !wb_hi || !wb_lo || !bc || (!out_hi != !out_lo) || (!out_hi && !out_f32)) return SVPS_ERR_BAD_ARG;
     if (T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     if (gprev && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;     // x2 upsampling: even sizes
@@ -524,10 +551,11 @@ extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, cons
 #define SVPS_LFH(TAPS, F32, PL)                                                                                                    \
     do {                                                                                                                           \
         const bool staged = TAPS && (W & 31) == 0 && HW < (1 << 22);   /* a tile = 32 pixels of one output row; 32-bit frame offsets */ \
-        auto kern = staged ? svps::level_fuse_hl_kernel<TAPS, F32, TAPS, PL> : svps::level_fuse_hl_kernel<TAPS, F32, false, PL>;  \
-        static SvpsLdsAttr attr[2];                                                                                                \
-        if ((e = attr[staged ? 1 : 0].ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;             \
-        hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, cur, gprev, static_cast<const H16*>(wb_hi),              \
+        auto kern = pm ? (staged ? svps::level_fuse_hl_kernel<TAPS, F32, TAPS, PL, true> : svps::level_fuse_hl_kernel<TAPS, F32, false, PL, true>) \
+                       : (staged ? svps::level_fuse_hl_kernel<TAPS, F32, TAPS, PL, false> : svps::level_fuse_hl_kernel<TAPS, F32, false, PL, false>); \
+        static SvpsLdsAttr attr[4];                                                                                                \
+        if ((e = attr[(pm ? 2 : 0) + (staged ? 1 : 0)].ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e; \
+        hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), lds, stream, cur, cur_lo, gprev, static_cast<const H16*>(wb_hi),      \
                            static_cast<const H16*>(wb_lo), bc, static_cast<H16*>(out_hi), static_cast<H16*>(out_lo), out_f32, H, W, tpc); \
     } while (0)
     if (!out_hi) { if (gprev) SVPS_LFH(true, true, false); else SVPS_LFH(false, true, false); }
@@ -537,4 +565,15 @@ extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, cons
     e = hipGetLastError();
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 1, stream);
     return (int)e;
+}
+
+extern "C" int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
+                                      void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream_) {
+    return svps_level_fuse_hl_launch(cur, nullptr, false, gprev, wb_hi, wb_lo, bc, out_hi, out_lo, out_f32, T, H, W, stream_);
+}
+
+// svps_level_fuse_hl_pm_fwd (include/slotvps_hip.h): the same with the incoming map as fp16 hi + lo pixel-major planes [T, H*W, 128]
+extern "C" int svps_level_fuse_hl_pm_fwd(const void* cur_hi, const void* cur_lo, const float* gprev, const void* wb_hi, const void* wb_lo,
+                                         const float* bc, void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream_) {
+    return svps_level_fuse_hl_launch(cur_hi, cur_lo, true, gprev, wb_hi, wb_lo, bc, out_hi, out_lo, out_f32, T, H, W, stream_);
 }

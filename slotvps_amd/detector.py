@@ -38,15 +38,17 @@ class _AttrDict(dict):
 
 class LevelMaps(list):
     """The level maps the trunk hands to the slot head, coarse -> fine. `hws` their sizes; `folded`: the maps are the semantic tower's OWN
-    output as 16-bit pixel-major rows [T, Hi*Wi, 128] and conv_trans (vps_capsule.py:76-79, a linear 1x1 conv) is still to be
-    applied - the head folds it into K4's weights; otherwise [T, 128, Hi, Wi] fp32 maps behind conv_trans, the reference's tensors."""
+    output as 16-bit pixel-major rows [T, Hi*Wi, 128] (head mode fp16x2: two fp16 planes hi + lo, [2, T, Hi*Wi, 128]) and conv_trans
+    (vps_capsule.py:76-79, a linear 1x1 conv) is still to be applied - the head folds it into K4's weights; otherwise [T, 128, Hi, Wi]
+    fp32 maps behind conv_trans, the reference's tensors."""
     hws = None
     folded = False
 
     @staticmethod
     def cat(a, b):
         """Frames of `a` followed by the frames of `b` (same geometry, same form)."""
-        out = LevelMaps(torch.cat([x, y], 0) for x, y in zip(a, b))
+        planes = bool(getattr(a, "folded", False)) and a[0].dim() == 4         # [2, T, HW, 128]: the frame axis is dim 1
+        out = LevelMaps(torch.cat([x, y], 1 if planes else 0) for x, y in zip(a, b))
         out.hws = getattr(a, "hws", None) or [tuple(x.shape[-2:]) for x in a]
         out.folded = bool(getattr(a, "folded", False))
         assert out.folded == bool(getattr(b, "folded", False))
@@ -304,7 +306,8 @@ class VPS_Temporal_Slots(nn.Module):
         self.use_graph = False                   # replay the slot head as one hipGraph per input geometry (_head_clip)
         # conv_trans folded into K4's weights (round 4): the semantic tower's last GroupNorm + ReLU writes its output as 16-bit
         # pixel-major rows and K4 reads THOSE (256 instead of 512 B per pixel, no framework conv, no layout copy in between). Applies in
-        # the 16-bit precision of the head with the pixel-major tower (fp32 trunk); otherwise the reference's tensors as before
+        # the 16-bit modes of the head and - as two fp16 planes hi + lo, round 6 - in mode fp16x2, with the pixel-major tower (fp32
+        # trunk); otherwise (exact mode, bf16 trunk) the reference's tensors as before
         self.fold_trans = True
         self._head_cache = {}
         self._trunk_bf16 = False
@@ -356,7 +359,9 @@ class VPS_Temporal_Slots(nn.Module):
         head = im.dynamic_mask_head
         pf = im.panopticFPN
         want16 = None
-        if self.fold_trans and head.precision == "bf16" and hasattr(pf, "emit_pm16"):
+        if self.fold_trans and head.precision == "fp16x2" and hasattr(pf, "emit_pm16"):
+            want16 = "hl"                                    # two fp16 planes hi + lo: K4-HL's operand tile is the tower's rows (round 6)
+        elif self.fold_trans and head.precision == "bf16" and hasattr(pf, "emit_pm16"):
             want16 = torch.float16 if head._map_form() == "fp16" else torch.bfloat16
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.trunk_bf16):
             x = im.backbone(imgs)

@@ -345,7 +345,8 @@ def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False, wan
     """relu(GroupNorm(groups)(x)) for pixel-major fp32 activations x [N, HW, C] (csrc/gn_relu.hip) -> (y [N, HW, C], y_nchw [N, C, HW]
     or None): the normalisation of the semantic tower in the layout of the deformable-convolution kernel, optionally also in the
     layout the framework's convolutions take. want_16 = torch.bfloat16 / torch.float16: a third result, the same values as 16-bit
-    pixel-major rows (what K4 takes as its incoming map); want_pm = False drops the fp32 rows (the tower's last layer).
+    pixel-major rows (what K4 takes as its incoming map); want_16 = "hl": as TWO fp16 planes [2 (hi, lo), N, HW, C] with hi + lo = y to 22
+    bits (what K4-HL takes, mode fp16x2: level_fuse_hl_g); want_pm = False drops the fp32 rows (the tower's last layer).
     stats = (partial [N, chunks, 2, C], chunks): per-channel sums from the kernel that produced x (dcn.deform_conv_fused_pm(...,
     gn_stats=True)) - the moments pass over x is skipped."""
     lib = _lib.load()
@@ -355,11 +356,15 @@ def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False, wan
     _need(beta, "beta", torch.float32, 1)
     if gamma.numel() != C or beta.numel() != C:
         raise ValueError("group_norm_relu_pm: affine parameters do not match C")
-    if want_16 not in (None, torch.bfloat16, torch.float16):
-        raise ValueError("group_norm_relu_pm: want_16 is torch.bfloat16, torch.float16 or None")
+    if want_16 not in (None, torch.bfloat16, torch.float16, "hl"):
+        raise ValueError("group_norm_relu_pm: want_16 is torch.bfloat16, torch.float16, 'hl' or None")
     y = torch.empty_like(x) if want_pm else None
     yn = torch.empty((N, C, HW), dtype=torch.float32, device=x.device) if want_nchw else None
-    y16 = torch.empty((N, HW, C), dtype=want_16, device=x.device) if want_16 is not None else None
+    if want_16 == "hl":
+        y16 = torch.empty((2, N, HW, C), dtype=torch.float16, device=x.device)
+    else:
+        y16 = torch.empty((N, HW, C), dtype=want_16, device=x.device) if want_16 is not None else None
+    f16_flag = 2 if want_16 == "hl" else int(want_16 == torch.float16)
     ws_bytes = lib.svps_group_norm_relu_workspace_bytes(N, HW, C)
     ws = torch.empty(max(ws_bytes, 4) // 4, dtype=torch.float32, device=x.device)
     with _on(x, gamma, beta, y, yn, y16, ws) as ctx:
@@ -367,7 +372,7 @@ def group_norm_relu_pm(x, gamma, beta, groups=32, eps=1e-5, want_nchw=False, wan
         if part is not None and (part.dtype != torch.float32 or not part.is_contiguous() or part.numel() != N * chunks * 2 * C):
             raise ValueError("group_norm_relu_pm: stats must be ([N, chunks, 2, C] fp32 contiguous, chunks)")
         rc = lib.svps_group_norm_relu_stats_fwd(_ptr(x), _ptr(part), chunks, _ptr(gamma), _ptr(beta), int(groups), float(eps), _ptr(y),
-                                                _ptr(yn), _ptr(y16), int(want_16 == torch.float16), _ptr(ws), ws_bytes, N, HW, C, ctx.stream)
+                                                _ptr(yn), _ptr(y16), f16_flag, _ptr(ws), ws_bytes, N, HW, C, ctx.stream)
     _lib.check(rc, "svps_group_norm_relu_stats_fwd")
     if want_16 is not None:
         return y, yn, y16
@@ -791,32 +796,53 @@ def level_fuse_hl_weights(wc):
     return {"wb_hl": split_hl(wb), "w0_hl": split_hl(w0), "wa_pack": pack_b_fragments(w[:, :256].float().contiguous(), "fp16")}
 
 
-def level_fuse_hl_composed(wc, bc, n_levels=4):
+def level_fuse_hl_composed(wc, bc, n_levels=4, pre=None):
     """Operands of the level recursion WITHOUT any 256-wide product (csrc/level_fuse_hl.hip, round 5): with W = [W_a | W_b] and
     G^(m)_i = f_i (W_a^m)^T, G^(m)_i = up(G^(m+1)_{i-1}) + (W_a^m W_b) x_i + W_a^m b (level 0: W_a^m (W_1 + W_2 + W_3) x_0). Composed in
-    float64: {"w": [m] -> [2, 256, 128] fp16 planes of W_a^m W_b, "w0": the same for level 0, "b": [m] -> [256] fp32 = W_a^m b}, m < n_levels."""
+    float64: {"w": [m] -> [2, 256, 128] fp16 planes of W_a^m W_b, "w0": the same for level 0, "b": [m] -> [256] fp32 = W_a^m b, "b0": the
+    level-0 bias}, m < n_levels. pre = (W_t [128, 128(, 1, 1)], b_t [128] or None): a linear 1x1 map x = W_t y + b_t in front of the head
+    (the detector's conv_trans, vps_capsule.py:76-79) composed into them, so that the kernel reads y: W_b -> W_b W_t, b -> b + W_b b_t
+    (level 0 with W_1 + W_2 + W_3 in the place of W_b)."""
     w = wc.detach().double().reshape(256, 384)
     b = bc.detach().double()
     wa, wb = w[:, :256], w[:, 256:]
     w0 = w[:, :128] + w[:, 128:256] + w[:, 256:]
-    out = {"w": [], "w0": [], "b": []}
+    b_lvl, b_lvl0 = b, b
+    if pre is not None:
+        wt = pre[0].detach().double().reshape(pre[0].shape[0], -1)
+        if wt.shape != (128, 128):
+            raise ValueError(f"level_fuse_hl_composed: pre_linear must map 128 -> 128 channels, got {tuple(wt.shape)}")
+        if pre[1] is not None:
+            bt = pre[1].detach().double()
+            b_lvl, b_lvl0 = b + wb @ bt, b + w0 @ bt
+        wb, w0 = wb @ wt, w0 @ wt
+    out = {"w": [], "w0": [], "b": [], "b0": []}
     p = torch.eye(256, dtype=torch.float64, device=w.device)
     for m in range(n_levels):
         out["w"].append(split_hl((p @ wb).float().contiguous()))
         out["w0"].append(split_hl((p @ w0).float().contiguous()))
-        out["b"].append((p @ b).float().contiguous())
+        out["b"].append((p @ b_lvl).float().contiguous())
+        out["b0"].append((p @ b_lvl0).float().contiguous())
         p = wa @ p
     return out
 
 
 def level_fuse_hl_g(cur, gprev, w_hl, bias, H, W, planes=True, f32=False):
-    """One launch of K4-HL: out = up(gprev) + w cur + bias. cur [T, 128, H, W] fp32 NCHW; gprev [T, (H/2)(W/2), 256] fp32 or None; w_hl
+    """One launch of K4-HL: out = up(gprev) + w cur + bias. cur [T, 128, H, W] fp32 NCHW, or [2 (hi, lo), T, H*W, 128] fp16 pixel-major
+    planes (the semantic tower's own rows: group_norm_relu_pm(want_16="hl")); gprev [T, (H/2)(W/2), 256] fp32 or None; w_hl
     [2, 256, 128] fp16 planes; bias [256] fp32. Returns (planes [2, T, H*W, 256] fp16 or None, fp32 [T, H*W, 256] or None)."""
     lib = _lib.load()
-    _need(cur, "cur", torch.float32, 4)
-    T = cur.shape[0]
-    if cur.shape != (T, 128, H, W):
-        raise ValueError(f"cur {tuple(cur.shape)} != [T, 128, {H}, {W}]")
+    pm = isinstance(cur, torch.Tensor) and cur.dtype == torch.float16
+    if pm:
+        _need(cur, "cur", torch.float16, 4)
+        T = cur.shape[1]
+        if cur.shape != (2, T, H * W, 128):
+            raise ValueError(f"cur {tuple(cur.shape)} != [2, T, {H * W}, 128]")
+    else:
+        _need(cur, "cur", torch.float32, 4)
+        T = cur.shape[0]
+        if cur.shape != (T, 128, H, W):
+            raise ValueError(f"cur {tuple(cur.shape)} != [T, 128, {H}, {W}]")
     _need(bias, "bias", torch.float32, 1)
     _need(w_hl, "w_hl", torch.float16, 3)
     if gprev is not None:
@@ -828,9 +854,12 @@ def level_fuse_hl_g(cur, gprev, w_hl, bias, H, W, planes=True, f32=False):
     out = torch.empty((2, T, H * W, 256), dtype=torch.float16, device=cur.device) if planes else None
     o32 = torch.empty((T, H * W, 256), dtype=torch.float32, device=cur.device) if f32 else None
     with _on(cur, gprev, w_hl, bias) as ctx:
-        rc = lib.svps_level_fuse_hl_fwd(_ptr(cur), _ptr(gprev), _ptr(w_hl[0]), _ptr(w_hl[1]), _ptr(bias), _ptr(out[0]) if planes else None,
-                                        _ptr(out[1]) if planes else None, _ptr(o32), T, H, W, ctx.stream)
-    _lib.check(rc, "svps_level_fuse_hl_fwd")
+        outs = (_ptr(out[0]) if planes else None, _ptr(out[1]) if planes else None, _ptr(o32), T, H, W, ctx.stream)
+        if pm:
+            rc = lib.svps_level_fuse_hl_pm_fwd(_ptr(cur[0]), _ptr(cur[1]), _ptr(gprev), _ptr(w_hl[0]), _ptr(w_hl[1]), _ptr(bias), *outs)
+        else:
+            rc = lib.svps_level_fuse_hl_fwd(_ptr(cur), _ptr(gprev), _ptr(w_hl[0]), _ptr(w_hl[1]), _ptr(bias), *outs)
+    _lib.check(rc, "svps_level_fuse_hl_pm_fwd" if pm else "svps_level_fuse_hl_fwd")
     return out, o32
 
 
@@ -1047,21 +1076,22 @@ def mask_decode_f32(feat, embed, bn_scale, bn_shift, fg_scale, fg_shift):
 
 
 class KernelTimer:
-    """Device-time accounting of the library's own launches (HIP events on the launch stream)."""
+    """Device-time accounting of the library's own launches (HIP events on the launch stream): the diagnostics library
+    (libslotvps_hip_diag.so) behind the product's launch hook - measurement code, not part of the product path."""
 
     def __enter__(self):
-        lib = _lib.load()
+        lib = _lib.load_diag()
         lib.svps_prof_reset()
         lib.svps_prof_enable(1)
         return self
 
     def __exit__(self, *exc):
-        _lib.load().svps_prof_enable(0)
+        _lib.load_diag().svps_prof_enable(0)
         return False
 
     @staticmethod
     def collect(kernel_id):
-        lib = _lib.load()
+        lib = _lib.load_diag()
         ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
         _lib.check(lib.svps_prof_collect(kernel_id, ctypes.byref(ms), ctypes.byref(n)), "svps_prof_collect")
         return ms.value, n.value

@@ -32,6 +32,12 @@ from . import ops
 from .registry import HEADS
 
 BF16 = torch.bfloat16
+# The mode every module of this file starts in (MultiScaleDynamicMaskHead.MODES): "fp16x2" is the fastest mode that meets the north star's
+# tolerance against the reference's own fp32 outputs at full size (1e-4 on the mask logits; tests/test_full_size_gpu.py). The 16-bit
+# storage policies ("bf16", "fp16") are opt-in: other_config=dict(mode="bf16") / head.set_mode("bf16") - 2x the rate, 1.4e-2 / 1.9e-3 from
+# the reference.
+DEFAULT_MODE = "fp16x2"
+DEFAULT_PRECISION = "fp16x2"
 
 
 def _get_activation_fn(activation):
@@ -192,7 +198,7 @@ class MaskDynamicConv(nn.Module):
         self.norm1 = nn.LayerNorm(dh_dim)
         self.activation = nn.ReLU(inplace=True)
         self.split_p = True     # carry softmax probabilities as bf16 hi+lo inside K1
-        self.precision = "bf16"  # "fp32": exact mode (csrc/exact_f32.hip)
+        self.precision = DEFAULT_PRECISION   # "fp16x2" (default), "bf16" (16-bit level maps), "fp32" (exact mode, csrc/exact_f32.hip)
         # bf16 mode, two forms of the same function: "fused" (default where it applies, L <= 128): statistics-fused retriever
         # K3' + K1' - no k / v tensors, the map is read once per kernel; "kv": K3 writes bf16 k / v, K1 streams them
         self.retriever = "fused"
@@ -438,7 +444,7 @@ class SlotsDynamicConv(nn.Module):
         self.norm_v = nn.LayerNorm(dh_dim)
         self.norm1 = nn.LayerNorm(dh_dim)
         self.activation = nn.ReLU(inplace=True)
-        self.precision = "bf16"
+        self.precision = DEFAULT_PRECISION
         self.use_slot_gemm = True
 
     def forward(self, curr_features, features, pos, groups=1):
@@ -499,7 +505,7 @@ class TemporalSlotsHead(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.norm3 = nn.LayerNorm(d_model)
         self.activation = _get_activation_fn(activation)
-        self.precision = "bf16"
+        self.precision = DEFAULT_PRECISION
         self.use_slot_gemm = True
 
     def forward(self, features, mask_query, pos=None, query_pos=None, add_input=False, groups=1):
@@ -547,7 +553,7 @@ class MaskRCNNHead(nn.Module):
         self.use_focal = use_focal
         self.class_logits = nn.Linear(d_model, num_classes)
         self.scale_clamp = scale_clamp
-        self.precision = "bf16"
+        self.precision = DEFAULT_PRECISION
         self.use_slot_gemm = True
 
     def _self_attention(self, slots, residual_norm=False):
@@ -705,6 +711,12 @@ class MultiScaleDynamicMaskHead(nn.Module):
         self.map_encoding = "auto"                       # "bf16": plain bf16 tensors for the bf16 policy (see _map_form)
         self.stats_form = "level"                        # "level": K3'' - both stages of a pyramid level from one read of the map; "stage": K3' per stage
         self._cfg_mode = other_config.get("mode") if isinstance(other_config, dict) else None
+        if isinstance(other_config, dict):
+            # the switches of rounds 1 - 4 were collapsed into `mode`: a config that still carries them must not silently run another mode
+            legacy = sorted(k for k in ("precision", "map_dtype", "retriever", "statistics") if k in other_config)
+            if legacy:
+                raise ValueError(f"other_config keys {legacy} are no longer read: select the head mode with other_config=dict(mode=...), "
+                                 f"one of {sorted(self.MODES)} (default {DEFAULT_MODE!r})")
         self.trans_in_dim = trans_in_dim
         self.apply_temporal_query_atten_stages = apply_temporal_query_atten_stages
         self.other_config = other_config
@@ -731,11 +743,10 @@ class MultiScaleDynamicMaskHead(nn.Module):
         if use_focal:
             self.prior_prob = prior_prob
             self.bias_value = -math.log((1 - prior_prob) / prior_prob)
-        self.precision = "bf16"
-        self.mode = "bf16"
+        self.precision = DEFAULT_PRECISION
+        self.mode = DEFAULT_MODE
         self._reset_parameters()
-        if self._cfg_mode is not None:
-            self.set_mode(self._cfg_mode)
+        self.set_mode(self._cfg_mode if self._cfg_mode is not None else DEFAULT_MODE)
 
     # THE mode surface of the head: name -> (precision, storage of the level maps, retriever form). What each costs and how far it sits
     # from the reference's own fp32 outputs at BASELINE's sizes: tests/test_full_size_gpu.py, bench.py (config.mode_*), README.
@@ -832,8 +843,13 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 if pre[1] is not None:
                     b = (conv.bias.detach().double() + wx_sum @ pre[1].detach().double()).float()
             ent = (w.to(torch.float16 if form == "fp16" else BF16).contiguous(), b)     # (bf16 weights in the bf16-in-fp16 form as well)
-            while len(cache) >= 8:                       # evict the OLDEST entry only (dict order = insertion order): the tensors of the
-                cache.pop(next(iter(cache)))             # newer entries may be baked into a live hipGraph of a clip runner
+            # Entries may be baked into a live hipGraph (SlotClipRunner, detector._head_cache): an entry of the CURRENT weight version is
+            # never evicted (at most form x level0 x pre = a handful per version); entries of older weight versions go - a graph keyed
+            # on them is re-captured by its owner anyway (both owners key their graphs on the parameter versions)
+            for k in [k for k in cache if k[:4] != key[:4]]:
+                del cache[k]
+            while len(cache) >= 32:                      # (a caller cycling through many pre_linear tensors on one weight version)
+                cache.pop(next(iter(cache)))
             cache[key] = ent
         return ent
 
@@ -841,33 +857,37 @@ class MultiScaleDynamicMaskHead(nn.Module):
         """K4 (:171-188). cur [T, 128, H, W] fp32 (the reference's layout) or [T, H*W, 128] 16-bit pixel-major (bf16; fp16 with
         map_dtype "fp16"); prev_pm [T, (H/2)*(W/2), 256] fused map of the coarser level or None (level 0); pre: see _conv_weights.
         Returns the fused map [T, H*W, 256] pixel-major."""
-        if pre is not None and self.precision != "bf16":
-            raise NotImplementedError("a folded pre_linear needs the 16-bit level fusion (precision 'bf16')")
+        if pre is not None and self.precision not in ("bf16", "fp16x2"):
+            raise NotImplementedError("a folded pre_linear needs the 16-bit or the fp16x2 level fusion (precision 'bf16' / 'fp16x2')")
         if self.precision == "fp32":
             conv = self.conv_trans.conv
             wT = _cached(self, "cwT", [conv.weight], lambda: conv.weight.reshape(self.dh_dim, self.trans_in_dim).t().contiguous())
             return ops.level_fuse_f32(cur.float().contiguous(), prev_pm, wT, conv.bias, hw[0], hw[1])
         if self.precision == "fp16x2":
             conv = self.conv_trans.conv
-            if cur.dim() != 4:
-                raise NotImplementedError("precision 'fp16x2' takes the incoming maps as [T, 128, H, W] fp32 (NCHW)")
+            planes_in = cur.dim() == 4 and cur.dtype == torch.float16       # [2 (hi, lo), T, HW, 128]: the semantic tower's own rows
+            if cur.dim() != 4 or (pre is not None and not planes_in):
+                raise NotImplementedError("precision 'fp16x2' takes the incoming maps as [T, 128, H, W] fp32 (NCHW) or, with a folded "
+                                          "pre_linear, as fp16 hi + lo pixel-major planes [2, T, H*W, 128]")
             # the level recursion without any 256-wide product (csrc/level_fuse_hl.hip): G^(m)_i = f_i (W_a^m)^T = up(G^(m+1)_{i-1}) +
             # (W_a^m W_b) x_i + W_a^m b. `level` counts from the coarsest; level i produces the orders m = 0 .. (levels_left) its finer
             # levels will ask for: m = 0 the planes of f_i, m >= 1 fp32 only
-            cw = _cached(self, "cw_hl_composed", [conv.weight, conv.bias],
-                         lambda: ops.level_fuse_hl_composed(conv.weight, conv.bias, self.feat_num_levels))
+            srcs = [conv.weight, conv.bias] + ([t for t in pre if t is not None] if pre is not None else [])
+            cw = _cached(self, "cw_hl_composed" + ("_pre" if pre is not None else ""), srcs,
+                         lambda: ops.level_fuse_hl_composed(conv.weight, conv.bias, self.feat_num_levels, pre=pre))
             if prev_pm is None:
                 level, gp = 0, {}
             else:
                 level, gp = prev_pm._svps_level + 1, prev_pm._svps_g
             orders = 1 if last else max(1, self.feat_num_levels - level)
-            cur32 = cur.float().contiguous()
+            cur_in = cur.contiguous() if planes_in else cur.float().contiguous()
             out, g = None, {}
             for m in range(orders):
                 if prev_pm is not None and (m + 1) not in gp:
                     raise RuntimeError(f"level {level} needs G^({m + 1}) of the level below (was that level fused with last=True?)")
                 w_hl = cw["w0"][m] if prev_pm is None else cw["w"][m]
-                planes, f32 = ops.level_fuse_hl_g(cur32, None if prev_pm is None else gp[m + 1], w_hl, cw["b"][m], hw[0], hw[1],
+                bias = cw["b0"][m] if prev_pm is None else cw["b"][m]
+                planes, f32 = ops.level_fuse_hl_g(cur_in, None if prev_pm is None else gp[m + 1], w_hl, bias, hw[0], hw[1],
                                                   planes=m == 0, f32=m > 0)
                 if m == 0:
                     out = planes
@@ -890,7 +910,8 @@ class MultiScaleDynamicMaskHead(nn.Module):
         (T % clip_frames == 0): every kernel then covers all of them in one launch and the temporal slot attention
         stays inside each clip. None = one clip of T frames (the reference's call).
         feats: list over the 4 levels (coarse -> fine) of [T, 128, Hi, Wi] fp32 (NCHW, the reference's
-        layout) or [T, Hi*Wi, 128] 16-bit pixel-major (then hws = [(Hi, Wi)] is required); pre_linear = (W_t, b_t): a linear 1x1 map
+        layout), [T, Hi*Wi, 128] 16-bit pixel-major (16-bit modes) or [2 (hi, lo), T, Hi*Wi, 128] fp16 planes (mode fp16x2) - the
+        pixel-major forms need hws = [(Hi, Wi)]; pre_linear = (W_t, b_t): a linear 1x1 map
         in front of the head folded into K4's weights (_conv_weights: the detector's conv_trans - the feats are then ITS input, the
         semantic tower's own output); init_slots [L, 256];
         pos_tabs: per level the separable sine tables (ytab [Hi, 128], xtab [Wi, 128]) of
@@ -899,7 +920,8 @@ class MultiScaleDynamicMaskHead(nn.Module):
         [2, T, Hi*Wi, 256] fp16, the hi and lo planes)."""
         if not feats[0].is_cuda:
             raise RuntimeError("MultiScaleDynamicMaskHead runs on the GPU only; there is no CPU fallback")
-        T = feats[0].shape[0]
+        planes_in = feats[0].dim() == 4 and feats[0].dtype == torch.float16
+        T = feats[0].shape[1] if planes_in else feats[0].shape[0]
         clips = 1 if clip_frames is None else T // clip_frames
         if clip_frames is not None and clips * clip_frames != T:
             raise ValueError(f"T={T} is not a multiple of clip_frames={clip_frames}")
@@ -918,7 +940,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
         prev = None
         stage_idx = 0
         for i in range(self.feat_num_levels):
-            if feats[i].dim() == 4:
+            if feats[i].dim() == 4 and not planes_in:
                 h, w = feats[i].shape[-2:]
             else:
                 h, w = hws[i]
@@ -967,7 +989,10 @@ class MultiScaleDynamicMaskHead(nn.Module):
             per = []
             for i in range(nlev):
                 _, _, h, w = feats[i].shape
-                per.append(fused[i][t].view(h, w, -1).permute(2, 0, 1).unsqueeze(0))
+                f = fused[i]
+                # precision "fp16x2": the map is two fp16 planes [2 (hi, lo), T, HW, 256] - the frame is their sum (fp32, 22 bits)
+                ft = (f[0, t].float() + f[1, t].float()) if f.dim() == 4 else f[t]
+                per.append(ft.view(h, w, -1).permute(2, 0, 1).unsqueeze(0))
             ret_feats.append(per)
         if self.return_intermediate:
             return ([logits[:, t:t + 1] for t in range(T)], [embeds[:, t:t + 1] for t in range(T)], ret_feats)

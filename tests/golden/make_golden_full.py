@@ -24,7 +24,17 @@ that makes every third slot a confident segment: synth.full_size_class_bias) and
 output size 1024 x 2048, followed by the relabel of simple_test :411-435 (oracle/postprocess_oracle.panoptic_relabel, itself pinned by
 tests/golden/simple_test.npz): the uint8 panoptic id map of the frame, the kept slots and their labels.
 
-Runs only here (needs /root/reference); ~5 minutes, ~25 GB. Usage: python tests/golden/make_golden_full.py
+Round 6 part (tests/golden/head_full_r06.npz; `python tests/golden/make_golden_full.py --part r06`; head_full.npz stays as it is):
+  T10_1088x1920_L200       config 5 AT ITS OWN CLIP LENGTH: T = 10 frames, 200 slots - the temporal step attends over T L = 2000 slot rows
+                           (a 2000 x 2000 softmax over the query axis, dynamic_mask_head.py:559-567); all the keys of the cases above plus
+                           `mask_dense`, the mask logits of frames 0 and T - 1 at stride (4, 8)
+  T5_1024x2048_L100        re-run (the regenerated embeddings are asserted equal to head_full.npz's); new keys only: `mask_dense` - the mask
+                           logits of frames 0 and T - 1 at stride (2, 4), 16 x the samples of `mask_sample` -, and the reference's OWN
+                           disagreement on the integer targets as COUNTS: `floor_argmax_diff_pixels` (fp32 run vs the same modules in float64,
+                           all T HW pixels) and `floor_pan_diff_pixels_{t}` (the reference's post-process + relabel on the float64 outputs
+                           against the same on the fp32 outputs, frames 0 and T - 1)
+
+Runs only here (needs /root/reference); ~5 minutes, ~25 GB (part r06: ~25 minutes). Usage: python tests/golden/make_golden_full.py [--part r06]
 """
 import os
 import sys
@@ -47,6 +57,10 @@ CASES = {   # tag: (T, H, W, L, num_classes, seed, tau, (sy, sx) mask sample str
     "T2_1088x1920_L200": (2, 1088, 1920, 200, 24, 503, 0.25, (8, 16)),
     "T2_1024x2048_L100_swin": (2, 1024, 2048, 100, 20, 504, 0.25, (8, 16)),
 }
+CASES_R06 = {   # written to head_full_r06.npz; (.., (sy, sx) sample strides, (dy, dx) dense strides on frames 0 and T - 1)
+    "T10_1088x1920_L200": (10, 1088, 1920, 200, 24, 505, 0.25, (8, 16), (4, 8)),
+    "T5_1024x2048_L100": CASES["T5_1024x2048_L100"] + ((2, 4),),
+}
 # head-config overrides per case (the Swin-L config's head: ReLU in the stage FFN, GELU in the temporal head - swinL_fpn_slotvps.py:41)
 CFG_OVERRIDES = {"T2_1024x2048_L100_swin": dict(activation="relu", temporal_activation="gelu")}
 FUSED3_STRIDE, FUSED0_STRIDE = 16, 4
@@ -65,7 +79,7 @@ def build_head(dmh, nc, over=None):
 
 
 def run(dmh, pos_mod, NestedTensor, case, dt, over=None):
-    T, H, W, L, nc, seed, tau, _ = case
+    T, H, W, L, nc, seed, tau = case[:7]
     head = build_head(dmh, nc, over)
     params = synth.temper_queries(synth.make_params(synth.head_shapes(dict(synth.R50_HEAD_CFG, num_classes=nc)), seed), tau)
     mg.load_state(head, params)
@@ -105,6 +119,88 @@ def reference_postprocess():
                                           pixel_threshold=0.4, apply_mask_removal=True, apply_mask_removal_only_ins=True,
                                           use_mask_low_constant=False)
     return pp, Instances
+
+
+def pan_ids(pp, Instances, po, C_last, M_t, L, nc, H, W):
+    """The reference's post-process (:528-807) + the relabel of simple_test (:411-435) on one frame's head outputs -> (ids, slot_index, labels)."""
+    inst = Instances((1, 1))
+    inst.pred_logits = C_last + torch.from_numpy(synth.full_size_class_bias(L, nc)).to(C_last.dtype)
+    inst.pred_masks = (synth.FULL_SIZE_MASK_GAIN * M_t).contiguous()
+    inst.slot_index = torch.arange(L)
+    res = pp(inst, [(H, W)], id=0)
+    ids, _, _ = po.panoptic_relabel(res.masks.numpy(), res.labels.numpy())
+    return np.asarray(ids).astype(np.uint8), res.slot_index.numpy().astype(np.int64), res.labels.numpy().astype(np.int64)
+
+
+def main_r06():
+    """head_full_r06.npz (see the module docstring)."""
+    torch.set_grad_enabled(False)
+    dmh, pe, NestedTensor = mg.load_reference("/root/reference")
+    pos_mod = pe.PositionEmbeddingSine(128, normalize=True)
+    old = np.load(os.path.join(mg.GOLDEN, "head_full.npz"))
+    out = {}
+    for tag, case in CASES_R06.items():
+        T, H, W, L, nc, seed, tau, (sy, sx), (dy, dx) = case
+        t0 = time.time()
+        E, C, M, fused = run(dmh, pos_mod, NestedTensor, case, torch.float32)
+        srt = M.topk(2, dim=1)
+        am32 = srt.indices[:, 0].clone()
+        new_case = f"{tag}_embeds" not in old.files
+        if new_case:
+            out[f"{tag}_cfg"] = np.array(repr([]))
+            out[f"{tag}_meta"] = np.array([T, H, W, L, nc, seed, sy, sx, FUSED3_STRIDE, FUSED0_STRIDE], dtype=np.int64)
+            out[f"{tag}_tau"] = np.float32(tau)
+            out[f"{tag}_embeds"] = E.numpy().astype(np.float32)
+            out[f"{tag}_logits"] = C.numpy().astype(np.float32)
+            out[f"{tag}_argmax"] = am32.reshape(T, -1).numpy().astype(np.uint8)
+            out[f"{tag}_margin"] = (srt.values[:, 0] - srt.values[:, 1]).reshape(T, -1).numpy().astype(np.float16)
+            out[f"{tag}_mask_sample"] = M[:, :, ::sy, ::sx].contiguous().numpy().astype(np.float32)
+            out[f"{tag}_mask_absmax"] = np.float32(M.abs().max().item())
+            f3 = fused[T - 1][3][0]
+            out[f"{tag}_fused3_sample"] = f3[:, ::FUSED3_STRIDE, ::FUSED3_STRIDE].permute(1, 2, 0).contiguous().numpy().astype(np.float32)
+            f0 = fused[0][0][0]
+            out[f"{tag}_fused0_sample"] = f0[:, ::FUSED0_STRIDE, ::FUSED0_STRIDE].permute(1, 2, 0).contiguous().numpy().astype(np.float32)
+            out[f"{tag}_fused3_absmax"] = np.float32(f3.abs().max().item())
+        else:
+            # the same case as head_full.npz: the run must reproduce it (then the new keys belong to the same reference outputs)
+            assert np.array_equal(E.numpy().astype(np.float32), old[f"{tag}_embeds"]), "the re-run differs from head_full.npz"
+            assert np.array_equal(am32.reshape(T, -1).numpy().astype(np.uint8), old[f"{tag}_argmax"])
+        out[f"{tag}_dense_meta"] = np.array([0, T - 1, dy, dx], dtype=np.int64)
+        out[f"{tag}_mask_dense"] = M[[0, T - 1]][:, :, ::dy, ::dx].contiguous().numpy().astype(np.float32)
+        del fused, srt
+        t1 = time.time()
+        pans32 = {}
+        if not new_case:
+            from oracle import postprocess_oracle as po
+            pp, Instances = reference_postprocess()
+            for t in (0, T - 1):
+                pans32[t] = pan_ids(pp, Instances, po, C[t, 6], M[t], L, nc, H, W)
+                assert np.array_equal(pans32[t][0], old[f"{tag}_pan_ids_{t}"]), "the re-run's id map differs from head_full.npz"
+        E64, C64, M64, fused64 = run(dmh, pos_mod, NestedTensor, case, torch.float64)
+        del fused64
+        am64 = M64.argmax(dim=1)
+        diff = int((am32 != am64).sum().item())
+        out[f"{tag}_floor_argmax_diff_pixels"] = np.int64(diff)
+        out[f"{tag}_floor_argmax_diff_pixels_dense_frames"] = np.array([int((am32[t] != am64[t]).sum().item()) for t in (0, T - 1)], dtype=np.int64)
+        if new_case:
+            out[f"{tag}_floor_embeds"] = np.array([(E.double()[:, s] - E64[:, s]).abs().max().item() for s in range(7)], dtype=np.float64)
+            out[f"{tag}_floor_logits"] = np.array([(C.double()[:, s] - C64[:, s]).abs().max().item() for s in range(7)], dtype=np.float64)
+            out[f"{tag}_floor_mask"] = np.float64((M.double() - M64).abs().max().item())
+            out[f"{tag}_floor_argmax_same"] = np.float64(1.0 - diff / am32.numel())
+        for t, (ids32, si32, lb32) in pans32.items():
+            ids64, si64, lb64 = pan_ids(pp, Instances, po, C64[t, 6], M64[t], L, nc, H, W)
+            same_seg = bool(np.array_equal(si32, si64) and np.array_equal(lb32, lb64))
+            out[f"{tag}_floor_pan_diff_pixels_{t}"] = np.int64(int((ids32 != ids64).sum()))
+            out[f"{tag}_floor_pan_same_segments_{t}"] = np.bool_(same_seg)
+            print(f"  frame {t}: the reference's id map from its float64 outputs differs from the one from its fp32 outputs on "
+                  f"{int((ids32 != ids64).sum())} of {ids32.size} pixels (same segments: {same_seg})", flush=True)
+        print(f"{tag}: fp32 {t1 - t0:.0f} s, float64 + post {time.time() - t1:.0f} s; reference fp32 vs float64: argmax differs on {diff} of "
+              f"{am32.numel()} pixels; mask logits {(M.double() - M64).abs().max().item():.2e}; slots owning pixels: {am32.unique().numel()} of {L}",
+              flush=True)
+        del E, C, M, E64, C64, M64
+    path = os.path.join(mg.GOLDEN, "head_full_r06.npz")
+    np.savez_compressed(path, **out)
+    print(os.path.basename(path), os.path.getsize(path) // 1024, "KiB")
 
 
 def main():
@@ -175,4 +271,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--part" in sys.argv and sys.argv[sys.argv.index("--part") + 1] == "r06":
+        main_r06()
+    else:
+        main()

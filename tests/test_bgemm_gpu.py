@@ -28,7 +28,8 @@ def _check(got, a, b, bias, alpha, bound=2e-5):
 
 
 @pytest.mark.parametrize("G,M,N,K", [(3, 70, 50, 40), (1, 1, 1, 1), (2, 64, 64, 32), (2, 500, 500, 256), (2, 33, 129, 17),
-                                     (1, 1600, 20, 256), (5, 16, 128, 128)])
+                                     (1, 1600, 20, 256), (5, 16, 128, 128),
+                                     (2, 2000, 2000, 256), (1, 2000, 256, 2000)])     # VIPER T = 10 x L = 200: logits [TL, TL] and attn^T v (K = TL)
 def test_bgemm_contiguous(cuda, G, M, N, K):
     import torch
     from slotvps_amd import ops
@@ -95,6 +96,28 @@ def test_bgemm_temporal_retriever_shapes(cuda):
     attn_t = torch.softmax(logits_t, dim=-1)
     out = ops.bgemm(attn_t.transpose(1, 2), v.transpose(1, 2))   # A[m = lq, k = lk], B[n = c, k = lk]
     _check(out, attn_t.transpose(1, 2), v.transpose(1, 2), None, 1.0)
+
+
+@pytest.mark.parametrize("split", ["fp16", "bf16"])
+def test_bgemm_temporal_retriever_viper_clip(cuda, split):
+    """The temporal slot retriever of BASELINE config 5 (T = 10 frames x 200 slots = 2000 rows, dynamic_mask_head.py:559-567) exactly as
+    SlotsDynamicConv.forward runs it: logits^T = k q^T [2000, 2000], softmax over the QUERY axis (scaled by 2^14 in the fp16 split), then
+    attn^T v with the probabilities read k-major - two clips per launch - against float64."""
+    import torch
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(13)
+    G, Lq, C = 2, 2000, 256
+    q, k, v = (torch.nn.functional.layer_norm(torch.randn((G, Lq, C), generator=g, device=cuda), (C,)) * 0.5 for _ in range(3))
+    psc = 16384.0 if split == "fp16" else 1.0
+    logits_t = ops.bgemm(k, q, split=split)
+    want_l = torch.matmul(k.double(), q.double().transpose(1, 2))
+    e_l = (logits_t.double() - want_l).abs().max().item() / want_l.abs().max().item()
+    attn_t = ops.row_softmax(logits_t, inplace=False, scale=psc)
+    out = ops.bgemm(attn_t.transpose(1, 2), v.transpose(1, 2), split=split, alpha=1.0 / psc)
+    want = torch.matmul(torch.softmax(want_l, dim=-1).transpose(1, 2), v.double())
+    e_o = (out.double() - want).abs().max().item() / want.abs().max().item()
+    print(f"temporal retriever at T L = 2000, split {split}: logits {e_l:.2e}, output {e_o:.2e} (relative to the largest value)")
+    assert e_l <= (1e-6 if split == "fp16" else 4e-5) and e_o <= (2e-5 if split == "fp16" else 2e-4), (e_l, e_o)
 
 
 def test_bgemm_refuses_cpu_and_bad_shapes(cuda):

@@ -6,9 +6,10 @@ import re
 from util import ROOT
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "slotvps_hip.h")).read()
+def _header_symbols(name="slotvps_hip.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"typedef[^;]*;", "", text)                       # (the launch-hook function-pointer type is not an entry point)
     return sorted(set(re.findall(r"\b(svps_\w+)\s*\(", text)))
 
 
@@ -21,6 +22,27 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in include/slotvps_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == syms, (sorted(set(syms) ^ set(_lib.SIGNATURES)))
     assert lib.svps_abi_version() == 1
+
+
+def test_product_library_carries_no_diagnostics():
+    """the product library exports exactly the symbols of include/slotvps_hip.h - no probes, no event bookkeeping, no
+    stamp / ablation code; the diagnostics live in libslotvps_hip_diag.so behind include/slotvps_hip_diag.h and reach the product only
+    through its launch hook."""
+    import subprocess
+    from slotvps_amd import _lib
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("svps_"))
+    prod = exported(_lib.LIB_PATH)
+    assert prod == _header_symbols(), sorted(set(prod) ^ set(_header_symbols()))
+    assert not [s for s in prod if "probe" in s or "stamp" in s or "debug" in s or s in ("svps_prof_enable", "svps_prof_collect", "svps_prof_reset")]
+    diag = exported(_lib.DIAG_LIB_PATH)
+    assert diag == _header_symbols("slotvps_hip_diag.h") == sorted(_lib.DIAG_SIGNATURES), sorted(set(diag) ^ set(_lib.DIAG_SIGNATURES))
+    assert not set(diag) & set(prod)
+    lib, d = _lib.load(), _lib.load_diag()                       # loads without a GPU; installing the hook touches no device
+    d.svps_prof_enable(0)
+    lib.svps_prof_mark(0, 0, None)                               # recorder disabled: the hook returns at once
 
 
 def test_argument_errors_do_not_need_a_gpu():

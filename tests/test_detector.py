@@ -290,7 +290,9 @@ def test_baseline_config0_512x1024_first_frame():
         det(img=[img], img_meta=[[meta]], return_loss=False, rescale=True, ref_img=[img])
     feats, fcn = det.trunk(img)
     assert feats.hws == [(16, 32), (32, 64), (64, 128), (128, 256)] and fcn.shape == (1, 19, H, W)
-    assert feats.folded and all(f.shape == (1, h * w, 128) and f.dtype == torch.bfloat16 for f, (h, w) in zip(feats, feats.hws))
+    # the default head mode (fp16x2): the tower's own rows as two fp16 planes hi + lo, conv_trans folded into K4-HL's composed weights
+    assert det.image_model.dynamic_mask_head.mode == "fp16x2"
+    assert feats.folded and all(f.shape == (2, 1, h * w, 128) and f.dtype == torch.float16 for f, (h, w) in zip(feats, feats.hws))
     from slotvps_amd.detector import LevelMaps
     logits, embeds, masks = det.head_path(LevelMaps.cat(feats, feats), dense=True)             # the reference's all-slot form
     assert logits.shape == (2, 100, 20) and masks.shape == (2, 100, 128, 256) and torch.isfinite(masks).all()
@@ -412,12 +414,13 @@ def test_fp16_level_maps_through_the_whole_detector():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("map_dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("map_dtype", ["fp16x2", "bf16", "fp16"])
 def test_conv_trans_folded_into_level_fusion(map_dtype):
     """conv_trans (a linear 1x1 conv, vps_capsule.py:76-79) folded into K4's weights - the tower's last GroupNorm +
     ReLU hands K4 its own output as 16-bit pixel-major rows. Against the reference's order of operations (conv_trans in fp32 by the
     framework, then K4 on the fp32 NCHW map) the fused maps agree to the rounding of the 16-bit operands, and the semantic logits are
-    the same tensor."""
+    the same tensor. Mode fp16x2: the rows are two fp16 planes hi + lo (22 bits), conv_trans composed into K4-HL's
+    weights in float64 - the maps agree to fp32 rounding (the framework's conv_trans is itself an fp32 sum in another order)."""
     dev = torch.device("cuda:0")
     det = _make_detector(dev)
     head = det.image_model.dynamic_mask_head
@@ -429,17 +432,19 @@ def test_conv_trans_folded_into_level_fusion(map_dtype):
     imgs = torch.randn(2, 3, 128, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
     det.fold_trans = True
     fa, sa = det.trunk(imgs)
+    f32 = lambda f: (f[0].float() + f[1].float()) if f.dim() == 4 else f.float()      # fp16x2: the map is the sum of its planes
     la, ea, fused_a = det._head_clip(fa)
-    fused_a = [f.float().clone() for f in fused_a]
+    fused_a = [f32(f).clone() for f in fused_a]
     det.fold_trans = False
     fb, sb = det.trunk(imgs)
     lb, eb, fused_b = det._head_clip(fb)
     assert fa.folded and not fb.folded and fa.hws == fb.hws
-    assert fa[0].dtype == (torch.float16 if map_dtype == "fp16" else torch.bfloat16) and fb[0].dtype == torch.float32
+    assert fa[0].dtype == (torch.bfloat16 if map_dtype == "bf16" else torch.float16) and fb[0].dtype == torch.float32
+    assert (fa[0].dim() == 4 and fa[0].shape[0] == 2) == (map_dtype == "fp16x2")
     assert (sa - sb).abs().max().item() <= 1e-4 * sb.abs().max().item()      # (the framework's convolutions are not run-to-run identical)
-    ulp = 2.0 ** -7 if map_dtype == "bf16" else 2.0 ** -10
+    ulp = {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10, "fp16x2": 2.0 ** -19}[map_dtype]
     for a, b in zip(fused_a, fused_b):
-        b = b.float()
+        b = f32(b)
         scale = b.abs().max().item()
         # different rounding points (y rounded instead of W_t y + b_t, composed weights rounded once): a few operand ulps of the map's scale
         assert (a - b).abs().max().item() <= 3 * ulp * scale, ((a - b).abs().max().item(), scale)

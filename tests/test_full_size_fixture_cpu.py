@@ -15,8 +15,9 @@ import fullsize_parity as fsp  # noqa: E402
 
 def test_fixture_records_the_reference_floor():
     """`floor` = the reference's fp32 run against the SAME modules in float64: what the GPU bounds of tests/test_full_size_gpu.py lean on."""
-    z = np.load(fsp.FIXTURE)
+    z = fsp._Fixtures([fsp.FIXTURE, fsp.FIXTURE_R06])
     assert float(z["T5_1024x2048_L100_floor_mask"]) <= 2e-5 and float(z["T2_1088x1920_L200_floor_mask"]) <= 2e-5
+    assert float(z["T10_1088x1920_L200_floor_mask"]) <= 3e-5                  # config 5 at its own clip length (T L = 2000 temporal rows)
     assert 1e-4 <= float(z["T2_1024x2048_L100_sharp_floor_mask"]) <= 2e-3
     for tag in fsp.CASES:
         T, H, W, L, nc = (int(x) for x in z[f"{tag}_meta"][:5])
@@ -28,6 +29,17 @@ def test_fixture_records_the_reference_floor():
         ids = z[f"T5_1024x2048_L100_pan_ids_{t}"]
         assert ids.shape == (1024, 2048) and ids.dtype == np.uint8 and len(np.unique(ids)) >= 10
         assert len(z[f"T5_1024x2048_L100_pan_labels_{t}"]) == len(z[f"T5_1024x2048_L100_pan_slot_index_{t}"]) >= 10
+        # round 6: the reference's OWN disagreement on the integer targets, as counts (its fp32 run vs the same modules in float64)
+        assert 0 <= int(z[f"T5_1024x2048_L100_floor_pan_diff_pixels_{t}"]) <= 200 and bool(z[f"T5_1024x2048_L100_floor_pan_same_segments_{t}"])
+    assert int(z["T5_1024x2048_L100_floor_argmax_diff_pixels"]) == round((1 - float(z["T5_1024x2048_L100_floor_argmax_same"])) * 5 * 131072)
+    for tag, n in (("T5_1024x2048_L100", 100), ("T10_1088x1920_L200", 200)):
+        f0, f1, dy, dx = (int(x) for x in z[f"{tag}_dense_meta"])
+        T, H, W = (int(x) for x in z[f"{tag}_meta"][:3])
+        dense = z[f"{tag}_mask_dense"]
+        assert (f0, f1) == (0, T - 1) and dense.shape == (2, n, -(-(H // 4) // dy), -(-(W // 4) // dx))
+        # the dense sample contains the coarse one (same reference run): frames 0 and T - 1 at the coarse strides
+        sy, sx = (int(x) for x in z[f"{tag}_meta"][6:8])
+        assert np.array_equal(dense[:, :, ::sy // dy, ::sx // dx], z[f"{tag}_mask_sample"][[0, T - 1]])
 
 
 @pytest.mark.parametrize("tag", list(fsp.CASES))

@@ -60,6 +60,13 @@ BOUNDS = {
     ("fp32", "T2_1024x2048_L100_swin"): dict(mask=1e-4, tf=1e-4, eq=0.9995, contract=True),
     ("fp16", "T2_1024x2048_L100_swin"): dict(mask=4e-3, tf=8e-3, eq=0.99, contract=False),
     ("bf16", "T2_1024x2048_L100_swin"): dict(mask=3e-2, tf=6e-2, eq=0.93, contract=False),
+    # BASELINE config 5 at its OWN clip length (round 6): T = 10, 200 slots - the temporal step attends over T L = 2000 slot rows
+    # (dynamic_mask_head.py:559-567), more than 128 slots in every retriever launch. The reference's own fp32 run sits 1.5e-5 (mask logits) /
+    # 2.8e-4 (last-stage embeddings) from its float64 evaluation here
+    ("fp16x2", "T10_1088x1920_L200"): dict(mask=1e-4, tf=1e-4, eq=0.9995, contract=True),
+    ("fp32", "T10_1088x1920_L200"): dict(mask=1e-4, tf=1e-4, eq=0.9995, contract=True),
+    ("fp16", "T10_1088x1920_L200"): dict(mask=4e-3, tf=8e-3, eq=0.99, contract=False),
+    ("bf16", "T10_1088x1920_L200"): dict(mask=3e-2, tf=6e-2, eq=0.93, contract=False),
 }
 
 
@@ -78,6 +85,12 @@ def test_full_size_clip_against_the_reference(cuda, tag, mode):
     assert row["free_embed_err"][0] <= b["tf"]                          # stage 0 free-running == teacher-forced
     mask_bound = b["mask"] if b["mask"] is not None else 3.0 * floor     # sharp case: the reference's own fp32-vs-float64 distance
     assert row["mask_err"] <= mask_bound, (row["mask_err"], mask_bound)
+    if row["mask_err_dense"] is not None:                                # the 16 x denser sample of frames 0 and T - 1 (round 6) under the same bound
+        assert row["mask_err_dense"] <= mask_bound, (row["mask_err_dense"], mask_bound)
+    # the integer target as a COUNT: the modes that claim the contract may disagree with the reference on a few times as many pixels as the
+    # reference's own fp32 run disagrees with its float64 evaluation (those pixels sit on a top-2 tie at the modes' 1e-5-class error)
+    if b["contract"]:
+        assert row["argmax_diff_pixels"] <= max(20, 10 * row["ref_floor_argmax_diff_pixels"]), (row["argmax_diff_pixels"], row["ref_floor_argmax_diff_pixels"])
     assert row["argmax_equal"] >= b["eq"], row["argmax_equal"]
     assert row["argmax_equal_decidable"] == 1.0                          # integer target: identical wherever decidable at the measured error
     assert row["argmax_kernel_vs_own_logits"] >= 0.99999                 # the fused argmax byte is the argmax of the logits written
@@ -101,8 +114,11 @@ def test_full_size_panoptic_ids_against_the_reference(cuda, mode, bound):
     rows = fsp.panoptic_rows(cuda, case, mode)
     assert len(rows) == 2
     for r in rows:
-        print(f"\n[{mode}] frame {r['frame']}: panoptic ids equal on {100 * r['ids_equal']:.4f} % of the 1024 x 2048 pixels; kept slots equal "
+        print(f"\n[{mode}] frame {r['frame']}: panoptic ids differ on {r['ids_diff_pixels']} of the {r['pixels']} pixels (the reference's own fp32 run vs "
+              f"its float64 run: {r['ref_floor_ids_diff_pixels']}) = equal on {100 * r['ids_equal']:.4f} %; kept slots equal "
               f"{r['slots_equal']}, labels equal {r['labels_equal']} ({r['segments']} segments)")
         assert r["ids_equal"] >= bound, r
+        if mode in ("fp16x2", "fp32"):                                   # a small multiple of the reference's own disagreement (15 / 35 pixels)
+            assert r["ids_diff_pixels"] <= 10 * max(10, r["ref_floor_ids_diff_pixels"]), r
         if mode in ("fp16x2", "fp32"):
             assert r["slots_equal"] and r["labels_equal"], r

@@ -25,7 +25,8 @@ pytestmark = pytest.mark.gpu
 SAME_FREE_MIN = {"fused": 0.85, "kv": 0.80}      # measured 87.1 / 91.0 % (fused), 85.0 / 83.2 % (kv)
 
 
-def build_head(cuda, params):
+def build_head(cuda, params, mode=None):
+    """mode None: the product's default (MultiScaleDynamicMaskHead DEFAULT_MODE = "fp16x2")."""
     import torch
     from slotvps_amd.slot_head import MultiScaleDynamicMaskHead
     cfg = synth.R50_HEAD_CFG
@@ -39,7 +40,13 @@ def build_head(cuda, params):
         apply_temporal_query_atten_stages=list(cfg["apply_temporal_query_atten_stages"]))
     sd = {k: torch.from_numpy(v).reshape(head.state_dict()[k].shape) for k, v in params.items()}
     head.load_state_dict(sd, strict=True)
-    return head.to(cuda).eval()
+    head = head.to(cuda).eval()
+    return head if mode is None else head.set_mode(mode)
+
+
+def frames(fmap, sl):
+    """Frames `sl` of a fused level map: [T, HW, 256] (16-bit / fp32 modes) or [2 (hi, lo), T, HW, 256] (fp16x2)."""
+    return fmap[:, sl] if fmap.dim() == 4 else fmap[sl]
 
 
 @pytest.mark.parametrize("form", ["fused", "kv"])
@@ -188,9 +195,27 @@ def test_head_matches_oracle_and_reference(cuda, tag, form):
     assert same_free >= SAME_FREE_MIN[form], same_free          # free-running: seven stages of bf16-map rounding through sharp softmaxes
 
 
-@pytest.mark.parametrize("map_dtype", ["bf16", "fp16"])
+def test_default_mode_is_the_contract_mode(cuda):
+    """a head built without any mode key runs the mode that meets the north star's tolerance (fp16x2), so do its
+    stand-alone sub-modules; the 16-bit storage policies are opt-in; the switches of rounds 1 - 4 in other_config are refused."""
+    from slotvps_amd.slot_head import MultiScaleDynamicMaskHead, MaskDynamicConv, DEFAULT_MODE
+    params = synth.make_params(synth.head_shapes(), 7)
+    head = build_head(cuda, params)
+    assert DEFAULT_MODE == "fp16x2" and head.mode == "fp16x2" and head.precision == "fp16x2"
+    assert all(m.precision == "fp16x2" for m in head.modules() if hasattr(m, "precision"))
+    assert MaskDynamicConv(256).precision == "fp16x2"
+    assert MultiScaleDynamicMaskHead(num_classes=20, dh_num_heads=8, merge_operation="concat", trans_in_dim=384,
+                                     apply_temporal_query_atten_stages=[], other_config=dict(mode="bf16")).mode == "bf16"
+    for legacy in ("precision", "map_dtype"):
+        with pytest.raises(ValueError):
+            MultiScaleDynamicMaskHead(num_classes=20, dh_num_heads=8, merge_operation="concat", trans_in_dim=384,
+                                      apply_temporal_query_atten_stages=[], other_config={legacy: "bf16"})
+
+
+@pytest.mark.parametrize("map_dtype", ["fp16x2", "bf16", "fp16"])
 def test_reference_signature_roundtrip(cuda, map_dtype):
-    """The reference-style list-of-frames call returns the reference's structure (with either storage of the level maps)."""
+    """The reference-style list-of-frames call returns the reference's structure (with every storage of the level maps), and the maps it
+    returns are the ones forward_clip computes (in fp16x2 a map is two planes - the frame is their sum, not a plane)."""
     import torch
     from slotvps_amd.position_encoding import PositionEmbeddingSine, nested_tensor_from_tensor_list
     params = synth.make_params(synth.head_shapes(), 7)
@@ -207,6 +232,17 @@ def test_reference_signature_roundtrip(cuda, map_dtype):
     assert tuple(embeds[1].shape) == (7, 1, L, 256)
     assert tuple(fused[0][3].shape) == (1, 256, 16, 16) and tuple(init[0].shape) == (1, L, 256)
     assert torch.isfinite(embeds[0]).all()
+    from slotvps_amd.slot_head import pos_tables_from_map
+    with torch.no_grad():
+        tf = [torch.cat([features[t][i] for t in range(T)], 0) for i in range(4)]
+        lg_c, em_c, fu_c = head.forward_clip(tf, torch.from_numpy(synth.make_slots(9, L)).to(cuda), [pos_tables_from_map(pos[0][i]) for i in range(4)])
+    for t in range(T):
+        assert torch.equal(embeds[t][:, 0], em_c[:, t]) and torch.equal(logits[t][:, 0], lg_c[:, t])
+        for i, (h, w) in enumerate(synth.level_sizes(H, W)):
+            f = fu_c[i]
+            want = (f[0, t].float() + f[1, t].float()) if f.dim() == 4 else f[t]
+            got = fused[t][i]
+            assert tuple(got.shape) == (1, 256, h, w) and torch.equal(got[0].permute(1, 2, 0).reshape(h * w, 256).to(want.dtype), want)
     # a stage through its own reference-signature entry point (MaskRCNNHead.forward): the map is stored the way the head stores it
     stage = head.head_series_3[0]
     with torch.no_grad():
@@ -251,7 +287,7 @@ def test_head_variants_per_stage_parity(cuda, name):
                                              activation=cfg["temporal_activation"], softmax_dim="slots", drop_path=0.),
         apply_temporal_query_atten_stages=[3, 4, 5, 6])
     head.load_state_dict({k: torch.from_numpy(p).reshape(head.state_dict()[k].shape) for k, p in params.items()}, strict=True)
-    head.to(cuda).eval()
+    head.to(cuda).eval().set_mode("bf16")                          # the oracle below follows the 16-bit storage policy
     rng = np.random.default_rng(5)
     feats = [[synth.smooth_features(rng, 128, h, w) for (h, w) in sizes] for _ in range(T)]
     slots = synth.make_slots(6, L)
@@ -281,13 +317,14 @@ def test_head_variants_per_stage_parity(cuda, name):
     assert max(errs) <= 4e-3, errs                                 # fused form (default): measured <= 9.6e-4 (Swin-L head), <= 4.8e-4 (VIPER geometry)
 
 
-def test_stacked_clips_equal_separate_clips(cuda):
+@pytest.mark.parametrize("mode", ["fp16x2", "bf16"])
+def test_stacked_clips_equal_separate_clips(cuda, mode):
     """Several clips stacked along the frame axis of one launch (clip_frames) give each clip what it gets alone:
     all kernels are per frame, the temporal slot attention is blocked per clip."""
     import torch
     from slotvps_amd import ops
     params = synth.make_params(synth.head_shapes(), 3)
-    head = build_head(cuda, params)
+    head = build_head(cuda, params, mode)
     Tc, H, W, L = 2, 64, 128, 100
     sizes = synth.level_sizes(H, W)
     clips = [synth.make_clip_features(40 + c, Tc, H, W) for c in range(3)]
@@ -305,7 +342,7 @@ def test_stacked_clips_equal_separate_clips(cuda):
     for ci, (lg1, em1, fu1) in enumerate(alone):
         sl = slice(ci * Tc, (ci + 1) * Tc)
         for i in range(4):
-            assert torch.equal(fu[i][sl], fu1[i])                          # K4 is per frame: bit-identical
+            assert torch.equal(frames(fu[i], sl), fu1[i])                  # K4 is per frame: bit-identical
         # K1's pixel chunking depends on the number of frames per launch (summation order of the partials), so the
         # slot side is equal up to fp32 reassociation seen through the chaotic chain: tight on the first stage
         assert (em[0, sl] - em1[0]).abs().max().item() <= 5e-4
@@ -491,6 +528,7 @@ def test_map_dtype_switch_is_checked(cuda):
     from slotvps_amd import ops
     params = synth.make_params(synth.head_shapes(), 7)
     head = build_head(cuda, params)
+    assert head.mode == "fp16x2"                                   # the product's default
     with pytest.raises(ValueError):
         head.set_mode("fp8")
     head.set_mode("fp16")

@@ -1,5 +1,5 @@
 """Pins the gfx950 instruction semantics the kernels rely on (MFMA lane maps, transposed LDS read,
-swizzled LDS-DMA image) through the C ABI probes."""
+swizzled LDS-DMA image) through the probes of the DIAGNOSTICS library (include/slotvps_hip_diag.h, libslotvps_hip_diag.so)."""
 import ctypes
 
 import numpy as np
@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 def test_probe_mfma_layout(cuda):
     import torch
     from slotvps_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_diag()
     rng = np.random.default_rng(0)
     # small integers: exact in bf16 and in the fp32 accumulator; asymmetric operands
     a = rng.integers(-4, 5, (32, 16)).astype(np.float32)
@@ -29,7 +29,7 @@ def test_probe_mfma_layout(cuda):
 def test_probe_tile_roundtrip(cuda):
     import torch
     from slotvps_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_diag()
     x = (np.arange(32 * 256, dtype=np.float32).reshape(32, 256) % 251) - 125  # exact in bf16
     x += (np.arange(32, dtype=np.float32)[:, None] % 3)
     tx = torch.from_numpy(x).to(cuda).to(torch.bfloat16).contiguous()

@@ -69,6 +69,90 @@ def test_level_fuse_hl(cuda, T, H, W, lvl0):
     assert worst <= 5e-6
 
 
+@pytest.mark.parametrize("T,H,W,lvl0", [(2, 8, 16, True), (1, 6, 10, False), (2, 34, 60, False), (1, 4, 32, False), (2, 10, 96, False),
+                                        (1, 20, 1024, False)])
+def test_level_fuse_hl_from_pixel_major_planes(cuda, T, H, W, lvl0):
+    """svps_level_fuse_hl_pm_fwd (round 6): the incoming map as fp16 hi + lo PIXEL-MAJOR planes [2, T, HW, 128] - the semantic tower's own
+    rows - instead of the reference's fp32 NCHW tensor. The operand tile the kernel multiplies is the same bits either way (the NCHW form
+    splits x in the kernel exactly as ops.split_hl does), so every output - planes and fp32 G - is BIT-identical: row-major ragged tiles,
+    the staged column-strip walk (W % 32 == 0) and workgroups crossing strips."""
+    import torch
+    from slotvps_amd import ops
+    rng = np.random.default_rng(H * W + 1)
+    cur = rng.standard_normal((T, 128, H, W)).astype(np.float32)
+    g = None if lvl0 else _t((3.0 * rng.standard_normal((T, (H // 2) * (W // 2), 256))).astype(np.float32), cuda)
+    w_hl = ops.split_hl(_t((rng.standard_normal((256, 128)) / 12).astype(np.float32), cuda))
+    bias = _t(rng.standard_normal(256).astype(np.float32), cuda)
+    x = _t(cur, cuda)
+    rows = ops.split_hl(x.permute(0, 2, 3, 1).reshape(T, H * W, 128).contiguous())          # [2, T, HW, 128]
+    for planes, f32 in ((True, False), (False, True), (True, True)):
+        a = ops.level_fuse_hl_g(x, g, w_hl, bias, H, W, planes=planes, f32=f32)
+        b = ops.level_fuse_hl_g(rows, g, w_hl, bias, H, W, planes=planes, f32=f32)
+        torch.cuda.synchronize()
+        for u, v in zip(a, b):
+            assert (u is None) == (v is None)
+            if u is not None:
+                assert torch.equal(u.view(torch.int16 if u.dtype == torch.float16 else torch.int32), v.view(torch.int16 if v.dtype == torch.float16 else torch.int32))
+    with pytest.raises(ValueError):
+        ops.level_fuse_hl_g(rows[:, :, :-1].contiguous(), g, w_hl, bias, H, W)
+
+
+@pytest.mark.parametrize("N,HW,C", [(2, 200, 128), (1, 33, 128), (3, 1024, 256)])
+def test_group_norm_relu_hi_lo_rows(cuda, N, HW, C):
+    """ops.group_norm_relu_pm(want_16="hl") (csrc/gn_relu.hip, round 6): the tower's last GroupNorm + ReLU also writes its result as two
+    fp16 planes hi + lo - bit for bit ops.split_hl of the fp32 rows it writes (what K4-HL's NCHW form would have split in the kernel)."""
+    import torch
+    from slotvps_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(N * HW)
+    x = 3.0 * torch.randn((N, HW, C), generator=g, device=cuda)
+    gamma = torch.rand(C, generator=g, device=cuda) + 0.5
+    beta = 0.2 * torch.randn(C, generator=g, device=cuda)
+    y, y_nchw, y_hl = ops.group_norm_relu_pm(x, gamma, beta, 32, 1e-5, want_nchw=True, want_16="hl")
+    torch.cuda.synchronize()
+    assert y_hl.shape == (2, N, HW, C) and y_hl.dtype == torch.float16
+    assert torch.equal(y_hl.view(torch.int16), ops.split_hl(y).view(torch.int16))
+    assert torch.equal(y_nchw.transpose(1, 2), y)
+    ref = torch.relu(torch.nn.functional.group_norm(x.transpose(1, 2).double(), 32, gamma.double(), beta.double(), 1e-5)).transpose(1, 2)
+    assert (y_hl[0].double() + y_hl[1].double() - ref).abs().max().item() <= 2e-5
+    _, _, only = ops.group_norm_relu_pm(x, gamma, beta, 32, 1e-5, want_nchw=False, want_16="hl", want_pm=False)
+    assert torch.equal(only.view(torch.int16), y_hl.view(torch.int16))
+
+
+def test_level_recursion_from_the_tower_rows_with_conv_trans_folded(cuda):
+    """fuse_level in mode fp16x2 on the tower's rows y (two fp16 planes) with pre_linear = conv_trans composed into the weights in float64
+    (ops.level_fuse_hl_composed(pre=...)) against a float64 evaluation of the reference's order - x = conv_trans(y)
+    (vps_capsule.py:76-79), then cat / upsample / conv (dynamic_mask_head.py:171-188) - over all four levels: fp32-class."""
+    import torch
+    from slotvps_amd import ops
+    params = synth.make_params(synth.head_shapes(), 3)
+    head = build_head(cuda, params, "fp16x2")
+    T, sizes = 2, [(2, 4), (4, 8), (8, 16), (16, 32)]
+    rng = np.random.default_rng(9)
+    ys = [np.maximum(rng.standard_normal((T, h * w, 128)), 0).astype(np.float32) for (h, w) in sizes]
+    wt = (rng.standard_normal((128, 128)) * 0.12).astype(np.float32)
+    bt = (rng.standard_normal(128) * 0.3).astype(np.float32)
+    pre = (torch.nn.Parameter(_t(wt, cuda).view(128, 128, 1, 1)), torch.nn.Parameter(_t(bt, cuda)))
+    wc = params["conv_trans.conv.weight"].reshape(256, 384).astype(np.float64)
+    bc = params["conv_trans.conv.bias"].astype(np.float64)
+    prev, prev64, worst = None, None, 0.0
+    with torch.no_grad():
+        for i, (h, w) in enumerate(sizes):
+            rows = ops.split_hl(_t(ys[i], cuda))
+            y64 = _sum_hl(rows)                                                        # what the kernel sees, exactly
+            x64 = y64 @ wt.astype(np.float64).T + bt.astype(np.float64)                # [T, HW, 128]
+            prev = head.fuse_level(rows, prev, (h, w), last=i == 3, pre=pre)
+            got = _sum_hl(prev)
+            for t in range(T):
+                p64 = None if prev64 is None else np.ascontiguousarray(prev64[t].T).reshape(256, h // 2, w // 2)
+                ref = orc.fuse_level(np.ascontiguousarray(x64[t].T).reshape(128, h, w), p64, wc, bc)       # [HW, 256] float64
+                worst = max(worst, float(np.abs(got[t] - ref).max() / max(1.0, np.abs(ref).max())))
+            prev64 = got
+    print(f"\nK4-HL from the tower's rows, conv_trans folded: {worst:.2e} of the map's scale over four levels")
+    assert worst <= 5e-6
+    with pytest.raises(NotImplementedError):
+        head.fuse_level(_t(np.zeros((T, 128, 2, 4)), cuda), None, (2, 4), pre=pre)       # a folded pre_linear goes with the rows
+
+
 def _module(cuda, seed):
     import torch
     from slotvps_amd.slot_head import MaskDynamicConv

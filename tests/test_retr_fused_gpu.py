@@ -17,6 +17,7 @@ def make_module(cuda, seed):
     from slotvps_amd.slot_head import MaskDynamicConv
     rng = np.random.default_rng(seed)
     m = MaskDynamicConv(256).to(cuda).eval()
+    m.precision = "bf16"                                                         # this file: the 16-bit storage policy (the default is fp16x2)
     P = {}
     with torch.no_grad():
         for n in ("to_q", "to_k", "to_v"):
@@ -193,6 +194,7 @@ def test_statistics_against_float64_layernorm(cuda):
     from slotvps_amd.slot_head import MaskDynamicConv
     rng = np.random.default_rng(7)
     m = MaskDynamicConv(256).to(cuda).eval()
+    m.precision = "bf16"                                                         # this file: the 16-bit storage policy (the default is fp16x2)
     P = {}
     with torch.no_grad():
         for n in ("to_q", "to_k", "to_v"):
@@ -248,7 +250,9 @@ def test_fp16_map_equals_bf16_map_on_bf16_values(cuda, H, W, L):
     rng = np.random.default_rng(H * W + L)
     torch.manual_seed(5)
     m = MaskDynamicConv(256).to(cuda).eval()
+    m.precision = "bf16"                                                         # this file: the 16-bit storage policy (the default is fp16x2)
     m2 = MaskDynamicConv(256).to(cuda).eval()
+    m2.precision = "bf16"
     feat = orc.round_bf16(rng.standard_normal((2, H * W, 256)).astype(np.float32))
     feat[np.abs(feat) < 2.0 ** -13] = 0.0                  # below fp16's normal range a bf16 value is not an fp16 value (or a subnormal one)
     slots = torch.from_numpy(rng.standard_normal((2, L, 256)).astype(np.float32)).to(cuda)

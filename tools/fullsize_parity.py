@@ -20,15 +20,32 @@ if ROOT not in sys.path:
 from slotvps_amd import synth  # noqa: E402
 
 FIXTURE = os.path.join(ROOT, "tests", "golden", "head_full.npz")
-CASES = ("T5_1024x2048_L100", "T2_1024x2048_L100_sharp", "T2_1088x1920_L200", "T2_1024x2048_L100_swin")
+# round 6 (make_golden_full.py --part r06): BASELINE config 5 at its own clip length (T = 10, 200 slots: the temporal step over 2000 slot
+# rows), denser mask-logit samples of frames 0 and T - 1, and the reference's own fp32-vs-float64 disagreement on the integer targets as counts
+FIXTURE_R06 = os.path.join(ROOT, "tests", "golden", "head_full_r06.npz")
+CASES = ("T5_1024x2048_L100", "T2_1024x2048_L100_sharp", "T2_1088x1920_L200", "T2_1024x2048_L100_swin", "T10_1088x1920_L200")
 # the north star's contract: 1e-4 on the float mask logits, the integer slot argmax identical wherever the reference's own top-2 margin
 # exceeds DECIDABLE_FACTOR x the measured mask-logit error (below that a pixel's argmax is not determined by values known to +-error)
 TOL_MASK = 1e-4
 DECIDABLE_FACTOR = 2.0
 
 
-def load_case(tag, fixture=FIXTURE):
-    z = np.load(fixture)
+class _Fixtures:
+    """The keys of head_full.npz and head_full_r06.npz as one mapping (a case's keys may be spread over both)."""
+
+    def __init__(self, paths):
+        self.zs = [np.load(p) for p in paths if os.path.exists(p)]
+        self.files = [k for z in self.zs for k in z.files]
+
+    def __getitem__(self, k):
+        for z in self.zs:
+            if k in z.files:
+                return z[k]
+        raise KeyError(k)
+
+
+def load_case(tag, fixture=None):
+    z = _Fixtures([FIXTURE, FIXTURE_R06] if fixture is None else [fixture])
     T, H, W, L, nc, seed, sy, sx, s3, s0 = (int(x) for x in z[f"{tag}_meta"])
     tau = float(z[f"{tag}_tau"])
     import ast
@@ -74,7 +91,9 @@ def _map_f32(f):
 def run_mode(dev, case, mode, teacher_forced=True):
     """One clip of `case` through head.forward_clip + generate_final_outputs in `mode`, against the reference's outputs.
     Returns scalars: free_embed_err[7], free_logit_err[7], tf_embed_err[7] (stage s fed the REFERENCE's stage s-1 embeddings),
-    mask_err (sampled pixels, every frame, free-running), mask_err_tf (decode of the reference's own last-stage embeddings on this
+    mask_err (sampled pixels, every frame, free-running; mask_err_dense: the 16 x denser sample of frames 0 and T - 1 where the
+    fixture holds one - `meets` asks both), argmax_diff_pixels / pixels (COUNTS, beside ref_floor_argmax_diff_pixels: the reference's own
+    fp32 run against the same modules in float64), mask_err_tf (decode of the reference's own last-stage embeddings on this
     mode's map), argmax_equal (fraction of all pixels, free-running), decidable (fraction of pixels whose reference margin exceeds
     DECIDABLE_FACTOR x mask_err), argmax_equal_decidable, fused3_err / fused0_err (relative to the map's largest magnitude), meets."""
     import torch
@@ -110,9 +129,21 @@ def run_mode(dev, case, mode, teacher_forced=True):
         row["free_logit_err"] = [float(np.abs(C[s].astype(np.float64) - ref["logits"][:, s]).max()) for s in range(7)]
         row["mask_err"] = float(np.abs(samp.astype(np.float64) - ref["mask_sample"]).max())
         row["mask_err_tf"] = float(np.abs(samp_tf.astype(np.float64) - ref["mask_sample"]).max())
+        row["mask_err_dense"] = None
+        if "mask_dense" in ref:                                    # frames (f0, f1) at stride (dy, dx): 16 x the pixels of mask_sample
+            f0_, f1_, dy, dx = (int(x) for x in ref["dense_meta"])
+            dense = masks.view(T, L, h3, w3)[[f0_, f1_]][:, :, ::dy, ::dx].cpu().numpy()
+            row["mask_err_dense"] = float(np.abs(dense.astype(np.float64) - ref["mask_dense"]).max())
+            row["mask_dense_samples"] = int(dense.size)
+        row["mask_err_max"] = max(row["mask_err"], row["mask_err_dense"] or 0.0)
         same = am == ref["argmax"]
         margin = ref["margin"].astype(np.float64)
-        dec = margin > DECIDABLE_FACTOR * row["mask_err"]
+        dec = margin > DECIDABLE_FACTOR * row["mask_err_max"]
+        # the integer target as COUNTS, beside the reference's own disagreement with itself (its fp32 run vs the same modules in float64)
+        row["pixels"] = int(same.size)
+        row["argmax_diff_pixels"] = int((~same).sum())
+        row["ref_floor_argmax_diff_pixels"] = (int(ref["floor_argmax_diff_pixels"]) if "floor_argmax_diff_pixels" in ref
+                                               else int(round((1.0 - float(ref["floor_argmax_same"])) * same.size)))
         row["argmax_equal"] = float(same.mean())
         row["decidable"] = float(dec.mean())
         row["argmax_equal_decidable"] = float(same[dec].mean()) if dec.any() else 1.0
@@ -134,7 +165,7 @@ def run_mode(dev, case, mode, teacher_forced=True):
             row["tf_embed_err"] = tf_err
     row["ref_floor_mask"] = float(ref["floor_mask"])
     row["ref_floor_embeds"] = [float(x) for x in ref["floor_embeds"]]
-    row["meets"] = bool(row["mask_err"] <= TOL_MASK and row["argmax_equal_decidable"] == 1.0)
+    row["meets"] = bool(row["mask_err_max"] <= TOL_MASK and row["argmax_equal_decidable"] == 1.0)
     del head, fused, masks, masks_tf, tf
     torch.cuda.empty_cache()
     return row
@@ -171,7 +202,9 @@ def panoptic_rows(dev, case, mode):
             torch.cuda.synchronize()
             ids = ids.cpu().numpy().reshape(H, W).astype(np.int64)
             want = ref[f"pan_ids_{t}"].astype(np.int64)
-            rows.append(dict(mode=mode, frame=t, ids_equal=float((ids == want).mean()),
+            rows.append(dict(mode=mode, frame=t, ids_equal=float((ids == want).mean()), pixels=int(ids.size), ids_diff_pixels=int((ids != want).sum()),
+                             # the reference's own post-process on its float64 outputs against the same on its fp32 outputs (round 6)
+                             ref_floor_ids_diff_pixels=int(ref[f"floor_pan_diff_pixels_{t}"]) if f"floor_pan_diff_pixels_{t}" in ref else None,
                              slots_equal=bool(np.array_equal(res.slot_index.cpu().numpy(), ref[f"pan_slot_index_{t}"])),
                              labels_equal=bool(np.array_equal(res.labels.cpu().numpy(), ref[f"pan_labels_{t}"])),
                              segments=int(len(ref[f"pan_labels_{t}"]))))
@@ -182,8 +215,10 @@ def panoptic_rows(dev, case, mode):
 
 def fmt(row):
     e = lambda xs: " ".join(f"{x:.1e}" for x in xs)
-    s = (f"[{row['case']} / {row['mode']}] mask logits {row['mask_err']:.2e} free-running ({row['mask_err_tf']:.2e} with the reference's last embeddings; "
-         f"the reference's own fp32 vs float64: {row['ref_floor_mask']:.1e}); slot argmax equal on {100 * row['argmax_equal']:.4f} % of the pixels, "
+    dense = "" if row.get("mask_err_dense") is None else f", {row['mask_err_dense']:.2e} on the dense sample ({row['mask_dense_samples']} logits)"
+    s = (f"[{row['case']} / {row['mode']}] mask logits {row['mask_err']:.2e} free-running{dense} ({row['mask_err_tf']:.2e} with the reference's last embeddings; "
+         f"the reference's own fp32 vs float64: {row['ref_floor_mask']:.1e}); slot argmax differs on {row['argmax_diff_pixels']} of {row['pixels']} pixels "
+         f"(the reference's fp32 run vs its float64 run: {row['ref_floor_argmax_diff_pixels']}) = equal on {100 * row['argmax_equal']:.4f} %, "
          f"{100 * row['argmax_equal_decidable']:.4f} % of the {100 * row['decidable']:.2f} % decidable; fused maps {row['fused0_err']:.1e} / {row['fused3_err']:.1e}\n"
          f"    embeddings per stage, free-running  {e(row['free_embed_err'])}\n")
     if "tf_embed_err" in row:

@@ -21,6 +21,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = MaskDynamicConv(256).to(dev).eval()
+m.precision = "bf16"          # 16-bit maps (the module default is fp16x2)
 g = torch.Generator(device=dev).manual_seed(0)
 HW = a.H * a.W
 feat = torch.randn((a.T, HW, 256), generator=g, device=dev).to(torch.float16 if a.map_dtype == "fp16" else torch.bfloat16)

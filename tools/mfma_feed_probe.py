@@ -1,14 +1,13 @@
 """How fast does one wave run a chain of 32 v_mfma_f32_32x32x16_f16 per 32-pixel tile when the B operand comes from LDS (the
-producer loop of K1', the heavy phase of K3')? Needs the diagnostic library:
-    make -C slotvps_amd/csrc stamp
-    SLOTVPS_LIB=slotvps_amd/libslotvps_hip_stamp.so python tools/mfma_feed_probe.py"""
+producer loop of K1', the heavy phase of K3')? The probe lives in the diagnostics library
+(libslotvps_hip_diag.so, built by `make -C slotvps_amd/csrc`): python tools/mfma_feed_probe.py"""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slotvps_amd import _lib, ops
 
 dev = torch.device("cuda:0")
-lib = _lib.load()
+lib = _lib.load_diag()          # the probes live in the diagnostics library (libslotvps_hip_diag.so)
 lib.svps_probe_mfma_feed.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 blocks, tiles = 256, 400
 out = torch.zeros((blocks * 8, 2), dtype=torch.int64, device=dev)

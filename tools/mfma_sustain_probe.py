@@ -4,7 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slotvps_amd import _lib, ops
 dev = torch.device("cuda:0")
-lib = _lib.load()
+lib = _lib.load_diag()          # the probes live in the diagnostics library (libslotvps_hip_diag.so)
 lib.svps_probe_mfma_feed.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 blocks = 256
 out = torch.zeros((blocks * 8, 2), dtype=torch.int64, device=dev)

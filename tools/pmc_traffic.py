@@ -70,7 +70,7 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "bench.py"), "rb") as fh:
         sha = hashlib.sha256(fh.read()).hexdigest()[:16]
-    rec = {"calibration_kernel": "svps::probe_copy_kernel (csrc/probes.hip)", "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
+    rec = {"calibration_kernel": "svps::probe_copy_kernel (csrc/diag_probes.hip)", "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 "
                       "--cpu-baseline 0 --whole-detector 0 --latency-leg 0 --no-graph",
            "bench_sha": sha,
            "calibration": {"what": "1 GiB copies by svps::probe_copy_kernel launched by the same process (bench.py copy-ceiling leg)",

@@ -19,6 +19,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = MaskDynamicConv(256).to(dev).eval()
+m.precision = "bf16"          # 16-bit maps (the module default is fp16x2)
 HW = a.H * a.W
 feat = torch.randn((a.T, HW, 256), device=dev).to(torch.float16 if a.map_dtype == "fp16" else torch.bfloat16)
 slots = torch.randn((a.T, a.L, 256), device=dev)
