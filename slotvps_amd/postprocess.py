@@ -216,7 +216,9 @@ class PostProcessPanopticInstances(nn.Module):
 
     # rows of every frame that are decoded (and handed to `side`) BEFORE the host knows how many slots pass the score filter: the first
     # `clip_decode_cap` slots of the score order. A frame that keeps more (the released configs keep ~30 of 100 - 200) makes the clip run
-    # again with all L rows - never a wrong result. None: always all L rows (K2 then writes 4 L h w bytes per frame: ~1 GB per VIPER clip)
+    # again with all L rows - never a wrong result - and the cap is then RAISED for the clips that follow (to the next power of two above
+    # the largest count seen, at most L; logged once per raise), so that a model that keeps many slots pays the second pass once, not per
+    # clip. None: always all L rows (K2 then writes 4 L h w bytes per frame: ~1 GB per VIPER clip)
     clip_decode_cap = 64
 
     def _clip_on_device(self, scores, classes, nc, pred_masks, size, stuff_num, side, cap=None):
@@ -261,7 +263,15 @@ class PostProcessPanopticInstances(nn.Module):
         if (st[:, PPC_K] == 0).any():
             raise ValueError("no slot passes the score threshold (the reference's mask_removal fails here too, :652)")
         if (st[:, PPC_K] > cap).any():
-            # a frame keeps more slots than were decoded: the kernels skipped it (svps_panoptic_clip: Args::rows); everything again with all rows
+            # a frame keeps more slots than were decoded: the kernels skipped it (svps_panoptic_clip: Args::rows); everything again with all
+            # rows - and the following clips start with a cap that covers what this one kept
+            kmax = int(st[:, PPC_K].max())
+            new_cap = min(L, 1 << max(0, kmax - 1).bit_length())
+            if self.clip_decode_cap is not None and new_cap > int(self.clip_decode_cap):
+                import sys
+                print(f"[slotvps_amd.postprocess] a frame kept {kmax} slots, more than clip_decode_cap = {self.clip_decode_cap}: this clip was "
+                      f"post-processed twice; clip_decode_cap is now {new_cap}", file=sys.stderr, flush=True)
+                self.clip_decode_cap = new_cap
             return self._clip_on_device(scores, classes, nc, pred_masks, size, stuff_num, side, cap=L)
         while (st[:, PPC_PHASE] != 2).any():                                # a frame with more small-area rounds than were enqueued
             enqueue(2, 6)

@@ -38,6 +38,8 @@ def _case(tag):
 
 # (mode, case) -> bounds: mask = free-running mask logits (sampled pixels, all frames); tf = largest teacher-forced per-stage embedding
 # error; eq = fraction of ALL pixels with the reference's slot argmax (free-running); contract = must meet 1e-4 / argmax-where-decidable.
+# Measured (round 6, MI355X):  fp16x2  T5 9.5e-6 (dense sample 9.5e-6) / 28 of 655 360 argmax pixels (the reference's own fp32 vs float64: 10)
+#                                      VIPER T10 6.5e-6 / 45 of 1 305 600 (reference: 27); sharp 4.1e-4 (floor 4.3e-4) / 337 (reference: 197)
 # Measured (round 5, MI355X):  fp16x2  T5 9.7e-6 / 3.4e-5 / 99.996 %   sharp 4.0e-4 / 3.9e-5 / 99.86 %   VIPER see test
 #                              fp32    T5 5.0e-6 / 1.2e-5 / 99.999 %   sharp 3.9e-4 / 2.6e-5 / 99.91 %   VIPER 3.7e-6 / - / 99.997 %
 #                              fp16    T5 1.9e-3 / 3.7e-3 / 99.36 %    sharp 7.8e-2 / 1.3e-2 / 79 %      VIPER 1.6e-3 / 3.0e-3 / 99.32 %
@@ -47,8 +49,8 @@ BOUNDS = {
     ("fp32", "T5_1024x2048_L100"): dict(mask=1e-4, tf=1e-4, eq=0.9995, contract=True),
     ("fp16", "T5_1024x2048_L100"): dict(mask=4e-3, tf=8e-3, eq=0.99, contract=False),
     ("bf16", "T5_1024x2048_L100"): dict(mask=3e-2, tf=6e-2, eq=0.93, contract=False),
-    ("fp16x2", "T2_1024x2048_L100_sharp"): dict(mask=None, tf=1e-4, eq=0.995, contract=False),
-    ("fp32", "T2_1024x2048_L100_sharp"): dict(mask=None, tf=1e-4, eq=0.995, contract=False),
+    ("fp16x2", "T2_1024x2048_L100_sharp"): dict(mask=None, tf=1e-4, eq=0.995, contract=False, dec=0.9),
+    ("fp32", "T2_1024x2048_L100_sharp"): dict(mask=None, tf=1e-4, eq=0.995, contract=False, dec=0.9),
     ("fp16", "T2_1024x2048_L100_sharp"): dict(mask=2e-1, tf=3e-2, eq=0.6, contract=False),
     ("bf16", "T2_1024x2048_L100_sharp"): dict(mask=4e-1, tf=2e-1, eq=0.25, contract=False),
     ("fp16x2", "T2_1088x1920_L200"): dict(mask=1e-4, tf=1e-4, eq=0.9995, contract=True),
@@ -92,10 +94,15 @@ def test_full_size_clip_against_the_reference(cuda, tag, mode):
     if b["contract"]:
         assert row["argmax_diff_pixels"] <= max(20, 10 * row["ref_floor_argmax_diff_pixels"]), (row["argmax_diff_pixels"], row["ref_floor_argmax_diff_pixels"])
     assert row["argmax_equal"] >= b["eq"], row["argmax_equal"]
-    assert row["argmax_equal_decidable"] == 1.0                          # integer target: identical wherever decidable at the measured error
+    # integer target: identical wherever decidable at the measured error - claimed only where that set is (nearly) everything (ADVICE r05:
+    # the threshold derives from the measured error, so for the 16-bit modes the set shrinks to 0 - 60 % of the pixels and the statement would
+    # be vacuous; they are held to the `eq` regression bound on ALL pixels instead). Measured decidable: contract rows 99.7 - 99.9 %, sharp 93 %
+    dec_floor = 0.99 if b["contract"] else b.get("dec")
+    if dec_floor is not None:
+        assert row["decidable"] >= dec_floor and row["argmax_equal_decidable"] == 1.0, (row["decidable"], row["argmax_equal_decidable"])
     assert row["argmax_kernel_vs_own_logits"] >= 0.99999                 # the fused argmax byte is the argmax of the logits written
     if b["contract"]:
-        assert row["meets"] and row["mask_err"] <= fsp.TOL_MASK and row["decidable"] >= 0.99
+        assert row["meets"] and row["mask_err"] <= fsp.TOL_MASK
     if mode in ("fp16x2", "fp32"):
         # decode alone (the reference's own last-stage embeddings on this mode's finest map): fp32 summation order
         assert row["mask_err_tf"] <= 2e-6

@@ -273,5 +273,19 @@ def test_clip_postprocess_decode_cap(cuda, overflow_frame):
         PostProcessPanopticInstances.clip_decode_cap = None        # no cap: all L rows
         res = _clip_vs_frames(cuda, cases, (48, 96))
         assert res[0]._row_stride == 100
+        # the overflow is STICKY per instance - the clip that overflows runs twice, the next clip of the same model starts with
+        # a cap that covers what was kept (next power of two, at most L) and takes one pass
+        import torch
+        PostProcessPanopticInstances.clip_decode_cap = 16
+        pp = PostProcessPanopticInstances(**CFG)
+        lg = torch.from_numpy(np.stack([c[0] for c in cases])).to(cuda)
+        mk = torch.from_numpy(np.stack([c[1] for c in cases])).to(cuda)
+        first = pp.forward_clip(lg, mk, (48, 96))
+        assert first[0]._row_stride == 100 and pp.clip_decode_cap == 32 and PostProcessPanopticInstances.clip_decode_cap == 16
+        second = pp.forward_clip(lg, mk, (48, 96))
+        assert second[0]._row_stride == 32
+        for a_, b_ in zip(first, second):
+            np.testing.assert_array_equal(a_.slot_index_host, b_.slot_index_host)
+            np.testing.assert_array_equal(a_.labels_host, b_.labels_host)
     finally:
         PostProcessPanopticInstances.clip_decode_cap = saved
