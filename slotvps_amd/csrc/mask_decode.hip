@@ -769,6 +769,301 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// HL32 (round 6): the reference-precision decode on THIRTY-TWO-pixel tiles. mask_decode_kernel_v2<.., HL> borrowed the 16-pixel hi / lo tile
+// of the retriever: per 16 pixels it pays a whole tile's fixed cost (barrier, DMA issue, argmax reduction, two half-line stores), a useless
+// e_lo . f_lo quarter of its MFMAs and a fold of the two accumulator halves - 17 vector instructions per MFMA, VALU-issue-bound (round 5:
+// 0.44 of HBM). Here a tile is 32 pixels with the hi rows and the lo rows in TWO 16-KiB LDS tiles of the usual layout:
+//   * three MFMAs per k-step into ONE accumulator (e_lo f_hi + e_hi f_lo + e_hi f_hi): 48 per wave and 32 pixels instead of 64, no fold;
+//     lane = pixel, 16 accumulator elements = 16 slots, exactly the layout of the 16-bit fast path;
+//   * one barrier, one argmax reduction and four full 128-byte row-segment stores per wave and 32 pixels;
+//   * fragment addresses held in 8 registers (chunk ^ swizzle for k-steps 0 .. 7; k-steps 8 .. 15 and the lo tile are immediate offsets);
+//   * LDS: 2 stages x 32 KiB + a [16 slots][32 px] transpose tile per wave (the logits leave in two halves) = 78 KiB: two workgroups per CU.
+// Same skew as the fast path: the epilogue of tile it - 1 rides in the shadow of the chain of tile it; norms double-buffered by parity.
+struct DecHl32Lds {
+    static constexpr int kStages = 2;
+    static constexpr int kStageBytes = 2 * kTileBytes;               // hi tile, then lo tile
+    static constexpr int ring = 0;
+    static constexpr int kORow = 144;                                // [16 slots][32 px] fp32 per wave, rows padded to 144 B
+    static constexpr int kOWave = 16 * kORow;
+    static constexpr int otile = kStages * kStageBytes;
+    static constexpr int affine = otile + 4 * kOWave;                // scale[256], shift[256]
+    static constexpr int norm = affine + 2 * kD * 4;                 // [2][32] by tile parity: fg_scale / ||g||
+    static constexpr int cshift = norm + 2 * kTilePx * 4;            // [128]
+    static constexpr int amax = cshift + 128 * 4;                    // [2][4][32] float2
+    static constexpr int total = amax + 2 * 4 * kTilePx * 8;
+};
+static_assert(2 * DecHl32Lds::total <= 160 * 1024, "two workgroups per CU");
+
+template <bool ARGMAX, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
+    const _Float16* __restrict__ feat_hi, const _Float16* __restrict__ feat_lo, const float* __restrict__ embed,
+    const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
+    uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using Lds = DecHl32Lds;
+    constexpr int NW = 4, NT = 256, NST = Lds::kStages;
+    constexpr int PCW = (ABL & 8) ? 0 : 8;                         // 1-KiB DMA pieces per wave and tile
+    constexpr int kMS = 4;                                         // mask stores per wave and tile
+    constexpr int kAS = ARGMAX ? 1 : 0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x;
+    const int px_begin = c * tiles_per_chunk * kTilePx;
+    int px_end = px_begin + tiles_per_chunk * kTilePx;
+    px_end = px_end < HW ? px_end : HW;
+    const int nt = (px_end - px_begin + kTilePx - 1) / kTilePx;
+
+    float* aff = reinterpret_cast<float*>(smem + Lds::affine);
+    float* inv_norm = reinterpret_cast<float*>(smem + Lds::norm);
+    float* cs = reinterpret_cast<float*>(smem + Lds::cshift);
+    float2* am = reinterpret_cast<float2*>(smem + Lds::amax);
+    for (int i = tid; i < kD; i += NT) {
+        aff[i] = bn_scale[i];
+        aff[kD + i] = bn_shift[i];
+    }
+    __syncthreads();
+
+    f16x8 eh[16], el[16];                                          // (e . scale) of slot 32 w + r as fp16 hi + lo, A fragments
+    {
+        const int slot = 32 * w + r;
+        const float* erow = embed + ((size_t)t * L + (slot < L ? slot : 0)) * kD + 8 * h;
+        float dot = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(erow + 16 * ks);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(erow + 16 * ks + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = 16 * ks + 8 * h + j;
+                float x = j < 4 ? x0[j] : x1[j - 4];
+                if (slot >= L) x = 0.f;
+                dot += x * aff[kD + ch];
+                float xs = x * aff[ch];
+                asm volatile("" : "+v"(xs));                       // ONE fp32 value for both halves (see mask_decode_kernel_v2)
+                const _Float16 hi = (_Float16)xs;
+                eh[ks][j] = hi;
+                el[ks][j] = (_Float16)(xs - (float)hi);
+            }
+            if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        dot = wave_half_xor_sum(dot);
+        // a padded slot row (>= L) must never win the argmax: its constant is -inf x sign(fg_scale), so its logit is -inf (NaN for fg_scale = 0:
+        // never greater than anything); its logits are not stored
+        if (h == 0) cs[slot] = slot < L ? dot : (fg_scale >= 0.f ? -INFINITY : INFINITY);
+    }
+    wait_vm<0>();
+    __syncthreads();
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+    const u32x4 frs = make_srd_d((w >= 2 ? feat_lo : feat_hi) + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);   // waves 0, 1: hi plane; 2, 3: lo
+    const u32x4 ors = make_srd_d(out + (size_t)t * L * HW, (uint32_t)L * (uint32_t)HW * 4u);
+    const u32x4 ars = make_srd_d(ARGMAX ? slot_argmax + (size_t)t * HW : nullptr, ARGMAX ? (uint32_t)HW : 0u);
+    // wave w stages rows 16 (w & 1) .. + 15 of its plane: 8 pieces of two rows, two instructions groups of four
+    auto stage = [&](int tile) {
+        if (tile >= nt || (ABL & 8)) return;
+        int rr = r, hh = h;
+        asm volatile("" : "+v"(rr), "+v"(hh));
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * Lds::kStageBytes + (w >> 1) * kTileBytes + (w & 1) * 8192);
+        const int px0 = px_begin + tile * kTilePx;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + kTilePx <= HW) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                int vo[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 16 * (w & 1) + 8 * g + 2 * i + hh;
+                    vo[i] = row * kRowBytes + ((rr ^ swz(row)) * 16) - 1024 * i;
+                }
+                dma16x4_d(frs, st + 4096 * g, vo[0], vo[1], vo[2], vo[3], soff);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 16 * (w & 1) + 2 * i + hh;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                dma16_d(frs, st + i * 1024, src * kRowBytes + ((rr ^ swz(row)) * 16), soff);
+            }
+        }
+    };
+    stage(0);
+
+    // fragment addresses: chunk (2 ks + h) ^ swz(r) for ks = 0 .. 7; ks + 8 is + 256 B, the lo tile + kTileBytes (immediates)
+    int fa[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fa[k] = r * kRowBytes + (((2 * k + h) ^ swz(r)) * 16);
+    char* ot = smem + Lds::otile + w * Lds::kOWave;
+    f32x16 sp;                                                     // accumulators of the previous tile
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sp[i] = 0.f;
+
+    auto body = [&](const int it, auto has_chain, auto has_epi) {
+        constexpr bool CH = decltype(has_chain)::value, EP = decltype(has_epi)::value && !(ABL & 4);
+        // issue order per iteration: DMA(it + 1) x 8, argmax store of tile it - 2, mask stores of tile it - 1 x 4. Younger than DMA(it): the
+        // stores of iteration it - 1 (if it had an epilogue)
+        if constexpr (CH) {
+            if (it >= 2) wait_vm<kMS + kAS>();
+            else wait_vm<0>();
+        }
+        wg_barrier();
+        if constexpr (CH) stage(it + 1);
+        const char* fth = smem + Lds::ring + (it % NST) * Lds::kStageBytes;
+
+        if constexpr (CH) {   // fg_scale / ||scale (f_hi + f_lo) + shift|| per pixel: 8 threads per pixel, 4 chunks each
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
+            const int npx = tid_o >> 3, nsub = tid_o & 7;
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int chunk = nsub + 8 * i;
+                const int o = npx * kRowBytes + ((chunk ^ swz(npx)) * 16);
+                const f16x8 xh = *reinterpret_cast<const f16x8*>(fth + o);
+                const f16x8 xl = *reinterpret_cast<const f16x8*>(fth + kTileBytes + o);
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(aff + 8 * chunk), a1 = *reinterpret_cast<const f32x4*>(aff + 8 * chunk + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(aff + kD + 8 * chunk), b1 = *reinterpret_cast<const f32x4*>(aff + kD + 8 * chunk + 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xv = (float)xh[j] + (float)xl[j];                  // exact: 11 + 11 bits
+                    const float g = xv * (j < 4 ? a0[j] : a1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]);
+                    ss += g * g;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ss += __shfl_xor(ss, 1);
+            ss += __shfl_xor(ss, 2);
+            ss += __shfl_xor(ss, 4);
+            if (nsub == 0) inv_norm[(it & 1) * kTilePx + npx] = fg_scale / fmaxf(sqrtf(ss), 1e-12f);
+        }
+
+        constexpr bool FR = CH && !(ABL & 2);
+        f16x8 fh[2], fl[2];                              // operand fragments of one k-step, the next k-step's in flight
+        if constexpr (FR) {
+            fh[0] = *reinterpret_cast<const f16x8*>(fth + fa[0]);
+            fl[0] = *reinterpret_cast<const f16x8*>(fth + kTileBytes + fa[0]);
+        }
+        float2 cnd[NW];
+        if constexpr (ARGMAX && EP) {
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) cnd[ww] = am[(it & 1) * NW * kTilePx + ww * kTilePx + r];
+        }
+        float inr = 0.f;
+        f32x4 c4[2];                                     // e . shift of slots acc_row(4 q .. 4 q + 3, h), one quad ahead
+        if constexpr (EP) {
+            inr = inv_norm[((it - 1) & 1) * kTilePx + r];
+            c4[0] = *reinterpret_cast<const f32x4*>(cs + 32 * w + 4 * h);
+        }
+        const int px_prev = px_begin + (it - 1) * kTilePx;
+        auto half_store = [&](int hf) {        // slots 16 hf .. + 15 of this wave's block: two 1-KiB wave stores of 128-byte row segments
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int sl = 8 * u + (lane >> 3), cc = lane & 7;
+                const u32x4 val = *reinterpret_cast<const u32x4*>(ot + sl * Lds::kORow + cc * 16);
+                const int slot = 32 * w + 16 * hf + sl, px = px_prev + 4 * cc;
+                const bool ok = slot < L && px < px_end && !(ABL & 64);
+                store16_d(val, ors, ok ? (slot * HW + px) * 4 : 0x7ffffff0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        f32x16 s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+        float best = -INFINITY;
+        int best_slot = 0x7fffffff;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if constexpr (EP) {
+                if ((g & 1) == 0 && g < 6) c4[((g >> 1) + 1) & 1] = *reinterpret_cast<const f32x4*>(cs + 32 * w + 8 * ((g >> 1) + 1) + 4 * h);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ks = 2 * g + u;
+                if constexpr (FR) {
+                    if (ks < 15) {
+                        fh[(ks + 1) & 1] = *reinterpret_cast<const f16x8*>(fth + fa[(ks + 1) & 7] + ((ks + 1) >> 3) * 256);
+                        fl[(ks + 1) & 1] = *reinterpret_cast<const f16x8*>(fth + kTileBytes + fa[(ks + 1) & 7] + ((ks + 1) >> 3) * 256);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (ABL & 1) {
+                        asm volatile("" : : "v"(fh[ks & 1]), "v"(fl[ks & 1]), "v"(el[ks]), "v"(eh[ks]));
+                    } else {
+                        s = mfma16(el[ks], fh[ks & 1], s);
+                        s = mfma16(eh[ks], fl[ks & 1], s);
+                        s = mfma16(eh[ks], fh[ks & 1], s);
+                    }
+                }
+                if constexpr (ARGMAX && EP) {
+                    if (ks == 1) {                       // cross-wave part of the argmax of tile it - 2 (every wave computes, wave 0 stores)
+                        float b = -INFINITY;
+                        int bs = 0x7fffffff;
+#pragma unroll
+                        for (int ww = 0; ww < NW; ++ww) {
+                            const int sl = __float_as_int(cnd[ww].y);
+                            if (cnd[ww].x > b || (cnd[ww].x == b && sl < bs)) { b = cnd[ww].x; bs = sl; }
+                        }
+                        const int px = px_begin + (it - 2) * kTilePx + r;
+                        const bool ok = w == 0 && h == 0 && it >= 2 && px < px_end;
+                        store1_d(bs, ars, ok ? px : 0x7ffffff0);
+                    }
+                }
+                if constexpr (EP) {
+                    const int i = ks;                    // accumulator element = slot acc_row(i, h) of this wave's block
+                    const int sl = acc_row(i, h);
+                    const float m = (sp[i] + c4[(i >> 2) & 1][i & 3]) * inr + fg_shift;
+                    *reinterpret_cast<float*>(ot + (sl & 15) * Lds::kORow + r * 4) = m;
+                    if constexpr (ARGMAX) {
+                        if (m > best) { best = m; best_slot = 32 * w + sl; }      // slots ascend with i within a lane; padded rows are -inf / NaN
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (EP) {
+                if (g == 3) half_store(0);               // elements 0 .. 7 = slots 0 .. 15 are in the transpose tile
+            }
+        }
+        if constexpr (EP) {
+            half_store(1);
+            if constexpr (ARGMAX) {
+                const auto pb = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                const auto ps = __builtin_amdgcn_permlane32_swap((uint32_t)best_slot, (uint32_t)best_slot, false, false);
+                best = __uint_as_float(pb[0]);
+                best_slot = (int)ps[0];
+                const float ob = __uint_as_float(pb[1]);
+                const int os = (int)ps[1];
+                if (ob > best || (ob == best && os < best_slot)) { best = ob; best_slot = os; }
+                if (h == 0) am[((it - 1) & 1) * NW * kTilePx + w * kTilePx + r] = make_float2(best, __int_as_float(best_slot));
+            }
+        }
+        if constexpr (CH) sp = s;
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    body(0, T_{}, F_{});
+#pragma clang loop unroll(disable)
+    for (int it = 1; it < nt; ++it) body(it, T_{}, T_{});
+    body(nt, F_{}, T_{});
+    if constexpr (ARGMAX) {
+        wg_barrier();
+        if (w == 0 && h == 0) {                          // cross-wave part of the argmax of the last tile
+            float b = -INFINITY;
+            int bs = 0x7fffffff;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const float2 cn = am[((nt - 1) & 1) * NW * kTilePx + ww * kTilePx + r];
+                const int sl = __float_as_int(cn.y);
+                if (cn.x > b || (cn.x == b && sl < bs)) { b = cn.x; bs = sl; }
+            }
+            const int px = px_begin + (nt - 1) * kTilePx + r;
+            if (px < px_end) slot_argmax[(size_t)t * HW + px] = (uint8_t)bs;
+        }
+    }
+}
+
 }  // namespace svps
 
 namespace {
@@ -811,6 +1106,22 @@ hipError_t launch_decode_v2(const void* feat, const float* embed, const float* b
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(64 * NW), Lds::total, stream, static_cast<const MT*>(feat),
                        embed, bn_scale, bn_shift, fg_scale, fg_shift, static_cast<float*>(out), slot_argmax, L, HW, tpc,
                        static_cast<const MT*>(feat_lo));
+    return hipGetLastError();
+}
+
+template <bool ARGMAX, int ABL = 0>
+hipError_t launch_decode_hl32(const void* feat_hi, const void* feat_lo, const float* embed, const float* bn_scale, const float* bn_shift,
+                              float fg_scale, float fg_shift, float* out, uint8_t* slot_argmax, int T, int L, int HW, hipStream_t stream) {
+    auto kern = svps::mask_decode_hl32_kernel<ARGMAX, ABL>;
+    using Lds = svps::DecHl32Lds;
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
+    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+    int chunks = svps_pick_chunks(T, tiles, 2 * dec_num_cus());       // two co-resident workgroups per CU
+    const int tpc = (tiles + chunks - 1) / chunks;
+    chunks = (tiles + tpc - 1) / tpc;
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(256), Lds::total, stream, static_cast<const _Float16*>(feat_hi),
+                       static_cast<const _Float16*>(feat_lo), embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, L, HW, tpc);
     return hipGetLastError();
 }
 
@@ -932,7 +1243,12 @@ extern "C" int svps_mask_decode_hl_fwd(const void* feat_hi, const void* feat_lo,
         }
     }
 #endif
-    if (L <= 128 && (HW & 3) == 0 && !old_form) {
+    static const bool hl16 = getenv("SVPS_K2_HL16") != nullptr;              // comparison runs only: round 5's 16-pixel hi / lo tiles
+    if (L <= 128 && (HW & 3) == 0 && !old_form && !hl16 && (size_t)L * HW * 4 < 0x7ffffff0u) {
+        // round 6: 32-pixel tiles, three MFMAs per k-step into one accumulator (mask_decode_hl32_kernel)
+        e = slot_argmax ? launch_decode_hl32<true>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
+                        : launch_decode_hl32<false>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream);
+    } else if (L <= 128 && (HW & 3) == 0 && !old_form) {
         // round 5: the skewed fast path on 16-pixel hi / lo tiles (mask_decode_kernel_v2<.., HL>)
         e = slot_argmax ? launch_decode_v2<true, 4, true, 0, 0, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)
                         : launch_decode_v2<false, 4, true, 0, 0, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo);
