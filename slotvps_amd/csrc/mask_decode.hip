@@ -862,6 +862,8 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
     const u32x4 ors = make_srd_d(out + (size_t)t * L * HW, (uint32_t)L * (uint32_t)HW * 4u);
     const u32x4 ars = make_srd_d(ARGMAX ? slot_argmax + (size_t)t * HW : nullptr, ARGMAX ? (uint32_t)HW : 0u);
     // wave w stages rows 16 (w & 1) .. + 15 of its plane: 8 pieces of two rows, two instructions groups of four
+    // LDS position c of row `row` holds the logical chunk c ^ swz(row); with row = 16 (w & 1) + 8 g + 2 i + hh the swizzle is
+    // ((2 (i & 1) + hh) << 2) | (2 g + (i >> 1)): a lane constant (rr ^ (hh << 2)) xor a compile-time constant per piece
     auto stage = [&](int tile) {
         if (tile >= nt || (ABL & 8)) return;
         int rr = r, hh = h;
@@ -870,13 +872,15 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
         const int px0 = px_begin + tile * kTilePx;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
         if (px0 + kTilePx <= HW) {
+            const int cbase = (rr ^ (hh << 2)) * 16;                        // chunk term of this lane, before the piece's constant
+            const int rbase = (16 * (w & 1) + hh) * kRowBytes;              // row term
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 int vo[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int row = 16 * (w & 1) + 8 * g + 2 * i + hh;
-                    vo[i] = row * kRowBytes + ((rr ^ swz(row)) * 16) - 1024 * i;
+                    const int kc = (((2 * (i & 1)) << 2) | (2 * g + (i >> 1))) * 16;
+                    vo[i] = (cbase ^ kc) + rbase + (8 * g + 2 * i) * kRowBytes - 1024 * i;
                 }
                 dma16x4_d(frs, st + 4096 * g, vo[0], vo[1], vo[2], vo[3], soff);
             }
@@ -896,6 +900,9 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
 #pragma unroll
     for (int k = 0; k < 8; ++k) fa[k] = r * kRowBytes + (((2 * k + h) ^ swz(r)) * 16);
     char* ot = smem + Lds::otile + w * Lds::kOWave;
+    // the norm's thread -> (pixel tid >> 3, chunks (tid & 7) + 8 i): LDS offset of chunk i = 0 and first channel
+    const int nrm_o0 = (tid >> 3) * kRowBytes + (((tid & 7) ^ swz(tid >> 3)) * 16);
+    const int nrm_ch = 8 * (tid & 7);
     f32x16 sp;                                                     // accumulators of the previous tile
 #pragma unroll
     for (int i = 0; i < 16; ++i) sp[i] = 0.f;
@@ -913,30 +920,32 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
         const char* fth = smem + Lds::ring + (it % NST) * Lds::kStageBytes;
 
         if constexpr (CH) {   // fg_scale / ||scale (f_hi + f_lo) + shift|| per pixel: 8 threads per pixel, 4 chunks each
-            int tid_o = tid;
-            asm volatile("" : "+v"(tid_o));
-            const int npx = tid_o >> 3, nsub = tid_o & 7;
+            // chunk nsub + 8 i of pixel npx sits at LDS chunk (nsub + 8 i) ^ swz(npx): o_0 for i = 0, o_0 ^ 128 B for i = 1, + 256 B for i + 2
+            int o0 = nrm_o0;
+            asm volatile("" : "+v"(o0));                                     // (opaque per tile: no address table in registers)
+            const int o1 = o0 ^ 128;
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int chunk = nsub + 8 * i;
-                const int o = npx * kRowBytes + ((chunk ^ swz(npx)) * 16);
+                const int o = ((i & 1) ? o1 : o0) + (i >> 1) * 256;
                 const f16x8 xh = *reinterpret_cast<const f16x8*>(fth + o);
                 const f16x8 xl = *reinterpret_cast<const f16x8*>(fth + kTileBytes + o);
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(aff + 8 * chunk), a1 = *reinterpret_cast<const f32x4*>(aff + 8 * chunk + 4);
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(aff + kD + 8 * chunk), b1 = *reinterpret_cast<const f32x4*>(aff + kD + 8 * chunk + 4);
+                const float* ap = aff + nrm_ch + 64 * i;                      // channels 8 (nsub + 8 i) ..
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(ap + kD), b1 = *reinterpret_cast<const f32x4*>(ap + kD + 4);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float xv = (float)xh[j] + (float)xl[j];                  // exact: 11 + 11 bits
-                    const float g = xv * (j < 4 ? a0[j] : a1[j - 4]) + (j < 4 ? b0[j] : b1[j - 4]);
-                    ss += g * g;
+                    const float a_ = j < 4 ? a0[j] : a1[j - 4], b_ = j < 4 ? b0[j] : b1[j - 4];
+                    // scale (hi + lo) + shift as two fused multiply-adds on the fp16 values (v_fma_mix_f32: no conversion instructions)
+                    const float g = __builtin_fmaf((float)xl[j], a_, __builtin_fmaf((float)xh[j], a_, b_));
+                    ss = __builtin_fmaf(g, g, ss);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             ss += __shfl_xor(ss, 1);
             ss += __shfl_xor(ss, 2);
             ss += __shfl_xor(ss, 4);
-            if (nsub == 0) inv_norm[(it & 1) * kTilePx + npx] = fg_scale / fmaxf(sqrtf(ss), 1e-12f);
+            if ((tid & 7) == 0) inv_norm[(it & 1) * kTilePx + (tid >> 3)] = fg_scale / fmaxf(sqrtf(ss), 1e-12f);
         }
 
         constexpr bool FR = CH && !(ABL & 2);
