@@ -53,6 +53,10 @@ constexpr int kExtRow = 272;               // floats per slot row of the finishe
 
 template <int PT>    // PT = 1: P * rstd_v as one fp16 tile; 2: hi and lo tiles (the precision form, retr_attn_kernel<.., PHL = true>)
 struct RetrLdsT {
+    static constexpr int kA = kRPrefetch;
+    static constexpr int kNF = kRNF;
+    static constexpr int kPBufBytes = PT * kPTile;              // one P buffer: the hi tile (and the lo tile behind it)
+    static constexpr int kPLo = kPTile;
     static constexpr int fring = 0;                             // tile bases are multiples of 512 B (fragment address XORs)
     static constexpr int aring = kRNF * kTileBytes;
     static constexpr int yring = aring + kRNF * kAuxTile;
@@ -63,6 +67,25 @@ struct RetrLdsT {
 };
 using RetrLds = RetrLdsT<1>;
 static_assert(RetrLds::pring % 512 == 0 && RetrLds::total <= 160 * 1024 && RetrLdsT<2>::total <= 160 * 1024, "LDS layout");
+// HL form (round 6): a tile is sixteen pixels, so a P tile has sixteen rows per slot block - the hi rows at sb * 2 KiB + row * 64, the lo
+// rows in the other half of the block (+ 1 KiB): ONE 8-KiB tile per buffer instead of two with duplicated rows (round 5 wrote every row
+// twice so that the consumers' lo k-step could read rows 16 .. 31: it now re-uses the fragment of k-step 0). The 16 KiB this frees hold a
+// SEVENTH ring stage: the producers' softmax head runs one tile later (in the shadow of the next tile's chain, see retr_attn_kernel), the
+// consumers therefore three tiles behind the chain, with three batches still in flight ahead of it.
+struct RetrLdsHL {
+    static constexpr int kA = kRPrefetch;                       // batches requested ahead
+    static constexpr int kNF = kRPrefetch + 4;                  // tiles it-3 .. it+3 are live in iteration it
+    static constexpr int kPBufBytes = kPTile;
+    static constexpr int kPLo = 1024;                           // lo rows of a slot block: behind its sixteen hi rows
+    static constexpr int fring = 0;
+    static constexpr int aring = kNF * kTileBytes;
+    static constexpr int yring = aring + kNF * kAuxTile;
+    static constexpr int pring = yring + kNF * kCyTile;
+    static constexpr int stats = pring + 2 * kPBufBytes;
+    static constexpr int c3 = stats + 2 * 4 * 32 * 8;
+    static constexpr int total = c3 + 128 * 4;
+};
+static_assert(RetrLdsHL::pring % 512 == 0 && RetrLdsHL::total <= 160 * 1024, "LDS layout");
 
 __device__ __forceinline__ u32x4 ra_make_srd(const void* base, uint32_t bytes) {
     const uint64_t a = reinterpret_cast<uint64_t>(base);
@@ -170,10 +193,14 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     const __bf16* __restrict__ feat_lo) {                       // HL: the lo plane [T, HW, 256] fp16 (feat is the hi plane)
     static_assert(!HL || PHL, "the hi + lo map form goes with hi + lo probabilities");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    using Lds = RetrLdsT<PHL ? 2 : 1>;
-    constexpr int A = kRPrefetch;
+    using Lds = std::conditional_t<HL, RetrLdsHL, RetrLdsT<PHL ? 2 : 1>>;
+    constexpr int A = Lds::kA;
+    constexpr int NF = Lds::kNF;                                // ring depth (feature / aux / Cy tiles)
+    constexpr bool PIPE = HL;                                   // the softmax head of a tile runs one iteration behind its chain (see the producer)
+    constexpr int LAG = PIPE ? 3 : 2;                           // the consumers' distance behind the chain
     constexpr int TPX = HL ? 16 : kTilePx;                      // pixels per tile
-    constexpr int kPBuf = (PHL ? 2 : 1) * kPTile;               // one P buffer: the hi tile (and the lo tile behind it)
+    constexpr int kPBuf = Lds::kPBufBytes;                      // one P buffer: the hi tile (and the lo tile behind it / in its blocks' upper halves)
+    constexpr int kPLo = Lds::kPLo;
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -296,7 +323,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
         };
         auto prefetch = [&](int tile) {
-            const uint32_t slot = (uint32_t)(tile % kRNF);
+            const uint32_t slot = (uint32_t)(tile % NF);
             const uint32_t tb = lane_row + slot * kTileBytes;
 #pragma unroll
             for (int u = 0; u < 4; ++u) kf0[u] = frag(tb, kOrd[u]);
@@ -307,7 +334,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         // One iteration. CHAIN: tile `it` exists (MFMA chain + softmax head); P2: tile it-1 exists (softmax finish).
         auto body = [&](int it, auto chain_tag, auto p2_tag) {
             constexpr bool CHAIN = decltype(chain_tag)::value, P2 = decltype(p2_tag)::value;
-            const uint32_t tb = lane_row + (uint32_t)(it % kRNF) * kTileBytes;
+            const uint32_t tb = lane_row + (uint32_t)(it % NF) * kTileBytes;
             // ---- softmax finish of tile it-1, part 1: the four blocks' statistics (requested now, used under the second MFMA group)
             float fac = 0.f;
             float2 st_w[4];
@@ -345,16 +372,14 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                         pl[j] = (_Float16)(x - (float)ph[j]);
                     }
                     if constexpr (HL) {
-                        // this lane's slot group gsel + g of pixel r & 15 goes to BOTH rows of that pixel (rows 16 .. 31 of the P tile repeat
-                        // rows 0 .. 15: the A operand of the consumers' lo k-step); rows r and r + 16 share the swizzle key
+                        // this lane's slot group gsel + g of pixel r & 15: the hi row of that pixel, the lo row 1 KiB behind it (round 6: sixteen
+                        // rows per slot block; the consumers' lo k-step re-uses the A fragment of k-step 0)
                         char* pr = prowh + (((gsel + g) ^ key) * 16);
                         *reinterpret_cast<f16x4*>(pr) = ph;
-                        *reinterpret_cast<f16x4*>(pr + 1024) = ph;
-                        *reinterpret_cast<f16x4*>(pr + kPTile) = pl;
-                        *reinterpret_cast<f16x4*>(pr + kPTile + 1024) = pl;
+                        *reinterpret_cast<f16x4*>(pr + kPLo) = pl;
                         return;
                     }
-                    *reinterpret_cast<f16x4*>(prow + kPTile + ((g ^ key) * 16)) = pl;
+                    *reinterpret_cast<f16x4*>(prow + kPLo + ((g ^ key) * 16)) = pl;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ph[j] = (_Float16)(e[4 * g + j] * fac);
@@ -446,7 +471,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
             }
             // Cy row of tile it+1 (staged with batch `it`): requested now, added to Cx after the exponentials
             f32x4 cyv[4];
-            const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + ((it + 1) % kRNF) * kCyTile) + slot_off + slot0;
+            const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + ((it + 1) % NF) * kCyTile) + slot_off + slot0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) cyv[g] = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
             const f32x2 ext_c = ext_n;
@@ -521,7 +546,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     int ds = strip0, dy = row0;                                 // strip / image row of the next batch
     auto issue_batch = [&](int b) {
         if (b >= nt) return;
-        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % kRNF) * kTileBytes + sb * 4 * 1024);
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % NF) * kTileBytes + sb * 4 * 1024);
         const int px0 = dy * W + TPX * ds;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
         if (px0 + TPX <= HW) {
@@ -540,10 +565,10 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         if (dy == H) { dy = 0; ++ds; }
         if (sb == 0) {                                           // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
             // HL: 16 pixels, rows 16 .. 31 repeat rows 0 .. 15 (the producers' lanes r and r + 16 belong to the same pixel)
-            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % kRNF) * kAuxTile);
+            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % NF) * kAuxTile);
             ra_dma16(ars, sa, (px0 + (lane & (TPX - 1))) * kAuxRow, 0);
         } else if (sb == 2) {                                    // Cy row of tile b + 1 (1 KiB from the start of its image row)
-            const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b + 1) % kRNF) * kCyTile);
+            const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b + 1) % NF) * kCyTile);
             ra_dma16_cached(yrs, sy, dy * LP * 4 + lane * 16);
         }
     };
@@ -586,11 +611,11 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
         return cat(tr((v0 ^ ((db & 3) << 6)) + o_), tr((v1 ^ ((db & 3) << 6)) + o_));
     };
     auto pv_begin = [&](int j) {
-        const uint32_t pt = lds0 + Lds::pring + (j & 1) * kPBuf, vt = lds0 + Lds::fring + (j % kRNF) * kTileBytes;
-        const uint32_t at = lds0 + Lds::aring + (j % kRNF) * kAuxTile;
+        const uint32_t pt = lds0 + Lds::pring + (j & 1) * kPBuf, vt = lds0 + Lds::fring + (j % NF) * kTileBytes;
+        const uint32_t at = lds0 + Lds::aring + (j % NF) * kAuxTile;
         p0 = pt + lane_p0, p1 = pt + lane_p1, v0 = vt + lane_v0, v1 = vt + lane_v1, aa = at + lane_a;
         ah[0] = cat(tr(p0), tr(p1));
-        if constexpr (PHL) al[0] = cat(tr(p0 + kPTile), tr(p1 + kPTile));
+        if constexpr (PHL) al[0] = cat(tr(p0 + kPLo), tr(p1 + kPLo));
         af[0] = cat(tr(aa), tr(aa + 4 * kAuxRow));
 #pragma unroll
         for (int u = 0; u < 4; ++u) vf[0][u] = vfrag(0, u);
@@ -604,8 +629,9 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
                 for (int u = 0; u < 4; ++u) vf[(q + 1) & 1][u] = vfrag((q + 1) >> 1, 4 * ((q + 1) & 1) + u);
             }
             if (q == 1) {
-                ah[1] = cat(tr(p0 + 1024), tr(p1 + 1024));
-                if constexpr (PHL && !HL) al[1] = cat(tr(p0 + kPTile + 1024), tr(p1 + kPTile + 1024));
+                if constexpr (HL) ah[1] = ah[0];                 // the lo rows belong to the SAME sixteen pixels: the same probabilities
+                else ah[1] = cat(tr(p0 + 1024), tr(p1 + 1024));
+                if constexpr (PHL && !HL) al[1] = cat(tr(p0 + kPLo + 1024), tr(p1 + kPLo + 1024));
                 if constexpr (!HL) af[1] = cat(tr(aa + 16 * kAuxRow), tr(aa + 20 * kAuxRow));
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -629,7 +655,7 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     // rounding errors average out over the pixel sum) instead of bf16 hi + lo: half the MFMAs on the value side.
     auto convert_batch = [&](int b) {
         if (b >= nt || ABL == 8 || map_f16) return;
-        const uint32_t st = lds0 + Lds::fring + (b % kRNF) * kTileBytes + sb * 4096 + lane * 16;
+        const uint32_t st = lds0 + Lds::fring + (b % NF) * kTileBytes + sb * 4096 + lane * 16;
         u32x4 w_[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w_[i] = *reinterpret_cast<SVPS_LDS const u32x4*>((uintptr_t)(st + i * 1024));
@@ -1526,7 +1552,7 @@ int launch_retr_hl(const void* qh, const void* ql, const float* cy, const float*
     if (workspace_bytes < partial_bytes + stats_bytes) return SVPS_ERR_WORKSPACE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     float* partial = static_cast<float*>(workspace);
-    using Lds = svps::RetrLdsT<2>;
+    using Lds = svps::RetrLdsHL;
     const __bf16* qh_ = static_cast<const __bf16*>(qh);
     const __bf16* ql_ = static_cast<const __bf16*>(ql);
     const __bf16* fh_ = static_cast<const __bf16*>(feat);
