@@ -45,6 +45,17 @@ int svps_probe_mix(const void* src, void* dst, size_t units, int ri, int ro, voi
  * (tools/mfma_feed_probe.py, tools/mfma_sustain_probe.py) */
 int svps_probe_mfma_feed(int mode, int tiles, int nact, int blocks, unsigned long long* out_dev, float* sink_dev, void* stream);
 
+/* svps_probe_mx_fp8: one v_mfma_scale_f32_32x32x64_f8f6f4 (both operands FP8 e4m3) per problem on RAW operand registers - a_regs / b_regs
+ * [n][64 lanes][8 dwords], scale_a / scale_b [n][64] (the scale VGPRs), c_out [n][64][16] fp32 from a zero accumulator: pins the
+ * instruction's lane maps and scale semantics (tools/mx_probe.py) */
+/* svps_probe_cvt_fp8: out[i] = result dword of v_cvt_scalef32_pk_fp8_f16 on the fp16 pair x_pairs[i] with `scale` (bytes 0, 1) */
+int svps_probe_cvt_fp8(const void* x_pairs, float scale, int* out, int n, void* stream);
+/* svps_probe_mx_block: a [32][64], b [32][64] fp16 -> c [64 lanes][16] = a b^T through the in-kernel FP8 conversion (four fp16 k-step
+ * fragments per lane, scale bytes sa / sb [64]) and ONE scaled MFMA - the building block of retr_stats_hl.hip's F8 form; regs_out [64][16]:
+ * the operand registers as converted */
+int svps_probe_mx_block(const void* a, const void* b, const void* sa, const void* sb, float* c_out, int* regs_out, void* stream);
+int svps_probe_mx_fp8(const void* a_regs, const void* b_regs, const void* scale_a, const void* scale_b, float* c_out, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,6 +110,9 @@ DIAG_SIGNATURES = {
     "svps_probe_copy": (_i, [_vp, _vp, _sz, _vp]),
     "svps_probe_mix": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
     "svps_probe_mfma_feed": (_i, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "svps_probe_cvt_fp8": (_i, [_vp, _f, _vp, _i, _vp]),
+    "svps_probe_mx_block": (_i, [_vp] * 7),
+    "svps_probe_mx_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 
 _lib = None

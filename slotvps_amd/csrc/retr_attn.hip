@@ -39,6 +39,9 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
 typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+#ifndef SVPS_RETR_HL_PREFETCH
+#define SVPS_RETR_HL_PREFETCH 3     // HL form: tiles requested ahead (4 fits the LDS since the sixteen-row P tiles of round 6)
+#endif
 #ifndef SVPS_RETR_PREFETCH
 #define SVPS_RETR_PREFETCH 3        // tiles requested ahead (tools/variants.sh retr_attn SVPS_RETR_PREFETCH 2 3 4)
 #endif
@@ -69,12 +72,14 @@ using RetrLds = RetrLdsT<1>;
 static_assert(RetrLds::pring % 512 == 0 && RetrLds::total <= 160 * 1024 && RetrLdsT<2>::total <= 160 * 1024, "LDS layout");
 // HL form (round 6): a tile is sixteen pixels, so a P tile has sixteen rows per slot block - the hi rows at sb * 2 KiB + row * 64, the lo
 // rows in the other half of the block (+ 1 KiB): ONE 8-KiB tile per buffer instead of two with duplicated rows (round 5 wrote every row
-// twice so that the consumers' lo k-step could read rows 16 .. 31: it now re-uses the fragment of k-step 0). The 16 KiB this frees hold a
-// SEVENTH ring stage: the producers' softmax head runs one tile later (in the shadow of the next tile's chain, see retr_attn_kernel), the
-// consumers therefore three tiles behind the chain, with three batches still in flight ahead of it.
+// twice so that the consumers' lo k-step could read rows 16 .. 31: it now re-uses the fragment of k-step 0). The 16 KiB this frees were
+// tried as a SEVENTH ring stage for a pipelined producer schedule (the softmax head of tile it-1 in the shadow of chain(it), the consumers
+// three tiles behind): correct, and 3.7 % SLOWER on the same box (2 165 against 2 090 us, finest level, T = 40) - what bounds the
+// kernel is the matrix pipe shared by a producer and a consumer wave per SIMD (58 MFMAs x 32 cycles = 1 856 of ~2 840 cycles per tile), not the
+// head's latency; archived as profiles/r06/k1hl_pipelined_head_experiment.patch with its stamps (profiles/r06/README.md).
 struct RetrLdsHL {
-    static constexpr int kA = kRPrefetch;                       // batches requested ahead
-    static constexpr int kNF = kRPrefetch + 4;                  // tiles it-3 .. it+3 are live in iteration it
+    static constexpr int kA = SVPS_RETR_HL_PREFETCH;            // batches requested ahead
+    static constexpr int kNF = SVPS_RETR_HL_PREFETCH + 3;       // tiles it-2 .. it+A are live in iteration it
     static constexpr int kPBufBytes = kPTile;
     static constexpr int kPLo = 1024;                           // lo rows of a slot block: behind its sixteen hi rows
     static constexpr int fring = 0;
@@ -196,8 +201,6 @@ __global__ __launch_bounds__(512) void retr_attn_kernel(
     using Lds = std::conditional_t<HL, RetrLdsHL, RetrLdsT<PHL ? 2 : 1>>;
     constexpr int A = Lds::kA;
     constexpr int NF = Lds::kNF;                                // ring depth (feature / aux / Cy tiles)
-    constexpr bool PIPE = HL;                                   // the softmax head of a tile runs one iteration behind its chain (see the producer)
-    constexpr int LAG = PIPE ? 3 : 2;                           // the consumers' distance behind the chain
     constexpr int TPX = HL ? 16 : kTilePx;                      // pixels per tile
     constexpr int kPBuf = Lds::kPBufBytes;                      // one P buffer: the hi tile (and the lo tile behind it / in its blocks' upper halves)
     constexpr int kPLo = Lds::kPLo;

@@ -287,14 +287,18 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
                 fl[(ks + 2) % 3] = frag(xl, ks + 2);
             }
             constexpr bool kVLo = KEY || !(SVPS_SHL_EXP & 1);      // EXPERIMENT bit 0: the value statistic without its R_lo x_hi term
+            // bits 1 / 2 (round 6): the value / key statistic without its R_hi x_lo term - the MAP's low part, an error that is independent
+            // from pixel to pixel. Measured WORSE than bit 0 (mask logits T5 9.5e-6 -> 4.1e-5, VIPER T10 7.7e-5; both: 1.0e-4): at the coarse
+            // levels a slot owns ~20 pixels, nothing averages out (profiles/r06/README.md)
+            constexpr bool kXLo = KEY ? !(SVPS_SHL_EXP & 4) : !(SVPS_SHL_EXP & 2);
             if (ks >= KA && !(SVPS_SHL_ABL & 2)) {
                 if (kVLo) ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wla[ks - KA], fh[ks % 3], ca, 0, 0, 0);
-                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fl[ks % 3], ca, 0, 0, 0);
+                if (kXLo) ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fl[ks % 3], ca, 0, 0, 0);
                 ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fh[ks % 3], ca, 0, 0, 0);
             }
             if (ks >= KB && !(SVPS_SHL_ABL & 2)) {
                 if (kVLo) cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlb[ks - KB], fh[ks % 3], cb, 0, 0, 0);
-                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fl[ks % 3], cb, 0, 0, 0);
+                if (kXLo) cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fl[ks % 3], cb, 0, 0, 0);
                 cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fh[ks % 3], cb, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
