@@ -40,7 +40,7 @@ typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
 typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 #ifndef SVPS_RETR_HL_PREFETCH
-#define SVPS_RETR_HL_PREFETCH 3     // HL form: tiles requested ahead (4 fits the LDS since the sixteen-row P tiles of round 6)
+#define SVPS_RETR_HL_PREFETCH 4     // HL form: tiles requested ahead (4 fits the LDS since the sixteen-row P tiles of round 6)
 #endif
 #ifndef SVPS_RETR_PREFETCH
 #define SVPS_RETR_PREFETCH 3        // tiles requested ahead (tools/variants.sh retr_attn SVPS_RETR_PREFETCH 2 3 4)

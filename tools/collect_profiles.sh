@@ -4,7 +4,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 V=${1:-r05a}
-PARTS=${PARTS:-"1 2 3 4 7 8 5 6"}
+PARTS=${PARTS:-"1 2 3 4 7 8 5 6 9"}
 O=$R/gpurun_out/$V
 mkdir -p $O
 cd $R
@@ -20,7 +20,8 @@ has 7 && { echo "[7a] SQ counters a"; timeout -k 10 200 rocprofv3 --kernel-trace
 has 8 && { echo "[8] mode bf16 (round 4's headline definition): kernel stats"; timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/stats_bf16 -o b --output-format csv -- python3 $R/bench.py --mode bf16 $LEGS --no-graph --steps 5 --warmup 2 > $O/bench_bf16_under_rocprof_$V.json 2> $O/stats_bf16.err || echo "bf16 stats rc $?"; }
 cd $R
 has 5 && { echo "[5] viper"; timeout -k 10 200 python3 bench.py --height 1088 --width 1920 --frames 10 --slots 200 --num-classes 24 --clips-per-launch 8 --steps 6 --warmup 2 $LEGS > $O/bench_viper_$V.json 2> $O/viper.err || echo "viper rc $?"; }
-has 6 && { echo "[6] e2e"; for c in r50_fpn_slotvps_mi355x swinL_fpn_slotvps_mi355x viper_r50_slotvps_mi355x; do timeout -k 10 200 python3 tools/detector_e2e.py --config configs/$c.py >> $O/whole_detector_configs.jsonl 2>> $O/e2e.err; echo "e2e $c done"; done; }
+has 9 && { echo "[9] bench --legs all"; timeout -k 10 900 python3 bench.py --legs all > $O/bench_all_legs_$V.json 2> $O/bench_all_legs_$V.err || echo "bench all rc $?"; }
+has 6 && { echo "[6] e2e (the configs' own head mode fp16x2, then bf16)"; for c in r50_fpn_slotvps_mi355x; do timeout -k 10 200 python3 tools/detector_e2e.py --config configs/$c.py --mode bf16 >> $O/whole_detector_configs_mode_bf16.jsonl 2>> $O/e2e.err; done; for c in r50_fpn_slotvps_mi355x swinL_fpn_slotvps_mi355x viper_r50_slotvps_mi355x; do timeout -k 10 200 python3 tools/detector_e2e.py --config configs/$c.py >> $O/whole_detector_configs.jsonl 2>> $O/e2e.err; echo "e2e $c done"; done; }
 has 3 && has 4 && { python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json "1024x2048 T=5 L=100 cpl=32" fp16x2 > $O/pmc_traffic.log 2>&1; cat $O/pmc_traffic.log; }
 has 7 && { python3 tools/sq_counters.py $O/sq_a $O/sq_b $O/sq_counters.json > $O/sq_counters.log 2>&1; cat $O/sq_counters.log; }
 # keep the merge-back small: the raw counter CSVs are large

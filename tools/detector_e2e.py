@@ -17,14 +17,17 @@ ap.add_argument("--frames", type=int, default=0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--profile-tower", type=int, default=0)
-ap.add_argument("--mode", "--map-dtype", dest="map_dtype", default="bf16", help="head mode (MultiScaleDynamicMaskHead.MODES): bf16, fp16, fp16x2, fp32")
+ap.add_argument("--mode", "--map-dtype", dest="map_dtype", default=None,
+                help="head mode (MultiScaleDynamicMaskHead.MODES): fp16x2, fp32, bf16, fp16; default: the config's own (fp16x2)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = Config.fromfile(a.config)
 torch.manual_seed(0)
 det = build_detector(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg).to(dev).eval()
 det.use_graph = bool(a.graph)
-det.image_model.dynamic_mask_head.set_mode(a.map_dtype)
+if a.map_dtype is not None:
+    det.image_model.dynamic_mask_head.set_mode(a.map_dtype)
+a.map_dtype = det.image_model.dynamic_mask_head.mode
 T = a.frames or cfg.clip["frames"]
 H, W = cfg.clip["height"], cfg.clip["width"]
 L = det.image_model.init_mask_query.weight.shape[0]
