@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "retr_common.h"
 #include "../../include/slotvps_hip.h"
 
 namespace svps {
@@ -47,13 +48,6 @@ typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #endif
 constexpr int kRPrefetch = SVPS_RETR_PREFETCH;
 constexpr int kRNF = kRPrefetch + 3;       // feature / aux / Cy ring depth: tiles it-2 .. it+3 are live in iteration it
-constexpr int kAuxRow = 16;                // bytes per pixel of the aux tensor (retr_stats.hip)
-constexpr int kAuxTile = 1024;             // LDS per staged aux tile: 512 B of rows (+ 512 B the upper half of the DMA instruction repeats)
-constexpr int kPTile = 8192;               // P tile: 128 slots x 32 pixels fp16
-constexpr int kCyTile = 1024;              // one LDS-DMA piece: the Cy row of the tile's image row (LP = 128: and the next row)
-constexpr int kPartRow = 260;              // floats per slot row of a partial: 256 channels of A + 4 aux columns (every byte of a partial is written)
-constexpr int kExtRow = 272;               // floats per slot row of the finished result: 17 k-steps of 16 for the slot-side product
-
 template <int PT>    // PT = 1: P * rstd_v as one fp16 tile; 2: hi and lo tiles (the precision form, retr_attn_kernel<.., PHL = true>)
 struct RetrLdsT {
     static constexpr int kA = kRPrefetch;
@@ -91,52 +85,6 @@ struct RetrLdsHL {
     static constexpr int total = c3 + 128 * 4;
 };
 static_assert(RetrLdsHL::pring % 512 == 0 && RetrLdsHL::total <= 160 * 1024, "LDS layout");
-
-__device__ __forceinline__ u32x4 ra_make_srd(const void* base, uint32_t bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(base);
-    u32x4 d;
-    d[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
-    d[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
-    d[2] = __builtin_amdgcn_readfirstlane(bytes);
-    d[3] = 0x00020000u;
-    return d;
-}
-
-// asm LDS-DMA with the non-temporal hint (the map is read once per launch); see slot_attn.hip for why this is asm
-__device__ __forceinline__ void ra_dma16(u32x4 srd, uint32_t lds_addr, int voff, int soff) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen nt lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds_addr), "v"(voff), "s"(srd), "s"(soff)
-        : "memory");
-}
-// the same without the hint: the Cy rows are re-read by every workgroup of the frame (L2-resident)
-__device__ __forceinline__ void ra_dma16_cached(u32x4 srd, uint32_t lds_addr, int voff) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds_addr), "v"(voff), "s"(srd)
-        : "memory");
-}
-
-__device__ __forceinline__ float ra_half_swap_max(float x) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float ra_half_swap_sum(float x) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 #ifdef SVPS_RETR_STAMP
 // diagnostic build only (tools/retr_stamps.py): s_memtime stamps of one workgroup's producer 0 and consumer 0, iterations
@@ -1429,10 +1377,10 @@ struct RetrPlan {
     int chunks, tiles_per_chunk;
 };
 // retriever: tiles of 32 pixels inside an image row, walked strip by strip (retr_attn_kernel)
-RetrPlan plan_retr(int T, int H, int W, int chunks_req, int tpx = svps::kTilePx) {
+RetrPlan plan_retr(int T, int H, int W, int chunks_req, int tpx = svps::kTilePx, int min_tiles = 64) {
     const int tiles = ((W + tpx - 1) / tpx) * H;
     int chunks = chunks_req;
-    if (chunks <= 0) chunks = svps_pick_chunks(T, tiles, svps_num_cus(), 64);
+    if (chunks <= 0) chunks = svps_pick_chunks(T, tiles, svps_num_cus(), min_tiles);
     if (chunks > tiles) chunks = tiles;
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
@@ -1542,6 +1490,14 @@ extern "C" int svps_retr_attn_fwd(const void* qh, const void* ql, const float* c
 // (retr_logit_stats_kernel<true>: 8 B per pixel into the workspace), then the retriever once per half of the slots with those statistics
 // (retr_attn_kernel<0, true, true, true>) - every logit is computed twice, nothing of size [L, HW] passes through HBM.
 namespace {
+// round 6: 32-pixel tiles (retr_attn_hl32.hip) unless SVPS_K1_HL16 asks for the sixteen-pixel form of round 5 (comparison runs)
+bool retr_hl16() {
+    static const bool v = getenv("SVPS_K1_HL16") != nullptr;
+    return v;
+}
+RetrPlan plan_retr_hl(int T, int H, int W, int chunks) {
+    return retr_hl16() ? plan_retr(T, H, W, chunks, 16) : plan_retr(T, H, W, chunks, svps::kRetrHl32TilePx, 32);
+}
 int launch_retr_hl(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3, const void* feat,
                    const void* feat_lo, const void* aux, void* workspace, size_t workspace_bytes, float* out_ext, int T, int L,
                    int H, int W, int D, int chunks, void* stream_) {
@@ -1549,7 +1505,7 @@ int launch_retr_hl(const void* qh, const void* ql, const float* cy, const float*
     if (D != svps::kD || T <= 0 || L <= 0 || L > 256 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
     if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
     const int HW = H * W;
-    const RetrPlan p = plan_retr(T, H, W, chunks, 16);
+    const RetrPlan p = plan_retr_hl(T, H, W, chunks);
     const size_t partial_bytes = (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float);
     const size_t stats_bytes = L > 128 ? (size_t)T * HW * sizeof(float2) : 0;
     if (workspace_bytes < partial_bytes + stats_bytes) return SVPS_ERR_WORKSPACE;
@@ -1563,7 +1519,27 @@ int launch_retr_hl(const void* qh, const void* ql, const float* cy, const float*
     const __bf16* a_ = static_cast<const __bf16*>(aux);
     hipError_t e;
     svps_prof_mark(SVPS_KERNEL_RETR_ATTN, 0, stream);
-    if (L <= 128) {
+    if (!retr_hl16()) {
+        if (L <= 128) {
+            e = (hipError_t)svps::retr_attn_hl32_launch(qh, ql, cy, cx, c3, feat, feat_lo, aux, partial, T, L, H, W, p.chunks, p.tiles_per_chunk,
+                                                        128, L, 0, nullptr, stream_);
+        } else {
+            float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);     // partial_bytes is a multiple of 16
+            const RetrPlan pl = plan_retr(T, H, W, 0, 16);
+            auto kstat = svps::retr_logit_stats_kernel<true>;
+            static SvpsLdsAttr attr_s;
+            if (hipError_t ae = attr_s.ensure(reinterpret_cast<const void*>(kstat), svps::LStatsLds::total); ae != hipSuccess) return (int)ae;
+            hipLaunchKernelGGL(kstat, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream, static_cast<const _Float16*>(qh),
+                               static_cast<const _Float16*>(ql), cy, cx, c3, fh_, a_, st, L, HW, H, W, pl.tiles_per_chunk, 1, fl_);
+            e = hipGetLastError();
+            if (e != hipSuccess) return (int)e;
+            e = (hipError_t)svps::retr_attn_hl32_launch(qh, ql, cy, cx, c3, feat, feat_lo, aux, partial, T, 128, H, W, p.chunks,
+                                                        p.tiles_per_chunk, 256, L, 0, st, stream_);
+            if (e != hipSuccess) return (int)e;
+            e = (hipError_t)svps::retr_attn_hl32_launch(qh, ql, cy, cx, c3, feat, feat_lo, aux, partial, T, L - 128, H, W, p.chunks,
+                                                        p.tiles_per_chunk, 256, L, 128, st, stream_);
+        }
+    } else if (L <= 128) {
         auto kern = svps::retr_attn_kernel<0, false, true, true>;
         int slot = 0;
 #ifdef SVPS_RETR_ABLATE
@@ -1610,7 +1586,7 @@ int launch_retr_hl(const void* qh, const void* ql, const float* cy, const float*
 
 extern "C" size_t svps_retr_attn_hl_workspace_bytes(int T, int L, int H, int W, int chunks) {
     if (T <= 0 || L <= 0 || L > 256 || H <= 0 || W <= 0) return 0;
-    const RetrPlan p = plan_retr(T, H, W, chunks, 16);
+    const RetrPlan p = plan_retr_hl(T, H, W, chunks);
     return (size_t)T * p.chunks * L * svps::kPartRow * sizeof(float) + (L > 128 ? (size_t)T * H * W * sizeof(float2) : 0);
 }
 

@@ -1,0 +1,468 @@
+// K1'-HL32 - the statistics-fused retriever (retr_attn.hip; MaskDynamicConv.forward, mmdet/models/detectors/dynamic_mask_head.py:423-461)
+// in the reference's precision on THIRTY-TWO-pixel tiles (round 6).
+//
+// The level map is two fp16 planes (f = hi + lo to 22 bits). The first hi / lo form (retr_attn_kernel<.., HL = true>) kept the 16-KiB
+// ring stage of the 16-bit kernels and put sixteen pixels into it - hi rows 0 .. 15, lo rows 16 .. 31 - so that one B fragment carries
+// [f_hi | f_lo] of the same pixels. That costs the producers a quarter of their matrix work (Q''_lo . f_lo comes out with Q''_lo . f_hi
+// and is worth nothing), a register fold behind every chain, and every per-tile cost (barrier, landing wait, softmax exchange, position
+// rows) once per sixteen pixels. Here a ring stage is a hi tile AND a lo tile of the same 32 pixels (32 KiB), as mask_decode_hl32_kernel
+// does it:
+//   producers   s += Q''_lo f_hi + Q''_hi f_lo + Q''_hi f_hi : 48 MFMAs per 32 pixels (64 before), accumulator columns = pixels, no fold;
+//               the softmax head works on 16 registers per lane as in the 16-bit form
+//   consumers   A += P_lo f_hi + P_hi f_lo + P_hi f_hi (+ the aux block): 52 MFMAs per 32 pixels (as before), P tiles of 32 pixel rows
+// Four stages of 32 KiB leave no room for a second P buffer and a third live stage, so the schedule changes with the tile: the consumers
+// run ONE tile behind the producers (not two) and a tile has TWO workgroup barriers (the same number per pixel as before):
+//
+//   producer, iteration it:   chain(it) | softmax head(it) -> stats | B1(it) | finish(it): factor, P(it) -> LDS; first fragments of it+1 | B2(it)
+//   consumer, iteration it:   P(it-1) fragments; LDS-DMA of batch it+2; A += P(it-1) f(it-1), first part | landing wait of batch it+1 | B1(it)
+//                             | rest of A += P(it-1) f(it-1) | B2(it)
+//
+// P and the statistics are single-buffered: P(it) is written between B1(it) and B2(it) and read (into registers, at once) after B2(it);
+// stage (it+2) % 4 was last read by the consumers before B2(it-1). Everything else - tile walk down 32-pixel column strips, Cx in
+// registers per strip, Cy rows / aux rows / feature tiles by LDS-DMA, swizzled 512-B pixel rows, transposed value fragments, the aux
+// block, partials summed in fixed order by retr_finish_kernel - is the scheme of retr_attn.hip, whose comments carry the derivation.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "retr_common.h"
+#include "../../include/slotvps_hip.h"
+
+namespace svps {
+
+typedef __attribute__((ext_vector_type(2))) __fp16 fp16x2_t;
+typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+#ifndef SVPS_RETR_HL32_PREFETCH
+#define SVPS_RETR_HL32_PREFETCH 2
+#endif
+#ifndef SVPS_RETR_HL32_SPLIT
+#define SVPS_RETR_HL32_SPLIT 6      // consumer steps (of 8) in front of B1
+#endif
+
+struct RetrLdsHL32 {
+    static constexpr int kA = SVPS_RETR_HL32_PREFETCH;         // batches requested ahead
+    static constexpr int kNF = kA + 2;                          // tiles it-1 .. it+A are live in iteration it
+    static constexpr int kStage = 2 * kTileBytes;               // hi tile, lo tile
+    static constexpr int fring = 0;
+    static constexpr int aring = kNF * kStage;
+    static constexpr int yring = aring + kNF * kAuxTile;
+    static constexpr int pring = yring + kNF * kCyTile;         // P hi [8 KiB], P lo [8 KiB]: slot block sb at sb * 2 KiB, 32 pixel rows of 64 B
+    static constexpr int stats = pring + 2 * kPTile;            // [4][32] float2
+    static constexpr int c3 = stats + 4 * 32 * 8;               // [128] float
+    static constexpr int total = c3 + 128 * 4;
+};
+static_assert(RetrLdsHL32::pring % 512 == 0 && RetrLdsHL32::total <= 160 * 1024, "LDS layout");
+
+// ABL: timing-only ablations (diagnostic builds), outputs wrong. 1: DMA + barriers only  2: producers only  4: consumers only
+template <int ABL, bool EXT>
+__global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
+    const _Float16* __restrict__ qh,    // [T, LP, 256]  hi(Q''), rows >= the real slot count zero
+    const _Float16* __restrict__ ql,    // [T, LP, 256]  lo(Q'')
+    const float* __restrict__ cy,       // [T, H, LP]
+    const float* __restrict__ cx,       // [T, W, LP]
+    const float* __restrict__ c3g,      // [T, LP]
+    const _Float16* __restrict__ feat,  // [T, HW, 256] hi plane
+    const _Float16* __restrict__ feat_lo,
+    const _Float16* __restrict__ aux,   // [T, HW, 8]
+    float* __restrict__ partial,        // [T, C, Lrow, 260]
+    int L, int HW, int H, int W, int tiles_per_chunk, int LP, int Lrow, int slot_off, const float2* __restrict__ ext_stats) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    using Lds = RetrLdsHL32;
+    constexpr int A = Lds::kA;
+    constexpr int NF = Lds::kNF;
+    constexpr int TPX = 32;
+    constexpr int kPLo = kPTile;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sb = w & 3;
+    const bool consumer = w >= 4;
+    const int r = lane & 31, h = lane >> 5;
+    const int C = gridDim.x;
+    int t = blockIdx.y, c = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {                                 // XCD-aware frame placement (retr_attn.hip)
+        const int b = blockIdx.y * C + blockIdx.x;
+        const int n = b >> 3;
+        t = (b & 7) + 8 * (n / C);
+        c = n % C;
+    }
+    const int tiles = ((W + TPX - 1) / TPX) * H;
+    const int tid0 = c * tiles_per_chunk;
+    int nt = tiles - tid0;
+    nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;           // >= 1 by construction of the grid
+    const int strip0 = tid0 / H, row0 = tid0 - strip0 * H;
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+
+    float* c3l = reinterpret_cast<float*>(smem + Lds::c3);
+    if (threadIdx.x < 128) c3l[threadIdx.x] = c3g[(size_t)t * LP + slot_off + threadIdx.x];
+
+    if (!consumer) {
+        // ================================ producer =============================================
+        f16x8 qfh[16], qfl[16];
+        {
+            const size_t row = ((size_t)t * LP + slot_off + 32 * sb + r) * kD + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                qfh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
+                qfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
+            }
+        }
+        const int slot0 = 32 * sb + 4 * h;                          // accumulator register 4 g + j <-> slot row slot0 + 8 g + j
+        const int key = (r >> 1) & 3;
+        const uint32_t lane_row = lds0 + Lds::fring + r * kRowBytes + ((h ^ swz(r)) << 4);
+        auto uniform_rsrc = [](const void* p, int bytes) {
+            const uint64_t a = reinterpret_cast<uint64_t>(p);
+            const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+            return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * LP + slot_off, H * LP * 4 - slot_off * 4);
+        const __amdgpu_buffer_rsrc_t cxr = uniform_rsrc(cx + (size_t)t * W * LP + slot_off, W * LP * 4 - slot_off * 4);
+        const __amdgpu_buffer_rsrc_t exr = uniform_rsrc(EXT ? (const void*)(ext_stats + (size_t)t * HW) : (const void*)cy, EXT ? HW * 8 : 0);
+
+        // Cx of this lane's pixel column: constant down a strip (clamped past the right edge: those pixels are masked); added BEHIND the
+        // chain - the accumulator starts from the Cy row alone, read from LDS when the chain starts (no register copy of Cy + Cx)
+        f32x4 cxv[4];
+        auto load_cx = [&](int strip) {
+            int xx = TPX * strip + r;
+            xx = xx < W ? xx : W - 1;
+            const int xo = (xx * LP + slot0) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) cxv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cxr, xo + 32 * g, 0, 0));
+        };
+        int ts = strip0, ty = row0;                                 // strip / image row of tile `it`
+        f32x2 ext_n = {0.f, 0.f};                                   // EXT: statistics of this lane's pixel, requested one tile ahead
+        auto request_ext = [&](int strip, int row) {
+            if constexpr (EXT) {
+                int px = row * W + TPX * strip + r;
+                px = px < HW ? px : HW - 1;
+                ext_n = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(exr, px * 8, 0, 0));
+            }
+        };
+        load_cx(ts);
+        f32x16 s;                                                   // tile 0: its Cy row straight from global memory
+        {
+            const int yo = (ty * LP + slot0) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 cyv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j];
+            }
+        }
+        request_ext(ts, ty);
+        float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+
+        // LDS byte address of this lane's 16-B chunk of k-step ks = 8 a + b in a tile: (tile + lane_row) ^ (b << 5), + 256 a; lo tile + 16 KiB
+        auto frag = [&](uint32_t tb, int ks) {
+            return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
+        };
+        // fragment group g: k-steps g and g + 8 of the hi tile, then of the lo tile (one address, four immediate offsets)
+        f16x8 kf[2][4];
+        auto load_grp = [&](int buf, uint32_t tb, int g) {
+            kf[buf][0] = frag(tb, g);
+            kf[buf][1] = frag(tb, g + 8);
+            kf[buf][2] = frag(tb + kTileBytes, g);
+            kf[buf][3] = frag(tb + kTileBytes, g + 8);
+        };
+        f32x2 rt = {0.f, 0.f};
+        auto prefetch = [&](int tile) {                             // first fragment group and (rstd_k, rstd_v) of a tile
+            const uint32_t slot = (uint32_t)(tile % NF);
+            load_grp(0, lane_row + slot * Lds::kStage, 0);
+            rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + slot * kAuxTile + r * kAuxRow + 8));
+        };
+
+        constexpr bool kRun = ABL != 1 && ABL != 4;
+        wg_barrier();                                               // B(start): batch 0 landed
+        if constexpr (kRun) prefetch(0);
+        for (int it = 0; it < nt; ++it) {
+            float fac = 0.f;
+            const bool more = it + 1 < nt;
+            if constexpr (kRun) {
+                const uint32_t tb = lane_row + (uint32_t)(it % NF) * Lds::kStage;
+                f32x4 c3v[4];
+                const float rk_c = rt[0] * kLog2e, tau_c = rt[1] * kPScale;      // common.h: the probabilities carry 2^7
+                // ---- chain: eight groups of two k-steps, three MFMAs per k-step; the reads of group g + 1 in the shadow of group g
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    if (g < 7) {
+                        load_grp((g + 1) & 1, tb, g + 1);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) c3v[q] = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * q);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int ks = g + 8 * u;
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[ks], kf[g & 1][u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[g & 1][2 + u], s, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[g & 1][u], s, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- softmax head: log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no
+                // masking: their Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep): they exp2 to exactly 0
+                const bool live = TPX * ts + r < W;
+                ++ty;
+                float mloc = kNegBig;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        s[4 * g + j] = fmaf(rk_c, s[4 * g + j] + cxv[g][j], c3v[g][j]);
+                        if constexpr (!EXT) mloc = fmaxf(mloc, s[4 * g + j]);
+                    }
+                }
+                if (ty == H) { ty = 0; ++ts; if (more) load_cx(ts); }
+                const f32x2 ext_c = ext_n;
+                if constexpr (EXT) mloc = ext_c[0];                 // statistics over all slots are known (log2 domain as well)
+                else mloc = ra_half_swap_max(mloc);
+                if (more) request_ext(ts, ty);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] -= mloc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i]);
+                if constexpr (!EXT) {
+                    float sl[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sl[i] = (s[i] + s[4 + i]) + (s[8 + i] + s[12 + i]);
+                    float sloc = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+                    sloc = ra_half_swap_sum(sloc);
+                    if (h == 0) stats[sb * 32 + r] = make_float2(mloc, sloc);
+                    wg_barrier();                                   // B1(it)
+                    float2 st_w[4];
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) st_w[ww] = stats[ww * 32 + r];
+                    float mall = kNegBig;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) mall = fmaxf(mall, st_w[ww].x);
+                    float den = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < 4; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
+                    fac = __builtin_amdgcn_exp2f(mloc - mall) * __builtin_amdgcn_rcpf(den) * tau_c;
+                } else {
+                    wg_barrier();                                   // B1(it)
+                    fac = ext_c[1] * tau_c;
+                }
+                if (!live) fac = 0.f;                               // pixels past the right edge of the map
+                // ---- finish: P(it) = e * fac as fp16 hi + lo into the P tiles (row = pixel r, 64 B = 32 slots of this block)
+                char* prow = smem + Lds::pring + sb * 2048 + r * 64 + 8 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = s[4 * g + j] * fac;
+                        asm volatile("" : "+v"(x));                 // ONE fp32 value for both halves (retr_attn.hip)
+                        ph[j] = (_Float16)x;
+                        pl[j] = (_Float16)(x - (float)ph[j]);
+                    }
+                    *reinterpret_cast<f16x4*>(prow + ((g ^ key) * 16)) = ph;
+                    *reinterpret_cast<f16x4*>(prow + kPLo + ((g ^ key) * 16)) = pl;
+                }
+                // ---- next tile: its Cy row (staged with batch `it`) starts the accumulator; first fragment group (batch it+1 landed before B1)
+                if (more) {
+                    const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + ((it + 1) % NF) * kCyTile) + slot_off + slot0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 cyv = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j];
+                    }
+                    prefetch(it + 1);
+                }
+            } else {
+                wg_barrier();                                       // B1(it)
+            }
+            wg_barrier();                                           // B2(it)
+        }
+        return;
+    }
+
+    // =================================== consumer ===============================================
+    // waves 0, 1 stage the hi tile (sixteen rows each), waves 2, 3 the lo tile
+    const int pl_ = sb >> 1, rb = 16 * (sb & 1);
+    const u32x4 frs = ra_make_srd((pl_ ? feat_lo : feat) + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 ars = ra_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * kAuxRow);
+    const u32x4 yrs = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
+    int voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = rb + 2 * i + h;                          // row of the LDS tile
+        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+    }
+    const int nb = 8 + ((sb == 0 || sb == 2) ? 1 : 0);           // DMA instructions of one batch of this wave
+    int ds = strip0, dy = row0;                                  // strip / image row of the next batch
+    auto issue_batch = [&](int b) {
+        if (b >= nt) return;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % NF) * Lds::kStage + pl_ * kTileBytes + rb * kRowBytes);
+        const int px0 = dy * W + TPX * ds;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + TPX <= HW) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ra_dma16(frs, st + i * 1024, voff[i], soff);
+        } else {                                                 // last row of a ragged strip: clamp the source rows (their P is 0)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = rb + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+            }
+        }
+        ++dy;
+        if (dy == H) { dy = 0; ++ds; }
+        if (sb == 0) {                                           // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
+            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % NF) * kAuxTile);
+            ra_dma16(ars, sa, (px0 + (lane & 31)) * kAuxRow, 0);
+        } else if (sb == 2) {                                    // Cy row of tile b + 1 (1 KiB from the start of its image row)
+            const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b + 1) % NF) * kCyTile);
+            ra_dma16_cached(yrs, sy, dy * LP * 4 + lane * 16);
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < A; ++b) issue_batch(b);
+
+    f32x16 o[8], oa;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        oa[i] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[db][i] = 0.f;
+    }
+    // Fragment addresses as in retr_attn.hip:
+    //   value  V[pixels 16 ks + 8 h' .. + 8][channel 32 db + n]: vt + 8192 ks + 256 (db >> 2) + (lane_v{0,1} ^ ((db & 3) << 6)); lo tile + 16 KiB
+    //   P      rows rowl (+4) of 64 B, chunk cl ^ ((row >> 1) & 3): pt + 1024 ks + lane_p{0,1}; lo + 8 KiB
+    //   aux    rows rowl (+4) of 16 B, linear: at + 256 ks + lane_a
+    const int g2 = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int cl = 2 * (g2 & 1) + (pp >> 1), sub = 8 * (pp & 1), rowl = 8 * (g2 >> 1) + qq;
+    const uint32_t lane_v0 = rowl * kRowBytes + (((cl ^ (2 * (g2 >> 1))) + 4 * qq) << 4) + sub;
+    const uint32_t lane_v1 = (rowl + 4) * kRowBytes + (((cl ^ (2 * (g2 >> 1) + 1)) + 4 * qq) << 4) + sub;
+    const uint32_t p0 = lds0 + Lds::pring + sb * 2048 + sub + rowl * 64 + ((cl ^ (qq >> 1)) << 4);
+    const uint32_t p1 = lds0 + Lds::pring + sb * 2048 + sub + (rowl + 4) * 64 + ((cl ^ (qq >> 1) ^ 2) << 4);
+    const uint32_t lane_a = rowl * kAuxRow + ((cl == 0 && sub != 0) ? 8 : 0);
+    auto tr = [](uint32_t a) {
+        return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(reinterpret_cast<SVPS_LDS fp16x4_gcc*>((uintptr_t)a)));
+    };
+    auto cat = [](f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); };
+    f16x8 ah[2], al[2], af[2], vh[2][2], vl[2][2];
+    uint32_t v0 = 0, v1 = 0;
+    auto vfrag = [&](int lo, int ks, int db) {
+        const uint32_t o_ = kTileBytes * lo + 8192 * ks + 256 * (db >> 2);
+        return cat(tr((v0 ^ ((db & 3) << 6)) + o_), tr((v1 ^ ((db & 3) << 6)) + o_));
+    };
+    auto load_step = [&](int buf, int q) {                       // step q = (k-step q >> 2, channel blocks 2 (q & 3), + 1)
+        const int ks = q >> 2, db = 2 * (q & 3);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            vh[buf][u] = vfrag(0, ks, db + u);
+            vl[buf][u] = vfrag(1, ks, db + u);
+        }
+    };
+    auto pv_begin = [&](int j) {                                 // every fragment of P(j) (the P tiles are free again at B1), the aux rows, step 0
+        const uint32_t vt = lds0 + Lds::fring + (j % NF) * Lds::kStage;
+        const uint32_t aa = lds0 + Lds::aring + (j % NF) * kAuxTile + lane_a;
+        v0 = vt + lane_v0, v1 = vt + lane_v1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            ah[ks] = cat(tr(p0 + 1024 * ks), tr(p1 + 1024 * ks));
+            al[ks] = cat(tr(p0 + kPLo + 1024 * ks), tr(p1 + kPLo + 1024 * ks));
+            af[ks] = cat(tr(aa + 16 * ks * kAuxRow), tr(aa + (16 * ks + 4) * kAuxRow));
+        }
+        load_step(0, 0);
+    };
+    auto pv_steps = [&](auto lo_tag, auto hi_tag) {              // steps [Q0, Q1) of A += P f: six MFMAs each (+ two of the aux block per k-step)
+        constexpr int Q0 = decltype(lo_tag)::value, Q1 = decltype(hi_tag)::value;
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) {
+            const int ks = q >> 2, db = 2 * (q & 3);
+            if (q < 7) load_step((q + 1) & 1, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], vh[q & 1][u], o[db + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vl[q & 1][u], o[db + u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vh[q & 1][u], o[db + u], 0, 0, 0);
+            if ((q & 3) == 0) {
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], af[ks], oa, 0, 0, 0);
+                oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], af[ks], oa, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    constexpr int kSplit = SVPS_RETR_HL32_SPLIT;
+    using I0 = std::integral_constant<int, 0>;
+    using IS = std::integral_constant<int, kSplit>;
+    using I8 = std::integral_constant<int, 8>;
+    constexpr bool kWork = ABL != 1 && ABL != 2;
+
+    if (A - 1 < nt) wait_vm_dyn(nb * (A - 1));                   // batch 0 landed
+    else wait_vm<0>();
+    wg_barrier();                                                // B(start)
+    for (int it = 0; it < nt; ++it) {
+        const bool work = kWork && it >= 1;
+        if (work) pv_begin(it - 1);
+        issue_batch(it + A);
+        if (work) pv_steps(I0{}, IS{});
+        // batch it+1 landed for this wave (the producers read its first fragments behind B1): all but the A - 1 youngest batches
+        if (it + A < nt) wait_vm_dyn(nb * (A - 1));
+        else wait_vm<0>();
+        wg_barrier();                                            // B1(it)
+        if (work) pv_steps(IS{}, I8{});
+        wg_barrier();                                            // B2(it)
+    }
+    if (kWork) {
+        pv_begin(nt - 1);
+        pv_steps(I0{}, I8{});
+    }
+
+    float* dst = partial + (((size_t)t * C + c) * Lrow + slot_off) * kPartRow;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int slot = 32 * sb + acc_row(i, h);
+        if (slot < L) {
+#pragma unroll
+            for (int db = 0; db < 8; ++db) dst[(size_t)slot * kPartRow + 32 * db + r] = o[db][i];
+            if (r < 4) dst[(size_t)slot * kPartRow + 256 + r] = oa[i];     // aux columns 0 .. 2 (column 3 is zero); the rest is not data
+        }
+    }
+}
+
+int retr_attn_hl32_launch(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3, const void* feat_hi,
+                          const void* feat_lo, const void* aux, float* partial, int T, int L, int H, int W, int chunks, int tiles_per_chunk,
+                          int LP, int Lrow, int slot_off, const void* ext_stats, void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    using Lds = RetrLdsHL32;
+    const _Float16* qh_ = static_cast<const _Float16*>(qh);
+    const _Float16* ql_ = static_cast<const _Float16*>(ql);
+    const _Float16* fh_ = static_cast<const _Float16*>(feat_hi);
+    const _Float16* fl_ = static_cast<const _Float16*>(feat_lo);
+    const _Float16* a_ = static_cast<const _Float16*>(aux);
+    const int HW = H * W;
+    if (ext_stats) {
+        auto kern = retr_attn_hl32_kernel<0, true>;
+        static SvpsLdsAttr attr;
+        if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
+        hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), Lds::total, stream, qh_, ql_, cy, cx, c3, fh_, fl_, a_, partial, L, HW, H, W,
+                           tiles_per_chunk, LP, Lrow, slot_off, static_cast<const float2*>(ext_stats));
+        return (int)hipGetLastError();
+    }
+    auto kern = retr_attn_hl32_kernel<0, false>;
+    int slot = 0;
+#ifdef SVPS_RETR_ABLATE
+    // diagnostic build only (tools/ablate.sh builds it as a separate library): timing-only variants that return wrong results
+    static const int ablate = [] { const char* a = getenv("SVPS_RETR_ABLATE"); return a ? atoi(a) : 0; }();
+    if (ablate == 1) { kern = retr_attn_hl32_kernel<1, false>; slot = 1; }
+    else if (ablate == 2) { kern = retr_attn_hl32_kernel<2, false>; slot = 2; }
+    else if (ablate == 4) { kern = retr_attn_hl32_kernel<4, false>; slot = 3; }
+#endif
+    static SvpsLdsAttr attrs[4];
+    if (hipError_t ae = attrs[slot].ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), Lds::total, stream, qh_, ql_, cy, cx, c3, fh_, fl_, a_, partial, L, HW, H, W,
+                       tiles_per_chunk, LP, Lrow, slot_off, (const float2*)nullptr);
+    return (int)hipGetLastError();
+}
+
+}  // namespace svps
