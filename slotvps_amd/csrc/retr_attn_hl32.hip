@@ -37,6 +37,15 @@ typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef SVPS_RETR_HL32_PREFETCH
 #define SVPS_RETR_HL32_PREFETCH 2
 #endif
+#ifndef SVPS_RETR_HL32_SCHED
+#define SVPS_RETR_HL32_SCHED 1
+#endif
+#ifndef SVPS_RETR_HL32_PRIO
+#define SVPS_RETR_HL32_PRIO 0
+#endif
+#ifndef SVPS_RETR_HL32_ACC2
+#define SVPS_RETR_HL32_ACC2 0
+#endif
 #ifndef SVPS_RETR_HL32_SPLIT
 #define SVPS_RETR_HL32_SPLIT 6      // consumer steps (of 8) in front of B1
 #endif
@@ -54,6 +63,20 @@ struct RetrLdsHL32 {
     static constexpr int total = c3 + 128 * 4;
 };
 static_assert(RetrLdsHL32::pring % 512 == 0 && RetrLdsHL32::total <= 160 * 1024, "LDS layout");
+
+#ifdef SVPS_RETR_STAMP
+// diagnostic build only (tools/retr32_stamps.py): s_memtime stamps of one workgroup's producer 0 and consumer 0, iterations 8 .. 15
+__device__ unsigned long long retr32_stamps[2][8][8];      // [producer / consumer][iteration - 8][point]
+#define R32_STAMP(role, pt)                                                                           \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (blockIdx.x == 3 && blockIdx.y == 2 && sb == 0 && it >= 8 && it < 16 && lane == 0)         \
+            retr32_stamps[role][it - 8][pt] = __builtin_amdgcn_s_memtime();                           \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    } while (0)
+#else
+#define R32_STAMP(role, pt) do {} while (0)
+#endif
 
 // ABL: timing-only ablations (diagnostic builds), outputs wrong. 1: DMA + barriers only  2: producers only  4: consumers only
 template <int ABL, bool EXT>
@@ -180,11 +203,20 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         for (int it = 0; it < nt; ++it) {
             float fac = 0.f;
             const bool more = it + 1 < nt;
+            R32_STAMP(0, 0);
             if constexpr (kRun) {
                 const uint32_t tb = lane_row + (uint32_t)(it % NF) * Lds::kStage;
                 f32x4 c3v[4];
                 const float rk_c = rt[0] * kLog2e, tau_c = rt[1] * kPScale;      // common.h: the probabilities carry 2^7
                 // ---- chain: eight groups of two k-steps, three MFMAs per k-step; the reads of group g + 1 in the shadow of group g
+#if SVPS_RETR_HL32_ACC2
+                f32x16 s2;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s2[i] = 0.f;
+#endif
+#if SVPS_RETR_HL32_PRIO
+                __builtin_amdgcn_s_setprio(SVPS_RETR_HL32_PRIO);
+#endif
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     if (g < 7) {
@@ -193,6 +225,19 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
 #pragma unroll
                         for (int q = 0; q < 4; ++q) c3v[q] = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * q);
                     }
+#if SVPS_RETR_HL32_ACC2
+                    // two accumulators in alternation: a chain of DEPENDENT MFMAs cannot issue back to back, so a single accumulator leaves
+                    // every other slot of the matrix pipe to the consumer wave of the SIMD whatever the priorities say
+                    {
+                        const int k0 = g, k1 = g + 8;
+                        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[k0], kf[g & 1][0], s2, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[k0], kf[g & 1][0], s, 0, 0, 0);
+                        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[k0], kf[g & 1][2], s2, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[k1], kf[g & 1][1], s, 0, 0, 0);
+                        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[k1], kf[g & 1][1], s2, 0, 0, 0);
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[k1], kf[g & 1][3], s, 0, 0, 0);
+                    }
+#else
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int ks = g + 8 * u;
@@ -200,8 +245,20 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[g & 1][2 + u], s, 0, 0, 0);
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[g & 1][u], s, 0, 0, 0);
                     }
+#endif
+#if SVPS_RETR_HL32_SCHED
+                    // the four reads of the next group (their address XORs) in FRONT of this group's six MFMAs: hipcc otherwise sinks them
+                    // behind the fifth, and every group starts with an exposed LDS round trip
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#if SVPS_RETR_HL32_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                R32_STAMP(0, 1);
                 // ---- softmax head: log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no
                 // masking: their Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep): they exp2 to exactly 0
                 const bool live = TPX * ts + r < W;
@@ -211,7 +268,11 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+#if SVPS_RETR_HL32_ACC2
+                        s[4 * g + j] = fmaf(rk_c, (s[4 * g + j] + s2[4 * g + j]) + cxv[g][j], c3v[g][j]);
+#else
                         s[4 * g + j] = fmaf(rk_c, s[4 * g + j] + cxv[g][j], c3v[g][j]);
+#endif
                         if constexpr (!EXT) mloc = fmaxf(mloc, s[4 * g + j]);
                     }
                 }
@@ -231,7 +292,9 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                     float sloc = (sl[0] + sl[1]) + (sl[2] + sl[3]);
                     sloc = ra_half_swap_sum(sloc);
                     if (h == 0) stats[sb * 32 + r] = make_float2(mloc, sloc);
+                    R32_STAMP(0, 2);
                     wg_barrier();                                   // B1(it)
+                    R32_STAMP(0, 3);
                     float2 st_w[4];
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) st_w[ww] = stats[ww * 32 + r];
@@ -273,6 +336,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                     }
                     prefetch(it + 1);
                 }
+                R32_STAMP(0, 4);
             } else {
                 wg_barrier();                                       // B1(it)
             }
@@ -403,14 +467,19 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     wg_barrier();                                                // B(start)
     for (int it = 0; it < nt; ++it) {
         const bool work = kWork && it >= 1;
+        R32_STAMP(1, 0);
         if (work) pv_begin(it - 1);
         issue_batch(it + A);
         if (work) pv_steps(I0{}, IS{});
+        R32_STAMP(1, 1);
         // batch it+1 landed for this wave (the producers read its first fragments behind B1): all but the A - 1 youngest batches
         if (it + A < nt) wait_vm_dyn(nb * (A - 1));
         else wait_vm<0>();
+        R32_STAMP(1, 2);
         wg_barrier();                                            // B1(it)
+        R32_STAMP(1, 3);
         if (work) pv_steps(IS{}, I8{});
+        R32_STAMP(1, 4);
         wg_barrier();                                            // B2(it)
     }
     if (kWork) {
@@ -466,3 +535,9 @@ int retr_attn_hl32_launch(const void* qh, const void* ql, const float* cy, const
 }
 
 }  // namespace svps
+
+#ifdef SVPS_RETR_STAMP
+extern "C" int svps_retr32_debug_read(unsigned long long* stamps) {
+    return (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(svps::retr32_stamps), sizeof(unsigned long long) * 2 * 8 * 8);
+}
+#endif
