@@ -13,14 +13,26 @@
 // Four stages of 32 KiB leave no room for a second P buffer and a third live stage, so the schedule changes with the tile: the consumers
 // run ONE tile behind the producers (not two) and a tile has TWO workgroup barriers (the same number per pixel as before):
 //
-//   producer, iteration it:   chain(it) | softmax head(it) -> stats | B1(it) | finish(it): factor, P(it) -> LDS; first fragments of it+1 | B2(it)
+//   producer, iteration it:   chain(it) || d = rk (Cx + Cy) + c3' | softmax head(it) -> stats | B1(it) | first fragments of it+1; factor,
+//                             P(it) -> LDS | B2(it)
 //   consumer, iteration it:   P(it-1) fragments; LDS-DMA of batch it+2; A += P(it-1) f(it-1), first part | landing wait of batch it+1 | B1(it)
 //                             | rest of A += P(it-1) f(it-1) | B2(it)
 //
-// P and the statistics are single-buffered: P(it) is written between B1(it) and B2(it) and read (into registers, at once) after B2(it);
-// stage (it+2) % 4 was last read by the consumers before B2(it-1). Everything else - tile walk down 32-pixel column strips, Cx in
-// registers per strip, Cy rows / aux rows / feature tiles by LDS-DMA, swizzled 512-B pixel rows, transposed value fragments, the aux
-// block, partials summed in fixed order by retr_finish_kernel - is the scheme of retr_attn.hip, whose comments carry the derivation.
+// P is single-buffered: P(it) is written between B1(it) and B2(it) and read (into registers, at once) after B2(it); the statistics are
+// double-buffered; stage (it+2) % 4 was last read by the consumers before B2(it-1). Everything else - tile walk down 32-pixel column
+// strips, Cx in registers per strip, Cy rows / aux rows / feature tiles by LDS-DMA, swizzled 512-B pixel rows, transposed value fragments,
+// the aux block, partials summed in fixed order by retr_finish_kernel - is the scheme of retr_attn.hip, whose comments carry the derivation.
+//
+// Measured (finest level 256 x 512, T = 40, 100 slots; profiles/r06/README.md): 1 780 - 1 800 us against 2 090 - 2 110 of the sixteen-pixel
+// form on the same box. Timing-only ablations: DMA + barriers 859, producers only 1 370, consumers only 1 170, no LDS-DMA behind the first
+// ring fill 1 620, no landing wait 1 780; without the producers' Q''_lo MFMAs (16 of 48) - 170 us, without the consumers' P_lo MFMAs (16 of
+// 52) - 195 us, without both - 375: every MFMA costs its 32 cycles of the SIMD's matrix pipe, which the producer and the consumer wave of a
+// SIMD share (100 MFMAs = 3 200 of ~4 500 cycles per tile); the rest is the part of the producers' vector work (head + finish) the
+// consumers' MFMAs do not cover, and two barrier latencies. Built and measured equal or slower on the same box, not kept
+// (profiles/r06/k1hl32_experiment_options.patch): the hand-over of P(it) through one LDS flag per slot block instead of B2 (+ 7 %: the
+// consumer then starts its tile late and becomes the critical wave), two alternating accumulators in the chain and / or s_setprio around
+// it, the next group's reads forced in front of a group's MFMAs (sched_group_barrier), halving the finish's vector instructions
+// (v_cvt_pk_f16_f32 + v_fma_mixlo / mixhi_f16: kept, not faster), the consumers' split point 3 ... 7 (4).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -37,17 +49,8 @@ typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef SVPS_RETR_HL32_PREFETCH
 #define SVPS_RETR_HL32_PREFETCH 2
 #endif
-#ifndef SVPS_RETR_HL32_SCHED
-#define SVPS_RETR_HL32_SCHED 1
-#endif
-#ifndef SVPS_RETR_HL32_PRIO
-#define SVPS_RETR_HL32_PRIO 0
-#endif
-#ifndef SVPS_RETR_HL32_ACC2
-#define SVPS_RETR_HL32_ACC2 0
-#endif
 #ifndef SVPS_RETR_HL32_SPLIT
-#define SVPS_RETR_HL32_SPLIT 6      // consumer steps (of 8) in front of B1
+#define SVPS_RETR_HL32_SPLIT 4      // consumer steps (of 8) in front of B1
 #endif
 
 struct RetrLdsHL32 {
@@ -58,8 +61,8 @@ struct RetrLdsHL32 {
     static constexpr int aring = kNF * kStage;
     static constexpr int yring = aring + kNF * kAuxTile;
     static constexpr int pring = yring + kNF * kCyTile;         // P hi [8 KiB], P lo [8 KiB]: slot block sb at sb * 2 KiB, 32 pixel rows of 64 B
-    static constexpr int stats = pring + 2 * kPTile;            // [4][32] float2
-    static constexpr int c3 = stats + 4 * 32 * 8;               // [128] float
+    static constexpr int stats = pring + 2 * kPTile;            // [2][4][32] float2
+    static constexpr int c3 = stats + 2 * 4 * 32 * 8;           // [128] float
     static constexpr int total = c3 + 128 * 4;
 };
 static_assert(RetrLdsHL32::pring % 512 == 0 && RetrLdsHL32::total <= 160 * 1024, "LDS layout");
@@ -79,6 +82,7 @@ __device__ unsigned long long retr32_stamps[2][8][8];      // [producer / consum
 #endif
 
 // ABL: timing-only ablations (diagnostic builds), outputs wrong. 1: DMA + barriers only  2: producers only  4: consumers only
+//      8: no LDS-DMA behind the first ring fill (everything else runs on stale tiles)  16: no landing wait
 template <int ABL, bool EXT>
 __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     const _Float16* __restrict__ qh,    // [T, LP, 256]  hi(Q''), rows >= the real slot count zero
@@ -141,7 +145,6 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
             return __builtin_amdgcn_make_buffer_rsrc((void*)u, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
         };
-        const __amdgpu_buffer_rsrc_t cyr = uniform_rsrc(cy + (size_t)t * H * LP + slot_off, H * LP * 4 - slot_off * 4);
         const __amdgpu_buffer_rsrc_t cxr = uniform_rsrc(cx + (size_t)t * W * LP + slot_off, W * LP * 4 - slot_off * 4);
         const __amdgpu_buffer_rsrc_t exr = uniform_rsrc(EXT ? (const void*)(ext_stats + (size_t)t * HW) : (const void*)cy, EXT ? HW * 8 : 0);
 
@@ -165,16 +168,6 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             }
         };
         load_cx(ts);
-        f32x16 s;                                                   // tile 0: its Cy row straight from global memory
-        {
-            const int yo = (ty * LP + slot0) * 4;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 cyv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cyr, yo + 32 * g, 0, 0));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j];
-            }
-        }
         request_ext(ts, ty);
         float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
 
@@ -198,7 +191,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         };
 
         constexpr bool kRun = ABL != 1 && ABL != 4;
-        wg_barrier();                                               // B(start): batch 0 landed
+        wg_barrier();                                               // B(start): batch 0 and the Cy row of tile 0 landed
         if constexpr (kRun) prefetch(0);
         for (int it = 0; it < nt; ++it) {
             float fac = 0.f;
@@ -206,58 +199,40 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             R32_STAMP(0, 0);
             if constexpr (kRun) {
                 const uint32_t tb = lane_row + (uint32_t)(it % NF) * Lds::kStage;
-                f32x4 c3v[4];
                 const float rk_c = rt[0] * kLog2e, tau_c = rt[1] * kPScale;      // common.h: the probabilities carry 2^7
-                // ---- chain: eight groups of two k-steps, three MFMAs per k-step; the reads of group g + 1 in the shadow of group g
-#if SVPS_RETR_HL32_ACC2
-                f32x16 s2;
+                // d = (log2(e) rstd_k) (Cx + Cy) + c3', the affine part of the logits: from the tile's Cy row (staged one batch early) and the c3
+                // terms in the shadow of the chain's first groups - the head is then ONE fma per logit, and the accumulator starts from zero
+                const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + (it % NF) * kCyTile) + slot_off + slot0;
+                f32x4 d[4], cyq, c3q;
+                f32x16 s;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s2[i] = 0.f;
-#endif
-#if SVPS_RETR_HL32_PRIO
-                __builtin_amdgcn_s_setprio(SVPS_RETR_HL32_PRIO);
-#endif
+                for (int i = 0; i < 16; ++i) s[i] = 0.f;
+                // ---- chain: eight groups of two k-steps, three MFMAs per k-step; the reads of group g + 1 in the shadow of group g
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    if (g < 7) {
-                        load_grp((g + 1) & 1, tb, g + 1);
-                    } else {
+                    if (g < 7) load_grp((g + 1) & 1, tb, g + 1);
+                    if (g >= 1 && g < 5) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) c3v[q] = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * q);
+                        for (int j = 0; j < 4; ++j) {
+                            d[g - 1][j] = fmaf(rk_c, cxv[g - 1][j] + cyq[j], c3q[j]);
+                            asm volatile("" : "+v"(d[g - 1][j]));       // HERE, under this group's MFMAs (hipcc otherwise sinks it into the head)
+                        }
                     }
-#if SVPS_RETR_HL32_ACC2
-                    // two accumulators in alternation: a chain of DEPENDENT MFMAs cannot issue back to back, so a single accumulator leaves
-                    // every other slot of the matrix pipe to the consumer wave of the SIMD whatever the priorities say
-                    {
-                        const int k0 = g, k1 = g + 8;
-                        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[k0], kf[g & 1][0], s2, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[k0], kf[g & 1][0], s, 0, 0, 0);
-                        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[k0], kf[g & 1][2], s2, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[k1], kf[g & 1][1], s, 0, 0, 0);
-                        s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[k1], kf[g & 1][1], s2, 0, 0, 0);
-                        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[k1], kf[g & 1][3], s, 0, 0, 0);
+                    if (g < 4) {
+                        cyq = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
+                        c3q = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * g);
                     }
-#else
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int ks = g + 8 * u;
+#ifndef SVPS_R32_SKIP_QLO                                              // (timing experiments only)
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[ks], kf[g & 1][u], s, 0, 0, 0);
+#endif
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[g & 1][2 + u], s, 0, 0, 0);
                         s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[g & 1][u], s, 0, 0, 0);
                     }
-#endif
-#if SVPS_RETR_HL32_SCHED
-                    // the four reads of the next group (their address XORs) in FRONT of this group's six MFMAs: hipcc otherwise sinks them
-                    // behind the fifth, and every group starts with an exposed LDS round trip
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#if SVPS_RETR_HL32_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 R32_STAMP(0, 1);
                 // ---- softmax head: log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no
                 // masking: their Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep): they exp2 to exactly 0
@@ -268,11 +243,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                 for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-#if SVPS_RETR_HL32_ACC2
-                        s[4 * g + j] = fmaf(rk_c, (s[4 * g + j] + s2[4 * g + j]) + cxv[g][j], c3v[g][j]);
-#else
-                        s[4 * g + j] = fmaf(rk_c, s[4 * g + j] + cxv[g][j], c3v[g][j]);
-#endif
+                        s[4 * g + j] = fmaf(rk_c, s[4 * g + j], d[g][j]);
                         if constexpr (!EXT) mloc = fmaxf(mloc, s[4 * g + j]);
                     }
                 }
@@ -291,13 +262,15 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                     for (int i = 0; i < 4; ++i) sl[i] = (s[i] + s[4 + i]) + (s[8 + i] + s[12 + i]);
                     float sloc = (sl[0] + sl[1]) + (sl[2] + sl[3]);
                     sloc = ra_half_swap_sum(sloc);
-                    if (h == 0) stats[sb * 32 + r] = make_float2(mloc, sloc);
+                    float2* st = stats + (it & 1) * 128;            // double-buffered: nothing orders the producers between two B1
+                    if (h == 0) st[sb * 32 + r] = make_float2(mloc, sloc);
                     R32_STAMP(0, 2);
                     wg_barrier();                                   // B1(it)
                     R32_STAMP(0, 3);
                     float2 st_w[4];
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) st_w[ww] = stats[ww * 32 + r];
+                    for (int ww = 0; ww < 4; ++ww) st_w[ww] = st[ww * 32 + r];
+                    if (more) prefetch(it + 1);                     // batch it+1 landed before B1: its first fragments under the finish
                     float mall = kNegBig;
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) mall = fmaxf(mall, st_w[ww].x);
@@ -307,34 +280,31 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                     fac = __builtin_amdgcn_exp2f(mloc - mall) * __builtin_amdgcn_rcpf(den) * tau_c;
                 } else {
                     wg_barrier();                                   // B1(it)
+                    if (more) prefetch(it + 1);
                     fac = ext_c[1] * tau_c;
                 }
                 if (!live) fac = 0.f;                               // pixels past the right edge of the map
-                // ---- finish: P(it) = e * fac as fp16 hi + lo into the P tiles (row = pixel r, 64 B = 32 slots of this block)
+                // ---- finish: P(it) = e * fac as fp16 hi + lo into the P tiles (row = pixel r, 64 B = 32 slots of this block); the consumers'
+                // reads of P(it-1) completed before they entered B1(it)
                 char* prow = smem + Lds::pring + sb * 2048 + r * 64 + 8 * h;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f16x4 ph, pl;
+                    // hi = rne(e fac) two at a time (v_cvt_pk_f16_f32), lo = rne(e fac - hi) straight from the fused product
+                    // (v_fma_mixlo / mixhi_f16: the fp32 fma, the conversion and the half-register write in one instruction)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float x = s[4 * g + j] * fac;
-                        asm volatile("" : "+v"(x));                 // ONE fp32 value for both halves (retr_attn.hip)
-                        ph[j] = (_Float16)x;
-                        pl[j] = (_Float16)(x - (float)ph[j]);
+                    for (int j = 0; j < 4; j += 2) {
+                        typedef __attribute__((ext_vector_type(2))) float f32x2_;
+                        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_;
+                        const f32x2_ x = {s[4 * g + j] * fac, s[4 * g + j + 1] * fac};
+                        const f16x2_ hp = __builtin_convertvector(x, f16x2_);
+                        ph[j] = hp[0];
+                        ph[j + 1] = hp[1];
+                        pl[j] = (_Float16)fmaf(s[4 * g + j], fac, -(float)hp[0]);
+                        pl[j + 1] = (_Float16)fmaf(s[4 * g + j + 1], fac, -(float)hp[1]);
                     }
                     *reinterpret_cast<f16x4*>(prow + ((g ^ key) * 16)) = ph;
                     *reinterpret_cast<f16x4*>(prow + kPLo + ((g ^ key) * 16)) = pl;
-                }
-                // ---- next tile: its Cy row (staged with batch `it`) starts the accumulator; first fragment group (batch it+1 landed before B1)
-                if (more) {
-                    const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + ((it + 1) % NF) * kCyTile) + slot_off + slot0;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 cyv = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j];
-                    }
-                    prefetch(it + 1);
                 }
                 R32_STAMP(0, 4);
             } else {
@@ -361,6 +331,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     int ds = strip0, dy = row0;                                  // strip / image row of the next batch
     auto issue_batch = [&](int b) {
         if (b >= nt) return;
+        if (ABL == 8 && b >= NF) return;                         // timing only: no memory traffic behind the first ring fill
         const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % NF) * Lds::kStage + pl_ * kTileBytes + rb * kRowBytes);
         const int px0 = dy * W + TPX * ds;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
@@ -385,6 +356,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             ra_dma16_cached(yrs, sy, dy * LP * 4 + lane * 16);
         }
     };
+    if (sb == 2) ra_dma16_cached(yrs, __builtin_amdgcn_readfirstlane(lds0 + Lds::yring), row0 * LP * 4 + lane * 16);   // Cy row of tile 0
 #pragma unroll
     for (int b = 0; b < A; ++b) issue_batch(b);
 
@@ -443,8 +415,10 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             const int ks = q >> 2, db = 2 * (q & 3);
             if (q < 7) load_step((q + 1) & 1, q + 1);
             __builtin_amdgcn_sched_barrier(0);
+#ifndef SVPS_R32_SKIP_PLO                                              // (timing experiments only)
 #pragma unroll
             for (int u = 0; u < 2; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], vh[q & 1][u], o[db + u], 0, 0, 0);
+#endif
 #pragma unroll
             for (int u = 0; u < 2; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vl[q & 1][u], o[db + u], 0, 0, 0);
 #pragma unroll
@@ -462,7 +436,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     using I8 = std::integral_constant<int, 8>;
     constexpr bool kWork = ABL != 1 && ABL != 2;
 
-    if (A - 1 < nt) wait_vm_dyn(nb * (A - 1));                   // batch 0 landed
+    if (A - 1 < nt) wait_vm_dyn(nb * (A - 1));                   // batch 0 (and the Cy row of tile 0) landed
     else wait_vm<0>();
     wg_barrier();                                                // B(start)
     for (int it = 0; it < nt; ++it) {
@@ -473,8 +447,10 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         if (work) pv_steps(I0{}, IS{});
         R32_STAMP(1, 1);
         // batch it+1 landed for this wave (the producers read its first fragments behind B1): all but the A - 1 youngest batches
-        if (it + A < nt) wait_vm_dyn(nb * (A - 1));
-        else wait_vm<0>();
+        if (ABL != 16) {
+            if (it + A < nt) wait_vm_dyn(nb * (A - 1));
+            else wait_vm<0>();
+        } else if (it + 4 * A < nt) wait_vm_dyn(nb * (4 * A - 1));  // (timing only: the landing wait never binds)
         R32_STAMP(1, 2);
         wg_barrier();                                            // B1(it)
         R32_STAMP(1, 3);
@@ -526,8 +502,10 @@ int retr_attn_hl32_launch(const void* qh, const void* ql, const float* cy, const
     if (ablate == 1) { kern = retr_attn_hl32_kernel<1, false>; slot = 1; }
     else if (ablate == 2) { kern = retr_attn_hl32_kernel<2, false>; slot = 2; }
     else if (ablate == 4) { kern = retr_attn_hl32_kernel<4, false>; slot = 3; }
+    else if (ablate == 8) { kern = retr_attn_hl32_kernel<8, false>; slot = 4; }
+    else if (ablate == 16) { kern = retr_attn_hl32_kernel<16, false>; slot = 5; }
 #endif
-    static SvpsLdsAttr attrs[4];
+    static SvpsLdsAttr attrs[6];
     if (hipError_t ae = attrs[slot].ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return (int)ae;
     hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), Lds::total, stream, qh_, ql_, cy, cx, c3, fh_, fl_, a_, partial, L, HW, H, W,
                        tiles_per_chunk, LP, Lrow, slot_off, (const float2*)nullptr);

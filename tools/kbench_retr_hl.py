@@ -48,4 +48,4 @@ for rep in range(a.reps):
         a_ms, a_n = kt.collect(_lib.KERNEL_RETR_ATTN)
     su, au = s_ms / s_n * 1e3, a_ms / a_n * 1e3
     print(f"rep {rep}: retr_stats_hl {su:8.1f} us ({px * 1040 / su / 1e3:6.0f} GB/s)   retr_attn_hl {au:8.1f} us ({px * 1040 / au / 1e3:6.0f} GB/s, "
-          f"{px / 16 * 232 * 32768 / au / 1e6:5.0f} TF/s executed)   abl attn={os.environ.get('SVPS_RETR_ABLATE', '0')}", flush=True)
+          f"{px / 32 * 4 * 101 * 32768 / au / 1e6:5.0f} TF/s executed)   abl attn={os.environ.get('SVPS_RETR_ABLATE', '0')}", flush=True)

@@ -33,8 +33,8 @@ st = np.zeros((2, 8, 8), dtype=np.uint64)
 lib.svps_retr32_debug_read.argtypes = [ctypes.c_void_p]
 assert lib.svps_retr32_debug_read(st.ctypes.data_as(ctypes.c_void_p)) == 0
 st = st.astype(np.int64)
-names = [["top", "chain end", "head end (stats written)", "B1 passed", "finish end (P stored, next fragments requested)"],
-         ["top", "first steps end", "batch landed", "B1 passed", "last steps end"]]
+names = [["top (B1 passed)", "chain end", "head end (stats written)", "B1 passed", "finish end (P stored, flag set)"],
+         ["top (B1 passed)", "rest of the tile before", "flag seen, P fragments, DMA issued", "first steps end", "batch landed"]]
 for role in (0, 1):
     print("--- producer 0" if role == 0 else "--- consumer 0")
     for it in range(1, 7):
