@@ -23,7 +23,7 @@ import os
 import sys
 
 # kernel-name fragment in the trace -> the name bench.py uses in `roofline.per_kernel`
-KERNELS = {"retr_attn_kernel": "retr_attn", "retr_stats_kernel": "retr_stats", "retr_stats_hl_kernel": "retr_stats", "retr_stats2_kernel": "retr_stats", "retr_logit_stats": "retr_logit_stats", "retr_probs_kernel": "retr_probs", "retr_pv_kernel": "retr_pv",
+KERNELS = {"retr_attn_kernel": "retr_attn", "retr_attn_hl32_kernel": "retr_attn", "retr_stats_kernel": "retr_stats", "retr_stats_hl_kernel": "retr_stats", "retr_stats2_kernel": "retr_stats", "retr_logit_stats": "retr_logit_stats", "retr_probs_kernel": "retr_probs", "retr_pv_kernel": "retr_pv",
            "retr_finish": "retr_finish", "slot_attn_partial": "slot_attn", "slot_attn_finish": "slot_attn_finish",
            "kv_project": "kv_project", "level_fuse": "level_fuse", "mask_decode": "mask_decode", "row_ln": "row_ln",
            "slot_self_attn": "slot_self_attn"}

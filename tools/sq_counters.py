@@ -10,7 +10,7 @@ import json
 import os
 import sys
 
-KERNELS = {"retr_attn_kernel": "retr_attn", "retr_stats2_kernel": "retr_stats (level form, 2 stages)",
+KERNELS = {"retr_attn_kernel": "retr_attn", "retr_attn_hl32_kernel": "retr_attn", "retr_stats_hl_kernel": "retr_stats", "retr_stats2_kernel": "retr_stats (level form, 2 stages)",
            "retr_stats_kernel": "retr_stats", "level_fuse": "level_fuse", "mask_decode": "mask_decode", "slot_ffn_kernel": "slot_ffn",
            "slot_chain_kernel": "slot_chain", "slot_gemm_kernel": "slot_gemm", "bgemm_kernel": "bgemm"}
 
