@@ -781,30 +781,35 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
 //   * fragment addresses held in 8 registers (chunk ^ swizzle for k-steps 0 .. 7; k-steps 8 .. 15 and the lo tile are immediate offsets);
 //   * LDS: 2 stages x 32 KiB + a [16 slots][32 px] transpose tile per wave (the logits leave in two halves) = 78 KiB: two workgroups per CU.
 // Same skew as the fast path: the epilogue of tile it - 1 rides in the shadow of the chain of tile it; norms double-buffered by parity.
-struct DecHl32Lds {
+// NW = 4 waves (up to 128 slots, two workgroups per CU) or 8 (up to 256 slots - VIPER's 200 -, one workgroup per CU: the same eight waves).
+template <int NW>
+struct DecHl32LdsT {
     static constexpr int kStages = 2;
     static constexpr int kStageBytes = 2 * kTileBytes;               // hi tile, then lo tile
     static constexpr int ring = 0;
     static constexpr int kORow = 144;                                // [16 slots][32 px] fp32 per wave, rows padded to 144 B
     static constexpr int kOWave = 16 * kORow;
     static constexpr int otile = kStages * kStageBytes;
-    static constexpr int affine = otile + 4 * kOWave;                // scale[256], shift[256]
+    static constexpr int affine = otile + NW * kOWave;               // scale[256], shift[256]
     static constexpr int norm = affine + 2 * kD * 4;                 // [2][32] by tile parity: fg_scale / ||g||
-    static constexpr int cshift = norm + 2 * kTilePx * 4;            // [128]
-    static constexpr int amax = cshift + 128 * 4;                    // [2][4][32] float2
-    static constexpr int total = amax + 2 * 4 * kTilePx * 8;
+    static constexpr int cshift = norm + 2 * kTilePx * 4;            // [32 NW]
+    static constexpr int amax = cshift + 32 * NW * 4;                // [2][NW][32] float2
+    static constexpr int total = amax + 2 * NW * kTilePx * 8;
 };
-static_assert(2 * DecHl32Lds::total <= 160 * 1024, "two workgroups per CU");
+using DecHl32Lds = DecHl32LdsT<4>;
+static_assert(2 * DecHl32Lds::total <= 160 * 1024 && DecHl32LdsT<8>::total <= 160 * 1024, "two workgroups of four waves / one of eight per CU");
 
-template <bool ARGMAX, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
+template <bool ARGMAX, int ABL = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_hl32_kernel(
     const _Float16* __restrict__ feat_hi, const _Float16* __restrict__ feat_lo, const float* __restrict__ embed,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
     uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Lds = DecHl32Lds;
-    constexpr int NW = 4, NT = 256, NST = Lds::kStages;
-    constexpr int PCW = (ABL & 8) ? 0 : 8;                         // 1-KiB DMA pieces per wave and tile
+    using Lds = DecHl32LdsT<NW>;
+    constexpr int NT = 64 * NW, NST = Lds::kStages;
+    constexpr int PCW = 32 / NW;                                   // 1-KiB DMA pieces per wave and tile
+    constexpr int HWV = NW / 2;                                    // waves per plane
+    constexpr int TP = NT / kTilePx;                               // the norm's threads per pixel (8 or 16)
     constexpr int kMS = 4;                                         // mask stores per wave and tile
     constexpr int kAS = ARGMAX ? 1 : 0;
     const int tid = threadIdx.x;
@@ -858,36 +863,37 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
     wait_vm<0>();
     __syncthreads();
     const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
-    const u32x4 frs = make_srd_d((w >= 2 ? feat_lo : feat_hi) + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);   // waves 0, 1: hi plane; 2, 3: lo
+    const u32x4 frs = make_srd_d((w >= HWV ? feat_lo : feat_hi) + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);   // first half of the waves: hi plane
     const u32x4 ors = make_srd_d(out + (size_t)t * L * HW, (uint32_t)L * (uint32_t)HW * 4u);
     const u32x4 ars = make_srd_d(ARGMAX ? slot_argmax + (size_t)t * HW : nullptr, ARGMAX ? (uint32_t)HW : 0u);
-    // wave w stages rows 16 (w & 1) .. + 15 of its plane: 8 pieces of two rows, two instructions groups of four
-    // LDS position c of row `row` holds the logical chunk c ^ swz(row); with row = 16 (w & 1) + 8 g + 2 i + hh the swizzle is
-    // ((2 (i & 1) + hh) << 2) | (2 g + (i >> 1)): a lane constant (rr ^ (hh << 2)) xor a compile-time constant per piece
+    // wave w stages rows row0 .. row0 + 2 PCW - 1 of its plane (row0 = 2 PCW (w mod HWV)): PCW pieces of two rows, instruction groups of four
+    // LDS position c of row `row` holds the logical chunk c ^ swz(row); with row = row0 + 8 g + 2 i + hh the swizzle is
+    // ((2 (i & 1) + hh) << 2) | ((row0 / 4 + 2 g + (i >> 1)) & 3): a lane constant (rr ^ (hh << 2)) xor a wave-uniform constant per piece
+    const int row0 = 2 * PCW * (w % HWV);
     auto stage = [&](int tile) {
         if (tile >= nt || (ABL & 8)) return;
         int rr = r, hh = h;
         asm volatile("" : "+v"(rr), "+v"(hh));
-        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * Lds::kStageBytes + (w >> 1) * kTileBytes + (w & 1) * 8192);
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NST) * Lds::kStageBytes + (w / HWV) * kTileBytes + row0 * kRowBytes);
         const int px0 = px_begin + tile * kTilePx;
         const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
         if (px0 + kTilePx <= HW) {
             const int cbase = (rr ^ (hh << 2)) * 16;                        // chunk term of this lane, before the piece's constant
-            const int rbase = (16 * (w & 1) + hh) * kRowBytes;              // row term
+            const int rbase = (row0 + hh) * kRowBytes;                      // row term
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < PCW / 4; ++g) {
                 int vo[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int kc = (((2 * (i & 1)) << 2) | (2 * g + (i >> 1))) * 16;
+                    const int kc = (((2 * (i & 1)) << 2) | (((row0 >> 2) + 2 * g + (i >> 1)) & 3)) * 16;
                     vo[i] = (cbase ^ kc) + rbase + (8 * g + 2 * i) * kRowBytes - 1024 * i;
                 }
                 dma16x4_d(frs, st + 4096 * g, vo[0], vo[1], vo[2], vo[3], soff);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = 16 * (w & 1) + 2 * i + hh;
+            for (int i = 0; i < PCW; ++i) {
+                const int row = row0 + 2 * i + hh;
                 const int src = px0 + row < HW ? row : HW - 1 - px0;
                 dma16_d(frs, st + i * 1024, src * kRowBytes + ((rr ^ swz(row)) * 16), soff);
             }
@@ -900,9 +906,9 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
 #pragma unroll
     for (int k = 0; k < 8; ++k) fa[k] = r * kRowBytes + (((2 * k + h) ^ swz(r)) * 16);
     char* ot = smem + Lds::otile + w * Lds::kOWave;
-    // the norm's thread -> (pixel tid >> 3, chunks (tid & 7) + 8 i): LDS offset of chunk i = 0 and first channel
-    const int nrm_o0 = (tid >> 3) * kRowBytes + (((tid & 7) ^ swz(tid >> 3)) * 16);
-    const int nrm_ch = 8 * (tid & 7);
+    // the norm's thread -> (pixel tid / TP, chunks (tid mod TP) + TP i): LDS offset of chunk i = 0 and first channel
+    const int nrm_o0 = (tid / TP) * kRowBytes + (((tid % TP) ^ swz(tid / TP)) * 16);
+    const int nrm_ch = 8 * (tid % TP);
     f32x16 sp;                                                     // accumulators of the previous tile
 #pragma unroll
     for (int i = 0; i < 16; ++i) sp[i] = 0.f;
@@ -919,18 +925,19 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
         if constexpr (CH) stage(it + 1);
         const char* fth = smem + Lds::ring + (it % NST) * Lds::kStageBytes;
 
-        if constexpr (CH) {   // fg_scale / ||scale (f_hi + f_lo) + shift|| per pixel: 8 threads per pixel, 4 chunks each
-            // chunk nsub + 8 i of pixel npx sits at LDS chunk (nsub + 8 i) ^ swz(npx): o_0 for i = 0, o_0 ^ 128 B for i = 1, + 256 B for i + 2
+        if constexpr (CH) {   // fg_scale / ||scale (f_hi + f_lo) + shift|| per pixel: TP = 8 (16) threads per pixel, 4 (2) chunks each
+            // TP = 8: chunk nsub + 8 i of pixel npx sits at LDS chunk (nsub + 8 i) ^ swz(npx): o_0 for i = 0, o_0 ^ 128 B for i = 1, + 256 B for i + 2
+            // TP = 16: chunk nsub + 16 i: o_0 + 256 B i
             int o0 = nrm_o0;
             asm volatile("" : "+v"(o0));                                     // (opaque per tile: no address table in registers)
             const int o1 = o0 ^ 128;
             float ss = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int o = ((i & 1) ? o1 : o0) + (i >> 1) * 256;
+            for (int i = 0; i < 32 / TP; ++i) {
+                const int o = TP == 8 ? ((i & 1) ? o1 : o0) + (i >> 1) * 256 : o0 + i * 256;
                 const f16x8 xh = *reinterpret_cast<const f16x8*>(fth + o);
                 const f16x8 xl = *reinterpret_cast<const f16x8*>(fth + kTileBytes + o);
-                const float* ap = aff + nrm_ch + 64 * i;                      // channels 8 (nsub + 8 i) ..
+                const float* ap = aff + nrm_ch + 8 * TP * i;                  // channels 8 (nsub + TP i) ..
                 const f32x4 a0 = *reinterpret_cast<const f32x4*>(ap), a1 = *reinterpret_cast<const f32x4*>(ap + 4);
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(ap + kD), b1 = *reinterpret_cast<const f32x4*>(ap + kD + 4);
 #pragma unroll
@@ -945,7 +952,8 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
             ss += __shfl_xor(ss, 1);
             ss += __shfl_xor(ss, 2);
             ss += __shfl_xor(ss, 4);
-            if ((tid & 7) == 0) inv_norm[(it & 1) * kTilePx + (tid >> 3)] = fg_scale / fmaxf(sqrtf(ss), 1e-12f);
+            if constexpr (TP == 16) ss += __shfl_xor(ss, 8);
+            if ((tid % TP) == 0) inv_norm[(it & 1) * kTilePx + (tid / TP)] = fg_scale / fmaxf(sqrtf(ss), 1e-12f);
         }
 
         constexpr bool FR = CH && !(ABL & 2);
@@ -954,8 +962,8 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
             fh[0] = *reinterpret_cast<const f16x8*>(fth + fa[0]);
             fl[0] = *reinterpret_cast<const f16x8*>(fth + kTileBytes + fa[0]);
         }
-        float2 cnd[NW];
-        if constexpr (ARGMAX && EP) {
+        float2 cnd[NW];                                  // four waves: requested here, used under k-step 1; eight: read there (registers)
+        if constexpr (ARGMAX && EP && NW == 4) {
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) cnd[ww] = am[(it & 1) * NW * kTilePx + ww * kTilePx + r];
         }
@@ -1012,6 +1020,7 @@ __global__ __launch_bounds__(256, 2) void mask_decode_hl32_kernel(
                         int bs = 0x7fffffff;
 #pragma unroll
                         for (int ww = 0; ww < NW; ++ww) {
+                            if constexpr (NW != 4) cnd[ww] = am[(it & 1) * NW * kTilePx + ww * kTilePx + r];
                             const int sl = __float_as_int(cnd[ww].y);
                             if (cnd[ww].x > b || (cnd[ww].x == b && sl < bs)) { b = cnd[ww].x; bs = sl; }
                         }
@@ -1118,18 +1127,18 @@ hipError_t launch_decode_v2(const void* feat, const float* embed, const float* b
     return hipGetLastError();
 }
 
-template <bool ARGMAX, int ABL = 0>
+template <bool ARGMAX, int ABL = 0, int NW = 4>
 hipError_t launch_decode_hl32(const void* feat_hi, const void* feat_lo, const float* embed, const float* bn_scale, const float* bn_shift,
                               float fg_scale, float fg_shift, float* out, uint8_t* slot_argmax, int T, int L, int HW, hipStream_t stream) {
-    auto kern = svps::mask_decode_hl32_kernel<ARGMAX, ABL>;
-    using Lds = svps::DecHl32Lds;
+    auto kern = svps::mask_decode_hl32_kernel<ARGMAX, ABL, NW>;
+    using Lds = svps::DecHl32LdsT<NW>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
-    int chunks = svps_pick_chunks(T, tiles, 2 * dec_num_cus());       // two co-resident workgroups per CU
+    int chunks = svps_pick_chunks(T, tiles, (NW == 4 ? 2 : 1) * dec_num_cus());       // four waves: two co-resident workgroups per CU
     const int tpc = (tiles + chunks - 1) / chunks;
     chunks = (tiles + tpc - 1) / tpc;
-    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(256), Lds::total, stream, static_cast<const _Float16*>(feat_hi),
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(64 * NW), Lds::total, stream, static_cast<const _Float16*>(feat_hi),
                        static_cast<const _Float16*>(feat_lo), embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, L, HW, tpc);
     return hipGetLastError();
 }
@@ -1257,6 +1266,10 @@ extern "C" int svps_mask_decode_hl_fwd(const void* feat_hi, const void* feat_lo,
         // round 6: 32-pixel tiles, three MFMAs per k-step into one accumulator (mask_decode_hl32_kernel)
         e = slot_argmax ? launch_decode_hl32<true>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
                         : launch_decode_hl32<false>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream);
+    } else if (L > 128 && (HW & 3) == 0 && !old_form && !hl16 && (size_t)L * HW * 4 < 0x7ffffff0u) {
+        // the same kernel with eight waves (up to 256 slots: VIPER's 200), one workgroup per CU
+        e = slot_argmax ? launch_decode_hl32<true, 0, 8>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
+                        : launch_decode_hl32<false, 0, 8>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream);
     } else if (L <= 128 && (HW & 3) == 0 && !old_form) {
         // round 5: the skewed fast path on 16-pixel hi / lo tiles (mask_decode_kernel_v2<.., HL>)
         e = slot_argmax ? launch_decode_v2<true, 4, true, 0, 0, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)

@@ -1525,13 +1525,9 @@ int launch_retr_hl(const void* qh, const void* ql, const float* cy, const float*
                                                         128, L, 0, nullptr, stream_);
         } else {
             float2* st = reinterpret_cast<float2*>(static_cast<char*>(workspace) + partial_bytes);     // partial_bytes is a multiple of 16
-            const RetrPlan pl = plan_retr(T, H, W, 0, 16);
-            auto kstat = svps::retr_logit_stats_kernel<true>;
-            static SvpsLdsAttr attr_s;
-            if (hipError_t ae = attr_s.ensure(reinterpret_cast<const void*>(kstat), svps::LStatsLds::total); ae != hipSuccess) return (int)ae;
-            hipLaunchKernelGGL(kstat, dim3(pl.chunks, T), dim3(512), svps::LStatsLds::total, stream, static_cast<const _Float16*>(qh),
-                               static_cast<const _Float16*>(ql), cy, cx, c3, fh_, a_, st, L, HW, H, W, pl.tiles_per_chunk, 1, fl_);
-            e = hipGetLastError();
+            const RetrPlan pl = plan_retr(T, H, W, 0, svps::kRetrHl32TilePx, 32);
+            e = (hipError_t)svps::retr_logit_stats_hl32_launch(qh, ql, cy, cx, c3, feat, feat_lo, aux, st, T, H, W, pl.chunks, pl.tiles_per_chunk,
+                                                               stream_);
             if (e != hipSuccess) return (int)e;
             e = (hipError_t)svps::retr_attn_hl32_launch(qh, ql, cy, cx, c3, feat, feat_lo, aux, partial, T, 128, H, W, p.chunks,
                                                         p.tiles_per_chunk, 256, L, 0, st, stream_);

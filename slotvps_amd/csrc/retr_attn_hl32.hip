@@ -475,6 +475,253 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     }
 }
 
+// Per-pixel softmax statistics over up to 256 slots in the reference's precision, on the 32-pixel hi / lo tiles of the retriever above
+// (first kernel of the path for more than 128 slots; retr_logit_stats_kernel<true> in retr_attn.hip is the sixteen-pixel form):
+// stats[t, p] = (max_l S[l, p], 1 / sum_l exp2(S[l, p] - max)) with S exactly as retr_attn_hl32_kernel computes it (same fp16 operands,
+// same strip tile order, same position-term handling). Eight waves = eight slot blocks of 32 rows, Q'' hi / lo resident (128 registers),
+// 48 MFMAs per wave and tile (64 per 32 pixels in the sixteen-pixel form). Every wave stages four 1-KiB pieces of every stage (waves 0 .. 3
+// the hi tile, 4 .. 7 the lo tile; LDS-DMA, two stages ahead in a ring of four); wave 7 also stages the Cy row of the tile (1 KiB = 256
+// slots), wave 6 the 32 rstd_k values. ONE barrier per tile: the statistics of the eight blocks are double-buffered and combined at the
+// START of the next iteration (wave w: pixels 4 w .. 4 w + 3). Reads the planes once, writes 8 B per pixel.
+struct LStatsLdsHL32 {
+    static constexpr int kA = 2;                                // stages ahead
+    static constexpr int kNF = kA + 2;                          // tile it (compute), it+1 (landed), it+2 .. it+A+1 in flight
+    static constexpr int kStage = 2 * kTileBytes;
+    static constexpr int ring = 0;
+    static constexpr int yring = kNF * kStage;                  // kNF x 1 KiB Cy rows
+    static constexpr int kring = yring + kNF * 1024;            // kNF x 256 B rstd_k of the tile's pixels (64 lanes x 4 B, lanes >= 32 repeat)
+    static constexpr int stats = kring + kNF * 256;             // [2][8][32] float2
+    static constexpr int total = stats + 2 * 8 * 32 * 8;
+};
+static_assert(LStatsLdsHL32::total <= 160 * 1024, "LDS layout");
+
+__global__ __launch_bounds__(512) void retr_logit_stats_hl32_kernel(
+    const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,  // [T, 256, 256]
+    const float* __restrict__ cy, const float* __restrict__ cx,        // [T, H, 256], [T, W, 256]
+    const float* __restrict__ c3g,                                     // [T, 256]
+    const _Float16* __restrict__ feat, const _Float16* __restrict__ feat_lo,
+    const _Float16* __restrict__ aux,                                  // the 16-byte rows of retr_stats_hl.hip (rstd_k = bytes 8 .. 11)
+    float2* __restrict__ out,                                          // [T, HW]
+    int HW, int H, int W, int tiles_per_chunk) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    using Lds = LStatsLdsHL32;
+    constexpr int NF = Lds::kNF, A = Lds::kA, LP = 256, TPX = 32;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y, c = blockIdx.x;
+    const int tiles = ((W + TPX - 1) / TPX) * H;
+    const int tid0 = c * tiles_per_chunk;
+    int nt = tiles - tid0;
+    nt = nt < tiles_per_chunk ? nt : tiles_per_chunk;
+    const int strip0 = tid0 / H, row0 = tid0 - strip0 * H;
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((SVPS_LDS const void*)smem);
+
+    f16x8 qfh[16], qfl[16];
+    {
+        const size_t row = ((size_t)t * LP + 32 * w + r) * kD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            qfh[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(qh + row + 16 * ks));
+            qfl[ks] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(ql + row + 16 * ks));
+        }
+    }
+    const int slot0 = 32 * w + 4 * h;
+    f32x4 c3v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c3v[g] = *reinterpret_cast<const f32x4*>(c3g + (size_t)t * LP + slot0 + 8 * g);
+    // every register loaded above is consumed (and waited for) HERE: hipcc's wait-count pass does not see the asm waits below and would
+    // otherwise wait for them inside the main loop, where a small vmcnt also waits for the LDS-DMA ring (retr_attn.hip)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(qfh[ks]), "+v"(qfl[ks]));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(c3v[g]));
+    wait_vm<0>();
+
+    const u32x4 cys = ra_make_srd(cy + (size_t)t * H * LP, (uint32_t)(H * LP) * 4u);
+    const u32x4 cxs = ra_make_srd(cx + (size_t)t * W * LP, (uint32_t)(W * LP) * 4u);
+    const u32x4 frs = ra_make_srd((w >= 4 ? feat_lo : feat) + (size_t)t * HW * kD, (uint32_t)HW * kRowBytes);
+    const u32x4 krs = ra_make_srd(aux + (size_t)t * HW * 8, (uint32_t)HW * kAuxRow);
+    const u32x4 ors = ra_make_srd(out + (size_t)t * HW, (uint32_t)HW * 8u);
+    auto ld16 = [](u32x4 srd, int off) {                            // asm + its own wait (no compiler-visible load in the loop)
+        f32x4 v;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(off), "s"(srd) : "memory");
+        return v;
+    };
+    f32x4 cxv[4];
+    auto load_cx = [&](int strip) {
+        int xx = TPX * strip + r;
+        xx = xx < W ? xx : W - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cxv[g] = ld16(cxs, (xx * LP + slot0 + 8 * g) * 4);
+    };
+    load_cx(strip0);
+
+    // ---- staging: waves 0 .. 3 rows 8 w .. 8 w + 7 of the hi tile, waves 4 .. 7 the same rows of the lo tile (four pieces of two rows);
+    // wave 7: the Cy row; wave 6: rstd_k of the 32 pixels
+    const int rb = 8 * (w & 3);
+    int voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = rb + 2 * i + h;
+        voff[i] = row * kRowBytes + (((lane & 31) ^ swz(row)) * 16);
+    }
+    const int nb = 4 + (w >= 6 ? 1 : 0);                            // DMA instructions of one batch of this wave
+    int ds = strip0, dy = row0;
+    auto stage = [&](int tile) {
+        if (tile >= nt) return;
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::ring + (tile % NF) * Lds::kStage + (w >> 2) * kTileBytes + rb * kRowBytes);
+        const int px0 = dy * W + TPX * ds;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + TPX <= HW) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra_dma16(frs, st + i * 1024, voff[i], soff);
+        } else {                                                     // last row of a ragged strip: clamp the source rows (not stored)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = rb + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+            }
+        }
+        if (w == 7) {
+            ra_dma16_cached(cys, __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + (tile % NF) * 1024), dy * LP * 4 + lane * 16);
+        } else if (w == 6) {                                         // 4 B per lane: pixels px0 + (lane & 31), clamped into the frame
+            int px = px0 + (lane & 31);
+            px = px < HW ? px : HW - 1;
+            uint32_t keep;
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + Lds::kring + (tile % NF) * 256);
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %1\n\t"
+                "s_nop 0\n\t"
+                "buffer_load_dword %2, %3, 0 offen lds\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "s"(dst), "v"(px * kAuxRow + 8), "s"(krs)
+                : "memory");
+        }
+        ++dy;
+        if (dy == H) { dy = 0; ++ds; }
+    };
+    float2* stats = reinterpret_cast<float2*>(smem + Lds::stats);
+    // statistics of tile `tile` (strip fs, row fy): wave w combines the eight blocks for pixels 4w .. 4w+3 and stores them. The
+    // store is ALWAYS issued (out-of-range offset when there is nothing to store): the counted vmcnt waits rely on it.
+    int fs = strip0, fy = row0;
+    auto combine = [&](int tile) {
+        const bool have = tile >= 0;
+        float mall = kNegBig;
+        float2 st_w[8];
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) {
+            st_w[ww] = stats[((tile & 1) * 8 + ww) * 32 + r];
+            mall = fmaxf(mall, st_w[ww].x);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) den += st_w[ww].y * __builtin_amdgcn_exp2f(st_w[ww].x - mall);
+        const int xx = TPX * fs + r;
+        const int pxs = fy * W + xx;
+        const bool mine = have && h == 0 && (r >> 2) == w && xx < W;
+        const f32x2 val = {mall, 1.f / den};
+        const int so = mine ? pxs * 8 : 0x7ffffff0;                  // out of range -> dropped by the hardware range check
+        asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" : : "v"(val), "v"(so), "s"(ors) : "memory");
+        if (have) {
+            ++fy;
+            if (fy == H) { fy = 0; ++fs; }
+        }
+    };
+
+    // ---- prologue: batches 0 .. A in flight; tile 0 landed
+#pragma unroll
+    for (int b = 0; b <= A; ++b) stage(b);
+    {
+        int younger = nt - 1;
+        younger = younger < 0 ? 0 : (younger > A ? A : younger);
+        wait_vm_dyn(nb * younger);
+    }
+    const uint32_t lane_row = lds0 + Lds::ring + r * kRowBytes + ((h ^ swz(r)) << 4);
+    auto frag = [&](uint32_t tb, int ks) {
+        return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
+    };
+    int ts = strip0, ty = row0;
+    for (int it = 0; it <= nt; ++it) {
+        wg_barrier();                                                // B(it): tile it has landed for every wave; the statistics of tile it-1 are in LDS
+        combine(it - 1);
+        if (it == nt) break;
+        const uint32_t tb = lane_row + (uint32_t)(it % NF) * Lds::kStage;
+        f16x8 kf[2][4];
+        auto load_grp = [&](int buf, int g) {
+            kf[buf][0] = frag(tb, g);
+            kf[buf][1] = frag(tb, g + 8);
+            kf[buf][2] = frag(tb + kTileBytes, g);
+            kf[buf][3] = frag(tb + kTileBytes, g + 8);
+        };
+        load_grp(0, 0);
+        // Cy row and rstd_k of the tile (staged with it)
+        f32x16 s;
+        {
+            const float* cyl = reinterpret_cast<const float*>(smem + Lds::yring + (it % NF) * 1024) + slot0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 cyv = *reinterpret_cast<const f32x4*>(cyl + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[4 * g + j] = cyv[j] + cxv[g][j];
+            }
+        }
+        const float rk = *reinterpret_cast<const float*>(smem + Lds::kring + (it % NF) * 256 + r * 4) * kLog2e;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g < 7) load_grp((g + 1) & 1, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ks = g + 8 * u;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[ks], kf[g & 1][u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[g & 1][2 + u], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[g & 1][u], s, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stage(it + A + 1);                                           // its stage held tile it-1, which every wave left before B(it)
+        float mloc = kNegBig;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[4 * g + j] = fmaf(rk, s[4 * g + j], c3v[g][j]);    // padded rows: c3' = -1e30
+                mloc = fmaxf(mloc, s[4 * g + j]);
+            }
+        mloc = ra_half_swap_max(mloc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(s[i] - mloc);
+        float sl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sl[i] = (s[i] + s[4 + i]) + (s[8 + i] + s[12 + i]);
+        const float sloc = ra_half_swap_sum((sl[0] + sl[1]) + (sl[2] + sl[3]));
+        if (h == 0) stats[((it & 1) * 8 + w) * 32 + r] = make_float2(mloc, sloc);
+        // tile it+1: this wave's pieces landed. Younger operations than its batch: the batches it+2 .. it+A+1 and the stores of combine()
+        // of the iterations in between
+        if (it >= A + 1 && it + A + 1 < nt) wait_vm_dyn(A * (nb + 1));
+        else wait_vm<0>();
+        ++ty;
+        if (ty == H) { ty = 0; ++ts; if (it + 1 < nt) load_cx(ts); }
+    }
+}
+
+int retr_logit_stats_hl32_launch(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3, const void* feat_hi,
+                                 const void* feat_lo, const void* aux, void* stats, int T, int H, int W, int chunks, int tiles_per_chunk,
+                                 void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    auto kern = retr_logit_stats_hl32_kernel;
+    static SvpsLdsAttr attr;
+    if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), LStatsLdsHL32::total); ae != hipSuccess) return (int)ae;
+    hipLaunchKernelGGL(kern, dim3(chunks, T), dim3(512), LStatsLdsHL32::total, stream, static_cast<const _Float16*>(qh),
+                       static_cast<const _Float16*>(ql), cy, cx, c3, static_cast<const _Float16*>(feat_hi), static_cast<const _Float16*>(feat_lo),
+                       static_cast<const _Float16*>(aux), static_cast<float2*>(stats), H * W, H, W, tiles_per_chunk);
+    return (int)hipGetLastError();
+}
+
 int retr_attn_hl32_launch(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3, const void* feat_hi,
                           const void* feat_lo, const void* aux, float* partial, int T, int L, int H, int W, int chunks, int tiles_per_chunk,
                           int LP, int Lrow, int slot_off, const void* ext_stats, void* stream_) {

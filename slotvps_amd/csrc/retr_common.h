@@ -67,4 +67,9 @@ int retr_attn_hl32_launch(const void* qh, const void* ql, const float* cy, const
                           const void* feat_lo, const void* aux, float* partial, int T, int L, int H, int W, int chunks, int tiles_per_chunk,
                           int LP, int Lrow, int slot_off, const void* ext_stats, void* stream);
 
+// the logit statistics of the more-than-128-slot path on the same tiles ([T, HW] of (max, 1 / sum) over the 256 slot rows of the layout)
+int retr_logit_stats_hl32_launch(const void* qh, const void* ql, const float* cy, const float* cx, const float* c3, const void* feat_hi,
+                                 const void* feat_lo, const void* aux, void* stats, int T, int H, int W, int chunks, int tiles_per_chunk,
+                                 void* stream);
+
 }  // namespace svps

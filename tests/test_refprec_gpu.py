@@ -208,7 +208,10 @@ def test_retriever_hl_vs_float64_oracle(cuda, T, H, W, L, pos):
 def test_mask_decode_hl(cuda):
     from slotvps_amd import ops
     rng = np.random.default_rng(3)
-    for T, HW, L in ((2, 203, 100), (1, 64, 128), (1, 97, 200), (2, 2060, 100), (3, 4096, 37), (1, 20, 2)):    # HW % 4 == 0, L <= 128: the skewed fast path on 16-pixel hi / lo tiles (ragged last tile: 2060 = 128 x 16 + 12)
+    # HW % 4 == 0: the 32-pixel hi / lo tile kernel (four waves up to 128 slots, eight up to 256; ragged last tile: 2060 = 64 x 32 + 12);
+    # otherwise the first-generation kernel
+    for T, HW, L in ((2, 203, 100), (1, 64, 128), (1, 97, 200), (2, 2060, 100), (3, 4096, 37), (1, 20, 2), (2, 2060, 200), (1, 64, 129),
+                     (1, 4096, 256), (2, 36, 193)):
         feat = (2.0 * rng.standard_normal((T, HW, 256))).astype(np.float32)
         emb = np.abs(rng.standard_normal((T, L, 256))).astype(np.float32)
         sc = rng.uniform(0.5, 1.5, 256).astype(np.float32)
