@@ -782,9 +782,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
 //   * LDS: 2 stages x 32 KiB + a [16 slots][32 px] transpose tile per wave (the logits leave in two halves) = 78 KiB: two workgroups per CU.
 // Same skew as the fast path: the epilogue of tile it - 1 rides in the shadow of the chain of tile it; norms double-buffered by parity.
 // NW = 4 waves (up to 128 slots, two workgroups per CU) or 8 (up to 256 slots - VIPER's 200 -, one workgroup per CU: the same eight waves).
-template <int NW>
+#ifndef SVPS_K2_HL32_W8_STAGES
+#define SVPS_K2_HL32_W8_STAGES 2       // (3 measured 1 % slower at the VIPER shape: the eight-wave form is bound by its own work per pixel, not by landing waits)
+#endif
+template <int NW, int NST = 2>
 struct DecHl32LdsT {
-    static constexpr int kStages = 2;
+    static constexpr int kStages = NST;
     static constexpr int kStageBytes = 2 * kTileBytes;               // hi tile, then lo tile
     static constexpr int ring = 0;
     static constexpr int kORow = 144;                                // [16 slots][32 px] fp32 per wave, rows padded to 144 B
@@ -797,16 +800,18 @@ struct DecHl32LdsT {
     static constexpr int total = amax + 2 * NW * kTilePx * 8;
 };
 using DecHl32Lds = DecHl32LdsT<4>;
-static_assert(2 * DecHl32Lds::total <= 160 * 1024 && DecHl32LdsT<8>::total <= 160 * 1024, "two workgroups of four waves / one of eight per CU");
+static_assert(2 * DecHl32Lds::total <= 160 * 1024 && DecHl32LdsT<8, 3>::total <= 160 * 1024, "two workgroups of four waves / one of eight per CU");
 
-template <bool ARGMAX, int ABL = 0, int NW = 4>
+// NSTG stages = NSTG - 1 tiles requested ahead: 2 for the four-wave form (two workgroups per CU hide each other's landing waits); the
+// eight-wave form (one workgroup per CU) measured the same with 2 and 3 (SVPS_K2_HL32_W8_STAGES)
+template <bool ARGMAX, int ABL = 0, int NW = 4, int NSTG = 2>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_hl32_kernel(
     const _Float16* __restrict__ feat_hi, const _Float16* __restrict__ feat_lo, const float* __restrict__ embed,
     const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, float fg_scale, float fg_shift, float* __restrict__ out,
     uint8_t* __restrict__ slot_argmax, int L, int HW, int tiles_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using Lds = DecHl32LdsT<NW>;
-    constexpr int NT = 64 * NW, NST = Lds::kStages;
+    using Lds = DecHl32LdsT<NW, NSTG>;
+    constexpr int NT = 64 * NW, NST = Lds::kStages, DST = NST - 1;     // DST: tiles requested ahead
     constexpr int PCW = 32 / NW;                                   // 1-KiB DMA pieces per wave and tile
     constexpr int HWV = NW / 2;                                    // waves per plane
     constexpr int TP = NT / kTilePx;                               // the norm's threads per pixel (8 or 16)
@@ -899,7 +904,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_hl32_ker
             }
         }
     };
-    stage(0);
+#pragma unroll
+    for (int d = 0; d < DST; ++d) stage(d);
 
     // fragment addresses: chunk (2 ks + h) ^ swz(r) for ks = 0 .. 7; ks + 8 is + 256 B, the lo tile + kTileBytes (immediates)
     int fa[8];
@@ -915,14 +921,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_hl32_ker
 
     auto body = [&](const int it, auto has_chain, auto has_epi) {
         constexpr bool CH = decltype(has_chain)::value, EP = decltype(has_epi)::value && !(ABL & 4);
-        // issue order per iteration: DMA(it + 1) x 8, argmax store of tile it - 2, mask stores of tile it - 1 x 4. Younger than DMA(it): the
-        // stores of iteration it - 1 (if it had an epilogue)
+        // issue order per iteration: DMA(it + DST) x PCW, argmax store of tile it - 2, mask stores of tile it - 1 x 4. Younger than DMA(it)
+        // (requested in iteration it - DST): the stores of iterations it - DST .. it - 1 (if they had an epilogue) and the requests of tiles
+        // it + 1 .. it + DST - 1 that exist
         if constexpr (CH) {
-            if (it >= 2) wait_vm<kMS + kAS>();
-            else wait_vm<0>();
+            if constexpr (DST == 1) {
+                if (it >= 2) wait_vm<kMS + kAS>();
+                else wait_vm<0>();
+            } else {
+                int younger = nt - 1 - it;
+                younger = younger < DST - 1 ? younger : DST - 1;
+                if (it >= DST + 1) wait_vm_dyn(DST * (kMS + kAS) + PCW * younger);
+                else wait_vm<0>();
+            }
         }
         wg_barrier();
-        if constexpr (CH) stage(it + 1);
+        if constexpr (CH) stage(it + DST);
         const char* fth = smem + Lds::ring + (it % NST) * Lds::kStageBytes;
 
         if constexpr (CH) {   // fg_scale / ||scale (f_hi + f_lo) + shift|| per pixel: TP = 8 (16) threads per pixel, 4 (2) chunks each
@@ -1127,11 +1141,11 @@ hipError_t launch_decode_v2(const void* feat, const float* embed, const float* b
     return hipGetLastError();
 }
 
-template <bool ARGMAX, int ABL = 0, int NW = 4>
+template <bool ARGMAX, int ABL = 0, int NW = 4, int NSTG = 2>
 hipError_t launch_decode_hl32(const void* feat_hi, const void* feat_lo, const float* embed, const float* bn_scale, const float* bn_shift,
                               float fg_scale, float fg_shift, float* out, uint8_t* slot_argmax, int T, int L, int HW, hipStream_t stream) {
-    auto kern = svps::mask_decode_hl32_kernel<ARGMAX, ABL, NW>;
-    using Lds = svps::DecHl32LdsT<NW>;
+    auto kern = svps::mask_decode_hl32_kernel<ARGMAX, ABL, NW, NSTG>;
+    using Lds = svps::DecHl32LdsT<NW, NSTG>;
     static SvpsLdsAttr attr;
     if (hipError_t ae = attr.ensure(reinterpret_cast<const void*>(kern), Lds::total); ae != hipSuccess) return ae;
     const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
@@ -1268,8 +1282,8 @@ extern "C" int svps_mask_decode_hl_fwd(const void* feat_hi, const void* feat_lo,
                         : launch_decode_hl32<false>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream);
     } else if (L > 128 && (HW & 3) == 0 && !old_form && !hl16 && (size_t)L * HW * 4 < 0x7ffffff0u) {
         // the same kernel with eight waves (up to 256 slots: VIPER's 200), one workgroup per CU
-        e = slot_argmax ? launch_decode_hl32<true, 0, 8>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
-                        : launch_decode_hl32<false, 0, 8>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream);
+        e = slot_argmax ? launch_decode_hl32<true, 0, 8, SVPS_K2_HL32_W8_STAGES>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream)
+                        : launch_decode_hl32<false, 0, 8, SVPS_K2_HL32_W8_STAGES>(feat_hi, feat_lo, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream);
     } else if (L <= 128 && (HW & 3) == 0 && !old_form) {
         // round 5: the skewed fast path on 16-pixel hi / lo tiles (mask_decode_kernel_v2<.., HL>)
         e = slot_argmax ? launch_decode_v2<true, 4, true, 0, 0, H, true>(feat_hi, embed, bn_scale, bn_shift, fg_scale, fg_shift, out, slot_argmax, T, L, HW, stream, feat_lo)
