@@ -243,7 +243,7 @@ class SlotClipRunner:
         if getattr(self.head, "precision", "bf16") == "fp16x2":
             # reference precision on the matrix cores: the maps are 1 KiB per pixel (fp16 hi + lo planes). Algorithmic flops = one product
             # per multiply; executed = the MFMAs issued (three per product in K4 / K3-HL / K2; K1'-HL32, round 6: 4 x 48 producer + 4 x 52
-            # consumer per 32-pixel tile - 4 x 32 + 4 x 26 per SIXTEEN pixels before; more than 128 slots: two passes + the logit statistics).
+            # consumer per 32-pixel tile - 4 x 32 + 4 x 26 per SIXTEEN pixels before; more than 128 slots: two passes + 8 x 48 of the logit statistics).
             # K3-HL reads both planes once per stage; K4-HL: K = 128 products only (composed weights).
             tabs = sum(n * (h + w) * 128 * 4 for (h, w), n in zip(self.sizes, self.cfg["per_dh_num_heads"]))
             return {
@@ -258,7 +258,7 @@ class SlotClipRunner:
                 "retr_stats": {"bytes": T * ps * (1024 + 16), "flops": T * ps * int(2 * 36 / 64 * 2 * D * D),
                                "executed_flops": T * ps * 3 * int(2 * 36 / 64 * 2 * D * D)},
                 "retr_attn": {"bytes": T * (ps * (1024 + 16) + stages * (L * D * 4 + L * 260 * 4) + tabs), "flops": T * ps * 4 * L * D,
-                              "executed_flops": T * ps * ((400 if L <= 128 else 2 * 400 + 256) * 32768 // 32)},
+                              "executed_flops": T * ps * ((400 if L <= 128 else 2 * 400 + 8 * 48) * 32768 // 32)},
             }
         out = {
             "level_fuse": {"bytes": T * sum(hw * ((768 if self.input_form == "tower16" else 1024) + (128 if i else 0)) for i, hw in enumerate(px)),
