@@ -177,11 +177,12 @@ def _module(cuda, seed):
 @pytest.mark.parametrize("T,H,W,L,pos", [(2, 8, 32, 100, True), (1, 16, 64, 128, True), (1, 5, 20, 37, True), (2, 34, 60, 100, True),
                                          (1, 3, 64, 1, False), (1, 40, 16, 100, True), (3, 9, 40, 100, True), (1, 7, 7, 64, True),
                                          (2, 34, 60, 200, True), (1, 8, 32, 129, True), (1, 5, 20, 256, True), (1, 16, 64, 200, False),
-                                         (1, 20, 512, 100, True)])      # 320 tiles of 32 pixels on 256 CUs: workgroups of two tiles that cross column strips (K3-HL)
+                                         (1, 20, 512, 100, True),       # 320 tiles of 32 pixels on 256 CUs: workgroups of two tiles that cross column strips (K3-HL)
+                                         (8, 4, 96, 100, True), (1, 1, 33, 100, True), (1, 2, 33, 200, True)])   # round 6 (32-pixel tiles): frames in multiples of eight (XCD placement), one-row maps, a second strip of ONE pixel
 def test_retriever_hl_vs_float64_oracle(cuda, T, H, W, L, pos):
-    """MaskDynamicConv.forward (:423-461) in the fp16x2 form - statistics with hi + lo factors and map (K3t-HL), the retriever on 16-pixel
-    hi / lo tiles with hi + lo probabilities (K1'-HL), fp16-split query side - against the float64 oracle on the SAME map (the exact sum of
-    the planes): aligned, ragged (W % 16 != 0) and narrow (W < 16) strips, 1 ... 256 slots (more than 128: statistics over all slots +
+    """MaskDynamicConv.forward (:423-461) in the fp16x2 form - statistics with hi + lo factors and map (K3t-HL), the retriever on 32-pixel
+    hi / lo tiles with hi + lo probabilities (K1'-HL32), fp16-split query side - against the float64 oracle on the SAME map (the exact sum of
+    the planes): aligned, ragged (W % 32 != 0) and narrow (W < 32) strips, 1 ... 256 slots (more than 128: statistics over all slots +
     one retriever launch per half of the slots)."""
     import torch
     from slotvps_amd import ops
