@@ -476,8 +476,8 @@ int svps_retr_attn_fwd(const void* qh, const void* ql, const float* cy, const fl
  *                              32 pixels of a tile is one contiguous KiB
  *   svps_retr_attn_hl_fwd    = svps_retr_attn_fwd (:435-456) with hi + lo probabilities on the planes, 1 <= L <= 256 (more than 128 slots: the
  *                              per-pixel softmax statistics over all slots first, 8 B per pixel in the workspace, then the retriever once per
- *                              half of the slots); tiles of 16 pixels (hi rows + lo rows of
- *                              the same pixels share one LDS tile); workspace svps_retr_attn_hl_workspace_bytes()
+ *                              half of the slots); tiles of 32 pixels, a hi tile and a lo tile per LDS stage (round 6:
+ *                              slotvps_amd/csrc/retr_attn_hl32.hip); workspace svps_retr_attn_hl_workspace_bytes()
  *   svps_mask_decode_hl_fwd  = svps_mask_decode_fwd (vps_temporal_slots.py:144-160) on the planes: fp32 logits [T, L, HW] (required),
  *                              optional fused slot argmax [T, HW]; any HW, L <= 256
  * Same rules as everywhere: no allocation, no synchronisation, launched on `stream`, 0 or an error code.
