@@ -49,6 +49,18 @@ typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef SVPS_RETR_HL32_PREFETCH
 #define SVPS_RETR_HL32_PREFETCH 2
 #endif
+#ifndef SVPS_RETR_HL32_SUB
+#define SVPS_RETR_HL32_SUB 1        // consumers: channel blocks per sub-step (1: four fragment buffers, three sub-steps ahead; 2: two buffers, one ahead)
+#endif
+#ifndef SVPS_RETR_HL32_PSUB
+#define SVPS_RETR_HL32_PSUB 0       // producers: 1 = one k-step per fragment buffer, three k-steps ahead; 0 = groups of two k-steps, one group ahead
+#endif
+#ifndef SVPS_RETR_HL32_B0
+#define SVPS_RETR_HL32_B0 0         // 1: a third barrier behind the producers' chain; the consumers run SVPS_RETR_HL32_PRE steps beside the chain
+#endif
+#ifndef SVPS_RETR_HL32_PRE
+#define SVPS_RETR_HL32_PRE 0
+#endif
 #ifndef SVPS_RETR_HL32_SPLIT
 #define SVPS_RETR_HL32_SPLIT 4      // consumer steps (of 8) in front of B1
 #endif
@@ -175,6 +187,22 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         auto frag = [&](uint32_t tb, int ks) {
             return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
         };
+#if SVPS_RETR_HL32_PSUB
+        // one k-step (its hi and its lo fragment) per buffer, four buffers: the fragments of k-steps ks + 1 .. ks + 3 are in flight beside the three
+        // MFMAs of k-step ks (the same 32 registers as two groups of two k-steps, half as far ahead again)
+        f16x8 kf[4][2];
+        auto load_ks = [&](uint32_t tb, int ks) {
+            kf[ks & 3][0] = frag(tb, ks);
+            kf[ks & 3][1] = frag(tb + kTileBytes, ks);
+        };
+        f32x2 rt = {0.f, 0.f};
+        auto prefetch = [&](int tile) {                             // the first three k-steps and (rstd_k, rstd_v) of a tile
+            const uint32_t slot = (uint32_t)(tile % NF);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) load_ks(lane_row + slot * Lds::kStage, ks);
+            rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + slot * kAuxTile + r * kAuxRow + 8));
+        };
+#else
         // fragment group g: k-steps g and g + 8 of the hi tile, then of the lo tile (one address, four immediate offsets)
         f16x8 kf[2][4];
         auto load_grp = [&](int buf, uint32_t tb, int g) {
@@ -189,6 +217,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             load_grp(0, lane_row + slot * Lds::kStage, 0);
             rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + slot * kAuxTile + r * kAuxRow + 8));
         };
+#endif
 
         constexpr bool kRun = ABL != 1 && ABL != 4;
         wg_barrier();                                               // B(start): batch 0 and the Cy row of tile 0 landed
@@ -207,6 +236,31 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                 f32x16 s;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#if SVPS_RETR_HL32_PSUB
+                // ---- chain: sixteen k-steps of three MFMAs, fragments three k-steps ahead; d in pieces under k-steps 1, 3, 5, 7
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    if (ks + 3 < 16) load_ks(tb, ks + 3);
+                    if ((ks & 1) && ks < 8) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            d[ks >> 1][j] = fmaf(rk_c, cxv[ks >> 1][j] + cyq[j], c3q[j]);
+                            asm volatile("" : "+v"(d[ks >> 1][j]));     // HERE, under this k-step's MFMAs (hipcc otherwise sinks it into the head)
+                        }
+                    }
+                    if (!(ks & 1) && ks < 8) {
+                        cyq = *reinterpret_cast<const f32x4*>(cyl + 8 * (ks >> 1));
+                        c3q = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * (ks >> 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef SVPS_R32_SKIP_QLO                                              // (timing experiments only)
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[ks], kf[ks & 3][0], s, 0, 0, 0);
+#endif
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[ks & 3][1], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[ks & 3][0], s, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#else
                 // ---- chain: eight groups of two k-steps, three MFMAs per k-step; the reads of group g + 1 in the shadow of group g
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
@@ -233,6 +287,10 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
+#if SVPS_RETR_HL32_B0
+                wg_barrier();                                       // B0(it): the chain is through - the consumers' MFMAs start here
+#endif
                 R32_STAMP(0, 1);
                 // ---- softmax head: log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no
                 // masking: their Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep): they exp2 to exactly 0
@@ -308,6 +366,9 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                 }
                 R32_STAMP(0, 4);
             } else {
+#if SVPS_RETR_HL32_B0
+                wg_barrier();                                       // B0(it)
+#endif
                 wg_barrier();                                       // B1(it)
             }
             wg_barrier();                                           // B2(it)
@@ -382,21 +443,26 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16(reinterpret_cast<SVPS_LDS fp16x4_gcc*>((uintptr_t)a)));
     };
     auto cat = [](f16x4 a, f16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); };
-    f16x8 ah[2], al[2], af[2], vh[2][2], vl[2][2];
+    // A += P f in sub-steps of kSB channel blocks (k-step = pixels 0 .. 15 / 16 .. 31 first, then the blocks); NVB value-fragment buffers: the
+    // fragments of sub-steps q + 1 .. q + NVB - 1 are in flight beside sub-step q. A "step" of the split points = two blocks (six MFMAs).
+    constexpr int kSB = SVPS_RETR_HL32_SUB;                     // channel blocks per sub-step: 2 (two buffers) or 1 (four buffers, the same registers)
+    constexpr int NVB = 4 / kSB;
+    constexpr int kNQ = 16 / kSB;                               // sub-steps per tile
+    f16x8 ah[2], al[2], af[2], vh[NVB][kSB], vl[NVB][kSB];
     uint32_t v0 = 0, v1 = 0;
     auto vfrag = [&](int lo, int ks, int db) {
         const uint32_t o_ = kTileBytes * lo + 8192 * ks + 256 * (db >> 2);
         return cat(tr((v0 ^ ((db & 3) << 6)) + o_), tr((v1 ^ ((db & 3) << 6)) + o_));
     };
-    auto load_step = [&](int buf, int q) {                       // step q = (k-step q >> 2, channel blocks 2 (q & 3), + 1)
-        const int ks = q >> 2, db = 2 * (q & 3);
+    auto load_step = [&](int buf, int q) {
+        const int ks = q / (8 / kSB), db = kSB * (q % (8 / kSB));
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < kSB; ++u) {
             vh[buf][u] = vfrag(0, ks, db + u);
             vl[buf][u] = vfrag(1, ks, db + u);
         }
     };
-    auto pv_begin = [&](int j) {                                 // every fragment of P(j) (the P tiles are free again at B1), the aux rows, step 0
+    auto pv_begin = [&](int j) {                                 // every fragment of P(j) (the P tiles are free again at B1), the aux rows, the first sub-steps
         const uint32_t vt = lds0 + Lds::fring + (j % NF) * Lds::kStage;
         const uint32_t aa = lds0 + Lds::aring + (j % NF) * kAuxTile + lane_a;
         v0 = vt + lane_v0, v1 = vt + lane_v1;
@@ -406,24 +472,25 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             al[ks] = cat(tr(p0 + kPLo + 1024 * ks), tr(p1 + kPLo + 1024 * ks));
             af[ks] = cat(tr(aa + 16 * ks * kAuxRow), tr(aa + (16 * ks + 4) * kAuxRow));
         }
-        load_step(0, 0);
+#pragma unroll
+        for (int q = 0; q < NVB - 1; ++q) load_step(q, q);
     };
     auto pv_steps = [&](auto lo_tag, auto hi_tag) {              // steps [Q0, Q1) of A += P f: six MFMAs each (+ two of the aux block per k-step)
-        constexpr int Q0 = decltype(lo_tag)::value, Q1 = decltype(hi_tag)::value;
+        constexpr int Q0 = decltype(lo_tag)::value * (2 / kSB), Q1 = decltype(hi_tag)::value * (2 / kSB);
 #pragma unroll
         for (int q = Q0; q < Q1; ++q) {
-            const int ks = q >> 2, db = 2 * (q & 3);
-            if (q < 7) load_step((q + 1) & 1, q + 1);
+            const int ks = q / (8 / kSB), db = kSB * (q % (8 / kSB));
+            if (q + NVB - 1 < kNQ) load_step((q + NVB - 1) % NVB, q + NVB - 1);
             __builtin_amdgcn_sched_barrier(0);
 #ifndef SVPS_R32_SKIP_PLO                                              // (timing experiments only)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], vh[q & 1][u], o[db + u], 0, 0, 0);
+            for (int u = 0; u < kSB; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], vh[q % NVB][u], o[db + u], 0, 0, 0);
 #endif
 #pragma unroll
-            for (int u = 0; u < 2; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vl[q & 1][u], o[db + u], 0, 0, 0);
+            for (int u = 0; u < kSB; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vl[q % NVB][u], o[db + u], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vh[q & 1][u], o[db + u], 0, 0, 0);
-            if ((q & 3) == 0) {
+            for (int u = 0; u < kSB; ++u) o[db + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], vh[q % NVB][u], o[db + u], 0, 0, 0);
+            if (db == 0) {
                 oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], af[ks], oa, 0, 0, 0);
                 oa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], af[ks], oa, 0, 0, 0);
             }
@@ -434,6 +501,10 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     using I0 = std::integral_constant<int, 0>;
     using IS = std::integral_constant<int, kSplit>;
     using I8 = std::integral_constant<int, 8>;
+#if SVPS_RETR_HL32_B0
+    using IP = std::integral_constant<int, SVPS_RETR_HL32_PRE>;
+    static_assert(SVPS_RETR_HL32_PRE <= kSplit, "steps beside the chain <= steps in front of B1");
+#endif
     constexpr bool kWork = ABL != 1 && ABL != 2;
 
     if (A - 1 < nt) wait_vm_dyn(nb * (A - 1));                   // batch 0 (and the Cy row of tile 0) landed
@@ -444,6 +515,15 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         R32_STAMP(1, 0);
         if (work) pv_begin(it - 1);
         issue_batch(it + A);
+#if SVPS_RETR_HL32_B0
+        if (work) pv_steps(I0{}, IP{});                          // (SVPS_RETR_HL32_PRE steps beside the producers' chain)
+        if (it + A < nt) wait_vm_dyn(nb * (A - 1));              // batch it+1 landed for this wave
+        else wait_vm<0>();
+        wg_barrier();                                            // B0(it): the producers' chains are through - the matrix pipe is the consumers'
+        if (work) pv_steps(IP{}, IS{});
+        R32_STAMP(1, 1);
+        R32_STAMP(1, 2);
+#else
         if (work) pv_steps(I0{}, IS{});
         R32_STAMP(1, 1);
         // batch it+1 landed for this wave (the producers read its first fragments behind B1): all but the A - 1 youngest batches
@@ -452,6 +532,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             else wait_vm<0>();
         } else if (it + 4 * A < nt) wait_vm_dyn(nb * (4 * A - 1));  // (timing only: the landing wait never binds)
         R32_STAMP(1, 2);
+#endif
         wg_barrier();                                            // B1(it)
         R32_STAMP(1, 3);
         if (work) pv_steps(IS{}, I8{});
