@@ -45,6 +45,9 @@
                             // parity goes from the reference's own reproducibility (mask logits 8.7e-6, stages <= 2.7e-5) to 2.9e-5 / 4.9e-5 (sharp
                             // case 3.3e-4 -> 8.1e-4): inside the tolerance, not adopted - the mode's point is to be indistinguishable from the reference
 #endif
+#ifndef SVPS_SHL_AHEAD
+#define SVPS_SHL_AHEAD 2    // operand fragments requested this many k-steps ahead of their MFMAs
+#endif
 #ifndef SVPS_SHL_PRIO
 #define SVPS_SHL_PRIO 1     // tiled-tables form: 1 = s_setprio 1 around each chain, 2 = static s_setprio 1 for the value waves (the younger half), 0 none
 #endif
@@ -272,19 +275,19 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
         };
         // fragments TWO k-steps ahead of their MFMAs (a k-step of one row block is three MFMAs = 96 cycles, less than an LDS round trip under
         // load); the fences keep hipcc from hoisting all sixteen k-steps' reads to the top of the tile
-        sh_f16x8 fh[3], fl[3];
-        fh[K0 % 3] = frag(xh, K0);
-        fl[K0 % 3] = frag(xl, K0);
-        if (K0 + 1 < 16) {
-            fh[(K0 + 1) % 3] = frag(xh, K0 + 1);
-            fl[(K0 + 1) % 3] = frag(xl, K0 + 1);
+        constexpr int AH = SVPS_SHL_AHEAD, NB = AH + 1;         // k-steps ahead (2; 3 and 4 measured in round 6: profiles/r06/README.md)
+        sh_f16x8 fh[NB], fl[NB];
+#pragma unroll
+        for (int k = K0; k < K0 + AH && k < 16; ++k) {
+            fh[k % NB] = frag(xh, k);
+            fl[k % NB] = frag(xl, k);
         }
         if (TLDS && SVPS_SHL_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = K0; ks < 16; ++ks) {
-            if (ks + 2 < 16) {
-                fh[(ks + 2) % 3] = frag(xh, ks + 2);
-                fl[(ks + 2) % 3] = frag(xl, ks + 2);
+            if (ks + AH < 16) {
+                fh[(ks + AH) % NB] = frag(xh, ks + AH);
+                fl[(ks + AH) % NB] = frag(xl, ks + AH);
             }
             constexpr bool kVLo = KEY || !(SVPS_SHL_EXP & 1);      // EXPERIMENT bit 0: the value statistic without its R_lo x_hi term
             // bits 1 / 2 (round 6): the value / key statistic without its R_hi x_lo term - the MAP's low part, an error that is independent
@@ -292,14 +295,14 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
             // levels a slot owns ~20 pixels, nothing averages out (profiles/r06/README.md)
             constexpr bool kXLo = KEY ? !(SVPS_SHL_EXP & 4) : !(SVPS_SHL_EXP & 2);
             if (ks >= KA && !(SVPS_SHL_ABL & 2)) {
-                if (kVLo) ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wla[ks - KA], fh[ks % 3], ca, 0, 0, 0);
-                if (kXLo) ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fl[ks % 3], ca, 0, 0, 0);
-                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fh[ks % 3], ca, 0, 0, 0);
+                if (kVLo) ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wla[ks - KA], fh[ks % NB], ca, 0, 0, 0);
+                if (kXLo) ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fl[ks % NB], ca, 0, 0, 0);
+                ca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wha[ks - KA], fh[ks % NB], ca, 0, 0, 0);
             }
             if (ks >= KB && !(SVPS_SHL_ABL & 2)) {
-                if (kVLo) cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlb[ks - KB], fh[ks % 3], cb, 0, 0, 0);
-                if (kXLo) cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fl[ks % 3], cb, 0, 0, 0);
-                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fh[ks % 3], cb, 0, 0, 0);
+                if (kVLo) cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlb[ks - KB], fh[ks % NB], cb, 0, 0, 0);
+                if (kXLo) cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fl[ks % NB], cb, 0, 0, 0);
+                cb = __builtin_amdgcn_mfma_f32_32x32x16_f16(whb[ks - KB], fh[ks % NB], cb, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
