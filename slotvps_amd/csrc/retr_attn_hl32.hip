@@ -52,6 +52,9 @@ typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef SVPS_RETR_HL32_SUB
 #define SVPS_RETR_HL32_SUB 1        // consumers: channel blocks per sub-step (1: four fragment buffers, three sub-steps ahead; 2: two buffers, one ahead)
 #endif
+#ifndef SVPS_RETR_HL32_ILV
+#define SVPS_RETR_HL32_ILV 0        // consumers: 1 = the nine LDS-DMA pieces of a batch between the first sub-steps (measured 9.5 % slower); 0: all in front of them
+#endif
 #ifndef SVPS_RETR_HL32_PSUB
 #define SVPS_RETR_HL32_PSUB 0       // producers: 1 = one k-step per fragment buffer, three k-steps ahead; 0 = groups of two k-steps, one group ahead
 #endif
@@ -390,32 +393,45 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     }
     const int nb = 8 + ((sb == 0 || sb == 2) ? 1 : 0);           // DMA instructions of one batch of this wave
     int ds = strip0, dy = row0;                                  // strip / image row of the next batch
-    auto issue_batch = [&](int b) {
-        if (b >= nt) return;
-        if (ABL == 8 && b >= NF) return;                         // timing only: no memory traffic behind the first ring fill
-        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % NF) * Lds::kStage + pl_ * kTileBytes + rb * kRowBytes);
-        const int px0 = dy * W + TPX * ds;
-        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
-        if (px0 + TPX <= HW) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ra_dma16(frs, st + i * 1024, voff[i], soff);
-        } else {                                                 // last row of a ragged strip: clamp the source rows (their P is 0)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = rb + 2 * i + h;
-                const int src = px0 + row < HW ? row : HW - 1 - px0;
-                ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
-            }
-        }
+    // a batch = nine 1-KiB pieces of this wave (eight feature pieces, the aux tile or the Cy row); begin_batch fixes its addresses. The pieces go
+    // out in a row in front of the tile's MFMAs; spreading them between the first sub-steps of A += P f (SVPS_RETR_HL32_ILV = 1) measured 9.5 %
+    // SLOWER (1 915 against 1 748 us on the same box: an LDS-DMA instruction between two MFMA groups stalls the group behind it)
+    uint32_t b_st = 0;
+    int b_px0 = 0, b_soff = 0, b_idx = 0;
+    bool b_live = false, b_full = false;
+    auto begin_batch = [&](int b) {
+        b_live = b < nt && !(ABL == 8 && b >= NF);               // (ABL 8, timing only: no memory traffic behind the first ring fill)
+        if (!b_live) return;
+        b_idx = b;
+        b_st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % NF) * Lds::kStage + pl_ * kTileBytes + rb * kRowBytes);
+        b_px0 = dy * W + TPX * ds;
+        b_soff = __builtin_amdgcn_readfirstlane(b_px0 * kRowBytes);
+        b_full = b_px0 + TPX <= HW;
         ++dy;
         if (dy == H) { dy = 0; ++ds; }
-        if (sb == 0) {                                           // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
-            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % NF) * kAuxTile);
-            ra_dma16(ars, sa, (px0 + (lane & 31)) * kAuxRow, 0);
+    };
+    auto issue_piece = [&](int i) {
+        if (!b_live) return;
+        if (i < 8) {
+            if (b_full) {
+                ra_dma16(frs, b_st + i * 1024, voff[i], b_soff);
+            } else {                                             // last row of a ragged strip: clamp the source rows (their P is 0)
+                const int row = rb + 2 * i + h;
+                const int src = b_px0 + row < HW ? row : HW - 1 - b_px0;
+                ra_dma16(frs, b_st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), b_soff);
+            }
+        } else if (sb == 0) {                                    // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
+            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b_idx % NF) * kAuxTile);
+            ra_dma16(ars, sa, (b_px0 + (lane & 31)) * kAuxRow, 0);
         } else if (sb == 2) {                                    // Cy row of tile b + 1 (1 KiB from the start of its image row)
-            const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b + 1) % NF) * kCyTile);
+            const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b_idx + 1) % NF) * kCyTile);
             ra_dma16_cached(yrs, sy, dy * LP * 4 + lane * 16);
         }
+    };
+    auto issue_batch = [&](int b) {
+        begin_batch(b);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) issue_piece(i);
     };
     if (sb == 2) ra_dma16_cached(yrs, __builtin_amdgcn_readfirstlane(lds0 + Lds::yring), row0 * LP * 4 + lane * 16);   // Cy row of tile 0
 #pragma unroll
@@ -475,12 +491,18 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
 #pragma unroll
         for (int q = 0; q < NVB - 1; ++q) load_step(q, q);
     };
-    auto pv_steps = [&](auto lo_tag, auto hi_tag) {              // steps [Q0, Q1) of A += P f: six MFMAs each (+ two of the aux block per k-step)
+    auto pv_steps = [&](auto lo_tag, auto hi_tag, auto dma_tag) { // steps [Q0, Q1) of A += P f: six MFMAs each (+ two of the aux block per k-step)
         constexpr int Q0 = decltype(lo_tag)::value * (2 / kSB), Q1 = decltype(hi_tag)::value * (2 / kSB);
+        constexpr bool DMA = decltype(dma_tag)::value;           // the pieces of the batch begun before, spread over these sub-steps
+        constexpr int kPP = DMA ? (9 + (Q1 - Q0) - 1) / (Q1 - Q0) : 0;      // pieces per sub-step
 #pragma unroll
         for (int q = Q0; q < Q1; ++q) {
             const int ks = q / (8 / kSB), db = kSB * (q % (8 / kSB));
             if (q + NVB - 1 < kNQ) load_step((q + NVB - 1) % NVB, q + NVB - 1);
+            if constexpr (DMA) {
+#pragma unroll
+                for (int i = kPP * (q - Q0); i < kPP * (q - Q0 + 1) && i < 9; ++i) issue_piece(i);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #ifndef SVPS_R32_SKIP_PLO                                              // (timing experiments only)
 #pragma unroll
@@ -501,6 +523,9 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     using I0 = std::integral_constant<int, 0>;
     using IS = std::integral_constant<int, kSplit>;
     using I8 = std::integral_constant<int, 8>;
+    using WithDma = std::true_type;
+    using NoDma = std::false_type;
+    static_assert(!SVPS_RETR_HL32_ILV || kSplit >= 1, "the batch's pieces go out in front of B1");
 #if SVPS_RETR_HL32_B0
     using IP = std::integral_constant<int, SVPS_RETR_HL32_PRE>;
     static_assert(SVPS_RETR_HL32_PRE <= kSplit, "steps beside the chain <= steps in front of B1");
@@ -514,17 +539,32 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         const bool work = kWork && it >= 1;
         R32_STAMP(1, 0);
         if (work) pv_begin(it - 1);
+#if SVPS_RETR_HL32_ILV && !SVPS_RETR_HL32_B0
+        begin_batch(it + A);                                     // its pieces go out between the sub-steps below (all of them in front of B1)
+        if (work) {
+            pv_steps(I0{}, IS{}, WithDma{});
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) issue_piece(i);
+        }
+        R32_STAMP(1, 1);
+        if (ABL != 16) {
+            if (it + A < nt) wait_vm_dyn(nb * (A - 1));          // batch it+1 landed for this wave: all but the A - 1 youngest batches
+            else wait_vm<0>();
+        } else if (it + 4 * A < nt) wait_vm_dyn(nb * (4 * A - 1));  // (timing only: the landing wait never binds)
+        R32_STAMP(1, 2);
+#elif SVPS_RETR_HL32_B0
         issue_batch(it + A);
-#if SVPS_RETR_HL32_B0
-        if (work) pv_steps(I0{}, IP{});                          // (SVPS_RETR_HL32_PRE steps beside the producers' chain)
+        if (work) pv_steps(I0{}, IP{}, NoDma{});                 // (SVPS_RETR_HL32_PRE steps beside the producers' chain)
         if (it + A < nt) wait_vm_dyn(nb * (A - 1));              // batch it+1 landed for this wave
         else wait_vm<0>();
         wg_barrier();                                            // B0(it): the producers' chains are through - the matrix pipe is the consumers'
-        if (work) pv_steps(IP{}, IS{});
+        if (work) pv_steps(IP{}, IS{}, NoDma{});
         R32_STAMP(1, 1);
         R32_STAMP(1, 2);
 #else
-        if (work) pv_steps(I0{}, IS{});
+        issue_batch(it + A);
+        if (work) pv_steps(I0{}, IS{}, NoDma{});
         R32_STAMP(1, 1);
         // batch it+1 landed for this wave (the producers read its first fragments behind B1): all but the A - 1 youngest batches
         if (ABL != 16) {
@@ -535,13 +575,13 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
 #endif
         wg_barrier();                                            // B1(it)
         R32_STAMP(1, 3);
-        if (work) pv_steps(IS{}, I8{});
+        if (work) pv_steps(IS{}, I8{}, NoDma{});
         R32_STAMP(1, 4);
         wg_barrier();                                            // B2(it)
     }
     if (kWork) {
         pv_begin(nt - 1);
-        pv_steps(I0{}, I8{});
+        pv_steps(I0{}, I8{}, NoDma{});
     }
 
     float* dst = partial + (((size_t)t * C + c) * Lrow + slot_off) * kPartRow;
