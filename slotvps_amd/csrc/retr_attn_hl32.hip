@@ -55,6 +55,9 @@ typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #ifndef SVPS_RETR_HL32_ILV
 #define SVPS_RETR_HL32_ILV 0        // consumers: 1 = the nine LDS-DMA pieces of a batch between the first sub-steps (measured 9.5 % slower); 0: all in front of them
 #endif
+#ifndef SVPS_RETR_HL32_DMA_LATE
+#define SVPS_RETR_HL32_DMA_LATE 0   // consumers: 1 = the batch goes out at the END of the iteration before (in front of B2) instead of at its top
+#endif
 #ifndef SVPS_RETR_HL32_PSUB
 #define SVPS_RETR_HL32_PSUB 0       // producers: 1 = one k-step per fragment buffer, three k-steps ahead; 0 = groups of two k-steps, one group ahead
 #endif
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     };
     if (sb == 2) ra_dma16_cached(yrs, __builtin_amdgcn_readfirstlane(lds0 + Lds::yring), row0 * LP * 4 + lane * 16);   // Cy row of tile 0
 #pragma unroll
-    for (int b = 0; b < A; ++b) issue_batch(b);
+    for (int b = 0; b < A + (SVPS_RETR_HL32_DMA_LATE ? 1 : 0); ++b) issue_batch(b);
 
     f32x16 o[8], oa;
 #pragma unroll
@@ -532,8 +535,11 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
 #endif
     constexpr bool kWork = ABL != 1 && ABL != 2;
 
-    if (A - 1 < nt) wait_vm_dyn(nb * (A - 1));                   // batch 0 (and the Cy row of tile 0) landed
-    else wait_vm<0>();
+    {
+        constexpr int kIssued = A + (SVPS_RETR_HL32_DMA_LATE ? 1 : 0);
+        if (kIssued - 1 < nt) wait_vm_dyn(nb * (kIssued - 1));   // batch 0 (and the Cy row of tile 0) landed
+        else wait_vm<0>();
+    }
     wg_barrier();                                                // B(start)
     for (int it = 0; it < nt; ++it) {
         const bool work = kWork && it >= 1;
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         R32_STAMP(1, 1);
         R32_STAMP(1, 2);
 #else
-        issue_batch(it + A);
+        if (!SVPS_RETR_HL32_DMA_LATE) issue_batch(it + A);
         if (work) pv_steps(I0{}, IS{}, NoDma{});
         R32_STAMP(1, 1);
         // batch it+1 landed for this wave (the producers read its first fragments behind B1): all but the A - 1 youngest batches
@@ -577,6 +583,8 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         R32_STAMP(1, 3);
         if (work) pv_steps(IS{}, I8{}, NoDma{});
         R32_STAMP(1, 4);
+        // (DMA_LATE) batch it+1+A into the stage of tile it-1, which this wave has just left: issued while the wave would wait at B2
+        if (SVPS_RETR_HL32_DMA_LATE && !SVPS_RETR_HL32_ILV && !SVPS_RETR_HL32_B0) issue_batch(it + 1 + A);
         wg_barrier();                                            // B2(it)
     }
     if (kWork) {
