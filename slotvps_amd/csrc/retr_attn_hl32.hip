@@ -33,6 +33,12 @@
 // consumer then starts its tile late and becomes the critical wave), two alternating accumulators in the chain and / or s_setprio around
 // it, the next group's reads forced in front of a group's MFMAs (sched_group_barrier), halving the finish's vector instructions
 // (v_cvt_pk_f16_f32 + v_fma_mixlo / mixhi_f16: kept, not faster), the consumers' split point 3 ... 7 (4).
+// What DID pay after that (-5 %, 1 855 -> 1 765 us on one box, 1 780 -> 1 675 on another): the consumers' value fragments three sub-steps
+// ahead instead of one - sub-steps of ONE channel block (3 MFMAs) with four fragment buffers in the registers of two buffers of two blocks:
+// a consumer MFMA cost ~41 cycles, not 32, because a fragment requested 192 cycles ahead is not there under load. The same for the producers
+// (one k-step per buffer, three ahead: SVPS_RETR_HL32_PSUB) + 1.8 %; a third barrier behind the chain (strict ping-pong, SVPS_RETR_HL32_B0)
+// equal; the nine LDS-DMA pieces of a batch between the consumers' sub-steps (SVPS_RETR_HL32_ILV) + 9.5 %, the batch in front of B2 instead
+// of behind it (SVPS_RETR_HL32_DMA_LATE) + 10 %: an LDS-DMA instruction next to in-flight MFMAs of its wave stalls them.
 #include <stdlib.h>
 
 #include <type_traits>
