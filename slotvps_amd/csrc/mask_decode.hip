@@ -782,6 +782,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_kernel_v
 //   * LDS: 2 stages x 32 KiB + a [16 slots][32 px] transpose tile per wave (the logits leave in two halves) = 78 KiB: two workgroups per CU.
 // Same skew as the fast path: the epilogue of tile it - 1 rides in the shadow of the chain of tile it; norms double-buffered by parity.
 // NW = 4 waves (up to 128 slots, two workgroups per CU) or 8 (up to 256 slots - VIPER's 200 -, one workgroup per CU: the same eight waves).
+#ifndef SVPS_K2_HL32_AHEAD
+#define SVPS_K2_HL32_AHEAD 1        // operand fragments requested this many k-steps (of three MFMAs) ahead
+#endif
 #ifndef SVPS_K2_HL32_W8_STAGES
 #define SVPS_K2_HL32_W8_STAGES 2       // (3 measured 1 % slower at the VIPER shape: the eight-wave form is bound by its own work per pixel, not by landing waits)
 #endif
@@ -971,10 +974,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_hl32_ker
         }
 
         constexpr bool FR = CH && !(ABL & 2);
-        f16x8 fh[2], fl[2];                              // operand fragments of one k-step, the next k-step's in flight
+        constexpr int FAH = SVPS_K2_HL32_AHEAD, FNB = FAH + 1;
+        f16x8 fh[FNB], fl[FNB];                          // operand fragments of one k-step, the next FAH k-steps' in flight
         if constexpr (FR) {
-            fh[0] = *reinterpret_cast<const f16x8*>(fth + fa[0]);
-            fl[0] = *reinterpret_cast<const f16x8*>(fth + kTileBytes + fa[0]);
+#pragma unroll
+            for (int k = 0; k < FAH; ++k) {
+                fh[k] = *reinterpret_cast<const f16x8*>(fth + fa[k & 7] + (k >> 3) * 256);
+                fl[k] = *reinterpret_cast<const f16x8*>(fth + kTileBytes + fa[k & 7] + (k >> 3) * 256);
+            }
         }
         float2 cnd[NW];                                  // four waves: requested here, used under k-step 1; eight: read there (registers)
         if constexpr (ARGMAX && EP && NW == 4) {
@@ -1015,17 +1022,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void mask_decode_hl32_ker
             for (int u = 0; u < 2; ++u) {
                 const int ks = 2 * g + u;
                 if constexpr (FR) {
-                    if (ks < 15) {
-                        fh[(ks + 1) & 1] = *reinterpret_cast<const f16x8*>(fth + fa[(ks + 1) & 7] + ((ks + 1) >> 3) * 256);
-                        fl[(ks + 1) & 1] = *reinterpret_cast<const f16x8*>(fth + kTileBytes + fa[(ks + 1) & 7] + ((ks + 1) >> 3) * 256);
+                    if (ks + FAH < 16) {
+                        fh[(ks + FAH) % FNB] = *reinterpret_cast<const f16x8*>(fth + fa[(ks + FAH) & 7] + ((ks + FAH) >> 3) * 256);
+                        fl[(ks + FAH) % FNB] = *reinterpret_cast<const f16x8*>(fth + kTileBytes + fa[(ks + FAH) & 7] + ((ks + FAH) >> 3) * 256);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (ABL & 1) {
-                        asm volatile("" : : "v"(fh[ks & 1]), "v"(fl[ks & 1]), "v"(el[ks]), "v"(eh[ks]));
+                        asm volatile("" : : "v"(fh[ks % FNB]), "v"(fl[ks % FNB]), "v"(el[ks]), "v"(eh[ks]));
                     } else {
-                        s = mfma16(el[ks], fh[ks & 1], s);
-                        s = mfma16(eh[ks], fl[ks & 1], s);
-                        s = mfma16(eh[ks], fh[ks & 1], s);
+                        s = mfma16(el[ks], fh[ks % FNB], s);
+                        s = mfma16(eh[ks], fl[ks % FNB], s);
+                        s = mfma16(eh[ks], fh[ks % FNB], s);
                     }
                 }
                 if constexpr (ARGMAX && EP) {
