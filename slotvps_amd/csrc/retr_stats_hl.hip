@@ -48,6 +48,10 @@
 #ifndef SVPS_SHL_AHEAD
 #define SVPS_SHL_AHEAD 2    // operand fragments requested this many k-steps ahead of their MFMAs
 #endif
+#ifndef SVPS_SHL_STAGGER
+#define SVPS_SHL_STAGGER 0  // tiled-tables form: 1 = ONE barrier per tile - the key waves run chain then light work, the value waves light work then chain, so
+                            // the two chains of a SIMD overlap in the middle of the period (a lone chain issues an MFMA every 36 cycles, two share the pipe at 32)
+#endif
 #ifndef SVPS_SHL_PRIO
 #define SVPS_SHL_PRIO 1     // tiled-tables form: 1 = s_setprio 1 around each chain, 2 = static s_setprio 1 for the value waves (the younger half), 0 none
 #endif
@@ -78,8 +82,8 @@ struct StatsHlLds {
     static constexpr int kSlots = 3;                 // tile ring: tile t in work, t + 1 landed, t + 2 in flight
     static constexpr int plane = kTileBytes;         // one plane of one tile: 32 pixel rows of 512 B, 16-byte chunks swizzled (common.h)
     static constexpr int xt = 0;                     // [3 slots][hi, lo][16 KiB]
-    static constexpr int part = kSlots * 2 * plane;  // [2 buffers][key, value][4 waves][32 px] float
-    static constexpr int total = part + 2 * 2 * 4 * 32 * 4;
+    static constexpr int part = kSlots * 2 * plane;  // [3 buffers][key, value][4 waves][32 px] float (three: the staggered schedule has ONE barrier per tile)
+    static constexpr int total = part + 3 * 2 * 4 * 32 * 4;
     // TILED tables only (round 5): the start values come through LDS as well, so that no wave waits on an L2 round trip
     static constexpr int tabx = total;               // [4 key waves][2 row blocks][4 g][1 KiB: lane's 16 bytes]  Tx' of the NEXT tile
     static constexpr int taby = tabx + 4 * 8192;     // [4 key waves][1 KiB: 16 chunks (block, h, g), repeated]     Ty' of the next tile's row
@@ -181,7 +185,7 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
     };
     // wave (key, 0), lanes h == 0: the tile's 32 aux rows from the eight waves' sums (one 16-byte store per pixel: whole rows)
     auto finish = [&](int tile) {
-        const int cur = (tile - tile0) & 1;
+        const int cur = (tile - tile0) % 3;
         float tk = 0.f, tv = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
@@ -266,7 +270,7 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
     };
     // the chain of `tile` on the staged planes, then this wave's 64 rows' sum of squares per pixel
     auto heavy = [&](int tile) {
-        const int cur = (tile - tile0) & 1;
+        const int cur = (tile - tile0) % 3;
         // this lane's 16-byte chunk of k-step ks in pixel row r: chunk (2 ks + h) ^ swz(r) - one XOR on the lane's base address
         const uint32_t xh = lds0 + StatsHlLds::xt + ((tile - tile0) % 3) * 2 * StatsHlLds::plane + r * kRowBytes + ((h ^ swz(r)) << 4);
         const uint32_t xl = xh + StatsHlLds::plane;
@@ -315,7 +319,7 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
     };
     // (TLDS) the sums of squares of `tile`'s finished chains - in the wave's LIGHT half-period, under the other wave's chain
     auto sums = [&](int tile) {
-        const int cur = (tile - tile0) & 1;
+        const int cur = (tile - tile0) % 3;
         float ss = sumsq(ca) + sumsq(cb);
         ss += __shfl_xor(ss, 32);
         if (h == 0) part[(cur * 2 + (KEY ? 0 : 1)) * 128 + J * 32 + r] = ss;
@@ -412,7 +416,9 @@ __device__ __forceinline__ void stats_hl_role(const StatsHlArgs& a, char* smem, 
                 if (J == 0 && tile >= tile0 + 2 && !(SVPS_SHL_ABL & 8)) finish(tile - 2);
             }
             SHL_STAMP(3);
+#if !SVPS_SHL_STAGGER
             __syncthreads();
+#endif
             SHL_STAMP(4);
             if constexpr (KEY) {
                 const bool ahead = tile + 2 < tile1 && !(SVPS_SHL_ABL & 4);
