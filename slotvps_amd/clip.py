@@ -5,6 +5,7 @@ The reference's detector runs [ref_frame, cur_frame] pairs (T = 2, vps_temporal_
 decodes the current frame only (:297-299); the head itself is generic in T (dynamic_mask_head.py:143-164).
 This driver feeds a whole T-frame clip through the head at once and decodes every frame.
 """
+import os
 import sys
 import torch
 from torch import nn
@@ -79,6 +80,11 @@ class SlotClipRunner:
                                nn.Parameter((torch.randn(c, generator=g) * 0.1 - 0.45).to(self.device), requires_grad=False))
         self._alloc_inputs()
         self.use_graph = use_graph
+        # graph mode, fp16x2: K4 / K3 as a parallel branch of the slot chain (see _step). OFF by default: built, bitwise the single-stream result,
+        # the branches do overlap in the kernel trace (rocprofv3: 4 queues), and the step measures the SAME (61.9 - 62.4 against 61.75 ms, same
+        # box, profiles/r06/README.md) - the pixel-side kernels hold every CU for their whole launch (one workgroup per CU, most of its LDS and
+        # registers), so a small slot-side kernel of the other branch waits for a CU instead of filling idle ones
+        self.overlap_pixel_side = os.environ.get("SVPS_OVERLAP_PIXEL_SIDE", "0") == "1"
         self.graphs = [None] * n_slots
         self.validation_reports = []                      # graph validations that failed and were repeated (run())
         self.outs = [None] * n_slots
@@ -113,8 +119,14 @@ class SlotClipRunner:
             self.fg_scale, self.fg_shift = float(fs.item()), float(fb.item())
 
     def _step(self, slot=0):
+        # graph mode: the pixel side (K4, K3) as a parallel branch of the slot chain (MultiScaleDynamicMaskHead.forward_clip, pixel_stream)
+        pix = None
+        if self.use_graph and self.overlap_pixel_side and getattr(self.head, "precision", "") == "fp16x2":
+            if getattr(self, "_pix_stream", None) is None:
+                self._pix_stream = torch.cuda.Stream(device=self.device)
+            pix = self._pix_stream
         logits, embeds, fused = self.head.forward_clip(self.slots_feats[slot], self.init_slots, self.pos_tabs, hws=self.sizes,
-                                                       clip_frames=self.clip_frames, pre_linear=self.pre_linear)
+                                                       clip_frames=self.clip_frames, pre_linear=self.pre_linear, pixel_stream=pix)
         if fused[-1].dim() == 4:                             # precision "fp16x2": the map as fp16 hi + lo planes; the logits are always written
             masks, amax = ops.mask_decode_hl(fused[-1], embeds[-1].contiguous(), self.bn_scale, self.bn_shift, self.fg_scale, self.fg_shift,
                                              want_argmax=True)

@@ -297,6 +297,14 @@ class MaskDynamicConv(nn.Module):
             cache[key] = (tyk, txk, c["rbv"][perm].contiguous(), tiled, pos_tabs)
         return cache[key][:4]
 
+    def stats_hl(self, feat_pm, hw, pos_tabs):
+        """K3-HL (csrc/retr_stats_hl.hip): the aux rows of this stage on the fp16 hi + lo planes - factors AND map as hi + lo, three MFMAs per
+        product. Depends on the map and the weights only (not on the slots): forward_clip may run it ahead on another stream."""
+        c = self._fused_consts()
+        tyk, txk, rbv_p, tiled = self.stats_hl_tables(pos_tabs)
+        return ops.retr_stats_hl(feat_pm, hw[0], hw[1], tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p,
+                                 self.norm_v.eps, tx_tiled=tiled)
+
     def stats_args(self, pos_tabs):
         """(pos_proj, rk, rbk, eps_k, rv, rbv, eps_v): this stage's arguments of ops.retr_stats / one entry of ops.retr_stats_level."""
         c = self._fused_consts()
@@ -319,11 +327,11 @@ class MaskDynamicConv(nn.Module):
             self._level_stats = None
             if pending is not None and pending[0] is feat_pm:
                 stats = pending[1]
+                if len(pending) > 2:                     # computed on the pixel-side stream (forward_clip): this stream continues behind it
+                    torch.cuda.current_stream(feat_pm.device).wait_event(pending[2])
         if hl:
-            # reference precision: factors AND map as fp16 hi + lo (K3-HL: three MFMAs per product)
-            tyk, txk, rbv_p, tiled = self.stats_hl_tables(pos_tabs)
-            stats = ops.retr_stats_hl(feat_pm, H, W, tyk, txk, c["rk"], c["rk_lo"], self.norm_k.eps, c["rv"], c["rv_lo"], rbv_p, self.norm_v.eps,
-                                      tx_tiled=tiled)
+            if stats is None:
+                stats = self.stats_hl(feat_pm, hw, pos_tabs)
         elif stats is None:
             stats = ops.retr_stats(feat_pm, H, W, *self.stats_args(pos_tabs))
         LP = ops.retr_slot_pad(L)
@@ -905,7 +913,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
             cur = cur.to(wc.dtype)                                         # pixel-major rows: the conv's operand type
         return ops.level_fuse(cur.contiguous(), prev_pm, wc, bc, hw[0], hw[1], bf16_values=form == "bf16_in_fp16")
 
-    def forward_clip(self, feats, init_slots, pos_tabs, hws=None, clip_frames=None, pre_linear=None):
+    def forward_clip(self, feats, init_slots, pos_tabs, hws=None, clip_frames=None, pre_linear=None, pixel_stream=None):
         """Batched clip entry. clip_frames: frames per clip when several clips of equal length are stacked along T
         (T % clip_frames == 0): every kernel then covers all of them in one launch and the temporal slot attention
         stays inside each clip. None = one clip of T frames (the reference's call).
@@ -916,6 +924,12 @@ class MultiScaleDynamicMaskHead(nn.Module):
         semantic tower's own output); init_slots [L, 256];
         pos_tabs: per level the separable sine tables (ytab [Hi, 128], xtab [Wi, 128]) of
         ops.pos_embed_sine_tables, or None for no position embedding.
+        pixel_stream (mode fp16x2): a second stream for the PIXEL side. Level fusion (K4) and the LayerNorm statistics (K3) of every stage
+        depend on the incoming maps and the weights only, never on the slots; the slot chain (self-attention, query side, K1', feed-forward,
+        temporal step, towers: ~40 small launches per stage that leave most of the chip idle) is the other dependency chain. With a stream
+        given, all of K4 / K3 is issued on it first, each stage's retriever waits for its own statistics, and the streams join at the end -
+        inside a captured hipGraph the two chains become parallel branches (clip.SlotClipRunner). Same kernels, same order per tensor:
+        bitwise the single-stream result.
         Returns logits [S, T, L, nc], embeds [S, T, L, 256], fused list of [T, Hi*Wi, 256] bf16 (fp32 in exact mode; precision "fp16x2":
         [2, T, Hi*Wi, 256] fp16, the hi and lo planes)."""
         if not feats[0].is_cuda:
@@ -939,12 +953,35 @@ class MultiScaleDynamicMaskHead(nn.Module):
         all_logits, all_embeds, fused = [], [], []
         prev = None
         stage_idx = 0
+        level_hw = [feats[i].shape[-2:] if (feats[i].dim() == 4 and not planes_in) else hws[i] for i in range(self.feat_num_levels)]
+        ahead = None
+        if pixel_stream is not None and self.precision == "fp16x2":
+            # the pixel side of ALL levels on its own stream (see the docstring); every tensor it allocates stays referenced until the streams
+            # have joined, so the allocator cannot hand one of its blocks out again while the other stream still reads it
+            main = torch.cuda.current_stream(slots.device)
+            pixel_stream.wait_stream(main)
+            ahead = []
+            with torch.cuda.stream(pixel_stream):
+                p_ = None
+                for i in range(self.feat_num_levels):
+                    h, w = level_hw[i]
+                    p_ = self.fuse_level(feats[i], p_, (h, w), last=i == self.feat_num_levels - 1, pre=pre_linear)
+                    tabs_i = None if pos_tabs is None else pos_tabs[i]
+                    per_stage = []
+                    for stage in getattr(self, f"head_series_{i}"):
+                        aux = stage.inst_interact.stats_hl(p_, (h, w), tabs_i)
+                        ev = torch.cuda.Event()
+                        ev.record(pixel_stream)
+                        per_stage.append((aux, ev))
+                    ahead.append((p_, per_stage))
         for i in range(self.feat_num_levels):
-            if feats[i].dim() == 4 and not planes_in:
-                h, w = feats[i].shape[-2:]
+            h, w = level_hw[i]
+            if ahead is not None:
+                f_pm = ahead[i][0]
+                for stage, (aux, ev) in zip(getattr(self, f"head_series_{i}"), ahead[i][1]):
+                    stage.inst_interact._level_stats = (f_pm, aux, ev)
             else:
-                h, w = hws[i]
-            f_pm = self.fuse_level(feats[i], prev, (h, w), last=i == self.feat_num_levels - 1, pre=pre_linear)
+                f_pm = self.fuse_level(feats[i], prev, (h, w), last=i == self.feat_num_levels - 1, pre=pre_linear)
             series = getattr(self, f"head_series_{i}")
             mdcs = [stage.inst_interact for stage in series]
             if (self.stats_form == "level" and len(mdcs) == 2 and f_pm.dtype in (BF16, torch.float16) and f_pm.dim() == 3
@@ -966,6 +1003,8 @@ class MultiScaleDynamicMaskHead(nn.Module):
                 stage_idx += 1
             prev = f_pm
             fused.append(f_pm)
+        if ahead is not None:
+            torch.cuda.current_stream(slots.device).wait_stream(pixel_stream)      # join (every stage has waited for its own event already)
         if direct and all(t.data_ptr() == out_logits[j].data_ptr() for j, t in enumerate(all_logits)) \
                 and all(t.data_ptr() == out_embeds[j].data_ptr() for j, t in enumerate(all_embeds)):
             return out_logits, out_embeds, fused
