@@ -212,6 +212,29 @@ def test_default_mode_is_the_contract_mode(cuda):
                                       apply_temporal_query_atten_stages=[], other_config={legacy: "bf16"})
 
 
+def test_pixel_side_on_its_own_stream_is_bitwise_the_same(cuda):
+    """forward_clip(pixel_stream=...) (round 6): level fusion and the LayerNorm statistics of every stage on a second stream, each stage's
+    retriever behind its own event - same kernels, same order per tensor, so the results are bitwise those of the single-stream call
+    (and the captured form of it is what clip.SlotClipRunner validates against the eager step when SVPS_OVERLAP_PIXEL_SIDE=1)."""
+    import torch
+    from slotvps_amd import ops
+    params = synth.make_params(synth.head_shapes(), 3)
+    head = build_head(cuda, params)
+    T, H, W, L = 3, 64, 96, 37
+    sizes = synth.level_sizes(H, W)
+    g = torch.Generator(device=cuda).manual_seed(5)
+    feats = [torch.randn((T, 128, h, w), generator=g, device=cuda) for (h, w) in sizes]
+    slots = torch.randn((L, 256), generator=g, device=cuda)
+    tabs = [ops.pos_embed_sine_tables(h, w, 256, cuda) for (h, w) in sizes]
+    with torch.no_grad():
+        a = head.forward_clip(feats, slots, tabs)
+        side = torch.cuda.Stream(device=cuda)
+        b = head.forward_clip(feats, slots, tabs, pixel_stream=side)
+        torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+
+
 @pytest.mark.parametrize("map_dtype", ["fp16x2", "bf16", "fp16"])
 def test_reference_signature_roundtrip(cuda, map_dtype):
     """The reference-style list-of-frames call returns the reference's structure (with every storage of the level maps), and the maps it
