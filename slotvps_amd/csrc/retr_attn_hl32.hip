@@ -35,10 +35,10 @@
 // (v_cvt_pk_f16_f32 + v_fma_mixlo / mixhi_f16: kept, not faster), the consumers' split point 3 ... 7 (4).
 // What DID pay after that (-5 %, 1 855 -> 1 765 us on one box, 1 780 -> 1 675 on another): the consumers' value fragments three sub-steps
 // ahead instead of one - sub-steps of ONE channel block (3 MFMAs) with four fragment buffers in the registers of two buffers of two blocks:
-// a consumer MFMA cost ~41 cycles, not 32, because a fragment requested 192 cycles ahead is not there under load. The same for the producers
-// (one k-step per buffer, three ahead: SVPS_RETR_HL32_PSUB) + 1.8 %; a third barrier behind the chain (strict ping-pong, SVPS_RETR_HL32_B0)
-// equal; the nine LDS-DMA pieces of a batch between the consumers' sub-steps (SVPS_RETR_HL32_ILV) + 9.5 %, the batch in front of B2 instead
-// of behind it (SVPS_RETR_HL32_DMA_LATE) + 10 %: an LDS-DMA instruction next to in-flight MFMAs of its wave stalls them.
+// a consumer MFMA cost ~41 cycles, not 32, because a fragment requested 192 cycles ahead is not there under load. Tried after that and
+// not kept (profiles/r06/k1hl32_late_experiment_options.patch): the same for the producers (one k-step per buffer, three ahead) + 1.8 %; a
+// third barrier behind the chain (strict ping-pong) equal; the nine LDS-DMA pieces of a batch between the consumers' sub-steps + 9.5 %, the
+// batch in front of B2 instead of behind it + 10 %: an LDS-DMA instruction next to in-flight MFMAs of its wave stalls them.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -57,21 +57,6 @@ typedef __fp16 fp16x4_gcc __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #endif
 #ifndef SVPS_RETR_HL32_SUB
 #define SVPS_RETR_HL32_SUB 1        // consumers: channel blocks per sub-step (1: four fragment buffers, three sub-steps ahead; 2: two buffers, one ahead)
-#endif
-#ifndef SVPS_RETR_HL32_ILV
-#define SVPS_RETR_HL32_ILV 0        // consumers: 1 = the nine LDS-DMA pieces of a batch between the first sub-steps (measured 9.5 % slower); 0: all in front of them
-#endif
-#ifndef SVPS_RETR_HL32_DMA_LATE
-#define SVPS_RETR_HL32_DMA_LATE 0   // consumers: 1 = the batch goes out at the END of the iteration before (in front of B2) instead of at its top
-#endif
-#ifndef SVPS_RETR_HL32_PSUB
-#define SVPS_RETR_HL32_PSUB 0       // producers: 1 = one k-step per fragment buffer, three k-steps ahead; 0 = groups of two k-steps, one group ahead
-#endif
-#ifndef SVPS_RETR_HL32_B0
-#define SVPS_RETR_HL32_B0 0         // 1: a third barrier behind the producers' chain; the consumers run SVPS_RETR_HL32_PRE steps beside the chain
-#endif
-#ifndef SVPS_RETR_HL32_PRE
-#define SVPS_RETR_HL32_PRE 0
 #endif
 #ifndef SVPS_RETR_HL32_SPLIT
 #define SVPS_RETR_HL32_SPLIT 4      // consumer steps (of 8) in front of B1
@@ -199,22 +184,6 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
         auto frag = [&](uint32_t tb, int ks) {
             return *reinterpret_cast<SVPS_LDS const f16x8*>((uintptr_t)((tb ^ ((ks & 7) << 5)) + 256 * (ks >> 3)));
         };
-#if SVPS_RETR_HL32_PSUB
-        // one k-step (its hi and its lo fragment) per buffer, four buffers: the fragments of k-steps ks + 1 .. ks + 3 are in flight beside the three
-        // MFMAs of k-step ks (the same 32 registers as two groups of two k-steps, half as far ahead again)
-        f16x8 kf[4][2];
-        auto load_ks = [&](uint32_t tb, int ks) {
-            kf[ks & 3][0] = frag(tb, ks);
-            kf[ks & 3][1] = frag(tb + kTileBytes, ks);
-        };
-        f32x2 rt = {0.f, 0.f};
-        auto prefetch = [&](int tile) {                             // the first three k-steps and (rstd_k, rstd_v) of a tile
-            const uint32_t slot = (uint32_t)(tile % NF);
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) load_ks(lane_row + slot * Lds::kStage, ks);
-            rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + slot * kAuxTile + r * kAuxRow + 8));
-        };
-#else
         // fragment group g: k-steps g and g + 8 of the hi tile, then of the lo tile (one address, four immediate offsets)
         f16x8 kf[2][4];
         auto load_grp = [&](int buf, uint32_t tb, int g) {
@@ -229,7 +198,6 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             load_grp(0, lane_row + slot * Lds::kStage, 0);
             rt = *reinterpret_cast<SVPS_LDS const f32x2*>((uintptr_t)(lds0 + Lds::aring + slot * kAuxTile + r * kAuxRow + 8));
         };
-#endif
 
         constexpr bool kRun = ABL != 1 && ABL != 4;
         wg_barrier();                                               // B(start): batch 0 and the Cy row of tile 0 landed
@@ -248,31 +216,6 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                 f32x16 s;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s[i] = 0.f;
-#if SVPS_RETR_HL32_PSUB
-                // ---- chain: sixteen k-steps of three MFMAs, fragments three k-steps ahead; d in pieces under k-steps 1, 3, 5, 7
-#pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    if (ks + 3 < 16) load_ks(tb, ks + 3);
-                    if ((ks & 1) && ks < 8) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            d[ks >> 1][j] = fmaf(rk_c, cxv[ks >> 1][j] + cyq[j], c3q[j]);
-                            asm volatile("" : "+v"(d[ks >> 1][j]));     // HERE, under this k-step's MFMAs (hipcc otherwise sinks it into the head)
-                        }
-                    }
-                    if (!(ks & 1) && ks < 8) {
-                        cyq = *reinterpret_cast<const f32x4*>(cyl + 8 * (ks >> 1));
-                        c3q = *reinterpret_cast<const f32x4*>(c3l + slot0 + 8 * (ks >> 1));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#ifndef SVPS_R32_SKIP_QLO                                              // (timing experiments only)
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfl[ks], kf[ks & 3][0], s, 0, 0, 0);
-#endif
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[ks & 3][1], s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfh[ks], kf[ks & 3][0], s, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#else
                 // ---- chain: eight groups of two k-steps, three MFMAs per k-step; the reads of group g + 1 in the shadow of group g
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
@@ -299,10 +242,6 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#endif
-#if SVPS_RETR_HL32_B0
-                wg_barrier();                                       // B0(it): the chain is through - the consumers' MFMAs start here
-#endif
                 R32_STAMP(0, 1);
                 // ---- softmax head: log2(e) * S = (log2(e) rstd_k) * (Q''.f + Cy + Cx) + c3'. Rows past the real slot count need no
                 // masking: their Q'', Cy, Cx are zero and their c3' is -1e30 (retr_query_prep): they exp2 to exactly 0
@@ -378,9 +317,6 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
                 }
                 R32_STAMP(0, 4);
             } else {
-#if SVPS_RETR_HL32_B0
-                wg_barrier();                                       // B0(it)
-#endif
                 wg_barrier();                                       // B1(it)
             }
             wg_barrier();                                           // B2(it)
@@ -402,49 +338,38 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     }
     const int nb = 8 + ((sb == 0 || sb == 2) ? 1 : 0);           // DMA instructions of one batch of this wave
     int ds = strip0, dy = row0;                                  // strip / image row of the next batch
-    // a batch = nine 1-KiB pieces of this wave (eight feature pieces, the aux tile or the Cy row); begin_batch fixes its addresses. The pieces go
-    // out in a row in front of the tile's MFMAs; spreading them between the first sub-steps of A += P f (SVPS_RETR_HL32_ILV = 1) measured 9.5 %
-    // SLOWER (1 915 against 1 748 us on the same box: an LDS-DMA instruction between two MFMA groups stalls the group behind it)
-    uint32_t b_st = 0;
-    int b_px0 = 0, b_soff = 0, b_idx = 0;
-    bool b_live = false, b_full = false;
-    auto begin_batch = [&](int b) {
-        b_live = b < nt && !(ABL == 8 && b >= NF);               // (ABL 8, timing only: no memory traffic behind the first ring fill)
-        if (!b_live) return;
-        b_idx = b;
-        b_st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % NF) * Lds::kStage + pl_ * kTileBytes + rb * kRowBytes);
-        b_px0 = dy * W + TPX * ds;
-        b_soff = __builtin_amdgcn_readfirstlane(b_px0 * kRowBytes);
-        b_full = b_px0 + TPX <= HW;
+    // a batch = nine 1-KiB pieces of this wave (eight feature pieces, the aux tile or the Cy row), issued in a row in front of the tile's MFMAs
+    // (spread between the consumers' sub-steps, or issued in front of B2, they measured 10 % slower: profiles/r06/README.md)
+    auto issue_batch = [&](int b) {
+        if (b >= nt) return;
+        if (ABL == 8 && b >= NF) return;                         // timing only: no memory traffic behind the first ring fill
+        const uint32_t st = __builtin_amdgcn_readfirstlane(lds0 + Lds::fring + (b % NF) * Lds::kStage + pl_ * kTileBytes + rb * kRowBytes);
+        const int px0 = dy * W + TPX * ds;
+        const int soff = __builtin_amdgcn_readfirstlane(px0 * kRowBytes);
+        if (px0 + TPX <= HW) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ra_dma16(frs, st + i * 1024, voff[i], soff);
+        } else {                                                 // last row of a ragged strip: clamp the source rows (their P is 0)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = rb + 2 * i + h;
+                const int src = px0 + row < HW ? row : HW - 1 - px0;
+                ra_dma16(frs, st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), soff);
+            }
+        }
         ++dy;
         if (dy == H) { dy = 0; ++ds; }
-    };
-    auto issue_piece = [&](int i) {
-        if (!b_live) return;
-        if (i < 8) {
-            if (b_full) {
-                ra_dma16(frs, b_st + i * 1024, voff[i], b_soff);
-            } else {                                             // last row of a ragged strip: clamp the source rows (their P is 0)
-                const int row = rb + 2 * i + h;
-                const int src = b_px0 + row < HW ? row : HW - 1 - b_px0;
-                ra_dma16(frs, b_st + i * 1024, src * kRowBytes + (((lane & 31) ^ swz(row)) * 16), b_soff);
-            }
-        } else if (sb == 0) {                                    // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
-            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b_idx % NF) * kAuxTile);
-            ra_dma16(ars, sa, (b_px0 + (lane & 31)) * kAuxRow, 0);
+        if (sb == 0) {                                           // aux tile: 32 rows of 16 B (lanes >= 32 repeat them); rows past the frame read zeros
+            const uint32_t sa = __builtin_amdgcn_readfirstlane(lds0 + Lds::aring + (b % NF) * kAuxTile);
+            ra_dma16(ars, sa, (px0 + (lane & 31)) * kAuxRow, 0);
         } else if (sb == 2) {                                    // Cy row of tile b + 1 (1 KiB from the start of its image row)
-            const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b_idx + 1) % NF) * kCyTile);
+            const uint32_t sy = __builtin_amdgcn_readfirstlane(lds0 + Lds::yring + ((b + 1) % NF) * kCyTile);
             ra_dma16_cached(yrs, sy, dy * LP * 4 + lane * 16);
         }
     };
-    auto issue_batch = [&](int b) {
-        begin_batch(b);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) issue_piece(i);
-    };
     if (sb == 2) ra_dma16_cached(yrs, __builtin_amdgcn_readfirstlane(lds0 + Lds::yring), row0 * LP * 4 + lane * 16);   // Cy row of tile 0
 #pragma unroll
-    for (int b = 0; b < A + (SVPS_RETR_HL32_DMA_LATE ? 1 : 0); ++b) issue_batch(b);
+    for (int b = 0; b < A; ++b) issue_batch(b);
 
     f32x16 o[8], oa;
 #pragma unroll
@@ -500,18 +425,12 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
 #pragma unroll
         for (int q = 0; q < NVB - 1; ++q) load_step(q, q);
     };
-    auto pv_steps = [&](auto lo_tag, auto hi_tag, auto dma_tag) { // steps [Q0, Q1) of A += P f: six MFMAs each (+ two of the aux block per k-step)
+    auto pv_steps = [&](auto lo_tag, auto hi_tag) {              // steps [Q0, Q1) of A += P f: six MFMAs each (+ two of the aux block per k-step)
         constexpr int Q0 = decltype(lo_tag)::value * (2 / kSB), Q1 = decltype(hi_tag)::value * (2 / kSB);
-        constexpr bool DMA = decltype(dma_tag)::value;           // the pieces of the batch begun before, spread over these sub-steps
-        constexpr int kPP = DMA ? (9 + (Q1 - Q0) - 1) / (Q1 - Q0) : 0;      // pieces per sub-step
 #pragma unroll
         for (int q = Q0; q < Q1; ++q) {
             const int ks = q / (8 / kSB), db = kSB * (q % (8 / kSB));
             if (q + NVB - 1 < kNQ) load_step((q + NVB - 1) % NVB, q + NVB - 1);
-            if constexpr (DMA) {
-#pragma unroll
-                for (int i = kPP * (q - Q0); i < kPP * (q - Q0 + 1) && i < 9; ++i) issue_piece(i);
-            }
             __builtin_amdgcn_sched_barrier(0);
 #ifndef SVPS_R32_SKIP_PLO                                              // (timing experiments only)
 #pragma unroll
@@ -532,51 +451,17 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
     using I0 = std::integral_constant<int, 0>;
     using IS = std::integral_constant<int, kSplit>;
     using I8 = std::integral_constant<int, 8>;
-    using WithDma = std::true_type;
-    using NoDma = std::false_type;
-    static_assert(!SVPS_RETR_HL32_ILV || kSplit >= 1, "the batch's pieces go out in front of B1");
-#if SVPS_RETR_HL32_B0
-    using IP = std::integral_constant<int, SVPS_RETR_HL32_PRE>;
-    static_assert(SVPS_RETR_HL32_PRE <= kSplit, "steps beside the chain <= steps in front of B1");
-#endif
     constexpr bool kWork = ABL != 1 && ABL != 2;
 
-    {
-        constexpr int kIssued = A + (SVPS_RETR_HL32_DMA_LATE ? 1 : 0);
-        if (kIssued - 1 < nt) wait_vm_dyn(nb * (kIssued - 1));   // batch 0 (and the Cy row of tile 0) landed
-        else wait_vm<0>();
-    }
+    if (A - 1 < nt) wait_vm_dyn(nb * (A - 1));                   // batch 0 (and the Cy row of tile 0) landed
+    else wait_vm<0>();
     wg_barrier();                                                // B(start)
     for (int it = 0; it < nt; ++it) {
         const bool work = kWork && it >= 1;
         R32_STAMP(1, 0);
         if (work) pv_begin(it - 1);
-#if SVPS_RETR_HL32_ILV && !SVPS_RETR_HL32_B0
-        begin_batch(it + A);                                     // its pieces go out between the sub-steps below (all of them in front of B1)
-        if (work) {
-            pv_steps(I0{}, IS{}, WithDma{});
-        } else {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) issue_piece(i);
-        }
-        R32_STAMP(1, 1);
-        if (ABL != 16) {
-            if (it + A < nt) wait_vm_dyn(nb * (A - 1));          // batch it+1 landed for this wave: all but the A - 1 youngest batches
-            else wait_vm<0>();
-        } else if (it + 4 * A < nt) wait_vm_dyn(nb * (4 * A - 1));  // (timing only: the landing wait never binds)
-        R32_STAMP(1, 2);
-#elif SVPS_RETR_HL32_B0
         issue_batch(it + A);
-        if (work) pv_steps(I0{}, IP{}, NoDma{});                 // (SVPS_RETR_HL32_PRE steps beside the producers' chain)
-        if (it + A < nt) wait_vm_dyn(nb * (A - 1));              // batch it+1 landed for this wave
-        else wait_vm<0>();
-        wg_barrier();                                            // B0(it): the producers' chains are through - the matrix pipe is the consumers'
-        if (work) pv_steps(IP{}, IS{}, NoDma{});
-        R32_STAMP(1, 1);
-        R32_STAMP(1, 2);
-#else
-        if (!SVPS_RETR_HL32_DMA_LATE) issue_batch(it + A);
-        if (work) pv_steps(I0{}, IS{}, NoDma{});
+        if (work) pv_steps(I0{}, IS{});
         R32_STAMP(1, 1);
         // batch it+1 landed for this wave (the producers read its first fragments behind B1): all but the A - 1 youngest batches
         if (ABL != 16) {
@@ -584,18 +469,15 @@ __global__ __launch_bounds__(512) void retr_attn_hl32_kernel(
             else wait_vm<0>();
         } else if (it + 4 * A < nt) wait_vm_dyn(nb * (4 * A - 1));  // (timing only: the landing wait never binds)
         R32_STAMP(1, 2);
-#endif
         wg_barrier();                                            // B1(it)
         R32_STAMP(1, 3);
-        if (work) pv_steps(IS{}, I8{}, NoDma{});
+        if (work) pv_steps(IS{}, I8{});
         R32_STAMP(1, 4);
-        // (DMA_LATE) batch it+1+A into the stage of tile it-1, which this wave has just left: issued while the wave would wait at B2
-        if (SVPS_RETR_HL32_DMA_LATE && !SVPS_RETR_HL32_ILV && !SVPS_RETR_HL32_B0) issue_batch(it + 1 + A);
         wg_barrier();                                            // B2(it)
     }
     if (kWork) {
         pv_begin(nt - 1);
-        pv_steps(I0{}, I8{}, NoDma{});
+        pv_steps(I0{}, I8{});
     }
 
     float* dst = partial + (((size_t)t * C + c) * Lrow + slot_off) * kPartRow;
