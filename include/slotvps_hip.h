@@ -489,6 +489,14 @@ int svps_level_fuse_hl_fwd(const float* cur, const float* gprev, const void* wb_
  * (vps_capsule.py:76-79) composed into wb / bc by the caller) - no NCHW detour, no split in the kernel: the operand tile is the rows. */
 int svps_level_fuse_hl_pm_fwd(const void* cur_hi, const void* cur_lo, const float* gprev, const void* wb_hi, const void* wb_lo, const float* bc,
                               void* out_hi, void* out_lo, float* out_f32, int T, int H, int W, void* stream);
+/* ALL orders m = 0 .. n - 1 of a level in ONE launch (round 6; 1 <= n <= 4: level i of 4 asks for n = 4 - i): HOST arrays of n device pointers
+ * gprev (all NULL at level 0), wb_hi / wb_lo (the composed weights W_a^m W_b), bc, out_f32 (entry 0 ignored: order 0 writes the planes out_hi /
+ * out_lo, orders >= 1 their fp32 G^(m)). cur: fp32 NCHW (cur_lo NULL) or the hi plane of pixel-major fp16 rows (cur_lo: the lo plane). The n
+ * workgroups of a chunk of tiles meet on one XCD, so the incoming map crosses HBM -> L2 once; results bit-identical to n calls of
+ * svps_level_fuse_hl_fwd / _pm_fwd (slotvps_amd/csrc/level_fuse_hl.hip, level_fuse_hl_multi_kernel). dynamic_mask_head.py:171-188. */
+int svps_level_fuse_hl_multi_fwd(const void* cur, const void* cur_lo, int n, const float* const* gprev, const void* const* wb_hi,
+                                 const void* const* wb_lo, const float* const* bc, void* out_hi, void* out_lo, float* const* out_f32,
+                                 int T, int H, int W, void* stream);
 int svps_retr_stats_hl_fwd(const void* feat_hi, const void* feat_lo, const float* tyk, int ty_rows, const float* txk, int tx_rows, int tx_tiled,
                            const void* rk_hi, const void* rk_lo, float lnk_eps, const void* rv_hi, const void* rv_lo,
                            const float* rbv, float lnv_eps, void* aux, int T, int H, int W, int D, void* stream);

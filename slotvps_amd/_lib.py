@@ -80,6 +80,7 @@ SIGNATURES = {
     "svps_retr_attn_fwd": (_i, [_vp] * 8 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "svps_level_fuse_hl_fwd": (_i, [_vp] * 8 + [_i, _i, _i, _vp]),   # cur, gprev, wb_hi, wb_lo, bc, out_hi, out_lo, out_f32
     "svps_level_fuse_hl_pm_fwd": (_i, [_vp] * 9 + [_i, _i, _i, _vp]),   # cur_hi, cur_lo, gprev, wb_hi, wb_lo, bc, out_hi, out_lo, out_f32
+    "svps_level_fuse_hl_multi_fwd": (_i, [_vp, _vp, _i] + [_vp] * 7 + [_i, _i, _i, _vp]),   # cur, cur_lo, n, gprev[], wb_hi[], wb_lo[], bc[], out_hi, out_lo, out_f32[]
     "svps_retr_stats_hl_fwd": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "svps_retr_attn_hl_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "svps_retr_attn_hl_fwd": (_i, [_vp] * 9 + [_sz, _vp, _i, _i, _i, _i, _i, _i, _vp]),

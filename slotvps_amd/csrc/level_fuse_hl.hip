@@ -110,7 +110,8 @@ struct HlCursor {
 // PMIN (round 6): the incoming map arrives as fp16 hi + lo PIXEL-MAJOR planes [T, HW, 128] (cur_ = hi, cur_lo_ = lo: the semantic tower's
 // own rows, gn_relu.hip) - a thread moves one 16-byte chunk of each plane straight into the operand tile: no transposition, no split.
 template <bool TAPS, bool F32OUT, bool STAGED = false, bool PLANES = true, bool PMIN = false>
-__global__ __launch_bounds__(512) void level_fuse_hl_kernel(
+__device__ __forceinline__ void level_fuse_hl_body(
+    const int t, const int c,                 // frame and chunk of this workgroup (level_fuse_hl_kernel: blockIdx.y, .x; the multi-order kernel decodes them)
     const void* __restrict__ cur_,            // [T, 128, H, W] fp32 (NCHW, the reference's layout); PMIN: [T, HW, 128] fp16, the hi plane
     const void* __restrict__ cur_lo_,         // PMIN: the lo plane
     const float* __restrict__ gprev,          // TAPS: [T, (H/2)*(W/2), 256] fp32 = f_{i-1} W_a^T, pixel-major
@@ -128,7 +129,6 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int t = blockIdx.y, c = blockIdx.x;
     const int HW = H * W;
     const int Hp = H >> 1, Wp = W >> 1;
 
@@ -517,6 +517,53 @@ __global__ __launch_bounds__(512) void level_fuse_hl_kernel(
     }
 }
 
+template <bool TAPS, bool F32OUT, bool STAGED = false, bool PLANES = true, bool PMIN = false>
+__global__ __launch_bounds__(512) void level_fuse_hl_kernel(const void* __restrict__ cur_, const void* __restrict__ cur_lo_,
+                                                            const float* __restrict__ gprev, const _Float16* __restrict__ wb_hi,
+                                                            const _Float16* __restrict__ wb_lo, const float* __restrict__ bc,
+                                                            _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo,
+                                                            float* __restrict__ out_f32, int H, int W, int tiles_per_chunk) {
+    level_fuse_hl_body<TAPS, F32OUT, STAGED, PLANES, PMIN>(blockIdx.y, blockIdx.x, cur_, cur_lo_, gprev, wb_hi, wb_lo, bc, out_hi, out_lo, out_f32,
+                                                           H, W, tiles_per_chunk);
+}
+
+// ALL orders m = 0 .. n - 1 of a level in ONE launch (round 6): level i of 4 needs G^(m) for m = 0 .. 3 - i, every one a
+// K = 128 product on the SAME incoming tile. A workgroup still computes one order of one chunk of tiles (the weights of an order fill the
+// matrix waves' registers: two orders per workgroup do not fit, and streaming a second order's 64 KiB of weights per 32-pixel tile would move
+// more bytes than the re-read of x_i it saves) - but the n workgroups of a chunk are handed to the SAME XCD back to back (workgroup ids go to
+// the XCDs round-robin: ids b and b + 8 meet on one XCD), so they walk the same tiles at the same pace and the incoming map crosses
+// HBM -> L2 once instead of n times; one launch tail per level instead of n. Order 0 writes the planes, orders >= 1 fp32 only.
+struct FuseHlMultiArgs {
+    const float* gprev[4];
+    const _Float16* wb_hi[4];
+    const _Float16* wb_lo[4];
+    const float* bc[4];
+    float* out_f32[4];
+    _Float16* out_hi;
+    _Float16* out_lo;
+    int n, chunks, pairs;                     // pairs = frames x chunks
+};
+
+template <bool TAPS, bool STAGED, bool PMIN>
+__global__ __launch_bounds__(512) void level_fuse_hl_multi_kernel(const void* __restrict__ cur_, const void* __restrict__ cur_lo_, FuseHlMultiArgs a,
+                                                                  int H, int W, int tiles_per_chunk) {
+    // one-dimensional grid over (frame, chunk) pairs q = t * chunks + c and orders m: id = ((q / 8) * n + m) * 8 + q % 8 - the n orders of a pair
+    // are 8 ids apart (the same XCD, back to back), consecutive pairs go round the XCDs as the chunks of the per-order launch do
+    const int id = blockIdx.x;
+    const int x = id & 7, k = id >> 3;
+    const int m = k % a.n, q = (k / a.n) * 8 + x;
+    if (q >= a.pairs) return;
+    const int t = q / a.chunks, c = q - t * a.chunks;
+    if (m == 0) {
+        level_fuse_hl_body<TAPS, false, STAGED, true, PMIN>(t, c, cur_, cur_lo_, a.gprev[0], a.wb_hi[0], a.wb_lo[0], a.bc[0], a.out_hi, a.out_lo,
+                                                            nullptr, H, W, tiles_per_chunk);
+    } else {
+        level_fuse_hl_body<TAPS, true, STAGED, false, PMIN>(t, c, cur_, cur_lo_, a.gprev[m], a.wb_hi[m], a.wb_lo[m], a.bc[m], nullptr, nullptr,
+                                                            a.out_f32[m], H, W, tiles_per_chunk);
+    }
+}
+
+
 }  // namespace svps
 
 // svps_level_fuse_hl_fwd (include/slotvps_hip.h): out = up(gprev) + wb cur + bc. cur [T, 128, H, W] fp32 NCHW; gprev [T, (H/2)(W/2), 256]
@@ -562,6 +609,60 @@ static int svps_level_fuse_hl_launch(const void* cur, const void* cur_lo, bool p
     else if (gprev) { if (out_f32) SVPS_LFH(true, true, true); else SVPS_LFH(true, false, true); }
     else { if (out_f32) SVPS_LFH(false, true, true); else SVPS_LFH(false, false, true); }
 #undef SVPS_LFH
+    e = hipGetLastError();
+    svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 1, stream);
+    return (int)e;
+}
+
+// svps_level_fuse_hl_multi_fwd (include/slotvps_hip.h): orders 0 .. n - 1 of a level in one launch (level_fuse_hl_multi_kernel)
+extern "C" int svps_level_fuse_hl_multi_fwd(const void* cur, const void* cur_lo, int n, const float* const* gprev, const void* const* wb_hi,
+                                            const void* const* wb_lo, const float* const* bc, void* out_hi, void* out_lo,
+                                            float* const* out_f32, int T, int H, int W, void* stream_) {
+    if (!cur || !wb_hi || !wb_lo || !bc || !out_hi || !out_lo || n < 1 || n > 4 || (n > 1 && !out_f32)) return SVPS_ERR_BAD_ARG;
+    if (T <= 0 || H <= 0 || W <= 0) return SVPS_ERR_BAD_SHAPE;
+    if ((size_t)H * W > svps::kMaxFramePixels) return SVPS_ERR_BAD_SHAPE;
+    const bool taps = gprev && gprev[0];
+    svps::FuseHlMultiArgs a = {};
+    for (int m = 0; m < n; ++m) {
+        if (!wb_hi[m] || !wb_lo[m] || !bc[m] || (m > 0 && !out_f32[m]) || (taps != (gprev && gprev[m] != nullptr))) return SVPS_ERR_BAD_ARG;
+        a.gprev[m] = taps ? gprev[m] : nullptr;
+        a.wb_hi[m] = static_cast<const _Float16*>(wb_hi[m]);
+        a.wb_lo[m] = static_cast<const _Float16*>(wb_lo[m]);
+        a.bc[m] = bc[m];
+        a.out_f32[m] = m > 0 ? out_f32[m] : nullptr;
+    }
+    if (taps && ((H & 1) || (W & 1))) return SVPS_ERR_BAD_SHAPE;
+    a.out_hi = static_cast<_Float16*>(out_hi);
+    a.out_lo = static_cast<_Float16*>(out_lo);
+    a.n = n;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool pm = cur_lo != nullptr;
+    const int HW = H * W;
+    const int tiles = (HW + svps::kTilePx - 1) / svps::kTilePx;
+    int chunks = svps_pick_chunks(T * n, tiles, svps_num_cus());     // n workgroups per chunk share the chip
+    const int tpc = (tiles + chunks - 1) / chunks;
+    chunks = (tiles + tpc - 1) / tpc;
+    a.chunks = chunks;
+    a.pairs = T * chunks;
+    const int gx = ((a.pairs + 7) / 8) * 8 * n;
+    constexpr int lds = svps::FuseHlLds::total;
+    const bool staged = taps && (W & 31) == 0 && HW < (1 << 22);
+    hipError_t e = hipSuccess;
+    svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 0, stream);
+#define SVPS_LFM(TAPS, STAGED, PM)                                                                                          \
+    do {                                                                                                                    \
+        auto kern = svps::level_fuse_hl_multi_kernel<TAPS, STAGED, PM>;                                                      \
+        static SvpsLdsAttr attr;                                                                                            \
+        if ((e = attr.ensure(reinterpret_cast<const void*>(kern), lds)) != hipSuccess) return (int)e;                       \
+        hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, stream, cur, cur_lo, a, H, W, tpc);                              \
+    } while (0)
+    if (taps) {
+        if (staged) { if (pm) SVPS_LFM(true, true, true); else SVPS_LFM(true, true, false); }
+        else { if (pm) SVPS_LFM(true, false, true); else SVPS_LFM(true, false, false); }
+    } else {
+        if (pm) SVPS_LFM(false, false, true); else SVPS_LFM(false, false, false);
+    }
+#undef SVPS_LFM
     e = hipGetLastError();
     svps_prof_mark(SVPS_KERNEL_LEVEL_FUSE, 1, stream);
     return (int)e;

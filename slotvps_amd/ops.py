@@ -863,6 +863,46 @@ def level_fuse_hl_g(cur, gprev, w_hl, bias, H, W, planes=True, f32=False):
     return out, o32
 
 
+def level_fuse_hl_orders(cur, gprevs, w_hls, biases, H, W):
+    """ALL orders of a level in ONE launch of K4-HL (svps_level_fuse_hl_multi_fwd): out_m = up(gprevs[m]) + w_hls[m] cur + biases[m] for
+    m = 0 .. n - 1 (n <= 4). cur as in level_fuse_hl_g; gprevs: list of n fp32 [T, (H/2)(W/2), 256] or None (level 0: no upsampled term).
+    Returns (planes [2, T, H*W, 256] fp16 of order 0, [None, G^(1), ...] fp32 [T, H*W, 256]); bit-identical to n level_fuse_hl_g calls."""
+    import ctypes
+    lib = _lib.load()
+    n = len(w_hls)
+    if not 1 <= n <= 4 or len(biases) != n or (gprevs is not None and len(gprevs) != n):
+        raise ValueError("1 ... 4 orders, one weight / bias (/ coarse map) each")
+    pm = cur.dtype == torch.float16
+    if pm:
+        _need(cur, "cur", torch.float16, 4)
+        T = cur.shape[1]
+        if cur.shape != (2, T, H * W, 128):
+            raise ValueError(f"cur {tuple(cur.shape)} != [2, T, {H * W}, 128]")
+    else:
+        _need(cur, "cur", torch.float32, 4)
+        T = cur.shape[0]
+        if cur.shape != (T, 128, H, W):
+            raise ValueError(f"cur {tuple(cur.shape)} != [T, 128, {H}, {W}]")
+    for m in range(n):
+        _need(w_hls[m], "w_hl", torch.float16, 3)
+        _need(biases[m], "bias", torch.float32, 1)
+        if gprevs is not None:
+            _need(gprevs[m], "gprev", torch.float32, 3)
+            if gprevs[m].shape != (T, (H // 2) * (W // 2), 256) or H % 2 or W % 2:
+                raise ValueError(f"gprev {tuple(gprevs[m].shape)} does not match an {H}x{W} level")
+    out = torch.empty((2, T, H * W, 256), dtype=torch.float16, device=cur.device)
+    o32 = [None] + [torch.empty((T, H * W, 256), dtype=torch.float32, device=cur.device) for _ in range(n - 1)]
+    arr = lambda ps: (ctypes.c_void_p * n)(*[p for p in ps])
+    with _on(cur, *w_hls, *biases, *(gprevs or [])) as ctx:
+        rc = lib.svps_level_fuse_hl_multi_fwd(
+            _ptr(cur[0]) if pm else _ptr(cur), _ptr(cur[1]) if pm else None, n,
+            arr([g.data_ptr() for g in gprevs]) if gprevs is not None else None,
+            arr([w[0].data_ptr() for w in w_hls]), arr([w[1].data_ptr() for w in w_hls]), arr([b.data_ptr() for b in biases]),
+            _ptr(out[0]), _ptr(out[1]), arr([0] + [o.data_ptr() for o in o32[1:]]), T, H, W, ctx.stream)
+    _lib.check(rc, "svps_level_fuse_hl_multi_fwd")
+    return out, o32
+
+
 def level_fuse_hl(cur, prev_f32, weights, bc, H, W, want_f32=False):
     """K4 at the reference's precision: f = up(prev W_a^T) + W_b cur + b (a 1x1 conv commutes with bilinear interpolation; the 256-wide
     product runs at the coarse resolution on K8 with fp16 hi + lo operands). cur [T, 128, H, W] fp32 NCHW; prev_f32 [T, (H/2)(W/2), 256]

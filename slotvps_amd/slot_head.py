@@ -718,6 +718,7 @@ class MultiScaleDynamicMaskHead(nn.Module):
         self.map_dtype = "bf16"
         self.map_encoding = "auto"                       # "bf16": plain bf16 tensors for the bf16 policy (see _map_form)
         self.stats_form = "level"                        # "level": K3'' - both stages of a pyramid level from one read of the map; "stage": K3' per stage
+        self.fuse_orders_in_one_launch = True            # fp16x2: all orders G^(m) of a level from one launch of K4-HL (False: one launch per order)
         self._cfg_mode = other_config.get("mode") if isinstance(other_config, dict) else None
         if isinstance(other_config, dict):
             # the switches of rounds 1 - 4 were collapsed into `mode`: a config that still carries them must not silently run another mode
@@ -893,14 +894,22 @@ class MultiScaleDynamicMaskHead(nn.Module):
             for m in range(orders):
                 if prev_pm is not None and (m + 1) not in gp:
                     raise RuntimeError(f"level {level} needs G^({m + 1}) of the level below (was that level fused with last=True?)")
-                w_hl = cw["w0"][m] if prev_pm is None else cw["w"][m]
-                bias = cw["b0"][m] if prev_pm is None else cw["b"][m]
-                planes, f32 = ops.level_fuse_hl_g(cur_in, None if prev_pm is None else gp[m + 1], w_hl, bias, hw[0], hw[1],
-                                                  planes=m == 0, f32=m > 0)
-                if m == 0:
-                    out = planes
-                else:
-                    g[m] = f32
+            w_hls = [cw["w0"][m] if prev_pm is None else cw["w"][m] for m in range(orders)]
+            biases = [cw["b0"][m] if prev_pm is None else cw["b"][m] for m in range(orders)]
+            if self.fuse_orders_in_one_launch and orders > 1:
+                # every order of the level from ONE launch: the n workgroups of a chunk of tiles share the incoming tile through L2
+                # (csrc/level_fuse_hl.hip, level_fuse_hl_multi_kernel); bit-identical to the per-order launches below
+                out, f32s = ops.level_fuse_hl_orders(cur_in, None if prev_pm is None else [gp[m + 1] for m in range(orders)], w_hls, biases,
+                                                     hw[0], hw[1])
+                g = {m: f32s[m] for m in range(1, orders)}
+            else:
+                for m in range(orders):
+                    planes, f32 = ops.level_fuse_hl_g(cur_in, None if prev_pm is None else gp[m + 1], w_hls[m], biases[m], hw[0], hw[1],
+                                                      planes=m == 0, f32=m > 0)
+                    if m == 0:
+                        out = planes
+                    else:
+                        g[m] = f32
             out._svps_level, out._svps_g = level, g
             return out
         form = self._map_form(cur)

@@ -516,3 +516,24 @@ def test_level_recursion_without_wide_products(cuda, T, H, W):
             prev = f
     print(f"\nlevel recursion T={T} {H}x{W}: {worst:.2e} of the maps' scale over the four levels")
     assert worst <= 5e-6
+    # round 6: all orders of a level from ONE launch (svps_level_fuse_hl_multi_fwd) - bit-identical to one launch per order, for the fp32 NCHW
+    # maps and for pixel-major hi / lo rows
+    from slotvps_amd import ops
+    assert head.fuse_orders_in_one_launch
+    for rows in (False, True):
+        res = {}
+        for one in (True, False):
+            head.fuse_orders_in_one_launch = one
+            prev, outs = None, []
+            with torch.no_grad():
+                for i, (h, w) in enumerate(sizes):
+                    cur = torch.from_numpy(np.stack([feats[t][i] for t in range(T)])).to(cuda)
+                    if rows:
+                        cur = ops.split_hl(cur.permute(0, 2, 3, 1).reshape(T, h * w, 128).contiguous())
+                    f = head.fuse_level(cur, prev, (h, w), last=i == 3)
+                    outs.append((f, dict(f._svps_g)))
+                    prev = f
+            res[one] = outs
+        head.fuse_orders_in_one_launch = True
+        for (fa, ga), (fb, gb) in zip(res[True], res[False]):
+            assert torch.equal(fa, fb) and sorted(ga) == sorted(gb) and all(torch.equal(ga[m], gb[m]) for m in ga)
