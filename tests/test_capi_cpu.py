@@ -68,6 +68,14 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.svps_retr_attn_fwd(one, one, one, one, one, one, one, one, 1 << 30, one, 1, 257, 4, 32, 256, 0, 0, None) == -2
     assert lib.svps_retr_attn_fwd(one, one, one, one, one, one, one, one, 16, one, 1, 100, 4, 32, 256, 0, 2, None) == -3   # workspace too small (flags: fp16 map)
     assert lib.svps_retr_attn_workspace_bytes(1, 100, 4, 32, 0) > 0 and lib.svps_retr_attn_workspace_bytes(0, 100, 4, 32, 0) == 0
+    # round 6: the multi-order level fusion (host arrays of device pointers) and the reference-precision entries validate before any launch
+    arr = (ctypes.c_void_p * 2)(16, 16)
+    assert lib.svps_level_fuse_hl_multi_fwd(None, None, 2, arr, arr, arr, arr, one, one, arr, 1, 8, 32, None) == -1          # no incoming map
+    assert lib.svps_level_fuse_hl_multi_fwd(one, None, 5, arr, arr, arr, arr, one, one, arr, 1, 8, 32, None) == -1           # 1 ... 4 orders
+    assert lib.svps_level_fuse_hl_multi_fwd(one, None, 2, arr, arr, arr, arr, one, one, arr, 1, 7, 32, None) == -2           # x2 upsampling: even sizes
+    assert lib.svps_level_fuse_hl_fwd(one, one, one, one, one, one, None, None, 1, 8, 32, None) == -1                       # planes: both or neither
+    assert lib.svps_retr_attn_hl_fwd(one, one, one, one, one, one, one, one, one, 16, one, 1, 257, 4, 32, 256, 0, None) == -2
+    assert lib.svps_mask_decode_hl_fwd(one, one, one, one, one, 1.0, 0.0, None, None, 1, 100, 64, 256, None) == -1           # fp32 logits are required
     assert lib.svps_slot_gemm_ln(one, one, None, None, None, None, one, 1e-5, 0, one, 8, 256, None) == -1             # no gamma
     assert lib.svps_slot_gemm_ln(one, one, None, None, None, one, one, 1e-5, 0, one, 8, 250, None) == -2              # K % 16
     three = (ctypes.c_longlong * 3)(1, 1, 1)
